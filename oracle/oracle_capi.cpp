@@ -1,0 +1,262 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// extern "C" surface of the CPU restatement (liboracle.so), loaded through ctypes by tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product path.
+// All pointers are host pointers; matrices are column-major (Eigen .data() order).
+#include <omp.h>
+
+#include <random>
+
+#include "oracle_features.hpp"
+#include "oracle_knn.hpp"
+#include "oracle_math.hpp"
+#include "oracle_registration.hpp"
+
+using namespace oracle;
+
+extern "C" {
+
+int orc_num_threads() { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { omp_set_num_threads(n); }
+
+// ---- synthetic clouds: the reference tests' idiom (cpp/tests/test_kdtree.cpp:69-75), x then y then z.
+// `state` lets a caller continue the same generator across calls (targets, then queries).
+void* orc_rng_new(uint32_t seed) { return new std::mt19937(seed); }
+void orc_rng_free(void* g) { delete static_cast<std::mt19937*>(g); }
+void orc_rng_uniform_points(void* g, float range, size_t n, float* out) {
+    auto& gen = *static_cast<std::mt19937*>(g);
+    std::uniform_real_distribution<float> dist(-range, range);
+    for (size_t i = 0; i < n; ++i) {
+        const float x = dist(gen);
+        const float y = dist(gen);
+        const float z = dist(gen);
+        out[4 * i + 0] = x; out[4 * i + 1] = y; out[4 * i + 2] = z; out[4 * i + 3] = 1.0f;
+    }
+}
+void orc_rng_normal(void* g, float stddev, size_t n, float* out) {
+    auto& gen = *static_cast<std::mt19937*>(g);
+    std::normal_distribution<float> dist(0.0f, stddev);
+    for (size_t i = 0; i < n; ++i) out[i] = dist(gen);
+}
+// random_sampling_operator.hpp:36-42 — partial Fisher-Yates with std::mt19937 + uniform_int_distribution<size_t>
+void orc_random_sampling_flags(uint32_t seed, size_t N, size_t num, uint8_t* flags) {
+    std::mt19937 mt(seed);
+    std::vector<size_t> indices(N);
+    std::iota(indices.begin(), indices.end(), 0);
+    for (size_t i = 0; i < N; ++i) flags[i] = 0;
+    if (N <= num) { for (size_t i = 0; i < N; ++i) flags[i] = 1; return; }
+    for (size_t i = 0; i < num; ++i) {
+        std::uniform_int_distribution<size_t> dist(i, N - 1);
+        const size_t j = dist(mt);
+        std::swap(indices[i], indices[j]);
+    }
+    for (size_t i = 0; i < num; ++i) flags[indices[i]] = 1;
+}
+
+// ---- math probes (for pinning against cpp/tests/test_eigen_utils.cpp)
+void orc_eigen3(const float* A_colmajor9, float* vals3, float* vecs_colmajor9) {
+    Mat3 A; std::memcpy(A.d, A_colmajor9, 36);
+    Vec3 v; Mat3 V;
+    symmetric_eigen_decomposition_3x3(A, v, V);
+    std::memcpy(vals3, v.d, 12); std::memcpy(vecs_colmajor9, V.d, 36);
+}
+void orc_inverse3(const float* A, float* out) { Mat3 m; std::memcpy(m.d, A, 36); const Mat3 r = inverse(m); std::memcpy(out, r.d, 36); }
+float orc_det3(const float* A) { Mat3 m; std::memcpy(m.d, A, 36); return determinant(m); }
+void orc_matmul4(const float* A, const float* B, float* out) {
+    Mat4 a, b; std::memcpy(a.d, A, 64); std::memcpy(b.d, B, 64);
+    const Mat4 r = matmul<4, 4, 4>(a, b); std::memcpy(out, r.d, 64);
+}
+void orc_se3_exp(const float* twist6, float* T16) { Vec6 a; std::memcpy(a.d, twist6, 24); const Mat4 T = se3_exp(a); std::memcpy(T16, T.d, 64); }
+void orc_se3_log(const float* T16, float* twist6) { Mat4 T; std::memcpy(T.d, T16, 64); const Vec6 a = se3_log(T); std::memcpy(twist6, a.d, 24); }
+void orc_so3_exp(const float* w3, float* q4) { Vec3 w; std::memcpy(w.d, w3, 12); const Vec4 q = so3_exp(w); std::memcpy(q4, q.d, 16); }
+void orc_so3_log(const float* q4, float* w3) { Vec4 q; std::memcpy(q.d, q4, 16); const Vec3 w = so3_log(q); std::memcpy(w3, w.d, 12); }
+void orc_isometry_mul(const float* A, const float* B, float* out) {
+    const Mat4 r = isometry_mul(to_mat4(A), to_mat4(B)); std::memcpy(out, r.d, 64);
+}
+int orc_ldlt6_solve(const float* H36_colmajor, const float* b6, float* x6) {
+    Mat6 H; Vec6 b, x; std::memcpy(H.d, H36_colmajor, 144); std::memcpy(b.d, b6, 24);
+    const bool ok = ldlt6_solve(H, b, x); std::memcpy(x6, x.d, 24); return ok ? 1 : 0;
+}
+float orc_robust_weight(int loss, float r, float s) { return robust_weight(loss, r, s); }
+float orc_robust_error(int loss, float r, float s) { return robust_error(loss, r, s); }
+
+// ---- KNN
+void orc_knn_bruteforce(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t* idx, float* d2) {
+    knn_bruteforce(q, nq, t, nt, k, idx, d2);
+}
+// nodes_out must hold 2*n nodes of 32 bytes; returns the used node count.
+size_t orc_kdtree_build(const float* pts, size_t n, size_t leaf_threshold, void* nodes_out) {
+    const std::vector<FlatKDNode> tree = kdtree_build(pts, n, leaf_threshold);
+    if (!tree.empty()) std::memcpy(nodes_out, tree.data(), tree.size() * sizeof(FlatKDNode));
+    return tree.size();
+}
+int orc_kdtree_knn(const void* nodes, size_t n_nodes, const float* q, size_t nq, size_t k, const float* T16, int32_t* idx,
+                   float* d2) {
+    if (kdtree_max_k_class(k) == 0) return 1;
+    kdtree_search(static_cast<const FlatKDNode*>(nodes), n_nodes, q, nq, k, T16, idx, d2, -1.0f);
+    return 0;
+}
+int orc_kdtree_radius(const void* nodes, size_t n_nodes, const float* q, size_t nq, size_t max_k, float radius,
+                      const float* T16, int32_t* idx, float* d2) {
+    if (kdtree_max_k_class(max_k) == 0) return 1;
+    kdtree_search(static_cast<const FlatKDNode*>(nodes), n_nodes, q, nq, max_k, T16, idx, d2, radius * radius);
+    return 0;
+}
+void orc_kdtree_remove_by_flags(void* nodes, size_t n_nodes, const uint8_t* flags, const int32_t* new_idx, size_t nflags) {
+    kdtree_remove_by_flags(static_cast<FlatKDNode*>(nodes), n_nodes, flags, new_idx, nflags);
+}
+
+// ---- features
+void orc_cov_estimate(const float* pts, size_t n, const int32_t* idx, size_t k, float* covs) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) cov_estimate_one(covs + 16 * i, pts, k, idx, (size_t)i);
+}
+void orc_normals_from_knn(const float* pts, size_t n, const int32_t* idx, size_t k, float* normals) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) {
+        float cov[16];
+        cov_estimate_one(cov, pts, k, idx, (size_t)i);
+        extract_normal(pts + 4 * i, cov, normals + 4 * i);
+    }
+}
+void orc_normals_from_cov(const float* pts, const float* covs, size_t n, float* normals) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) extract_normal(pts + 4 * i, covs + 16 * i, normals + 4 * i);
+}
+void orc_update_covariance_plane(float* covs, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) update_covariance_plane(covs + 16 * i);
+}
+void orc_normalize_covariance(float* covs, size_t n) {
+    for (size_t i = 0; i < n; ++i) normalize_covariance(covs + 16 * i);
+}
+void orc_transform_points(const float* in, float* out, size_t n, const float* T16) {
+    for (size_t i = 0; i < n; ++i) { float r[4]; transform_point(in + 4 * i, r, T16); std::memcpy(out + 4 * i, r, 16); }
+}
+void orc_transform_covs(const float* in, float* out, size_t n, const float* T16) {
+    for (size_t i = 0; i < n; ++i) { float r[16]; transform_cov(in + 16 * i, r, T16); std::memcpy(out + 16 * i, r, 64); }
+}
+void orc_transform_normals(const float* in, float* out, size_t n, const float* T16) {
+    for (size_t i = 0; i < n; ++i) { float r[4]; transform_normal(in + 4 * i, r, T16); std::memcpy(out + 4 * i, r, 16); }
+}
+void orc_voxel_keys(const float* pts, size_t n, float voxel_size, uint64_t* keys) {
+    const float inv = 1.0f / voxel_size;
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) keys[i] = compute_voxel_bit(pts + 4 * i, inv);
+}
+// Outputs must hold n entries (worst case); optional attributes may be null. Returns the voxel count.
+size_t orc_voxel_downsample(const float* pts, size_t n, float voxel_size, size_t min_count, const float* rgb,
+                            const float* intensity, const float* ts, int stable, float* out_pts, float* out_rgb,
+                            float* out_intensity, float* out_ts, uint64_t* out_keys) {
+    const VoxelOut o = voxel_downsample(pts, n, voxel_size, min_count, rgb, intensity, ts, stable != 0);
+    const size_t v = o.keys.size();
+    if (v) {
+        std::memcpy(out_pts, o.points.data(), v * 16);
+        if (rgb && out_rgb) std::memcpy(out_rgb, o.rgb.data(), v * 16);
+        if (intensity && out_intensity) std::memcpy(out_intensity, o.intensities.data(), v * 4);
+        if (ts && out_ts) std::memcpy(out_ts, o.timestamps.data(), v * 4);
+        if (out_keys) std::memcpy(out_keys, o.keys.data(), v * 8);
+    }
+    return v;
+}
+void orc_box_filter(const float* pts, size_t n, float min_d, float max_d, uint8_t* flags) {
+    for (size_t i = 0; i < n; ++i) flags[i] = box_filter_flag(pts + 4 * i, min_d, max_d);
+}
+
+// ---- registration
+static FactorParams make_fp(int reg, int loss, float max_corr, float genz_thr) {
+    FactorParams fp;
+    fp.reg_type = reg; fp.robust_type = loss; fp.max_correspondence_distance = max_corr; fp.genz_planarity_threshold = genz_thr;
+    return fp;
+}
+// out44: H row-major [0..35], b [36..41], error [42], inlier as uint32 bits [43]. per_point may be null (n*44 floats).
+void orc_gicp_linearize(const float* src, const float* src_cov, size_t n, const float* tgt, const float* tgt_cov,
+                        const float* tgt_nrm, const int32_t* nn_idx, const float* nn_d2, const float* T16, float max_corr,
+                        int reg, int loss, float robust_scale, float genz_alpha, float* out44, float* per_point) {
+    Cloud s, t;
+    s.points = src; s.covs = src_cov; s.n = n;
+    t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm;
+    const Linearized L = linearize_reduce(make_fp(reg, loss, max_corr, 0.2f), s, t, nn_idx, nn_d2, T16, robust_scale, genz_alpha, per_point);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) out44[r * 6 + c] = L.H(r, c);
+    for (int r = 0; r < 6; ++r) out44[36 + r] = L.b[r];
+    out44[42] = L.error;
+    std::memcpy(out44 + 43, &L.inlier, 4);
+}
+void orc_gicp_error(const float* src, const float* src_cov, size_t n, const float* tgt, const float* tgt_cov,
+                    const float* tgt_nrm, const int32_t* nn_idx, const float* nn_d2, const float* T16, float max_corr, int reg,
+                    int loss, float robust_scale, float genz_alpha, float* out2) {
+    Cloud s, t;
+    s.points = src; s.covs = src_cov; s.n = n;
+    t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm;
+    float e; uint32_t inl;
+    error_reduce(make_fp(reg, loss, max_corr, 0.2f), s, t, nn_idx, nn_d2, T16, robust_scale, genz_alpha, e, inl);
+    out2[0] = e; std::memcpy(out2 + 1, &inl, 4);
+}
+void orc_icp_robust_weights(const float* src, const float* src_cov, size_t n, const float* tgt, const float* tgt_cov,
+                            const float* tgt_nrm, const int32_t* nn_idx, const float* nn_d2, const float* T16, float max_corr,
+                            int reg, int loss, float robust_scale, float* out) {
+    Cloud s, t;
+    s.points = src; s.covs = src_cov; s.n = n;
+    t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm;
+    icp_robust_weights(make_fp(reg, loss, max_corr, 0.2f), s, t, nn_idx, nn_d2, T16, robust_scale, 1.0f, out);
+}
+
+struct orc_reg_params {
+    int reg_type, robust_type, optimization_method, max_iterations;
+    float max_correspondence_distance, robust_default_scale, gn_lambda;
+    float lm_init_lambda, lm_lambda_factor, lm_min_lambda, lm_max_lambda;
+    int lm_max_inner_iterations;
+    float crit_translation, crit_rotation;
+    // annealing wrapper (pipeline/robust.hpp); auto_scale=0 -> plain align with robust_default_scale
+    int auto_scale, auto_scaling_iter;
+    float init_scale, min_scale;
+};
+struct orc_reg_result {
+    float T[16];
+    float H[36];  // column-major
+    float b[6];
+    float error;
+    uint32_t inlier;
+    int iterations;
+    int converged;
+};
+// nn_mode: 0 = KD-tree built on target (the reference's default KNNBase), 1 = brute force.
+// trace_T (optional, max_iterations*16 floats) receives the pose after every outer iteration; *trace_n their count.
+void orc_registration_align(const orc_reg_params* P, const float* src, const float* src_cov, size_t ns, const float* tgt,
+                            const float* tgt_cov, const float* tgt_nrm, size_t nt, const float* init_T16, int nn_mode,
+                            orc_reg_result* out, float* trace_T, int* trace_n) {
+    RegParams p;
+    p.reg_type = P->reg_type; p.robust_type = P->robust_type; p.optimization_method = P->optimization_method;
+    p.max_iterations = (size_t)P->max_iterations; p.max_correspondence_distance = P->max_correspondence_distance;
+    p.robust_default_scale = P->robust_default_scale; p.gn_lambda = P->gn_lambda;
+    p.lm_init_lambda = P->lm_init_lambda; p.lm_lambda_factor = P->lm_lambda_factor;
+    p.lm_min_lambda = P->lm_min_lambda; p.lm_max_lambda = P->lm_max_lambda;
+    p.lm_max_inner_iterations = (size_t)P->lm_max_inner_iterations;
+    p.crit_translation = P->crit_translation; p.crit_rotation = P->crit_rotation;
+    Cloud s, t;
+    s.points = src; s.covs = src_cov; s.n = ns;
+    t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm; t.n = nt;
+    std::vector<FlatKDNode> tree;
+    if (nn_mode == 0) tree = kdtree_build(tgt, nt, 16);
+    NearestFn nearest = [&](const float* q, size_t nq, const float* T, int32_t* idx, float* d2) {
+        if (nn_mode == 0) {
+            kdtree_search(tree.data(), tree.size(), q, nq, 1, T, idx, d2, -1.0f);
+        } else {
+            std::vector<float> tq(nq * 4);
+            for (size_t i = 0; i < nq; ++i) transform_point(q + 4 * i, tq.data() + 4 * i, T);
+            knn_bruteforce(tq.data(), nq, tgt, nt, 1, idx, d2);
+        }
+    };
+    std::vector<float> trace;
+    RegResult r;
+    if (P->auto_scale)
+        r = align_robust_annealing(p, s, t, nearest, init_T16, true, P->init_scale, P->min_scale, (size_t)P->auto_scaling_iter);
+    else
+        r = align(p, s, t, nearest, init_T16, -1.0f, trace_T ? &trace : nullptr);
+    std::memcpy(out->T, r.T.d, 64);
+    std::memcpy(out->H, r.H.d, 144);
+    std::memcpy(out->b, r.b.d, 24);
+    out->error = r.error; out->inlier = r.inlier; out->iterations = (int)r.iterations; out->converged = r.converged ? 1 : 0;
+    if (trace_T) { std::memcpy(trace_T, trace.data(), trace.size() * 4); *trace_n = (int)(trace.size() / 16); }
+}
+
+}  // extern "C"

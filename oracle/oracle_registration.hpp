@@ -1,0 +1,576 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp header).
+// CPU restatement of the registration path:
+//   per-point factors   /root/reference/cpp/include/sycl_points/algorithms/registration/factor.hpp:69-482
+//   robust kernels      .../robust/robust.hpp:56-114
+//   linearize + reduce  .../registration/registration.hpp:513-664 (K11), error-only :678-777 (K12)
+//   GenZ alpha          .../registration/registration.hpp:464-511
+//   optimisers          .../registration/registration.hpp:201-276, 407-410, 791-895
+//   annealing wrapper   .../registration/pipeline/robust.hpp:42-114
+// The reduction order of sycl::reduction is unspecified (parity unpinned); this restatement sums
+// fixed blocks of 1024 points sequentially in fp32 and then the block partials sequentially in fp32,
+// which is deterministic and independent of the OpenMP thread count.
+#pragma once
+#include <functional>
+#include <vector>
+
+#include "oracle_features.hpp"
+#include "oracle_knn.hpp"
+#include "oracle_math.hpp"
+
+namespace oracle {
+
+enum RegType { POINT_TO_POINT = 0, POINT_TO_PLANE = 1, POINT_TO_DISTRIBUTION = 2, GICP = 3, GENZ = 4 };  // factor.hpp:18-32
+enum RobustLossType { LOSS_NONE = 0, HUBER = 1, TUKEY = 2, CAUCHY = 3, GEMAN_MCCLURE = 4 };             // robust.hpp:13-19
+enum OptimizationMethod { GAUSS_NEWTON = 0, LEVENBERG_MARQUARDT = 1, POWELL_DOGLEG = 2 };
+
+// robust.hpp:56-90
+inline float robust_weight(int loss, float residual_norm, float scale) {
+    if (loss == LOSS_NONE) return 1.0f;
+    if (residual_norm <= 1e-8f) return 1.0f;
+    const float nr = residual_norm / scale;
+    switch (loss) {
+        case HUBER: return sycl_min(1.0f, 1.0f / nr);
+        case TUKEY: {
+            if (nr >= 1.0f) return 0.0f;
+            const float x = nr * nr;
+            const float f = 1.0f - x;
+            return f * f;
+        }
+        case CAUCHY: {
+            const float x = nr * nr;
+            return 1.0f / (1.0f + x);
+        }
+        case GEMAN_MCCLURE: {
+            const float x = nr * nr;
+            const float den = 1.0f + x;
+            return 1.0f / (den * den);
+        }
+    }
+    return 1.0f;
+}
+// robust.hpp:96-114
+inline float robust_error(int loss, float r, float s) {
+    switch (loss) {
+        case LOSS_NONE: return 0.5f * r * r;
+        case HUBER: return r <= s ? 0.5f * r * r : s * (r - 0.5f * s);
+        case TUKEY:
+            return r <= s ? (s * s / 6.0f) * (1.0f - std::pow(1.0f - ((r * r) / (s * s)), 3.0f)) : s * s / 6.0f;
+        case CAUCHY: return 0.5f * s * s * std::log(1.0f + ((r * r) / (s * s)));
+        case GEMAN_MCCLURE: return 0.5f * (s * s * r * r) / (s * s + r * r);
+    }
+    return 0.5f * r * r;
+}
+
+struct KernelResult {  // linearized_result.hpp:27-38
+    Mat6 H = Mat6::Zero();
+    Vec6 b = Vec6::Zero();
+    float squared_error = std::numeric_limits<float>::max();
+    uint32_t inlier = 0;
+};
+
+inline Mat4 to_mat4(const float* colmajor) {
+    Mat4 m;
+    std::memcpy(m.d, colmajor, 64);
+    return m;
+}
+inline Vec4 to_vec4(const float* p) {
+    Vec4 v;
+    std::memcpy(v.d, p, 16);
+    return v;
+}
+
+// factor.hpp:69-84
+inline Mat<4, 6> compute_se3_jacobian(const Mat4& T, const Vec4& source_pt) {
+    Mat<4, 6> J = Mat<4, 6>::Zero();
+    const Mat3 skewed = skew(source_pt);
+    Mat3 R;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) R(i, j) = T(i, j);
+    const Mat3 T_skewed = matmul<3, 3, 3>(R, skewed);
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) {
+            J(i, j) = T_skewed(i, j);
+            J(i, 3 + j) = -R(i, j);
+        }
+    return J;
+}
+// factor.hpp:90-104 (weight matrix is Identity at every call site: an fma product with I)
+inline Mat<4, 6> compute_weighted_se3_jacobian(const Mat4& T, const Vec4& source_pt, const Mat4& W) {
+    return matmul<4, 4, 6>(W, compute_se3_jacobian(T, source_pt));
+}
+// factor.hpp:111-123
+inline Mat4 compute_mahalanobis_covariance(const Mat4& source_cov, const Mat4& target_cov, const Mat4& T) {
+    Mat4 mah = Mat4::Zero();
+    Mat4 tsc;
+    transform_cov(source_cov.d, tsc.d, T.d);
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) mah(i, j) = tsc(i, j) + target_cov(i, j);
+    return mah;
+}
+// feature/covariance.hpp:143-148
+inline Mat4 cov_inverse(const Mat4& cov) {
+    Mat4 r = Mat4::Zero();
+    const Mat3 inv = inverse(block3(cov.d));
+    set_block3(r.d, inv);
+    return r;
+}
+inline Vec4 residual_of(const Mat4& T, const Vec4& s, const Vec4& t) {
+    Vec4 ts;
+    transform_point(s.d, ts.d, T.d);
+    Vec4 r;
+    r[0] = t[0] - ts[0]; r[1] = t[1] - ts[1]; r[2] = t[2] - ts[2]; r[3] = 0.0f;
+    return r;
+}
+
+// factor.hpp:130-149
+inline KernelResult linearize_point_to_point(const Mat4& T, const Vec4& s, const Vec4& t, float& residual_norm) {
+    const Vec4 residual = residual_of(T, s, t);
+    const Mat<4, 6> J = compute_weighted_se3_jacobian(T, s, Mat4::Identity());
+    KernelResult ret;
+    const Mat<6, 4> JT = transpose<4, 6>(J);
+    ret.H = ensure_symmetric<6>(matmul<6, 4, 6>(JT, J));
+    ret.b = matvec<6, 4>(JT, residual);
+    const float sq = norm_squared<4>(residual);
+    residual_norm = std::sqrt(sq);
+    ret.squared_error = sq;
+    ret.inlier = 1;
+    return ret;
+}
+inline float error_point_to_point(const Mat4& T, const Vec4& s, const Vec4& t) {  // factor.hpp:156-164
+    return norm_squared<4>(residual_of(T, s, t));
+}
+// factor.hpp:172-210
+inline KernelResult linearize_point_to_plane(const Mat4& T, const Vec4& s, const Vec4& t, const Vec4& tn,
+                                             float& residual_norm) {
+    const Vec4 residual = residual_of(T, s, t);
+    Vec3 normal, r3;
+    for (int i = 0; i < 3; ++i) { normal[i] = tn[i]; r3[i] = residual[i]; }
+    const float proj = dot<3>(normal, r3);
+    Vec4 plane_error = Vec4::Zero();
+    for (int i = 0; i < 3; ++i) plane_error[i] = normal[i] * proj;
+    const Mat<4, 6> se3J = compute_se3_jacobian(T, s);
+    Mat<3, 6> J36;
+    for (int j = 0; j < 6; ++j)
+        for (int i = 0; i < 3; ++i) J36(i, j) = se3J(i, j);
+    const Mat<1, 3> nT = transpose<3, 1>(normal);
+    const Mat<1, 6> row = matmul<1, 3, 6>(nT, J36);
+    const Mat<3, 6> Jp = matmul<3, 1, 6>(normal, row);
+    Mat<4, 6> J = Mat<4, 6>::Zero();
+    for (int j = 0; j < 6; ++j)
+        for (int i = 0; i < 3; ++i) J(i, j) = Jp(i, j);
+    KernelResult ret;
+    const Mat<6, 4> JT = transpose<4, 6>(J);
+    ret.H = ensure_symmetric<6>(matmul<6, 4, 6>(JT, J));
+    ret.b = matvec<6, 4>(JT, plane_error);
+    residual_norm = std::fabs(proj);
+    ret.squared_error = proj * proj;
+    ret.inlier = 1;
+    return ret;
+}
+inline float error_point_to_plane(const Mat4& T, const Vec4& s, const Vec4& t, const Vec4& tn) {  // factor.hpp:218-230
+    const Vec4 residual = residual_of(T, s, t);
+    Vec3 normal, r3;
+    for (int i = 0; i < 3; ++i) { normal[i] = tn[i]; r3[i] = residual[i]; }
+    const float proj = dot<3>(normal, r3);
+    return proj * proj;
+}
+// factor.hpp:239-278
+inline KernelResult linearize_gicp(const Mat4& T, const Vec4& s, const Mat4& scov, const Vec4& t, const Mat4& tcov,
+                                   float& residual_norm) {
+    const Vec4 residual = residual_of(T, s, t);
+    Mat4 ns = scov, nt = tcov;
+    update_covariance_plane(ns.d);
+    update_covariance_plane(nt.d);
+    const Mat4 mah_inv = cov_inverse(compute_mahalanobis_covariance(ns, nt, T));
+    const Mat<4, 6> J = compute_weighted_se3_jacobian(T, s, Mat4::Identity());
+    const Mat<6, 4> JTm = matmul<6, 4, 4>(transpose<4, 6>(J), mah_inv);
+    KernelResult ret;
+    ret.H = ensure_symmetric<6>(matmul<6, 4, 6>(JTm, J));
+    ret.b = matvec<6, 4>(JTm, residual);
+    const float sq = dot<4>(residual, matvec<4, 4>(mah_inv, residual));
+    residual_norm = std::sqrt(sq);
+    ret.squared_error = sq;
+    ret.inlier = 1;
+    return ret;
+}
+inline float error_gicp(const Mat4& T, const Vec4& s, const Mat4& scov, const Vec4& t, const Mat4& tcov) {  // :287-306
+    const Vec4 residual = residual_of(T, s, t);
+    Mat4 ns = scov, nt = tcov;
+    update_covariance_plane(ns.d);
+    update_covariance_plane(nt.d);
+    const Mat4 mah_inv = cov_inverse(compute_mahalanobis_covariance(ns, nt, T));
+    return dot<4>(residual, matvec<4, 4>(mah_inv, residual));
+}
+// factor.hpp:311-354
+inline KernelResult linearize_point_to_distribution(const Mat4& T, const Vec4& s, const Vec4& t, const Mat4& tcov,
+                                                    float& residual_norm) {
+    const Vec4 residual = residual_of(T, s, t);
+    const Mat<4, 6> J = compute_weighted_se3_jacobian(T, s, Mat4::Identity());
+    const Mat4 mah = cov_inverse(tcov);
+    const Mat<6, 4> JTm = matmul<6, 4, 4>(transpose<4, 6>(J), mah);
+    KernelResult ret;
+    ret.H = ensure_symmetric<6>(matmul<6, 4, 6>(JTm, J));
+    ret.b = matvec<6, 4>(JTm, residual);
+    const float sq = dot<4>(residual, matvec<4, 4>(mah, residual));
+    residual_norm = std::sqrt(sq);
+    ret.squared_error = sq;
+    ret.inlier = 1;
+    return ret;
+}
+inline float error_point_to_distribution(const Mat4& T, const Vec4& s, const Vec4& t, const Mat4& tcov) {  // :362-373
+    const Mat4 mah = cov_inverse(tcov);
+    const Vec4 residual = residual_of(T, s, t);
+    return dot<4>(residual, matvec<4, 4>(mah, residual));
+}
+// factor.hpp:378-392
+inline bool genz_is_planar(const Mat4& tcov, float thr) {
+    Vec3 vals;
+    Mat3 vecs;
+    symmetric_eigen_decomposition_3x3(block3(tcov.d), vals, vecs);
+    const float sum = vals[0] + vals[1] + vals[2];
+    const float curv = (sum > 1e-12f) ? vals[0] / sum : 1.0f;
+    return curv < thr;
+}
+// factor.hpp:413-449
+inline KernelResult linearize_geometry(int reg, const Mat4& T, const Vec4& s, const Mat4& scov, const Vec4& t,
+                                       const Mat4& tcov, const Vec4& tn, float& residual_norm, float genz_alpha,
+                                       float& genz_weight, float genz_thr) {
+    switch (reg) {
+        case POINT_TO_POINT: return linearize_point_to_point(T, s, t, residual_norm);
+        case POINT_TO_PLANE: return linearize_point_to_plane(T, s, t, tn, residual_norm);
+        case GICP: return linearize_gicp(T, s, scov, t, tcov, residual_norm);
+        case POINT_TO_DISTRIBUTION: return linearize_point_to_distribution(T, s, t, tcov, residual_norm);
+        case GENZ: {
+            const bool planar = genz_is_planar(tcov, genz_thr);
+            genz_weight = planar ? genz_alpha : (1.0f - genz_alpha);
+            float sel_norm = 0.0f;
+            const KernelResult sel =
+                planar ? linearize_point_to_plane(T, s, t, tn, sel_norm) : linearize_point_to_point(T, s, t, sel_norm);
+            residual_norm = sel_norm;
+            KernelResult r;
+            r.H = scale<6, 6>(sel.H, genz_weight);
+            r.b = scale<6, 1>(sel.b, genz_weight);
+            r.squared_error = sel.squared_error * genz_weight;
+            r.inlier = 1;
+            return r;
+        }
+    }
+    return KernelResult();
+}
+// factor.hpp:459-482
+inline float geometry_error(int reg, const Mat4& T, const Vec4& s, const Mat4& scov, const Vec4& t, const Mat4& tcov,
+                            const Vec4& tn, float genz_alpha, float& genz_weight, float genz_thr) {
+    switch (reg) {
+        case POINT_TO_POINT: return error_point_to_point(T, s, t);
+        case POINT_TO_PLANE: return error_point_to_plane(T, s, t, tn);
+        case GICP: return error_gicp(T, s, scov, t, tcov);
+        case POINT_TO_DISTRIBUTION: return error_point_to_distribution(T, s, t, tcov);
+        case GENZ: {
+            const bool planar = genz_is_planar(tcov, genz_thr);
+            genz_weight = planar ? genz_alpha : (1.0f - genz_alpha);
+            return planar ? error_point_to_plane(T, s, t, tn) : error_point_to_point(T, s, t);
+        }
+    }
+    return 0.0f;
+}
+
+// ------------------------------------------------------------------ clouds + reductions
+struct Cloud {  // borrowed host pointers; covs/normals may be null (registration.hpp:539-543)
+    const float* points = nullptr;   // N x 4
+    const float* covs = nullptr;     // N x 16 column-major
+    const float* normals = nullptr;  // N x 4
+    size_t n = 0;
+};
+
+struct Linearized {  // linearized_result.hpp:12-24
+    Mat6 H = Mat6::Zero();
+    Vec6 b = Vec6::Zero();
+    float error = std::numeric_limits<float>::max();
+    uint32_t inlier = 0;
+};
+
+struct FactorParams {  // registration_params.hpp:46-71 (rotation constraint: out of scope, default off)
+    int reg_type = GICP;
+    float max_correspondence_distance = 2.0f;
+    int robust_type = LOSS_NONE;
+    float robust_default_scale = 10.0f;
+    float genz_planarity_threshold = 0.2f;
+};
+
+constexpr size_t REDUCE_BLOCK = 1024;
+
+// registration.hpp:464-511
+inline float compute_genz_alpha(const Cloud& target, const int32_t* nn_idx, const float* nn_d2, size_t N, float max_corr,
+                                float thr) {
+    uint32_t inl = 0, plane = 0;
+    const float max_d2 = max_corr * max_corr;
+    for (size_t i = 0; i < N; ++i) {
+        if (nn_d2[i] > max_d2) continue;
+        if (genz_is_planar(to_mat4(target.covs + 16 * (size_t)nn_idx[i]), thr)) ++plane;
+        ++inl;
+    }
+    if (inl == 0) return 1.0f;
+    return (float)plane / (float)inl;
+}
+
+// registration.hpp:513-664 (K11).  Optional per-point outputs (H 36 row-major, b 6, err 1, flag 1 = 44 floats)
+inline Linearized linearize_reduce(const FactorParams& fp, const Cloud& source, const Cloud& target, const int32_t* nn_idx,
+                                   const float* nn_d2, const float* T_colmajor, float robust_scale, float genz_alpha,
+                                   float* per_point = nullptr) {
+    const size_t N = source.n;
+    const Mat4 T = to_mat4(T_colmajor);
+    const float max_d2 = fp.max_correspondence_distance * fp.max_correspondence_distance;
+    const size_t nblocks = (N + REDUCE_BLOCK - 1) / REDUCE_BLOCK;
+    std::vector<float> partial(nblocks * 43, 0.0f);
+    std::vector<uint32_t> partial_inl(nblocks, 0);
+#pragma omp parallel for schedule(static)
+    for (long long blk = 0; blk < (long long)nblocks; ++blk) {
+        float acc[43];
+        for (int e = 0; e < 43; ++e) acc[e] = 0.0f;
+        uint32_t inl = 0;
+        const size_t lo = blk * REDUCE_BLOCK, hi = std::min(N, lo + REDUCE_BLOCK);
+        for (size_t i = lo; i < hi; ++i) {
+            if (per_point)
+                for (int e = 0; e < 44; ++e) per_point[i * 44 + e] = 0.0f;
+            if (nn_d2[i] > max_d2) continue;
+            const size_t ti = (size_t)nn_idx[i];
+            const Mat4 scov = source.covs ? to_mat4(source.covs + 16 * i) : Mat4::Identity();
+            const Mat4 tcov = target.covs ? to_mat4(target.covs + 16 * ti) : Mat4::Identity();
+            const Vec4 tn = target.normals ? to_vec4(target.normals + 4 * ti) : Vec4::Zero();
+            float residual_norm = 0.0f, genz_weight = 1.0f;
+            const KernelResult lin =
+                linearize_geometry(fp.reg_type, T, to_vec4(source.points + 4 * i), scov, to_vec4(target.points + 4 * ti),
+                                   tcov, tn, residual_norm, genz_alpha, genz_weight, fp.genz_planarity_threshold);
+            const float w = robust_weight(fp.robust_type, residual_norm, robust_scale);
+            float e = robust_error(fp.robust_type, residual_norm, robust_scale);
+            if (fp.reg_type == GENZ) e = genz_weight * e;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) {
+                    const float v = w * lin.H(r, c);
+                    acc[r * 6 + c] += v;
+                    if (per_point) per_point[i * 44 + r * 6 + c] = v;
+                }
+            for (int r = 0; r < 6; ++r) {
+                const float v = w * lin.b[r];
+                acc[36 + r] += v;
+                if (per_point) per_point[i * 44 + 36 + r] = v;
+            }
+            acc[42] += e;
+            if (per_point) { per_point[i * 44 + 42] = e; per_point[i * 44 + 43] = 1.0f; }
+            ++inl;
+        }
+        for (int e = 0; e < 43; ++e) partial[blk * 43 + e] = acc[e];
+        partial_inl[blk] = inl;
+    }
+    float tot[43];
+    for (int e = 0; e < 43; ++e) tot[e] = 0.0f;
+    uint32_t inl = 0;
+    for (size_t blk = 0; blk < nblocks; ++blk) {
+        for (int e = 0; e < 43; ++e) tot[e] += partial[blk * 43 + e];
+        inl += partial_inl[blk];
+    }
+    Linearized out;
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) out.H(r, c) = tot[r * 6 + c];
+    for (int r = 0; r < 6; ++r) out.b[r] = tot[36 + r];
+    out.error = tot[42];
+    out.inlier = inl;
+    return out;
+}
+
+// registration.hpp:678-777 (K12)
+inline void error_reduce(const FactorParams& fp, const Cloud& source, const Cloud& target, const int32_t* nn_idx,
+                         const float* nn_d2, const float* T_colmajor, float robust_scale, float genz_alpha, float& error,
+                         uint32_t& inlier) {
+    const size_t N = source.n;
+    const Mat4 T = to_mat4(T_colmajor);
+    const float max_d2 = fp.max_correspondence_distance * fp.max_correspondence_distance;
+    const size_t nblocks = (N + REDUCE_BLOCK - 1) / REDUCE_BLOCK;
+    std::vector<float> partial(nblocks, 0.0f);
+    std::vector<uint32_t> partial_inl(nblocks, 0);
+#pragma omp parallel for schedule(static)
+    for (long long blk = 0; blk < (long long)nblocks; ++blk) {
+        float acc = 0.0f;
+        uint32_t inl = 0;
+        const size_t lo = blk * REDUCE_BLOCK, hi = std::min(N, lo + REDUCE_BLOCK);
+        for (size_t i = lo; i < hi; ++i) {
+            if (nn_d2[i] > max_d2) continue;
+            const size_t ti = (size_t)nn_idx[i];
+            const Mat4 scov = source.covs ? to_mat4(source.covs + 16 * i) : Mat4::Identity();
+            const Mat4 tcov = target.covs ? to_mat4(target.covs + 16 * ti) : Mat4::Identity();
+            const Vec4 tn = target.normals ? to_vec4(target.normals + 4 * ti) : Vec4::Zero();
+            float genz_weight = 1.0f;
+            const float sq = geometry_error(fp.reg_type, T, to_vec4(source.points + 4 * i), scov,
+                                            to_vec4(target.points + 4 * ti), tcov, tn, genz_alpha, genz_weight,
+                                            fp.genz_planarity_threshold);
+            const float rn = std::sqrt(sq);
+            float e = robust_error(fp.robust_type, rn, robust_scale);
+            if (fp.reg_type == GENZ) e = genz_weight * e;
+            acc += e;
+            ++inl;
+        }
+        partial[blk] = acc;
+        partial_inl[blk] = inl;
+    }
+    float tot = 0.0f;
+    uint32_t inl = 0;
+    for (size_t blk = 0; blk < nblocks; ++blk) { tot += partial[blk]; inl += partial_inl[blk]; }
+    error = tot;
+    inlier = inl;
+}
+
+// registration.hpp:439-459 (K13)
+inline void icp_robust_weights(const FactorParams& fp, const Cloud& source, const Cloud& target, const int32_t* nn_idx,
+                               const float* nn_d2, const float* T_colmajor, float robust_scale, float genz_alpha,
+                               float* out) {
+    const Mat4 T = to_mat4(T_colmajor);
+    const float max_d2 = fp.max_correspondence_distance * fp.max_correspondence_distance;
+    for (size_t i = 0; i < source.n; ++i) {
+        float w = 0.0f;
+        if (nn_d2[i] <= max_d2) {
+            const size_t ti = (size_t)nn_idx[i];
+            const Mat4 scov = source.covs ? to_mat4(source.covs + 16 * i) : Mat4::Identity();
+            const Mat4 tcov = target.covs ? to_mat4(target.covs + 16 * ti) : Mat4::Identity();
+            const Vec4 tn = target.normals ? to_vec4(target.normals + 4 * ti) : Vec4::Zero();
+            float gw = 1.0f;
+            const float sq = geometry_error(fp.reg_type, T, to_vec4(source.points + 4 * i), scov,
+                                            to_vec4(target.points + 4 * ti), tcov, tn, genz_alpha, gw,
+                                            fp.genz_planarity_threshold);
+            w = robust_weight(fp.robust_type, std::sqrt(sq), robust_scale);
+        }
+        out[i] = w;
+    }
+}
+
+// ------------------------------------------------------------------ outer loop
+struct RegParams : FactorParams {  // registration_params.hpp:74-114
+    float gn_lambda = 1.0f;
+    size_t lm_max_inner_iterations = 10;
+    float lm_lambda_factor = 2.0f, lm_init_lambda = 1.0f, lm_max_lambda = 1e3f, lm_min_lambda = 1e-6f;
+    int optimization_method = GAUSS_NEWTON;
+    size_t max_iterations = 20;
+    float crit_translation = 1e-3f, crit_rotation = 1e-3f;
+};
+
+struct RegResult {  // result.hpp:12-28
+    Mat4 T = Mat4::Identity();
+    bool converged = false;
+    size_t iterations = 0;
+    Mat6 H = Mat6::Zero();
+    Vec6 b = Vec6::Zero();
+    float error = std::numeric_limits<float>::max();
+    uint32_t inlier = 0;
+};
+
+// The KNNBase seam (knn/knn.hpp:14-61): nearest neighbour of T*q for every source point.
+using NearestFn = std::function<void(const float* queries, size_t nq, const float* T_colmajor, int32_t* idx, float* d2)>;
+
+inline bool is_converged(const RegParams& p, const Vec6& d) {  // registration.hpp:407-410 (Eigen .norm(): plain sum)
+    const float nr = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float nt = std::sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    return nr < p.crit_rotation && nt < p.crit_translation;
+}
+inline bool solve_linear_system(const Mat6& H, const Vec6& b, Vec6& x) {  // registration.hpp:791-801
+    const Vec6 nb = scale<6, 1>(b, -1.0f);
+    return ldlt6_solve(H, nb, x);
+}
+inline Mat6 add_lambda(const Mat6& H, float lambda) {
+    Mat6 r = H;
+    for (int i = 0; i < 6; ++i) r(i, i) = H(i, i) + lambda * 1.0f;
+    return r;
+}
+
+// registration.hpp:201-276 with GN (:803-828) and LM (:830-895).  Degenerate regularisation and MAP prior are
+// default-off no-ops in the reference (degenerate_regularization.hpp:40, map_prior.hpp:15) and are not restated.
+inline RegResult align(const RegParams& params, const Cloud& source, const Cloud& target, const NearestFn& nearest,
+                       const float* init_T_colmajor, float opt_robust_scale = -1.0f,
+                       std::vector<float>* trace_T = nullptr) {
+    RegResult result;
+    result.T = to_mat4(init_T_colmajor);
+    const size_t N = source.n;
+    if (N == 0) return result;
+    RegParams p = params;
+    if (p.robust_type != LOSS_NONE && p.robust_default_scale <= 0.0f) p.robust_type = LOSS_NONE;  // :186-192
+    const float robust_scale = opt_robust_scale > 0.0f ? opt_robust_scale : p.robust_default_scale;
+    float lm_lambda = p.lm_init_lambda;
+    std::vector<int32_t> nn_idx(N);
+    std::vector<float> nn_d2(N);
+    float genz_alpha = 1.0f;
+    for (size_t iter = 0; iter < p.max_iterations; ++iter) {
+        nearest(source.points, N, result.T.d, nn_idx.data(), nn_d2.data());
+        if (p.reg_type == GENZ)
+            genz_alpha = compute_genz_alpha(target, nn_idx.data(), nn_d2.data(), N, p.max_correspondence_distance,
+                                            p.genz_planarity_threshold);
+        const Linearized lin =
+            linearize_reduce(p, source, target, nn_idx.data(), nn_d2.data(), result.T.d, robust_scale, genz_alpha);
+        if (p.optimization_method == GAUSS_NEWTON) {
+            Vec6 delta;
+            const bool ok = solve_linear_system(add_lambda(lin.H, p.gn_lambda), lin.b, delta);
+            result.converged = ok ? is_converged(p, delta) : false;
+            result.T = isometry_mul(result.T, se3_exp(delta));
+            result.iterations = iter;
+            result.H = lin.H;
+            result.b = lin.b;
+            result.error = lin.error;
+            result.inlier = lin.inlier;
+        } else if (p.optimization_method == LEVENBERG_MARQUARDT) {
+            const float current_error = lin.error;
+            float last_error = std::numeric_limits<float>::max();
+            Vec6 delta;
+            for (size_t i = 0; i < p.lm_max_inner_iterations; ++i) {
+                const bool ok = solve_linear_system(add_lambda(lin.H, lm_lambda), lin.b, delta);
+                result.converged = ok ? is_converged(p, delta) : false;
+                const Mat4 new_T = isometry_mul(result.T, se3_exp(delta));
+                float new_error;
+                uint32_t inl;
+                error_reduce(p, source, target, nn_idx.data(), nn_d2.data(), new_T.d, robust_scale, genz_alpha, new_error,
+                             inl);
+                if (new_error <= current_error) {
+                    result.converged = is_converged(p, delta);
+                    result.T = new_T;
+                    result.error = new_error;
+                    result.inlier = inl;
+                    lm_lambda = std::clamp(lm_lambda / p.lm_lambda_factor, p.lm_min_lambda, p.lm_max_lambda);
+                    break;
+                } else if (std::fabs(new_error - last_error) <= 1e-6f) {
+                    result.converged = is_converged(p, delta);
+                    result.T = new_T;
+                    result.error = new_error;
+                    result.inlier = inl;
+                    break;
+                } else {
+                    lm_lambda = std::clamp(lm_lambda * p.lm_lambda_factor, p.lm_min_lambda, p.lm_max_lambda);
+                }
+                last_error = new_error;
+            }
+            result.iterations = iter;
+            result.H = lin.H;
+            result.b = lin.b;
+        }
+        if (trace_T) trace_T->insert(trace_T->end(), result.T.d, result.T.d + 16);
+        if (result.converged) break;
+    }
+    return result;
+}
+
+// pipeline/robust.hpp:42-114 — geometric robust-scale annealing around align().
+inline RegResult align_robust_annealing(const RegParams& params, const Cloud& source, const Cloud& target,
+                                        const NearestFn& nearest, const float* init_T_colmajor, bool auto_scale,
+                                        float init_scale, float min_scale, size_t auto_scaling_iter) {
+    RegResult result;
+    result.T = to_mat4(init_T_colmajor);
+    if (source.n == 0) return result;
+    bool enable = params.robust_type != LOSS_NONE && auto_scale;
+    if (enable && (min_scale <= 0.0f || min_scale >= init_scale)) enable = false;
+    if (enable && auto_scaling_iter == 0) enable = false;
+    const size_t levels = enable ? std::max<size_t>(1, auto_scaling_iter) : 1;
+    float robust_scale = enable ? init_scale : params.robust_default_scale;
+    const float factor = levels > 1 ? std::pow(min_scale / init_scale, 1.0f / (float)(levels - 1)) : 1.0f;
+    for (size_t level = 0; level < levels; ++level) {
+        result = align(params, source, target, nearest, result.T.d, robust_scale);
+        robust_scale *= factor;
+    }
+    return result;
+}
+
+}  // namespace oracle

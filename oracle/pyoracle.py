@@ -1,0 +1,385 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so (the CPU restatement of the reference's hot path).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (sycl_points_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+REG = {"POINT_TO_POINT": 0, "POINT_TO_PLANE": 1, "POINT_TO_DISTRIBUTION": 2, "GICP": 3, "GENZ": 4}
+LOSS = {"NONE": 0, "HUBER": 1, "TUKEY": 2, "CAUCHY": 3, "GEMAN_MCCLURE": 4}
+OPT = {"GN": 0, "LM": 1, "DOGLEG": 2}
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
+    stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+class RegParams(C.Structure):
+    _fields_ = [
+        ("reg_type", C.c_int), ("robust_type", C.c_int), ("optimization_method", C.c_int), ("max_iterations", C.c_int),
+        ("max_correspondence_distance", C.c_float), ("robust_default_scale", C.c_float), ("gn_lambda", C.c_float),
+        ("lm_init_lambda", C.c_float), ("lm_lambda_factor", C.c_float), ("lm_min_lambda", C.c_float),
+        ("lm_max_lambda", C.c_float), ("lm_max_inner_iterations", C.c_int),
+        ("crit_translation", C.c_float), ("crit_rotation", C.c_float),
+        ("auto_scale", C.c_int), ("auto_scaling_iter", C.c_int), ("init_scale", C.c_float), ("min_scale", C.c_float),
+    ]
+
+    @staticmethod
+    def defaults(**kw):
+        # registration_params.hpp:46-114 defaults
+        p = RegParams(reg_type=REG["GICP"], robust_type=LOSS["NONE"], optimization_method=OPT["GN"], max_iterations=20,
+                      max_correspondence_distance=2.0, robust_default_scale=10.0, gn_lambda=1.0,
+                      lm_init_lambda=1.0, lm_lambda_factor=2.0, lm_min_lambda=1e-6, lm_max_lambda=1e3,
+                      lm_max_inner_iterations=10, crit_translation=1e-3, crit_rotation=1e-3,
+                      auto_scale=0, auto_scaling_iter=4, init_scale=10.0, min_scale=0.5)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
+class RegResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("H", C.c_float * 36), ("b", C.c_float * 6), ("error", C.c_float),
+                ("inlier", C.c_uint32), ("iterations", C.c_int), ("converged", C.c_int)]
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=C.c_float):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.orc_rng_new.restype = C.c_void_p
+        L.orc_rng_new.argtypes = [C.c_uint32]
+        L.orc_rng_free.argtypes = [C.c_void_p]
+        L.orc_rng_uniform_points.argtypes = [C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]
+        L.orc_rng_normal.argtypes = [C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]
+        L.orc_det3.restype = C.c_float
+        L.orc_robust_weight.restype = C.c_float
+        L.orc_robust_weight.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.orc_robust_error.restype = C.c_float
+        L.orc_robust_error.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.orc_kdtree_build.restype = C.c_size_t
+        L.orc_voxel_downsample.restype = C.c_size_t
+        L.orc_num_threads.restype = C.c_int
+
+    # ---- rng / synthetic clouds
+    def rng(self, seed):
+        return _Rng(self, seed)
+
+    def random_sampling_flags(self, seed, n, num):
+        flags = np.zeros(n, np.uint8)
+        self.lib.orc_random_sampling_flags(C.c_uint32(seed), C.c_size_t(n), C.c_size_t(num), _p(flags, C.c_uint8))
+        return flags
+
+    def num_threads(self):
+        return self.lib.orc_num_threads()
+
+    def set_num_threads(self, n):
+        self.lib.orc_set_num_threads(C.c_int(n))
+
+    # ---- math probes (matrices in/out as numpy row-major [i,j]; converted to column-major storage)
+    def eigen3(self, A):
+        A = _f(np.asarray(A).T)  # row-major of A^T == column-major of A
+        vals = np.zeros(3, np.float32)
+        vecs = np.zeros((3, 3), np.float32)
+        self.lib.orc_eigen3(_p(A), _p(vals), _p(vecs))
+        return vals, vecs.T.copy()
+
+    def inverse3(self, A):
+        A = _f(np.asarray(A).T)
+        out = np.zeros((3, 3), np.float32)
+        self.lib.orc_inverse3(_p(A), _p(out))
+        return out.T.copy()
+
+    def det3(self, A):
+        A = _f(np.asarray(A).T)
+        return float(self.lib.orc_det3(_p(A)))
+
+    def matmul4(self, A, B):
+        A = _f(np.asarray(A).T)
+        B = _f(np.asarray(B).T)
+        out = np.zeros((4, 4), np.float32)
+        self.lib.orc_matmul4(_p(A), _p(B), _p(out))
+        return out.T.copy()
+
+    def se3_exp(self, twist):
+        t = _f(twist)
+        out = np.zeros((4, 4), np.float32)
+        self.lib.orc_se3_exp(_p(t), _p(out))
+        return out.T.copy()
+
+    def se3_log(self, T):
+        Tc = _f(np.asarray(T).T)
+        out = np.zeros(6, np.float32)
+        self.lib.orc_se3_log(_p(Tc), _p(out))
+        return out
+
+    def so3_exp(self, w):
+        w = _f(w)
+        out = np.zeros(4, np.float32)
+        self.lib.orc_so3_exp(_p(w), _p(out))
+        return out
+
+    def so3_log(self, q):
+        q = _f(q)
+        out = np.zeros(3, np.float32)
+        self.lib.orc_so3_log(_p(q), _p(out))
+        return out
+
+    def isometry_mul(self, A, B):
+        A = _f(np.asarray(A).T)
+        B = _f(np.asarray(B).T)
+        out = np.zeros((4, 4), np.float32)
+        self.lib.orc_isometry_mul(_p(A), _p(B), _p(out))
+        return out.T.copy()
+
+    def ldlt6_solve(self, H, b):
+        Hc = _f(np.asarray(H).T)
+        b = _f(b)
+        x = np.zeros(6, np.float32)
+        ok = self.lib.orc_ldlt6_solve(_p(Hc), _p(b), _p(x))
+        return bool(ok), x
+
+    def robust_weight(self, loss, r, s):
+        return float(self.lib.orc_robust_weight(LOSS[loss], r, s))
+
+    def robust_error(self, loss, r, s):
+        return float(self.lib.orc_robust_error(LOSS[loss], r, s))
+
+    # ---- knn
+    def knn_bruteforce(self, q, t, k):
+        q, t = _f(q), _f(t)
+        idx = np.empty((len(q), k), np.int32)
+        d2 = np.empty((len(q), k), np.float32)
+        self.lib.orc_knn_bruteforce(_p(q), C.c_size_t(len(q)), _p(t), C.c_size_t(len(t)), C.c_size_t(k),
+                                    _p(idx, C.c_int32), _p(d2))
+        return idx, d2
+
+    def kdtree_build(self, pts, leaf=16):
+        pts = _f(pts)
+        nodes = np.zeros(max(2 * len(pts), 1) * 32, np.uint8)
+        n = self.lib.orc_kdtree_build(_p(pts), C.c_size_t(len(pts)), C.c_size_t(leaf), nodes.ctypes.data_as(C.c_void_p))
+        return nodes[: n * 32].copy()
+
+    def kdtree_knn(self, nodes, q, k, T=None):
+        q = _f(q)
+        Tc = _f(np.eye(4) if T is None else np.asarray(T).T)
+        idx = np.empty((len(q), k), np.int32)
+        d2 = np.empty((len(q), k), np.float32)
+        rc = self.lib.orc_kdtree_knn(nodes.ctypes.data_as(C.c_void_p), C.c_size_t(len(nodes) // 32), _p(q),
+                                     C.c_size_t(len(q)), C.c_size_t(k), _p(Tc), _p(idx, C.c_int32), _p(d2))
+        if rc != 0:
+            raise RuntimeError("[KDTree::knn_search_async] `k` is too large. not support.")
+        return idx, d2
+
+    def kdtree_radius(self, nodes, q, max_k, radius, T=None):
+        q = _f(q)
+        Tc = _f(np.eye(4) if T is None else np.asarray(T).T)
+        idx = np.empty((len(q), max_k), np.int32)
+        d2 = np.empty((len(q), max_k), np.float32)
+        rc = self.lib.orc_kdtree_radius(nodes.ctypes.data_as(C.c_void_p), C.c_size_t(len(nodes) // 32), _p(q),
+                                        C.c_size_t(len(q)), C.c_size_t(max_k), C.c_float(radius), _p(Tc),
+                                        _p(idx, C.c_int32), _p(d2))
+        if rc != 0:
+            raise RuntimeError("[KDTree::radius_search_async] `max_k` is too large. not support.")
+        return idx, d2
+
+    def kdtree_remove_by_flags(self, nodes, flags, new_idx):
+        flags = np.ascontiguousarray(flags, np.uint8)
+        new_idx = np.ascontiguousarray(new_idx, np.int32)
+        self.lib.orc_kdtree_remove_by_flags(nodes.ctypes.data_as(C.c_void_p), C.c_size_t(len(nodes) // 32),
+                                            _p(flags, C.c_uint8), _p(new_idx, C.c_int32), C.c_size_t(len(flags)))
+
+    # ---- features
+    def cov_estimate(self, pts, idx):
+        pts = _f(pts)
+        idx = np.ascontiguousarray(idx, np.int32)
+        covs = np.empty((len(pts), 16), np.float32)
+        self.lib.orc_cov_estimate(_p(pts), C.c_size_t(len(pts)), _p(idx, C.c_int32), C.c_size_t(idx.shape[1]), _p(covs))
+        return covs
+
+    def normals_from_knn(self, pts, idx):
+        pts = _f(pts)
+        idx = np.ascontiguousarray(idx, np.int32)
+        out = np.empty((len(pts), 4), np.float32)
+        self.lib.orc_normals_from_knn(_p(pts), C.c_size_t(len(pts)), _p(idx, C.c_int32), C.c_size_t(idx.shape[1]), _p(out))
+        return out
+
+    def normals_from_cov(self, pts, covs):
+        pts, covs = _f(pts), _f(covs)
+        out = np.empty((len(pts), 4), np.float32)
+        self.lib.orc_normals_from_cov(_p(pts), _p(covs), C.c_size_t(len(pts)), _p(out))
+        return out
+
+    def update_covariance_plane(self, covs):
+        covs = _f(covs).copy()
+        self.lib.orc_update_covariance_plane(_p(covs), C.c_size_t(len(covs)))
+        return covs
+
+    def normalize_covariance(self, covs):
+        covs = _f(covs).copy()
+        self.lib.orc_normalize_covariance(_p(covs), C.c_size_t(len(covs)))
+        return covs
+
+    def transform_points(self, pts, T):
+        pts = _f(pts)
+        Tc = _f(np.asarray(T).T)
+        out = np.empty_like(pts)
+        self.lib.orc_transform_points(_p(pts), _p(out), C.c_size_t(len(pts)), _p(Tc))
+        return out
+
+    def transform_covs(self, covs, T):
+        covs = _f(covs)
+        Tc = _f(np.asarray(T).T)
+        out = np.empty_like(covs)
+        self.lib.orc_transform_covs(_p(covs), _p(out), C.c_size_t(len(covs)), _p(Tc))
+        return out
+
+    def transform_normals(self, nrm, T):
+        nrm = _f(nrm)
+        Tc = _f(np.asarray(T).T)
+        out = np.empty_like(nrm)
+        self.lib.orc_transform_normals(_p(nrm), _p(out), C.c_size_t(len(nrm)), _p(Tc))
+        return out
+
+    def voxel_keys(self, pts, voxel_size):
+        pts = _f(pts)
+        keys = np.empty(len(pts), np.uint64)
+        self.lib.orc_voxel_keys(_p(pts), C.c_size_t(len(pts)), C.c_float(voxel_size), _p(keys, C.c_uint64))
+        return keys
+
+    def voxel_downsample(self, pts, voxel_size, min_count=1, rgb=None, intensity=None, ts=None, stable=True):
+        pts = _f(pts)
+        n = len(pts)
+        rgb = None if rgb is None else _f(rgb)
+        intensity = None if intensity is None else _f(intensity)
+        ts = None if ts is None else _f(ts)
+        o_p = np.empty((max(n, 1), 4), np.float32)
+        o_c = np.empty((max(n, 1), 4), np.float32)
+        o_i = np.empty(max(n, 1), np.float32)
+        o_t = np.empty(max(n, 1), np.float32)
+        o_k = np.empty(max(n, 1), np.uint64)
+        v = self.lib.orc_voxel_downsample(_p(pts), C.c_size_t(n), C.c_float(voxel_size), C.c_size_t(min_count), _p(rgb),
+                                          _p(intensity), _p(ts), C.c_int(1 if stable else 0), _p(o_p), _p(o_c), _p(o_i),
+                                          _p(o_t), _p(o_k, C.c_uint64))
+        return {"points": o_p[:v].copy(), "rgb": None if rgb is None else o_c[:v].copy(),
+                "intensities": None if intensity is None else o_i[:v].copy(),
+                "timestamps": None if ts is None else o_t[:v].copy(), "keys": o_k[:v].copy()}
+
+    def box_filter(self, pts, min_d, max_d):
+        pts = _f(pts)
+        flags = np.empty(len(pts), np.uint8)
+        self.lib.orc_box_filter(_p(pts), C.c_size_t(len(pts)), C.c_float(min_d), C.c_float(max_d), _p(flags, C.c_uint8))
+        return flags
+
+    # ---- registration
+    def gicp_linearize(self, src, src_cov, tgt, tgt_cov, tgt_nrm, nn_idx, nn_d2, T, max_corr=2.0, reg="GICP",
+                       loss="NONE", robust_scale=10.0, genz_alpha=1.0, per_point=False):
+        src, tgt = _f(src), _f(tgt)
+        src_cov = None if src_cov is None else _f(src_cov)
+        tgt_cov = None if tgt_cov is None else _f(tgt_cov)
+        tgt_nrm = None if tgt_nrm is None else _f(tgt_nrm)
+        nn_idx = np.ascontiguousarray(nn_idx, np.int32).reshape(-1)
+        nn_d2 = _f(nn_d2).reshape(-1)
+        Tc = _f(np.asarray(T).T)
+        out = np.zeros(44, np.float32)
+        pp = np.zeros((len(src), 44), np.float32) if per_point else None
+        self.lib.orc_gicp_linearize(_p(src), _p(src_cov), C.c_size_t(len(src)), _p(tgt), _p(tgt_cov), _p(tgt_nrm),
+                                    _p(nn_idx, C.c_int32), _p(nn_d2), _p(Tc), C.c_float(max_corr), REG[reg], LOSS[loss],
+                                    C.c_float(robust_scale), C.c_float(genz_alpha), _p(out), _p(pp))
+        res = {"H": out[:36].reshape(6, 6).copy(), "b": out[36:42].copy(), "error": float(out[42]),
+               "inlier": int(out[43:44].view(np.uint32)[0])}
+        if per_point:
+            res["per_point"] = pp
+        return res
+
+    def gicp_error(self, src, src_cov, tgt, tgt_cov, tgt_nrm, nn_idx, nn_d2, T, max_corr=2.0, reg="GICP", loss="NONE",
+                   robust_scale=10.0, genz_alpha=1.0):
+        src, tgt = _f(src), _f(tgt)
+        src_cov = None if src_cov is None else _f(src_cov)
+        tgt_cov = None if tgt_cov is None else _f(tgt_cov)
+        tgt_nrm = None if tgt_nrm is None else _f(tgt_nrm)
+        nn_idx = np.ascontiguousarray(nn_idx, np.int32).reshape(-1)
+        nn_d2 = _f(nn_d2).reshape(-1)
+        Tc = _f(np.asarray(T).T)
+        out = np.zeros(2, np.float32)
+        self.lib.orc_gicp_error(_p(src), _p(src_cov), C.c_size_t(len(src)), _p(tgt), _p(tgt_cov), _p(tgt_nrm),
+                                _p(nn_idx, C.c_int32), _p(nn_d2), _p(Tc), C.c_float(max_corr), REG[reg], LOSS[loss],
+                                C.c_float(robust_scale), C.c_float(genz_alpha), _p(out))
+        return float(out[0]), int(out[1:2].view(np.uint32)[0])
+
+    def icp_robust_weights(self, src, src_cov, tgt, tgt_cov, tgt_nrm, nn_idx, nn_d2, T, max_corr=2.0, reg="GICP",
+                           loss="NONE", robust_scale=10.0):
+        src, tgt = _f(src), _f(tgt)
+        src_cov = None if src_cov is None else _f(src_cov)
+        tgt_cov = None if tgt_cov is None else _f(tgt_cov)
+        tgt_nrm = None if tgt_nrm is None else _f(tgt_nrm)
+        nn_idx = np.ascontiguousarray(nn_idx, np.int32).reshape(-1)
+        nn_d2 = _f(nn_d2).reshape(-1)
+        Tc = _f(np.asarray(T).T)
+        out = np.zeros(len(src), np.float32)
+        self.lib.orc_icp_robust_weights(_p(src), _p(src_cov), C.c_size_t(len(src)), _p(tgt), _p(tgt_cov), _p(tgt_nrm),
+                                        _p(nn_idx, C.c_int32), _p(nn_d2), _p(Tc), C.c_float(max_corr), REG[reg],
+                                        LOSS[loss], C.c_float(robust_scale), _p(out))
+        return out
+
+    def registration_align(self, params, src, src_cov, tgt, tgt_cov, tgt_nrm=None, init_T=None, nn_mode="kdtree",
+                           trace=False):
+        src, tgt = _f(src), _f(tgt)
+        src_cov = None if src_cov is None else _f(src_cov)
+        tgt_cov = None if tgt_cov is None else _f(tgt_cov)
+        tgt_nrm = None if tgt_nrm is None else _f(tgt_nrm)
+        Tc = _f(np.eye(4) if init_T is None else np.asarray(init_T).T)
+        res = RegResult()
+        tr = np.zeros((max(params.max_iterations, 1), 16), np.float32) if trace else None
+        trn = C.c_int(0)
+        self.lib.orc_registration_align(C.byref(params), _p(src), _p(src_cov), C.c_size_t(len(src)), _p(tgt), _p(tgt_cov),
+                                        _p(tgt_nrm), C.c_size_t(len(tgt)), _p(Tc), C.c_int(0 if nn_mode == "kdtree" else 1),
+                                        C.byref(res), _p(tr), C.byref(trn))
+        out = {"T": np.array(res.T, np.float32).reshape(4, 4).T.copy(),
+               "H": np.array(res.H, np.float32).reshape(6, 6).T.copy(), "b": np.array(res.b, np.float32),
+               "error": float(res.error), "inlier": int(res.inlier), "iterations": int(res.iterations),
+               "converged": bool(res.converged)}
+        if trace:
+            out["trace"] = np.stack([tr[i].reshape(4, 4).T for i in range(trn.value)]) if trn.value else np.zeros((0, 4, 4))
+        return out
+
+
+class _Rng:
+    def __init__(self, orc, seed):
+        self.orc = orc
+        self.h = C.c_void_p(orc.lib.orc_rng_new(C.c_uint32(seed)))
+
+    def uniform_points(self, n, rng_range):
+        out = np.empty((n, 4), np.float32)
+        self.orc.lib.orc_rng_uniform_points(self.h, C.c_float(rng_range), C.c_size_t(n), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def normal(self, n, stddev):
+        out = np.empty(n, np.float32)
+        self.orc.lib.orc_rng_normal(self.h, C.c_float(stddev), C.c_size_t(n), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def __del__(self):
+        try:
+            self.orc.lib.orc_rng_free(self.h)
+        except Exception:
+            pass
