@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""GICP hot-path benchmark (BASELINE.json: "GICP iterations/sec & correspondences/sec at 1M pts").
+
+A step = one GICP iteration over the rank's source shard: nearest neighbour (k=1, query transformed by the current
+pose) -> K11 linearise + reduce -> [all-reduce of the 176-byte system over ranks] -> 6x6 solve + pose update, all on
+the device with inputs resident in HBM. Steps run in alignments of 20 iterations from the identity initial guess
+(BASELINE config 4: GICP, GN lambda=1, max_corr 2.0, robust NONE, convergence criteria 0).
+N = 1: 1M-vs-1M clouds (config 4). N > 1: config 5 generalised — N x 1M source points tile-sharded 1M per GPU,
+target (N x 1M points, same density) replicated on every GPU: weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel and
+`cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ITERS_PER_ALIGN = 20
+PER_GPU_POINTS = 1_000_000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
+BYTES_NN = 24          # in-loop NN k=1 lower bound (16 B query + 8 B result)
+BYTES_K11 = 168        # K11 per source point at the API layouts
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=PER_GPU_POINTS, help="source points per GPU (default: the config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="points in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import sycl_points_amd.api as sp
+    from sycl_points_amd.synthetic import gicp_pair
+
+    n_gpu = args.points
+    n_total = n_gpu * world
+    rng_range = 10.0 * (n_total / 1e6) ** (1.0 / 3.0)  # config 4 density at every size (R=20 at 8M)
+
+    # ---- untimed set-up: clouds, KD-trees (host build), k=20 covariances (HIP path)
+    t_setup = time.time()
+    src, tgt, T_gt = gicp_pair(n_total, rng_range)
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    Tg = sp.PointCloudShared(to_dev(tgt), device=dev)
+    ttree = sp.KDTree.build(tgt)
+    sp.covariance.estimate(ttree.knn_search(Tg, 20), Tg)
+    lo, hi = rank * n_gpu, (rank + 1) * n_gpu
+    S_all = to_dev(src)
+    stree = sp.KDTree.build(src)
+    S = sp.PointCloudShared(S_all[lo:hi].contiguous(), device=dev)
+    nbr = sp.KNNResult()
+    stree.knn_search_async(S.points, 20, nbr)
+    S.covs = _cov_from(sp, S_all, nbr.indices)  # neighbours are indices into the full source cloud
+    del stree, S_all
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    params = sp.RegistrationParams(reg_type="GICP", optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
+                                   criteria_translation=0.0, criteria_rotation=0.0)
+    reg = sp.Registration(params)
+    T_dev = torch.zeros(16, dtype=torch.float32, device=dev)
+    T_ident = torch.eye(4, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    delta = torch.zeros(8, dtype=torch.float32, device=dev)
+    group = dist.group.WORLD if world > 1 else None
+
+    def run_steps(k):
+        done = 0
+        while done < k:
+            if done % ITERS_PER_ALIGN == 0:
+                T_dev.copy_(T_ident)  # a new alignment starts from the identity initial guess
+            chunk = min(ITERS_PER_ALIGN - done % ITERS_PER_ALIGN, k - done)
+            reg.align_device_loop(S, Tg, ttree, iterations=chunk, group=group, T_dev=T_dev, delta_dev=delta)
+            done += chunk
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- correctness of what was timed: pose after a full alignment vs the ground truth used to make the data
+    T_dev.copy_(T_ident)
+    reg.align_device_loop(S, Tg, ttree, iterations=ITERS_PER_ALIGN, group=group, T_dev=T_dev, delta_dev=delta)
+    torch.cuda.synchronize()
+    T_final = reg.T_from_device(T_dev)
+    lin = reg._read_lin(reg._lin)
+    pose_err = float(np.abs(T_final - T_gt).max())
+
+    # ---- per-kernel durations, measured live with events on the launch stream (same stream torch uses)
+    kern = kernel_times(sp, torch, reg, S, Tg, ttree, T_dev, n_gpu)
+
+    out = None
+    if rank == 0:
+        corr_per_s = n_total * args.steps / elapsed
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        out = {
+            "metric": "gicp_correspondences_per_sec",
+            "value": corr_per_s,
+            "unit": "correspondences/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"GICP {n_total}-vs-{n_total} uniform-random clouds (BASELINE config "
+                                   f"{'4' if world == 1 else '5 generalised'}), k=20 covariances, GN lambda=1, "
+                                   f"max_corr 2.0, robust NONE, {ITERS_PER_ALIGN} iterations per alignment",
+                       "source_points_per_gpu": n_gpu, "target_points": n_total, "nn": "kdtree(k=1)",
+                       "sharding": "source tile-sharded, target replicated" if world > 1 else "none"},
+            "iterations_per_sec": args.steps / elapsed,
+            "pose_max_abs_err_vs_ground_truth": pose_err,
+            "inliers_last_iteration": int(lin.inlier),
+            "setup_s": t_setup,
+            "kernels": kern,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": kern[dom]["bytes"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _cov_from(sp, all_points, idx):
+    """Covariances of the shard's points from neighbours indexed into the full cloud (K5 gathers by index)."""
+    import ctypes as C
+
+    import torch
+
+    from sycl_points_amd import _lib
+
+    n = idx.shape[0]
+    covs = torch.empty((n, 16), dtype=torch.float32, device=idx.device)
+    _lib.check(_lib.lib().sp_cov_estimate(C.c_void_p(all_points.data_ptr()), n, C.c_void_p(idx.data_ptr()),
+                                          idx.shape[1], C.c_void_p(covs.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return covs
+
+
+def kernel_times(sp, torch, reg, S, Tg, ttree, T_dev, n, reps=20):
+    """Average launch duration of the two hot kernels at the converged pose, by HIP events on the launch stream."""
+    res = {}
+    scale = reg.params.robust_default_scale
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_nn = timed(lambda: ttree.nearest_neighbor_search_async(S, reg.neighbors, T_dev))
+    ms_k11 = timed(lambda: reg._linearize("linearize", S, Tg, T_dev, scale, reg._lin))
+    for name, ms, bpp in (("kdtree_search_k1", ms_nn, BYTES_NN), ("gicp_linearize_reduce", ms_k11, BYTES_K11)):
+        res[name] = {"ms": ms, "bytes": bpp * n, "GBps": bpp * n / (ms * 1e-3) / 1e9}
+    return res
+
+
+def cpu_baseline(n_cpu):
+    """The CPU oracle (kind "port": our restatement of the reference's algorithms, OpenMP over points) on a bounded
+    sample of the same workload: n_cpu points at config-4 density, 20 GN iterations, KD-tree NN."""
+    from oracle.pyoracle import Oracle, RegParams
+    from sycl_points_amd.synthetic import gicp_pair
+
+    orc = Oracle()
+    r = 10.0 * (n_cpu / 1e6) ** (1.0 / 3.0)
+    src, tgt, _ = gicp_pair(n_cpu, r)
+    ti, _ = orc.kdtree_knn(orc.kdtree_build(tgt), tgt, 20)
+    si, _ = orc.kdtree_knn(orc.kdtree_build(src), src, 20)
+    scov, tcov = orc.cov_estimate(src, si), orc.cov_estimate(tgt, ti)
+    p = RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=ITERS_PER_ALIGN)
+    orc.registration_align(p, src[:2000], scov[:2000], tgt, tcov)  # warm-up
+    t0 = time.perf_counter()
+    runs = 0
+    while True:
+        orc.registration_align(p, src, scov, tgt, tcov)
+        runs += 1
+        if time.perf_counter() - t0 > 10.0 or runs >= 5:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_cpu * ITERS_PER_ALIGN * runs / dt, "unit": "correspondences/s", "cores": orc.num_threads(),
+            "kind": "port",
+            "sample": f"{runs} alignments x {ITERS_PER_ALIGN} iterations of GICP {n_cpu}-vs-{n_cpu} (config-4 density, "
+                      f"KD-tree NN incl. per-alignment tree build), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+/*
+ * sycl_points_amd — C ABI of the MI355X (gfx950) hot path.
+ *
+ * The reference (fateshelled/sycl_points) is a header-only C++/SYCL library with no C ABI: its device code is
+ * reached through C++ templates. This header is the boundary a maintainer would bind instead of
+ * those SYCL kernels; every entry point cites the reference interface it replaces
+ * (paths relative to /root/reference/cpp/include/sycl_points/).
+ *
+ * Conventions
+ *  - all array pointers are DEVICE pointers (HBM) unless the parameter name ends in `_host`;
+ *  - points / normals are float[4] (x,y,z,w), covariances are float[16] column-major 4x4 with the 3x3 block used
+ *    (Eigen::Vector4f / Eigen::Matrix4f storage, points/types.hpp:11-18); entries outside the 3x3 block are
+ *    written as 0 and ignored on input; transforms are float[16] column-major (Eigen::Matrix4f::data());
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t, may be NULL for the default stream) and returns
+ *    immediately; no call allocates or synchronises unless its comment says so, so a sequence of calls can be
+ *    captured into a hipGraph;
+ *  - return value: SP_OK, or an error code whose meaning mirrors the C++ exception the reference would throw;
+ *    sp_last_error() returns the message (thread local).
+ */
+#ifndef SYCL_POINTS_AMD_H
+#define SYCL_POINTS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_ERR_INVALID_ARGUMENT 1 /* reference: std::invalid_argument */
+#define SP_ERR_RUNTIME 2          /* reference: std::runtime_error    */
+#define SP_ERR_HIP 3              /* reference: sycl::exception from wait_and_throw */
+
+#define SP_ABI_VERSION 1
+int sp_abi_version(void);
+const char* sp_last_error(void);
+
+/* Number of devices visible / select the device for the calling thread (utils/sycl_utils.hpp:398-465). */
+int sp_device_count(void);
+int sp_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------------ KNN */
+
+/* Brute-force kNN (algorithms/knn/bruteforce.hpp:24-96, kernel K1).
+ * Exact; k <= 20 (SP_ERR_INVALID_ARGUMENT otherwise — the reference has no check and overruns its arrays);
+ * strict '<' so the lowest target index wins ties; rows ascending by squared distance, padded with -1 / FLT_MAX.
+ * workspace: sp_knn_bruteforce_workspace_bytes(nq, nt, k) bytes. */
+size_t sp_knn_bruteforce_workspace_bytes(size_t nq, size_t nt, size_t k);
+int sp_knn_bruteforce(const float* queries, size_t nq, const float* targets, size_t nt, size_t k, int32_t* idx_out,
+                      float* d2_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* KD-tree (algorithms/knn/kdtree.hpp:142-766).
+ * sp_kdtree_create: KDTree::build (kdtree.hpp:165-178, 292-413) — host median-split build from HOST points
+ *   (same split rule, same std::nth_element, so the same topology as the reference), then upload. Allocates and
+ *   synchronises. leaf_threshold default in the reference is 16.
+ * sp_kdtree_search: KDTree::knn_search_async (kdtree.hpp:203-224, 424-562, kernel K2): neighbours of transT*q,
+ *   traversal order, tie rule (first visited wins) and the 16-entry far stack of the reference;
+ *   k <= 100 else SP_ERR_RUNTIME ("`k` is too large", kdtree.hpp:221-223).
+ * sp_kdtree_radius_search: KDTree::radius_search_async (kdtree.hpp:251-280, 574-719, kernel K3).
+ * sp_kdtree_remove_by_flags: KDTree::remove_nodes_by_flags (kdtree.hpp:282-284, 721-765, kernel K4);
+ *   flags 1 = keep, 0 = remove; new_indices[p] must be >= 0 for kept points (filter_by_flags.hpp:97-99). */
+typedef struct sp_kdtree sp_kdtree;
+int sp_kdtree_create(const float* points_host, size_t n, size_t leaf_threshold, void* stream, sp_kdtree** out);
+void sp_kdtree_destroy(sp_kdtree* tree);
+size_t sp_kdtree_size(const sp_kdtree* tree); /* number of points */
+int sp_kdtree_search(const sp_kdtree* tree, const float* queries, size_t nq, size_t k, const float* transT,
+                     int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
+int sp_kdtree_radius_search(const sp_kdtree* tree, const float* queries, size_t nq, size_t max_k, float radius,
+                            const float* transT, int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
+int sp_kdtree_remove_by_flags(sp_kdtree* tree, const uint8_t* flags, const int32_t* new_indices, size_t n_flags,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------ covariance / normals */
+
+/* covariance::estimate_async (algorithms/feature/covariance.hpp:16-47, 260-311, kernel K5). */
+int sp_cov_estimate(const float* points, size_t n, const int32_t* knn_idx, size_t k, float* covs_out, void* stream);
+/* covariance::estimate_normals_async (covariance.hpp:49-65, 417-459, kernel K6). */
+int sp_normals_from_knn(const float* points, size_t n, const int32_t* knn_idx, size_t k, float* normals_out,
+                        void* stream);
+/* covariance::extract_normals_async (covariance.hpp:465-503, kernel K7). */
+int sp_normals_from_cov(const float* points, const float* covs, size_t n, float* normals_out, void* stream);
+/* covariance::kernel::update_covariance_plane applied to a whole array (covariance.hpp:67-74); in place allowed. */
+int sp_cov_update_plane(const float* covs, size_t n, float* covs_out, void* stream);
+
+/* --------------------------------------------------------------------------------------- voxel grid */
+
+/* filter::kernel::compute_voxel_bit (algorithms/common/voxel_constants.hpp:36-62, kernel K9).
+ * inv_voxel_size is 1.0f / voxel_size computed once on the host (filter/voxel_downsampling.hpp:27). */
+int sp_voxel_keys(const float* points, size_t n, float inv_voxel_size, uint64_t* keys_out, void* stream);
+
+/* VoxelGrid::downsampling (filter/voxel_downsampling.hpp:50-79, 146-288): per-voxel mean of the points (and of rgb
+ * and timestamps, median of intensities, when those attribute pointers are non-NULL), voxels with
+ * point_sum.w < min_voxel_count dropped, output in ascending key order. The host std::sort + sequential
+ * run-length mean of the reference is replaced by a device radix sort of (key, index) and a segmented reduction;
+ * within a voxel points are summed in ascending index order (the reference's order is unspecified: its sort is
+ * unstable). *n_out_dev (a device uint32) receives the voxel count; out arrays must hold n entries.
+ * workspace: sp_voxel_downsample_workspace_bytes(n) bytes. */
+size_t sp_voxel_downsample_workspace_bytes(size_t n);
+int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
+                        const float* rgb, const float* intensities, const float* timestamps, float* points_out,
+                        float* rgb_out, float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt,
+                        uint32_t* n_out_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------- transform */
+
+/* transform::transform_async (algorithms/common/transform.hpp:14-37, 45-94, kernel K14); in place allowed;
+ * covs / normals may be NULL. */
+int sp_transform(const float* points, const float* covs, const float* normals, size_t n, const float* transT_host,
+                 float* points_out, float* covs_out, float* normals_out, void* stream);
+
+/* BoxFilterOperator kernel (filter/preprocess_operator/box_filter_operator.hpp:36-44, common.hpp:15-25, K10):
+ * flags_out[i] = 1 keep / 0 remove. */
+int sp_box_filter_flags(const float* points, size_t n, float min_distance, float max_distance, uint8_t* flags_out,
+                        void* stream);
+/* FilterByFlags (algorithms/common/filter_by_flags.hpp:30-57, 87-99) on the device: stable compaction of rows of
+ * `row_bytes` bytes; new_indices_out_opt[i] = new index or -1; *n_out_dev = kept count.
+ * workspace: sp_compact_workspace_bytes(n). */
+size_t sp_compact_workspace_bytes(size_t n);
+int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes, const uint8_t* flags, void* rows_out,
+                        int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------- registration */
+
+/* RegType (algorithms/registration/factor.hpp:18-32) and RobustLossType (algorithms/robust/robust.hpp:13-19). */
+enum { SP_REG_POINT_TO_POINT = 0, SP_REG_POINT_TO_PLANE = 1, SP_REG_POINT_TO_DISTRIBUTION = 2, SP_REG_GICP = 3,
+       SP_REG_GENZ = 4 };
+enum { SP_LOSS_NONE = 0, SP_LOSS_HUBER = 1, SP_LOSS_TUKEY = 2, SP_LOSS_CAUCHY = 3, SP_LOSS_GEMAN_MCCLURE = 4 };
+
+/* The reduced linear system, the 176 bytes the reference keeps in LinearizedDevice
+ * (algorithms/registration/registration.hpp:26-84): H row-major, b, error, inlier count.
+ * inlier_lo/inlier_hi carry the same count as two exactly-representable floats (count = hi*4096 + lo) so that a
+ * float sum all-reduce over ranks stays exact. */
+typedef struct sp_linearized {
+    float H[36];
+    float b[6];
+    float error;
+    uint32_t inlier;
+    float inlier_lo;
+    float inlier_hi;
+    float pad[2];
+} sp_linearized; /* 192 bytes */
+
+typedef struct sp_factor_params { /* RegistrationFactorParams, registration_params.hpp:46-71 */
+    int reg_type;
+    int robust_type;
+    float max_correspondence_distance;
+    float robust_scale;
+    float genz_alpha;               /* Registration::genz_alpha_ (registration.hpp:370,519) */
+    float genz_planarity_threshold; /* registration_params.hpp:52-54 */
+} sp_factor_params;
+
+/* Registration::linearize_parallel_reduction_async (registration.hpp:513-664, kernel K11): for every source point
+ * whose neighbour distance nn_d2 <= max_corr^2, linearise the factor (factor.hpp:69-449), apply the robust weight
+ * (robust.hpp:56-114) and sum H, b, error, inlier count into *out. src_covs / tgt_covs / tgt_normals may be NULL
+ * where the reg_type does not need them (registration.hpp:539-543: Identity / Zero are substituted).
+ * transT: current pose, host or device (transT_on_device). workspace: sp_gicp_workspace_bytes(n).
+ * The reduction is a fixed tree: two runs on the same inputs give bit-identical sums. */
+size_t sp_gicp_workspace_bytes(size_t n);
+int sp_gicp_linearize(const float* src_points, const float* src_covs, size_t n, const float* tgt_points,
+                      const float* tgt_covs, const float* tgt_normals, const int32_t* nn_idx, const float* nn_d2,
+                      const float* transT, int transT_on_device, const sp_factor_params* params, sp_linearized* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Registration::compute_error_parallel_reduction (registration.hpp:678-777, kernel K12): out->error, out->inlier. */
+int sp_gicp_error(const float* src_points, const float* src_covs, size_t n, const float* tgt_points,
+                  const float* tgt_covs, const float* tgt_normals, const int32_t* nn_idx, const float* nn_d2,
+                  const float* transT, int transT_on_device, const sp_factor_params* params, sp_linearized* out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* Registration::compute_icp_robust_weights_async (registration.hpp:412-462, kernel K13). */
+int sp_icp_robust_weights(const float* src_points, const float* src_covs, size_t n, const float* tgt_points,
+                          const float* tgt_covs, const float* tgt_normals, const int32_t* nn_idx, const float* nn_d2,
+                          const float* transT, int transT_on_device, const sp_factor_params* params,
+                          float* weights_out, void* stream);
+/* Registration::compute_genz_alpha (registration.hpp:464-511): writes {inlier, planar} counts to counts_out[2]. */
+int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn_d2, size_t n, float max_corr,
+                   float planarity_threshold, uint32_t* counts_out, void* stream);
+
+/* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
+ * iteration loop can stay on the stream with no host round trip:
+ *   delta = LDLT(H + lambda*I).solve(-b);  T <- T * se3_exp(delta);  delta_out[0..5] = delta,
+ *   delta_out[6] = 1.0f if converged (|rot| < crit_rot && |trans| < crit_trans) else 0, delta_out[7] = solve ok.
+ * lin->inlier_lo/hi (possibly summed over ranks) are folded back into lin->inlier. T_dev is updated in place. */
+int sp_gn_update(sp_linearized* lin, float* T_dev, float lambda, float crit_rotation, float crit_translation,
+                 float* delta_out8, void* stream);
+/* Host twin of the same arithmetic, for a host-driven loop (reads/writes HOST memory, no stream). */
+int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, float lambda, float crit_rotation,
+                      float crit_translation, float* delta_out8_host);
+/* lie::se3_exp (utils/eigen_utils.hpp:909-943) and the Isometry3f product used for T <- T*exp(delta), on the host. */
+void sp_se3_exp_host(const float* twist6, float* T_out16);
+void sp_rigid_mul_host(const float* A16, const float* B16, float* out16);
+int sp_ldlt6_solve_host(const float* H36_rowmajor, const float* rhs6, float* x6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYCL_POINTS_AMD_H */

@@ -1,0 +1,114 @@
+"""ctypes loader for libsycl_points_amd.so (the C ABI declared in include/sycl_points_amd.h).
+
+The product path has no CPU fallback: if the library is missing this module raises, loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsycl_points_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SP_OK, SP_ERR_INVALID_ARGUMENT, SP_ERR_RUNTIME, SP_ERR_HIP = 0, 1, 2, 3
+
+
+class SpError(RuntimeError):
+    """Mirrors the C++ exceptions of the reference: code 1 -> std::invalid_argument, 2 -> std::runtime_error,
+    3 -> device error (sycl::exception from wait_and_throw)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[sycl_points_amd] error {code}: {msg}")
+        self.code = code
+
+
+class Linearized(C.Structure):  # sp_linearized
+    _fields_ = [("H", C.c_float * 36), ("b", C.c_float * 6), ("error", C.c_float), ("inlier", C.c_uint32),
+                ("inlier_lo", C.c_float), ("inlier_hi", C.c_float), ("pad", C.c_float * 2)]
+
+
+class FactorParams(C.Structure):  # sp_factor_params
+    _fields_ = [("reg_type", C.c_int), ("robust_type", C.c_int), ("max_correspondence_distance", C.c_float),
+                ("robust_scale", C.c_float), ("genz_alpha", C.c_float), ("genz_planarity_threshold", C.c_float)]
+
+
+assert C.sizeof(Linearized) == 192
+
+_vp, _sz, _f, _i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
+
+# name -> (restype, argtypes); every symbol include/sycl_points_amd.h declares
+SIGNATURES = {
+    "sp_abi_version": (_i, []),
+    "sp_last_error": (C.c_char_p, []),
+    "sp_device_count": (_i, []),
+    "sp_set_device": (_i, [_i]),
+    "sp_knn_bruteforce_workspace_bytes": (_sz, [_sz, _sz, _sz]),
+    "sp_knn_bruteforce": (_i, [_vp, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp]),
+    "sp_kdtree_create": (_i, [_vp, _sz, _sz, _vp, C.POINTER(_vp)]),
+    "sp_kdtree_destroy": (None, [_vp]),
+    "sp_kdtree_size": (_sz, [_vp]),
+    "sp_kdtree_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
+    "sp_kdtree_radius_search": (_i, [_vp, _vp, _sz, _sz, _f, _vp, _i, _vp, _vp, _vp]),
+    "sp_kdtree_remove_by_flags": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "sp_cov_estimate": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "sp_normals_from_knn": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "sp_normals_from_cov": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "sp_cov_update_plane": (_i, [_vp, _sz, _vp, _vp]),
+    "sp_voxel_keys": (_i, [_vp, _sz, _f, _vp, _vp]),
+    "sp_voxel_downsample_workspace_bytes": (_sz, [_sz]),
+    "sp_voxel_downsample": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_transform": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sp_box_filter_flags": (_i, [_vp, _sz, _f, _f, _vp, _vp]),
+    "sp_compact_workspace_bytes": (_sz, [_sz]),
+    "sp_compact_by_flags": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_gicp_workspace_bytes": (_sz, [_sz]),
+    "sp_gicp_linearize": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _sz, _vp]),
+    "sp_gicp_error": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _sz, _vp]),
+    "sp_icp_robust_weights": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp]),
+    "sp_genz_counts": (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp, _vp]),
+    "sp_gn_update": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp]),
+    "sp_gn_update_host": (_i, [_vp, _vp, _f, _f, _f, _vp]),
+    "sp_se3_exp_host": (None, [_vp, _vp]),
+    "sp_rigid_mul_host": (None, [_vp, _vp, _vp]),
+    "sp_ldlt6_solve_host": (_i, [_vp, _vp, _vp]),
+}
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into sycl_points_amd/lib/libsycl_points_amd.so (hipcc cross-compiles
+    without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "sycl_points_amd.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j8", "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library with typed entry points. torch must be imported first so that its bundled HIP runtime
+    (same SONAME, libamdhip64.so.7) is the one both sides share."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the HIP path)")
+        import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
+
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.sp_abi_version() != 1:
+            raise ImportError("libsycl_points_amd.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != SP_OK:
+        raise SpError(code, lib().sp_last_error().decode())

@@ -1,0 +1,637 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (paths relative to
+/root/reference/cpp/include/sycl_points/): PointCloudShared (points/point_cloud.hpp:73-476), KNNResult
+(algorithms/knn/result.hpp), KNNBase / KDTree / knn_search_bruteforce (algorithms/knn/), covariance::estimate*
+(algorithms/feature/covariance.hpp), VoxelGrid (algorithms/filter/voxel_downsampling.hpp), Registration
+(algorithms/registration/registration.hpp). Every array is a torch CUDA tensor resident in HBM; torch is used for
+device memory, streams and torch.distributed only — all compute goes through libsycl_points_amd.so.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FactorParams, Linearized, SpError, check
+
+REG = {"POINT_TO_POINT": 0, "POINT_TO_PLANE": 1, "POINT_TO_DISTRIBUTION": 2, "GICP": 3, "GENZ": 4}
+LOSS = {"NONE": 0, "HUBER": 1, "TUKEY": 2, "CAUCHY": 3, "GEMAN_MCCLURE": 4}
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, cols=None):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise SpError(1, "expected a contiguous float32 CUDA tensor")
+    if cols is not None and (t.dim() != 2 or t.shape[1] != cols):
+        raise SpError(1, f"expected shape (N, {cols}), got {tuple(t.shape)}")
+    return t
+
+
+def _T16(T):
+    """4x4 (row-major numpy / torch CPU) -> 16 floats column-major (Eigen::Matrix4f::data())."""
+    a = np.ascontiguousarray(np.asarray(T, dtype=np.float32).T)
+    return a
+
+
+def identity():
+    return np.eye(4, dtype=np.float32)
+
+
+class PointCloudShared:
+    """points/point_cloud.hpp:73-476 — attribute containers resident in HBM. covs are (N,16) column-major 4x4."""
+
+    def __init__(self, points=None, covs=None, normals=None, rgb=None, intensities=None, timestamp_offsets=None,
+                 device="cuda"):
+        self.device = torch.device(device)
+        self.points = points if points is not None else torch.empty((0, 4), dtype=torch.float32, device=self.device)
+        self.covs = covs
+        self.normals = normals
+        self.rgb = rgb
+        self.intensities = intensities
+        self.timestamp_offsets = timestamp_offsets
+
+    @staticmethod
+    def from_numpy(points, device="cuda", **attrs):
+        pc = PointCloudShared(torch.from_numpy(np.ascontiguousarray(points, np.float32)).to(device), device=device)
+        for k, v in attrs.items():
+            if v is not None:
+                setattr(pc, k, torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(device))
+        return pc
+
+    def size(self):
+        return int(self.points.shape[0])
+
+    def has_cov(self):
+        return self.covs is not None and self.covs.shape[0] == self.points.shape[0]
+
+    def has_normal(self):
+        return self.normals is not None and self.normals.shape[0] == self.points.shape[0]
+
+    def has_rgb(self):
+        return self.rgb is not None and self.rgb.shape[0] == self.points.shape[0]
+
+    def has_intensity(self):
+        return self.intensities is not None and self.intensities.shape[0] == self.points.shape[0]
+
+    def has_timestamps(self):
+        return (self.timestamp_offsets is not None and self.timestamp_offsets.shape[0] == self.points.shape[0]
+                and self.points.shape[0] > 0)
+
+
+@dataclass
+class KNNResult:
+    """algorithms/knn/result.hpp:12-34 — row-major (query_size, k), squared distances, -1 / FLT_MAX padding."""
+    indices: torch.Tensor = None
+    distances: torch.Tensor = None
+    query_size: int = 0
+    k: int = 0
+
+    def allocate(self, query_size, k, device="cuda"):
+        self.query_size, self.k = query_size, k
+        self.indices = torch.full((query_size, k), -1, dtype=torch.int32, device=device)
+        self.distances = torch.full((query_size, k), FLT_MAX, dtype=torch.float32, device=device)
+
+    def resize(self, query_size, k, device="cuda"):
+        """result.resize(query_size, k) (result.hpp:28-33); reallocates only when the shape changes."""
+        if self.indices is None or tuple(self.indices.shape) != (query_size, k) or self.indices.device != torch.device(device):
+            self.allocate(query_size, k, device)
+        self.query_size, self.k = query_size, k
+
+
+def _points_of(q):
+    return q.points if isinstance(q, PointCloudShared) else q
+
+
+def knn_search_bruteforce(queries, targets, k):
+    """algorithms/knn/bruteforce.hpp:24-96 (synchronous in the reference; here enqueued on the current stream)."""
+    q = _dev_f32(_points_of(queries), 4)
+    t = _dev_f32(_points_of(targets), 4)
+    L = _lib.lib()
+    res = KNNResult()
+    res.allocate(q.shape[0], k, q.device)
+    nbytes = L.sp_knn_bruteforce_workspace_bytes(q.shape[0], t.shape[0], k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=q.device)
+    check(L.sp_knn_bruteforce(_ptr(q), q.shape[0], _ptr(t), t.shape[0], k, _ptr(res.indices), _ptr(res.distances),
+                              _ptr(ws), nbytes, _stream()))
+    return res
+
+
+class KNNBase:
+    """algorithms/knn/knn.hpp:14-61 — the operator boundary Registration::align sits on."""
+
+    def knn_search_async(self, queries, k, result, transT=None):
+        raise NotImplementedError
+
+    def knn_search(self, queries, k, transT=None):
+        r = KNNResult()
+        self.knn_search_async(queries, k, r, transT)
+        torch.cuda.current_stream().synchronize()
+        return r
+
+    def nearest_neighbor_search_async(self, queries, result, transT=None):
+        return self.knn_search_async(queries, 1, result, transT)
+
+    def nearest_neighbor_search(self, queries, result, transT=None):
+        self.nearest_neighbor_search_async(queries, result, transT)
+        torch.cuda.current_stream().synchronize()
+
+
+def _trans_arg(transT):
+    """-> (pointer, on_device flag, keepalive). Accepts None, a 4x4 host matrix, or a 16-float CUDA tensor
+    (column-major) for device-resident loops."""
+    if transT is None:
+        return None, 0, None
+    if isinstance(transT, torch.Tensor) and transT.is_cuda:
+        if transT.numel() != 16 or transT.dtype != torch.float32:
+            raise SpError(1, "device transT must be 16 float32 (column-major)")
+        return _ptr(transT), 1, transT
+    a = _T16(transT.cpu().numpy() if isinstance(transT, torch.Tensor) else transT)
+    return a.ctypes.data_as(C.c_void_p), 0, a
+
+
+class KDTree(KNNBase):
+    """algorithms/knn/kdtree.hpp:142-766."""
+
+    def __init__(self, handle, n, device):
+        self._h = handle
+        self.n = n
+        self.device = device
+
+    @staticmethod
+    def build(points, leaf_threshold=16):
+        p = _points_of(points)
+        host = np.ascontiguousarray(p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else p, np.float32)
+        dev = p.device if isinstance(p, torch.Tensor) and p.is_cuda else torch.device("cuda")
+        h = C.c_void_p()
+        check(_lib.lib().sp_kdtree_create(host.ctypes.data_as(C.c_void_p), host.shape[0], leaf_threshold, _stream(),
+                                          C.byref(h)))
+        return KDTree(h, host.shape[0], dev)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_kdtree_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def knn_search_async(self, queries, k, result, transT=None):
+        q = _dev_f32(_points_of(queries), 4)
+        if k > 100:
+            raise SpError(2, "[KDTree::knn_search_async] `k` is too large. not support.")
+        result.resize(q.shape[0], k, q.device)
+        if q.shape[0] == 0:
+            return
+        tp, on_dev, keep = _trans_arg(transT)
+        check(_lib.lib().sp_kdtree_search(self._h, _ptr(q), q.shape[0], k, tp, on_dev, _ptr(result.indices),
+                                          _ptr(result.distances), _stream()))
+
+    def radius_search_async(self, queries, max_k, radius, result, transT=None):
+        q = _dev_f32(_points_of(queries), 4)
+        if max_k > 100:
+            raise SpError(2, "[KDTree::radius_search_async] `max_k` is too large. not support.")
+        if q.shape[0] == 0 or max_k == 0:
+            result.resize(0, 0, q.device)
+            return
+        result.resize(q.shape[0], max_k, q.device)
+        tp, on_dev, keep = _trans_arg(transT)
+        check(_lib.lib().sp_kdtree_radius_search(self._h, _ptr(q), q.shape[0], max_k, radius, tp, on_dev,
+                                                 _ptr(result.indices), _ptr(result.distances), _stream()))
+
+    def remove_nodes_by_flags(self, flags, indices):
+        if flags.shape[0] != indices.shape[0]:
+            raise SpError(2, "[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.")
+        check(_lib.lib().sp_kdtree_remove_by_flags(self._h, _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
+        torch.cuda.current_stream().synchronize()
+
+
+class BruteForceKNN(KNNBase):
+    """A KNNBase over knn_search_bruteforce (the reference tests inject such host fakes through the same seam,
+    tests/test_registration_pipeline.cpp:16-61). The query transform is applied with sp_transform first."""
+
+    def __init__(self, targets):
+        self.targets = _dev_f32(_points_of(targets), 4)
+
+    def knn_search_async(self, queries, k, result, transT=None):
+        q = _dev_f32(_points_of(queries), 4)
+        if transT is not None:
+            if isinstance(transT, torch.Tensor) and transT.is_cuda:
+                transT = transT.cpu().numpy().reshape(4, 4).T
+            q = transform_points(q, transT)
+        r = knn_search_bruteforce(q, self.targets, k)
+        result.indices, result.distances, result.query_size, result.k = r.indices, r.distances, r.query_size, r.k
+
+
+# ------------------------------------------------------------------ covariance / normals
+class covariance:
+    """algorithms/feature/covariance.hpp"""
+
+    @staticmethod
+    def estimate(neighbors, points):
+        """estimate_async (covariance.hpp:260-311): returns (N,16) column-major covariances."""
+        p = _dev_f32(_points_of(points), 4)
+        idx = neighbors.indices if isinstance(neighbors, KNNResult) else neighbors
+        covs = torch.empty((p.shape[0], 16), dtype=torch.float32, device=p.device)
+        check(_lib.lib().sp_cov_estimate(_ptr(p), p.shape[0], _ptr(idx), idx.shape[1] if idx.dim() == 2 else 0,
+                                         _ptr(covs), _stream()))
+        if isinstance(points, PointCloudShared):
+            points.covs = covs
+        return covs
+
+    @staticmethod
+    def estimate_normals(neighbors, points):
+        """estimate_normals_async (covariance.hpp:417-459)"""
+        p = _dev_f32(_points_of(points), 4)
+        idx = neighbors.indices if isinstance(neighbors, KNNResult) else neighbors
+        nrm = torch.empty((p.shape[0], 4), dtype=torch.float32, device=p.device)
+        check(_lib.lib().sp_normals_from_knn(_ptr(p), p.shape[0], _ptr(idx), idx.shape[1], _ptr(nrm), _stream()))
+        if isinstance(points, PointCloudShared):
+            points.normals = nrm
+        return nrm
+
+    @staticmethod
+    def extract_normals(points, covs=None):
+        """extract_normals_async (covariance.hpp:465-503)"""
+        p = _dev_f32(_points_of(points), 4)
+        c = covs if covs is not None else (points.covs if isinstance(points, PointCloudShared) else None)
+        if c is None:
+            raise SpError(2, "[covariance::extract_normals_async] covariances not computed")
+        nrm = torch.empty((p.shape[0], 4), dtype=torch.float32, device=p.device)
+        check(_lib.lib().sp_normals_from_cov(_ptr(p), _ptr(c), p.shape[0], _ptr(nrm), _stream()))
+        if isinstance(points, PointCloudShared):
+            points.normals = nrm
+        return nrm
+
+    @staticmethod
+    def update_covariance_plane(covs):
+        """kernel::update_covariance_plane over an array (covariance.hpp:67-74)"""
+        out = torch.empty_like(covs)
+        check(_lib.lib().sp_cov_update_plane(_ptr(covs), covs.shape[0], _ptr(out), _stream()))
+        return out
+
+
+# ------------------------------------------------------------------ voxel grid
+class VoxelGrid:
+    """algorithms/filter/voxel_downsampling.hpp:14-289"""
+
+    def __init__(self, voxel_size):
+        if voxel_size <= 0.0:
+            raise SpError(1, "voxel_size must be positive")
+        self.voxel_size = float(voxel_size)
+        self.voxel_size_inv = float(np.float32(1.0) / np.float32(voxel_size))  # voxel_downsampling.hpp:27
+        self.min_voxel_count = 1
+
+    def set_voxel_size(self, voxel_size):
+        if voxel_size <= 0.0:
+            raise SpError(1, "voxel_size must be positive")
+        self.voxel_size = float(voxel_size)
+        self.voxel_size_inv = float(np.float32(1.0) / np.float32(voxel_size))
+
+    def get_voxel_size(self):
+        return self.voxel_size
+
+    def set_min_voxel_count(self, n):
+        self.min_voxel_count = int(n)
+
+    def compute_voxel_bit(self, points):
+        p = _dev_f32(_points_of(points), 4)
+        keys = torch.empty(p.shape[0], dtype=torch.int64, device=p.device)  # bit pattern of the uint64 keys
+        check(_lib.lib().sp_voxel_keys(_ptr(p), p.shape[0], self.voxel_size_inv, _ptr(keys), _stream()))
+        return keys
+
+    def downsampling(self, cloud, return_keys=False):
+        """downsampling(cloud, result) (voxel_downsampling.hpp:64-79). Synchronises once to read the voxel count,
+        as the reference's host aggregation does."""
+        pc = cloud if isinstance(cloud, PointCloudShared) else PointCloudShared(cloud)
+        p = _dev_f32(pc.points, 4)
+        n = p.shape[0]
+        out = PointCloudShared(device=p.device)
+        if n == 0:
+            return (out, torch.empty(0, dtype=torch.int64, device=p.device)) if return_keys else out
+        L = _lib.lib()
+        nbytes = L.sp_voxel_downsample_workspace_bytes(n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+        o_p = torch.empty((n, 4), dtype=torch.float32, device=p.device)
+        rgb = pc.rgb if pc.has_rgb() else None
+        inten = pc.intensities if pc.has_intensity() else None
+        ts = pc.timestamp_offsets if pc.has_timestamps() else None
+        o_c = torch.empty((n, 4), dtype=torch.float32, device=p.device) if rgb is not None else None
+        o_i = torch.empty(n, dtype=torch.float32, device=p.device) if inten is not None else None
+        o_t = torch.empty(n, dtype=torch.float32, device=p.device) if ts is not None else None
+        o_k = torch.empty(n, dtype=torch.int64, device=p.device) if return_keys else None
+        n_out = torch.zeros(1, dtype=torch.int32, device=p.device)
+        check(L.sp_voxel_downsample(_ptr(p), n, self.voxel_size_inv, self.min_voxel_count, _ptr(rgb), _ptr(inten),
+                                    _ptr(ts), _ptr(o_p), _ptr(o_c), _ptr(o_i), _ptr(o_t), _ptr(o_k), _ptr(n_out),
+                                    _ptr(ws), nbytes, _stream()))
+        v = int(n_out.item())
+        out.points = o_p[:v]
+        out.rgb = None if o_c is None else o_c[:v]
+        out.intensities = None if o_i is None else o_i[:v]
+        out.timestamp_offsets = None if o_t is None else o_t[:v]
+        return (out, o_k[:v]) if return_keys else out
+
+
+# ------------------------------------------------------------------ transform / filters
+def transform_points(points, T):
+    p = _dev_f32(points, 4)
+    out = torch.empty_like(p)
+    a = _T16(T)
+    check(_lib.lib().sp_transform(_ptr(p), None, None, p.shape[0], a.ctypes.data_as(C.c_void_p), _ptr(out), None, None,
+                                  _stream()))
+    return out
+
+
+def transform(cloud, T):
+    """transform::transform (common/transform.hpp:45-101), in place on the cloud's attributes."""
+    a = _T16(T)
+    n = cloud.size()
+    covs = cloud.covs if cloud.has_cov() else None
+    nrm = cloud.normals if cloud.has_normal() else None
+    check(_lib.lib().sp_transform(_ptr(cloud.points), _ptr(covs), _ptr(nrm), n, a.ctypes.data_as(C.c_void_p),
+                                  _ptr(cloud.points), _ptr(covs), _ptr(nrm), _stream()))
+    return cloud
+
+
+def transform_copy(cloud, T):
+    out = PointCloudShared(cloud.points.clone(), None if cloud.covs is None else cloud.covs.clone(),
+                           None if cloud.normals is None else cloud.normals.clone(), cloud.rgb, cloud.intensities,
+                           cloud.timestamp_offsets, device=cloud.points.device)
+    return transform(out, T)
+
+
+def box_filter_flags(points, min_distance, max_distance):
+    p = _dev_f32(_points_of(points), 4)
+    flags = torch.empty(p.shape[0], dtype=torch.uint8, device=p.device)
+    check(_lib.lib().sp_box_filter_flags(_ptr(p), p.shape[0], min_distance, max_distance, _ptr(flags), _stream()))
+    return flags
+
+
+def compact_by_flags(rows, flags, want_indices=False):
+    """FilterByFlags::filter_by_flags / calculate_indices (common/filter_by_flags.hpp:30-99) on the device."""
+    L = _lib.lib()
+    n = rows.shape[0]
+    row_bytes = rows.element_size() * (rows.numel() // max(n, 1)) if n else 4
+    out = torch.empty_like(rows)
+    idx = torch.empty(n, dtype=torch.int32, device=rows.device) if want_indices else None
+    n_out = torch.zeros(1, dtype=torch.int32, device=rows.device)
+    nbytes = L.sp_compact_workspace_bytes(n)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=rows.device)
+    check(L.sp_compact_by_flags(_ptr(rows), n, row_bytes, _ptr(flags), _ptr(out), _ptr(idx), _ptr(n_out), _ptr(ws),
+                                nbytes, _stream()))
+    v = int(n_out.item())
+    return (out[:v], idx) if want_indices else out[:v]
+
+
+# ------------------------------------------------------------------ registration
+@dataclass
+class RegistrationParams:
+    """registration_params.hpp:46-114 (defaults copied from there)."""
+    reg_type: str = "GICP"
+    max_correspondence_distance: float = 2.0
+    robust_type: str = "NONE"
+    robust_default_scale: float = 10.0
+    genz_planarity_threshold: float = 0.2
+    optimization_method: str = "GN"  # GN | LM
+    gn_lambda: float = 1.0
+    lm_max_inner_iterations: int = 10
+    lm_lambda_factor: float = 2.0
+    lm_init_lambda: float = 1.0
+    lm_max_lambda: float = 1e3
+    lm_min_lambda: float = 1e-6
+    max_iterations: int = 20
+    criteria_translation: float = 1e-3
+    criteria_rotation: float = 1e-3
+    verbose: bool = False
+
+
+@dataclass
+class RegistrationResult:
+    """result.hpp:12-28"""
+    T: np.ndarray = field(default_factory=identity)
+    converged: bool = False
+    iterations: int = 0
+    H: np.ndarray = field(default_factory=lambda: np.zeros((6, 6), np.float32))
+    b: np.ndarray = field(default_factory=lambda: np.zeros(6, np.float32))
+    error: float = FLT_MAX
+    inlier: int = 0
+
+
+class Registration:
+    """algorithms/registration/registration.hpp:88-965 for the GN / LM optimisers.
+
+    align() is the reference's host-driven loop (one 192-byte read-back per iteration).
+    align_device_loop() keeps pose, linear system and solve on the device for a fixed number of iterations — the
+    form the benchmark times — and takes an optional torch.distributed process group: each rank linearises its shard
+    of the source and the 176-byte system is summed over ranks (RCCL over xGMI) before the solve.
+    """
+
+    def __init__(self, params=None):
+        self.params = params or RegistrationParams()
+        self.neighbors = KNNResult()
+        self._ws = None
+        self._lin = None
+        self.genz_alpha = 1.0
+
+    # -- helpers
+    def _buffers(self, device):
+        L = _lib.lib()
+        if self._ws is None or self._ws.device != device:
+            self._ws = torch.empty(L.sp_gicp_workspace_bytes(0), dtype=torch.uint8, device=device)
+            self._lin = torch.zeros(48, dtype=torch.float32, device=device)
+        return self._ws, self._lin
+
+    def _factor_params(self, robust_scale):
+        p = self.params
+        return FactorParams(REG[p.reg_type], LOSS[p.robust_type], p.max_correspondence_distance, robust_scale,
+                            self.genz_alpha, p.genz_planarity_threshold)
+
+    def _validate(self, source, target):
+        p = self.params
+        if p.reg_type == "POINT_TO_PLANE" and not target.has_normal():
+            if not target.has_cov():
+                raise SpError(2, "[Registration::validate_params] Normal vector or covariance matrices of target must "
+                                 "be pre-computed before performing Point-to-Plane ICP matching.")
+            covariance.extract_normals(target)
+        if p.reg_type == "GICP" and (not source.has_cov() or not target.has_cov()):
+            raise SpError(2, "[Registration::validate_params] Covariance matrices of source and target must be "
+                             "pre-computed before performing GICP matching.")
+        if p.reg_type == "GENZ":
+            if not target.has_cov():
+                raise SpError(2, "[Registration::validate_params] Covariance matrices of target must be pre-computed "
+                                 "before performing GenZ-ICP matching.")
+            if not target.has_normal():
+                covariance.extract_normals(target)
+        if p.reg_type == "POINT_TO_DISTRIBUTION" and not target.has_cov():
+            raise SpError(2, "[Registration::validate_params] Covariance matrices of target must be pre-computed "
+                             "before performing Point-to-Distribution ICP matching.")
+        if p.robust_type != "NONE" and p.robust_default_scale <= 0.0:
+            p.robust_type = "NONE"
+
+    def _linearize(self, which, source, target, transT, robust_scale, lin):
+        L = _lib.lib()
+        ws, _ = self._buffers(source.points.device)
+        fp = self._factor_params(robust_scale)
+        tp, on_dev, keep = _trans_arg(transT)
+        fn = L.sp_gicp_linearize if which == "linearize" else L.sp_gicp_error
+        check(fn(_ptr(source.points), _ptr(source.covs if source.has_cov() else None), source.size(),
+                 _ptr(target.points), _ptr(target.covs if target.has_cov() else None),
+                 _ptr(target.normals if target.has_normal() else None), _ptr(self.neighbors.indices),
+                 _ptr(self.neighbors.distances), tp, on_dev, C.byref(fp), _ptr(lin), _ptr(ws), ws.numel(), _stream()))
+
+    def _genz_alpha(self, source, target):
+        cnt = torch.zeros(2, dtype=torch.int32, device=source.points.device)
+        check(_lib.lib().sp_genz_counts(_ptr(target.covs), _ptr(self.neighbors.indices), _ptr(self.neighbors.distances),
+                                        source.size(), self.params.max_correspondence_distance,
+                                        self.params.genz_planarity_threshold, _ptr(cnt), _stream()))
+        inl, pl = [int(x) for x in cnt.cpu().tolist()]
+        return 1.0 if inl == 0 else float(np.float32(pl) / np.float32(inl))
+
+    @staticmethod
+    def _read_lin(lin):
+        h = lin.cpu().numpy()
+        out = Linearized()
+        C.memmove(C.byref(out), h.ctypes.data, 192)
+        return out
+
+    def compute_linearized_result(self, source, target, target_knn, pose, robust_scale=-1.0):
+        """registration.hpp:312-331 (without degenerate regularisation, which is default-off)."""
+        scale = robust_scale if robust_scale > 0 else self.params.robust_default_scale
+        _, lin = self._buffers(source.points.device)
+        target_knn.nearest_neighbor_search_async(source, self.neighbors, pose)
+        if self.params.reg_type == "GENZ":
+            self.genz_alpha = self._genz_alpha(source, target)
+        self._linearize("linearize", source, target, pose, scale, lin)
+        r = self._read_lin(lin)
+        return {"H": np.array(r.H, np.float32).reshape(6, 6), "b": np.array(r.b, np.float32), "error": float(r.error),
+                "inlier": int(r.inlier)}
+
+    def compute_error_frozen(self, source, target, pose, robust_scale=-1.0):
+        """registration.hpp:350-359 — error at `pose` with the cached correspondences."""
+        scale = robust_scale if robust_scale > 0 else self.params.robust_default_scale
+        _, lin = self._buffers(source.points.device)
+        self._linearize("error", source, target, pose, scale, lin)
+        r = self._read_lin(lin)
+        return float(r.error), int(r.inlier)
+
+    def compute_icp_robust_weights(self, source, target, target_knn, pose, robust_scale):
+        """registration.hpp:279-294"""
+        out = torch.zeros(source.size(), dtype=torch.float32, device=source.points.device)
+        if source.size() == 0:
+            return out
+        target_knn.nearest_neighbor_search_async(source, self.neighbors, pose)
+        fp = self._factor_params(robust_scale)
+        tp, on_dev, keep = _trans_arg(pose)
+        check(_lib.lib().sp_icp_robust_weights(
+            _ptr(source.points), _ptr(source.covs if source.has_cov() else None), source.size(), _ptr(target.points),
+            _ptr(target.covs if target.has_cov() else None), _ptr(target.normals if target.has_normal() else None),
+            _ptr(self.neighbors.indices), _ptr(self.neighbors.distances), tp, on_dev, C.byref(fp), _ptr(out), _stream()))
+        return out
+
+    # -- the reference's host-driven loop
+    def align(self, source, target, target_knn, initial_guess=None, robust_scale=-1.0):
+        """registration.hpp:201-276 with optimize_gauss_newton (:803-828) / optimize_levenberg_marquardt (:830-895)."""
+        L = _lib.lib()
+        p = self.params
+        result = RegistrationResult()
+        result.T = identity() if initial_guess is None else np.array(initial_guess, np.float32)
+        if source.size() == 0:
+            return result
+        self._validate(source, target)
+        scale = robust_scale if robust_scale > 0 else p.robust_default_scale
+        _, lin = self._buffers(source.points.device)
+        lm_lambda = p.lm_init_lambda
+        T = _T16(result.T).copy().reshape(-1)  # column-major working copy
+        delta8 = np.zeros(8, np.float32)
+        for it in range(p.max_iterations):
+            Tmat = T.reshape(4, 4).T
+            target_knn.nearest_neighbor_search_async(source, self.neighbors, Tmat)
+            if p.reg_type == "GENZ":
+                self.genz_alpha = self._genz_alpha(source, target)
+            self._linearize("linearize", source, target, Tmat, scale, lin)
+            lr = self._read_lin(lin)  # the reference's wait_and_throw + toCPU (registration.hpp:674-675)
+            H = np.array(lr.H, np.float32).reshape(6, 6)
+            b = np.array(lr.b, np.float32)
+            if p.optimization_method == "GN":
+                L.sp_gn_update_host(C.byref(lr), T.ctypes.data_as(C.c_void_p), p.gn_lambda, p.criteria_rotation,
+                                    p.criteria_translation, delta8.ctypes.data_as(C.c_void_p))
+                result.converged = bool(delta8[6] > 0.5)
+                result.iterations, result.H, result.b = it, H, b
+                result.error, result.inlier = float(lr.error), int(lr.inlier)
+            else:  # LM
+                current_error = np.float32(lr.error)
+                last_error = np.float32(FLT_MAX)
+                for _inner in range(p.lm_max_inner_iterations):
+                    Ttry = T.copy()
+                    L.sp_gn_update_host(C.byref(lr), Ttry.ctypes.data_as(C.c_void_p), lm_lambda, p.criteria_rotation,
+                                        p.criteria_translation, delta8.ctypes.data_as(C.c_void_p))
+                    conv = bool(delta8[6] > 0.5)
+                    result.converged = conv
+                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale)
+                    new_error = np.float32(new_error)
+                    if new_error <= current_error:
+                        result.converged, T = conv, Ttry
+                        result.error, result.inlier = float(new_error), inl
+                        lm_lambda = float(np.clip(np.float32(lm_lambda) / np.float32(p.lm_lambda_factor),
+                                                  p.lm_min_lambda, p.lm_max_lambda))
+                        break
+                    elif abs(np.float32(new_error - last_error)) <= 1e-6:
+                        result.converged, T = conv, Ttry
+                        result.error, result.inlier = float(new_error), inl
+                        break
+                    else:
+                        lm_lambda = float(np.clip(np.float32(lm_lambda) * np.float32(p.lm_lambda_factor),
+                                                  p.lm_min_lambda, p.lm_max_lambda))
+                    last_error = new_error
+                result.iterations, result.H, result.b = it, H, b
+            if result.converged:
+                break
+        result.T = T.reshape(4, 4).T.copy()
+        return result
+
+    # -- device-resident fixed-length loop (GN), optionally sharded over ranks
+    def align_device_loop(self, source, target, target_knn, initial_guess=None, iterations=None, robust_scale=-1.0,
+                          group=None, T_dev=None, delta_dev=None):
+        """`iterations` Gauss-Newton steps with no host round trip: NN(k=1) -> K11 -> [all-reduce] -> device solve.
+        Returns the device tensors (T_dev 16 floats column-major, lin 48 floats, delta 8 floats); nothing is
+        synchronised here."""
+        import torch.distributed as dist
+
+        L = _lib.lib()
+        p = self.params
+        if p.optimization_method != "GN":
+            raise SpError(1, "align_device_loop implements the Gauss-Newton optimiser only")
+        self._validate(source, target)
+        iters = p.max_iterations if iterations is None else iterations
+        scale = robust_scale if robust_scale > 0 else p.robust_default_scale
+        dev = source.points.device
+        _, lin = self._buffers(dev)
+        if T_dev is None:
+            T0 = identity() if initial_guess is None else np.asarray(initial_guess, np.float32)
+            T_dev = torch.from_numpy(_T16(T0).reshape(-1).copy()).to(dev)
+        if delta_dev is None:
+            delta_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+        sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        for _ in range(iters):
+            target_knn.nearest_neighbor_search_async(source, self.neighbors, T_dev)
+            self._linearize("linearize", source, target, T_dev, scale, lin)
+            if sharded:
+                dist.all_reduce(lin, op=dist.ReduceOp.SUM, group=group)  # 192 B over xGMI; latency-bound
+            check(L.sp_gn_update(_ptr(lin), _ptr(T_dev), p.gn_lambda, p.criteria_rotation, p.criteria_translation,
+                                 _ptr(delta_dev), _stream()))
+        return T_dev, lin, delta_dev
+
+    @staticmethod
+    def T_from_device(T_dev):
+        return T_dev.cpu().numpy().reshape(4, 4).T.copy()

@@ -1,0 +1,40 @@
+// C-ABI housekeeping: error message slot, device selection, host twins of the solver arithmetic.
+#include <string>
+
+#include "sp_common.h"
+#include "sp_math.h"
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void sp_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+
+extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
+extern "C" const char* sp_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int sp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int sp_set_device(int device) {
+    const hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        sp_set_error(hipGetErrorString(e));
+        return SP_ERR_HIP;
+    }
+    return SP_OK;
+}
+
+extern "C" void sp_se3_exp_host(const float* twist6, float* T_out16) {
+    const sp::Rigid r = sp::se3_exp(twist6);
+    sp::store_rigid_colmajor(r, T_out16);
+}
+extern "C" void sp_rigid_mul_host(const float* A16, const float* B16, float* out16) {
+    const sp::Rigid r = sp::rigid_mul(sp::load_rigid_colmajor(A16), sp::load_rigid_colmajor(B16));
+    sp::store_rigid_colmajor(r, out16);
+}
+extern "C" int sp_ldlt6_solve_host(const float* H36_rowmajor, const float* rhs6, float* x6) {
+    return sp::ldlt6_solve(H36_rowmajor, rhs6, x6) ? SP_OK : SP_ERR_RUNTIME;
+}

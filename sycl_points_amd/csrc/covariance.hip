@@ -1,0 +1,148 @@
+// K5/K6/K7 — neighbourhood covariance and normals for gfx950
+// (replaces algorithms/feature/covariance.hpp:16-74, 260-311, 417-503).
+//
+// One lane per point. The k neighbour indices of a point are contiguous (k*4 bytes), the k gathered points are
+// random 16-byte reads served by L2 / Infinity Cache; the output covariance is one 64-byte row written as four
+// 16-byte stores. Sums follow the reference order exactly (sequential over j, multiply then add, no fusion), so
+// K5 is bit-identical to an IEEE evaluation of the reference; K6/K7 go through acosf/cosf and agree to a few ulp.
+// Algorithmic bytes per point (k = 20): 80 idx + 320 gathered + 64 written = 464 B.
+#include "sp_common.h"
+#include "sp_math.h"
+
+void sp_set_error(const char* msg);
+
+namespace sp {
+namespace {
+
+// covariance::kernel::estimate (covariance.hpp:16-47). Returns false when fewer than 4 neighbours: identity.
+__device__ __forceinline__ bool estimate_cov(const float4* __restrict__ pts, const int32_t* __restrict__ nbr, int k,
+                                             Mat3& C) {
+    // outer(p,p) is bitwise symmetric (p_i*p_j == p_j*p_i), so 6 running sums carry all 9 entries.
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    float oxx = 0.0f, oxy = 0.0f, oxz = 0.0f, oyy = 0.0f, oyz = 0.0f, ozz = 0.0f;
+    unsigned cnt = 0;
+    for (int j = 0; j < k; ++j) {
+        const int idx = nbr[j];
+        if (idx < 0) continue;
+        const float4 p = pts[idx];
+        sx += p.x; sy += p.y; sz += p.z;
+        oxx += p.x * p.x; oxy += p.x * p.y; oxz += p.x * p.z;
+        oyy += p.y * p.y; oyz += p.y * p.z; ozz += p.z * p.z;
+        ++cnt;
+    }
+    if (cnt < 4) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) C.m[i][j] = (i == j) ? 1.0f : 0.0f;
+        return false;
+    }
+    const float inv = 1.0f / (float)cnt;  // 1.0f / correspondences (size_t -> float), covariance.hpp:44
+    const float mx = sx * inv, my = sy * inv, mz = sz * inv;
+    // (sum_outer * inv) - outer(mean, mean), then ensure_symmetric (eigen_utils.hpp:208-219): (a + a) * 0.5
+    const float cxx = oxx * inv - mx * mx, cxy = oxy * inv - mx * my, cxz = oxz * inv - mx * mz;
+    const float cyy = oyy * inv - my * my, cyz = oyz * inv - my * mz, czz = ozz * inv - mz * mz;
+    const float sxy = (cxy + cxy) * 0.5f, sxz = (cxz + cxz) * 0.5f, syz = (cyz + cyz) * 0.5f;
+    C.m[0][0] = cxx; C.m[0][1] = sxy; C.m[0][2] = sxz;
+    C.m[1][0] = sxy; C.m[1][1] = cyy; C.m[1][2] = syz;
+    C.m[2][0] = sxz; C.m[2][1] = syz; C.m[2][2] = czz;
+    return true;
+}
+
+__device__ __forceinline__ void store_cov(float4* __restrict__ out, const Mat3& C) {
+    out[0] = make_float4(C.m[0][0], C.m[1][0], C.m[2][0], 0.0f);  // column 0
+    out[1] = make_float4(C.m[0][1], C.m[1][1], C.m[2][1], 0.0f);
+    out[2] = make_float4(C.m[0][2], C.m[1][2], C.m[2][2], 0.0f);
+    out[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+__device__ __forceinline__ Mat3 load_cov(const float4* __restrict__ in) {
+    const float4 c0 = in[0], c1 = in[1], c2 = in[2];
+    Mat3 C;
+    C.m[0][0] = c0.x; C.m[1][0] = c0.y; C.m[2][0] = c0.z;
+    C.m[0][1] = c1.x; C.m[1][1] = c1.y; C.m[2][1] = c1.z;
+    C.m[0][2] = c2.x; C.m[1][2] = c2.y; C.m[2][2] = c2.z;
+    return C;
+}
+
+// covariance::kernel::extract_normal (covariance.hpp:49-65): smallest-eigenvalue eigenvector, flipped when n.p > 1.
+__device__ __forceinline__ float4 normal_of(const Mat3& C, const float4 p) {
+    float ev[3];
+    Mat3 V;
+    symmetric_eigen3(C, ev, V);
+    const float nx = V.m[0][0], ny = V.m[1][0], nz = V.m[2][0];
+    const float d = chain3(nx, p.x, ny, p.y, nz, p.z);
+    if (d <= 1.0f) return make_float4(nx, ny, nz, 0.0f);
+    return make_float4(-nx, -ny, -nz, 0.0f);
+}
+
+__global__ __launch_bounds__(kBlock) void cov_kernel(const float4* __restrict__ pts, unsigned n,
+                                                     const int32_t* __restrict__ knn, int k,
+                                                     float4* __restrict__ covs) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Mat3 C;
+    estimate_cov(pts, knn + (size_t)i * k, k, C);
+    store_cov(covs + 4 * (size_t)i, C);
+}
+__global__ __launch_bounds__(kBlock) void normal_knn_kernel(const float4* __restrict__ pts, unsigned n,
+                                                            const int32_t* __restrict__ knn, int k,
+                                                            float4* __restrict__ normals) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Mat3 C;
+    estimate_cov(pts, knn + (size_t)i * k, k, C);
+    normals[i] = normal_of(C, pts[i]);
+}
+__global__ __launch_bounds__(kBlock) void normal_cov_kernel(const float4* __restrict__ pts,
+                                                            const float4* __restrict__ covs, unsigned n,
+                                                            float4* __restrict__ normals) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    normals[i] = normal_of(load_cov(covs + 4 * (size_t)i), pts[i]);
+}
+__global__ __launch_bounds__(kBlock) void cov_plane_kernel(const float4* __restrict__ covs, unsigned n,
+                                                           float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Mat3 P = plane_regularize(load_cov(covs + 4 * (size_t)i));
+    store_cov(out + 4 * (size_t)i, P);
+}
+
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_cov_estimate(const float* points, size_t n, const int32_t* knn_idx, size_t k, float* covs_out,
+                               void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    cov_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(points), (unsigned)n,
+                                                                    knn_idx, (int)k, reinterpret_cast<float4*>(covs_out));
+    return launch_status();
+}
+extern "C" int sp_normals_from_knn(const float* points, size_t n, const int32_t* knn_idx, size_t k, float* normals_out,
+                                   void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    normal_knn_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(points), (unsigned)n, knn_idx, (int)k, reinterpret_cast<float4*>(normals_out));
+    return launch_status();
+}
+extern "C" int sp_normals_from_cov(const float* points, const float* covs, size_t n, float* normals_out, void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    if (!covs) {
+        sp_set_error("[covariance::extract_normals_async] covariances not computed");
+        return SP_ERR_RUNTIME;
+    }
+    normal_cov_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(covs), (unsigned)n,
+        reinterpret_cast<float4*>(normals_out));
+    return launch_status();
+}
+extern "C" int sp_cov_update_plane(const float* covs, size_t n, float* covs_out, void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    cov_plane_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(covs),
+                                                                          (unsigned)n, reinterpret_cast<float4*>(covs_out));
+    return launch_status();
+}

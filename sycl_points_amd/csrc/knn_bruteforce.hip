@@ -1,0 +1,212 @@
+// K1 — brute-force kNN for gfx950 (replaces algorithms/knn/bruteforce.hpp:24-96).
+//
+// Layout of the work: a 2-D grid, x = tiles of 256*QPT queries, y = contiguous chunks of the target cloud.
+// Every workgroup stages its target chunk through LDS in tiles of 1024 float4 (coalesced 16-byte loads, 16 KiB),
+// then all 256 lanes walk the tile with wave-uniform (broadcast) ds_read_b128 and keep a sorted top-k per query
+// in registers. Chunks write partial top-k lists; a second tiny kernel merges them in chunk order, which keeps
+// the reference's tie rule (strict '<': the lowest target index wins) exactly.
+// The bound is fp32 VALU, not HBM: 9 VALU ops per (query, target) pair, HBM traffic is O(nq + nt).
+#include "sp_common.h"
+#include "sp_math.h"
+
+namespace sp {
+namespace {
+
+constexpr int kTile = 1024;
+
+// Sorted insertion into the first k slots (strict '<', later arrivals go after equal distances), written as a
+// fully unrolled carry chain so the arrays stay in registers.
+template <int KCAP>
+__device__ __forceinline__ void topk_insert(float (&bd)[KCAP], int (&bi)[KCAP], int k, float d, int idx, float& kth) {
+    if (KCAP == 1) {
+        const bool better = d < bd[0];
+        bi[0] = better ? idx : bi[0];
+        bd[0] = better ? d : bd[0];
+        kth = bd[0];
+        return;
+    }
+    float cd = d;
+    int ci = idx;
+    bool shifting = false;
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) {
+        if (i < k) {
+            const bool sw = shifting || (cd < bd[i]);
+            const float td = bd[i];
+            const int ti = bi[i];
+            const float nd = sw ? cd : td;
+            bd[i] = nd;
+            bi[i] = sw ? ci : ti;
+            cd = sw ? td : cd;
+            ci = sw ? ti : ci;
+            shifting = sw;
+            kth = nd;  // after the last executed iteration (i == k-1) this is bestK[k-1].dist_sq
+        }
+    }
+}
+
+template <int KCAP, int QPT>
+__global__ __launch_bounds__(kBlock) void knn_bf_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                        const float4* __restrict__ targets, unsigned nt, int k,
+                                                        unsigned chunk, int32_t* __restrict__ idx_out,
+                                                        float* __restrict__ d2_out) {
+    __shared__ float4 tile[kTile];
+    const unsigned split = blockIdx.y;
+    const unsigned t_begin = split * chunk;
+    const unsigned t_end = min(nt, t_begin + chunk);
+
+    float qx[QPT], qy[QPT], qz[QPT];
+    unsigned qid[QPT];
+    float bd[QPT][KCAP];
+    int bi[QPT][KCAP];
+    float kth[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        qid[u] = (blockIdx.x * QPT + u) * kBlock + threadIdx.x;
+        const float4 q = queries[min(qid[u], nq - 1)];
+        qx[u] = q.x; qy[u] = q.y; qz[u] = q.z;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) { bd[u][i] = FLT_MAX; bi[u][i] = -1; }
+        kth[u] = FLT_MAX;
+    }
+
+    for (unsigned base = t_begin; base < t_end; base += kTile) {
+        const unsigned cnt = min((unsigned)kTile, t_end - base);
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < cnt; i += kBlock) tile[i] = targets[base + i];
+        __syncthreads();
+#pragma unroll 4
+        for (unsigned j = 0; j < cnt; ++j) {
+            const float4 p = tile[j];  // same address in every lane: one broadcast LDS read
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const float d = dist2(qx[u], qy[u], qz[u], p.x, p.y, p.z);
+                if (d < kth[u]) {
+                    topk_insert<KCAP>(bd[u], bi[u], k, d, (int)(base + j), kth[u]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        if (qid[u] < nq) {
+            const size_t o = ((size_t)split * nq + qid[u]) * (size_t)k;
+#pragma unroll
+            for (int i = 0; i < KCAP; ++i)
+                if (i < k) { d2_out[o + i] = bd[u][i]; idx_out[o + i] = bi[u][i]; }
+        }
+    }
+}
+
+// Merge nsplit sorted partial lists per query, in chunk order (ascending target index at equal distance).
+template <int KCAP>
+__global__ __launch_bounds__(kBlock) void knn_bf_merge_kernel(const int32_t* __restrict__ pidx,
+                                                              const float* __restrict__ pd2, unsigned nq, int k,
+                                                              unsigned nsplit, int32_t* __restrict__ idx_out,
+                                                              float* __restrict__ d2_out) {
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nq) return;
+    float bd[KCAP];
+    int bi[KCAP];
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
+    float kth = FLT_MAX;
+    for (unsigned s = 0; s < nsplit; ++s) {
+        const size_t o = ((size_t)s * nq + q) * (size_t)k;
+        for (int i = 0; i < k; ++i) {
+            const float d = pd2[o + i];
+            if (!(d < kth)) break;  // list is ascending: nothing further in this chunk can enter
+            topk_insert<KCAP>(bd, bi, k, d, pidx[o + i], kth);
+        }
+    }
+    const size_t o = (size_t)q * (size_t)k;
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i)
+        if (i < k) { d2_out[o + i] = bd[i]; idx_out[o + i] = bi[i]; }
+}
+
+struct BfPlan {
+    unsigned qblocks, nsplit, chunk;
+    int qpt;
+};
+
+BfPlan plan(size_t nq, size_t nt, size_t k) {
+    BfPlan p;
+    p.qpt = (k == 1) ? 2 : 1;
+    p.qblocks = div_up(nq, (size_t)kBlock * p.qpt);
+    const unsigned max_split = div_up(nt, kTile);
+    unsigned want = div_up((size_t)kNumCU * 4, p.qblocks);  // >= 4 workgroups per CU
+    if (want < 1) want = 1;
+    p.nsplit = want > max_split ? max_split : want;
+    if (p.nsplit < 1) p.nsplit = 1;
+    if (p.nsplit > 65535) p.nsplit = 65535;
+    unsigned chunk = div_up(nt, p.nsplit);
+    chunk = div_up(chunk, kTile) * kTile;  // whole LDS tiles per chunk
+    p.chunk = chunk ? chunk : kTile;
+    p.nsplit = div_up(nt, p.chunk);
+    if (p.nsplit < 1) p.nsplit = 1;
+    return p;
+}
+
+template <int KCAP, int QPT>
+int run(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t* idx, float* d2, void* ws,
+        const BfPlan& p, hipStream_t st) {
+    int32_t* pidx = idx;
+    float* pd2 = d2;
+    if (p.nsplit > 1) {
+        pidx = static_cast<int32_t*>(ws);
+        pd2 = reinterpret_cast<float*>(pidx + (size_t)p.nsplit * nq * k);
+    }
+    knn_bf_kernel<KCAP, QPT><<<dim3(p.qblocks, p.nsplit), kBlock, 0, st>>>(
+        reinterpret_cast<const float4*>(q), (unsigned)nq, reinterpret_cast<const float4*>(t), (unsigned)nt, (int)k,
+        p.chunk, pidx, pd2);
+    if (p.nsplit > 1)
+        knn_bf_merge_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(pidx, pd2, (unsigned)nq, (int)k, p.nsplit,
+                                                                          idx, d2);
+    return launch_status();
+}
+
+__global__ void fill_empty_kernel(int32_t* idx, float* d2, size_t n) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) { idx[i] = -1; d2[i] = FLT_MAX; }
+}
+
+}  // namespace
+}  // namespace sp
+
+extern "C" size_t sp_knn_bruteforce_workspace_bytes(size_t nq, size_t nt, size_t k) {
+    if (nq == 0 || nt == 0 || k == 0) return 0;
+    const sp::BfPlan p = sp::plan(nq, nt, k);
+    return p.nsplit > 1 ? (size_t)p.nsplit * nq * k * 8 : 0;
+}
+
+void sp_set_error(const char* msg);
+
+extern "C" int sp_knn_bruteforce(const float* queries, size_t nq, const float* targets, size_t nt, size_t k,
+                                 int32_t* idx_out, float* d2_out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    using namespace sp;
+    if (k == 0 || k > 20) {
+        sp_set_error("[knn_search_bruteforce] k must be in [1, 20] (MAX_K = 20, bruteforce.hpp:26)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (nq >= (1ull << 31) || nt >= (1ull << 31)) {
+        sp_set_error("[knn_search_bruteforce] more than 2^31 points: indices are int32");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (nq == 0) return SP_OK;
+    hipStream_t st = as_stream(stream);
+    if (nt == 0) {  // no targets: every slot keeps its initial -1 / FLT_MAX (knn/result.hpp:21-27)
+        fill_empty_kernel<<<div_up(nq * k, kBlock), kBlock, 0, st>>>(idx_out, d2_out, nq * k);
+        return launch_status();
+    }
+    const BfPlan p = plan(nq, nt, k);
+    if (p.nsplit > 1 && (workspace == nullptr || workspace_bytes < (size_t)p.nsplit * nq * k * 8)) {
+        sp_set_error("[knn_search_bruteforce] workspace too small (sp_knn_bruteforce_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (k == 1) return run<1, 2>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
+    if (k <= 5) return run<5, 1>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
+    if (k <= 10) return run<10, 1>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
+    return run<20, 1>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
+}

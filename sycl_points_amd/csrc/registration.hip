@@ -1,0 +1,596 @@
+// K11/K12/K13 + Gauss-Newton update for gfx950
+// (replaces algorithms/registration/registration.hpp:412-462, 464-511, 513-664, 678-777, 791-828 and the per-point
+//  factors of algorithms/registration/factor.hpp:69-482).
+//
+// K11: one lane walks source points with a grid stride; per point it gathers the correspondence
+// (target point, 64-byte target covariance row, optional normal), linearises the factor in registers and adds the
+// weighted 21 unique entries of H, the 6 of b, the error and the inlier count to 29 lane-private accumulators.
+// A wave64 butterfly, then a 4-wave LDS step, gives one 32-float partial per workgroup; a second one-workgroup kernel
+// sums the <= 1024 partials in a fixed order and writes the 176-byte system. No atomics: the sum is a fixed tree,
+// bit-reproducible from run to run. HBM-bound: 168 B per source point.
+// The factor arithmetic keeps the reference's fma chains (sp_math.h); structural zeros of the padded 4x4/4x6 types
+// are skipped, which leaves every finite result bit-identical.
+#include "sp_common.h"
+#include "sp_math.h"
+
+void sp_set_error(const char* msg);
+
+namespace sp {
+namespace {
+
+constexpr int kAcc = 29;       // 21 H (upper, row-major) + 6 b + error + count
+constexpr int kPartial = 32;   // floats per workgroup partial
+constexpr int kMaxBlocks = 1024;
+
+struct PointTerm {
+    float H[6][6];  // symmetrised, unweighted
+    float b[6];
+    float sq;             // squared error of the factor
+    float residual_norm;  // fed to the robust kernel
+    float genz_weight;
+};
+
+__device__ __forceinline__ Mat3 load_cov3(const float4* __restrict__ c) {
+    const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+    Mat3 C;
+    C.m[0][0] = c0.x; C.m[1][0] = c0.y; C.m[2][0] = c0.z;
+    C.m[0][1] = c1.x; C.m[1][1] = c1.y; C.m[2][1] = c1.z;
+    C.m[0][2] = c2.x; C.m[1][2] = c2.y; C.m[2][2] = c2.z;
+    return C;
+}
+__device__ __forceinline__ Mat3 identity3() {
+    Mat3 I;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) I.m[i][j] = (i == j) ? 1.0f : 0.0f;
+    return I;
+}
+
+// compute_se3_jacobian (factor.hpp:69-84): rows 0..2 of [R*skew(p) | -R]; row 3 is zero and never stored.
+__device__ __forceinline__ void se3_jacobian(const Rigid& T, float px, float py, float pz, float J[3][6]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float r0 = T.R[i][0], r1 = T.R[i][1], r2 = T.R[i][2];
+        J[i][0] = chain3(r0, 0.0f, r1, pz, r2, -py);
+        J[i][1] = chain3(r0, -pz, r1, 0.0f, r2, px);
+        J[i][2] = chain3(r0, py, r1, -px, r2, 0.0f);
+        J[i][3] = -r0;
+        J[i][4] = -r1;
+        J[i][5] = -r2;
+    }
+}
+
+// H = sym(J^T M J), b = J^T M r, sq = r^T M r   (factor.hpp:262-275, 339-351; M is a general 3x3)
+__device__ __forceinline__ void quadratic_form(const float J[3][6], const Mat3& M, float r0, float r1, float r2,
+                                               PointTerm& out) {
+    float JTm[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) JTm[a][k] = chain3(J[0][a], M.m[0][k], J[1][a], M.m[1][k], J[2][a], M.m[2][k]);
+    float Hf[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Hf[a][c] = chain3(JTm[a][0], J[0][c], JTm[a][1], J[1][c], JTm[a][2], J[2][c]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out.H[a][c] = (a == c) ? Hf[a][c] : (Hf[a][c] + Hf[c][a]) * 0.5f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) out.b[a] = chain3(JTm[a][0], r0, JTm[a][1], r1, JTm[a][2], r2);
+    const float v0 = chain3(M.m[0][0], r0, M.m[0][1], r1, M.m[0][2], r2);
+    const float v1 = chain3(M.m[1][0], r0, M.m[1][1], r1, M.m[1][2], r2);
+    const float v2 = chain3(M.m[2][0], r0, M.m[2][1], r1, M.m[2][2], r2);
+    out.sq = chain3(r0, v0, r1, v1, r2, v2);
+}
+
+__device__ __forceinline__ void point_to_point(const float J[3][6], float r0, float r1, float r2, PointTerm& out) {
+    quadratic_form(J, identity3(), r0, r1, r2, out);  // factor.hpp:130-149 with J^T*I == J^T
+    out.residual_norm = sqrtf(out.sq);
+}
+
+// linearize_point_to_plane (factor.hpp:172-210)
+__device__ __forceinline__ void point_to_plane(const float J[3][6], float r0, float r1, float r2, const float4 nrm,
+                                               PointTerm& out) {
+    const float proj = chain3(nrm.x, r0, nrm.y, r1, nrm.z, r2);
+    const float n[3] = {nrm.x, nrm.y, nrm.z};
+    float row[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) row[c] = chain3(n[0], J[0][c], n[1], J[1][c], n[2], J[2][c]);
+    float Jp[3][6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Jp[i][c] = fmaf(n[i], row[c], 0.0f);
+    const float pe0 = n[0] * proj, pe1 = n[1] * proj, pe2 = n[2] * proj;
+    float Hf[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Hf[a][c] = chain3(Jp[0][a], Jp[0][c], Jp[1][a], Jp[1][c], Jp[2][a], Jp[2][c]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out.H[a][c] = (a == c) ? Hf[a][c] : (Hf[a][c] + Hf[c][a]) * 0.5f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) out.b[a] = chain3(Jp[0][a], pe0, Jp[1][a], pe1, Jp[2][a], pe2);
+    out.sq = proj * proj;
+    out.residual_norm = fabsf(proj);
+}
+
+// compute_pca_normalized_curvature / is_genz_planar_correspondence (factor.hpp:378-392)
+__device__ __forceinline__ bool genz_planar(const Mat3& tcov, float thr) {
+    float ev[3];
+    Mat3 V;
+    symmetric_eigen3(tcov, ev, V);
+    const float sum = ev[0] + ev[1] + ev[2];
+    const float curv = (sum > 1e-12f) ? ev[0] / sum : 1.0f;
+    return curv < thr;
+}
+
+// GICP information matrix: (Ct' + R Cs' R^T)^-1 with both covariances plane-regularised
+// (factor.hpp:249-258, 111-123; transform_covs = T*(C*T^T), common/transform.hpp:14-22).
+__device__ __forceinline__ Mat3 gicp_information(const Rigid& T, const Mat3& scov, const Mat3& tcov) {
+    const Mat3 Cs = plane_regularize(scov);
+    const Mat3 Ct = plane_regularize(tcov);
+    Mat3 R;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R.m[i][j] = T.R[i][j];
+    const Mat3 Y = matmul_bt(Cs, R);  // Cs * R^T
+    const Mat3 RCR = matmul(R, Y);
+    Mat3 S;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) S.m[i][j] = RCR.m[i][j] + Ct.m[i][j];
+    return inverse(S);
+}
+
+struct Corr {  // everything gathered for one correspondence
+    float4 s, t, tn;
+    Mat3 scov, tcov;
+};
+
+template <int REG>
+__device__ __forceinline__ Corr gather(unsigned i, const float4* __restrict__ src, const float4* __restrict__ scov,
+                                       const float4* __restrict__ tgt, const float4* __restrict__ tcov,
+                                       const float4* __restrict__ tnrm, const int32_t* __restrict__ nn_idx) {
+    Corr c;
+    const int ti = nn_idx[i];
+    c.s = src[i];
+    c.t = tgt[ti];
+    if (REG == SP_REG_GICP) c.scov = scov ? load_cov3(scov + 4 * (size_t)i) : identity3();
+    if (REG == SP_REG_GICP || REG == SP_REG_POINT_TO_DISTRIBUTION || REG == SP_REG_GENZ)
+        c.tcov = tcov ? load_cov3(tcov + 4 * (size_t)ti) : identity3();
+    if (REG == SP_REG_POINT_TO_PLANE || REG == SP_REG_GENZ)
+        c.tn = tnrm ? tnrm[ti] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return c;
+}
+
+// linearize_geometry<reg> (factor.hpp:413-449)
+template <int REG>
+__device__ __forceinline__ void linearize_point(const Rigid& T, const Corr& c, float genz_alpha, float genz_thr,
+                                                PointTerm& out) {
+    float tx, ty, tz;
+    transform_point(T, c.s.x, c.s.y, c.s.z, tx, ty, tz);
+    const float r0 = c.t.x - tx, r1 = c.t.y - ty, r2 = c.t.z - tz;
+    float J[3][6];
+    se3_jacobian(T, c.s.x, c.s.y, c.s.z, J);
+    out.genz_weight = 1.0f;
+    if (REG == SP_REG_POINT_TO_POINT) {
+        point_to_point(J, r0, r1, r2, out);
+    } else if (REG == SP_REG_POINT_TO_PLANE) {
+        point_to_plane(J, r0, r1, r2, c.tn, out);
+    } else if (REG == SP_REG_GICP) {
+        quadratic_form(J, gicp_information(T, c.scov, c.tcov), r0, r1, r2, out);
+        out.residual_norm = sqrtf(out.sq);
+    } else if (REG == SP_REG_POINT_TO_DISTRIBUTION) {
+        quadratic_form(J, inverse(c.tcov), r0, r1, r2, out);  // factor.hpp:311-354
+        out.residual_norm = sqrtf(out.sq);
+    } else {  // GENZ (factor.hpp:426-443)
+        const bool planar = genz_planar(c.tcov, genz_thr);
+        const float w = planar ? genz_alpha : (1.0f - genz_alpha);
+        if (planar) point_to_plane(J, r0, r1, r2, c.tn, out);
+        else point_to_point(J, r0, r1, r2, out);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) out.H[a][cc] *= w;
+            out.b[a] *= w;
+        }
+        out.sq *= w;
+        out.genz_weight = w;
+    }
+}
+
+// calculate_geometry_error<reg> (factor.hpp:459-482): squared error only.
+template <int REG>
+__device__ __forceinline__ float error_point(const Rigid& T, const Corr& c, float genz_alpha, float genz_thr,
+                                             float& genz_weight) {
+    float tx, ty, tz;
+    transform_point(T, c.s.x, c.s.y, c.s.z, tx, ty, tz);
+    const float r0 = c.t.x - tx, r1 = c.t.y - ty, r2 = c.t.z - tz;
+    genz_weight = 1.0f;
+    auto maha = [&](const Mat3& M) {
+        const float v0 = chain3(M.m[0][0], r0, M.m[0][1], r1, M.m[0][2], r2);
+        const float v1 = chain3(M.m[1][0], r0, M.m[1][1], r1, M.m[1][2], r2);
+        const float v2 = chain3(M.m[2][0], r0, M.m[2][1], r1, M.m[2][2], r2);
+        return chain3(r0, v0, r1, v1, r2, v2);
+    };
+    auto plane = [&]() {
+        const float proj = chain3(c.tn.x, r0, c.tn.y, r1, c.tn.z, r2);
+        return proj * proj;
+    };
+    if (REG == SP_REG_POINT_TO_POINT) return chain3(r0, r0, r1, r1, r2, r2);
+    if (REG == SP_REG_POINT_TO_PLANE) return plane();
+    if (REG == SP_REG_GICP) return maha(gicp_information(T, c.scov, c.tcov));
+    if (REG == SP_REG_POINT_TO_DISTRIBUTION) return maha(inverse(c.tcov));
+    const bool planar = genz_planar(c.tcov, genz_thr);
+    genz_weight = planar ? genz_alpha : (1.0f - genz_alpha);
+    return planar ? plane() : chain3(r0, r0, r1, r1, r2, r2);
+}
+
+struct KParams {
+    const float4 *src, *scov, *tgt, *tcov, *tnrm;
+    const int32_t* nn_idx;
+    const float* nn_d2;
+    unsigned n;
+    float max_d2, scale, genz_alpha, genz_thr;
+    Mat4Arg T_val;
+    const float* T_dev;
+};
+
+// Sum NV lane values over the workgroup in a fixed order and let lane e < NV of wave 0 write partial[e].
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cnt, float* __restrict__ partial) {
+    __shared__ float red[kBlock / kWave][kPartial];
+    const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[e] = wave_sum(acc[e]);
+    cnt = wave_sum_u32(cnt);
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) red[wave][e] = acc[e];
+        red[wave][NV] = __uint_as_float(cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) s += red[w][threadIdx.x];
+        partial[threadIdx.x] = s;
+    } else if (threadIdx.x == NV) {
+        unsigned c = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) c += __float_as_uint(red[w][NV]);
+        partial[NV] = __uint_as_float(c);
+    }
+}
+
+template <int REG, int LOSS>
+__global__ __launch_bounds__(kBlock) void linearize_kernel(KParams P, float* __restrict__ partials) {
+    const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
+    float acc[kAcc - 1];
+#pragma unroll
+    for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
+    unsigned cnt = 0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock) {
+        if (P.nn_d2[i] > P.max_d2) continue;
+        const Corr c = gather<REG>(i, P.src, P.scov, P.tgt, P.tcov, P.tnrm, P.nn_idx);
+        PointTerm pt;
+        linearize_point<REG>(T, c, P.genz_alpha, P.genz_thr, pt);
+        const float w = robust_weight<LOSS>(pt.residual_norm, P.scale);
+        float err = robust_error<LOSS>(pt.residual_norm, P.scale);
+        if (REG == SP_REG_GENZ) err = pt.genz_weight * err;
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int cc = a; cc < 6; ++cc) acc[e++] += w * pt.H[a][cc];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += w * pt.b[a];
+        acc[27] += err;
+        ++cnt;
+    }
+    block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
+}
+
+template <int REG, int LOSS>
+__global__ __launch_bounds__(kBlock) void error_kernel(KParams P, float* __restrict__ partials) {
+    const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
+    float acc[1] = {0.0f};
+    unsigned cnt = 0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock) {
+        if (P.nn_d2[i] > P.max_d2) continue;
+        const Corr c = gather<REG>(i, P.src, P.scov, P.tgt, P.tcov, P.tnrm, P.nn_idx);
+        float gw;
+        const float sq = error_point<REG>(T, c, P.genz_alpha, P.genz_thr, gw);
+        float err = robust_error<LOSS>(sqrtf(sq), P.scale);
+        if (REG == SP_REG_GENZ) err = gw * err;
+        acc[0] += err;
+        ++cnt;
+    }
+    block_reduce_store<1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
+}
+
+template <int REG, int LOSS>
+__global__ __launch_bounds__(kBlock) void weights_kernel(KParams P, float* __restrict__ out) {
+    const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock) {
+        float w = 0.0f;
+        if (P.nn_d2[i] <= P.max_d2) {
+            const Corr c = gather<REG>(i, P.src, P.scov, P.tgt, P.tcov, P.tnrm, P.nn_idx);
+            float gw;
+            const float sq = error_point<REG>(T, c, P.genz_alpha, P.genz_thr, gw);
+            w = robust_weight<LOSS>(sqrtf(sq), P.scale);
+        }
+        out[i] = w;
+    }
+}
+
+// Second stage: one workgroup sums the per-workgroup partials in a fixed order.
+// nv = number of float slots (28 for K11, 1 for K12); slot nv holds the uint32 count.
+__global__ __launch_bounds__(kBlock) void final_reduce_kernel(const float* __restrict__ partials, unsigned nblocks,
+                                                              int nv, sp_linearized* __restrict__ out) {
+    __shared__ float red[8][kPartial];
+    const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts x 32 slots
+    const unsigned per = (nblocks + 7) / 8;
+    const unsigned lo = part * per, hi = min(nblocks, lo + per);
+    float s = 0.0f;
+    unsigned c = 0;
+    for (unsigned b = lo; b < hi; ++b) {
+        const float v = partials[(size_t)b * kPartial + e];
+        if ((int)e < nv) s += v;
+        else if ((int)e == nv) c += __float_as_uint(v);
+    }
+    red[part][e] = ((int)e == nv) ? __uint_as_float(c) : s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.0f;
+        unsigned ct = 0;
+        for (int p = 0; p < 8; ++p) {
+            if ((int)e == nv) ct += __float_as_uint(red[p][e]);
+            else t += red[p][e];
+        }
+        red[0][e] = ((int)e == nv) ? __uint_as_float(ct) : t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (nv == kAcc - 1) {
+            int k = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int cc = a; cc < 6; ++cc) {
+                    const float v = red[0][k++];
+                    out->H[a * 6 + cc] = v;
+                    out->H[cc * 6 + a] = v;
+                }
+            for (int a = 0; a < 6; ++a) out->b[a] = red[0][21 + a];
+            out->error = red[0][27];
+        } else {
+            out->error = red[0][0];
+        }
+        const unsigned cnt = __float_as_uint(red[0][nv]);
+        out->inlier = cnt;
+        out->inlier_lo = (float)(cnt & 4095u);
+        out->inlier_hi = (float)(cnt >> 12);
+    }
+}
+
+__global__ void genz_counts_kernel(const float4* __restrict__ tcov, const int32_t* __restrict__ nn_idx,
+                                   const float* __restrict__ nn_d2, unsigned n, float max_d2, float thr,
+                                   uint32_t* __restrict__ counts) {
+    unsigned inl = 0, pl = 0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (nn_d2[i] > max_d2) continue;
+        if (genz_planar(load_cov3(tcov + 4 * (size_t)nn_idx[i]), thr)) ++pl;
+        ++inl;
+    }
+    inl = wave_sum_u32(inl);
+    pl = wave_sum_u32(pl);
+    if ((threadIdx.x & (kWave - 1)) == 0) {  // integer atomics: order-independent, exact
+        atomicAdd(&counts[0], inl);
+        atomicAdd(&counts[1], pl);
+    }
+}
+
+// optimize_gauss_newton (registration.hpp:803-828) + solve_linear_system (:791-801) + is_converged (:407-410)
+__host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, float lambda, float crit_rot,
+                                               float crit_trans, float* delta_out8, bool fold_inlier) {
+    if (fold_inlier) lin->inlier = (uint32_t)(lin->inlier_hi * 4096.0f + lin->inlier_lo);
+    float H[36], nb[6], delta[6];
+    for (int i = 0; i < 36; ++i) H[i] = lin->H[i];
+    for (int i = 0; i < 6; ++i) {
+        H[i * 6 + i] = lin->H[i * 6 + i] + lambda * 1.0f;
+        nb[i] = -lin->b[i];
+    }
+    const bool ok = ldlt6_solve(H, nb, delta);
+    const float nr = sqrtf(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+    const float nt = sqrtf(delta[3] * delta[3] + delta[4] * delta[4] + delta[5] * delta[5]);
+    const bool conv = ok && (nr < crit_rot) && (nt < crit_trans);
+    const Rigid cur = load_rigid_colmajor(T);
+    const Rigid upd = rigid_mul(cur, se3_exp(delta));
+    store_rigid_colmajor(upd, T);
+    if (delta_out8) {
+        for (int i = 0; i < 6; ++i) delta_out8[i] = delta[i];
+        delta_out8[6] = conv ? 1.0f : 0.0f;
+        delta_out8[7] = ok ? 1.0f : 0.0f;
+    }
+}
+__global__ void gn_update_kernel(sp_linearized* lin, float* T, float lambda, float crit_rot, float crit_trans,
+                                 float* delta_out8) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) gn_update_impl(lin, T, lambda, crit_rot, crit_trans, delta_out8, true);
+}
+
+unsigned reduce_grid(size_t n) {
+    unsigned g = div_up(n, kBlock);
+    if (g > kMaxBlocks) g = kMaxBlocks;
+    return g ? g : 1;
+}
+
+KParams make_params(const float* src, const float* scov, size_t n, const float* tgt, const float* tcov,
+                    const float* tnrm, const int32_t* nn_idx, const float* nn_d2, const float* T, int T_dev,
+                    const sp_factor_params* fp) {
+    KParams P;
+    P.src = reinterpret_cast<const float4*>(src);
+    P.scov = reinterpret_cast<const float4*>(scov);
+    P.tgt = reinterpret_cast<const float4*>(tgt);
+    P.tcov = reinterpret_cast<const float4*>(tcov);
+    P.tnrm = reinterpret_cast<const float4*>(tnrm);
+    P.nn_idx = nn_idx;
+    P.nn_d2 = nn_d2;
+    P.n = (unsigned)n;
+    P.max_d2 = fp->max_correspondence_distance * fp->max_correspondence_distance;  // registration.hpp:554-555
+    P.scale = fp->robust_scale;
+    P.genz_alpha = fp->genz_alpha;
+    P.genz_thr = fp->genz_planarity_threshold;
+    for (int i = 0; i < 16; ++i) P.T_val.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    if (T && !T_dev)
+        for (int i = 0; i < 16; ++i) P.T_val.m[i] = T[i];
+    P.T_dev = T_dev ? T : nullptr;
+    return P;
+}
+
+enum Which { K_LINEARIZE, K_ERROR, K_WEIGHTS };
+
+template <int REG, int LOSS>
+void launch_one(Which which, const KParams& P, float* partials, float* weights, unsigned grid, hipStream_t st) {
+    if (which == K_LINEARIZE) linearize_kernel<REG, LOSS><<<grid, kBlock, 0, st>>>(P, partials);
+    else if (which == K_ERROR) error_kernel<REG, LOSS><<<grid, kBlock, 0, st>>>(P, partials);
+    else weights_kernel<REG, LOSS><<<grid, kBlock, 0, st>>>(P, weights);
+}
+template <int REG>
+bool launch_loss(Which which, int loss, const KParams& P, float* partials, float* weights, unsigned grid,
+                 hipStream_t st) {
+    switch (loss) {  // Registration::dispatch (registration.hpp:372-405)
+        case SP_LOSS_NONE: launch_one<REG, LOSS_NONE>(which, P, partials, weights, grid, st); return true;
+        case SP_LOSS_HUBER: launch_one<REG, LOSS_HUBER>(which, P, partials, weights, grid, st); return true;
+        case SP_LOSS_TUKEY: launch_one<REG, LOSS_TUKEY>(which, P, partials, weights, grid, st); return true;
+        case SP_LOSS_CAUCHY: launch_one<REG, LOSS_CAUCHY>(which, P, partials, weights, grid, st); return true;
+        case SP_LOSS_GEMAN_MCCLURE: launch_one<REG, LOSS_GEMAN_MCCLURE>(which, P, partials, weights, grid, st); return true;
+    }
+    return false;
+}
+bool launch_reg(Which which, int reg, int loss, const KParams& P, float* partials, float* weights, unsigned grid,
+                hipStream_t st) {
+    switch (reg) {
+        case SP_REG_POINT_TO_POINT: return launch_loss<SP_REG_POINT_TO_POINT>(which, loss, P, partials, weights, grid, st);
+        case SP_REG_POINT_TO_PLANE: return launch_loss<SP_REG_POINT_TO_PLANE>(which, loss, P, partials, weights, grid, st);
+        case SP_REG_POINT_TO_DISTRIBUTION: return launch_loss<SP_REG_POINT_TO_DISTRIBUTION>(which, loss, P, partials, weights, grid, st);
+        case SP_REG_GICP: return launch_loss<SP_REG_GICP>(which, loss, P, partials, weights, grid, st);
+        case SP_REG_GENZ: return launch_loss<SP_REG_GENZ>(which, loss, P, partials, weights, grid, st);
+    }
+    return false;
+}
+
+// validate_params (registration.hpp:129-193): which attribute arrays a reg_type needs.
+int validate(const sp_factor_params* fp, const float* scov, const float* tcov, const float* tnrm) {
+    if (!fp) return SP_ERR_INVALID_ARGUMENT;
+    if (fp->reg_type == SP_REG_GICP && (!scov || !tcov)) {
+        sp_set_error("[Registration::validate_params] Covariance matrices of source and target must be pre-computed "
+                     "before performing GICP matching.");
+        return SP_ERR_RUNTIME;
+    }
+    if (fp->reg_type == SP_REG_POINT_TO_DISTRIBUTION && !tcov) {
+        sp_set_error("[Registration::validate_params] Covariance matrices of target must be pre-computed before "
+                     "performing Point-to-Distribution ICP matching.");
+        return SP_ERR_RUNTIME;
+    }
+    if (fp->reg_type == SP_REG_GENZ && (!tcov || !tnrm)) {
+        sp_set_error("[Registration::validate_params] Covariance matrices and normals of target must be pre-computed "
+                     "before performing GenZ-ICP matching.");
+        return SP_ERR_RUNTIME;
+    }
+    if (fp->reg_type == SP_REG_POINT_TO_PLANE && !tnrm) {
+        sp_set_error("[Registration::validate_params] Normal vector of target must be pre-computed before performing "
+                     "Point-to-Plane ICP matching.");
+        return SP_ERR_RUNTIME;
+    }
+    return SP_OK;
+}
+
+int run_reduction(Which which, const float* src, const float* scov, size_t n, const float* tgt, const float* tcov,
+                  const float* tnrm, const int32_t* nn_idx, const float* nn_d2, const float* T, int T_dev,
+                  const sp_factor_params* fp, sp_linearized* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int v = validate(fp, scov, tcov, tnrm);
+    if (v != SP_OK) return v;
+    if (n >= (1ull << 32)) { sp_set_error("[Registration] more than 2^32 source points"); return SP_ERR_INVALID_ARGUMENT; }
+    if (n == 0) return hip_status(hipMemsetAsync(out, 0, sizeof(sp_linearized), st));
+    if (!ws || ws_bytes < sp_gicp_workspace_bytes(n)) {
+        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    const KParams P = make_params(src, scov, n, tgt, tcov, tnrm, nn_idx, nn_d2, T, T_dev, fp);
+    const unsigned grid = reduce_grid(n);
+    float* partials = static_cast<float*>(ws);
+    if (!launch_reg(which, fp->reg_type, fp->robust_type, P, partials, nullptr, grid, st)) {
+        sp_set_error("[Registration::dispatch] Combination not found in tags!");
+        return SP_ERR_RUNTIME;
+    }
+    final_reduce_kernel<<<1, kBlock, 0, st>>>(partials, grid, which == K_LINEARIZE ? kAcc - 1 : 1, out);
+    return launch_status();
+}
+
+}  // namespace
+}  // namespace sp
+
+extern "C" size_t sp_gicp_workspace_bytes(size_t n) { return (size_t)sp::kMaxBlocks * sp::kPartial * sizeof(float); }
+
+extern "C" int sp_gicp_linearize(const float* src_points, const float* src_covs, size_t n, const float* tgt_points,
+                                 const float* tgt_covs, const float* tgt_normals, const int32_t* nn_idx,
+                                 const float* nn_d2, const float* transT, int transT_on_device,
+                                 const sp_factor_params* params, sp_linearized* out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    return sp::run_reduction(sp::K_LINEARIZE, src_points, src_covs, n, tgt_points, tgt_covs, tgt_normals, nn_idx, nn_d2,
+                             transT, transT_on_device, params, out, workspace, workspace_bytes, sp::as_stream(stream));
+}
+extern "C" int sp_gicp_error(const float* src_points, const float* src_covs, size_t n, const float* tgt_points,
+                             const float* tgt_covs, const float* tgt_normals, const int32_t* nn_idx, const float* nn_d2,
+                             const float* transT, int transT_on_device, const sp_factor_params* params,
+                             sp_linearized* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return sp::run_reduction(sp::K_ERROR, src_points, src_covs, n, tgt_points, tgt_covs, tgt_normals, nn_idx, nn_d2,
+                             transT, transT_on_device, params, out, workspace, workspace_bytes, sp::as_stream(stream));
+}
+extern "C" int sp_icp_robust_weights(const float* src_points, const float* src_covs, size_t n, const float* tgt_points,
+                                     const float* tgt_covs, const float* tgt_normals, const int32_t* nn_idx,
+                                     const float* nn_d2, const float* transT, int transT_on_device,
+                                     const sp_factor_params* params, float* weights_out, void* stream) {
+    using namespace sp;
+    const int v = validate(params, src_covs, tgt_covs, tgt_normals);
+    if (v != SP_OK) return v;
+    if (n == 0) return SP_OK;
+    const KParams P = make_params(src_points, src_covs, n, tgt_points, tgt_covs, tgt_normals, nn_idx, nn_d2, transT,
+                                  transT_on_device, params);
+    if (!launch_reg(K_WEIGHTS, params->reg_type, params->robust_type, P, nullptr, weights_out, stream_grid(n),
+                    as_stream(stream))) {
+        sp_set_error("[Registration::dispatch] Combination not found in tags!");
+        return SP_ERR_RUNTIME;
+    }
+    return launch_status();
+}
+extern "C" int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn_d2, size_t n, float max_corr,
+                              float planarity_threshold, uint32_t* counts_out, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(counts_out, 0, 8, st) != hipSuccess) return SP_ERR_HIP;
+    if (n == 0) return SP_OK;
+    genz_counts_kernel<<<reduce_grid(n), kBlock, 0, st>>>(reinterpret_cast<const float4*>(tgt_covs), nn_idx, nn_d2,
+                                                          (unsigned)n, max_corr * max_corr, planarity_threshold,
+                                                          counts_out);
+    return launch_status();
+}
+extern "C" int sp_gn_update(sp_linearized* lin, float* T_dev, float lambda, float crit_rotation, float crit_translation,
+                            float* delta_out8, void* stream) {
+    sp::gn_update_kernel<<<1, 64, 0, sp::as_stream(stream)>>>(lin, T_dev, lambda, crit_rotation, crit_translation,
+                                                              delta_out8);
+    return sp::launch_status();
+}
+extern "C" int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, float lambda, float crit_rotation,
+                                 float crit_translation, float* delta_out8_host) {
+    sp_linearized tmp = *lin_host;
+    sp::gn_update_impl(&tmp, T_host, lambda, crit_rotation, crit_translation, delta_out8_host, false);
+    return SP_OK;
+}

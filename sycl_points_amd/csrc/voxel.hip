@@ -1,0 +1,305 @@
+// K9 + voxel aggregation, K10 box filter and flag compaction for gfx950
+// (replaces algorithms/common/voxel_constants.hpp:36-62, filter/voxel_downsampling.hpp:50-79,146-288,
+//  filter/preprocess_operator/{common.hpp:15-25, box_filter_operator.hpp:36-44}, common/filter_by_flags.hpp:30-99).
+//
+// The reference computes keys on the device, then copies them to the host, std::sort's an index array and walks
+// the runs sequentially. Here everything stays in HBM:
+//   keys (24 B/pt) -> device LSD radix sort of (key u64, index u32) -> one pass that finds run heads and lets the
+//   head lane sum its run in ascending point-index order (the sort is stable) -> exclusive scan of keep flags ->
+//   scatter in ascending key order.
+// Sort and scan use rocPRIM's device primitives (radix_sort_pairs / exclusive_scan); the key, aggregation and
+// scatter kernels are written here. Headline algorithmic bytes: 40 B/pt (key kernel + one aggregation pass).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "sp_common.h"
+#include "sp_math.h"
+
+void sp_set_error(const char* msg);
+
+namespace sp {
+namespace {
+
+constexpr uint64_t kInvalidKey = ~0ull;  // VoxelConstants::invalid_coord
+
+// filter::kernel::compute_voxel_bit (voxel_constants.hpp:36-62)
+__device__ __forceinline__ uint64_t voxel_key(const float4 p, float inv) {
+    constexpr int64_t mask = (1 << 21) - 1;
+    constexpr int64_t offset = 1 << 20;
+    if (!isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z)) return kInvalidKey;
+    const int64_t c0 = (int64_t)floorf(p.x * inv) + offset;
+    const int64_t c1 = (int64_t)floorf(p.y * inv) + offset;
+    const int64_t c2 = (int64_t)floorf(p.z * inv) + offset;
+    if (c0 < 0 || mask < c0 || c1 < 0 || mask < c1 || c2 < 0 || mask < c2) return kInvalidKey;
+    return ((uint64_t)(c0 & mask)) | ((uint64_t)(c1 & mask) << 21) | ((uint64_t)(c2 & mask) << 42);
+}
+
+__global__ __launch_bounds__(kBlock) void key_kernel(const float4* __restrict__ pts, unsigned n, float inv,
+                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        keys[i] = voxel_key(pts[i], inv);
+        if (vals) vals[i] = i;
+    }
+}
+
+// VoxelGrid::compute_median (voxel_downsampling.hpp:82-98) without a scratch array: the element of rank r in a run
+// is the one with exactly r elements ordered before it ((value, position) lexicographic). O(L^2) per run.
+__device__ float run_select(const float* __restrict__ inten, const uint32_t* __restrict__ sv, unsigned b, unsigned e,
+                            unsigned rank) {
+    for (unsigned a = b; a < e; ++a) {
+        const float va = inten[sv[a]];
+        unsigned before = 0;
+        for (unsigned c = b; c < e; ++c) {
+            const float vc = inten[sv[c]];
+            before += (vc < va || (vc == va && c < a)) ? 1u : 0u;
+        }
+        if (before == rank) return va;
+    }
+    return 0.0f;
+}
+
+struct AggPtrs {
+    const float4* rgb;
+    const float* inten;
+    const float* ts;
+    float4* t_rgb;
+    float* t_inten;
+    float* t_ts;
+};
+
+// One lane per sorted position; the head lane of a run owns the whole run (voxel_downsampling.hpp:194-208,243-268).
+__global__ __launch_bounds__(kBlock) void aggregate_kernel(const uint64_t* __restrict__ sk,
+                                                           const uint32_t* __restrict__ sv, unsigned n,
+                                                           const float4* __restrict__ pts, float min_count, AggPtrs a,
+                                                           float4* __restrict__ t_pts, uint32_t* __restrict__ flag) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = sk[i];
+    const bool head = key != kInvalidKey && (i == 0 || sk[i - 1] != key);
+    uint32_t keep = 0;
+    if (head) {
+        float px = 0.0f, py = 0.0f, pz = 0.0f, pw = 0.0f;
+        float cx = 0.0f, cy = 0.0f, cz = 0.0f, cw = 0.0f, tsum = 0.0f;
+        unsigned e = i;
+        while (e < n && sk[e] == key) {
+            const uint32_t src = sv[e];
+            const float4 p = pts[src];
+            px += p.x; py += p.y; pz += p.z; pw += p.w;
+            if (a.rgb) { const float4 c = a.rgb[src]; cx += c.x; cy += c.y; cz += c.z; cw += c.w; }
+            if (a.ts) tsum += a.ts[src];
+            ++e;
+        }
+        if (pw >= min_count) {
+            keep = 1;
+            t_pts[i] = make_float4(px / pw, py / pw, pz / pw, pw / pw);
+            if (a.rgb) a.t_rgb[i] = make_float4(cx / pw, cy / pw, cz / pw, cw / pw);
+            if (a.ts) a.t_ts[i] = tsum / pw;
+            if (a.inten) {
+                const unsigned L = e - i, mid = L / 2;
+                const float upper = run_select(a.inten, sv, i, e, mid);
+                a.t_inten[i] = (L & 1u) ? upper : 0.5f * (run_select(a.inten, sv, i, e, mid - 1) + upper);
+            }
+        }
+    }
+    flag[i] = keep;
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restrict__ flag,
+                                                         const uint32_t* __restrict__ pos, unsigned n,
+                                                         const uint64_t* __restrict__ sk,
+                                                         const float4* __restrict__ t_pts, AggPtrs a,
+                                                         float4* __restrict__ o_pts, float4* __restrict__ o_rgb,
+                                                         float* __restrict__ o_inten, float* __restrict__ o_ts,
+                                                         uint64_t* __restrict__ o_keys, uint32_t* __restrict__ n_out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t f = flag[i], p = pos[i];
+    if (f) {
+        o_pts[p] = t_pts[i];
+        if (a.rgb) o_rgb[p] = a.t_rgb[i];
+        if (a.inten) o_inten[p] = a.t_inten[i];
+        if (a.ts) o_ts[p] = a.t_ts[i];
+        if (o_keys) o_keys[p] = sk[i];
+    }
+    if (i == n - 1) *n_out = p + f;
+}
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct VoxelWs {
+    size_t keys_in, keys_out, vals_in, vals_out, flag, pos, t_pts, t_rgb, t_inten, t_ts, prim, prim_bytes, total;
+};
+
+VoxelWs voxel_ws(size_t n) {
+    VoxelWs w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes); return at; };
+    w.keys_in = take(n * 8); w.keys_out = take(n * 8);
+    w.vals_in = take(n * 4); w.vals_out = take(n * 4);
+    w.flag = take(n * 4); w.pos = take(n * 4);
+    w.t_pts = take(n * 16); w.t_rgb = take(n * 16); w.t_inten = take(n * 4); w.t_ts = take(n * 4);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
+    (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n,
+                                  rocprim::plus<uint32_t>(), (hipStream_t)0);
+    w.prim_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    w.prim = take(w.prim_bytes);
+    w.total = o;
+    return w;
+}
+
+// ---- box filter (K10) and stable compaction
+__global__ __launch_bounds__(kBlock) void box_filter_kernel(const float4* __restrict__ pts, unsigned n, float mn,
+                                                            float mx, uint8_t* __restrict__ flags) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    uint8_t f = 1;
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w))) {
+        f = 0;
+    } else {
+        const float linf = sycl_max(fabsf(p.x), sycl_max(fabsf(p.y), fabsf(p.z)));
+        if (linf < mn || linf > mx) f = 0;
+    }
+    flags[i] = f;
+}
+__global__ __launch_bounds__(kBlock) void widen_flags_kernel(const uint8_t* __restrict__ flags, unsigned n,
+                                                             uint32_t* __restrict__ wide) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) wide[i] = flags[i] == 1 ? 1u : 0u;  // INCLUDE_FLAG == 1 (filter_by_flags.hpp:12)
+}
+__global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restrict__ wide,
+                                                         const uint32_t* __restrict__ pos, unsigned n,
+                                                         const uint32_t* __restrict__ rows, unsigned row_dwords,
+                                                         uint32_t* __restrict__ rows_out, int32_t* __restrict__ new_idx,
+                                                         uint32_t* __restrict__ n_out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t f = wide[i], p = pos[i];
+    if (f && rows_out)
+        for (unsigned d = 0; d < row_dwords; ++d) rows_out[(size_t)p * row_dwords + d] = rows[(size_t)i * row_dwords + d];
+    if (new_idx) new_idx[i] = f ? (int32_t)p : -1;
+    if (i == n - 1) *n_out = p + f;
+}
+
+size_t scan_bytes_for(size_t n) {
+    size_t b = 0;
+    (void)rocprim::exclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(),
+                                  (hipStream_t)0);
+    return b;
+}
+
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_voxel_keys(const float* points, size_t n, float inv_voxel_size, uint64_t* keys_out, void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    key_kernel<<<stream_grid(n), kBlock, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(points), (unsigned)n,
+                                                                 inv_voxel_size, keys_out, nullptr);
+    return launch_status();
+}
+
+extern "C" size_t sp_voxel_downsample_workspace_bytes(size_t n) { return n ? sp::voxel_ws(n).total : 0; }
+
+extern "C" int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
+                                   const float* rgb, const float* intensities, const float* timestamps,
+                                   float* points_out, float* rgb_out, float* intensities_out, float* timestamps_out,
+                                   uint64_t* keys_out_opt, uint32_t* n_out_dev, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (!(inv_voxel_size > 0.0f)) {
+        sp_set_error("voxel_size must be positive");  // voxel_downsampling.hpp:23-25
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return hip_status(hipMemsetAsync(n_out_dev, 0, 4, st));
+    if (n >= (1ull << 32)) {
+        sp_set_error("[VoxelGrid::downsampling] more than 2^32 points");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    const VoxelWs w = voxel_ws(n);
+    if (!workspace || workspace_bytes < w.total) {
+        sp_set_error("[VoxelGrid::downsampling] workspace too small (sp_voxel_downsample_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    char* base = static_cast<char*>(workspace);
+    uint64_t* keys_in = (uint64_t*)(base + w.keys_in);
+    uint64_t* keys_sorted = (uint64_t*)(base + w.keys_out);
+    uint32_t* vals_in = (uint32_t*)(base + w.vals_in);
+    uint32_t* vals_sorted = (uint32_t*)(base + w.vals_out);
+    uint32_t* flag = (uint32_t*)(base + w.flag);
+    uint32_t* pos = (uint32_t*)(base + w.pos);
+    float4* t_pts = (float4*)(base + w.t_pts);
+    const float4* pts = reinterpret_cast<const float4*>(points);
+
+    key_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, keys_in, vals_in);
+    size_t prim_bytes = w.prim_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(base + w.prim, prim_bytes, keys_in, keys_sorted, vals_in, vals_sorted, n,
+                                             0, 64, st);
+    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+
+    AggPtrs a;
+    a.rgb = reinterpret_cast<const float4*>(rgb);
+    a.inten = intensities;
+    a.ts = timestamps;
+    a.t_rgb = (float4*)(base + w.t_rgb);
+    a.t_inten = (float*)(base + w.t_inten);
+    a.t_ts = (float*)(base + w.t_ts);
+    aggregate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(keys_sorted, vals_sorted, (unsigned)n, pts,
+                                                           (float)min_voxel_count, a, t_pts, flag);
+    prim_bytes = w.prim_bytes;
+    e = rocprim::exclusive_scan(base + w.prim, prim_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st);
+    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    scatter_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(flag, pos, (unsigned)n, keys_sorted, t_pts, a,
+                                                         reinterpret_cast<float4*>(points_out),
+                                                         reinterpret_cast<float4*>(rgb_out), intensities_out,
+                                                         timestamps_out, keys_out_opt, n_out_dev);
+    return launch_status();
+}
+
+extern "C" int sp_box_filter_flags(const float* points, size_t n, float min_distance, float max_distance,
+                                   uint8_t* flags_out, void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    box_filter_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(points),
+                                                                           (unsigned)n, min_distance, max_distance,
+                                                                           flags_out);
+    return launch_status();
+}
+
+extern "C" size_t sp_compact_workspace_bytes(size_t n) {
+    if (n == 0) return 0;
+    return sp::align_up(n * 4) * 2 + sp::align_up(sp::scan_bytes_for(n));
+}
+
+extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes, const uint8_t* flags, void* rows_out,
+                                   int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (n == 0) return hip_status(hipMemsetAsync(n_out_dev, 0, 4, st));
+    if (row_bytes % 4 != 0 || n >= (1ull << 31)) {
+        sp_set_error("[FilterByFlags] row_bytes must be a multiple of 4 and n < 2^31");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (!workspace || workspace_bytes < sp_compact_workspace_bytes(n)) {
+        sp_set_error("[FilterByFlags] workspace too small (sp_compact_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    char* base = static_cast<char*>(workspace);
+    uint32_t* wide = (uint32_t*)base;
+    uint32_t* pos = (uint32_t*)(base + align_up(n * 4));
+    void* prim = base + 2 * align_up(n * 4);
+    size_t prim_bytes = scan_bytes_for(n);
+    widen_flags_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(flags, (unsigned)n, wide);
+    const hipError_t e = rocprim::exclusive_scan(prim, prim_bytes, wide, pos, 0u, n, rocprim::plus<uint32_t>(), st);
+    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    compact_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(wide, pos, (unsigned)n, static_cast<const uint32_t*>(rows),
+                                                         (unsigned)(row_bytes / 4), static_cast<uint32_t*>(rows_out),
+                                                         new_indices_out_opt, n_out_dev);
+    return launch_status();
+}
