@@ -332,31 +332,38 @@ __global__ __launch_bounds__(kBlock) void weights_kernel(KParams P, float* __res
     }
 }
 
-// Second stage: one workgroup sums the per-workgroup partials in a fixed order.
-// nv = number of float slots (28 for K11, 1 for K12); slot nv holds the uint32 count.
-__global__ __launch_bounds__(kBlock) void final_reduce_kernel(const float* __restrict__ partials, unsigned nblocks,
-                                                              int nv, sp_linearized* __restrict__ out) {
-    __shared__ float red[8][kPartial];
-    const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts x 32 slots
-    const unsigned per = (nblocks + 7) / 8;
+// Second stage: one workgroup of 1024 lanes sums the per-workgroup partials in a fixed order:
+// lane = (part, slot); a part covers a contiguous range of workgroups (independent loads, summed in order),
+// then lanes 0..31 add the 32 parts in order. nv = number of float slots (28 for K11, 1 for K12); slot nv holds the
+// uint32 count.
+constexpr int kFinalThreads = 1024;
+__global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float* __restrict__ partials,
+                                                                     unsigned nblocks, int nv,
+                                                                     sp_linearized* __restrict__ out) {
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    constexpr unsigned kParts = kFinalThreads / 32;
+    const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const unsigned per = (nblocks + kParts - 1) / kParts;
     const unsigned lo = part * per, hi = min(nblocks, lo + per);
     float s = 0.0f;
     unsigned c = 0;
+    const bool is_count = ((int)e == nv);
+#pragma unroll 8
     for (unsigned b = lo; b < hi; ++b) {
         const float v = partials[(size_t)b * kPartial + e];
-        if ((int)e < nv) s += v;
-        else if ((int)e == nv) c += __float_as_uint(v);
+        if (is_count) c += __float_as_uint(v);
+        else s += v;
     }
-    red[part][e] = ((int)e == nv) ? __uint_as_float(c) : s;
+    red[part][e] = is_count ? __uint_as_float(c) : s;
     __syncthreads();
     if (threadIdx.x < 32) {
         float t = 0.0f;
         unsigned ct = 0;
-        for (int p = 0; p < 8; ++p) {
-            if ((int)e == nv) ct += __float_as_uint(red[p][e]);
+        for (unsigned p = 0; p < kParts; ++p) {
+            if (is_count) ct += __float_as_uint(red[p][e]);
             else t += red[p][e];
         }
-        red[0][e] = ((int)e == nv) ? __uint_as_float(ct) : t;
+        red[0][e] = is_count ? __uint_as_float(ct) : t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -400,7 +407,7 @@ __global__ void genz_counts_kernel(const float4* __restrict__ tcov, const int32_
 // optimize_gauss_newton (registration.hpp:803-828) + solve_linear_system (:791-801) + is_converged (:407-410)
 __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, float lambda, float crit_rot,
                                                float crit_trans, float* delta_out8, bool fold_inlier) {
-    if (fold_inlier) lin->inlier = (uint32_t)(lin->inlier_hi * 4096.0f + lin->inlier_lo);
+    if (fold_inlier) lin->inlier = (uint32_t)lin->inlier_hi * 4096u + (uint32_t)lin->inlier_lo;  // integer fold: exact
     float H[36], nb[6], delta[6];
     for (int i = 0; i < 36; ++i) H[i] = lin->H[i];
     for (int i = 0; i < 6; ++i) {
@@ -530,7 +537,7 @@ int run_reduction(Which which, const float* src, const float* scov, size_t n, co
         sp_set_error("[Registration::dispatch] Combination not found in tags!");
         return SP_ERR_RUNTIME;
     }
-    final_reduce_kernel<<<1, kBlock, 0, st>>>(partials, grid, which == K_LINEARIZE ? kAcc - 1 : 1, out);
+    final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, which == K_LINEARIZE ? kAcc - 1 : 1, out);
     return launch_status();
 }
 

@@ -1,0 +1,39 @@
+"""Multi-GPU sharding rules of the GICP path: contiguous source tiles, replicated target, one
+all-reduce of the 192-byte linear system per iteration. Pure host logic, importable without a GPU."""
+import numpy as np
+
+LIN_FLOATS = 48          # sizeof(sp_linearized) / 4
+IDX_ERROR, IDX_INLIER_U32, IDX_LO, IDX_HI = 42, 43, 44, 45
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous index range [lo, hi) of `rank`: tiles differ by at most one point."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def split_count(count):
+    """Inlier count as two floats that stay exact under a float sum over ranks (count = hi * 4096 + lo)."""
+    return float(count & 4095), float(count >> 12)
+
+
+def fold_count(lo, hi):
+    return int(np.float32(hi)) * 4096 + int(np.float32(lo))  # integer fold, as sp_gn_update does
+
+
+def pack_linearized(H, b, error, inlier):
+    """Host image of sp_linearized as 48 floats (what final_reduce_kernel writes on the device)."""
+    buf = np.zeros(LIN_FLOATS, np.float32)
+    buf[:36] = np.asarray(H, np.float32).reshape(-1)
+    buf[36:42] = np.asarray(b, np.float32)
+    buf[IDX_ERROR] = np.float32(error)
+    buf[IDX_INLIER_U32:IDX_INLIER_U32 + 1].view(np.uint32)[0] = np.uint32(inlier)
+    buf[IDX_LO], buf[IDX_HI] = split_count(int(inlier))
+    return buf
+
+
+def unpack_linearized(buf):
+    buf = np.asarray(buf, np.float32)
+    return {"H": buf[:36].reshape(6, 6).copy(), "b": buf[36:42].copy(), "error": float(buf[IDX_ERROR]),
+            "inlier": fold_count(buf[IDX_LO], buf[IDX_HI])}

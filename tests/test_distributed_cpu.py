@@ -1,0 +1,101 @@
+"""N > 1 path on CPU: two gloo ranks shard the source cloud, each linearises its tile (the oracle stands in for the
+K11 kernel, which needs a GPU), the 192-byte systems are all-reduced, and every rank applies the identical
+Gauss-Newton update through the product's host solver. The result must equal the single-process run to rounding and
+the inlier count must be exact."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sycl_points_amd import sharding
+
+
+def test_shard_ranges_cover_exactly():
+    for n, w in ((10, 3), (1_000_000, 8), (7, 8), (0, 2), (8_000_001, 8)):
+        r = [sharding.shard_range(n, k, w) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_count_split_is_exact_under_float_sum():
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        counts = rs.randint(0, 40_000_000, size=8)
+        lo = np.float32(0)
+        hi = np.float32(0)
+        for c in counts:
+            l, h = sharding.split_count(int(c))
+            lo = np.float32(lo + np.float32(l))
+            hi = np.float32(hi + np.float32(h))
+        assert sharding.fold_count(lo, hi) == int(counts.sum())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, iters, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import Oracle
+    from sycl_points_amd import _lib
+    from sycl_points_amd.synthetic import gicp_pair
+
+    orc = Oracle()
+    orc.set_num_threads(2)
+    L = _lib.lib()
+    src, tgt, _ = gicp_pair(n, 10.0 * (n / 1e6) ** (1.0 / 3.0))
+    nodes_t, nodes_s = orc.kdtree_build(tgt), orc.kdtree_build(src)
+    tcov = orc.cov_estimate(tgt, orc.kdtree_knn(nodes_t, tgt, 20)[0])
+    scov = orc.cov_estimate(src, orc.kdtree_knn(nodes_s, src, 20)[0])
+    lo, hi = sharding.shard_range(n, rank, world)           # source tile of this rank; target replicated
+    T = np.ascontiguousarray(np.eye(4, dtype=np.float32).T).reshape(-1)   # column-major pose
+    for _ in range(iters):
+        Tm = T.reshape(4, 4).T
+        idx, d2 = orc.kdtree_knn(nodes_t, src[lo:hi], 1, Tm)
+        part = orc.gicp_linearize(src[lo:hi], scov[lo:hi], tgt, tcov, None, idx, d2, Tm)
+        buf = torch.from_numpy(sharding.pack_linearized(part["H"], part["b"], part["error"], part["inlier"]))
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)          # the only exchange of the iteration
+        tot = sharding.unpack_linearized(buf.numpy())
+        lin = _lib.Linearized()
+        for i in range(36):
+            lin.H[i] = float(tot["H"].reshape(-1)[i])
+        for i in range(6):
+            lin.b[i] = float(tot["b"][i])
+        lin.error, lin.inlier = tot["error"], tot["inlier"]
+        d8 = np.zeros(8, np.float32)
+        L.sp_gn_update_host(C.byref(lin), T.ctypes.data_as(C.c_void_p), 1.0, 0.0, 0.0, d8.ctypes.data_as(C.c_void_p))
+    np.save(out_path % rank, np.concatenate([T, [np.float32(tot["inlier"])]]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_gicp_matches_single_process(tmp_path, orc):
+    from oracle.pyoracle import RegParams
+    from sycl_points_amd.synthetic import gicp_pair
+
+    n, iters, world = 6000, 5, 2
+    out = str(tmp_path / "rank%d.npy")
+    mp.spawn(_worker, args=(world, _free_port(), n, iters, out), nprocs=world, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert np.array_equal(r0, r1)                            # every rank holds the identical pose
+    src, tgt, T_gt = gicp_pair(n, 10.0 * (n / 1e6) ** (1.0 / 3.0))
+    tcov = orc.cov_estimate(tgt, orc.kdtree_knn(orc.kdtree_build(tgt), tgt, 20)[0])
+    scov = orc.cov_estimate(src, orc.kdtree_knn(orc.kdtree_build(src), src, 20)[0])
+    p = RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=iters)
+    ref = orc.registration_align(p, src, scov, tgt, tcov)
+    T2 = r0[:16].reshape(4, 4).T
+    assert np.abs(T2 - ref["T"]).max() < 1e-5                # sharded == unsharded to rounding
+    assert int(r0[16]) == ref["inlier"] == n
+    assert np.abs(T2 - T_gt).max() < 2e-3
