@@ -27,6 +27,7 @@ PER_GPU_POINTS = 1_000_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 BYTES_NN = 24          # in-loop NN k=1 lower bound (16 B query + 8 B result)
 BYTES_K11 = 168        # K11 per source point at the API layouts
+BYTES_ITER = 192       # one GICP iteration (NN 24 B + K11 168 B) per correspondence
 
 
 def parse():
@@ -35,6 +36,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=PER_GPU_POINTS, help="source points per GPU (default: the config)")
+    ap.add_argument("--path", choices=["fused", "generic"], default="fused",
+                    help="fused: GridKNN + prepared covariances, NN+K11 in one kernel; generic: KNNBase search + K11")
+    ap.add_argument("--nn", choices=["grid", "kdtree"], default="grid", help="KNNBase used by --path generic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline sample")
     return ap.parse_args()
@@ -89,14 +93,29 @@ def main():
     T_ident = torch.eye(4, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     delta = torch.zeros(8, dtype=torch.float32, device=dev)
     group = dist.group.WORLD if world > 1 else None
+    # NN structure on the (replicated) target: part of target preprocessing, like the reference's KDTree::build
+    grid = sp.GridKNN.build(Tg.points) if (args.path == "fused" or args.nn == "grid") else None
+    knn = grid if args.nn == "grid" else ttree
+    prep = sp.PreparedTarget(grid, Tg.covs) if args.path == "fused" else None
+    torch.cuda.synchronize()
+
+    def align_chunk(iters, first):
+        if args.path == "fused":
+            # the per-alignment preparation (plane regularisation of source and target covariances) is inside the
+            # timed region, once per alignment
+            reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta,
+                                 src_covp=None if first else reg._src_covp)
+        else:
+            reg.align_device_loop(S, Tg, knn, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta)
 
     def run_steps(k):
         done = 0
         while done < k:
-            if done % ITERS_PER_ALIGN == 0:
+            first = done % ITERS_PER_ALIGN == 0
+            if first:
                 T_dev.copy_(T_ident)  # a new alignment starts from the identity initial guess
             chunk = min(ITERS_PER_ALIGN - done % ITERS_PER_ALIGN, k - done)
-            reg.align_device_loop(S, Tg, ttree, iterations=chunk, group=group, T_dev=T_dev, delta_dev=delta)
+            align_chunk(chunk, first)
             done += chunk
 
     def fence():
@@ -117,14 +136,14 @@ def main():
 
     # ---- correctness of what was timed: pose after a full alignment vs the ground truth used to make the data
     T_dev.copy_(T_ident)
-    reg.align_device_loop(S, Tg, ttree, iterations=ITERS_PER_ALIGN, group=group, T_dev=T_dev, delta_dev=delta)
+    align_chunk(ITERS_PER_ALIGN, True)
     torch.cuda.synchronize()
     T_final = reg.T_from_device(T_dev)
     lin = reg._read_lin(reg._lin)
     pose_err = float(np.abs(T_final - T_gt).max())
 
     # ---- per-kernel durations, measured live with events on the launch stream (same stream torch uses)
-    kern = kernel_times(sp, torch, reg, S, Tg, ttree, T_dev, n_gpu)
+    kern = kernel_times(sp, torch, args, reg, S, Tg, knn, prep, T_dev, delta, n_gpu)
 
     out = None
     if rank == 0:
@@ -146,7 +165,8 @@ def main():
             "config": {"workload": f"GICP {n_total}-vs-{n_total} uniform-random clouds (BASELINE config "
                                    f"{'4' if world == 1 else '5 generalised'}), k=20 covariances, GN lambda=1, "
                                    f"max_corr 2.0, robust NONE, {ITERS_PER_ALIGN} iterations per alignment",
-                       "source_points_per_gpu": n_gpu, "target_points": n_total, "nn": "kdtree(k=1)",
+                       "source_points_per_gpu": n_gpu, "target_points": n_total,
+                       "path": args.path, "nn": "grid(k=1)" if (args.path == "fused" or args.nn == "grid") else "kdtree(k=1)",
                        "sharding": "source tile-sharded, target replicated" if world > 1 else "none"},
             "iterations_per_sec": args.steps / elapsed,
             "pose_max_abs_err_vs_ground_truth": pose_err,
@@ -181,8 +201,9 @@ def _cov_from(sp, all_points, idx):
     return covs
 
 
-def kernel_times(sp, torch, reg, S, Tg, ttree, T_dev, n, reps=20):
-    """Average launch duration of the two hot kernels at the converged pose, by HIP events on the launch stream."""
+def kernel_times(sp, torch, args, reg, S, Tg, knn, prep, T_dev, delta, n, reps=20):
+    """Average launch duration of the hot kernels at the converged pose, by HIP events recorded on the stream the
+    kernels are launched on (the C ABI is handed torch's current stream)."""
     res = {}
     scale = reg.params.robust_default_scale
 
@@ -197,10 +218,29 @@ def kernel_times(sp, torch, reg, S, Tg, ttree, T_dev, n, reps=20):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    ms_nn = timed(lambda: ttree.nearest_neighbor_search_async(S, reg.neighbors, T_dev))
-    ms_k11 = timed(lambda: reg._linearize("linearize", S, Tg, T_dev, scale, reg._lin))
-    for name, ms, bpp in (("kdtree_search_k1", ms_nn, BYTES_NN), ("gicp_linearize_reduce", ms_k11, BYTES_K11)):
-        res[name] = {"ms": ms, "bytes": bpp * n, "GBps": bpp * n / (ms * 1e-3) / 1e9}
+    if args.path == "fused":
+        import ctypes as C
+
+        from sycl_points_amd import _lib
+
+        L = _lib.lib()
+        ws, lin = reg._buffers(S.points.device)
+        fp = reg._factor_params(scale)
+        covp = reg._src_covp
+
+        def fused_only():  # gn = NULL: the NN + linearise + reduce launch and the partial-sum launch, no solve
+            _lib.check(L.sp_gicp_iteration_fused(prep._h, sp._ptr(S.points), sp._ptr(covp), n, sp._ptr(T_dev), 1,
+                                                 C.byref(fp), None, None, None, sp._ptr(lin), None, sp._ptr(ws),
+                                                 ws.numel(), sp._stream()))
+
+        ms = timed(fused_only)
+        res["gicp_fused_iteration"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9,
+                                       "note": "gicp_fused_kernel + final_reduce_kernel (2 launches)"}
+    else:
+        ms_nn = timed(lambda: knn.nearest_neighbor_search_async(S, reg.neighbors, T_dev))
+        ms_k11 = timed(lambda: reg._linearize("linearize", S, Tg, T_dev, scale, reg._lin))
+        for name, ms, bpp in (("nn_search_k1", ms_nn, BYTES_NN), ("gicp_linearize_reduce", ms_k11, BYTES_K11)):
+            res[name] = {"ms": ms, "bytes": bpp * n, "GBps": bpp * n / (ms * 1e-3) / 1e9}
     return res
 
 

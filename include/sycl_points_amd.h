@@ -71,6 +71,21 @@ int sp_kdtree_radius_search(const sp_kdtree* tree, const float* queries, size_t 
 int sp_kdtree_remove_by_flags(sp_kdtree* tree, const uint8_t* flags, const int32_t* new_indices, size_t n_flags,
                               void* stream);
 
+/* GridKNN — an MI355X-native KNNBase implementation (no counterpart file in the reference; it plugs into the
+ * KNNBase::knn_search_async seam, algorithms/knn/knn.hpp:14-61, exactly as KDTree / Octree do).
+ * Exact kNN on a uniform cell grid built ON THE DEVICE from device points (bounding box, cell ids, radix sort,
+ * cell_start table): a handful of independent loads per query instead of the KD-tree's chain of dependent node loads.
+ * Results are bit-identical to sp_knn_bruteforce (same distance arithmetic, ties to the lowest index), k <= 20.
+ * sp_grid_create allocates and synchronises. cell_size <= 0: chosen so that a cell holds `points_per_cell` points on
+ * average (<= 0: 2). */
+typedef struct sp_grid sp_grid;
+int sp_grid_create(const float* points, size_t n, float cell_size, float points_per_cell, void* stream, sp_grid** out);
+void sp_grid_destroy(sp_grid* grid);
+size_t sp_grid_size(const sp_grid* grid);
+float sp_grid_cell_size(const sp_grid* grid);
+int sp_grid_search(const sp_grid* grid, const float* queries, size_t nq, size_t k, const float* transT,
+                   int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
+
 /* ------------------------------------------------------------------------------ covariance / normals */
 
 /* covariance::estimate_async (algorithms/feature/covariance.hpp:16-47, 260-311, kernel K5). */
@@ -175,6 +190,31 @@ int sp_icp_robust_weights(const float* src_points, const float* src_covs, size_t
 /* Registration::compute_genz_alpha (registration.hpp:464-511): writes {inlier, planar} counts to counts_out[2]. */
 int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn_d2, size_t n, float max_corr,
                    float planarity_threshold, uint32_t* counts_out, void* stream);
+
+/* Prepared / fused GICP iteration (MI355X-native form of registration.hpp:229-234 = NN search + K11 in one pass).
+ * The reference recomputes covariance::kernel::update_covariance_plane for both covariances of every correspondence in
+ * every iteration (factor.hpp:249-255). The result depends on the covariance alone, so here it is computed once:
+ *   sp_gicp_prepare_source: plane-regularised source covariances, packed 8 floats per point (xx,xy,xz,yy | yz,zz,0,0);
+ *   sp_gicp_target_create : the same for the target, stored in the cell order of `grid` (which must have been built on
+ *                           the target points and must outlive the object); sp_gicp_target_update recomputes in place.
+ *   sp_gicp_iteration_fused: per source point q = T p -> exact NN on the grid -> linearise with the packed
+ *                           covariances -> reduce to *out. If nn_idx_out/nn_d2_out are non-NULL the correspondences
+ *                           are also written (for sp_gicp_error / compute_error_frozen). If `gn` is non-NULL (single-GPU
+ *                           loops) the same launch also solves (H + lambda I) delta = -b and updates the DEVICE pose
+ *                           transT in place, writing delta_out8 as sp_gn_update does; with gn == NULL the caller
+ *                           all-reduces *out over ranks and calls sp_gn_update.
+ * Same mathematics as sp_kdtree_search/sp_grid_search + sp_gicp_linearize; rounding differs (symmetric packing,
+ * upper-triangle H). reg_type must be SP_REG_GICP; every robust loss is supported. */
+typedef struct sp_gicp_target sp_gicp_target;
+typedef struct sp_gn_params { float lambda, crit_rotation, crit_translation; } sp_gn_params;
+int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream, sp_gicp_target** out);
+int sp_gicp_target_update(sp_gicp_target* target, const float* tgt_covs, void* stream);
+void sp_gicp_target_destroy(sp_gicp_target* target);
+int sp_gicp_prepare_source(const float* src_covs, size_t n, float* covp_out, void* stream);
+int sp_gicp_iteration_fused(const sp_gicp_target* target, const float* src_points, const float* src_covp, size_t n,
+                            float* transT, int transT_on_device, const sp_factor_params* params, const sp_gn_params* gn,
+                            int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* out, float* delta_out8,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
  * iteration loop can stay on the stream with no host round trip:

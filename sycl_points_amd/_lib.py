@@ -32,6 +32,10 @@ class FactorParams(C.Structure):  # sp_factor_params
                 ("robust_scale", C.c_float), ("genz_alpha", C.c_float), ("genz_planarity_threshold", C.c_float)]
 
 
+class GnParams(C.Structure):  # sp_gn_params
+    _fields_ = [("lambda_", C.c_float), ("crit_rotation", C.c_float), ("crit_translation", C.c_float)]
+
+
 assert C.sizeof(Linearized) == 192
 
 _vp, _sz, _f, _i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
@@ -50,6 +54,11 @@ SIGNATURES = {
     "sp_kdtree_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
     "sp_kdtree_radius_search": (_i, [_vp, _vp, _sz, _sz, _f, _vp, _i, _vp, _vp, _vp]),
     "sp_kdtree_remove_by_flags": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "sp_grid_create": (_i, [_vp, _sz, _f, _f, _vp, C.POINTER(_vp)]),
+    "sp_grid_destroy": (None, [_vp]),
+    "sp_grid_size": (_sz, [_vp]),
+    "sp_grid_cell_size": (_f, [_vp]),
+    "sp_grid_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
     "sp_cov_estimate": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "sp_normals_from_knn": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "sp_normals_from_cov": (_i, [_vp, _vp, _sz, _vp, _vp]),
@@ -66,6 +75,12 @@ SIGNATURES = {
     "sp_gicp_error": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _sz, _vp]),
     "sp_icp_robust_weights": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp]),
     "sp_genz_counts": (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp, _vp]),
+    "sp_gicp_target_create": (_i, [_vp, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "sp_gicp_target_update": (_i, [_vp, _vp, _vp]),
+    "sp_gicp_target_destroy": (None, [_vp]),
+    "sp_gicp_prepare_source": (_i, [_vp, _sz, _vp, _vp]),
+    "sp_gicp_iteration_fused": (_i, [_vp, _vp, _vp, _sz, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _sz, _vp]),
     "sp_gn_update": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp]),
     "sp_gn_update_host": (_i, [_vp, _vp, _f, _f, _f, _vp]),
     "sp_se3_exp_host": (None, [_vp, _vp]),

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FactorParams, Linearized, SpError, check
+from ._lib import FactorParams, GnParams, Linearized, SpError, check
 
 REG = {"POINT_TO_POINT": 0, "POINT_TO_PLANE": 1, "POINT_TO_DISTRIBUTION": 2, "GICP": 3, "GENZ": 4}
 LOSS = {"NONE": 0, "HUBER": 1, "TUKEY": 2, "CAUCHY": 3, "GEMAN_MCCLURE": 4}
@@ -217,6 +217,45 @@ class KDTree(KNNBase):
         torch.cuda.current_stream().synchronize()
 
 
+class GridKNN(KNNBase):
+    """MI355X-native KNNBase: exact kNN on a device-built uniform grid (csrc/grid.hip); bit-identical to
+    knn_search_bruteforce. `points_per_cell` tunes the cell size (about 2 for k = 1, about 6-8 for k = 20)."""
+
+    def __init__(self, handle, n, device):
+        self._h = handle
+        self.n = n
+        self.device = device
+
+    @staticmethod
+    def build(points, cell_size=0.0, points_per_cell=2.0):
+        p = _dev_f32(_points_of(points), 4)
+        h = C.c_void_p()
+        check(_lib.lib().sp_grid_create(_ptr(p), p.shape[0], cell_size, points_per_cell, _stream(), C.byref(h)))
+        return GridKNN(h, p.shape[0], p.device)
+
+    def cell_size(self):
+        return float(_lib.lib().sp_grid_cell_size(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_grid_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def knn_search_async(self, queries, k, result, transT=None):
+        q = _dev_f32(_points_of(queries), 4)
+        if k > 20:
+            raise SpError(2, "[GridKNN::knn_search_async] `k` is too large (max 20).")
+        result.resize(q.shape[0], k, q.device)
+        if q.shape[0] == 0:
+            return
+        tp, on_dev, keep = _trans_arg(transT)
+        check(_lib.lib().sp_grid_search(self._h, _ptr(q), q.shape[0], k, tp, on_dev, _ptr(result.indices),
+                                        _ptr(result.distances), _stream()))
+
+
 class BruteForceKNN(KNNBase):
     """A KNNBase over knn_search_bruteforce (the reference tests inject such host fakes through the same seam,
     tests/test_registration_pipeline.cpp:16-61). The query transform is applied with sp_transform first."""
@@ -392,6 +431,40 @@ def compact_by_flags(rows, flags, want_indices=False):
                                 nbytes, _stream()))
     v = int(n_out.item())
     return (out[:v], idx) if want_indices else out[:v]
+
+
+class PreparedTarget:
+    """Plane-regularised target covariances stored in the cell order of a GridKNN (sp_gicp_target_*): the target half of
+    the prepared / fused GICP iteration. Holds a reference to the grid, which it borrows."""
+
+    def __init__(self, grid, covs):
+        self.grid = grid
+        self.covs = _dev_f32(covs, 16)
+        h = C.c_void_p()
+        check(_lib.lib().sp_gicp_target_create(grid._h, _ptr(self.covs), self.covs.shape[0], _stream(), C.byref(h)))
+        self._h = h
+
+    def update(self, covs=None):
+        if covs is not None:
+            self.covs = _dev_f32(covs, 16)
+        check(_lib.lib().sp_gicp_target_update(self._h, _ptr(self.covs), _stream()))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_gicp_target_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def prepare_source_covs(covs, out=None):
+    """sp_gicp_prepare_source: (N,16) API covariances -> (N,8) packed plane-regularised covariances."""
+    c = _dev_f32(covs, 16)
+    if out is None:
+        out = torch.empty((c.shape[0], 8), dtype=torch.float32, device=c.device)
+    check(_lib.lib().sp_gicp_prepare_source(_ptr(c), c.shape[0], _ptr(out), _stream()))
+    return out
 
 
 # ------------------------------------------------------------------ registration
@@ -630,6 +703,56 @@ class Registration:
                 dist.all_reduce(lin, op=dist.ReduceOp.SUM, group=group)  # 192 B over xGMI; latency-bound
             check(L.sp_gn_update(_ptr(lin), _ptr(T_dev), p.gn_lambda, p.criteria_rotation, p.criteria_translation,
                                  _ptr(delta_dev), _stream()))
+        return T_dev, lin, delta_dev
+
+    def align_fused_loop(self, source, prepared_target, initial_guess=None, iterations=None, robust_scale=-1.0,
+                         group=None, T_dev=None, delta_dev=None, src_covp=None, write_neighbors=False,
+                         prepare_each_call=True):
+        """The same fixed-length Gauss-Newton loop as align_device_loop on the prepared / fused path
+        (sp_gicp_iteration_fused): one launch per iteration does NN + linearise + reduce, and, on a single GPU, the
+        second (one-workgroup) launch also solves and updates the pose. The per-alignment preparation (plane
+        regularisation of both clouds' covariances) is part of this call unless prepare_each_call is False."""
+        import torch.distributed as dist
+
+        L = _lib.lib()
+        p = self.params
+        if p.reg_type != "GICP" or p.optimization_method != "GN":
+            raise SpError(1, "align_fused_loop implements GICP with the Gauss-Newton optimiser")
+        if not source.has_cov():
+            raise SpError(2, "[Registration::validate_params] Covariance matrices of source and target must be "
+                             "pre-computed before performing GICP matching.")
+        iters = p.max_iterations if iterations is None else iterations
+        scale = robust_scale if robust_scale > 0 else p.robust_default_scale
+        dev = source.points.device
+        ws, lin = self._buffers(dev)
+        n = source.size()
+        if src_covp is None:
+            if getattr(self, "_src_covp", None) is None or self._src_covp.shape[0] != n:
+                self._src_covp = torch.empty((n, 8), dtype=torch.float32, device=dev)
+            src_covp = self._src_covp
+            prepare_source_covs(source.covs, src_covp)
+            if prepare_each_call:
+                prepared_target.update()
+        if T_dev is None:
+            T0 = identity() if initial_guess is None else np.asarray(initial_guess, np.float32)
+            T_dev = torch.from_numpy(_T16(T0).reshape(-1).copy()).to(dev)
+        if delta_dev is None:
+            delta_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+        sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        fp = self._factor_params(scale)
+        gn = GnParams(p.gn_lambda, p.criteria_rotation, p.criteria_translation)
+        if write_neighbors:
+            self.neighbors.resize(n, 1, dev)
+        ni = _ptr(self.neighbors.indices) if write_neighbors else None
+        nd = _ptr(self.neighbors.distances) if write_neighbors else None
+        for _ in range(iters):
+            check(L.sp_gicp_iteration_fused(prepared_target._h, _ptr(source.points), _ptr(src_covp), n, _ptr(T_dev), 1,
+                                            C.byref(fp), None if sharded else C.byref(gn), ni, nd, _ptr(lin),
+                                            _ptr(delta_dev), _ptr(ws), ws.numel(), _stream()))
+            if sharded:
+                dist.all_reduce(lin, op=dist.ReduceOp.SUM, group=group)
+                check(L.sp_gn_update(_ptr(lin), _ptr(T_dev), p.gn_lambda, p.criteria_rotation, p.criteria_translation,
+                                     _ptr(delta_dev), _stream()))
         return T_dev, lin, delta_dev
 
     @staticmethod

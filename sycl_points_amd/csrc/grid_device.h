@@ -1,0 +1,148 @@
+// Device-side pieces of the uniform-grid search shared by grid.hip (GridKNN) and gicp_fused.hip.
+#pragma once
+#include "sp_common.h"
+#include "sp_math.h"
+
+struct sp_grid {
+    size_t n = 0;
+    float h = 1.0f, inv_h = 1.0f, eps = 0.0f;
+    float org[3] = {0, 0, 0};
+    int dims[3] = {1, 1, 1};
+    size_t ncells = 1;
+    float4* d_pts = nullptr;      // n points in cell order, w = original index bits
+    uint32_t* d_start = nullptr;  // ncells + 1
+};
+
+namespace sp {
+
+struct GridDesc {
+    float inv_h, h, eps;
+    float ox, oy, oz;
+    int nx, ny, nz;
+    unsigned n;
+};
+
+inline GridDesc grid_desc(const sp_grid* gr) {
+    return GridDesc{gr->inv_h, gr->h, gr->eps, gr->org[0], gr->org[1], gr->org[2], gr->dims[0], gr->dims[1],
+                    gr->dims[2], (unsigned)gr->n};
+}
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim) {
+    const float t = floorf((v - o) * inv_h);
+    return (int)fminf(fmaxf(t, 0.0f), (float)(dim - 1));
+}
+
+// (distance, index) lexicographic sorted insertion into the first k slots.
+template <int KCAP>
+__device__ __forceinline__ void lex_insert(float (&bd)[KCAP], int (&bi)[KCAP], int k, float d, int idx, float& kth,
+                                           int& kth_idx) {
+    if (KCAP == 1) {
+        const bool better = d < bd[0] || (d == bd[0] && idx < bi[0]);
+        bi[0] = better ? idx : bi[0];
+        bd[0] = better ? d : bd[0];
+        kth = bd[0];
+        kth_idx = bi[0];
+        return;
+    }
+    float cd = d;
+    int ci = idx;
+    bool shifting = false;
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) {
+        if (i < k) {
+            const bool sw = shifting || cd < bd[i] || (cd == bd[i] && ci < bi[i]);
+            const float td = bd[i];
+            const int ti = bi[i];
+            const float nd = sw ? cd : td;
+            const int ni = sw ? ci : ti;
+            bd[i] = nd;
+            bi[i] = ni;
+            cd = sw ? td : cd;
+            ci = sw ? ti : ci;
+            shifting = sw;
+            kth = nd;
+            kth_idx = ni;
+        }
+    }
+}
+
+// squared distance from coordinate v to the interval [lo, hi], made conservative by eps
+__device__ __forceinline__ float gap2(float v, float lo, float hi, float eps) {
+    const float g = fmaxf(fmaxf(lo - v, v - hi) - eps, 0.0f);
+    return g * g;
+}
+
+// Exact nearest neighbour (k = 1) of (qx,qy,qz) on the grid, ties to the lowest original index — the same walk as
+// grid_search_kernel<1>, additionally reporting the winner's position in the cell-ordered point array and its
+// coordinates (so a caller can read per-point data stored in grid order without another gather of the point).
+struct Nearest {
+    float d2;
+    int idx;        // original index of the target point (-1: none)
+    unsigned pos;   // position in grid order
+    float x, y, z;  // its coordinates
+};
+
+__device__ __forceinline__ Nearest grid_nn1(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                            const GridDesc& g, float qx, float qy, float qz) {
+    Nearest best;
+    best.d2 = FLT_MAX; best.idx = -1; best.pos = 0; best.x = best.y = best.z = 0.0f;
+    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return best;
+    const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny),
+              cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+    const int rmax = max(max(g.nx, g.ny), g.nz);
+    auto consider = [&](const float4 p, unsigned pos) {
+        const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
+        const int pi = __float_as_int(p.w);
+        if (d < best.d2 || (d == best.d2 && pi < best.idx)) {
+            best.d2 = d; best.idx = pi; best.pos = pos; best.x = p.x; best.y = p.y; best.z = p.z;
+        }
+    };
+    for (int r = 0; r <= rmax; ++r) {
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const float dz2 = gap2(qz, g.oz + z * g.h, g.oz + (z + 1) * g.h, g.eps);
+            if (dz2 > best.d2) continue;
+            for (int y = y0; y <= y1; ++y) {
+                const float dyz2 = dz2 + gap2(qy, g.oy + y * g.h, g.oy + (y + 1) * g.h, g.eps);
+                if (dyz2 > best.d2) continue;
+                const bool shell_row = (r == 0) || (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+                const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
+                const int nseg = shell_row ? 1 : 2;
+                for (int sgi = 0; sgi < nseg; ++sgi) {
+                    int xa, xb;
+                    if (shell_row) { xa = x0; xb = x1; }
+                    else if (sgi == 0) { xa = cx - r; xb = cx - r; if (xa < 0) continue; }
+                    else { xa = cx + r; xb = cx + r; if (xb > g.nx - 1) continue; }
+                    const float d2box = dyz2 + gap2(qx, g.ox + xa * g.h, g.ox + (xb + 1) * g.h, g.eps);
+                    if (d2box > best.d2) continue;
+                    const unsigned s = start[row + xa], e = start[row + xb + 1];
+                    for (unsigned i = s; i < e; i += 4) {
+                        const float4 p0 = pts[i];
+                        const float4 p1 = pts[min(i + 1, e - 1)];
+                        const float4 p2 = pts[min(i + 2, e - 1)];
+                        const float4 p3 = pts[min(i + 3, e - 1)];
+                        consider(p0, i);
+                        if (i + 1 < e) consider(p1, i + 1);
+                        if (i + 2 < e) consider(p2, i + 2);
+                        if (i + 3 < e) consider(p3, i + 3);
+                    }
+                }
+            }
+        }
+        float cov = FLT_MAX;
+        if (cx - r > 0) cov = fminf(cov, qx - (g.ox + (cx - r) * g.h));
+        if (cx + r < g.nx - 1) cov = fminf(cov, (g.ox + (cx + r + 1) * g.h) - qx);
+        if (cy - r > 0) cov = fminf(cov, qy - (g.oy + (cy - r) * g.h));
+        if (cy + r < g.ny - 1) cov = fminf(cov, (g.oy + (cy + r + 1) * g.h) - qy);
+        if (cz - r > 0) cov = fminf(cov, qz - (g.oz + (cz - r) * g.h));
+        if (cz + r < g.nz - 1) cov = fminf(cov, (g.oz + (cz + r + 1) * g.h) - qz);
+        if (cov == FLT_MAX) break;
+        cov = fmaxf(cov - g.eps, 0.0f);
+        if (best.d2 < cov * cov) break;
+    }
+    return best;
+}
+
+}  // namespace sp

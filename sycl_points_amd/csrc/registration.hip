@@ -10,8 +10,7 @@
 // bit-reproducible from run to run. HBM-bound: 168 B per source point.
 // The factor arithmetic keeps the reference's fma chains (sp_math.h); structural zeros of the padded 4x4/4x6 types
 // are skipped, which leaves every finite result bit-identical.
-#include "sp_common.h"
-#include "sp_math.h"
+#include "grid_device.h"
 
 void sp_set_error(const char* msg);
 
@@ -337,9 +336,17 @@ __global__ __launch_bounds__(kBlock) void weights_kernel(KParams P, float* __res
 // then lanes 0..31 add the 32 parts in order. nv = number of float slots (28 for K11, 1 for K12); slot nv holds the
 // uint32 count.
 constexpr int kFinalThreads = 1024;
+struct GnArgs {  // optional fused Gauss-Newton step (single-GPU loops): T == nullptr -> reduction only
+    float* T;
+    float lambda, crit_rot, crit_trans;
+    float* delta_out8;
+};
+__host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, float lambda, float crit_rot,
+                                               float crit_trans, float* delta_out8, bool fold_inlier);
+
 __global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float* __restrict__ partials,
                                                                      unsigned nblocks, int nv,
-                                                                     sp_linearized* __restrict__ out) {
+                                                                     sp_linearized* __restrict__ out, GnArgs gn) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     constexpr unsigned kParts = kFinalThreads / 32;
     const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float
         out->inlier = cnt;
         out->inlier_lo = (float)(cnt & 4095u);
         out->inlier_hi = (float)(cnt >> 12);
+        if (gn.T) gn_update_impl(out, gn.T, gn.lambda, gn.crit_rot, gn.crit_trans, gn.delta_out8, false);
     }
 }
 
@@ -430,6 +438,117 @@ __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, flo
 __global__ void gn_update_kernel(sp_linearized* lin, float* T, float lambda, float crit_rot, float crit_trans,
                                  float* delta_out8) {
     if (threadIdx.x == 0 && blockIdx.x == 0) gn_update_impl(lin, T, lambda, crit_rot, crit_trans, delta_out8, true);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused GICP iteration on a prepared target (GridKNN + plane-regularised covariances stored in grid order).
+//
+// The reference recomputes update_covariance_plane for the source AND the target covariance of every correspondence
+// in every iteration (factor.hpp:249-255: two eigen-decompositions per point per iteration). The regularised matrix
+// depends only on the covariance itself, so it is computed ONCE per cloud (prepare kernels below) and stored packed
+// (6 unique entries, 32-byte rows). The per-iteration kernel then does, per source point, in one pass:
+//   q = T p  ->  exact NN on the grid (k = 1)  ->  Ct' of the winner read in grid order (next to the points just
+//   scanned)  ->  M = (Ct' + R Cs' R^T)^-1  ->  H (21 unique), b, error accumulated in registers.
+// No neighbour arrays are written or re-read unless the caller asks for them. Algorithmic bytes per correspondence:
+// 192 B (NN 24 + K11 168); actually moved: 16 + 32 (source) + cell extents + scanned points + 32 (Ct').
+// Mathematically identical to K2+K11; numerically the symmetric packing and the upper-triangle H differ from the
+// reference's expression order by rounding only (tests: H, b within 2e-5 relative, final pose within 1e-5).
+struct Sym3 {
+    float xx, xy, xz, yy, yz, zz;
+};
+
+__device__ __forceinline__ Sym3 load_sym(const float4* __restrict__ p) {
+    const float4 a = p[0], b = p[1];
+    return Sym3{a.x, a.y, a.z, a.w, b.x, b.y};
+}
+
+__global__ __launch_bounds__(kBlock) void prepare_cov_kernel(const float4* __restrict__ covs, unsigned n,
+                                                             const float4* __restrict__ order_pts,
+                                                             float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    // order_pts != nullptr: row i of the output belongs to the point whose original index sits in order_pts[i].w
+    const unsigned src = order_pts ? __float_as_uint(order_pts[i].w) : i;
+    const Mat3 P = plane_regularize(load_cov3(covs + 4 * (size_t)src));
+    out[2 * (size_t)i] = make_float4(P.m[0][0], (P.m[0][1] + P.m[1][0]) * 0.5f, (P.m[0][2] + P.m[2][0]) * 0.5f, P.m[1][1]);
+    out[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], 0.0f, 0.0f);
+}
+
+struct FusedParams {
+    const float4* src;
+    const float4* scovp;
+    const float4* tpts;    // grid-ordered target points
+    const unsigned* tstart;
+    const float4* tcovp;   // grid-ordered prepared target covariances
+    GridDesc g;
+    unsigned n;
+    float max_d2, scale;
+    Mat4Arg T_val;
+    const float* T_dev;
+    int32_t* nn_idx;
+    float* nn_d2;
+};
+
+template <int LOSS>
+__global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float* __restrict__ partials) {
+    const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
+    float acc[kAcc - 1];
+#pragma unroll
+    for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
+    unsigned cnt = 0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock) {
+        const float4 s = P.src[i];
+        float qx, qy, qz;
+        transform_point(T, s.x, s.y, s.z, qx, qy, qz);
+        const Nearest nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+        if (P.nn_idx) { P.nn_idx[i] = nn.idx; P.nn_d2[i] = nn.d2; }
+        if (nn.idx < 0 || nn.d2 > P.max_d2) continue;
+        const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
+        const Sym3 Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
+        const float r0 = nn.x - qx, r1 = nn.y - qy, r2 = nn.z - qz;
+        // Y = Cs' R^T ; S = R Y + Ct'  (symmetric: 6 unique entries)
+        const float (&R)[3][3] = T.R;
+        float Y[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Y[0][j] = chain3(Cs.xx, R[j][0], Cs.xy, R[j][1], Cs.xz, R[j][2]);
+            Y[1][j] = chain3(Cs.xy, R[j][0], Cs.yy, R[j][1], Cs.yz, R[j][2]);
+            Y[2][j] = chain3(Cs.xz, R[j][0], Cs.yz, R[j][1], Cs.zz, R[j][2]);
+        }
+        Mat3 S;
+        S.m[0][0] = chain3(R[0][0], Y[0][0], R[0][1], Y[1][0], R[0][2], Y[2][0]) + Ct.xx;
+        S.m[0][1] = chain3(R[0][0], Y[0][1], R[0][1], Y[1][1], R[0][2], Y[2][1]) + Ct.xy;
+        S.m[0][2] = chain3(R[0][0], Y[0][2], R[0][1], Y[1][2], R[0][2], Y[2][2]) + Ct.xz;
+        S.m[1][1] = chain3(R[1][0], Y[0][1], R[1][1], Y[1][1], R[1][2], Y[2][1]) + Ct.yy;
+        S.m[1][2] = chain3(R[1][0], Y[0][2], R[1][1], Y[1][2], R[1][2], Y[2][2]) + Ct.yz;
+        S.m[2][2] = chain3(R[2][0], Y[0][2], R[2][1], Y[1][2], R[2][2], Y[2][2]) + Ct.zz;
+        S.m[1][0] = S.m[0][1]; S.m[2][0] = S.m[0][2]; S.m[2][1] = S.m[1][2];
+        const Mat3 M = inverse(S);  // Zero when |det| < 1e-6, as eigen_utils::inverse
+        float J[3][6];
+        se3_jacobian(T, s.x, s.y, s.z, J);
+        float JTm[6][3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) JTm[a][k] = chain3(J[0][a], M.m[0][k], J[1][a], M.m[1][k], J[2][a], M.m[2][k]);
+        const float v0 = chain3(M.m[0][0], r0, M.m[0][1], r1, M.m[0][2], r2);
+        const float v1 = chain3(M.m[1][0], r0, M.m[1][1], r1, M.m[1][2], r2);
+        const float v2 = chain3(M.m[2][0], r0, M.m[2][1], r1, M.m[2][2], r2);
+        const float sq = chain3(r0, v0, r1, v1, r2, v2);
+        const float rn = sqrtf(sq);
+        const float w = robust_weight<LOSS>(rn, P.scale);
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c)
+                acc[e++] += w * chain3(JTm[a][0], J[0][c], JTm[a][1], J[1][c], JTm[a][2], J[2][c]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += w * chain3(JTm[a][0], r0, JTm[a][1], r1, JTm[a][2], r2);
+        acc[27] += robust_error<LOSS>(rn, P.scale);
+        ++cnt;
+    }
+    block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
 }
 
 unsigned reduce_grid(size_t n) {
@@ -537,7 +656,8 @@ int run_reduction(Which which, const float* src, const float* scov, size_t n, co
         sp_set_error("[Registration::dispatch] Combination not found in tags!");
         return SP_ERR_RUNTIME;
     }
-    final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, which == K_LINEARIZE ? kAcc - 1 : 1, out);
+    final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, which == K_LINEARIZE ? kAcc - 1 : 1, out,
+                                                     GnArgs{nullptr, 0.0f, 0.0f, 0.0f, nullptr});
     return launch_status();
 }
 
@@ -600,4 +720,120 @@ extern "C" int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, f
     sp_linearized tmp = *lin_host;
     sp::gn_update_impl(&tmp, T_host, lambda, crit_rotation, crit_translation, delta_out8_host, false);
     return SP_OK;
+}
+
+// ------------------------------------------------------------------ prepared / fused path (C ABI)
+struct sp_gicp_target {
+    const sp_grid* grid = nullptr;  // borrowed: must outlive this object
+    float4* covp = nullptr;         // 2 x float4 per target point, grid order
+    size_t n = 0;
+};
+
+extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
+    if (!t) return;
+    if (t->covp) (void)hipFree(t->covp);
+    delete t;
+}
+extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, void* stream) {
+    using namespace sp;
+    if (!t || !tgt_covs) {
+        sp_set_error("[Registration::validate_params] Covariance matrices of source and target must be pre-computed "
+                     "before performing GICP matching.");
+        return SP_ERR_RUNTIME;
+    }
+    if (t->n == 0) return SP_OK;
+    prepare_cov_kernel<<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(tgt_covs), (unsigned)t->n, t->grid->d_pts, t->covp);
+    return launch_status();
+}
+extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream,
+                                     sp_gicp_target** out) {
+    using namespace sp;
+    if (!out || !grid) return SP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (grid->n != n) {
+        sp_set_error("[sp_gicp_target_create] the grid was built on a cloud of a different size");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    sp_gicp_target* t = new sp_gicp_target();
+    t->grid = grid;
+    t->n = n;
+    if (n) {
+        const hipError_t e = hipMalloc(&t->covp, n * 2 * sizeof(float4));
+        if (e != hipSuccess) {
+            sp_set_error(hipGetErrorString(e));
+            sp_gicp_target_destroy(t);
+            return SP_ERR_HIP;
+        }
+    }
+    const int rc = sp_gicp_target_update(t, tgt_covs, stream);
+    if (rc != SP_OK) { sp_gicp_target_destroy(t); return rc; }
+    *out = t;
+    return SP_OK;
+}
+extern "C" int sp_gicp_prepare_source(const float* src_covs, size_t n, float* covp_out, void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    if (!src_covs) {
+        sp_set_error("[Registration::validate_params] Covariance matrices of source and target must be pre-computed "
+                     "before performing GICP matching.");
+        return SP_ERR_RUNTIME;
+    }
+    prepare_cov_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(src_covs), (unsigned)n, nullptr, reinterpret_cast<float4*>(covp_out));
+    return launch_status();
+}
+
+extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const float* src_points, const float* src_covp,
+                                       size_t n, float* transT, int transT_on_device, const sp_factor_params* params,
+                                       const sp_gn_params* gn, int32_t* nn_idx_out, float* nn_d2_out,
+                                       sp_linearized* out, float* delta_out8, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (!target || !params || !out) return SP_ERR_INVALID_ARGUMENT;
+    if (params->reg_type != SP_REG_GICP) {
+        sp_set_error("[sp_gicp_iteration_fused] only RegType::GICP has a prepared/fused form");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (gn && !transT_on_device) {
+        sp_set_error("[sp_gicp_iteration_fused] the fused Gauss-Newton update needs the pose on the device");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (n >= (1ull << 32)) { sp_set_error("[Registration] more than 2^32 source points"); return SP_ERR_INVALID_ARGUMENT; }
+    if (n == 0) return hip_status(hipMemsetAsync(out, 0, sizeof(sp_linearized), st));
+    if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
+        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    FusedParams P;
+    P.src = reinterpret_cast<const float4*>(src_points);
+    P.scovp = reinterpret_cast<const float4*>(src_covp);
+    P.tpts = target->grid->d_pts;
+    P.tstart = target->grid->d_start;
+    P.tcovp = target->covp;
+    P.g = grid_desc(target->grid);
+    P.n = (unsigned)n;
+    P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
+    P.scale = params->robust_scale;
+    for (int i = 0; i < 16; ++i) P.T_val.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    if (transT && !transT_on_device)
+        for (int i = 0; i < 16; ++i) P.T_val.m[i] = transT[i];
+    P.T_dev = transT_on_device ? transT : nullptr;
+    P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
+    P.nn_d2 = nn_d2_out;
+    const unsigned grid = reduce_grid(n);
+    float* partials = static_cast<float*>(workspace);
+    switch (params->robust_type) {
+        case SP_LOSS_NONE: gicp_fused_kernel<LOSS_NONE><<<grid, kBlock, 0, st>>>(P, partials); break;
+        case SP_LOSS_HUBER: gicp_fused_kernel<LOSS_HUBER><<<grid, kBlock, 0, st>>>(P, partials); break;
+        case SP_LOSS_TUKEY: gicp_fused_kernel<LOSS_TUKEY><<<grid, kBlock, 0, st>>>(P, partials); break;
+        case SP_LOSS_CAUCHY: gicp_fused_kernel<LOSS_CAUCHY><<<grid, kBlock, 0, st>>>(P, partials); break;
+        case SP_LOSS_GEMAN_MCCLURE: gicp_fused_kernel<LOSS_GEMAN_MCCLURE><<<grid, kBlock, 0, st>>>(P, partials); break;
+        default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
+    }
+    GnArgs ga{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
+    if (gn) ga = GnArgs{transT, gn->lambda, gn->crit_rotation, gn->crit_translation, delta_out8};
+    final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
+    return launch_status();
 }

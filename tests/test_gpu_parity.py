@@ -465,3 +465,121 @@ def test_gicp_config4_1m(sp, orc):
     g2 = reg2._read_lin(lin2)
     H = np.array(g2.H, np.float32).reshape(6, 6)
     assert np.allclose(H, ref["H"], atol=2e-5 * np.abs(ref["H"]).max()) and g2.inlier == ref["inlier"]
+
+
+# ------------------------------------------------------------------ GridKNN (MI355X-native KNNBase)
+@pytest.mark.parametrize("k", [1, 2, 5, 10, 20])
+@pytest.mark.parametrize("ppc", [0.3, 2.0, 8.0])
+def test_grid_knn_equals_bruteforce_bitwise(sp, orc, k, ppc):
+    g = orc.rng(77)
+    tgt = g.uniform_points(20000, 5.0)
+    qry = g.uniform_points(2500, 6.0)  # some queries outside the target bounding box
+    grid = sp.GridKNN.build(dev(tgt), points_per_cell=ppc)
+    T = orc.se3_exp([0.02, -0.01, 0.03, 0.2, -0.1, 0.05])
+    r = grid.knn_search(dev(qry), k, T)
+    oi, od = orc.knn_bruteforce(orc.transform_points(qry, T), tgt, k)
+    assert np.array_equal(r.distances.cpu().numpy(), od)
+    assert np.array_equal(r.indices.cpu().numpy(), oi)
+
+
+def test_grid_knn_edge_cases(sp, orc):
+    # duplicates (ties -> lowest index), a flat cloud (zero extent on one axis), fewer points than k, non-finite points
+    base = cloud(orc, 3, 3000, 4.0)
+    tgt = np.concatenate([base, base])
+    grid = sp.GridKNN.build(dev(tgt))
+    for k in (1, 3):
+        r = grid.knn_search(dev(base[:500]), k)
+        oi, od = orc.knn_bruteforce(base[:500], tgt, k)
+        assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    flat = cloud(orc, 4, 5000, 3.0)
+    flat[:, 2] = 1.5
+    r = sp.GridKNN.build(dev(flat)).knn_search(dev(flat[:300] + np.float32([0.01, 0, 0.4, 0])), 4)
+    oi, od = orc.knn_bruteforce(flat[:300] + np.float32([0.01, 0, 0.4, 0]), flat, 4)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    few = cloud(orc, 5, 3)
+    r = sp.GridKNN.build(dev(few)).knn_search(dev(cloud(orc, 6, 7)), 5)
+    oi, od = orc.knn_bruteforce(cloud(orc, 6, 7), few, 5)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    bad = cloud(orc, 7, 1000)
+    bad[10, 0] = np.nan
+    bad[20, 1] = np.inf
+    r = sp.GridKNN.build(dev(bad)).knn_search(dev(cloud(orc, 8, 200)), 2)
+    oi, od = orc.knn_bruteforce(cloud(orc, 8, 200), bad, 2)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    r = sp.GridKNN.build(dev(np.zeros((0, 4), np.float32))).knn_search(dev(cloud(orc, 8, 5)), 2)
+    assert (r.indices.cpu().numpy() == -1).all() and (r.distances.cpu().numpy() == FLT_MAX).all()
+    one = sp.GridKNN.build(dev(np.array([[0, 0, 0, 1]], np.float32)))
+    r = one.knn_search(dev(np.array([[1, 1, 1, 1]], np.float32)), 1)
+    assert int(r.indices[0, 0]) == 0 and abs(float(r.distances[0, 0]) - 3.0) < 1e-6
+
+
+def test_grid_knn_1m_matches_kdtree(sp, orc):
+    from sycl_points_amd.synthetic import gicp_pair
+
+    src, tgt, T_gt = gicp_pair(1000000, 10.0)
+    Tg = sp.PointCloudShared(dev(tgt))
+    S = sp.PointCloudShared(dev(src))
+    grid = sp.GridKNN.build(Tg.points)
+    tree = sp.KDTree.build(tgt)
+    a = grid.knn_search(S, 1)
+    b = tree.knn_search(S, 1)
+    assert torch.equal(a.distances, b.distances) and torch.equal(a.indices, b.indices)  # tie-free data
+    g20 = sp.GridKNN.build(Tg.points, points_per_cell=8.0)
+    a = g20.knn_search(Tg.points[:200000].contiguous(), 20)
+    b = tree.knn_search(Tg.points[:200000].contiguous(), 20)
+    assert torch.equal(a.distances, b.distances) and torch.equal(a.indices, b.indices)
+
+
+# ------------------------------------------------------------------ prepared / fused GICP iteration
+@pytest.mark.parametrize("loss", ["NONE", "HUBER", "CAUCHY"])
+def test_fused_iteration_matches_oracle_linear_system(sp, orc, gicp20k, loss):
+    src, scov, tgt, tcov, T_gt = gicp20k
+    T = orc.se3_exp([0.004, -0.01, 0.008, 0.02, -0.01, 0.005])
+    idx, d2 = orc.knn_bruteforce(orc.transform_points(src, T), tgt, 1)
+    ref = orc.gicp_linearize(src, scov, tgt, tcov, None, idx, d2, T, 0.05, "GICP", loss, 0.5)  # max_corr rejects some
+    assert 0 < ref["inlier"] < len(src)
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    grid = sp.GridKNN.build(dev(tgt))
+    prep = sp.PreparedTarget(grid, dev(tcov))
+    reg = sp.Registration(sp.RegistrationParams(max_correspondence_distance=0.05, robust_type=loss,
+                                                criteria_translation=0.0, criteria_rotation=0.0))
+    L = sp._lib.lib()
+    import ctypes as C
+    ws, lin = reg._buffers(S.points.device)
+    covp = sp.prepare_source_covs(S.covs)
+    fp = reg._factor_params(0.5)
+    reg.neighbors.resize(len(src), 1, S.points.device)
+    Tc = np.ascontiguousarray(T.T).reshape(-1)
+    sp.check(L.sp_gicp_iteration_fused(prep._h, sp._ptr(S.points), sp._ptr(covp), len(src), Tc.ctypes.data_as(C.c_void_p), 0,
+                                       C.byref(fp), None, sp._ptr(reg.neighbors.indices), sp._ptr(reg.neighbors.distances),
+                                       sp._ptr(lin), None, sp._ptr(ws), ws.numel(), sp._stream()))
+    got = reg._read_lin(lin)
+    assert np.array_equal(reg.neighbors.indices.cpu().numpy(), idx) and np.array_equal(reg.neighbors.distances.cpu().numpy(), d2)
+    H = np.array(got.H, np.float32).reshape(6, 6)
+    hs = np.abs(ref["H"]).max()
+    assert got.inlier == ref["inlier"]
+    assert np.allclose(H, ref["H"], atol=2e-5 * hs), np.abs(H - ref["H"]).max() / hs
+    assert np.allclose(np.array(got.b), ref["b"], atol=2e-5 * max(np.abs(ref["b"]).max(), 1e-3 * hs))
+    assert abs(got.error - ref["error"]) <= 2e-5 * abs(ref["error"])
+    assert np.array_equal(H, H.T)
+
+
+def test_fused_loop_equals_generic_loop_and_oracle(sp, orc, gicp20k):
+    from oracle.pyoracle import RegParams
+
+    src, scov, tgt, tcov, T_gt = gicp20k
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    grid = sp.GridKNN.build(Tg.points)
+    prep = sp.PreparedTarget(grid, Tg.covs)
+    p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=10)
+    reg = sp.Registration(p)
+    T_dev, lin, delta = reg.align_fused_loop(S, prep, iterations=10)
+    Tf = reg.T_from_device(T_dev)
+    generic = sp.Registration(p).align(S, Tg, grid)
+    assert np.abs(Tf - generic.T).max() < 2e-6
+    ref = orc.registration_align(RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=10), src, scov,
+                                 tgt, tcov)
+    assert np.abs(Tf - ref["T"]).max() < 1e-5
+    assert reg._read_lin(lin).inlier == ref["inlier"]
+    assert float(delta[7]) == 1.0
