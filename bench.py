@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--path", choices=["fused", "generic"], default="fused",
                     help="fused: GridKNN + prepared covariances, NN+K11 in one kernel; generic: KNNBase search + K11")
     ap.add_argument("--nn", choices=["grid", "kdtree"], default="grid", help="KNNBase used by --path generic")
+    ap.add_argument("--ppc", type=float, default=0.5, help="GridKNN points per cell")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline sample")
     return ap.parse_args()
@@ -94,17 +95,16 @@ def main():
     delta = torch.zeros(8, dtype=torch.float32, device=dev)
     group = dist.group.WORLD if world > 1 else None
     # NN structure on the (replicated) target: part of target preprocessing, like the reference's KDTree::build
-    grid = sp.GridKNN.build(Tg.points) if (args.path == "fused" or args.nn == "grid") else None
+    grid = sp.GridKNN.build(Tg.points, points_per_cell=args.ppc) if (args.path == "fused" or args.nn == "grid") else None
     knn = grid if args.nn == "grid" else ttree
     prep = sp.PreparedTarget(grid, Tg.covs) if args.path == "fused" else None
     torch.cuda.synchronize()
 
     def align_chunk(iters, first):
         if args.path == "fused":
-            # the per-alignment preparation (plane regularisation of source and target covariances) is inside the
-            # timed region, once per alignment
-            reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta,
-                                 src_covp=None if first else reg._src_covp)
+            # the per-alignment preparation (plane regularisation of source and target covariances, cell-order sort of
+            # the source) is inside the timed region, once per alignment
+            reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta, prepare=first)
         else:
             reg.align_device_loop(S, Tg, knn, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta)
 
@@ -226,12 +226,10 @@ def kernel_times(sp, torch, args, reg, S, Tg, knn, prep, T_dev, delta, n, reps=2
         L = _lib.lib()
         ws, lin = reg._buffers(S.points.device)
         fp = reg._factor_params(scale)
-        covp = reg._src_covp
 
         def fused_only():  # gn = NULL: the NN + linearise + reduce launch and the partial-sum launch, no solve
-            _lib.check(L.sp_gicp_iteration_fused(prep._h, sp._ptr(S.points), sp._ptr(covp), n, sp._ptr(T_dev), 1,
-                                                 C.byref(fp), None, None, None, sp._ptr(lin), None, sp._ptr(ws),
-                                                 ws.numel(), sp._stream()))
+            _lib.check(L.sp_gicp_iteration_fused(prep._h, reg._psrc._h, sp._ptr(T_dev), 1, C.byref(fp), None, None, None,
+                                                 sp._ptr(lin), None, sp._ptr(ws), ws.numel(), sp._stream()))
 
         ms = timed(fused_only)
         res["gicp_fused_iteration"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9,

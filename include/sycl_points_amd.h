@@ -194,27 +194,40 @@ int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn
 /* Prepared / fused GICP iteration (MI355X-native form of registration.hpp:229-234 = NN search + K11 in one pass).
  * The reference recomputes covariance::kernel::update_covariance_plane for both covariances of every correspondence in
  * every iteration (factor.hpp:249-255). The result depends on the covariance alone, so here it is computed once:
- *   sp_gicp_prepare_source: plane-regularised source covariances, packed 8 floats per point (xx,xy,xz,yy | yz,zz,0,0);
- *   sp_gicp_target_create : the same for the target, stored in the cell order of `grid` (which must have been built on
- *                           the target points and must outlive the object); sp_gicp_target_update recomputes in place.
+ *   sp_gicp_target_create : plane-regularised target covariances, packed 8 floats per point
+ *                           (xx,xy,xz,yy | yz,zz,0,0) and stored in the cell order of `grid` (which must have been built
+ *                           on the target points and must outlive the object); sp_gicp_target_update recomputes in place.
+ *   sp_gicp_source_create : buffers for a prepared source of up to n_max points (allocates).
+ *   sp_gicp_source_prepare: (enqueue only) packed plane-regularised source covariances and, when sort_by_cell != 0,
+ *                           the source reordered by the target-grid cell that transT*p falls into, so that
+ *                           consecutive lanes walk consecutive cells of a grid row (their loads share cache lines).
+ *                           The order only changes which lane handles which point, never a result.
  *   sp_gicp_iteration_fused: per source point q = T p -> exact NN on the grid -> linearise with the packed
  *                           covariances -> reduce to *out. If nn_idx_out/nn_d2_out are non-NULL the correspondences
- *                           are also written (for sp_gicp_error / compute_error_frozen). If `gn` is non-NULL (single-GPU
- *                           loops) the same launch also solves (H + lambda I) delta = -b and updates the DEVICE pose
- *                           transT in place, writing delta_out8 as sp_gn_update does; with gn == NULL the caller
- *                           all-reduces *out over ranks and calls sp_gn_update.
- * Same mathematics as sp_kdtree_search/sp_grid_search + sp_gicp_linearize; rounding differs (symmetric packing,
- * upper-triangle H). reg_type must be SP_REG_GICP; every robust loss is supported. */
+ *                           are also written, in ORIGINAL source order (for sp_gicp_error / compute_error_frozen). If
+ *                           `gn` is non-NULL (single-GPU loops) the same launch also solves (H + lambda I) delta = -b
+ *                           and updates the DEVICE pose transT in place, writing delta_out8 as sp_gn_update does; with
+ *                           gn == NULL the caller all-reduces *out over ranks and calls sp_gn_update.
+ * Same mathematics as sp_grid_search + sp_gicp_linearize; rounding differs (symmetric packing, upper-triangle H,
+ * summation order). reg_type must be SP_REG_GICP; every robust loss is supported. */
 typedef struct sp_gicp_target sp_gicp_target;
+typedef struct sp_gicp_source sp_gicp_source;
 typedef struct sp_gn_params { float lambda, crit_rotation, crit_translation; } sp_gn_params;
 int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream, sp_gicp_target** out);
 int sp_gicp_target_update(sp_gicp_target* target, const float* tgt_covs, void* stream);
 void sp_gicp_target_destroy(sp_gicp_target* target);
-int sp_gicp_prepare_source(const float* src_covs, size_t n, float* covp_out, void* stream);
-int sp_gicp_iteration_fused(const sp_gicp_target* target, const float* src_points, const float* src_covp, size_t n,
-                            float* transT, int transT_on_device, const sp_factor_params* params, const sp_gn_params* gn,
+int sp_gicp_source_create(size_t n_max, sp_gicp_source** out);
+int sp_gicp_source_prepare(sp_gicp_source* source, const sp_gicp_target* target, const float* src_points,
+                           const float* src_covs, size_t n, const float* transT, int transT_on_device, int sort_by_cell,
+                           void* stream);
+void sp_gicp_source_destroy(sp_gicp_source* source);
+int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT,
+                            int transT_on_device, const sp_factor_params* params, const sp_gn_params* gn,
                             int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* out, float* delta_out8,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Tuning hook, not part of the stable surface: NN walk used inside the fused kernel
+ * (-1 automatic: 2x2x2 fast path iff the source is cell-sorted; 0 ring walk; 1 fast path). */
+void sp_debug_set_fused_fast_nn(int mode);
 
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
  * iteration loop can stay on the stream with no host round trip:

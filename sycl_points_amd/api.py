@@ -458,13 +458,32 @@ class PreparedTarget:
             pass
 
 
-def prepare_source_covs(covs, out=None):
-    """sp_gicp_prepare_source: (N,16) API covariances -> (N,8) packed plane-regularised covariances."""
-    c = _dev_f32(covs, 16)
-    if out is None:
-        out = torch.empty((c.shape[0], 8), dtype=torch.float32, device=c.device)
-    check(_lib.lib().sp_gicp_prepare_source(_ptr(c), c.shape[0], _ptr(out), _stream()))
-    return out
+class PreparedSource:
+    """Prepared source of the fused GICP iteration (sp_gicp_source_*): packed plane-regularised covariances and,
+    optionally, the cloud reordered by target-grid cell. Buffers are allocated once for n_max points."""
+
+    def __init__(self, n_max):
+        h = C.c_void_p()
+        check(_lib.lib().sp_gicp_source_create(n_max, C.byref(h)))
+        self._h = h
+        self.n_max = n_max
+
+    def prepare(self, prepared_target, source, transT=None, sort_by_cell=True):
+        if not source.has_cov():
+            raise SpError(2, "[Registration::validate_params] Covariance matrices of source and target must be "
+                             "pre-computed before performing GICP matching.")
+        tp, on_dev, keep = _trans_arg(transT)
+        check(_lib.lib().sp_gicp_source_prepare(self._h, prepared_target._h, _ptr(source.points), _ptr(source.covs),
+                                                source.size(), tp, on_dev, 1 if sort_by_cell else 0, _stream()))
+        self.n = source.size()
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_gicp_source_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------ registration
@@ -706,38 +725,35 @@ class Registration:
         return T_dev, lin, delta_dev
 
     def align_fused_loop(self, source, prepared_target, initial_guess=None, iterations=None, robust_scale=-1.0,
-                         group=None, T_dev=None, delta_dev=None, src_covp=None, write_neighbors=False,
-                         prepare_each_call=True):
+                         group=None, T_dev=None, delta_dev=None, prepare=True, sort_by_cell=True,
+                         write_neighbors=False):
         """The same fixed-length Gauss-Newton loop as align_device_loop on the prepared / fused path
         (sp_gicp_iteration_fused): one launch per iteration does NN + linearise + reduce, and, on a single GPU, the
-        second (one-workgroup) launch also solves and updates the pose. The per-alignment preparation (plane
-        regularisation of both clouds' covariances) is part of this call unless prepare_each_call is False."""
+        second (one-workgroup) launch also solves and updates the pose. With prepare=True (a new alignment) the
+        per-alignment preparation — plane regularisation of both clouds' covariances and the cell-order sort of the
+        source at the initial pose — is enqueued first."""
         import torch.distributed as dist
 
         L = _lib.lib()
         p = self.params
         if p.reg_type != "GICP" or p.optimization_method != "GN":
             raise SpError(1, "align_fused_loop implements GICP with the Gauss-Newton optimiser")
-        if not source.has_cov():
-            raise SpError(2, "[Registration::validate_params] Covariance matrices of source and target must be "
-                             "pre-computed before performing GICP matching.")
         iters = p.max_iterations if iterations is None else iterations
         scale = robust_scale if robust_scale > 0 else p.robust_default_scale
         dev = source.points.device
         ws, lin = self._buffers(dev)
         n = source.size()
-        if src_covp is None:
-            if getattr(self, "_src_covp", None) is None or self._src_covp.shape[0] != n:
-                self._src_covp = torch.empty((n, 8), dtype=torch.float32, device=dev)
-            src_covp = self._src_covp
-            prepare_source_covs(source.covs, src_covp)
-            if prepare_each_call:
-                prepared_target.update()
         if T_dev is None:
             T0 = identity() if initial_guess is None else np.asarray(initial_guess, np.float32)
             T_dev = torch.from_numpy(_T16(T0).reshape(-1).copy()).to(dev)
         if delta_dev is None:
             delta_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+        if getattr(self, "_psrc", None) is None or self._psrc.n_max < n:
+            self._psrc = PreparedSource(n)
+            prepare = True
+        if prepare:
+            prepared_target.update()
+            self._psrc.prepare(prepared_target, source, T_dev, sort_by_cell)
         sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         fp = self._factor_params(scale)
         gn = GnParams(p.gn_lambda, p.criteria_rotation, p.criteria_translation)
@@ -746,9 +762,9 @@ class Registration:
         ni = _ptr(self.neighbors.indices) if write_neighbors else None
         nd = _ptr(self.neighbors.distances) if write_neighbors else None
         for _ in range(iters):
-            check(L.sp_gicp_iteration_fused(prepared_target._h, _ptr(source.points), _ptr(src_covp), n, _ptr(T_dev), 1,
-                                            C.byref(fp), None if sharded else C.byref(gn), ni, nd, _ptr(lin),
-                                            _ptr(delta_dev), _ptr(ws), ws.numel(), _stream()))
+            check(L.sp_gicp_iteration_fused(prepared_target._h, self._psrc._h, _ptr(T_dev), 1, C.byref(fp),
+                                            None if sharded else C.byref(gn), ni, nd, _ptr(lin), _ptr(delta_dev),
+                                            _ptr(ws), ws.numel(), _stream()))
             if sharded:
                 dist.all_reduce(lin, op=dist.ReduceOp.SUM, group=group)
                 check(L.sp_gn_update(_ptr(lin), _ptr(T_dev), p.gn_lambda, p.criteria_rotation, p.criteria_translation,

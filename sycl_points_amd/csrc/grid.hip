@@ -192,6 +192,23 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
         if (i < k) { d2_out[o + i] = bd[i]; idx_out[o + i] = bi[i]; }
 }
 
+__global__ __launch_bounds__(kBlock) void grid_search_k1_kernel(const float4* __restrict__ pts,
+                                                                const unsigned* __restrict__ start, GridDesc g,
+                                                                const float4* __restrict__ queries, unsigned nq,
+                                                                Mat4Arg T_val, const float* __restrict__ T_dev,
+                                                                int32_t* __restrict__ idx_out,
+                                                                float* __restrict__ d2_out) {
+    const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
+    if (qi >= nq) return;
+    const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+    const float4 q4 = queries[qi];
+    float qx, qy, qz;
+    transform_point(T, q4.x, q4.y, q4.z, qx, qy, qz);
+    const Nearest nn = grid_nn1_auto(pts, start, g, qx, qy, qz);
+    idx_out[qi] = nn.idx;
+    d2_out[qi] = nn.d2;
+}
+
 template <int KCAP>
 int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* T, int T_dev, int32_t* idx, float* d2,
            hipStream_t st) {
@@ -200,6 +217,12 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
     if (T && !T_dev)
         for (int i = 0; i < 16; ++i) tv.m[i] = T[i];
     const GridDesc g = grid_desc(gr);
+    if (KCAP == 1) {
+        grid_search_k1_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g,
+                                                                      reinterpret_cast<const float4*>(q), (unsigned)nq,
+                                                                      tv, T_dev ? T : nullptr, idx, d2);
+        return launch_status();
+    }
     grid_search_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g,
                                                                   reinterpret_cast<const float4*>(q), (unsigned)nq,
                                                                   (int)k, tv, T_dev ? T : nullptr, idx, d2);

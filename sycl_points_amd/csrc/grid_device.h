@@ -145,4 +145,68 @@ __device__ __forceinline__ Nearest grid_nn1(const float4* __restrict__ pts, cons
     return best;
 }
 
+// Fast path for k = 1: scan only the 2x2x2 block of cells nearest to the query (own cell plus the neighbour on the
+// nearer side of each axis): 4 x-rows of at most 2 cells, 8 independent extent loads up front, no per-row pruning.
+// Every point within `cov` (>= h/2 away from the grid boundary cases) of the query lies in that block, so the result
+// is exact whenever the winner is closer than cov; otherwise the caller falls back to the full ring walk (grid_nn1).
+// Returns true when the answer in `best` is proven exact.
+__device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                              const GridDesc& g, float qx, float qy, float qz, Nearest& best) {
+    best.d2 = FLT_MAX; best.idx = -1; best.pos = 0; best.x = best.y = best.z = 0.0f;
+    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return true;
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    const int cx = (int)fminf(fmaxf(floorf(fx), 0.0f), (float)(g.nx - 1));
+    const int cy = (int)fminf(fmaxf(floorf(fy), 0.0f), (float)(g.ny - 1));
+    const int cz = (int)fminf(fmaxf(floorf(fz), 0.0f), (float)(g.nz - 1));
+    const int sx = (fx - (float)cx < 0.5f) ? -1 : 1, sy = (fy - (float)cy < 0.5f) ? -1 : 1,
+              sz = (fz - (float)cz < 0.5f) ? -1 : 1;
+    const int xa = max(min(cx, cx + sx), 0), xb = min(max(cx, cx + sx), g.nx - 1);
+    const int ya = max(min(cy, cy + sy), 0), yb = min(max(cy, cy + sy), g.ny - 1);
+    const int za = max(min(cz, cz + sz), 0), zb = min(max(cz, cz + sz), g.nz - 1);
+    // extents of the (up to) four rows; a row that does not exist repeats an existing one with an empty range
+    unsigned s[4], e[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = (r & 1) ? yb : ya, z = (r & 2) ? zb : za;
+        const bool dup = ((r & 1) && yb == ya) || ((r & 2) && zb == za);
+        const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
+        const unsigned s0 = start[row + xa], e0 = start[row + xb + 1];
+        s[r] = s0;
+        e[r] = dup ? s0 : e0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        for (unsigned i = s[r]; i < e[r]; i += 2) {
+            const float4 p0 = pts[i];
+            const float4 p1 = pts[min(i + 1, e[r] - 1)];
+            const float d0 = dist2(qx, qy, qz, p0.x, p0.y, p0.z);
+            const float d1 = dist2(qx, qy, qz, p1.x, p1.y, p1.z);
+            const int i0 = __float_as_int(p0.w), i1 = __float_as_int(p1.w);
+            if (d0 < best.d2 || (d0 == best.d2 && i0 < best.idx)) {
+                best.d2 = d0; best.idx = i0; best.pos = i; best.x = p0.x; best.y = p0.y; best.z = p0.z;
+            }
+            if (i + 1 < e[r] && (d1 < best.d2 || (d1 == best.d2 && i1 < best.idx))) {
+                best.d2 = d1; best.idx = i1; best.pos = i + 1; best.x = p1.x; best.y = p1.y; best.z = p1.z;
+            }
+        }
+    }
+    float cov = FLT_MAX;
+    if (xa > 0) cov = fminf(cov, qx - (g.ox + xa * g.h));
+    if (xb < g.nx - 1) cov = fminf(cov, (g.ox + (xb + 1) * g.h) - qx);
+    if (ya > 0) cov = fminf(cov, qy - (g.oy + ya * g.h));
+    if (yb < g.ny - 1) cov = fminf(cov, (g.oy + (yb + 1) * g.h) - qy);
+    if (za > 0) cov = fminf(cov, qz - (g.oz + za * g.h));
+    if (zb < g.nz - 1) cov = fminf(cov, (g.oz + (zb + 1) * g.h) - qz);
+    if (cov == FLT_MAX) return true;  // the block is the whole grid
+    cov = fmaxf(cov - g.eps, 0.0f);
+    return best.d2 < cov * cov;  // strict: an unseen point at exactly this distance could win a tie
+}
+
+__device__ __forceinline__ Nearest grid_nn1_auto(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                 const GridDesc& g, float qx, float qy, float qz) {
+    Nearest best;
+    if (!grid_nn1_fast(pts, start, g, qx, qy, qz, best)) best = grid_nn1(pts, start, g, qx, qy, qz);
+    return best;
+}
+
 }  // namespace sp

@@ -14,6 +14,8 @@
 
 void sp_set_error(const char* msg);
 
+static int g_fused_fast_nn = -1;  // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
+
 namespace sp {
 namespace {
 
@@ -464,14 +466,46 @@ __device__ __forceinline__ Sym3 load_sym(const float4* __restrict__ p) {
 
 __global__ __launch_bounds__(kBlock) void prepare_cov_kernel(const float4* __restrict__ covs, unsigned n,
                                                              const float4* __restrict__ order_pts,
+                                                             const unsigned* __restrict__ order_idx,
                                                              float4* __restrict__ out) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    // order_pts != nullptr: row i of the output belongs to the point whose original index sits in order_pts[i].w
-    const unsigned src = order_pts ? __float_as_uint(order_pts[i].w) : i;
+    // row i of the output belongs to the point whose original index is order_pts[i].w / order_idx[i] (or i itself)
+    const unsigned src = order_pts ? __float_as_uint(order_pts[i].w) : (order_idx ? order_idx[i] : i);
     const Mat3 P = plane_regularize(load_cov3(covs + 4 * (size_t)src));
     out[2 * (size_t)i] = make_float4(P.m[0][0], (P.m[0][1] + P.m[1][0]) * 0.5f, (P.m[0][2] + P.m[2][0]) * 0.5f, P.m[1][1]);
     out[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], 0.0f, 0.0f);
+}
+
+// Source ordering: key = cell (of the TARGET grid) that T*p falls into, so that consecutive lanes of the fused
+// kernel walk consecutive cells of a grid row and their extent / point / covariance loads share cache lines.
+__global__ __launch_bounds__(kBlock) void query_cell_kernel(const float4* __restrict__ pts, unsigned n, GridDesc g,
+                                                            Mat4Arg T_val, const float* __restrict__ T_dev,
+                                                            unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+    const float4 p = pts[i];
+    float qx, qy, qz;
+    transform_point(T, p.x, p.y, p.z, qx, qy, qz);
+    unsigned key = (unsigned)g.nx * g.ny * g.nz;
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+        const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny),
+                  cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+        key = ((unsigned)cz * g.ny + cy) * g.nx + cx;
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+__global__ __launch_bounds__(kBlock) void gather_points_kernel(const float4* __restrict__ pts,
+                                                               const unsigned* __restrict__ order, unsigned n,
+                                                               float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = pts[order ? order[i] : i];
+}
+__global__ __launch_bounds__(kBlock) void iota_kernel(unsigned* __restrict__ v, unsigned n) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) v[i] = i;
 }
 
 struct FusedParams {
@@ -485,11 +519,12 @@ struct FusedParams {
     float max_d2, scale;
     Mat4Arg T_val;
     const float* T_dev;
+    const unsigned* perm;  // prepared-source order -> original source index (for the optional neighbour outputs)
     int32_t* nn_idx;
     float* nn_d2;
 };
 
-template <int LOSS>
+template <int LOSS, bool FAST_NN>
 __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float* __restrict__ partials) {
     const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
     float acc[kAcc - 1];
@@ -500,8 +535,13 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
         const float4 s = P.src[i];
         float qx, qy, qz;
         transform_point(T, s.x, s.y, s.z, qx, qy, qz);
-        const Nearest nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
-        if (P.nn_idx) { P.nn_idx[i] = nn.idx; P.nn_d2[i] = nn.d2; }
+        const Nearest nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz)
+                                   : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+        if (P.nn_idx) {
+            const unsigned o = P.perm[i];
+            P.nn_idx[o] = nn.idx;
+            P.nn_d2[o] = nn.d2;
+        }
         if (nn.idx < 0 || nn.d2 > P.max_d2) continue;
         const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
         const Sym3 Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
@@ -723,10 +763,22 @@ extern "C" int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, f
 }
 
 // ------------------------------------------------------------------ prepared / fused path (C ABI)
+#include <rocprim/device/device_radix_sort.hpp>
+
 struct sp_gicp_target {
     const sp_grid* grid = nullptr;  // borrowed: must outlive this object
     float4* covp = nullptr;         // 2 x float4 per target point, grid order
     size_t n = 0;
+};
+struct sp_gicp_source {
+    size_t n_max = 0, n = 0;
+    float4* pts = nullptr;    // n points in prepared order
+    float4* covp = nullptr;   // 2 x float4 per point, prepared order
+    unsigned* perm = nullptr; // prepared position -> original index
+    bool sorted = false;
+    unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
 };
 
 extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
@@ -743,7 +795,7 @@ extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, v
     }
     if (t->n == 0) return SP_OK;
     prepare_cov_kernel<<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(tgt_covs), (unsigned)t->n, t->grid->d_pts, t->covp);
+        reinterpret_cast<const float4*>(tgt_covs), (unsigned)t->n, t->grid->d_pts, nullptr, t->covp);
     return launch_status();
 }
 extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream,
@@ -771,27 +823,88 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
     *out = t;
     return SP_OK;
 }
-extern "C" int sp_gicp_prepare_source(const float* src_covs, size_t n, float* covp_out, void* stream) {
+
+extern "C" void sp_gicp_source_destroy(sp_gicp_source* s) {
+    if (!s) return;
+    (void)hipFree(s->pts); (void)hipFree(s->covp); (void)hipFree(s->perm);
+    (void)hipFree(s->keys_in); (void)hipFree(s->keys_out); (void)hipFree(s->vals_in); (void)hipFree(s->sort_tmp);
+    delete s;
+}
+extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     using namespace sp;
-    if (n == 0) return SP_OK;
-    if (!src_covs) {
+    if (!out) return SP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (n_max >= (1ull << 32)) { sp_set_error("[Registration] more than 2^32 source points"); return SP_ERR_INVALID_ARGUMENT; }
+    sp_gicp_source* s = new sp_gicp_source();
+    s->n_max = n_max;
+    const size_t n = n_max ? n_max : 1;
+    (void)rocprim::radix_sort_pairs(nullptr, s->sort_tmp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+                                    (unsigned*)nullptr, n, 0, 32, (hipStream_t)0);
+    hipError_t e = hipMalloc(&s->pts, n * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&s->covp, n * 2 * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&s->perm, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->keys_in, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->keys_out, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->vals_in, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->sort_tmp, s->sort_tmp_bytes ? s->sort_tmp_bytes : 16);
+    if (e != hipSuccess) {
+        sp_set_error(hipGetErrorString(e));
+        sp_gicp_source_destroy(s);
+        return SP_ERR_HIP;
+    }
+    *out = s;
+    return SP_OK;
+}
+extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* target, const float* src_points,
+                                      const float* src_covs, size_t n, const float* transT, int transT_on_device,
+                                      int sort_by_cell, void* stream) {
+    using namespace sp;
+    if (!s || !target) return SP_ERR_INVALID_ARGUMENT;
+    if (n > s->n_max) {
+        sp_set_error("[sp_gicp_source_prepare] more points than the object was created for");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (!src_covs && n) {
         sp_set_error("[Registration::validate_params] Covariance matrices of source and target must be pre-computed "
                      "before performing GICP matching.");
         return SP_ERR_RUNTIME;
     }
-    prepare_cov_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(src_covs), (unsigned)n, nullptr, reinterpret_cast<float4*>(covp_out));
+    s->n = n;
+    s->sorted = sort_by_cell != 0;
+    if (n == 0) return SP_OK;
+    hipStream_t st = as_stream(stream);
+    const float4* pts = reinterpret_cast<const float4*>(src_points);
+    const unsigned nb = div_up(n, kBlock);
+    if (sort_by_cell) {
+        Mat4Arg tv;
+        for (int i = 0; i < 16; ++i) tv.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        if (transT && !transT_on_device)
+            for (int i = 0; i < 16; ++i) tv.m[i] = transT[i];
+        const GridDesc g = grid_desc(target->grid);
+        query_cell_kernel<<<nb, kBlock, 0, st>>>(pts, (unsigned)n, g, tv, transT_on_device ? transT : nullptr, s->keys_in,
+                                                 s->vals_in);
+        unsigned end_bit = 1;
+        while ((1ull << end_bit) <= target->grid->ncells && end_bit < 32) ++end_bit;
+        size_t tmp = s->sort_tmp_bytes;
+        const hipError_t e = rocprim::radix_sort_pairs(s->sort_tmp, tmp, s->keys_in, s->keys_out, s->vals_in, s->perm, n,
+                                                       0, end_bit, st);
+        if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    } else {
+        iota_kernel<<<nb, kBlock, 0, st>>>(s->perm, (unsigned)n);
+    }
+    gather_points_kernel<<<nb, kBlock, 0, st>>>(pts, s->perm, (unsigned)n, s->pts);
+    prepare_cov_kernel<<<nb, kBlock, 0, st>>>(reinterpret_cast<const float4*>(src_covs), (unsigned)n, nullptr, s->perm,
+                                              s->covp);
     return launch_status();
 }
 
-extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const float* src_points, const float* src_covp,
-                                       size_t n, float* transT, int transT_on_device, const sp_factor_params* params,
-                                       const sp_gn_params* gn, int32_t* nn_idx_out, float* nn_d2_out,
-                                       sp_linearized* out, float* delta_out8, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT,
+                                       int transT_on_device, const sp_factor_params* params, const sp_gn_params* gn,
+                                       int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* out, float* delta_out8,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
     using namespace sp;
     hipStream_t st = as_stream(stream);
-    if (!target || !params || !out) return SP_ERR_INVALID_ARGUMENT;
+    if (!target || !source || !params || !out) return SP_ERR_INVALID_ARGUMENT;
     if (params->reg_type != SP_REG_GICP) {
         sp_set_error("[sp_gicp_iteration_fused] only RegType::GICP has a prepared/fused form");
         return SP_ERR_INVALID_ARGUMENT;
@@ -800,15 +913,15 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const float
         sp_set_error("[sp_gicp_iteration_fused] the fused Gauss-Newton update needs the pose on the device");
         return SP_ERR_INVALID_ARGUMENT;
     }
-    if (n >= (1ull << 32)) { sp_set_error("[Registration] more than 2^32 source points"); return SP_ERR_INVALID_ARGUMENT; }
+    const size_t n = source->n;
     if (n == 0) return hip_status(hipMemsetAsync(out, 0, sizeof(sp_linearized), st));
     if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
     }
     FusedParams P;
-    P.src = reinterpret_cast<const float4*>(src_points);
-    P.scovp = reinterpret_cast<const float4*>(src_covp);
+    P.src = source->pts;
+    P.scovp = source->covp;
     P.tpts = target->grid->d_pts;
     P.tstart = target->grid->d_start;
     P.tcovp = target->covp;
@@ -820,20 +933,30 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const float
     if (transT && !transT_on_device)
         for (int i = 0; i < 16; ++i) P.T_val.m[i] = transT[i];
     P.T_dev = transT_on_device ? transT : nullptr;
+    P.perm = source->perm;
     P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
     P.nn_d2 = nn_d2_out;
     const unsigned grid = reduce_grid(n);
     float* partials = static_cast<float*>(workspace);
+    // Unsorted lanes touch unrelated cells: the ring walk (fewest cache lines per query) wins. Cell-sorted lanes share
+    // their lines: the branch-light 2x2x2 walk wins (profiles/README.md, r01_c).
+    const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
+#define SP_LAUNCH_FUSED(L)                                                              \
+    if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);        \
+    else gicp_fused_kernel<L, false><<<grid, kBlock, 0, st>>>(P, partials)
     switch (params->robust_type) {
-        case SP_LOSS_NONE: gicp_fused_kernel<LOSS_NONE><<<grid, kBlock, 0, st>>>(P, partials); break;
-        case SP_LOSS_HUBER: gicp_fused_kernel<LOSS_HUBER><<<grid, kBlock, 0, st>>>(P, partials); break;
-        case SP_LOSS_TUKEY: gicp_fused_kernel<LOSS_TUKEY><<<grid, kBlock, 0, st>>>(P, partials); break;
-        case SP_LOSS_CAUCHY: gicp_fused_kernel<LOSS_CAUCHY><<<grid, kBlock, 0, st>>>(P, partials); break;
-        case SP_LOSS_GEMAN_MCCLURE: gicp_fused_kernel<LOSS_GEMAN_MCCLURE><<<grid, kBlock, 0, st>>>(P, partials); break;
+        case SP_LOSS_NONE: SP_LAUNCH_FUSED(LOSS_NONE); break;
+        case SP_LOSS_HUBER: SP_LAUNCH_FUSED(LOSS_HUBER); break;
+        case SP_LOSS_TUKEY: SP_LAUNCH_FUSED(LOSS_TUKEY); break;
+        case SP_LOSS_CAUCHY: SP_LAUNCH_FUSED(LOSS_CAUCHY); break;
+        case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_FUSED(LOSS_GEMAN_MCCLURE); break;
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
+#undef SP_LAUNCH_FUSED
     GnArgs ga{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
     if (gn) ga = GnArgs{transT, gn->lambda, gn->crit_rotation, gn->crit_translation, delta_out8};
     final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
     return launch_status();
 }
+// Tuning hook (not part of the stable surface): choose the NN walk used inside the fused kernel.
+extern "C" void sp_debug_set_fused_fast_nn(int mode) { g_fused_fast_nn = mode; }

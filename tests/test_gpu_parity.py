@@ -532,7 +532,10 @@ def test_grid_knn_1m_matches_kdtree(sp, orc):
 
 # ------------------------------------------------------------------ prepared / fused GICP iteration
 @pytest.mark.parametrize("loss", ["NONE", "HUBER", "CAUCHY"])
-def test_fused_iteration_matches_oracle_linear_system(sp, orc, gicp20k, loss):
+@pytest.mark.parametrize("sort,fast", [(True, False), (False, False), (True, True)])
+def test_fused_iteration_matches_oracle_linear_system(sp, orc, gicp20k, loss, sort, fast):
+    import ctypes as C
+
     src, scov, tgt, tcov, T_gt = gicp20k
     T = orc.se3_exp([0.004, -0.01, 0.008, 0.02, -0.01, 0.005])
     idx, d2 = orc.knn_bruteforce(orc.transform_points(src, T), tgt, 1)
@@ -544,16 +547,21 @@ def test_fused_iteration_matches_oracle_linear_system(sp, orc, gicp20k, loss):
     reg = sp.Registration(sp.RegistrationParams(max_correspondence_distance=0.05, robust_type=loss,
                                                 criteria_translation=0.0, criteria_rotation=0.0))
     L = sp._lib.lib()
-    import ctypes as C
-    ws, lin = reg._buffers(S.points.device)
-    covp = sp.prepare_source_covs(S.covs)
-    fp = reg._factor_params(0.5)
-    reg.neighbors.resize(len(src), 1, S.points.device)
-    Tc = np.ascontiguousarray(T.T).reshape(-1)
-    sp.check(L.sp_gicp_iteration_fused(prep._h, sp._ptr(S.points), sp._ptr(covp), len(src), Tc.ctypes.data_as(C.c_void_p), 0,
-                                       C.byref(fp), None, sp._ptr(reg.neighbors.indices), sp._ptr(reg.neighbors.distances),
-                                       sp._ptr(lin), None, sp._ptr(ws), ws.numel(), sp._stream()))
-    got = reg._read_lin(lin)
+    L.sp_debug_set_fused_fast_nn(1 if fast else 0)
+    try:
+        ws, lin = reg._buffers(S.points.device)
+        psrc = sp.PreparedSource(len(src))
+        psrc.prepare(prep, S, T, sort_by_cell=sort)
+        fp = reg._factor_params(0.5)
+        reg.neighbors.resize(len(src), 1, S.points.device)
+        Tc = np.ascontiguousarray(T.T).reshape(-1)
+        sp.check(L.sp_gicp_iteration_fused(prep._h, psrc._h, Tc.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None,
+                                           sp._ptr(reg.neighbors.indices), sp._ptr(reg.neighbors.distances), sp._ptr(lin),
+                                           None, sp._ptr(ws), ws.numel(), sp._stream()))
+        got = reg._read_lin(lin)
+    finally:
+        L.sp_debug_set_fused_fast_nn(-1)
+    # correspondences come back in ORIGINAL source order whatever the internal order
     assert np.array_equal(reg.neighbors.indices.cpu().numpy(), idx) and np.array_equal(reg.neighbors.distances.cpu().numpy(), d2)
     H = np.array(got.H, np.float32).reshape(6, 6)
     hs = np.abs(ref["H"]).max()
