@@ -36,5 +36,6 @@ extern "C" void sp_rigid_mul_host(const float* A16, const float* B16, float* out
     sp::store_rigid_colmajor(r, out16);
 }
 extern "C" int sp_ldlt6_solve_host(const float* H36_rowmajor, const float* rhs6, float* x6) {
-    return sp::ldlt6_solve(H36_rowmajor, rhs6, x6) ? SP_OK : SP_ERR_RUNTIME;
+    sp::LdltScratch w;
+    return sp::ldlt6_solve(H36_rowmajor, rhs6, x6, w) ? SP_OK : SP_ERR_RUNTIME;
 }

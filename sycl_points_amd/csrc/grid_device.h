@@ -174,19 +174,27 @@ __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, co
         s[r] = s0;
         e[r] = dup ? s0 : e0;
     }
+    // Flatten the four ranges into one candidate list and fetch it in batches of 8 INDEPENDENT 16-byte loads
+    // (one memory round trip for almost every query instead of one per row and per pair of points).
+    const unsigned n0 = e[0] - s[0], n1 = e[1] - s[1], n2 = e[2] - s[2], n3 = e[3] - s[3];
+    const unsigned c1 = n0, c2 = n0 + n1, c3 = n0 + n1 + n2, total = c3 + n3;
+    for (unsigned base = 0; base < total; base += 8) {
+        float4 cand[8];
+        unsigned cpos[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        for (unsigned i = s[r]; i < e[r]; i += 2) {
-            const float4 p0 = pts[i];
-            const float4 p1 = pts[min(i + 1, e[r] - 1)];
-            const float d0 = dist2(qx, qy, qz, p0.x, p0.y, p0.z);
-            const float d1 = dist2(qx, qy, qz, p1.x, p1.y, p1.z);
-            const int i0 = __float_as_int(p0.w), i1 = __float_as_int(p1.w);
-            if (d0 < best.d2 || (d0 == best.d2 && i0 < best.idx)) {
-                best.d2 = d0; best.idx = i0; best.pos = i; best.x = p0.x; best.y = p0.y; best.z = p0.z;
-            }
-            if (i + 1 < e[r] && (d1 < best.d2 || (d1 == best.d2 && i1 < best.idx))) {
-                best.d2 = d1; best.idx = i1; best.pos = i + 1; best.x = p1.x; best.y = p1.y; best.z = p1.z;
+        for (int j = 0; j < 8; ++j) {
+            const unsigned jj = min(base + j, total - 1);
+            const unsigned pos = jj < c1 ? s[0] + jj : (jj < c2 ? s[1] + (jj - c1) : (jj < c3 ? s[2] + (jj - c2) : s[3] + (jj - c3)));
+            cpos[j] = pos;
+            cand[j] = pts[pos];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = dist2(qx, qy, qz, cand[j].x, cand[j].y, cand[j].z);
+            const int pi = __float_as_int(cand[j].w);
+            const bool valid = base + j < total;
+            if (valid && (d < best.d2 || (d == best.d2 && pi < best.idx))) {
+                best.d2 = d; best.idx = pi; best.pos = cpos[j]; best.x = cand[j].x; best.y = cand[j].y; best.z = cand[j].z;
             }
         }
     }

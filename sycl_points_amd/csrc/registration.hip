@@ -344,12 +344,13 @@ struct GnArgs {  // optional fused Gauss-Newton step (single-GPU loops): T == nu
     float* delta_out8;
 };
 __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, float lambda, float crit_rot,
-                                               float crit_trans, float* delta_out8, bool fold_inlier);
+                                               float crit_trans, float* delta_out8, bool fold_inlier, LdltScratch& w);
 
 __global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float* __restrict__ partials,
                                                                      unsigned nblocks, int nv,
                                                                      sp_linearized* __restrict__ out, GnArgs gn) {
     __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ LdltScratch ldlt_ws;
     constexpr unsigned kParts = kFinalThreads / 32;
     const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;
     const unsigned per = (nblocks + kParts - 1) / kParts;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float
         out->inlier = cnt;
         out->inlier_lo = (float)(cnt & 4095u);
         out->inlier_hi = (float)(cnt >> 12);
-        if (gn.T) gn_update_impl(out, gn.T, gn.lambda, gn.crit_rot, gn.crit_trans, gn.delta_out8, false);
+        if (gn.T) gn_update_impl(out, gn.T, gn.lambda, gn.crit_rot, gn.crit_trans, gn.delta_out8, false, ldlt_ws);
     }
 }
 
@@ -416,15 +417,17 @@ __global__ void genz_counts_kernel(const float4* __restrict__ tcov, const int32_
 
 // optimize_gauss_newton (registration.hpp:803-828) + solve_linear_system (:791-801) + is_converged (:407-410)
 __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, float lambda, float crit_rot,
-                                               float crit_trans, float* delta_out8, bool fold_inlier) {
+                                               float crit_trans, float* delta_out8, bool fold_inlier, LdltScratch& w) {
     if (fold_inlier) lin->inlier = (uint32_t)lin->inlier_hi * 4096u + (uint32_t)lin->inlier_lo;  // integer fold: exact
-    float H[36], nb[6], delta[6];
+    float* H = w.H;
+    float* nb = w.rhs;
+    float* delta = w.x;
     for (int i = 0; i < 36; ++i) H[i] = lin->H[i];
     for (int i = 0; i < 6; ++i) {
         H[i * 6 + i] = lin->H[i * 6 + i] + lambda * 1.0f;
         nb[i] = -lin->b[i];
     }
-    const bool ok = ldlt6_solve(H, nb, delta);
+    const bool ok = ldlt6_solve(H, nb, delta, w);
     const float nr = sqrtf(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
     const float nt = sqrtf(delta[3] * delta[3] + delta[4] * delta[4] + delta[5] * delta[5]);
     const bool conv = ok && (nr < crit_rot) && (nt < crit_trans);
@@ -439,7 +442,8 @@ __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, flo
 }
 __global__ void gn_update_kernel(sp_linearized* lin, float* T, float lambda, float crit_rot, float crit_trans,
                                  float* delta_out8) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) gn_update_impl(lin, T, lambda, crit_rot, crit_trans, delta_out8, true);
+    __shared__ LdltScratch ldlt_ws;
+    if (threadIdx.x == 0 && blockIdx.x == 0) gn_update_impl(lin, T, lambda, crit_rot, crit_trans, delta_out8, true, ldlt_ws);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -758,7 +762,8 @@ extern "C" int sp_gn_update(sp_linearized* lin, float* T_dev, float lambda, floa
 extern "C" int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, float lambda, float crit_rotation,
                                  float crit_translation, float* delta_out8_host) {
     sp_linearized tmp = *lin_host;
-    sp::gn_update_impl(&tmp, T_host, lambda, crit_rotation, crit_translation, delta_out8_host, false);
+    sp::LdltScratch w;
+    sp::gn_update_impl(&tmp, T_host, lambda, crit_rotation, crit_translation, delta_out8_host, false, w);
     return SP_OK;
 }
 

@@ -337,54 +337,62 @@ SP_HD void store_rigid_colmajor(const Rigid& r, float* T) {
 // 6x6 LDL^T with diagonal pivoting, the algorithm of Eigen::LDLT (registration.hpp:791-801): left-looking,
 // pivot = largest |diagonal| of the not-yet-factored part. H is row-major and symmetric. Solves H x = rhs.
 // Returns false on a zero pivot with a non-zero column (Eigen: NumericalIssue), x = 0 then.
-SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x) {
+// The run-time indexed working set lives in an LdltScratch the caller provides: a stack object on the host, an LDS
+// object on the device (a private array indexed at run time would be placed in scratch memory, i.e. off chip).
+struct LdltScratch {
     float m[6][6];
+    float y[6];
+    float temp[6];
+    float rhs[6];
+    float x[6];
+    float H[36];
+    int perm[6];
+};
+SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch& w) {
     for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) m[i][j] = H[i * 6 + j];
-    int perm[6] = {0, 1, 2, 3, 4, 5};
+        for (int j = 0; j < 6; ++j) w.m[i][j] = H[i * 6 + j];
+    for (int i = 0; i < 6; ++i) w.perm[i] = i;
     bool ok = true;
     for (int k = 0; k < 6; ++k) {
         int piv = k;
-        float best = fabsf(m[k][k]);
+        float best = fabsf(w.m[k][k]);
         for (int i = k + 1; i < 6; ++i)
-            if (fabsf(m[i][i]) > best) { best = fabsf(m[i][i]); piv = i; }
+            if (fabsf(w.m[i][i]) > best) { best = fabsf(w.m[i][i]); piv = i; }
         if (piv != k) {
-            for (int j = 0; j < 6; ++j) { const float t = m[k][j]; m[k][j] = m[piv][j]; m[piv][j] = t; }
-            for (int i = 0; i < 6; ++i) { const float t = m[i][k]; m[i][k] = m[i][piv]; m[i][piv] = t; }
-            const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+            for (int j = 0; j < 6; ++j) { const float t = w.m[k][j]; w.m[k][j] = w.m[piv][j]; w.m[piv][j] = t; }
+            for (int i = 0; i < 6; ++i) { const float t = w.m[i][k]; w.m[i][k] = w.m[i][piv]; w.m[i][piv] = t; }
+            const int t = w.perm[k]; w.perm[k] = w.perm[piv]; w.perm[piv] = t;
         }
-        float temp[6];
-        for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+        for (int j = 0; j < k; ++j) w.temp[j] = w.m[j][j] * w.m[k][j];
         if (k > 0) {
             float s = 0.0f;
-            for (int j = 0; j < k; ++j) s += m[k][j] * temp[j];
-            m[k][k] -= s;
+            for (int j = 0; j < k; ++j) s += w.m[k][j] * w.temp[j];
+            w.m[k][k] -= s;
             for (int i = k + 1; i < 6; ++i) {
                 float t = 0.0f;
-                for (int j = 0; j < k; ++j) t += m[i][j] * temp[j];
-                m[i][k] -= t;
+                for (int j = 0; j < k; ++j) t += w.m[i][j] * w.temp[j];
+                w.m[i][k] -= t;
             }
         }
-        const float d = m[k][k];
+        const float d = w.m[k][k];
         if (fabsf(d) > 0.0f) {
-            for (int i = k + 1; i < 6; ++i) m[i][k] /= d;
+            for (int i = k + 1; i < 6; ++i) w.m[i][k] /= d;
         } else {
             for (int i = k + 1; i < 6; ++i)
-                if (m[i][k] != 0.0f) ok = false;
+                if (w.m[i][k] != 0.0f) ok = false;
         }
     }
     if (!ok) {
         for (int i = 0; i < 6; ++i) x[i] = 0.0f;
         return false;
     }
-    float y[6];
-    for (int i = 0; i < 6; ++i) y[i] = rhs[perm[i]];
+    for (int i = 0; i < 6; ++i) w.y[i] = rhs[w.perm[i]];
     for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < i; ++j) y[i] -= m[i][j] * y[j];
-    for (int i = 0; i < 6; ++i) y[i] = (fabsf(m[i][i]) > FLT_MIN) ? y[i] / m[i][i] : 0.0f;
+        for (int j = 0; j < i; ++j) w.y[i] -= w.m[i][j] * w.y[j];
+    for (int i = 0; i < 6; ++i) w.y[i] = (fabsf(w.m[i][i]) > FLT_MIN) ? w.y[i] / w.m[i][i] : 0.0f;
     for (int i = 5; i >= 0; --i)
-        for (int j = i + 1; j < 6; ++j) y[i] -= m[j][i] * y[j];
-    for (int i = 0; i < 6; ++i) x[perm[i]] = y[i];
+        for (int j = i + 1; j < 6; ++j) w.y[i] -= w.m[j][i] * w.y[j];
+    for (int i = 0; i < 6; ++i) x[w.perm[i]] = w.y[i];
     return true;
 }
 
