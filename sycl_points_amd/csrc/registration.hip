@@ -419,10 +419,10 @@ __global__ void genz_counts_kernel(const float4* __restrict__ tcov, const int32_
 __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, float lambda, float crit_rot,
                                                float crit_trans, float* delta_out8, bool fold_inlier, LdltScratch& w) {
     if (fold_inlier) lin->inlier = (uint32_t)lin->inlier_hi * 4096u + (uint32_t)lin->inlier_lo;  // integer fold: exact
-    float* H = w.H;
-    float* nb = w.rhs;
-    float* delta = w.x;
+    float H[36], nb[6], delta[6];
+#pragma unroll
     for (int i = 0; i < 36; ++i) H[i] = lin->H[i];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         H[i * 6 + i] = lin->H[i * 6 + i] + lambda * 1.0f;
         nb[i] = -lin->b[i];

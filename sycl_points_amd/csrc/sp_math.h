@@ -348,51 +348,92 @@ struct LdltScratch {
     float H[36];
     int perm[6];
 };
-SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch& w) {
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) w.m[i][j] = H[i * 6 + j];
-    for (int i = 0; i < 6; ++i) w.perm[i] = i;
+SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch&) {
+    // Fully unrolled: every array index below is a compile-time constant after unrolling, so the 6x6 working set stays
+    // in registers. The run-time pivot is applied with predicated swaps (`if (piv == p)`), which performs exactly the
+    // arithmetic of the textbook loop form, in the same order.
+    float m[6][6];
+    int perm[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = H[i * 6 + j];
+        perm[i] = i;
+    }
     bool ok = true;
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         int piv = k;
-        float best = fabsf(w.m[k][k]);
+        float best = fabsf(m[k][k]);
+#pragma unroll
         for (int i = k + 1; i < 6; ++i)
-            if (fabsf(w.m[i][i]) > best) { best = fabsf(w.m[i][i]); piv = i; }
-        if (piv != k) {
-            for (int j = 0; j < 6; ++j) { const float t = w.m[k][j]; w.m[k][j] = w.m[piv][j]; w.m[piv][j] = t; }
-            for (int i = 0; i < 6; ++i) { const float t = w.m[i][k]; w.m[i][k] = w.m[i][piv]; w.m[i][piv] = t; }
-            const int t = w.perm[k]; w.perm[k] = w.perm[piv]; w.perm[piv] = t;
-        }
-        for (int j = 0; j < k; ++j) w.temp[j] = w.m[j][j] * w.m[k][j];
-        if (k > 0) {
-            float s = 0.0f;
-            for (int j = 0; j < k; ++j) s += w.m[k][j] * w.temp[j];
-            w.m[k][k] -= s;
-            for (int i = k + 1; i < 6; ++i) {
-                float t = 0.0f;
-                for (int j = 0; j < k; ++j) t += w.m[i][j] * w.temp[j];
-                w.m[i][k] -= t;
+            if (fabsf(m[i][i]) > best) { best = fabsf(m[i][i]); piv = i; }
+#pragma unroll
+        for (int p = k + 1; p < 6; ++p) {
+            if (piv == p) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const float t = m[k][j]; m[k][j] = m[p][j]; m[p][j] = t; }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { const float t = m[i][k]; m[i][k] = m[i][p]; m[i][p] = t; }
+                const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
             }
         }
-        const float d = w.m[k][k];
+        float temp[6];
+#pragma unroll
+        for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+        if (k > 0) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < k; ++j) s += m[k][j] * temp[j];
+            m[k][k] -= s;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) {
+                float t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < k; ++j) t += m[i][j] * temp[j];
+                m[i][k] -= t;
+            }
+        }
+        const float d = m[k][k];
         if (fabsf(d) > 0.0f) {
-            for (int i = k + 1; i < 6; ++i) w.m[i][k] /= d;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) m[i][k] /= d;
         } else {
+#pragma unroll
             for (int i = k + 1; i < 6; ++i)
-                if (w.m[i][k] != 0.0f) ok = false;
+                if (m[i][k] != 0.0f) ok = false;
         }
     }
     if (!ok) {
+#pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = 0.0f;
         return false;
     }
-    for (int i = 0; i < 6; ++i) w.y[i] = rhs[w.perm[i]];
+    float y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float v = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) v = (perm[i] == t) ? rhs[t] : v;
+        y[i] = v;
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < i; ++j) w.y[i] -= w.m[i][j] * w.y[j];
-    for (int i = 0; i < 6; ++i) w.y[i] = (fabsf(w.m[i][i]) > FLT_MIN) ? w.y[i] / w.m[i][i] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < i; ++j) y[i] -= m[i][j] * y[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = (fabsf(m[i][i]) > FLT_MIN) ? y[i] / m[i][i] : 0.0f;
+#pragma unroll
     for (int i = 5; i >= 0; --i)
-        for (int j = i + 1; j < 6; ++j) w.y[i] -= w.m[j][i] * w.y[j];
-    for (int i = 0; i < 6; ++i) x[w.perm[i]] = w.y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) y[i] -= m[j][i] * y[j];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v = (perm[i] == t) ? y[i] : v;
+        x[t] = v;
+    }
     return true;
 }
 
