@@ -86,6 +86,16 @@ float sp_grid_cell_size(const sp_grid* grid);
 int sp_grid_search(const sp_grid* grid, const float* queries, size_t nq, size_t k, const float* transT,
                    int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
 
+/* Self-kNN of the cloud a grid was built on, with the covariance / normal estimation optionally fused in
+ * (covariance::estimate_async(knn, points, k), feature/covariance.hpp:305-311, and estimate_normals_async(knn, ...),
+ * :451-459, when the KNNBase is a GridKNN over the same cloud). Any of idx_out+d2_out / covs_out / normals_out may be
+ * NULL; rows are written at the points' ORIGINAL indices. Neighbour lists are bit-identical to sp_knn_bruteforce of the
+ * cloud against itself, covariances bit-identical to sp_cov_estimate on those lists. k <= 20.
+ * workspace: sp_grid_self_workspace_bytes(grid). */
+size_t sp_grid_self_workspace_bytes(const sp_grid* grid);
+int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, float* covs_out, float* normals_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------ covariance / normals */
 
 /* covariance::estimate_async (algorithms/feature/covariance.hpp:16-47, 260-311, kernel K5). */

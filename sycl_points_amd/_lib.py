@@ -59,6 +59,8 @@ SIGNATURES = {
     "sp_grid_size": (_sz, [_vp]),
     "sp_grid_cell_size": (_f, [_vp]),
     "sp_grid_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
+    "sp_grid_self_workspace_bytes": (_sz, [_vp]),
+    "sp_grid_self_knn": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_cov_estimate": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "sp_normals_from_knn": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "sp_normals_from_cov": (_i, [_vp, _vp, _sz, _vp, _vp]),

@@ -244,6 +244,27 @@ class GridKNN(KNNBase):
         except Exception:
             pass
 
+    def self_knn(self, k, want_knn=True, want_covs=False, want_normals=False):
+        """kNN of the grid's own cloud (tile kernel, csrc/grid.hip) with covariance / normal estimation optionally
+        fused in — covariance::estimate_async(knn, points, k) (covariance.hpp:305-311) when the KNNBase is a GridKNN
+        built on `points`. Returns (KNNResult | None, covs | None, normals | None), rows in original point order."""
+        if k > 20:
+            raise SpError(2, "[GridKNN::knn_search_async] `k` is too large (max 20).")
+        L = _lib.lib()
+        dev = self.device
+        res = None
+        if want_knn:
+            res = KNNResult()
+            res.allocate(self.n, k, dev)
+        covs = torch.empty((self.n, 16), dtype=torch.float32, device=dev) if want_covs else None
+        nrm = torch.empty((self.n, 4), dtype=torch.float32, device=dev) if want_normals else None
+        nbytes = L.sp_grid_self_workspace_bytes(self._h)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        check(L.sp_grid_self_knn(self._h, k, _ptr(res.indices) if res else None, _ptr(res.distances) if res else None,
+                                 _ptr(covs), _ptr(nrm), _ptr(ws), nbytes, _stream()))
+        self._keep = ws
+        return res, covs, nrm
+
     def knn_search_async(self, queries, k, result, transT=None):
         q = _dev_f32(_points_of(queries), 4)
         if k > 20:

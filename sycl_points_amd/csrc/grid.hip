@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "grid_device.h"
 
@@ -39,8 +40,11 @@ __host__ __device__ inline float dec(unsigned u) {
     return f;
 }
 
-// bbox[0..2] = min xyz, bbox[3..5] = max xyz (encoded), over finite points
+// bbox[0..2] = min xyz, bbox[3..5] = max xyz (encoded), over finite points.
+// Grid-stride over <= 256 workgroups, wave butterfly, LDS across the 4 waves, then 6 integer atomics per workgroup
+// (exact, order independent).
 __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__ pts, unsigned n, unsigned* bbox) {
+    __shared__ unsigned red[kBlock / kWave][6];
     unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float4 p = pts[i];
@@ -58,9 +62,17 @@ __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__
             mx[a] = max(mx[a], (unsigned)__shfl_xor((int)mx[a], o, 64));
         }
     }
-    if ((threadIdx.x & 63) == 0) {  // integer atomics: exact and order independent
+    const unsigned wave = threadIdx.x / kWave;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(&bbox[a], mn[a]); atomicMax(&bbox[3 + a], mx[a]); }
+        for (int a = 0; a < 3; ++a) { red[wave][a] = mn[a]; red[wave][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned v = red[0][threadIdx.x];
+        for (int w = 1; w < kBlock / kWave; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bbox[threadIdx.x], v);
+        else atomicMax(&bbox[threadIdx.x], v);
     }
 }
 
@@ -192,6 +204,319 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
         if (i < k) { d2_out[o + i] = bd[i]; idx_out[o + i] = bi[i]; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Self-kNN on the grid (every point of the cloud queries its own cloud: the covariance / normal preprocessing of
+// the pipeline, pipeline/pointcloud_processing.hpp:144-156 and examples/example_registration.cpp:92-109).
+// Work unit = up to 64 consecutive points of one x-row of cells, one wave per unit. The unit's candidate set is the
+// 3 x 3 block of rows around it over the unit's x-span +- 1 cell: nine contiguous segments of the cell-ordered point
+// array. Candidates are streamed 64 at a time: one coalesced 16-byte load per lane, parked in LDS, then every lane
+// tests all of them with wave-uniform (broadcast) LDS reads — a brute force over a small local tile, with no
+// per-lane pointer chasing and no divergence except in the sorted insertion. A query whose k-th distance reaches
+// outside the scanned block (sparse regions) is appended to a to-do list and finished by the ring walk.
+__global__ void row_units_kernel(const unsigned* __restrict__ start, unsigned nx, unsigned rows,
+                                 unsigned* __restrict__ units) {
+    const unsigned r = blockIdx.x * kBlock + threadIdx.x;
+    if (r < rows) units[r] = (start[(size_t)(r + 1) * nx] - start[(size_t)r * nx] + 63u) / 64u;
+}
+
+struct TileOut {
+    int32_t* knn_idx;  // [n][k] original order (may be null)
+    float* knn_d2;
+    float4* covs;      // [n][4] (may be null)
+    float4* normals;   // [n] (may be null)
+    unsigned* todo;    // queries (positions in grid order) the ring walk must finish
+    unsigned* todo_count;
+};
+
+// covariance::kernel::estimate (feature/covariance.hpp:16-47) over the neighbour list in ascending order, reading
+// the neighbours from the cell-ordered copy (same values as points[idx], nearby in memory).
+__device__ __forceinline__ void cov_from_list(const float4* __restrict__ pts, const int* bp, int k, float c[6],
+                                              bool& identity) {
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, oxx = 0.0f, oxy = 0.0f, oxz = 0.0f, oyy = 0.0f, oyz = 0.0f, ozz = 0.0f;
+    unsigned cnt = 0;
+    for (int j = 0; j < k; ++j) {
+        const int pos = bp[j];
+        if (pos < 0) continue;
+        const float4 p = pts[pos];
+        sx += p.x; sy += p.y; sz += p.z;
+        oxx += p.x * p.x; oxy += p.x * p.y; oxz += p.x * p.z;
+        oyy += p.y * p.y; oyz += p.y * p.z; ozz += p.z * p.z;
+        ++cnt;
+    }
+    identity = cnt < 4;
+    if (identity) return;
+    const float inv = 1.0f / (float)cnt;
+    const float mx = sx * inv, my = sy * inv, mz = sz * inv;
+    const float cxy = oxy * inv - mx * my, cxz = oxz * inv - mx * mz, cyz = oyz * inv - my * mz;
+    c[0] = oxx * inv - mx * mx; c[1] = (cxy + cxy) * 0.5f; c[2] = (cxz + cxz) * 0.5f;
+    c[3] = oyy * inv - my * my; c[4] = (cyz + cyz) * 0.5f; c[5] = ozz * inv - mz * mz;
+}
+
+template <int KCAP>
+__global__ __launch_bounds__(kWave) void grid_self_knn_tile_kernel(const float4* __restrict__ pts,
+                                                                   const unsigned* __restrict__ start,
+                                                                   const unsigned* __restrict__ unit_off, GridDesc g,
+                                                                   int k, TileOut out) {
+    __shared__ float4 tile[kWave];
+    const unsigned unit = blockIdx.x;
+    const unsigned rows = (unsigned)g.ny * g.nz;
+    // row of this unit: last r with unit_off[r] <= unit (wave-uniform binary search)
+    unsigned lo = 0, hi = rows;
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (unit_off[mid] <= unit) lo = mid;
+        else hi = mid;
+    }
+    const unsigned row = lo;
+    const int ry = (int)(row % g.ny), rz = (int)(row / g.ny);
+    const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
+    const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
+    const unsigned qe = min(qs + 64u, row_e);
+    const unsigned lane = threadIdx.x;
+    const bool active = qs + lane < qe;
+    const float4 q = pts[min(qs + lane, qe - 1)];
+    // x-span of the unit's queries (cells are ascending along the row)
+    const float4 qf = pts[qs], ql = pts[qe - 1];
+    const int cxa = cell_coord(qf.x, g.ox, g.inv_h, g.nx), cxb = cell_coord(ql.x, g.ox, g.inv_h, g.nx);
+    const int xa = max(cxa - 1, 0), xb = min(cxb + 1, g.nx - 1);
+    const int ya = max(ry - 1, 0), yb = min(ry + 1, g.ny - 1), za = max(rz - 1, 0), zb = min(rz + 1, g.nz - 1);
+
+    float bd[KCAP];
+    int bi[KCAP], bp[KCAP];
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; bp[i] = -1; }
+    float kth = FLT_MAX;
+    int kth_idx = -1;
+
+    for (int z = za; z <= zb; ++z)
+        for (int y = ya; y <= yb; ++y) {
+            const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
+            const unsigned s = start[rr + xa], e = start[rr + xb + 1];
+            for (unsigned base = s; base < e; base += kWave) {
+                const unsigned cnt = min((unsigned)kWave, e - base);
+                __syncthreads();
+                if (lane < cnt) tile[lane] = pts[base + lane];
+                __syncthreads();
+                for (unsigned c = 0; c < cnt; ++c) {
+                    const float4 p = tile[c];
+                    const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+                    const int pi = __float_as_int(p.w);
+                    if (d < kth || (d == kth && pi < kth_idx)) {
+                        // sorted insertion by (distance, original index); positions ride along
+                        float cd = d;
+                        int ci = pi, cp = (int)(base + c);
+                        bool shifting = false;
+#pragma unroll
+                        for (int i = 0; i < KCAP; ++i) {
+                            if (i < k) {
+                                const bool sw = shifting || cd < bd[i] || (cd == bd[i] && ci < bi[i]);
+                                const float td = bd[i];
+                                const int ti = bi[i], tp = bp[i];
+                                const float nd = sw ? cd : td;
+                                const int ni = sw ? ci : ti;
+                                bd[i] = nd; bi[i] = ni; bp[i] = sw ? cp : tp;
+                                cd = sw ? td : cd; ci = sw ? ti : ci; cp = sw ? tp : cp;
+                                shifting = sw;
+                                kth = nd; kth_idx = ni;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    if (!active) return;
+    // is the k-th neighbour provably inside the scanned block?
+    float cov = FLT_MAX;
+    if (xa > 0) cov = fminf(cov, q.x - (g.ox + xa * g.h));
+    if (xb < g.nx - 1) cov = fminf(cov, (g.ox + (xb + 1) * g.h) - q.x);
+    if (ya > 0) cov = fminf(cov, q.y - (g.oy + ya * g.h));
+    if (yb < g.ny - 1) cov = fminf(cov, (g.oy + (yb + 1) * g.h) - q.y);
+    if (za > 0) cov = fminf(cov, q.z - (g.oz + za * g.h));
+    if (zb < g.nz - 1) cov = fminf(cov, (g.oz + (zb + 1) * g.h) - q.z);
+    bool exact = true;
+    if (cov != FLT_MAX) {
+        cov = fmaxf(cov - g.eps, 0.0f);
+        exact = kth < cov * cov;
+    }
+    if (!exact) {
+        const unsigned slot = atomicAdd(out.todo_count, 1u);
+        out.todo[slot] = qs + lane;
+        return;
+    }
+    const unsigned orig = __float_as_uint(q.w);
+    if (out.knn_idx) {
+        const size_t o = (size_t)orig * (size_t)k;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i)
+            if (i < k) { out.knn_idx[o + i] = bi[i]; out.knn_d2[o + i] = bd[i]; }
+    }
+    if (out.covs || out.normals) {
+        float c[6];
+        bool identity;
+        cov_from_list(pts, bp, k, c, identity);
+        Mat3 C;
+        if (identity) {
+            C.m[0][0] = C.m[1][1] = C.m[2][2] = 1.0f;
+            C.m[0][1] = C.m[0][2] = C.m[1][0] = C.m[1][2] = C.m[2][0] = C.m[2][1] = 0.0f;
+        } else {
+            C.m[0][0] = c[0]; C.m[0][1] = c[1]; C.m[0][2] = c[2];
+            C.m[1][0] = c[1]; C.m[1][1] = c[3]; C.m[1][2] = c[4];
+            C.m[2][0] = c[2]; C.m[2][1] = c[4]; C.m[2][2] = c[5];
+        }
+        if (out.covs) {
+            float4* o4 = out.covs + 4 * (size_t)orig;
+            o4[0] = make_float4(C.m[0][0], C.m[1][0], C.m[2][0], 0.0f);
+            o4[1] = make_float4(C.m[0][1], C.m[1][1], C.m[2][1], 0.0f);
+            o4[2] = make_float4(C.m[0][2], C.m[1][2], C.m[2][2], 0.0f);
+            o4[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        if (out.normals) {  // covariance::kernel::extract_normal (covariance.hpp:49-65)
+            float ev[3];
+            Mat3 V;
+            symmetric_eigen3(C, ev, V);
+            const float nx_ = V.m[0][0], ny_ = V.m[1][0], nz_ = V.m[2][0];
+            const float dd = chain3(nx_, q.x, ny_, q.y, nz_, q.z);
+            out.normals[orig] = (dd <= 1.0f) ? make_float4(nx_, ny_, nz_, 0.0f) : make_float4(-nx_, -ny_, -nz_, 0.0f);
+        }
+    }
+}
+
+// Ring walk for the queries the tile kernel could not prove exact (their positions are listed in `todo`).
+template <int KCAP>
+__global__ __launch_bounds__(kBlock) void grid_self_knn_todo_kernel(const float4* __restrict__ pts,
+                                                                    const unsigned* __restrict__ start, GridDesc g,
+                                                                    int k, TileOut out) {
+    const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= *out.todo_count) return;
+    const float4 q = pts[out.todo[t]];
+    float bd[KCAP];
+    int bi[KCAP], bp[KCAP];
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; bp[i] = -1; }
+    float kth = FLT_MAX;
+    int kth_idx = -1;
+    const int cx = cell_coord(q.x, g.ox, g.inv_h, g.nx), cy = cell_coord(q.y, g.oy, g.inv_h, g.ny),
+              cz = cell_coord(q.z, g.oz, g.inv_h, g.nz);
+    const int rmax = max(max(g.nx, g.ny), g.nz);
+    for (int r = 0; r <= rmax; ++r) {
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const float dz2 = gap2(q.z, g.oz + z * g.h, g.oz + (z + 1) * g.h, g.eps);
+            if (dz2 > kth) continue;
+            for (int y = y0; y <= y1; ++y) {
+                const float dyz2 = dz2 + gap2(q.y, g.oy + y * g.h, g.oy + (y + 1) * g.h, g.eps);
+                if (dyz2 > kth) continue;
+                const bool shell_row = (r == 0) || (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+                const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
+                const int nseg = shell_row ? 1 : 2;
+                for (int sgi = 0; sgi < nseg; ++sgi) {
+                    int xa, xb;
+                    if (shell_row) { xa = x0; xb = x1; }
+                    else if (sgi == 0) { xa = cx - r; xb = cx - r; if (xa < 0) continue; }
+                    else { xa = cx + r; xb = cx + r; if (xb > g.nx - 1) continue; }
+                    if (dyz2 + gap2(q.x, g.ox + xa * g.h, g.ox + (xb + 1) * g.h, g.eps) > kth) continue;
+                    const unsigned s = start[row + xa], e = start[row + xb + 1];
+                    for (unsigned i = s; i < e; ++i) {
+                        const float4 p = pts[i];
+                        const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+                        const int pi = __float_as_int(p.w);
+                        if (d < kth || (d == kth && pi < kth_idx)) {
+                            float cd = d;
+                            int ci = pi, cp = (int)i;
+                            bool shifting = false;
+#pragma unroll
+                            for (int j = 0; j < KCAP; ++j) {
+                                if (j < k) {
+                                    const bool sw = shifting || cd < bd[j] || (cd == bd[j] && ci < bi[j]);
+                                    const float td = bd[j];
+                                    const int ti = bi[j], tp = bp[j];
+                                    const float nd = sw ? cd : td;
+                                    const int ni = sw ? ci : ti;
+                                    bd[j] = nd; bi[j] = ni; bp[j] = sw ? cp : tp;
+                                    cd = sw ? td : cd; ci = sw ? ti : ci; cp = sw ? tp : cp;
+                                    shifting = sw;
+                                    kth = nd; kth_idx = ni;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        float cov = FLT_MAX;
+        if (cx - r > 0) cov = fminf(cov, q.x - (g.ox + (cx - r) * g.h));
+        if (cx + r < g.nx - 1) cov = fminf(cov, (g.ox + (cx + r + 1) * g.h) - q.x);
+        if (cy - r > 0) cov = fminf(cov, q.y - (g.oy + (cy - r) * g.h));
+        if (cy + r < g.ny - 1) cov = fminf(cov, (g.oy + (cy + r + 1) * g.h) - q.y);
+        if (cz - r > 0) cov = fminf(cov, q.z - (g.oz + (cz - r) * g.h));
+        if (cz + r < g.nz - 1) cov = fminf(cov, (g.oz + (cz + r + 1) * g.h) - q.z);
+        if (cov == FLT_MAX) break;
+        cov = fmaxf(cov - g.eps, 0.0f);
+        if (kth < cov * cov) break;
+    }
+    const unsigned orig = __float_as_uint(q.w);
+    if (out.knn_idx) {
+        const size_t o = (size_t)orig * (size_t)k;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i)
+            if (i < k) { out.knn_idx[o + i] = bi[i]; out.knn_d2[o + i] = bd[i]; }
+    }
+    if (out.covs || out.normals) {
+        float c[6];
+        bool identity;
+        cov_from_list(pts, bp, k, c, identity);
+        Mat3 C;
+        if (identity) {
+            C.m[0][0] = C.m[1][1] = C.m[2][2] = 1.0f;
+            C.m[0][1] = C.m[0][2] = C.m[1][0] = C.m[1][2] = C.m[2][0] = C.m[2][1] = 0.0f;
+        } else {
+            C.m[0][0] = c[0]; C.m[0][1] = c[1]; C.m[0][2] = c[2];
+            C.m[1][0] = c[1]; C.m[1][1] = c[3]; C.m[1][2] = c[4];
+            C.m[2][0] = c[2]; C.m[2][1] = c[4]; C.m[2][2] = c[5];
+        }
+        if (out.covs) {
+            float4* o4 = out.covs + 4 * (size_t)orig;
+            o4[0] = make_float4(C.m[0][0], C.m[1][0], C.m[2][0], 0.0f);
+            o4[1] = make_float4(C.m[0][1], C.m[1][1], C.m[2][1], 0.0f);
+            o4[2] = make_float4(C.m[0][2], C.m[1][2], C.m[2][2], 0.0f);
+            o4[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        if (out.normals) {
+            float ev[3];
+            Mat3 V;
+            symmetric_eigen3(C, ev, V);
+            const float nx_ = V.m[0][0], ny_ = V.m[1][0], nz_ = V.m[2][0];
+            const float dd = chain3(nx_, q.x, ny_, q.y, nz_, q.z);
+            out.normals[orig] = (dd <= 1.0f) ? make_float4(nx_, ny_, nz_, 0.0f) : make_float4(-nx_, -ny_, -nz_, 0.0f);
+        }
+    }
+}
+
+__global__ void fill_todo_kernel(unsigned* todo, unsigned* count, unsigned n) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) todo[i] = i;
+    if (i == 0) *count = n;
+}
+
+template <int KCAP>
+int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
+    const GridDesc g = grid_desc(gr);
+    if (KCAP <= 10) {
+        if (hipMemsetAsync(out.todo_count, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
+        if (gr->n_units)
+            grid_self_knn_tile_kernel<KCAP><<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
+    } else {
+        // Long lists: the tile kernel's sorted insertion runs for almost every candidate as soon as ANY lane of the wave
+        // needs it (measured 22.9 ms per 1M points at k = 20, profiles/README.md r01_e), so every point takes the
+        // ring walk instead, in cell order (neighbouring lanes share their rows).
+        fill_todo_kernel<<<div_up(gr->n, kBlock), kBlock, 0, st>>>(out.todo, out.todo_count, (unsigned)gr->n);
+    }
+    grid_self_knn_todo_kernel<KCAP><<<div_up(gr->n, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
+    return launch_status();
+}
+
 __global__ __launch_bounds__(kBlock) void grid_search_k1_kernel(const float4* __restrict__ pts,
                                                                 const unsigned* __restrict__ start, GridDesc g,
                                                                 const float4* __restrict__ queries, unsigned nq,
@@ -236,6 +561,7 @@ extern "C" void sp_grid_destroy(sp_grid* g) {
     if (!g) return;
     if (g->d_pts) (void)hipFree(g->d_pts);
     if (g->d_start) (void)hipFree(g->d_start);
+    if (g->d_unit_off) (void)hipFree(g->d_unit_off);
     delete g;
 }
 
@@ -271,7 +597,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     unsigned h_bbox[6];
     e = hipMemcpyAsync(d_bbox, init, sizeof init, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        bbox_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, d_bbox);
+        bbox_kernel<<<std::min(stream_grid(n), 256u), kBlock, 0, st>>>(pts, (unsigned)n, d_bbox);
         e = hipMemcpyAsync(h_bbox, d_bbox, sizeof h_bbox, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -343,6 +669,24 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
                                                                           g->d_start);
         e = hipStreamSynchronize(st);
     }
+    if (e == hipSuccess) {  // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed
+        const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
+        unsigned* units = nullptr;
+        void* stmp = nullptr;
+        size_t stmp_bytes = 0;
+        (void)rocprim::exclusive_scan(nullptr, stmp_bytes, units, units, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+        e = hipMalloc(&units, (rows + 1) * 4);
+        if (e == hipSuccess) e = hipMalloc(&g->d_unit_off, (rows + 1) * 4);
+        if (e == hipSuccess) e = hipMalloc(&stmp, std::max<size_t>(stmp_bytes, 16));
+        if (e == hipSuccess) e = hipMemsetAsync(units, 0, (rows + 1) * 4, st);
+        if (e == hipSuccess) {
+            row_units_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
+            e = rocprim::exclusive_scan(stmp, stmp_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(units); (void)hipFree(stmp);
+    }
     (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(tmp);
     if (e != hipSuccess) return fail(e);
     *out = g;
@@ -368,4 +712,34 @@ extern "C" int sp_grid_search(const sp_grid* grid, const float* queries, size_t 
     if (k == 1) return launch<1>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     if (k <= 10) return launch<10>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     return launch<20>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
+}
+
+extern "C" size_t sp_grid_self_workspace_bytes(const sp_grid* grid) { return grid ? (grid->n + 2) * 4 : 0; }
+
+extern "C" int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, float* covs_out,
+                                float* normals_out, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    if (!grid || k == 0) {
+        sp_set_error("[GridKNN::self_knn] null grid or k == 0");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (k > 20) {
+        sp_set_error("[GridKNN::knn_search_async] `k` is too large (max 20).");
+        return SP_ERR_RUNTIME;
+    }
+    if (grid->n == 0) return SP_OK;
+    if (!workspace || workspace_bytes < sp_grid_self_workspace_bytes(grid)) {
+        sp_set_error("[GridKNN::self_knn] workspace too small (sp_grid_self_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    TileOut out;
+    out.knn_idx = (idx_out && d2_out) ? idx_out : nullptr;
+    out.knn_d2 = d2_out;
+    out.covs = reinterpret_cast<float4*>(covs_out);
+    out.normals = reinterpret_cast<float4*>(normals_out);
+    out.todo_count = static_cast<unsigned*>(workspace);
+    out.todo = out.todo_count + 2;
+    hipStream_t st = as_stream(stream);
+    if (k <= 10) return launch_self<10>(grid, (int)k, out, st);
+    return launch_self<20>(grid, (int)k, out, st);
 }

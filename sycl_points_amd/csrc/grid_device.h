@@ -11,6 +11,8 @@ struct sp_grid {
     size_t ncells = 1;
     float4* d_pts = nullptr;      // n points in cell order, w = original index bits
     uint32_t* d_start = nullptr;  // ncells + 1
+    uint32_t* d_unit_off = nullptr;  // rows + 1: first 64-query work unit of every x-row (self-kNN tiling)
+    uint32_t n_units = 0;
 };
 
 namespace sp {

@@ -591,3 +591,42 @@ def test_fused_loop_equals_generic_loop_and_oracle(sp, orc, gicp20k):
     assert np.abs(Tf - ref["T"]).max() < 1e-5
     assert reg._read_lin(lin).inlier == ref["inlier"]
     assert float(delta[7]) == 1.0
+
+
+# ------------------------------------------------------------------ tile self-kNN (+ fused covariance / normals)
+@pytest.mark.parametrize("k", [4, 10, 20])
+@pytest.mark.parametrize("shape", ["uniform", "clustered"])
+def test_grid_self_knn_and_fused_covariance(sp, orc, k, shape):
+    n = 12000
+    pts = cloud(orc, 11, n, 4.0)
+    if shape == "clustered":  # dense blobs + empty space + far outliers: exercises the to-do (ring walk) path
+        rs = np.random.RandomState(1)
+        pts[: n // 2, :3] = (rs.normal(0, 0.05, (n // 2, 3)) + rs.randint(-3, 4, (n // 2, 1)) * 1.0).astype(np.float32)
+        pts[-20:, :3] *= 50.0
+    for ppc in (1.0, 8.0):
+        grid = sp.GridKNN.build(dev(pts), points_per_cell=ppc)
+        res, covs, nrm = grid.self_knn(k, want_knn=True, want_covs=True, want_normals=True)
+        oi, od = orc.knn_bruteforce(pts, pts, k)
+        assert np.array_equal(res.distances.cpu().numpy(), od)
+        assert np.array_equal(res.indices.cpu().numpy(), oi)
+        ocov = orc.cov_estimate(pts, oi)
+        assert np.array_equal(covs.cpu().numpy(), ocov)
+        onrm = orc.normals_from_cov(pts, ocov)
+        dots = np.abs((nrm.cpu().numpy()[:, :3] * onrm[:, :3]).sum(1))
+        assert np.percentile(dots, 2) > 1 - 1e-3
+
+
+def test_grid_self_knn_1m_matches_kdtree_covariances(sp, orc):
+    pts = cloud(orc, 1234, 1000000, 10.0)
+    P = dev(pts)
+    grid = sp.GridKNN.build(P, points_per_cell=8.0)
+    res, covs, _ = grid.self_knn(20, want_knn=True, want_covs=True)
+    tree = sp.KDTree.build(pts)
+    ref = tree.knn_search(P, 20)
+    assert torch.equal(res.distances, ref.distances)
+    # indices may differ only inside exact-distance tie groups (KD-tree: first visited; grid: lowest index)
+    diff = (res.indices != ref.indices).any(1)
+    d = res.distances[diff]
+    assert diff.float().mean().item() < 1e-3 and bool(((d[:, 1:] == d[:, :-1]).any(1)).all())
+    same = ~diff
+    assert torch.equal(covs[same], sp.covariance.estimate(ref, P)[same])
