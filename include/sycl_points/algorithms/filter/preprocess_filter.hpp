@@ -1,0 +1,3 @@
+// Reference-path forwarding header: algorithms/filter/preprocess_filter.hpp of fateshelled/sycl_points maps onto the MI355X facade.
+#pragma once
+#include "../../amd/features.hpp"

@@ -1,0 +1,392 @@
+// sycl_points facade for MI355X — core types.
+//
+// Source-compatible stand-ins for the reference's L1/L3 layers:
+//   utils/sycl_utils.hpp  : sycl_utils::DeviceQueue, sycl_utils::events, shared_vector<T>, shared_vector_ptr<T>
+//   points/types.hpp      : PointType, Covariance, Normal, RGBType, TransformMatrix, containers
+//   points/point_cloud.hpp: PointCloudCPU, PointCloudShared
+// The reference keeps every attribute in USM-shared std::vectors and lets pages migrate. On MI355X (XNACK off) managed
+// pages would be served over PCIe, so shared_vector<T> here is a host std::vector<T> plus an explicit HBM mirror with
+// dirty tracking: host accessors behave like std::vector, kernels take device_data(), and copies happen only when the
+// side being read is stale — at the same points where the reference calls set_accessed_by_host / _device
+// (utils/sycl_utils.hpp:572-625).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <sycl_points_amd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <initializer_list>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#include <Eigen/Geometry>
+#else
+// Minimal Eigen subset (the container image has no Eigen): fixed-size float matrices, column-major like Eigen.
+namespace Eigen {
+template <typename T, int R, int C>
+struct Matrix {
+    static_assert(std::is_same<T, float>::value, "eigen_lite: float only");
+    T d[R * C];
+    Matrix() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
+    Matrix(T x, T y, T z) { static_assert(R * C == 3, "size"); d[0] = x; d[1] = y; d[2] = z; }
+    Matrix(T x, T y, T z, T w) { static_assert(R * C == 4, "size"); d[0] = x; d[1] = y; d[2] = z; d[3] = w; }
+    static Matrix Zero() { return Matrix(); }
+    static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
+    T& operator()(int i, int j) { return d[j * R + i]; }
+    const T& operator()(int i, int j) const { return d[j * R + i]; }
+    T& operator()(int i) { return d[i]; }
+    const T& operator()(int i) const { return d[i]; }
+    T& operator[](int i) { return d[i]; }
+    const T& operator[](int i) const { return d[i]; }
+    T* data() { return d; }
+    const T* data() const { return d; }
+    T& x() { return d[0]; } T& y() { return d[1]; } T& z() { return d[2]; } T& w() { return d[3]; }
+    const T& x() const { return d[0]; } const T& y() const { return d[1]; } const T& z() const { return d[2]; } const T& w() const { return d[3]; }
+    static constexpr int rows() { return R; }
+    static constexpr int cols() { return C; }
+    void setZero() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
+    void setIdentity() { *this = Identity(); }
+    Matrix<T, C, R> transpose() const { Matrix<T, C, R> t; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) t(j, i) = (*this)(i, j); return t; }
+    Matrix operator+(const Matrix& o) const { Matrix r; for (int i = 0; i < R * C; ++i) r.d[i] = d[i] + o.d[i]; return r; }
+    Matrix operator-(const Matrix& o) const { Matrix r; for (int i = 0; i < R * C; ++i) r.d[i] = d[i] - o.d[i]; return r; }
+    Matrix operator-() const { Matrix r; for (int i = 0; i < R * C; ++i) r.d[i] = -d[i]; return r; }
+    Matrix operator*(T s) const { Matrix r; for (int i = 0; i < R * C; ++i) r.d[i] = d[i] * s; return r; }
+    Matrix operator/(T s) const { Matrix r; for (int i = 0; i < R * C; ++i) r.d[i] = d[i] / s; return r; }
+    Matrix& operator+=(const Matrix& o) { for (int i = 0; i < R * C; ++i) d[i] += o.d[i]; return *this; }
+    template <int K>
+    Matrix<T, R, K> operator*(const Matrix<T, C, K>& o) const {
+        Matrix<T, R, K> r;
+        for (int i = 0; i < R; ++i) for (int j = 0; j < K; ++j) { T s = T(0); for (int k = 0; k < C; ++k) s += (*this)(i, k) * o(k, j); r(i, j) = s; }
+        return r;
+    }
+    T norm() const { T s = T(0); for (int i = 0; i < R * C; ++i) s += d[i] * d[i]; return std::sqrt(s); }
+    T squaredNorm() const { T s = T(0); for (int i = 0; i < R * C; ++i) s += d[i] * d[i]; return s; }
+    bool operator==(const Matrix& o) const { return std::memcmp(d, o.d, sizeof d) == 0; }
+};
+template <typename T, int N>
+using Vector = Matrix<T, N, 1>;
+using Vector3f = Matrix<float, 3, 1>;
+using Vector4f = Matrix<float, 4, 1>;
+using Matrix3f = Matrix<float, 3, 3>;
+using Matrix4f = Matrix<float, 4, 4>;
+template <typename T> struct aligned_allocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = aligned_allocator<U>; };
+};
+enum TransformTraits { Isometry = 1 };
+// Transform<float,3,Isometry> subset: a 4x4 whose last row is 0 0 0 1.
+struct Isometry3f {
+    Matrix4f m = Matrix4f::Identity();
+    Isometry3f() = default;
+    explicit Isometry3f(const Matrix4f& mm) : m(mm) {}
+    static Isometry3f Identity() { return Isometry3f(); }
+    Matrix4f& matrix() { return m; }
+    const Matrix4f& matrix() const { return m; }
+    Matrix3f linear() const { Matrix3f r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = m(i, j); return r; }
+    Vector3f translation() const { return Vector3f(m(0, 3), m(1, 3), m(2, 3)); }
+    Isometry3f operator*(const Isometry3f& o) const { Isometry3f r; sp_rigid_mul_host(m.data(), o.m.data(), r.m.data()); return r; }
+    Isometry3f inverse() const {
+        Isometry3f r;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m(i, j) = m(j, i);
+        for (int i = 0; i < 3; ++i) r.m(i, 3) = -(r.m(i, 0) * m(0, 3) + r.m(i, 1) * m(1, 3) + r.m(i, 2) * m(2, 3));
+        return r;
+    }
+};
+}  // namespace Eigen
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#endif
+
+namespace sycl_points {
+
+// ---------------------------------------------------------------------------------------------- errors
+inline void throw_on_error(int rc) {
+    if (rc == SP_OK) return;
+    const std::string msg = sp_last_error();
+    if (rc == SP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+namespace sycl_utils {
+
+/// utils/sycl_utils.hpp:491-626 — queue handle. Here: a device ordinal and an in-order HIP stream.
+struct DeviceQueue {
+    using Ptr = std::shared_ptr<DeviceQueue>;
+    struct StreamHolder {
+        hipStream_t stream = nullptr;
+        int device = 0;
+        ~StreamHolder() { if (stream) (void)hipStreamDestroy(stream); }
+    };
+    std::shared_ptr<StreamHolder> ptr;  // the reference exposes `ptr` (a sycl::queue); kept as the stream holder
+
+    DeviceQueue() : DeviceQueue(0) {}
+    explicit DeviceQueue(int device) {
+        ptr = std::make_shared<StreamHolder>();
+        ptr->device = device;
+        throw_on_error(sp_set_device(device));
+        hip_check(hipStreamCreateWithFlags(&ptr->stream, hipStreamNonBlocking), "hipStreamCreate");
+    }
+    hipStream_t stream() const { return ptr->stream; }
+    void wait() const { hip_check(hipStreamSynchronize(ptr->stream), "hipStreamSynchronize"); }
+    size_t get_work_group_size() const { return 256; }
+    size_t get_global_size(size_t n) const { return (n + 255) / 256 * 256; }
+    void print_device_info() const {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, ptr->device) == hipSuccess)
+            printf("Device: %s (%s), %d CUs\n", p.name, p.gcnArchName, p.multiProcessorCount);
+    }
+    // mem-advise hooks of the reference (utils/sycl_utils.hpp:572-625): residency is explicit here, so they are no-ops.
+    template <typename T> void set_accessed_by_device(const T*, size_t) const {}
+    template <typename T> void clear_accessed_by_device(const T*, size_t) const {}
+    template <typename T> void set_accessed_by_host(const T*, size_t) const {}
+    template <typename T> void clear_accessed_by_host(const T*, size_t) const {}
+};
+
+/// The reference's `sycl::event`: here the stream the work was enqueued on (all work of a cloud shares one in-order
+/// stream, so "depends on these events" is already implied by enqueue order; the type exists for source compatibility).
+struct event {
+    hipStream_t stream = nullptr;
+};
+/// utils/sycl_utils.hpp:234-280 — a set of events.
+struct events {
+    std::vector<event> evs;
+    events() = default;
+    explicit events(hipStream_t s) { evs.push_back(event{s}); }
+    events& operator+=(const events& o) { evs.insert(evs.end(), o.evs.begin(), o.evs.end()); return *this; }
+    void wait() const { for (const auto& e : evs) hip_check(hipStreamSynchronize(e.stream), "hipStreamSynchronize"); }
+    void wait_and_throw() const { wait(); hip_check(hipGetLastError(), "device error"); }
+};
+
+}  // namespace sycl_utils
+
+// ---------------------------------------------------------------------------------------------- shared_vector
+/// utils/sycl_utils.hpp:630-635. std::vector semantics on the host + an HBM mirror.
+template <typename T>
+class shared_vector {
+public:
+    using value_type = T;
+    using iterator = typename std::vector<T>::iterator;
+    using const_iterator = typename std::vector<T>::const_iterator;
+
+    shared_vector() = default;
+    explicit shared_vector(const sycl_utils::DeviceQueue& q) : queue_(q.ptr) {}
+    shared_vector(size_t n, const sycl_utils::DeviceQueue& q) : host_(n), queue_(q.ptr) {}
+    shared_vector(size_t n, const T& v, const sycl_utils::DeviceQueue& q) : host_(n, v), queue_(q.ptr) {}
+    // the reference passes `*queue.ptr` (a sycl::queue) to the allocator; accept the stream holder the same way
+    shared_vector(size_t n, const sycl_utils::DeviceQueue::StreamHolder& h) : host_(n) { bind(h); }
+    shared_vector(size_t n, const T& v, const sycl_utils::DeviceQueue::StreamHolder& h) : host_(n, v) { bind(h); }
+    shared_vector(const shared_vector& o) : host_(o.host()), queue_(o.queue_), stream_(o.stream_) {}
+    shared_vector& operator=(const shared_vector& o) {
+        if (this != &o) { host_ = o.host(); host_dirty_ = true; dev_dirty_ = false; }
+        return *this;
+    }
+    ~shared_vector() { if (dev_) (void)hipFree(dev_); }
+
+    // ---- host side (std::vector surface)
+    size_t size() const { return size_override_ ? dev_size_ : host_.size(); }
+    bool empty() const { return size() == 0; }
+    void resize(size_t n) { sync_host(); host_.resize(n); host_dirty_ = true; }
+    void resize(size_t n, const T& v) { sync_host(); host_.resize(n, v); host_dirty_ = true; }
+    void reserve(size_t n) { host_.reserve(n); }
+    void clear() { size_override_ = false; dev_dirty_ = false; host_.clear(); host_dirty_ = true; }
+    void assign(size_t n, const T& v) { size_override_ = false; dev_dirty_ = false; host_.assign(n, v); host_dirty_ = true; }
+    void push_back(const T& v) { sync_host(); host_.push_back(v); host_dirty_ = true; }
+    template <class... A> void emplace_back(A&&... a) { sync_host(); host_.emplace_back(std::forward<A>(a)...); host_dirty_ = true; }
+    T& operator[](size_t i) { sync_host(); host_dirty_ = true; return host_[i]; }
+    const T& operator[](size_t i) const { sync_host(); return host_[i]; }
+    T& at(size_t i) { sync_host(); host_dirty_ = true; return host_.at(i); }
+    const T& at(size_t i) const { sync_host(); return host_.at(i); }
+    T* data() { sync_host(); host_dirty_ = true; return host_.data(); }
+    const T* data() const { sync_host(); return host_.data(); }
+    iterator begin() { sync_host(); host_dirty_ = true; return host_.begin(); }
+    iterator end() { sync_host(); host_dirty_ = true; return host_.end(); }
+    const_iterator begin() const { sync_host(); return host_.begin(); }
+    const_iterator end() const { sync_host(); return host_.end(); }
+    const std::vector<T>& host() const { sync_host(); return host_; }
+
+    // ---- device side (what the kernels get)
+    /// Read-only device pointer; uploads first if the host copy is newer.
+    const T* device_data() const { sync_device(); return dev_; }
+    /// Writable device pointer for `n` elements (kernel output): the host copy becomes stale, nothing is uploaded.
+    T* device_data_for_write(size_t n) {
+        ensure_capacity(n);
+        dev_size_ = n; size_override_ = true; dev_dirty_ = true; host_dirty_ = false;
+        return dev_;
+    }
+    /// Read-write device pointer (in-place kernels).
+    T* device_data_rw() { sync_device(); dev_dirty_ = true; dev_size_ = host_.size(); size_override_ = true; return dev_; }
+    /// After a kernel produced fewer rows than reserved (compaction, downsampling).
+    void set_device_size(size_t n) { dev_size_ = n; size_override_ = true; dev_dirty_ = true; }
+    hipStream_t stream() const { return queue_ ? queue_->stream : stream_; }
+
+private:
+    void bind(const sycl_utils::DeviceQueue::StreamHolder& h) { stream_ = h.stream; }
+    void ensure_capacity(size_t n) const {
+        if (n <= dev_cap_) return;
+        T* nd = nullptr;
+        hip_check(hipMalloc(&nd, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc");
+        if (dev_) {
+            if (dev_dirty_ && dev_size_) hip_check(hipMemcpy(nd, dev_, std::min(dev_size_, n) * sizeof(T), hipMemcpyDeviceToDevice), "hipMemcpy");
+            (void)hipFree(dev_);
+        }
+        dev_ = nd;
+        dev_cap_ = n;
+    }
+    void sync_device() const {
+        if (dev_dirty_) return;  // device is the newest copy
+        if (host_dirty_ || dev_ == nullptr || dev_size_ != host_.size()) {
+            ensure_capacity(host_.size());
+            if (!host_.empty())
+                hip_check(hipMemcpyAsync(dev_, host_.data(), host_.size() * sizeof(T), hipMemcpyHostToDevice, stream()), "H2D");
+            hip_check(hipStreamSynchronize(stream()), "H2D sync");  // the host vector may be modified right after
+            dev_size_ = host_.size();
+            host_dirty_ = false;
+        }
+    }
+    void sync_host() const {
+        if (!dev_dirty_) return;
+        hip_check(hipStreamSynchronize(stream()), "sync");
+        host_.resize(dev_size_);
+        if (dev_size_) hip_check(hipMemcpy(host_.data(), dev_, dev_size_ * sizeof(T), hipMemcpyDeviceToHost), "D2H");
+        dev_dirty_ = false;
+        size_override_ = false;
+        host_dirty_ = false;
+    }
+
+    mutable std::vector<T> host_;
+    mutable T* dev_ = nullptr;
+    mutable size_t dev_cap_ = 0, dev_size_ = 0;
+    mutable bool host_dirty_ = true, dev_dirty_ = false, size_override_ = false;
+    std::shared_ptr<sycl_utils::DeviceQueue::StreamHolder> queue_;
+    hipStream_t stream_ = nullptr;
+};
+template <typename T>
+using shared_vector_ptr = std::shared_ptr<shared_vector<T>>;
+
+// ---------------------------------------------------------------------------------------------- points/types.hpp
+using PointType = Eigen::Vector4f;
+using Covariance = Eigen::Matrix4f;
+using Normal = Eigen::Vector4f;
+using RGBType = Eigen::Vector4f;
+using TransformMatrix = Eigen::Matrix4f;
+using TimestampOffset = float;
+using PointContainerCPU = std::vector<PointType, Eigen::aligned_allocator<PointType>>;
+using CovarianceContainerCPU = std::vector<Covariance, Eigen::aligned_allocator<Covariance>>;
+using NormalContainerCPU = std::vector<Normal, Eigen::aligned_allocator<Normal>>;
+using RGBContainerCPU = std::vector<RGBType, Eigen::aligned_allocator<RGBType>>;
+using IntensityContainerCPU = std::vector<float>;
+using TimestampContainerCPU = std::vector<TimestampOffset>;
+using PointContainerShared = shared_vector<PointType>;
+using CovarianceContainerShared = shared_vector<Covariance>;
+using NormalContainerShared = shared_vector<Normal>;
+using RGBContainerShared = shared_vector<RGBType>;
+using IntensityContainerShared = shared_vector<float>;
+using TimestampContainerShared = shared_vector<TimestampOffset>;
+static_assert(sizeof(PointType) == 16 && sizeof(Covariance) == 64, "API layouts: 16-byte points, 64-byte covariances");
+
+// ---------------------------------------------------------------------------------------------- points/point_cloud.hpp
+/// points/point_cloud.hpp:12-70
+struct PointCloudCPU {
+    using Ptr = std::shared_ptr<PointCloudCPU>;
+    std::shared_ptr<PointContainerCPU> points = std::make_shared<PointContainerCPU>();
+    std::shared_ptr<CovarianceContainerCPU> covs = std::make_shared<CovarianceContainerCPU>();
+    std::shared_ptr<NormalContainerCPU> normals = std::make_shared<NormalContainerCPU>();
+    std::shared_ptr<RGBContainerCPU> rgb = std::make_shared<RGBContainerCPU>();
+    std::shared_ptr<IntensityContainerCPU> intensities = std::make_shared<IntensityContainerCPU>();
+    std::shared_ptr<TimestampContainerCPU> timestamp_offsets = std::make_shared<TimestampContainerCPU>();
+    double start_time_ms = 0.0, end_time_ms = 0.0;
+    size_t size() const { return points->size(); }
+    bool has_cov() const { return covs && covs->size() == points->size(); }
+    bool has_normal() const { return normals && normals->size() == points->size(); }
+    bool has_rgb() const { return rgb && rgb->size() == points->size(); }
+    bool has_intensity() const { return intensities && intensities->size() == points->size(); }
+    bool has_timestamps() const { return timestamp_offsets && timestamp_offsets->size() == points->size() && !timestamp_offsets->empty(); }
+};
+
+/// points/point_cloud.hpp:73-476 — six attribute containers + the queue; deep copy constructor, shallow assignment.
+struct PointCloudShared {
+    using Ptr = std::shared_ptr<PointCloudShared>;
+    sycl_utils::DeviceQueue queue;
+    std::shared_ptr<PointContainerShared> points;
+    std::shared_ptr<CovarianceContainerShared> covs;
+    std::shared_ptr<NormalContainerShared> normals;
+    std::shared_ptr<RGBContainerShared> rgb;
+    std::shared_ptr<IntensityContainerShared> intensities;
+    std::shared_ptr<TimestampContainerShared> timestamp_offsets;
+    double start_time_ms = 0.0, end_time_ms = 0.0;
+
+    explicit PointCloudShared(const sycl_utils::DeviceQueue& q) : queue(q) { alloc(); }
+    PointCloudShared(const sycl_utils::DeviceQueue& q, const PointCloudCPU& cpu) : queue(q) {
+        alloc();
+        copy_in(*points, *cpu.points);
+        if (cpu.has_cov()) copy_in(*covs, *cpu.covs);
+        if (cpu.has_normal()) copy_in(*normals, *cpu.normals);
+        if (cpu.has_rgb()) copy_in(*rgb, *cpu.rgb);
+        if (cpu.has_intensity()) copy_in(*intensities, *cpu.intensities);
+        if (cpu.has_timestamps()) copy_in(*timestamp_offsets, *cpu.timestamp_offsets);
+        start_time_ms = cpu.start_time_ms;
+        end_time_ms = cpu.end_time_ms;
+    }
+    PointCloudShared(const PointCloudShared& o) : queue(o.queue), start_time_ms(o.start_time_ms), end_time_ms(o.end_time_ms) {
+        points = std::make_shared<PointContainerShared>(*o.points);  // deep copy (point_cloud.hpp:202-236)
+        covs = std::make_shared<CovarianceContainerShared>(*o.covs);
+        normals = std::make_shared<NormalContainerShared>(*o.normals);
+        rgb = std::make_shared<RGBContainerShared>(*o.rgb);
+        intensities = std::make_shared<IntensityContainerShared>(*o.intensities);
+        timestamp_offsets = std::make_shared<TimestampContainerShared>(*o.timestamp_offsets);
+    }
+    PointCloudShared& operator=(const PointCloudShared&) = default;  // shallow, as the reference's implicit operator=
+
+    size_t size() const { return points->size(); }
+    bool has_cov() const { return covs && covs->size() == points->size() && points->size() > 0; }
+    bool has_normal() const { return normals && normals->size() == points->size() && points->size() > 0; }
+    bool has_rgb() const { return rgb && rgb->size() == points->size() && points->size() > 0; }
+    bool has_intensity() const { return intensities && intensities->size() == points->size() && points->size() > 0; }
+    bool has_timestamps() const { return timestamp_offsets && timestamp_offsets->size() == points->size() && points->size() > 0; }
+    PointType* points_ptr() const { return points->data(); }
+    Covariance* covs_ptr() const { return covs->data(); }
+    Normal* normals_ptr() const { return normals->data(); }
+    void resize_points(size_t n) const { points->resize(n); }
+    void resize_covs(size_t n) const { covs->resize(n); }
+    void resize_normals(size_t n) const { normals->resize(n); }
+    void resize_rgb(size_t n) const { rgb->resize(n); }
+    void resize_intensities(size_t n) const { intensities->resize(n); }
+    void resize_timestamps(size_t n) const { timestamp_offsets->resize(n); }
+    void reserve_points(size_t n) const { points->reserve(n); }
+    void reserve_covs(size_t n) const { covs->reserve(n); }
+    void reserve_normals(size_t n) const { normals->reserve(n); }
+    void reserve_rgb(size_t n) const { rgb->reserve(n); }
+    void reserve_intensities(size_t n) const { intensities->reserve(n); }
+    void reserve_timestamps(size_t n) const { timestamp_offsets->reserve(n); }
+    void clear() const { points->clear(); covs->clear(); normals->clear(); rgb->clear(); intensities->clear(); timestamp_offsets->clear(); }
+
+    // device views for the kernels
+    const float* points_device() const { return reinterpret_cast<const float*>(points->device_data()); }
+    const float* covs_device() const { return has_cov() ? reinterpret_cast<const float*>(covs->device_data()) : nullptr; }
+    const float* normals_device() const { return has_normal() ? reinterpret_cast<const float*>(normals->device_data()) : nullptr; }
+
+private:
+    void alloc() {
+        points = std::make_shared<PointContainerShared>(queue);
+        covs = std::make_shared<CovarianceContainerShared>(queue);
+        normals = std::make_shared<NormalContainerShared>(queue);
+        rgb = std::make_shared<RGBContainerShared>(queue);
+        intensities = std::make_shared<IntensityContainerShared>(queue);
+        timestamp_offsets = std::make_shared<TimestampContainerShared>(queue);
+    }
+    template <class S, class V>
+    static void copy_in(S& dst, const V& src) {
+        dst.resize(src.size());
+        if (!src.empty()) std::memcpy(static_cast<void*>(dst.data()), static_cast<const void*>(src.data()), src.size() * sizeof(src[0]));
+    }
+};
+
+}  // namespace sycl_points

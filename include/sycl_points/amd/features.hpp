@@ -1,0 +1,297 @@
+// sycl_points facade for MI355X — covariance / normals, voxel grid, pre-filters, transform.
+//   algorithms/feature/covariance.hpp            : covariance::estimate_async, estimate_normals_async, extract_normals(_async)
+//   algorithms/filter/voxel_downsampling.hpp     : filter::VoxelGrid
+//   algorithms/filter/preprocess_filter.hpp      : filter::PreprocessFilter (box_filter, random_sampling)
+//   algorithms/common/filter_by_flags.hpp        : filter::FilterByFlags
+//   algorithms/common/transform.hpp              : transform::transform, transform_copy
+#pragma once
+#include <numeric>
+#include <random>
+
+#include "knn.hpp"
+
+namespace sycl_points {
+namespace algorithms {
+
+namespace detail {
+/// Scratch device memory that lives for one call (the reference allocates shared_vectors per call the same way,
+/// e.g. registration.hpp:685-686).
+struct DeviceScratch {
+    void* p = nullptr;
+    explicit DeviceScratch(size_t bytes) { if (bytes) hip_check(hipMalloc(&p, bytes), "hipMalloc"); }
+    ~DeviceScratch() { if (p) (void)hipFree(p); }
+    DeviceScratch(const DeviceScratch&) = delete;
+    DeviceScratch& operator=(const DeviceScratch&) = delete;
+};
+inline uint32_t read_u32(const void* dev, hipStream_t st) {
+    uint32_t v = 0;
+    hip_check(hipMemcpyAsync(&v, dev, 4, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+    return v;
+}
+}  // namespace detail
+
+// ================================================================================================ covariance
+namespace covariance {
+
+/// covariance.hpp:260-295
+inline sycl_utils::events estimate_async(const sycl_utils::DeviceQueue& queue, const knn::KNNResult& neighbors,
+                                         const PointContainerShared& points, CovarianceContainerShared& covs,
+                                         const std::vector<sycl_utils::event>& = {}) {
+    const size_t N = points.size();
+    if (N == 0) { covs.resize(0); return sycl_utils::events(); }
+    throw_on_error(sp_cov_estimate(reinterpret_cast<const float*>(points.device_data()), N, neighbors.indices->device_data(),
+                                   neighbors.k, reinterpret_cast<float*>(covs.device_data_for_write(N)), queue.stream()));
+    return sycl_utils::events(queue.stream());
+}
+/// covariance.hpp:297-303
+inline sycl_utils::events estimate_async(const knn::KNNResult& neighbors, const PointCloudShared& points,
+                                         const std::vector<sycl_utils::event>& depends = {}) {
+    return estimate_async(points.queue, neighbors, *points.points, *points.covs, depends);
+}
+/// covariance.hpp:305-311 — search + estimate. With a GridKNN built on `points` the neighbour lists are never written:
+/// the self-kNN kernel accumulates the covariance directly (sp_grid_self_knn).
+inline sycl_utils::events estimate_async(const knn::KNNBase& knn, const PointCloudShared& points, const size_t k,
+                                         const std::vector<sycl_utils::event>& depends = {}) {
+    if (const auto* grid = dynamic_cast<const knn::GridKNN*>(&knn)) {
+        if (grid->size() == points.size() && k <= 20 && points.size() > 0) {
+            detail::DeviceScratch ws(sp_grid_self_workspace_bytes(grid->handle()));
+            throw_on_error(sp_grid_self_knn(grid->handle(), k, nullptr, nullptr,
+                                            reinterpret_cast<float*>(points.covs->device_data_for_write(points.size())),
+                                            nullptr, ws.p, sp_grid_self_workspace_bytes(grid->handle()), points.queue.stream()));
+            points.queue.wait();  // the scratch dies with this scope
+            return sycl_utils::events(points.queue.stream());
+        }
+    }
+    knn::KNNResult neighbors;
+    auto ev = knn.knn_search_async(points, k, neighbors, depends);
+    return estimate_async(neighbors, points, ev.evs);
+}
+/// covariance.hpp:417-443
+inline sycl_utils::events estimate_normals_async(const knn::KNNResult& neighbors, const PointCloudShared& points,
+                                                 const std::vector<sycl_utils::event>& = {}) {
+    const size_t N = points.size();
+    if (N == 0) { points.normals->resize(0); return sycl_utils::events(); }
+    throw_on_error(sp_normals_from_knn(points.points_device(), N, neighbors.indices->device_data(), neighbors.k,
+                                       reinterpret_cast<float*>(points.normals->device_data_for_write(N)), points.queue.stream()));
+    return sycl_utils::events(points.queue.stream());
+}
+/// covariance.hpp:451-459
+inline sycl_utils::events estimate_normals_async(const knn::KNNBase& knn, const PointCloudShared& points, const size_t k,
+                                                 const std::vector<sycl_utils::event>& depends = {}) {
+    knn::KNNResult neighbors;
+    auto ev = knn.knn_search_async(points, k, neighbors, depends);
+    return estimate_normals_async(neighbors, points, ev.evs);
+}
+/// covariance.hpp:465-495
+inline sycl_utils::events extract_normals_async(const PointCloudShared& points, const std::vector<sycl_utils::event>& = {}) {
+    if (!points.has_cov()) throw std::runtime_error("[covariance::extract_normals_async] covariances not computed");
+    const size_t N = points.size();
+    throw_on_error(sp_normals_from_cov(points.points_device(), points.covs_device(), N,
+                                       reinterpret_cast<float*>(points.normals->device_data_for_write(N)), points.queue.stream()));
+    return sycl_utils::events(points.queue.stream());
+}
+inline void extract_normals(const PointCloudShared& points, const std::vector<sycl_utils::event>& depends = {}) {
+    extract_normals_async(points, depends).wait_and_throw();
+}
+
+}  // namespace covariance
+
+// ================================================================================================ filters
+namespace filter {
+
+/// filter/voxel_downsampling.hpp:14-289. Keys, sort and aggregation all run on the device (sp_voxel_downsample).
+class VoxelGrid {
+public:
+    using Ptr = std::shared_ptr<VoxelGrid>;
+    VoxelGrid(const sycl_utils::DeviceQueue& queue, const float voxel_size) : queue_(queue) { set_voxel_size(voxel_size); }
+    void set_voxel_size(const float voxel_size) {
+        if (voxel_size <= 0.0f) throw std::invalid_argument("voxel_size must be positive");
+        voxel_size_ = voxel_size;
+        voxel_size_inv_ = 1.0f / voxel_size_;
+    }
+    float get_voxel_size() const { return voxel_size_; }
+    void set_min_voxel_count(const size_t n) { min_voxel_count_ = n; }
+
+    void downsampling(const PointContainerShared& points, PointContainerShared& result) {
+        const size_t N = points.size();
+        if (N == 0) { result.resize(0); return; }
+        run(reinterpret_cast<const float*>(points.device_data()), N, nullptr, nullptr, nullptr, result, nullptr, nullptr, nullptr);
+    }
+    void downsampling(const PointCloudShared& cloud, PointCloudShared& result) {
+        const size_t N = cloud.size();
+        if (N == 0) { result.resize_points(0); return; }
+        const bool in_place = (&cloud == &result) || (cloud.points == result.points);
+        PointCloudShared tmp(queue_);
+        PointCloudShared& out = in_place ? tmp : result;
+        run(cloud.points_device(), N, cloud.has_rgb() ? cloud.rgb.get() : nullptr,
+            cloud.has_intensity() ? cloud.intensities.get() : nullptr,
+            cloud.has_timestamps() ? cloud.timestamp_offsets.get() : nullptr, *out.points, out.rgb.get(),
+            out.intensities.get(), out.timestamp_offsets.get());
+        if (!cloud.has_rgb()) out.rgb->clear();
+        if (!cloud.has_intensity()) out.intensities->clear();
+        if (!cloud.has_timestamps()) out.timestamp_offsets->clear();
+        out.covs->clear();
+        out.normals->clear();
+        const double t0 = cloud.start_time_ms, t1 = cloud.end_time_ms;
+        const bool ts = cloud.has_timestamps();
+        if (in_place) {
+            result.points = tmp.points; result.rgb = tmp.rgb; result.intensities = tmp.intensities;
+            result.timestamp_offsets = tmp.timestamp_offsets; result.covs = tmp.covs; result.normals = tmp.normals;
+        }
+        if (ts) { result.start_time_ms = t0; result.end_time_ms = t1; }
+    }
+
+private:
+    void run(const float* pts, size_t N, const RGBContainerShared* rgb, const IntensityContainerShared* inten,
+             const TimestampContainerShared* ts, PointContainerShared& out_pts, RGBContainerShared* out_rgb,
+             IntensityContainerShared* out_inten, TimestampContainerShared* out_ts) {
+        const size_t ws_bytes = sp_voxel_downsample_workspace_bytes(N);
+        detail::DeviceScratch ws(ws_bytes), count(4);
+        hipStream_t st = queue_.stream();
+        throw_on_error(sp_voxel_downsample(
+            pts, N, voxel_size_inv_, min_voxel_count_, rgb ? reinterpret_cast<const float*>(rgb->device_data()) : nullptr,
+            inten ? inten->device_data() : nullptr, ts ? ts->device_data() : nullptr,
+            reinterpret_cast<float*>(out_pts.device_data_for_write(N)),
+            rgb ? reinterpret_cast<float*>(out_rgb->device_data_for_write(N)) : nullptr,
+            inten ? out_inten->device_data_for_write(N) : nullptr, ts ? out_ts->device_data_for_write(N) : nullptr, nullptr,
+            static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
+        const size_t V = detail::read_u32(count.p, st);
+        out_pts.set_device_size(V);
+        if (rgb) out_rgb->set_device_size(V);
+        if (inten) out_inten->set_device_size(V);
+        if (ts) out_ts->set_device_size(V);
+    }
+    sycl_utils::DeviceQueue queue_;
+    float voxel_size_ = 1.0f, voxel_size_inv_ = 1.0f;
+    size_t min_voxel_count_ = 1;
+};
+
+/// common/filter_by_flags.hpp:15-99 — stable compaction on the device (sp_compact_by_flags).
+class FilterByFlags {
+public:
+    using Ptr = std::shared_ptr<FilterByFlags>;
+    explicit FilterByFlags(const sycl_utils::DeviceQueue& queue) : queue_(queue) {}
+
+    template <typename T>
+    void filter_by_flags(const shared_vector<T>& source, shared_vector<T>& output, const shared_vector<uint8_t>& flags) const {
+        const size_t N = source.size();
+        if (N == 0) return;
+        const size_t ws_bytes = sp_compact_workspace_bytes(N);
+        detail::DeviceScratch ws(ws_bytes), count(4), tmp(N * sizeof(T));
+        hipStream_t st = queue_.stream();
+        throw_on_error(sp_compact_by_flags(source.device_data(), N, sizeof(T), flags.device_data(), tmp.p, nullptr,
+                                           static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
+        const size_t M = detail::read_u32(count.p, st);
+        T* dst = output.device_data_for_write(std::max<size_t>(M, 1));
+        if (M) hip_check(hipMemcpyAsync(dst, tmp.p, M * sizeof(T), hipMemcpyDeviceToDevice, st), "D2D");
+        hip_check(hipStreamSynchronize(st), "sync");
+        output.set_device_size(M);
+    }
+    template <typename T>
+    void filter_by_flags(shared_vector<T>& data, const shared_vector<uint8_t>& flags) const { filter_by_flags(data, data, flags); }
+
+    void calculate_indices(const shared_vector<uint8_t>& flags, shared_vector<int32_t>& indices) const {
+        const size_t N = flags.size();
+        if (N == 0) return;
+        const size_t ws_bytes = sp_compact_workspace_bytes(N);
+        detail::DeviceScratch ws(ws_bytes), count(4);
+        throw_on_error(sp_compact_by_flags(flags.device_data(), N, 0 + 4 * 0 + 4, flags.device_data(), nullptr,
+                                           indices.device_data_for_write(N), static_cast<uint32_t*>(count.p), ws.p, ws_bytes,
+                                           queue_.stream()));
+        queue_.wait();
+    }
+
+private:
+    sycl_utils::DeviceQueue queue_;
+};
+
+/// filter/preprocess_filter.hpp — the two operators the hot path's callers use (box filter, random sampling).
+class PreprocessFilter {
+public:
+    using Ptr = std::shared_ptr<PreprocessFilter>;
+    explicit PreprocessFilter(const sycl_utils::DeviceQueue& queue) : queue_(queue), by_flags_(queue), mt_(1234) {
+        flags_ = std::make_shared<shared_vector<uint8_t>>(queue);
+    }
+    void set_random_seed(uint_fast32_t seed) { mt_.seed(seed); }
+
+    /// preprocess_operator/box_filter_operator.hpp:24-54 (K10 on the device, compaction on the device)
+    void box_filter(const PointCloudShared& source, PointCloudShared& output, float min_distance = 1.0f,
+                    float max_distance = std::numeric_limits<float>::max()) {
+        const size_t N = source.size();
+        if (N == 0) return;
+        throw_on_error(sp_box_filter_flags(source.points_device(), N, min_distance, max_distance,
+                                           flags_->device_data_for_write(N), queue_.stream()));
+        apply_flags(source, output);
+    }
+    void box_filter(PointCloudShared& data, float min_distance = 1.0f, float max_distance = std::numeric_limits<float>::max()) {
+        box_filter(data, data, min_distance, max_distance);
+    }
+    /// preprocess_operator/random_sampling_operator.hpp:24-51 — host partial Fisher-Yates with std::mt19937
+    void random_sampling(const PointCloudShared& source, PointCloudShared& output, size_t sampling_num) {
+        const size_t N = source.size();
+        if (N <= sampling_num) {
+            if (&source != &output) output = PointCloudShared(source);
+            return;
+        }
+        flags_->assign(N, REMOVE_FLAG);
+        std::vector<size_t> indices(N);
+        std::iota(indices.begin(), indices.end(), 0);
+        for (size_t i = 0; i < sampling_num; ++i) {
+            std::uniform_int_distribution<size_t> dist(i, N - 1);
+            std::swap(indices[i], indices[dist(mt_)]);
+        }
+        for (size_t i = 0; i < sampling_num; ++i) (*flags_)[indices[i]] = INCLUDE_FLAG;
+        apply_flags(source, output);
+    }
+    void random_sampling(PointCloudShared& data, size_t sampling_num) { random_sampling(data, data, sampling_num); }
+
+private:
+    void apply_flags(const PointCloudShared& source, PointCloudShared& output) {
+        const bool c = source.has_cov(), n = source.has_normal(), r = source.has_rgb(), i = source.has_intensity(),
+                   t = source.has_timestamps();
+        PointCloudShared out(queue_);
+        by_flags_.filter_by_flags(*source.points, *out.points, *flags_);
+        if (c) by_flags_.filter_by_flags(*source.covs, *out.covs, *flags_);
+        if (n) by_flags_.filter_by_flags(*source.normals, *out.normals, *flags_);
+        if (r) by_flags_.filter_by_flags(*source.rgb, *out.rgb, *flags_);
+        if (i) by_flags_.filter_by_flags(*source.intensities, *out.intensities, *flags_);
+        if (t) by_flags_.filter_by_flags(*source.timestamp_offsets, *out.timestamp_offsets, *flags_);
+        const double t0 = source.start_time_ms, t1 = source.end_time_ms;
+        output.points = out.points; output.covs = out.covs; output.normals = out.normals; output.rgb = out.rgb;
+        output.intensities = out.intensities; output.timestamp_offsets = out.timestamp_offsets;
+        output.start_time_ms = t0; output.end_time_ms = t1;
+    }
+    sycl_utils::DeviceQueue queue_;
+    FilterByFlags by_flags_;
+    shared_vector_ptr<uint8_t> flags_;
+    std::mt19937 mt_;
+};
+
+}  // namespace filter
+
+// ================================================================================================ transform
+namespace transform {
+
+/// common/transform.hpp:45-94
+inline sycl_utils::events transform_async(PointCloudShared& cloud, const TransformMatrix& trans) {
+    const size_t N = cloud.size();
+    if (N == 0) return sycl_utils::events();
+    const bool c = cloud.has_cov(), n = cloud.has_normal();
+    float* cv = c ? reinterpret_cast<float*>(cloud.covs->device_data_rw()) : nullptr;
+    float* nr = n ? reinterpret_cast<float*>(cloud.normals->device_data_rw()) : nullptr;
+    float* pt = reinterpret_cast<float*>(cloud.points->device_data_rw());
+    throw_on_error(sp_transform(pt, cv, nr, N, trans.data(), pt, cv, nr, cloud.queue.stream()));
+    return sycl_utils::events(cloud.queue.stream());
+}
+inline void transform(PointCloudShared& cloud, const TransformMatrix& trans) { transform_async(cloud, trans).wait_and_throw(); }
+/// common/transform.hpp:107-147
+inline PointCloudShared transform_copy(const PointCloudShared& cloud, const TransformMatrix& trans) {
+    PointCloudShared ret(cloud);
+    transform(ret, trans);
+    return ret;
+}
+
+}  // namespace transform
+}  // namespace algorithms
+}  // namespace sycl_points

@@ -1,0 +1,195 @@
+// sycl_points facade for MI355X — KNN layer.
+//   algorithms/knn/result.hpp     : KNNResult
+//   algorithms/knn/knn.hpp        : KNNBase (the operator boundary Registration::align sits on)
+//   algorithms/knn/bruteforce.hpp : knn_search_bruteforce
+//   algorithms/knn/kdtree.hpp     : KDTree (host build with the reference's split rule, device search)
+//   + GridKNN: an MI355X-native KNNBase (device-built uniform grid), no counterpart file in the reference.
+#pragma once
+#include "core.hpp"
+
+namespace sycl_points {
+namespace algorithms {
+
+namespace filter {
+constexpr uint8_t REMOVE_FLAG = 0;   // common/filter_by_flags.hpp:11-12
+constexpr uint8_t INCLUDE_FLAG = 1;
+}  // namespace filter
+
+namespace knn {
+
+/// algorithms/knn/result.hpp:12-34
+struct KNNResult {
+    using Ptr = std::shared_ptr<KNNResult>;
+    shared_vector_ptr<int32_t> indices = nullptr;
+    shared_vector_ptr<float> distances = nullptr;
+    size_t query_size = 0;
+    size_t k = 0;
+
+    void allocate(const sycl_utils::DeviceQueue& queue, size_t query_size_ = 0, size_t k_ = 0) {
+        query_size = query_size_;
+        k = k_;
+        indices = std::make_shared<shared_vector<int32_t>>(query_size * k, -1, queue);
+        distances = std::make_shared<shared_vector<float>>(query_size * k, std::numeric_limits<float>::max(), queue);
+    }
+    void resize(size_t query_size_ = 0, size_t k_ = 0) {
+        query_size = query_size_;
+        k = k_;
+        indices->resize(query_size * k);
+        distances->resize(query_size * k);
+    }
+};
+
+/// algorithms/knn/knn.hpp:14-61 — same virtual interface; `depends` is kept for source compatibility (all work is
+/// enqueued in order on the cloud's stream, so dependencies are implicit).
+class KNNBase {
+public:
+    virtual ~KNNBase() = default;
+    virtual sycl_utils::events knn_search_async(const PointCloudShared& queries, const size_t k, KNNResult& result,
+                                                const std::vector<sycl_utils::event>& depends = {},
+                                                const TransformMatrix& transT = TransformMatrix::Identity()) const = 0;
+
+    KNNResult knn_search(const PointCloudShared& queries, const size_t k, const std::vector<sycl_utils::event>& depends = {},
+                         const TransformMatrix& transT = TransformMatrix::Identity()) const {
+        KNNResult result;
+        knn_search_async(queries, k, result, depends, transT).wait_and_throw();
+        return result;
+    }
+    sycl_utils::events nearest_neighbor_search_async(const PointCloudShared& queries, KNNResult& result,
+                                                     const std::vector<sycl_utils::event>& depends = {},
+                                                     const TransformMatrix& transT = TransformMatrix::Identity()) const {
+        return knn_search_async(queries, 1, result, depends, transT);
+    }
+    void nearest_neighbor_search(const PointCloudShared& queries, KNNResult& result,
+                                 const std::vector<sycl_utils::event>& depends = {},
+                                 const TransformMatrix& transT = TransformMatrix::Identity()) const {
+        nearest_neighbor_search_async(queries, result, depends, transT).wait_and_throw();
+    }
+};
+
+namespace detail {
+inline void prepare_result(const sycl_utils::DeviceQueue& q, KNNResult& r, size_t nq, size_t k) {
+    if (r.indices == nullptr || r.distances == nullptr) r.allocate(q, nq, k);  // kdtree.hpp:446-450
+    else r.resize(nq, k);
+}
+}  // namespace detail
+
+/// algorithms/knn/bruteforce.hpp:24-96 (synchronous, like the reference)
+inline KNNResult knn_search_bruteforce(const sycl_utils::DeviceQueue& queue, const PointCloudShared& queries,
+                                       const PointCloudShared& targets, const size_t k) {
+    const size_t nq = queries.size(), nt = targets.size();
+    KNNResult result;
+    result.allocate(queue, nq, k);
+    if (nq == 0) return result;
+    const size_t ws_bytes = sp_knn_bruteforce_workspace_bytes(nq, nt, k);
+    void* ws = nullptr;
+    if (ws_bytes) hip_check(hipMalloc(&ws, ws_bytes), "hipMalloc");
+    const int rc = sp_knn_bruteforce(queries.points_device(), nq, targets.points_device(), nt, k,
+                                     result.indices->device_data_for_write(nq * k),
+                                     result.distances->device_data_for_write(nq * k), ws, ws_bytes, queue.stream());
+    if (rc == SP_OK) queue.wait();
+    if (ws) (void)hipFree(ws);
+    throw_on_error(rc);
+    return result;
+}
+
+/// algorithms/knn/kdtree.hpp:142-766
+class KDTree : public KNNBase {
+public:
+    using Ptr = std::shared_ptr<KDTree>;
+    sycl_utils::DeviceQueue queue;
+
+    explicit KDTree(const sycl_utils::DeviceQueue& q) : queue(q) {}
+    ~KDTree() override { if (tree_) sp_kdtree_destroy(tree_); }
+    KDTree(const KDTree&) = delete;
+    KDTree& operator=(const KDTree&) = delete;
+
+    static Ptr build(const sycl_utils::DeviceQueue& q, const PointContainerShared& points, size_t leaf_threshold = 16) {
+        auto t = std::make_shared<KDTree>(q);
+        throw_on_error(sp_kdtree_create(reinterpret_cast<const float*>(points.data()), points.size(), leaf_threshold,
+                                        q.stream(), &t->tree_));
+        return t;
+    }
+    static Ptr build(const sycl_utils::DeviceQueue& q, const PointCloudShared& cloud, size_t leaf_threshold = 16) {
+        return build(q, *cloud.points, leaf_threshold);
+    }
+
+    sycl_utils::events knn_search_async(const PointCloudShared& queries, const size_t k, KNNResult& result,
+                                        const std::vector<sycl_utils::event>& = {},
+                                        const TransformMatrix& transT = TransformMatrix::Identity()) const override {
+        const size_t nq = queries.size();
+        if (k > 100) throw std::runtime_error("[KDTree::knn_search_async] `k` is too large. not support.");
+        detail::prepare_result(queue, result, nq, nq ? k : 0);
+        if (nq == 0) return sycl_utils::events();
+        throw_on_error(sp_kdtree_search(tree_, queries.points_device(), nq, k, transT.data(), 0,
+                                        result.indices->device_data_for_write(nq * k),
+                                        result.distances->device_data_for_write(nq * k), queue.stream()));
+        return sycl_utils::events(queue.stream());
+    }
+    sycl_utils::events radius_search_async(const PointCloudShared& queries, const size_t max_k, const float radius,
+                                           KNNResult& result, const std::vector<sycl_utils::event>& = {},
+                                           const TransformMatrix& transT = TransformMatrix::Identity()) const {
+        const size_t nq = queries.size();
+        if (max_k > 100) throw std::runtime_error("[KDTree::radius_search_async] `max_k` is too large. not support.");
+        if (nq == 0 || max_k == 0) {
+            detail::prepare_result(queue, result, 0, 0);
+            return sycl_utils::events();
+        }
+        detail::prepare_result(queue, result, nq, max_k);
+        throw_on_error(sp_kdtree_radius_search(tree_, queries.points_device(), nq, max_k, radius, transT.data(), 0,
+                                               result.indices->device_data_for_write(nq * max_k),
+                                               result.distances->device_data_for_write(nq * max_k), queue.stream()));
+        return sycl_utils::events(queue.stream());
+    }
+    void remove_nodes_by_flags(const shared_vector<uint8_t>& flags, const shared_vector<int32_t>& indices) {
+        if (flags.size() != indices.size())
+            throw std::runtime_error("[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.");
+        throw_on_error(sp_kdtree_remove_by_flags(tree_, flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
+        queue.wait();
+    }
+
+private:
+    sp_kdtree* tree_ = nullptr;
+};
+
+/// MI355X-native KNNBase: exact kNN on a device-built uniform grid (sp_grid_*). Bit-identical to
+/// knn_search_bruteforce. Registration::align recognises it and takes the fused NN + linearise path.
+class GridKNN : public KNNBase {
+public:
+    using Ptr = std::shared_ptr<GridKNN>;
+    sycl_utils::DeviceQueue queue;
+
+    explicit GridKNN(const sycl_utils::DeviceQueue& q) : queue(q) {}
+    ~GridKNN() override { if (grid_) sp_grid_destroy(grid_); }
+    GridKNN(const GridKNN&) = delete;
+    GridKNN& operator=(const GridKNN&) = delete;
+
+    static Ptr build(const sycl_utils::DeviceQueue& q, const PointCloudShared& cloud, float points_per_cell = 0.5f,
+                     float cell_size = 0.0f) {
+        auto g = std::make_shared<GridKNN>(q);
+        throw_on_error(sp_grid_create(cloud.points_device(), cloud.size(), cell_size, points_per_cell, q.stream(), &g->grid_));
+        return g;
+    }
+    const sp_grid* handle() const { return grid_; }
+    size_t size() const { return sp_grid_size(grid_); }
+    float cell_size() const { return sp_grid_cell_size(grid_); }
+
+    sycl_utils::events knn_search_async(const PointCloudShared& queries, const size_t k, KNNResult& result,
+                                        const std::vector<sycl_utils::event>& = {},
+                                        const TransformMatrix& transT = TransformMatrix::Identity()) const override {
+        const size_t nq = queries.size();
+        if (k > 20) throw std::runtime_error("[GridKNN::knn_search_async] `k` is too large (max 20).");
+        detail::prepare_result(queue, result, nq, nq ? k : 0);
+        if (nq == 0) return sycl_utils::events();
+        throw_on_error(sp_grid_search(grid_, queries.points_device(), nq, k, transT.data(), 0,
+                                      result.indices->device_data_for_write(nq * k),
+                                      result.distances->device_data_for_write(nq * k), queue.stream()));
+        return sycl_utils::events(queue.stream());
+    }
+
+private:
+    sp_grid* grid_ = nullptr;
+};
+
+}  // namespace knn
+}  // namespace algorithms
+}  // namespace sycl_points

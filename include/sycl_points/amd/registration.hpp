@@ -1,0 +1,483 @@
+// sycl_points facade for MI355X — registration layer.
+//   algorithms/robust/robust.hpp                         : RobustLossType (+ from_string)
+//   algorithms/registration/factor.hpp                   : RegType (+ from_string)
+//   algorithms/registration/registration_params.hpp      : RegistrationParams and friends
+//   algorithms/registration/{linearized_result,result}.hpp
+//   algorithms/registration/registration.hpp             : Registration (align, compute_linearized_result,
+//                                                          compute_error_frozen, compute_icp_robust_weights)
+//   algorithms/registration/pipeline/{aligner,robust}.hpp, registration_pipeline(_params).hpp
+// Host control flow follows the reference; every per-point kernel is a C-ABI call. When the KNNBase handed to align()
+// is a GridKNN and the factor is GICP, the iteration uses the prepared / fused kernel (sp_gicp_iteration_fused).
+#pragma once
+#include <cctype>
+#include <functional>
+#include <iostream>
+#include <tuple>
+
+#include "features.hpp"
+
+namespace sycl_points {
+namespace algorithms {
+
+namespace robust {
+enum class RobustLossType { NONE, HUBER, TUKEY, CAUCHY, GEMAN_MCCLURE };  // robust/robust.hpp:13-19
+inline RobustLossType RobustLossType_from_string(const std::string& str) {
+    std::string u = str;
+    for (auto& c : u) c = (char)std::toupper((unsigned char)c);
+    if (u == "NONE") return RobustLossType::NONE;
+    if (u == "HUBER") return RobustLossType::HUBER;
+    if (u == "TUKEY") return RobustLossType::TUKEY;
+    if (u == "CAUCHY") return RobustLossType::CAUCHY;
+    if (u == "GEMAN_MCCLURE") return RobustLossType::GEMAN_MCCLURE;
+    throw std::runtime_error("[RobustLossType_from_string] Invalid RobustLossType str '" + str + "'");
+}
+}  // namespace robust
+
+namespace registration {
+
+enum class RegType { POINT_TO_POINT = 0, POINT_TO_PLANE, POINT_TO_DISTRIBUTION, GICP, GENZ };  // factor.hpp:18-32
+inline RegType RegType_from_string(const std::string& str) {
+    std::string u = str;
+    for (auto& c : u) c = (char)std::toupper((unsigned char)c);
+    if (u == "POINT_TO_POINT") return RegType::POINT_TO_POINT;
+    if (u == "POINT_TO_PLANE") return RegType::POINT_TO_PLANE;
+    if (u == "GICP") return RegType::GICP;
+    if (u == "GENZ") return RegType::GENZ;
+    if (u == "POINT_TO_DISTRIBUTION" || u == "P2D") return RegType::POINT_TO_DISTRIBUTION;
+    throw std::runtime_error("[RegType_from_string] Invalid RegType str '" + str + "'");
+}
+enum class OptimizationMethod { GAUSS_NEWTON = 0, LEVENBERG_MARQUARDT, POWELL_DOGLEG };
+inline OptimizationMethod OptimizationMethod_from_string(const std::string& str) {
+    std::string u = str;
+    for (auto& c : u) c = (char)std::toupper((unsigned char)c);
+    if (u == "GN" || u == "GAUSS_NEWTON") return OptimizationMethod::GAUSS_NEWTON;
+    if (u == "LM" || u == "LEVENBERG_MARQUARDT") return OptimizationMethod::LEVENBERG_MARQUARDT;
+    if (u == "DOGLEG" || u == "POWELL_DOGLEG") return OptimizationMethod::POWELL_DOGLEG;
+    throw std::runtime_error("[OptimizationMethod_from_string] Invalid OptimizationMethod str [" + str + "]");
+}
+
+/// registration_params.hpp:41-114 (same fields, same defaults)
+struct RegistrationConvergenceCriteria {
+    float translation = 1e-3f;
+    float rotation = 1e-3f;
+};
+struct RegistrationFactorParams {
+    struct Robust { robust::RobustLossType type = robust::RobustLossType::NONE; float default_scale = 10.0f; };
+    struct GenZ { float planarity_threshold = 0.2f; };
+    RegType reg_type = RegType::GICP;
+    float max_correspondence_distance = 2.0f;
+    Robust robust;
+    GenZ genz;
+    bool verbose = false;
+};
+struct RegistrationOptimizationParams {
+    struct GaussNewton { float lambda = 1.0f; };
+    struct LevenbergMarquardt {
+        size_t max_inner_iterations = 10;
+        float lambda_factor = 2.0f, init_lambda = 1.0f, max_lambda = 1e3f, min_lambda = 1e-6f;
+    };
+    GaussNewton gn;
+    LevenbergMarquardt lm;
+    OptimizationMethod optimization_method = OptimizationMethod::GAUSS_NEWTON;
+};
+struct RegistrationParams : public RegistrationFactorParams, public RegistrationOptimizationParams {
+    using Criteria = RegistrationConvergenceCriteria;
+    size_t max_iterations = 20;
+    Criteria criteria;
+};
+
+/// linearized_result.hpp:12-24
+struct LinearizedResult {
+    Eigen::Matrix<float, 6, 6> H = Eigen::Matrix<float, 6, 6>::Zero();
+    Eigen::Matrix<float, 6, 1> b = Eigen::Matrix<float, 6, 1>::Zero();
+    float error = std::numeric_limits<float>::max();
+    uint32_t inlier = 0;
+};
+/// result.hpp:12-28
+struct RegistrationResult {
+    using Ptr = std::shared_ptr<RegistrationResult>;
+    Eigen::Isometry3f T = Eigen::Isometry3f::Identity();
+    bool converged = false;
+    size_t iterations = 0;
+    Eigen::Matrix<float, 6, 6> H = Eigen::Matrix<float, 6, 6>::Zero();
+    Eigen::Matrix<float, 6, 1> b = Eigen::Matrix<float, 6, 1>::Zero();
+    float error = std::numeric_limits<float>::max();
+    Eigen::Matrix<float, 6, 6> H_raw = Eigen::Matrix<float, 6, 6>::Zero();
+    Eigen::Matrix<float, 6, 1> b_raw = Eigen::Matrix<float, 6, 1>::Zero();
+    float error_raw = std::numeric_limits<float>::max();
+    uint32_t inlier = 0;
+};
+
+/// registration.hpp:88-965
+class Registration {
+public:
+    using Ptr = std::shared_ptr<Registration>;
+    struct ExecutionOptions {  // registration.hpp:92-100
+        float robust_scale;
+        float rotation_robust_scale;
+        float dt;
+        TransformMatrix prev_pose;
+        ExecutionOptions() : robust_scale(-1.0f), rotation_robust_scale(-1.0f), dt(0.1f), prev_pose(TransformMatrix::Identity()) {}
+    };
+
+    explicit Registration(const sycl_utils::DeviceQueue& queue, const RegistrationParams& params = RegistrationParams())
+        : params_(params), queue_(queue) {
+        hip_check(hipMalloc(&lin_dev_, sizeof(sp_linearized)), "hipMalloc");
+        ws_bytes_ = sp_gicp_workspace_bytes(0);
+        hip_check(hipMalloc(&ws_, ws_bytes_), "hipMalloc");
+        hip_check(hipMalloc(&T_dev_, 16 * sizeof(float) + 8 * sizeof(float)), "hipMalloc");
+    }
+    ~Registration() {
+        if (psrc_) sp_gicp_source_destroy(psrc_);
+        if (ptgt_) sp_gicp_target_destroy(ptgt_);
+        (void)hipFree(lin_dev_); (void)hipFree(ws_); (void)hipFree(T_dev_);
+    }
+    Registration(const Registration&) = delete;
+    Registration& operator=(const Registration&) = delete;
+
+    /// registration.hpp:129-193
+    void validate_params(const PointCloudShared& source, const PointCloudShared& target, RegistrationParams& params) const {
+        if (params.reg_type == RegType::POINT_TO_PLANE && !target.has_normal()) {
+            if (!target.has_cov())
+                throw std::runtime_error("[Registration::validate_params] Normal vector or covariance matrices of target "
+                                         "must be pre-computed before performing Point-to-Plane ICP matching.");
+            covariance::extract_normals(target);
+        }
+        if (params.reg_type == RegType::GICP && (!source.has_cov() || !target.has_cov()))
+            throw std::runtime_error("[Registration::validate_params] Covariance matrices of source and target must be "
+                                     "pre-computed before performing GICP matching.");
+        if (params.reg_type == RegType::GENZ) {
+            if (!target.has_cov())
+                throw std::runtime_error("[Registration::validate_params] Covariance matrices of target must be "
+                                         "pre-computed before performing GenZ-ICP matching.");
+            if (!target.has_normal()) covariance::extract_normals(target);
+        }
+        if (params.reg_type == RegType::POINT_TO_DISTRIBUTION && !target.has_cov())
+            throw std::runtime_error("[Registration::validate_params] Covariance matrices of target must be pre-computed "
+                                     "before performing Point-to-Distribution ICP matching.");
+        if (params.robust.type != robust::RobustLossType::NONE && params.robust.default_scale <= 0.0f) {
+            std::cout << "[Caution] `robust.default_scale` must be greater than zero. Disable robust loss." << std::endl;
+            params.robust.type = robust::RobustLossType::NONE;
+        }
+    }
+
+    /// registration.hpp:201-276
+    RegistrationResult align(const PointCloudShared& source, const PointCloudShared& target, const knn::KNNBase& target_knn,
+                             const TransformMatrix& initial_guess = TransformMatrix::Identity(),
+                             const ExecutionOptions& options = ExecutionOptions()) {
+        RegistrationResult result;
+        result.T.matrix() = initial_guess;
+        if (source.size() == 0) return result;
+        validate_params(source, target, params_);
+        const float robust_scale = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
+        float lm_lambda = params_.lm.init_lambda;
+        const auto* grid = dynamic_cast<const knn::GridKNN*>(&target_knn);
+        const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size();
+        if (fused) prepare_fused(source, target, *grid, initial_guess);
+
+        for (size_t iter = 0; iter < params_.max_iterations; ++iter) {
+            const LinearizedResult lin = fused ? linearize_fused(source.size(), result.T.matrix(), robust_scale)
+                                               : linearize_generic(source, target, target_knn, result.T.matrix(), robust_scale);
+            result.H_raw = lin.H; result.b_raw = lin.b; result.error_raw = lin.error;
+            switch (params_.optimization_method) {
+                case OptimizationMethod::LEVENBERG_MARQUARDT:
+                    optimize_levenberg_marquardt(source, target, result, lin, lm_lambda, iter, robust_scale);
+                    break;
+                case OptimizationMethod::GAUSS_NEWTON:
+                    optimize_gauss_newton(result, lin, iter);
+                    break;
+                case OptimizationMethod::POWELL_DOGLEG:
+                    throw std::runtime_error("[Registration::align] POWELL_DOGLEG is not implemented in this build");
+            }
+            if (result.converged) break;
+        }
+        return result;
+    }
+
+    /// registration.hpp:312-331 (degenerate regularisation is default-off and not built)
+    LinearizedResult compute_linearized_result(const PointCloudShared& source, const PointCloudShared& target,
+                                               const knn::KNNBase& target_knn, const TransformMatrix& pose,
+                                               const ExecutionOptions& options = ExecutionOptions()) {
+        const float s = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
+        return linearize_generic(source, target, target_knn, pose, s);
+    }
+    /// registration.hpp:350-359
+    std::tuple<float, uint32_t> compute_error_frozen(const PointCloudShared& source, const PointCloudShared& target,
+                                                     const TransformMatrix& pose,
+                                                     const ExecutionOptions& options = ExecutionOptions()) const {
+        const float s = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
+        return compute_error(source, target, pose, s);
+    }
+    /// registration.hpp:279-294
+    void compute_icp_robust_weights(const PointCloudShared& source, const PointCloudShared& target,
+                                    const knn::KNNBase& target_knn, const TransformMatrix& pose, float robust_scale,
+                                    shared_vector<float>& out) const {
+        const size_t N = source.size();
+        out.assign(N, 0.0f);
+        if (N == 0) return;
+        target_knn.nearest_neighbor_search_async(source, neighbors_, {}, pose);
+        const sp_factor_params fp = factor_params(robust_scale);
+        throw_on_error(sp_icp_robust_weights(source.points_device(), source.covs_device(), N, target.points_device(),
+                                             target.covs_device(), target.normals_device(), neighbors_.indices->device_data(),
+                                             neighbors_.distances->device_data(), pose.data(), 0, &fp,
+                                             out.device_data_for_write(N), queue_.stream()));
+        queue_.wait();
+    }
+    const RegistrationParams& params() const { return params_; }
+
+private:
+    sp_factor_params factor_params(float robust_scale) const {
+        return sp_factor_params{int(params_.reg_type), int(params_.robust.type), params_.max_correspondence_distance,
+                                robust_scale, genz_alpha_, params_.genz.planarity_threshold};
+    }
+    static LinearizedResult to_result(const sp_linearized& h) {
+        LinearizedResult r;
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) r.H(i, j) = h.H[i * 6 + j];
+            r.b(i) = h.b[i];
+        }
+        r.error = h.error;
+        r.inlier = h.inlier;
+        return r;
+    }
+    sp_linearized read_lin() const {  // the reference's wait_and_throw + toCPU(0) (registration.hpp:674-675)
+        sp_linearized h;
+        hip_check(hipMemcpyAsync(&h, lin_dev_, sizeof h, hipMemcpyDeviceToHost, queue_.stream()), "D2H");
+        hip_check(hipStreamSynchronize(queue_.stream()), "sync");
+        return h;
+    }
+    float compute_genz_alpha(const PointCloudShared& target, size_t N) const {  // registration.hpp:464-511
+        detail::DeviceScratch cnt(8);
+        throw_on_error(sp_genz_counts(target.covs_device(), neighbors_.indices->device_data(),
+                                      neighbors_.distances->device_data(), N, params_.max_correspondence_distance,
+                                      params_.genz.planarity_threshold, static_cast<uint32_t*>(cnt.p), queue_.stream()));
+        uint32_t h[2];
+        hip_check(hipMemcpyAsync(h, cnt.p, 8, hipMemcpyDeviceToHost, queue_.stream()), "D2H");
+        queue_.wait();
+        return h[0] == 0 ? 1.0f : static_cast<float>(h[1]) / static_cast<float>(h[0]);
+    }
+    LinearizedResult linearize_generic(const PointCloudShared& source, const PointCloudShared& target,
+                                       const knn::KNNBase& target_knn, const TransformMatrix& T, float robust_scale) {
+        target_knn.nearest_neighbor_search_async(source, neighbors_, {}, T);
+        if (params_.reg_type == RegType::GENZ) genz_alpha_ = compute_genz_alpha(target, source.size());
+        const sp_factor_params fp = factor_params(robust_scale);
+        throw_on_error(sp_gicp_linearize(source.points_device(), source.covs_device(), source.size(), target.points_device(),
+                                         target.covs_device(), target.normals_device(), neighbors_.indices->device_data(),
+                                         neighbors_.distances->device_data(), T.data(), 0, &fp, lin_dev_, ws_, ws_bytes_,
+                                         queue_.stream()));
+        return to_result(read_lin());
+    }
+    void prepare_fused(const PointCloudShared& source, const PointCloudShared& target, const knn::GridKNN& grid,
+                       const TransformMatrix& T0) {
+        if (ptgt_ == nullptr || ptgt_grid_ != grid.handle()) {
+            if (ptgt_) sp_gicp_target_destroy(ptgt_);
+            ptgt_ = nullptr;
+            throw_on_error(sp_gicp_target_create(grid.handle(), target.covs_device(), target.size(), queue_.stream(), &ptgt_));
+            ptgt_grid_ = grid.handle();
+        } else {
+            throw_on_error(sp_gicp_target_update(ptgt_, target.covs_device(), queue_.stream()));
+        }
+        if (psrc_ == nullptr || psrc_cap_ < source.size()) {
+            if (psrc_) sp_gicp_source_destroy(psrc_);
+            psrc_ = nullptr;
+            throw_on_error(sp_gicp_source_create(source.size(), &psrc_));
+            psrc_cap_ = source.size();
+        }
+        throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, source.points_device(), source.covs_device(), source.size(),
+                                              T0.data(), 0, /*sort_by_cell=*/1, queue_.stream()));
+        neighbors_.indices == nullptr ? neighbors_.allocate(queue_, source.size(), 1) : neighbors_.resize(source.size(), 1);
+    }
+    LinearizedResult linearize_fused(size_t N, const TransformMatrix& T, float robust_scale) {
+        const sp_factor_params fp = factor_params(robust_scale);
+        TransformMatrix Tc = T;
+        throw_on_error(sp_gicp_iteration_fused(ptgt_, psrc_, Tc.data(), 0, &fp, nullptr,
+                                               neighbors_.indices->device_data_for_write(N),
+                                               neighbors_.distances->device_data_for_write(N), lin_dev_, nullptr, ws_,
+                                               ws_bytes_, queue_.stream()));
+        return to_result(read_lin());
+    }
+    std::tuple<float, uint32_t> compute_error(const PointCloudShared& source, const PointCloudShared& target,
+                                              const TransformMatrix& T, float robust_scale) const {
+        const sp_factor_params fp = factor_params(robust_scale);
+        throw_on_error(sp_gicp_error(source.points_device(), source.covs_device(), source.size(), target.points_device(),
+                                     target.covs_device(), target.normals_device(), neighbors_.indices->device_data(),
+                                     neighbors_.distances->device_data(), T.data(), 0, &fp, lin_dev_, ws_, ws_bytes_,
+                                     queue_.stream()));
+        const sp_linearized h = read_lin();
+        return {h.error, h.inlier};
+    }
+    /// solve_linear_system + is_converged + pose update (registration.hpp:791-801, 407-410, 814): the host twin of the
+    /// device solver; returns {delta, converged}.
+    std::pair<Eigen::Matrix<float, 6, 1>, bool> gn_step(const LinearizedResult& lin, float lambda, TransformMatrix& T) const {
+        sp_linearized h{};
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) h.H[i * 6 + j] = lin.H(i, j);
+            h.b[i] = lin.b(i);
+        }
+        float d8[8];
+        sp_gn_update_host(&h, T.data(), lambda, params_.criteria.rotation, params_.criteria.translation, d8);
+        Eigen::Matrix<float, 6, 1> delta;
+        for (int i = 0; i < 6; ++i) delta(i) = d8[i];
+        return {delta, d8[6] > 0.5f};
+    }
+    void optimize_gauss_newton(RegistrationResult& result, const LinearizedResult& lin, size_t iter) const {  // :803-828
+        TransformMatrix T = result.T.matrix();
+        const auto [delta, conv] = gn_step(lin, params_.gn.lambda, T);
+        result.converged = conv;
+        result.T.matrix() = T;
+        result.iterations = iter;
+        result.H = lin.H; result.b = lin.b; result.error = lin.error; result.inlier = lin.inlier;
+        if (params_.verbose)
+            std::cout << "iter [" << iter << "] error: " << result.error << ", inlier: " << result.inlier << std::endl;
+        (void)delta;
+    }
+    bool optimize_levenberg_marquardt(const PointCloudShared& source, const PointCloudShared& target,
+                                      RegistrationResult& result, const LinearizedResult& lin, float& lambda, size_t iter,
+                                      float robust_scale) const {  // registration.hpp:830-895
+        const float current_error = lin.error;
+        bool updated = false;
+        float last_error = std::numeric_limits<float>::max();
+        for (size_t i = 0; i < params_.lm.max_inner_iterations; ++i) {
+            TransformMatrix new_T = result.T.matrix();
+            const auto [delta, conv] = gn_step(lin, lambda, new_T);
+            (void)delta;
+            result.converged = conv;
+            const auto [new_error, inlier] = compute_error(source, target, new_T, robust_scale);
+            if (new_error <= current_error) {
+                result.T.matrix() = new_T; result.error = new_error; result.inlier = inlier; updated = true;
+                lambda = std::clamp(lambda / params_.lm.lambda_factor, params_.lm.min_lambda, params_.lm.max_lambda);
+                break;
+            } else if (std::fabs(new_error - last_error) <= 1e-6f) {
+                result.T.matrix() = new_T; result.error = new_error; result.inlier = inlier;
+                break;
+            } else {
+                lambda = std::clamp(lambda * params_.lm.lambda_factor, params_.lm.min_lambda, params_.lm.max_lambda);
+            }
+            last_error = new_error;
+        }
+        result.iterations = iter;
+        result.H = lin.H; result.b = lin.b;
+        return updated;
+    }
+
+    RegistrationParams params_;
+    sycl_utils::DeviceQueue queue_;
+    mutable knn::KNNResult neighbors_;
+    sp_linearized* lin_dev_ = nullptr;
+    void* ws_ = nullptr;
+    size_t ws_bytes_ = 0;
+    float* T_dev_ = nullptr;
+    float genz_alpha_ = 1.0f;
+    sp_gicp_source* psrc_ = nullptr;
+    size_t psrc_cap_ = 0;
+    sp_gicp_target* ptgt_ = nullptr;
+    const sp_grid* ptgt_grid_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------ pipeline wrappers
+namespace pipeline {
+/// pipeline/aligner.hpp:13-15
+using RegistrationAligner = std::function<RegistrationResult(const PointCloudShared&, const PointCloudShared&,
+                                                             const knn::KNNBase&, const TransformMatrix&,
+                                                             const Registration::ExecutionOptions&)>;
+inline RegistrationAligner make_registration_aligner(const Registration::Ptr& registration) {
+    return [registration](const PointCloudShared& s, const PointCloudShared& t, const knn::KNNBase& k,
+                          const TransformMatrix& T, const Registration::ExecutionOptions& o) {
+        return registration->align(s, t, k, T, o);
+    };
+}
+}  // namespace pipeline
+
+/// registration_pipeline_params.hpp:11-43
+struct RegistrationRandomSamplingParams { bool enable = true; size_t num = 1000; };
+struct RegistrationRobustScheduleParams {
+    bool auto_scale = false;
+    float init_scale = 10.0f, min_scale = 0.5f, rotation_init_scale = 10.0f, rotation_min_scale = 0.5f;
+    size_t auto_scaling_iter = 4;
+};
+struct RegistrationPipelineParams {
+    using RandomSampling = RegistrationRandomSamplingParams;
+    using Robust = RegistrationRobustScheduleParams;
+    RegistrationParams registration;
+    RandomSampling random_sampling;
+    Robust robust;
+};
+
+namespace pipeline {
+/// pipeline/robust.hpp:17-128 — geometric annealing of the robust scale around the wrapped aligner.
+class RobustAligner {
+public:
+    using Ptr = std::shared_ptr<RobustAligner>;
+    RobustAligner(RegistrationAligner aligner, const RegistrationPipelineParams& p)
+        : aligner_(std::move(aligner)), params_(p.registration), sched_(p.robust) {}
+    RegistrationResult align(const PointCloudShared& source, const PointCloudShared& target, const knn::KNNBase& knn,
+                             const TransformMatrix& initial_guess = TransformMatrix::Identity(),
+                             const Registration::ExecutionOptions& options = Registration::ExecutionOptions()) const {
+        RegistrationResult result;
+        result.T.matrix() = initial_guess;
+        if (source.size() == 0) return result;
+        const bool fixed = options.robust_scale > 0.0f || options.rotation_robust_scale > 0.0f;
+        bool autos = !fixed && params_.robust.type != robust::RobustLossType::NONE && sched_.auto_scale;
+        if (autos && (sched_.min_scale <= 0.0f || sched_.min_scale >= sched_.init_scale)) autos = false;
+        if (autos && sched_.auto_scaling_iter == 0) autos = false;
+        const size_t levels = autos ? std::max<size_t>(1, sched_.auto_scaling_iter) : 1;
+        float scale = options.robust_scale > 0.0f ? options.robust_scale
+                                                  : (autos ? sched_.init_scale : params_.robust.default_scale);
+        const float factor = levels > 1 ? std::pow(sched_.min_scale / sched_.init_scale, 1.0f / static_cast<float>(levels - 1)) : 1.0f;
+        for (size_t level = 0; level < levels; ++level) {
+            auto o = options;
+            o.robust_scale = scale;
+            result = aligner_(source, target, knn, result.T.matrix(), o);
+            scale *= factor;
+        }
+        return result;
+    }
+    RegistrationAligner make_aligner() const {
+        return [this](const PointCloudShared& s, const PointCloudShared& t, const knn::KNNBase& k, const TransformMatrix& T,
+                      const Registration::ExecutionOptions& o) { return this->align(s, t, k, T, o); };
+    }
+
+private:
+    RegistrationAligner aligner_;
+    RegistrationParams params_;
+    RegistrationRobustScheduleParams sched_;
+};
+}  // namespace pipeline
+
+/// registration_pipeline.hpp:16-149 — optional random sampling of the source, then (annealed) alignment.
+class RegistrationPipeline {
+public:
+    using Ptr = std::shared_ptr<RegistrationPipeline>;
+    RegistrationPipeline(const sycl_utils::DeviceQueue& queue, const RegistrationPipelineParams& p = RegistrationPipelineParams())
+        : params_(p), registration_(std::make_shared<Registration>(queue, p.registration)) {
+        aligner_ = pipeline::make_registration_aligner(registration_);
+        if (params_.robust.auto_scale) {
+            robust_ = std::make_shared<pipeline::RobustAligner>(aligner_, params_);
+            aligner_ = robust_->make_aligner();
+        }
+        filter_ = std::make_shared<filter::PreprocessFilter>(queue);
+        input_ = std::make_shared<PointCloudShared>(queue);
+    }
+    RegistrationResult align(const PointCloudShared& source, const PointCloudShared& target, const knn::KNNBase& target_knn,
+                             const TransformMatrix& initial_guess = TransformMatrix::Identity(),
+                             const Registration::ExecutionOptions& options = Registration::ExecutionOptions()) const {
+        const auto& rs = params_.random_sampling;
+        if (rs.enable && source.size() > rs.num) filter_->random_sampling(source, *input_, rs.num);
+        else *input_ = source;  // shallow (registration_pipeline.hpp:138)
+        return aligner_(*input_, target, target_knn, initial_guess, options);
+    }
+    const Registration::Ptr& registration() const { return registration_; }
+    const PointCloudShared* get_registration_input_point_cloud() const { return input_.get(); }
+
+private:
+    RegistrationPipelineParams params_;
+    Registration::Ptr registration_;
+    pipeline::RobustAligner::Ptr robust_;
+    pipeline::RegistrationAligner aligner_;
+    mutable filter::PreprocessFilter::Ptr filter_;
+    mutable PointCloudShared::Ptr input_;
+};
+
+}  // namespace registration
+}  // namespace algorithms
+}  // namespace sycl_points

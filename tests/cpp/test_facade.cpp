@@ -1,0 +1,258 @@
+// C++ tests of the header facade (include/sycl_points/...), written against the reference's API and modelled on its
+// own gtest files: cpp/tests/test_kdtree.cpp, test_downsampling_filters.cpp, test_preprocess_filter.cpp and the
+// KNNBase-injection idiom of test_registration_pipeline.cpp:16-61. The CPU oracle (oracle/, test infrastructure) is the
+// checker for registration. Runs on a GPU box; exit code 0 = all checks passed.
+#include <cstdio>
+#include <random>
+
+#include "sycl_points/algorithms/common/transform.hpp"
+#include "sycl_points/algorithms/feature/covariance.hpp"
+#include "sycl_points/algorithms/filter/preprocess_filter.hpp"
+#include "sycl_points/algorithms/filter/voxel_downsampling.hpp"
+#include "sycl_points/algorithms/knn/bruteforce.hpp"
+#include "sycl_points/algorithms/knn/grid.hpp"
+#include "sycl_points/algorithms/knn/kdtree.hpp"
+#include "sycl_points/algorithms/registration/registration_pipeline.hpp"
+
+// ---- oracle (liboracle.so) entry points used as the checker
+struct orc_reg_params {
+    int reg_type, robust_type, optimization_method, max_iterations;
+    float max_correspondence_distance, robust_default_scale, gn_lambda;
+    float lm_init_lambda, lm_lambda_factor, lm_min_lambda, lm_max_lambda;
+    int lm_max_inner_iterations;
+    float crit_translation, crit_rotation;
+    int auto_scale, auto_scaling_iter;
+    float init_scale, min_scale;
+};
+struct orc_reg_result { float T[16]; float H[36]; float b[6]; float error; uint32_t inlier; int iterations; int converged; };
+extern "C" {
+void orc_knn_bruteforce(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t* idx, float* d2);
+void orc_cov_estimate(const float* pts, size_t n, const int32_t* idx, size_t k, float* covs);
+void orc_registration_align(const orc_reg_params* P, const float* src, const float* src_cov, size_t ns, const float* tgt,
+                            const float* tgt_cov, const float* tgt_nrm, size_t nt, const float* init_T16, int nn_mode,
+                            orc_reg_result* out, float* trace_T, int* trace_n);
+void orc_se3_exp(const float* twist6, float* T16);
+}
+
+using namespace sycl_points;
+namespace alg = sycl_points::algorithms;
+
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond)                                                                      \
+    do {                                                                                 \
+        ++g_checks;                                                                      \
+        if (!(cond)) { ++g_failed; std::printf("  CHECK FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+#define RUN(fn) do { std::printf("[ RUN  ] %s\n", #fn); const int before = g_failed; fn(); std::printf("[ %s ] %s\n", g_failed == before ? " OK " : "FAIL", #fn); } while (0)
+
+static sycl_utils::DeviceQueue* Q = nullptr;
+
+static void random_points(std::mt19937& gen, PointCloudCPU& c, size_t n, float range) {  // test_kdtree.cpp:69-75
+    std::uniform_real_distribution<float> dist(-range, range);
+    c.points->resize(n);
+    for (size_t i = 0; i < n; ++i) { const float x = dist(gen), y = dist(gen), z = dist(gen); (*c.points)[i] = PointType(x, y, z, 1.0f); }
+}
+
+static void kdtree_grid_vs_bruteforce() {  // test_kdtree.cpp:301-317, 392-408
+    std::mt19937 gen(1234);
+    PointCloudCPU tc, qc;
+    random_points(gen, tc, 1000, 10.0f);
+    random_points(gen, qc, 100, 10.0f);
+    PointCloudShared target(*Q, tc), query(*Q, qc);
+    auto tree = alg::knn::KDTree::build(*Q, target);
+    auto grid = alg::knn::GridKNN::build(*Q, target, 2.0f);
+    for (size_t k : {1, 3, 5, 10, 20}) {
+        auto kd = tree->knn_search(query, k);
+        auto gr = grid->knn_search(query, k);
+        auto bf = alg::knn::knn_search_bruteforce(*Q, query, target, k);
+        CHECK(kd.query_size == 100 && kd.k == k);
+        bool same = true;
+        for (size_t i = 0; i < 100 * k; ++i)
+            same = same && (*kd.indices)[i] == (*bf.indices)[i] && (*kd.distances)[i] == (*bf.distances)[i] &&
+                   (*gr.indices)[i] == (*bf.indices)[i] && (*gr.distances)[i] == (*bf.distances)[i];
+        CHECK(same);
+    }
+    // SinglePoint (test_kdtree.cpp:358-389)
+    PointCloudCPU one, q1;
+    one.points->push_back(PointType(0, 0, 0, 1));
+    q1.points->push_back(PointType(1, 1, 1, 1));
+    PointCloudShared t1(*Q, one), qq(*Q, q1);
+    auto r = alg::knn::KDTree::build(*Q, t1)->knn_search(qq, 1);
+    CHECK((*r.indices)[0] == 0 && std::fabs((*r.distances)[0] - 3.0f) < 1e-6f);
+    bool thrown = false;
+    try { tree->knn_search(query, 101); } catch (const std::runtime_error&) { thrown = true; }  // kdtree.hpp:221-223
+    CHECK(thrown);
+}
+
+static void voxelgrid_known_answer() {  // test_downsampling_filters.cpp:27-88
+    PointCloudCPU c;
+    const float xs[5] = {0.10f, 0.40f, 1.10f, 1.40f, 0.20f};
+    const float rgb[5][3] = {{10, 20, 30}, {20, 40, 60}, {30, 60, 90}, {50, 70, 90}, {70, 80, 90}};
+    const float inten[5] = {1, 3, 5, 7, 100}, ts[5] = {0, 2, 4, 6, 8};
+    for (int i = 0; i < 5; ++i) {
+        c.points->push_back(PointType(xs[i], 0, 0, 1));
+        c.rgb->push_back(RGBType(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f));
+        c.intensities->push_back(inten[i]);
+        c.timestamp_offsets->push_back(ts[i]);
+    }
+    PointCloudShared cloud(*Q, c), result(*Q);
+    alg::filter::VoxelGrid vg(*Q, 1.0f);
+    vg.set_min_voxel_count(2);
+    vg.downsampling(cloud, result);
+    CHECK(result.size() == 2);
+    CHECK(result.has_rgb() && result.has_intensity() && result.has_timestamps());
+    CHECK(std::fabs((*result.points)[0].x() - 0.233333f) < 1e-5f);
+    CHECK(std::fabs((*result.points)[1].x() - 1.25f) < 1e-5f);
+    CHECK(std::fabs((*result.intensities)[0] - 3.0f) < 1e-5f);
+    CHECK(std::fabs((*result.timestamp_offsets)[0] - 3.333333f) < 1e-5f);
+    CHECK(std::fabs((*result.rgb)[0].x() - 33.333333f) < 1e-4f && std::fabs((*result.rgb)[0].y() - 46.666667f) < 1e-4f);
+    vg.downsampling(cloud, cloud);  // in place (voxel_downsampling.hpp:189-190)
+    CHECK(cloud.size() == 2);
+    bool thrown = false;
+    try { alg::filter::VoxelGrid bad(*Q, 0.0f); } catch (const std::invalid_argument&) { thrown = true; }
+    CHECK(thrown);
+}
+
+static void preprocess_filter() {  // test_preprocess_filter.cpp:29-99
+    PointCloudCPU c;
+    c.points->push_back(PointType(0.5f, 0, 0, 1));
+    c.points->push_back(PointType(2.0f, 0, 0, 1));
+    c.points->push_back(PointType(0, 0, 4.0f, 1));
+    c.points->push_back(PointType(std::numeric_limits<float>::quiet_NaN(), 1.0f, 0, 1));
+    for (int i = 0; i < 4; ++i) c.intensities->push_back(float(i + 1));
+    PointCloudShared cloud(*Q, c);
+    alg::filter::PreprocessFilter f(*Q);
+    f.box_filter(cloud, 1.0f, 3.0f);
+    CHECK(cloud.size() == 1 && cloud.has_intensity());
+    CHECK((*cloud.points)[0].x() == 2.0f && (*cloud.intensities)[0] == 2.0f);
+    PointCloudCPU d;
+    for (int i = 0; i < 5; ++i) { d.points->push_back(PointType(float(i), 0, 0, 1)); d.intensities->push_back(float(i)); }
+    PointCloudShared a(*Q, d), b(*Q, d);
+    alg::filter::PreprocessFilter fa(*Q), fb(*Q);
+    fa.set_random_seed(42);
+    fb.set_random_seed(42);
+    fa.random_sampling(a, 2);
+    fb.random_sampling(b, 2);
+    CHECK(a.size() == 2 && b.size() == 2);
+    CHECK((*a.points)[0].x() == (*b.points)[0].x() && (*a.points)[1].x() == (*b.points)[1].x());
+    PointCloudShared e(*Q, d);
+    fa.random_sampling(e, 10);  // no-op when the request covers the input
+    CHECK(e.size() == 5);
+}
+
+// A host KNNBase injected through the operator boundary, as the reference's DummyKNN (test_registration_pipeline.cpp:16-61).
+class HostBruteForceKNN : public alg::knn::KNNBase {
+public:
+    HostBruteForceKNN(const sycl_utils::DeviceQueue& q, const PointCloudShared& t) : queue(q), target(t) {}
+    sycl_utils::events knn_search_async(const PointCloudShared& queries, const size_t k, alg::knn::KNNResult& result,
+                                        const std::vector<sycl_utils::event>& = {},
+                                        const TransformMatrix& T = TransformMatrix::Identity()) const override {
+        PointCloudShared moved = alg::transform::transform_copy(queries, T);
+        if (result.indices == nullptr) result.allocate(queue, queries.size(), k); else result.resize(queries.size(), k);
+        orc_knn_bruteforce(reinterpret_cast<const float*>(moved.points->data()), moved.size(),
+                           reinterpret_cast<const float*>(target.points->data()), target.size(), k, result.indices->data(),
+                           result.distances->data());
+        ++calls;
+        return sycl_utils::events();
+    }
+    sycl_utils::DeviceQueue queue;
+    const PointCloudShared& target;
+    mutable int calls = 0;
+};
+
+static float max_abs_diff(const TransformMatrix& A, const float* colmajor16) {
+    float m = 0;
+    for (int i = 0; i < 16; ++i) m = std::max(m, std::fabs(A.data()[i] - colmajor16[i]));
+    return m;
+}
+
+static void registration_matches_oracle() {
+    const size_t n = 20000;
+    std::mt19937 gen(1234);
+    PointCloudCPU tc;
+    random_points(gen, tc, n, 10.0f * std::cbrt(float(n) / 1e6f));
+    const float twist[6] = {0.01f, -0.02f, 0.015f, 0.03f, -0.02f, 0.01f};
+    TransformMatrix T_gt;
+    orc_se3_exp(twist, T_gt.data());
+    PointCloudShared target(*Q, tc);
+    Eigen::Isometry3f iso(T_gt);
+    PointCloudShared source = alg::transform::transform_copy(target, iso.inverse().matrix());
+    std::mt19937 ngen(4321);
+    std::normal_distribution<float> noise(0.0f, 0.005f);
+    for (size_t i = 0; i < n; ++i) { auto& p = (*source.points)[i]; p.x() += noise(ngen); p.y() += noise(ngen); p.z() += noise(ngen); }
+
+    auto tgrid20 = alg::knn::GridKNN::build(*Q, target, 8.0f);
+    auto sgrid20 = alg::knn::GridKNN::build(*Q, source, 8.0f);
+    alg::covariance::estimate_async(*tgrid20, target, 20).wait_and_throw();   // fused self-kNN + covariance
+    alg::covariance::estimate_async(*sgrid20, source, 20).wait_and_throw();
+    CHECK(target.has_cov() && source.has_cov());
+    {   // the fused covariances equal the two-step path (KD-tree search, then estimate) bit for bit
+        auto tree = alg::knn::KDTree::build(*Q, target);
+        PointCloudShared t2(target);
+        alg::covariance::estimate_async(tree->knn_search(t2, 20), t2).wait_and_throw();
+        size_t diff = 0;
+        for (size_t i = 0; i < n; ++i) diff += !((*t2.covs)[i] == (*target.covs)[i]);
+        CHECK(diff <= n / 1000);  // only exact-distance ties may order differently
+    }
+    alg::registration::RegistrationParams p;
+    p.max_iterations = 12;
+    p.criteria.translation = 0.0f;
+    p.criteria.rotation = 0.0f;
+    orc_reg_params op{3, 0, 0, 12, 2.0f, 10.0f, 1.0f, 1.0f, 2.0f, 1e-6f, 1e3f, 10, 0.0f, 0.0f, 0, 4, 10.0f, 0.5f};
+    orc_reg_result ref;
+    const TransformMatrix I = TransformMatrix::Identity();
+    orc_registration_align(&op, reinterpret_cast<const float*>(source.points->data()),
+                           reinterpret_cast<const float*>(source.covs->data()), n,
+                           reinterpret_cast<const float*>(target.points->data()),
+                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr);
+    auto tree = alg::knn::KDTree::build(*Q, target);
+    auto grid = alg::knn::GridKNN::build(*Q, target);
+    HostBruteForceKNN host_knn(*Q, target);
+    alg::registration::Registration reg(*Q, p);
+    const auto r_tree = reg.align(source, target, *tree);          // generic path: KNNBase search + K11
+    const auto r_grid = reg.align(source, target, *grid);          // fused path (GridKNN recognised)
+    const auto r_host = reg.align(source, target, host_knn);       // injected host KNN through the same seam
+    CHECK(max_abs_diff(r_tree.T.matrix(), ref.T) < 1e-5f);
+    CHECK(max_abs_diff(r_grid.T.matrix(), ref.T) < 1e-5f);
+    CHECK(max_abs_diff(r_host.T.matrix(), ref.T) < 1e-5f);
+    CHECK(max_abs_diff(r_grid.T.matrix(), T_gt.data()) < 5e-4f);
+    CHECK(r_tree.inlier == ref.inlier && r_grid.inlier == ref.inlier && host_knn.calls == 12);
+    // LM + Geman-McClure through the annealing pipeline (example_registration.cpp:31-45), against the oracle's restatement
+    alg::registration::RegistrationPipelineParams pp;
+    pp.registration.max_iterations = 10;
+    pp.registration.optimization_method = alg::registration::OptimizationMethod::LEVENBERG_MARQUARDT;
+    pp.registration.robust.type = alg::robust::RobustLossType::GEMAN_MCCLURE;
+    pp.registration.criteria.translation = 0.0f;
+    pp.registration.criteria.rotation = 0.0f;
+    pp.robust.auto_scale = true; pp.robust.init_scale = 10.0f; pp.robust.min_scale = 2.5f; pp.robust.auto_scaling_iter = 3;
+    pp.random_sampling.enable = false;
+    alg::registration::RegistrationPipeline pipe(*Q, pp);
+    const auto r_pipe = pipe.align(source, target, *grid);
+    orc_reg_params op2{3, 4, 1, 10, 2.0f, 10.0f, 1.0f, 1.0f, 2.0f, 1e-6f, 1e3f, 10, 0.0f, 0.0f, 1, 3, 10.0f, 2.5f};
+    orc_registration_align(&op2, reinterpret_cast<const float*>(source.points->data()),
+                           reinterpret_cast<const float*>(source.covs->data()), n,
+                           reinterpret_cast<const float*>(target.points->data()),
+                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr);
+    CHECK(max_abs_diff(r_pipe.T.matrix(), ref.T) < 1e-5f);
+    // validate_params (registration.hpp:144-150)
+    PointCloudShared nocov(*Q, tc);
+    bool thrown = false;
+    try { reg.align(nocov, target, *tree); } catch (const std::runtime_error&) { thrown = true; }
+    CHECK(thrown);
+    // random sampling default (num = 1000, mt19937(1234)) wires through
+    alg::registration::RegistrationPipeline sampled(*Q);
+    sampled.align(source, target, *tree);
+    CHECK(sampled.get_registration_input_point_cloud()->size() == 1000);
+}
+
+int main() {
+    sycl_utils::DeviceQueue queue(0);
+    Q = &queue;
+    queue.print_device_info();
+    RUN(kdtree_grid_vs_bruteforce);
+    RUN(voxelgrid_known_answer);
+    RUN(preprocess_filter);
+    RUN(registration_matches_oracle);
+    std::printf("%d checks, %d failed\n", g_checks, g_failed);
+    return g_failed == 0 ? 0 : 1;
+}
