@@ -238,6 +238,8 @@ int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* 
 /* Tuning hook, not part of the stable surface: NN walk used inside the fused kernel
  * (-1 automatic: 2x2x2 fast path iff the source is cell-sorted; 0 ring walk; 1 fast path). */
 void sp_debug_set_fused_fast_nn(int mode);
+/* Tuning hook: self-kNN kernel (0 wave-cooperative, default; 1 lane-per-query tile kernel for k <= 10). */
+void sp_debug_set_self_knn_mode(int mode);
 
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
  * iteration loop can stay on the stream with no host round trip:

@@ -11,7 +11,7 @@ def timed(fn,reps=5):
 pts=Mt19937Cloud(1234).uniform_points(1000000,10.0); P=torch.from_numpy(pts).cuda()
 tree=sp.KDTree.build(pts); r=sp.KNNResult()
 print("kdtree k=20 self: %.0f us ; K5 cov: %.0f us"%(timed(lambda: tree.knn_search_async(P,20,r)), timed(lambda: sp.covariance.estimate(r,P))))
-for ppc in (2.0,4.0,6.0,8.0,12.0,16.0):
+for ppc in (3.0,4.0,5.0,6.0,8.0,12.0):
     g=sp.GridKNN.build(P,points_per_cell=ppc)
     a=timed(lambda: g.self_knn(20,True,False,False)); b=timed(lambda: g.self_knn(20,False,True,False)); c=timed(lambda: g.self_knn(20,True,True,True))
     print("grid ppc %.0f h=%.3f: self kNN20 %.0f us | fused cov only %.0f us | knn+cov+normals %.0f us"%(ppc,g.cell_size(),a,b,c),flush=True)

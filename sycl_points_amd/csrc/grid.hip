@@ -26,6 +26,8 @@
 
 void sp_set_error(const char* msg);
 
+static int g_self_knn_mode = 0;  // tuning hook: 0 wave-cooperative kernel, 1 lane-per-query tile kernel (k <= 10)
+
 namespace sp {
 namespace {
 
@@ -381,6 +383,259 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_tile_kernel(const float4*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-cooperative self-kNN (k <= 32): the 64 lanes of a wave work on ONE query at a time.
+//   * candidates = the 3x3x3 block of cells around the query's cell: nine contiguous segments of the cell-ordered
+//     point array, flattened into one list and consumed 64 at a time — lane l evaluates candidate (base + l): coalesced
+//     16-byte loads, no LDS, no per-lane lists;
+//   * the sorted top-k lives ONE ENTRY PER LANE (lane i holds the i-th best (d, idx, pos)); the first 64 candidates are
+//     sorted with a wave bitonic network, later candidates that beat the k-th entry (found by ballot) are inserted with
+//     a rank computed by ballot + a one-lane shift: O(1) wave instructions per insertion, whatever k is;
+//   * queries are walked in cell order (work unit = 64 consecutive points of one x-row), so consecutive queries reuse
+//     the same nine segments out of L1/L2;
+//   * results are ordered by (distance, original index): bit-identical to brute force; the covariance (optional) is
+//     accumulated over the list in ascending order exactly as covariance::kernel::estimate does.
+struct Cand {
+    float d;
+    int idx, pos;
+};
+__device__ __forceinline__ bool cand_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+// Broadcast from a wave-uniform lane: v_readlane_b32 (VALU -> SGPR), not the LDS crossbar a generic __shfl uses.
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float bcast_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+// Lane i receives lane i-1's value (lane 0 keeps its own): one DPP move, wave_shr:1 (gfx9 DPP control 0x138).
+__device__ __forceinline__ int shift_up1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float shift_up1_f(float v) { return __int_as_float(shift_up1_i(__float_as_int(v))); }
+
+__device__ __forceinline__ Cand bitonic_sort64(Cand v, unsigned lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            Cand o;
+            o.d = __shfl_xor(v.d, stride, 64);
+            o.idx = __shfl_xor(v.idx, stride, 64);
+            o.pos = __shfl_xor(v.pos, stride, 64);
+            const bool up = ((lane & size) == 0);          // ascending block?
+            const bool lower = ((lane & stride) == 0);     // this lane keeps the smaller of the pair in an ascending block
+            const bool o_less = cand_less(o.d, o.idx, v.d, v.idx);
+            const bool take = (lower == up) ? o_less : !o_less && !(o.d == v.d && o.idx == v.idx);
+            v.d = take ? o.d : v.d;
+            v.idx = take ? o.idx : v.idx;
+            v.pos = take ? o.pos : v.pos;
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4* __restrict__ pts,
+                                                                   const unsigned* __restrict__ start,
+                                                                   const unsigned* __restrict__ unit_off, GridDesc g,
+                                                                   int k, TileOut out) {
+    const unsigned unit = blockIdx.x;
+    const unsigned rows = (unsigned)g.ny * g.nz;
+    unsigned lo = 0, hi = rows;
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (unit_off[mid] <= unit) lo = mid;
+        else hi = mid;
+    }
+    const unsigned row = lo;
+    const int ry = (int)(row % g.ny), rz = (int)(row / g.ny);
+    const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
+    const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
+    const unsigned nq = min(64u, row_e - qs);
+    const unsigned lane = threadIdx.x;
+    const float4 myq = pts[min(qs + lane, row_e - 1)];
+    const int ya = max(ry - 1, 0), yb = min(ry + 1, g.ny - 1), za = max(rz - 1, 0), zb = min(rz + 1, g.nz - 1);
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+
+    int cur_cx = -1;
+    unsigned seg_s[9], seg_c[10];  // start of each segment, running candidate counts (seg_c[9] = total)
+    int xa = 0, xb = 0;
+    for (unsigned j = 0; j < nq; ++j) {
+        // the query, made wave-uniform
+        const float qx = bcast_f(myq.x, (int)j), qy = bcast_f(myq.y, (int)j), qz = bcast_f(myq.z, (int)j);
+        const unsigned qorig = (unsigned)bcast_i(__float_as_int(myq.w), (int)j);
+        const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx);
+        if (cx != cur_cx) {  // wave-uniform: new cell, new segments
+            cur_cx = cx;
+            xa = max(cx - 1, 0);
+            xb = min(cx + 1, g.nx - 1);
+            unsigned c = 0;
+            int r = 0;
+            // centre row first, then the rest: the nearest candidates arrive early and keep later insertions rare
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+                for (int z = za; z <= zb; ++z)
+                    for (int y = ya; y <= yb; ++y) {
+                        const bool centre = (z == rz && y == ry);
+                        if ((pass == 0) != centre) continue;
+                        const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
+                        const unsigned s0 = start[rr + xa], e0 = start[rr + xb + 1];
+                        seg_s[r] = s0;
+                        seg_c[r] = c;
+                        c += e0 - s0;
+                        ++r;
+                    }
+            for (; r < 9; ++r) { seg_s[r] = 0; seg_c[r] = c; }
+            seg_c[9] = c;
+        }
+        const unsigned total = seg_c[9];
+        Cand best;  // lane i holds the i-th best
+        best.d = FLT_MAX; best.idx = 0x7fffffff; best.pos = -1;
+        float kth = FLT_MAX;
+        int kth_idx = 0x7fffffff;
+        auto fetch = [&](unsigned base, float4& p, unsigned& pos, bool& valid) {
+            const unsigned f = base + lane;
+            valid = f < total;
+            const unsigned ff = valid ? f : total - 1;
+            pos = seg_s[0] + ff;
+#pragma unroll
+            for (int r = 1; r < 9; ++r) pos = (ff >= seg_c[r]) ? seg_s[r] + (ff - seg_c[r]) : pos;
+            p = pts[pos];
+        };
+        float4 p_next;
+        unsigned pos_next;
+        bool valid_next;
+        fetch(0, p_next, pos_next, valid_next);
+        for (unsigned base = 0; base < total; base += 64) {
+            const float4 p = p_next;
+            const unsigned pos = pos_next;
+            const bool valid = valid_next;
+            if (base + 64 < total) fetch(base + 64, p_next, pos_next, valid_next);  // in flight while this chunk is merged
+            Cand c;
+            c.d = valid ? dist2(qx, qy, qz, p.x, p.y, p.z) : FLT_MAX;
+            c.idx = valid ? __float_as_int(p.w) : 0x7fffffff;
+            c.pos = (int)pos;
+            if (base == 0) {
+                best = bitonic_sort64(c, lane);
+                kth = bcast_f(best.d, k - 1);
+                kth_idx = bcast_i(best.idx, k - 1);
+            } else {
+                unsigned long long m = __ballot(cand_less(c.d, c.idx, kth, kth_idx));
+                while (m) {
+                    const int L = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float vd = bcast_f(c.d, L);
+                    const int vi = bcast_i(c.idx, L), vp = bcast_i(c.pos, L);
+                    if (!cand_less(vd, vi, kth, kth_idx)) continue;  // the k-th entry moved since the ballot
+                    const unsigned long long before = __ballot(cand_less(best.d, best.idx, vd, vi)) & kmask;
+                    const int rank = __builtin_popcountll(before);  // entries that stay in front of the newcomer
+                    const float ud = shift_up1_f(best.d);
+                    const int ui = shift_up1_i(best.idx), up = shift_up1_i(best.pos);
+                    if ((int)lane == rank) { best.d = vd; best.idx = vi; best.pos = vp; }
+                    else if ((int)lane > rank) { best.d = ud; best.idx = ui; best.pos = up; }
+                    kth = bcast_f(best.d, k - 1);
+                    kth_idx = bcast_i(best.idx, k - 1);
+                }
+            }
+        }
+        // Exactness: is the k-th neighbour inside the scanned block? If not (sparse neighbourhoods), keep adding rings
+        // of cells — still wave-cooperatively, one shell segment at a time — until it is.
+        const int cy = ry, cz = rz;
+        const int rmax = max(max(g.nx, g.ny), g.nz);
+        for (int R = 1; R <= rmax; ++R) {
+            float cov = FLT_MAX;
+            if (cx - R > 0) cov = fminf(cov, qx - (g.ox + (cx - R) * g.h));
+            if (cx + R < g.nx - 1) cov = fminf(cov, (g.ox + (cx + R + 1) * g.h) - qx);
+            if (cy - R > 0) cov = fminf(cov, qy - (g.oy + (cy - R) * g.h));
+            if (cy + R < g.ny - 1) cov = fminf(cov, (g.oy + (cy + R + 1) * g.h) - qy);
+            if (cz - R > 0) cov = fminf(cov, qz - (g.oz + (cz - R) * g.h));
+            if (cz + R < g.nz - 1) cov = fminf(cov, (g.oz + (cz + R + 1) * g.h) - qz);
+            if (cov == FLT_MAX) break;  // the block is the whole grid
+            cov = fmaxf(cov - g.eps, 0.0f);
+            if (kth < cov * cov) break;  // proven exact (strict: an unseen point at exactly kth could win a tie)
+            const int Rn = R + 1;        // add the shell at Chebyshev distance Rn
+            const int z0 = max(cz - Rn, 0), z1 = min(cz + Rn, g.nz - 1), y0 = max(cy - Rn, 0), y1 = min(cy + Rn, g.ny - 1);
+            const int x0 = max(cx - Rn, 0), x1 = min(cx + Rn, g.nx - 1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y) {
+                    const bool shell_row = (z == cz - Rn) || (z == cz + Rn) || (y == cy - Rn) || (y == cy + Rn);
+                    const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
+                    for (int sgi = 0; sgi < (shell_row ? 1 : 2); ++sgi) {
+                        int sxa, sxb;
+                        if (shell_row) { sxa = x0; sxb = x1; }
+                        else if (sgi == 0) { sxa = sxb = cx - Rn; if (sxa < 0) continue; }
+                        else { sxa = sxb = cx + Rn; if (sxb > g.nx - 1) continue; }
+                        const unsigned s0 = start[rr + sxa], e0 = start[rr + sxb + 1];
+                        for (unsigned base = s0; base < e0; base += 64) {
+                            const unsigned pos = base + lane;
+                            const bool valid = pos < e0;
+                            const float4 p = pts[valid ? pos : e0 - 1];
+                            Cand c;
+                            c.d = valid ? dist2(qx, qy, qz, p.x, p.y, p.z) : FLT_MAX;
+                            c.idx = valid ? __float_as_int(p.w) : 0x7fffffff;
+                            c.pos = (int)pos;
+                            unsigned long long m = __ballot(cand_less(c.d, c.idx, kth, kth_idx));
+                            while (m) {
+                                const int L = __builtin_ctzll(m);
+                                m &= m - 1;
+                                const float vd = bcast_f(c.d, L);
+                                const int vi = bcast_i(c.idx, L), vp = bcast_i(c.pos, L);
+                                if (!cand_less(vd, vi, kth, kth_idx)) continue;
+                                const unsigned long long before = __ballot(cand_less(best.d, best.idx, vd, vi)) & kmask;
+                                const int rank = __builtin_popcountll(before);
+                                const float ud = shift_up1_f(best.d);
+                                const int ui = shift_up1_i(best.idx), up = shift_up1_i(best.pos);
+                                if ((int)lane == rank) { best.d = vd; best.idx = vi; best.pos = vp; }
+                                else if ((int)lane > rank) { best.d = ud; best.idx = ui; best.pos = up; }
+                                kth = bcast_f(best.d, k - 1);
+                                kth_idx = bcast_i(best.idx, k - 1);
+                            }
+                        }
+                    }
+                }
+        }
+        const bool have = (int)lane < k && best.d != FLT_MAX;
+        if (out.knn_idx && (int)lane < k) {
+            const size_t o = (size_t)qorig * (size_t)k + lane;
+            out.knn_idx[o] = have ? best.idx : -1;
+            out.knn_d2[o] = best.d;
+        }
+        if (out.covs || out.normals) {
+            const float4 np = pts[have ? best.pos : 0];
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f, oxx = 0.0f, oxy = 0.0f, oxz = 0.0f, oyy = 0.0f, oyz = 0.0f, ozz = 0.0f;
+            const unsigned cnt = (unsigned)__builtin_popcountll(__ballot(have));
+            for (unsigned t = 0; t < cnt; ++t) {  // ascending order, as covariance::kernel::estimate sums (all lanes redundantly)
+                const float x = bcast_f(np.x, (int)t), y = bcast_f(np.y, (int)t), z = bcast_f(np.z, (int)t);
+                sx += x; sy += y; sz += z;
+                oxx += x * x; oxy += x * y; oxz += x * z;
+                oyy += y * y; oyz += y * z; ozz += z * z;
+            }
+            Mat3 C;
+            if (cnt < 4) {
+                C.m[0][0] = C.m[1][1] = C.m[2][2] = 1.0f;
+                C.m[0][1] = C.m[0][2] = C.m[1][0] = C.m[1][2] = C.m[2][0] = C.m[2][1] = 0.0f;
+            } else {
+                const float inv = 1.0f / (float)cnt;
+                const float mx = sx * inv, my = sy * inv, mz = sz * inv;
+                const float cxy = oxy * inv - mx * my, cxz = oxz * inv - mx * mz, cyz = oyz * inv - my * mz;
+                C.m[0][0] = oxx * inv - mx * mx; C.m[1][1] = oyy * inv - my * my; C.m[2][2] = ozz * inv - mz * mz;
+                C.m[0][1] = C.m[1][0] = (cxy + cxy) * 0.5f;
+                C.m[0][2] = C.m[2][0] = (cxz + cxz) * 0.5f;
+                C.m[1][2] = C.m[2][1] = (cyz + cyz) * 0.5f;
+            }
+            if (out.covs && lane < 4) {
+                const float4 col = lane == 0 ? make_float4(C.m[0][0], C.m[1][0], C.m[2][0], 0.0f)
+                                 : lane == 1 ? make_float4(C.m[0][1], C.m[1][1], C.m[2][1], 0.0f)
+                                 : lane == 2 ? make_float4(C.m[0][2], C.m[1][2], C.m[2][2], 0.0f)
+                                             : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                out.covs[4 * (size_t)qorig + lane] = col;
+            }
+            if (out.normals) {
+                float ev[3];
+                Mat3 V;
+                symmetric_eigen3(C, ev, V);
+                const float nx_ = V.m[0][0], ny_ = V.m[1][0], nz_ = V.m[2][0];
+                const float dd = chain3(nx_, qx, ny_, qy, nz_, qz);
+                if (lane == 0)
+                    out.normals[qorig] = (dd <= 1.0f) ? make_float4(nx_, ny_, nz_, 0.0f) : make_float4(-nx_, -ny_, -nz_, 0.0f);
+            }
+        }
+    }
+}
+
 // Ring walk for the queries the tile kernel could not prove exact (their positions are listed in `todo`).
 template <int KCAP>
 __global__ __launch_bounds__(kBlock) void grid_self_knn_todo_kernel(const float4* __restrict__ pts,
@@ -503,15 +758,12 @@ __global__ void fill_todo_kernel(unsigned* todo, unsigned* count, unsigned n) {
 template <int KCAP>
 int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
     const GridDesc g = grid_desc(gr);
-    if (KCAP <= 10) {
-        if (hipMemsetAsync(out.todo_count, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
-        if (gr->n_units)
+    if (hipMemsetAsync(out.todo_count, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
+    if (gr->n_units) {
+        if (g_self_knn_mode == 1 && KCAP <= 10)  // lane-per-query tile kernel (kept for comparison; slower from k ~ 8 up)
             grid_self_knn_tile_kernel<KCAP><<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
-    } else {
-        // Long lists: the tile kernel's sorted insertion runs for almost every candidate as soon as ANY lane of the wave
-        // needs it (measured 22.9 ms per 1M points at k = 20, profiles/README.md r01_e), so every point takes the
-        // ring walk instead, in cell order (neighbouring lanes share their rows).
-        fill_todo_kernel<<<div_up(gr->n, kBlock), kBlock, 0, st>>>(out.todo, out.todo_count, (unsigned)gr->n);
+        else
+            grid_self_knn_wave_kernel<<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
     }
     grid_self_knn_todo_kernel<KCAP><<<div_up(gr->n, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
     return launch_status();
@@ -743,3 +995,6 @@ extern "C" int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out,
     if (k <= 10) return launch_self<10>(grid, (int)k, out, st);
     return launch_self<20>(grid, (int)k, out, st);
 }
+
+// Tuning hook, not part of the stable surface.
+extern "C" void sp_debug_set_self_knn_mode(int mode) { g_self_knn_mode = mode; }
