@@ -238,6 +238,8 @@ int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* 
 /* Tuning hook, not part of the stable surface: NN walk used inside the fused kernel
  * (-1 automatic: 2x2x2 fast path iff the source is cell-sorted; 0 ring walk; 1 fast path). */
 void sp_debug_set_fused_fast_nn(int mode);
+/* Measurement hook: launches issued by sp_gicp_iteration_fused (bit 0 = fused kernel, bit 1 = final reduce + solve). */
+void sp_debug_set_fused_stage_mask(int mask);
 /* Tuning hook: self-kNN kernel (0 wave-cooperative, default; 1 lane-per-query tile kernel for k <= 10). */
 void sp_debug_set_self_knn_mode(int mode);
 

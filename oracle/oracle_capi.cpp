@@ -221,9 +221,11 @@ struct orc_reg_result {
 };
 // nn_mode: 0 = KD-tree built on target (the reference's default KNNBase), 1 = brute force.
 // trace_T (optional, max_iterations*16 floats) receives the pose after every outer iteration; *trace_n their count.
+// prebuilt_nodes (optional): a KD-tree from orc_kdtree_build on the same target, so the build is not part of the call.
 void orc_registration_align(const orc_reg_params* P, const float* src, const float* src_cov, size_t ns, const float* tgt,
                             const float* tgt_cov, const float* tgt_nrm, size_t nt, const float* init_T16, int nn_mode,
-                            orc_reg_result* out, float* trace_T, int* trace_n) {
+                            orc_reg_result* out, float* trace_T, int* trace_n, const void* prebuilt_nodes,
+                            size_t prebuilt_n_nodes) {
     RegParams p;
     p.reg_type = P->reg_type; p.robust_type = P->robust_type; p.optimization_method = P->optimization_method;
     p.max_iterations = (size_t)P->max_iterations; p.max_correspondence_distance = P->max_correspondence_distance;
@@ -236,10 +238,16 @@ void orc_registration_align(const orc_reg_params* P, const float* src, const flo
     s.points = src; s.covs = src_cov; s.n = ns;
     t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm; t.n = nt;
     std::vector<FlatKDNode> tree;
-    if (nn_mode == 0) tree = kdtree_build(tgt, nt, 16);
+    const FlatKDNode* nodes = static_cast<const FlatKDNode*>(prebuilt_nodes);
+    size_t n_nodes = prebuilt_n_nodes;
+    if (nn_mode == 0 && nodes == nullptr) {  // KDTree::build is target preprocessing in the reference's flow
+        tree = kdtree_build(tgt, nt, 16);
+        nodes = tree.data();
+        n_nodes = tree.size();
+    }
     NearestFn nearest = [&](const float* q, size_t nq, const float* T, int32_t* idx, float* d2) {
         if (nn_mode == 0) {
-            kdtree_search(tree.data(), tree.size(), q, nq, 1, T, idx, d2, -1.0f);
+            kdtree_search(nodes, n_nodes, q, nq, 1, T, idx, d2, -1.0f);
         } else {
             std::vector<float> tq(nq * 4);
             for (size_t i = 0; i < nq; ++i) transform_point(q + 4 * i, tq.data() + 4 * i, T);

@@ -342,7 +342,7 @@ class Oracle:
         return out
 
     def registration_align(self, params, src, src_cov, tgt, tgt_cov, tgt_nrm=None, init_T=None, nn_mode="kdtree",
-                           trace=False):
+                           trace=False, nodes=None):
         src, tgt = _f(src), _f(tgt)
         src_cov = None if src_cov is None else _f(src_cov)
         tgt_cov = None if tgt_cov is None else _f(tgt_cov)
@@ -353,7 +353,9 @@ class Oracle:
         trn = C.c_int(0)
         self.lib.orc_registration_align(C.byref(params), _p(src), _p(src_cov), C.c_size_t(len(src)), _p(tgt), _p(tgt_cov),
                                         _p(tgt_nrm), C.c_size_t(len(tgt)), _p(Tc), C.c_int(0 if nn_mode == "kdtree" else 1),
-                                        C.byref(res), _p(tr), C.byref(trn))
+                                        C.byref(res), _p(tr), C.byref(trn),
+                                        None if nodes is None else nodes.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(0 if nodes is None else len(nodes) // 32))
         out = {"T": np.array(res.T, np.float32).reshape(4, 4).T.copy(),
                "H": np.array(res.H, np.float32).reshape(6, 6).T.copy(), "b": np.array(res.b, np.float32),
                "error": float(res.error), "inlier": int(res.inlier), "iterations": int(res.iterations),

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Collect HBM traffic of the hot kernels with rocprofv3 PMC counters and write profiles/traffic.json.
+
+Run on the GPU box from the repository root:  python3 profiles/collect_traffic.py
+Method (MI355X_MICROARCH.md §HBM / cdna_hip_programming.md §7): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE
+passes (they do not fit one pass on gfx950), with --kernel-trace only; both are in KiB; on gfx950 FETCH_SIZE reports
+half the bytes of wide (16 B/lane) reads, so it is doubled. bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024, averaged
+over the launches of each kernel. This script never touches the GPU itself; rocprofv3 wraps `python3 bench.py` directly.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
+KERNELS = {"gicp_fused_kernel": "gicp_fused_kernel", "final_reduce_kernel": "final_reduce_kernel",
+           "prepare_cov_kernel": "prepare_cov_kernel"}
+
+
+def run_pass(counter):
+    d = os.path.join(OUT, counter)
+    os.makedirs(d, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "40", "--warmup", "20"]
+    subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[-1]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        for key, pat in KERNELS.items():
+            if pat in r["Kernel_Name"]:
+                acc[key].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    fetch = run_pass("FETCH_SIZE")
+    write = run_pass("WRITE_SIZE")
+    out = {}
+    for k in KERNELS:
+        if k in fetch and k in write:
+            f_kib, nf = fetch[k]
+            w_kib, _ = write[k]
+            out[k] = {"FETCH_SIZE_KiB_per_launch": f_kib, "WRITE_SIZE_KiB_per_launch": w_kib, "launches": nf,
+                      "hbm_bytes_per_launch": 2.0 * f_kib * 1024.0 + w_kib * 1024.0,
+                      "correction": "gfx950: FETCH_SIZE x2 (16 B/lane reads); WRITE_SIZE as is"}
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

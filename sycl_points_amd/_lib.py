@@ -86,6 +86,7 @@ SIGNATURES = {
     "sp_gicp_iteration_fused": (_i, [_vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_debug_set_fused_fast_nn": (None, [_i]),
     "sp_debug_set_self_knn_mode": (None, [_i]),
+    "sp_debug_set_fused_stage_mask": (None, [_i]),
     "sp_gn_update": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp]),
     "sp_gn_update_host": (_i, [_vp, _vp, _f, _f, _f, _vp]),
     "sp_se3_exp_host": (None, [_vp, _vp]),

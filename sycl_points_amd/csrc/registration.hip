@@ -14,6 +14,7 @@
 
 void sp_set_error(const char* msg);
 
+static int g_fused_stage_mask = 3;  // measurement hook: bit 0 = fused kernel, bit 1 = final reduce (+ solve)
 static int g_fused_fast_nn = -1;  // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
 
 namespace sp {
@@ -947,7 +948,8 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     // their lines: the branch-light 2x2x2 walk wins (profiles/README.md, r01_c).
     const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
 #define SP_LAUNCH_FUSED(L)                                                              \
-    if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);        \
+    if (!(g_fused_stage_mask & 1)) {}                                                   \
+    else if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else gicp_fused_kernel<L, false><<<grid, kBlock, 0, st>>>(P, partials)
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_FUSED(LOSS_NONE); break;
@@ -960,8 +962,10 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
 #undef SP_LAUNCH_FUSED
     GnArgs ga{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
     if (gn) ga = GnArgs{transT, gn->lambda, gn->crit_rotation, gn->crit_translation, delta_out8};
-    final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
+    if (g_fused_stage_mask & 2) final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
     return launch_status();
 }
+// Measurement hook (not part of the stable surface): which of the two launches sp_gicp_iteration_fused issues.
+extern "C" void sp_debug_set_fused_stage_mask(int mask) { g_fused_stage_mask = mask; }
 // Tuning hook (not part of the stable surface): choose the NN walk used inside the fused kernel.
 extern "C" void sp_debug_set_fused_fast_nn(int mode) { g_fused_fast_nn = mode; }

@@ -30,7 +30,8 @@ void orc_knn_bruteforce(const float* q, size_t nq, const float* t, size_t nt, si
 void orc_cov_estimate(const float* pts, size_t n, const int32_t* idx, size_t k, float* covs);
 void orc_registration_align(const orc_reg_params* P, const float* src, const float* src_cov, size_t ns, const float* tgt,
                             const float* tgt_cov, const float* tgt_nrm, size_t nt, const float* init_T16, int nn_mode,
-                            orc_reg_result* out, float* trace_T, int* trace_n);
+                            orc_reg_result* out, float* trace_T, int* trace_n, const void* prebuilt_nodes,
+                            size_t prebuilt_n_nodes);
 void orc_se3_exp(const float* twist6, float* T16);
 }
 
@@ -204,7 +205,7 @@ static void registration_matches_oracle() {
     orc_registration_align(&op, reinterpret_cast<const float*>(source.points->data()),
                            reinterpret_cast<const float*>(source.covs->data()), n,
                            reinterpret_cast<const float*>(target.points->data()),
-                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr);
+                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr, nullptr, 0);
     auto tree = alg::knn::KDTree::build(*Q, target);
     auto grid = alg::knn::GridKNN::build(*Q, target);
     HostBruteForceKNN host_knn(*Q, target);
@@ -232,7 +233,7 @@ static void registration_matches_oracle() {
     orc_registration_align(&op2, reinterpret_cast<const float*>(source.points->data()),
                            reinterpret_cast<const float*>(source.covs->data()), n,
                            reinterpret_cast<const float*>(target.points->data()),
-                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr);
+                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr, nullptr, 0);
     CHECK(max_abs_diff(r_pipe.T.matrix(), ref.T) < 1e-5f);
     // validate_params (registration.hpp:144-150)
     PointCloudShared nocov(*Q, tc);
