@@ -3,9 +3,12 @@
 
 Run on the GPU box from the repository root:  python3 profiles/collect_traffic.py
 Method (MI355X_MICROARCH.md §HBM / cdna_hip_programming.md §7): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE
-passes (they do not fit one pass on gfx950), with --kernel-trace only; both are in KiB; on gfx950 FETCH_SIZE reports
-half the bytes of wide (16 B/lane) reads, so it is doubled. bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024, averaged
-over the launches of each kernel. This script never touches the GPU itself; rocprofv3 wraps `python3 bench.py` directly.
+passes (they do not fit one pass on gfx950), with --kernel-trace only; both are in KiB. The guide's gfx950 correction
+(FETCH_SIZE reads exactly half for WIDE COALESCED streaming reads) does not transfer to gather-shaped kernels, so, as the
+guide prescribes for other access shapes, the read side is CALIBRATED on a known byte count in the same access pattern:
+prepare_cov_kernel gathers one 64-byte covariance row per lane through an index (the shape of the fused kernel's loads)
+and reads a known n x (64 + 4 or 16) bytes. factor = known / FETCH_SIZE; WRITE_SIZE is exact for 16-byte stores (checked:
+prepare_cov writes exactly n x 32 bytes). bytes = factor * FETCH_SIZE * 1024 + WRITE_SIZE * 1024, per launch. This script never touches the GPU itself; rocprofv3 wraps `python3 bench.py` directly.
 """
 import collections
 import csv
@@ -43,13 +46,19 @@ def main():
     fetch = run_pass("FETCH_SIZE")
     write = run_pass("WRITE_SIZE")
     out = {}
+    n = 1_000_000
+    known_prepare_read = n * (64 + (4 + 16) / 2.0)  # half the launches index through perm (4 B), half through grid points (16 B)
+    factor = known_prepare_read / (fetch["prepare_cov_kernel"][0] * 1024.0)
     for k in KERNELS:
         if k in fetch and k in write:
             f_kib, nf = fetch[k]
             w_kib, _ = write[k]
             out[k] = {"FETCH_SIZE_KiB_per_launch": f_kib, "WRITE_SIZE_KiB_per_launch": w_kib, "launches": nf,
-                      "hbm_bytes_per_launch": 2.0 * f_kib * 1024.0 + w_kib * 1024.0,
-                      "correction": "gfx950: FETCH_SIZE x2 (16 B/lane reads); WRITE_SIZE as is"}
+                      "read_calibration_factor": factor,
+                      "hbm_bytes_per_launch": factor * f_kib * 1024.0 + w_kib * 1024.0,
+                      "uncorrected_bytes_per_launch": f_kib * 1024.0 + w_kib * 1024.0,
+                      "correction": "read side calibrated on prepare_cov_kernel (known n*(64+10) B, same gather shape); "
+                                    "WRITE_SIZE exact"}
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
