@@ -204,7 +204,14 @@ __global__ __launch_bounds__(kBlock) void kdtree_search_kernel(const float4* __r
                     best_insert<KCAP>(bd, bi, k, d, pidx, kth);
                 }
             };
-            if (KCAP == 1) {
+            if (KCAP == 1 && stride == 16) {
+                // the default leaf size: fetch the whole 256-byte block with 16 independent loads, then visit in order
+                float4 slot[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) slot[s] = blk[s];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) visit(slot[s]);
+            } else if (KCAP == 1) {
 #pragma unroll 4
                 for (unsigned s = 0; s < stride; ++s) visit(blk[s]);
             } else {  // the insertion chain is long: keep one copy of it
