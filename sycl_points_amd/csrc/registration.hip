@@ -529,7 +529,7 @@ struct FusedParams {
     float* nn_d2;
 };
 
-template <int LOSS, bool FAST_NN>
+template <int LOSS, bool FAST_NN, int DBG = 0>
 __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float* __restrict__ partials) {
     const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
     float acc[kAcc - 1];
@@ -540,8 +540,14 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
         const float4 s = P.src[i];
         float qx, qy, qz;
         transform_point(T, s.x, s.y, s.z, qx, qy, qz);
-        const Nearest nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz)
-                                   : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+        Nearest nn;
+        if (DBG == 2) {  // timing experiment: no search, a nearby fake winner
+            nn.pos = min(i, P.g.n - 1); const float4 tp = P.tpts[nn.pos];
+            nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = (int)nn.pos; nn.d2 = 0.0f;
+        } else {
+            nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+        }
+        if (DBG == 1) { acc[27] += nn.d2 + nn.x; ++cnt; continue; }  // timing experiment: search only
         if (P.nn_idx) {
             const unsigned o = P.perm[i];
             P.nn_idx[o] = nn.idx;
@@ -551,45 +557,60 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
         const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
         const Sym3 Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
         const float r0 = nn.x - qx, r1 = nn.y - qy, r2 = nn.z - qz;
-        // Y = Cs' R^T ; S = R Y + Ct'  (symmetric: 6 unique entries)
+        // Source-frame form of factor.hpp:239-278. With S = skew(p), J = [R S | -R] and M = (Ct' + R Cs' R^T)^-1:
+        //   N := R^T M R = (Cs' + R^T Ct' R)^-1,  v := R^T r,  u := N v,  G := S N
+        //   H = [[-G S, G], [G^T, N]],   b = [u x p, -u],   e = v . u
+        // (same mathematics as J^T M J / J^T M r, about half the multiply-adds).
         const float (&R)[3][3] = T.R;
-        float Y[3][3];
+        float W[3][3];  // W = Ct' R
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            Y[0][j] = chain3(Cs.xx, R[j][0], Cs.xy, R[j][1], Cs.xz, R[j][2]);
-            Y[1][j] = chain3(Cs.xy, R[j][0], Cs.yy, R[j][1], Cs.yz, R[j][2]);
-            Y[2][j] = chain3(Cs.xz, R[j][0], Cs.yz, R[j][1], Cs.zz, R[j][2]);
+            W[0][j] = chain3(Ct.xx, R[0][j], Ct.xy, R[1][j], Ct.xz, R[2][j]);
+            W[1][j] = chain3(Ct.xy, R[0][j], Ct.yy, R[1][j], Ct.yz, R[2][j]);
+            W[2][j] = chain3(Ct.xz, R[0][j], Ct.yz, R[1][j], Ct.zz, R[2][j]);
         }
-        Mat3 S;
-        S.m[0][0] = chain3(R[0][0], Y[0][0], R[0][1], Y[1][0], R[0][2], Y[2][0]) + Ct.xx;
-        S.m[0][1] = chain3(R[0][0], Y[0][1], R[0][1], Y[1][1], R[0][2], Y[2][1]) + Ct.xy;
-        S.m[0][2] = chain3(R[0][0], Y[0][2], R[0][1], Y[1][2], R[0][2], Y[2][2]) + Ct.xz;
-        S.m[1][1] = chain3(R[1][0], Y[0][1], R[1][1], Y[1][1], R[1][2], Y[2][1]) + Ct.yy;
-        S.m[1][2] = chain3(R[1][0], Y[0][2], R[1][1], Y[1][2], R[1][2], Y[2][2]) + Ct.yz;
-        S.m[2][2] = chain3(R[2][0], Y[0][2], R[2][1], Y[1][2], R[2][2], Y[2][2]) + Ct.zz;
-        S.m[1][0] = S.m[0][1]; S.m[2][0] = S.m[0][2]; S.m[2][1] = S.m[1][2];
-        const Mat3 M = inverse(S);  // Zero when |det| < 1e-6, as eigen_utils::inverse
-        float J[3][6];
-        se3_jacobian(T, s.x, s.y, s.z, J);
-        float JTm[6][3];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) JTm[a][k] = chain3(J[0][a], M.m[0][k], J[1][a], M.m[1][k], J[2][a], M.m[2][k]);
-        const float v0 = chain3(M.m[0][0], r0, M.m[0][1], r1, M.m[0][2], r2);
-        const float v1 = chain3(M.m[1][0], r0, M.m[1][1], r1, M.m[1][2], r2);
-        const float v2 = chain3(M.m[2][0], r0, M.m[2][1], r1, M.m[2][2], r2);
-        const float sq = chain3(r0, v0, r1, v1, r2, v2);
+        Mat3 A;  // Cs' + R^T Ct' R (symmetric)
+        A.m[0][0] = chain3(R[0][0], W[0][0], R[1][0], W[1][0], R[2][0], W[2][0]) + Cs.xx;
+        A.m[0][1] = chain3(R[0][0], W[0][1], R[1][0], W[1][1], R[2][0], W[2][1]) + Cs.xy;
+        A.m[0][2] = chain3(R[0][0], W[0][2], R[1][0], W[1][2], R[2][0], W[2][2]) + Cs.xz;
+        A.m[1][1] = chain3(R[0][1], W[0][1], R[1][1], W[1][1], R[2][1], W[2][1]) + Cs.yy;
+        A.m[1][2] = chain3(R[0][1], W[0][2], R[1][1], W[1][2], R[2][1], W[2][2]) + Cs.yz;
+        A.m[2][2] = chain3(R[0][2], W[0][2], R[1][2], W[1][2], R[2][2], W[2][2]) + Cs.zz;
+        // symmetric inverse by the adjugate; Zero when |det| < 1e-6 (eigen_utils::inverse, eigen_utils.hpp:403-423;
+        // det is invariant under the rotation)
+        const float c00 = fmaf(A.m[1][1], A.m[2][2], -A.m[1][2] * A.m[1][2]);
+        const float c01 = fmaf(A.m[0][2], A.m[1][2], -A.m[0][1] * A.m[2][2]);
+        const float c02 = fmaf(A.m[0][1], A.m[1][2], -A.m[0][2] * A.m[1][1]);
+        const float det = fmaf(A.m[0][0], c00, fmaf(A.m[0][1], c01, A.m[0][2] * c02));
+        const float inv_det = fabsf(det) < 1e-6f ? 0.0f : 1.0f / det;
+        const float n00 = c00 * inv_det, n01 = c01 * inv_det, n02 = c02 * inv_det;
+        const float n11 = fmaf(A.m[0][0], A.m[2][2], -A.m[0][2] * A.m[0][2]) * inv_det;
+        const float n12 = fmaf(A.m[0][1], A.m[0][2], -A.m[0][0] * A.m[1][2]) * inv_det;
+        const float n22 = fmaf(A.m[0][0], A.m[1][1], -A.m[0][1] * A.m[0][1]) * inv_det;
+        const float v0 = chain3(R[0][0], r0, R[1][0], r1, R[2][0], r2);
+        const float v1 = chain3(R[0][1], r0, R[1][1], r1, R[2][1], r2);
+        const float v2 = chain3(R[0][2], r0, R[1][2], r1, R[2][2], r2);
+        const float u0 = chain3(n00, v0, n01, v1, n02, v2);
+        const float u1 = chain3(n01, v0, n11, v1, n12, v2);
+        const float u2 = chain3(n02, v0, n12, v1, n22, v2);
+        const float sq = chain3(v0, u0, v1, u1, v2, u2);
         const float rn = sqrtf(sq);
         const float w = robust_weight<LOSS>(rn, P.scale);
-        int e = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = a; c < 6; ++c)
-                acc[e++] += w * chain3(JTm[a][0], J[0][c], JTm[a][1], J[1][c], JTm[a][2], J[2][c]);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) acc[21 + a] += w * chain3(JTm[a][0], r0, JTm[a][1], r1, JTm[a][2], r2);
+        const float px = s.x, py = s.y, pz = s.z;
+        // G = S N, rows: p x (columns of N)
+        const float g00 = fmaf(py, n02, -pz * n01), g01 = fmaf(py, n12, -pz * n11), g02 = fmaf(py, n22, -pz * n12);
+        const float g10 = fmaf(pz, n00, -px * n02), g11 = fmaf(pz, n01, -px * n12), g12 = fmaf(pz, n02, -px * n22);
+        const float g20 = fmaf(px, n01, -py * n00), g21 = fmaf(px, n11, -py * n01), g22 = fmaf(px, n12, -py * n02);
+        // H_rr = -G S (symmetric)
+        const float h00 = fmaf(g02, py, -g01 * pz), h01 = fmaf(g00, pz, -g02 * px), h02 = fmaf(g01, px, -g00 * py);
+        const float h11 = fmaf(g10, pz, -g12 * px), h12 = fmaf(g11, px, -g10 * py), h22 = fmaf(g21, px, -g20 * py);
+        acc[0] += w * h00; acc[1] += w * h01; acc[2] += w * h02; acc[3] += w * g00; acc[4] += w * g01; acc[5] += w * g02;
+        acc[6] += w * h11; acc[7] += w * h12; acc[8] += w * g10; acc[9] += w * g11; acc[10] += w * g12;
+        acc[11] += w * h22; acc[12] += w * g20; acc[13] += w * g21; acc[14] += w * g22;
+        acc[15] += w * n00; acc[16] += w * n01; acc[17] += w * n02; acc[18] += w * n11; acc[19] += w * n12; acc[20] += w * n22;
+        // b = [u x p, -u]
+        acc[21] += w * fmaf(u1, pz, -u2 * py); acc[22] += w * fmaf(u2, px, -u0 * pz); acc[23] += w * fmaf(u0, py, -u1 * px);
+        acc[24] += w * -u0; acc[25] += w * -u1; acc[26] += w * -u2;
         acc[27] += robust_error<LOSS>(rn, P.scale);
         ++cnt;
     }
@@ -949,6 +970,8 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
 #define SP_LAUNCH_FUSED(L)                                                              \
     if (!(g_fused_stage_mask & 1)) {}                                                   \
+    else if (g_fused_stage_mask & 4) gicp_fused_kernel<LOSS_NONE, true, 1><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (g_fused_stage_mask & 8) gicp_fused_kernel<LOSS_NONE, true, 2><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else gicp_fused_kernel<L, false><<<grid, kBlock, 0, st>>>(P, partials)
     switch (params->robust_type) {
