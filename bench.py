@@ -197,7 +197,7 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
     """Average launch duration of the hot kernel(s) over ONE ALIGNMENT (20 poses, from the identity guess to
     convergence), measured with HIP events recorded on the stream the kernels are launched on (the C ABI is handed
     torch's current stream). For the fused path the second launch (partial sums + solve) is masked off while the first
-    is being timed, so the figure is the duration of `gicp_fused_kernel` alone, the number rocprofv3 reports."""
+    is being timed, so the figure is the duration of the per-iteration kernel alone, the number rocprofv3 reports."""
     L = _lib.lib()
     res = {}
     scale = reg.params.robust_default_scale
@@ -216,31 +216,49 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
         fp = reg._factor_params(scale)
         gn = _lib.GnParams(reg.params.gn_lambda, 0.0, 0.0)
 
-        def launch(gnp):
-            _lib.check(L.sp_gicp_iteration_fused(prep._h, reg._psrc._h, sp._ptr(T_dev), 1, C.byref(fp), gnp, None, None,
-                                                 sp._ptr(lin), sp._ptr(delta), sp._ptr(ws), ws.numel(), sp._stream()))
+        iters_dev = torch.zeros(1, dtype=torch.int32, device=S.points.device)
 
-        T_dev.copy_(T_ident)
+        def align_launches():
+            T_dev.copy_(T_ident)
+            _lib.check(L.sp_gicp_align_fused(prep._h, reg._psrc._h, sp._ptr(T_dev), C.byref(fp), C.byref(gn),
+                                             ITERS_PER_ALIGN, None, None, sp._ptr(lin), sp._ptr(delta), sp._ptr(iters_dev),
+                                             sp._ptr(ws), ws.numel(), sp._stream()))
+
         reg.align_fused_loop(S, prep, iterations=0, T_dev=T_dev, delta_dev=delta, prepare=True)
-        total = 0.0
-        for _ in range(ITERS_PER_ALIGN):
-            L.sp_debug_set_fused_stage_mask(1)
-            launch(None)
+        align_launches()
+        torch.cuda.synchronize()
+        # (a) the 20 per-iteration launches of one alignment, back to back, without the finish kernel: every launch
+        #     after the first starts from the pose the previous one's partial sums give, exactly as in the timed loop
+        L.sp_debug_set_fused_stage_mask(1)
+        T_dev.copy_(T_ident)
+        torch.cuda.synchronize()
+        reps_a = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(reps_a):
+            T_dev.copy_(T_ident)
+            e0.record()
+            _lib.check(L.sp_gicp_align_fused(prep._h, reg._psrc._h, sp._ptr(T_dev), C.byref(fp), C.byref(gn),
+                                             ITERS_PER_ALIGN, None, None, sp._ptr(lin), sp._ptr(delta), sp._ptr(iters_dev),
+                                             sp._ptr(ws), ws.numel(), sp._stream()))
+            e1.record()
             torch.cuda.synchronize()
-            total += timed(lambda: launch(None))   # gicp_fused_kernel only, at this iteration's pose
-            L.sp_debug_set_fused_stage_mask(3)
-            launch(C.byref(gn))                    # the real iteration: advances the pose
-        torch.cuda.synchronize()
-        ms = total / ITERS_PER_ALIGN
-        res["gicp_fused_kernel"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9,
-                                    "note": "NN(k=1) + linearise + workgroup reduction; mean over the 20 poses of an alignment"}
+            tot += e0.elapsed_time(e1)
+        ms = tot / reps_a / ITERS_PER_ALIGN
+        res["gicp_align_kernel"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9,
+                                    "note": "per-iteration launch: sum of the previous launch's partial rows + 6x6 solve + "
+                                            "pose update (prologue), then NN(k=1) + linearise + workgroup reduction; mean "
+                                            "over the 20 launches of an alignment started at the identity"}
+        # (b) the finish kernel alone
         L.sp_debug_set_fused_stage_mask(2)
-        launch(C.byref(gn))
+        align_launches()
         torch.cuda.synchronize()
-        ms2 = timed(lambda: launch(C.byref(gn)))
+        ms2 = timed(align_launches)
         L.sp_debug_set_fused_stage_mask(3)
-        res["final_reduce_kernel"] = {"ms": ms2, "bytes": 1024 * 128, "GBps": 1024 * 128 / (ms2 * 1e-3) / 1e9,
-                                      "note": "fixed-order sum of <=1024 partials + 6x6 solve + pose update (latency-bound)"}
+        res["align_finish_kernel"] = {"ms": ms2, "bytes": 256 * 128, "GBps": 256 * 128 / (ms2 * 1e-3) / 1e9,
+                                      "per_iteration": False,
+                                      "note": "once per alignment (incl. a 64-byte pose copy): last iteration's partial "
+                                              "sums + solve + outputs"}
         ms3 = timed(lambda: reg._psrc.prepare(prep, S, T_ident, True))
         res["source_prepare"] = {"ms": ms3, "bytes": 112 * n, "GBps": 112 * n / (ms3 * 1e-3) / 1e9, "per_iteration": False,
                                  "note": "once per alignment: cell-order sort + gather + plane-regularised covariances"}

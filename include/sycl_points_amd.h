@@ -235,10 +235,26 @@ int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* 
                             int transT_on_device, const sp_factor_params* params, const sp_gn_params* gn,
                             int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* out, float* delta_out8,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Registration::align's whole Gauss-Newton loop (registration.hpp:229-276) enqueued by ONE call, one kernel launch per
+ * iteration plus one at the end: launch k first finishes iteration k-1 (every workgroup sums the previous launch's
+ * partial rows in the same fixed order and solves the same 6x6 system, T <- T * se3_exp(delta)), then linearises at the
+ * new pose. Once is_converged() (registration.hpp:407-410) holds, the remaining launches return at once, as the
+ * reference breaks out of its loop. All pointers are device memory:
+ *   transT_device  in: initial guess, out: final pose (column-major 4x4)
+ *   lin_out        system of the last executed iteration (optional)
+ *   delta_out8     its delta[6], converged flag, solve-ok flag (optional)
+ *   iterations_out number of Gauss-Newton steps applied (optional); the reference's result.iterations is this - 1
+ *   nn_idx_out / nn_d2_out: neighbours of the last linearisation, in original source order (optional, both or none)
+ * Workspace: sp_gicp_workspace_bytes(n). Nothing is read back by the host; graph-capturable. */
+int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                        const sp_factor_params* params, const sp_gn_params* gn, int max_iterations,
+                        int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
+                        uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream);
 /* Tuning hook, not part of the stable surface: NN walk used inside the fused kernel
  * (-1 automatic: 2x2x2 fast path iff the source is cell-sorted; 0 ring walk; 1 fast path). */
 void sp_debug_set_fused_fast_nn(int mode);
-/* Measurement hook: launches issued by sp_gicp_iteration_fused (bit 0 = fused kernel, bit 1 = final reduce + solve). */
+/* Measurement hook: launches issued by sp_gicp_iteration_fused / sp_gicp_align_fused (bit 0 = per-iteration kernel,
+ * bit 1 = final reduce + solve / finish kernel). */
 void sp_debug_set_fused_stage_mask(int mask);
 /* Tuning hook: self-kNN kernel (0 wave-cooperative, default; 1 lane-per-query tile kernel for k <= 10). */
 void sp_debug_set_self_knn_mode(int mode);

@@ -20,7 +20,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
-KERNELS = {"gicp_fused_kernel": "gicp_fused_kernel", "final_reduce_kernel": "final_reduce_kernel",
+KERNELS = {"gicp_align_kernel": "gicp_align_kernel", "align_finish_kernel": "align_finish_kernel",
+           "gicp_fused_kernel": "gicp_fused_kernel", "final_reduce_kernel": "final_reduce_kernel",
            "prepare_cov_kernel": "prepare_cov_kernel"}
 
 

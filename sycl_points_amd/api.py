@@ -747,10 +747,13 @@ class Registration:
 
     def align_fused_loop(self, source, prepared_target, initial_guess=None, iterations=None, robust_scale=-1.0,
                          group=None, T_dev=None, delta_dev=None, prepare=True, sort_by_cell=True,
-                         write_neighbors=False):
+                         write_neighbors=False, per_iteration_launches=False):
         """The same fixed-length Gauss-Newton loop as align_device_loop on the prepared / fused path
         (sp_gicp_iteration_fused): one launch per iteration does NN + linearise + reduce, and, on a single GPU, the
-        second (one-workgroup) launch also solves and updates the pose. With prepare=True (a new alignment) the
+        second (one-workgroup) launch also solves and updates the pose. On one GPU the default is
+        sp_gicp_align_fused: the reduction + solve of iteration k-1 runs as the prologue of launch k, and once the
+        convergence criteria hold the remaining launches return immediately (self._iters_dev holds the number of
+        steps applied); per_iteration_launches=True keeps the two-launch fixed-length form. With prepare=True (a new alignment) the
         per-alignment preparation — plane regularisation of both clouds' covariances and the cell-order sort of the
         source at the initial pose — is enqueued first."""
         import torch.distributed as dist
@@ -782,6 +785,14 @@ class Registration:
             self.neighbors.resize(n, 1, dev)
         ni = _ptr(self.neighbors.indices) if write_neighbors else None
         nd = _ptr(self.neighbors.distances) if write_neighbors else None
+        if not sharded and not per_iteration_launches:
+            # one C call enqueues the whole loop: one launch per iteration (+ one to finish), convergence on the device
+            if getattr(self, "_iters_dev", None) is None or self._iters_dev.device != dev:
+                self._iters_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            check(L.sp_gicp_align_fused(prepared_target._h, self._psrc._h, _ptr(T_dev), C.byref(fp), C.byref(gn), iters,
+                                        ni, nd, _ptr(lin), _ptr(delta_dev), _ptr(self._iters_dev), _ptr(ws), ws.numel(),
+                                        _stream()))
+            return T_dev, lin, delta_dev
         for _ in range(iters):
             check(L.sp_gicp_iteration_fused(prepared_target._h, self._psrc._h, _ptr(T_dev), 1, C.byref(fp),
                                             None if sharded else C.byref(gn), ni, nd, _ptr(lin), _ptr(delta_dev),

@@ -84,11 +84,15 @@ struct Nearest {
     float x, y, z;  // its coordinates
 };
 
+// `seed` (optional) is an upper bound found earlier — every cell of the rings r < r_start must already have been
+// searched (or be provably unable to beat the seed).
 __device__ __forceinline__ Nearest grid_nn1(const float4* __restrict__ pts, const unsigned* __restrict__ start,
-                                            const GridDesc& g, float qx, float qy, float qz) {
+                                            const GridDesc& g, float qx, float qy, float qz,
+                                            const Nearest* seed = nullptr, int r_start = 0) {
     Nearest best;
     best.d2 = FLT_MAX; best.idx = -1; best.pos = 0; best.x = best.y = best.z = 0.0f;
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return best;
+    if (seed) best = *seed;
     const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny),
               cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
     const int rmax = max(max(g.nx, g.ny), g.nz);
@@ -99,7 +103,7 @@ __device__ __forceinline__ Nearest grid_nn1(const float4* __restrict__ pts, cons
             best.d2 = d; best.idx = pi; best.pos = pos; best.x = p.x; best.y = p.y; best.z = p.z;
         }
     };
-    for (int r = 0; r <= rmax; ++r) {
+    for (int r = r_start; r <= rmax; ++r) {
         const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
@@ -212,11 +216,99 @@ __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, co
     return best.d2 < cov * cov;  // strict: an unseen point at exactly this distance could win a tie
 }
 
+// Second stage for k = 1: a block of 4 cells per axis around the query (own cell, one more on the farther side, two
+// on the nearer side: every face of the block is >= 1.5 h away), searched as two groups of 8 x-rows. A row is skipped
+// when its (y,z) box distance exceeds the current best, and its x-range is trimmed to the cells the ball of radius
+// sqrt(best) can reach; the surviving extents are fetched as one batch of independent loads, then all candidates in
+// batches of BATCH (same flattening as the first stage). `best` must hold a valid upper bound or {FLT_MAX, -1}.
+template <int BATCH>
+__device__ __forceinline__ void grid_scan_rows8(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                const GridDesc& g, float qx, float qy, float qz, int xlo, int xhi,
+                                                int ylo, int zA, int zB, Nearest& best) {
+    unsigned off[8], c[9];
+    c[0] = 0;
+    const float fxq = (qx - g.ox) * g.inv_h;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int y = ylo + (r & 3), z = (r & 4) ? zB : zA;
+        bool ok = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+        const int yc = min(max(y, 0), g.ny - 1), zc = min(max(z, 0), g.nz - 1);
+        const float dyz2 = gap2(qz, g.oz + zc * g.h, g.oz + (zc + 1) * g.h, g.eps) +
+                           gap2(qy, g.oy + yc * g.h, g.oy + (yc + 1) * g.h, g.eps);
+        ok = ok && !(dyz2 > best.d2);
+        // cells of this row that the ball can reach: |x - qx| <= rad, widened by 2 eps for the rounding of the cell
+        // assignment and of this expression
+        const float rad = (sqrtf(fmaxf(best.d2 - dyz2, 0.0f)) * 1.000001f + 2.0f * g.eps) * g.inv_h;
+        const int xa = max(xlo, (int)fmaxf(floorf(fxq - rad), (float)xlo));
+        const int xb = min(xhi, (int)fminf(floorf(fxq + rad), (float)xhi));
+        ok = ok && xa <= xb;
+        const unsigned row = ((unsigned)zc * g.ny + yc) * g.nx;
+        unsigned s0 = 0, e0 = 0;
+        if (ok) { s0 = start[row + xa]; e0 = start[row + xb + 1]; }
+        off[r] = s0 - c[r];
+        c[r + 1] = c[r] + (e0 - s0);
+    }
+    const unsigned total = c[8];
+    for (unsigned base = 0; base < total; base += BATCH) {
+        float4 cand[BATCH];
+        unsigned cpos[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const unsigned jj = min(base + j, total - 1);
+            unsigned pos = off[0] + jj;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) pos = (jj >= c[r]) ? off[r] + jj : pos;
+            cpos[j] = pos;
+            cand[j] = pts[pos];
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const float d = dist2(qx, qy, qz, cand[j].x, cand[j].y, cand[j].z);
+            const int pi = __float_as_int(cand[j].w);
+            const bool valid = base + j < total;
+            if (valid && (d < best.d2 || (d == best.d2 && pi < best.idx))) {
+                best.d2 = d; best.idx = pi; best.pos = cpos[j]; best.x = cand[j].x; best.y = cand[j].y; best.z = cand[j].z;
+            }
+        }
+    }
+}
+
+// Returns true when `best` is proven exact after the 4x4x4 block.
+__device__ __forceinline__ bool grid_nn1_block4(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                const GridDesc& g, float qx, float qy, float qz, Nearest& best) {
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    const int cx = (int)fminf(fmaxf(floorf(fx), 0.0f), (float)(g.nx - 1));
+    const int cy = (int)fminf(fmaxf(floorf(fy), 0.0f), (float)(g.ny - 1));
+    const int cz = (int)fminf(fmaxf(floorf(fz), 0.0f), (float)(g.nz - 1));
+    const int ux = (fx - (float)cx < 0.5f) ? 0 : 1, uy = (fy - (float)cy < 0.5f) ? 0 : 1,
+              uz = (fz - (float)cz < 0.5f) ? 0 : 1;
+    const int xlo = max(cx - 2 + ux, 0), xhi = min(cx + 1 + ux, g.nx - 1);
+    const int ylo = cy - 2 + uy, zlo = cz - 2 + uz;  // rows outside the grid are skipped inside
+    // nearer two z-layers first (they tighten the bound for the outer two)
+    grid_scan_rows8<4>(pts, start, g, qx, qy, qz, xlo, xhi, ylo, zlo + 1, zlo + 2, best);
+    grid_scan_rows8<4>(pts, start, g, qx, qy, qz, xlo, xhi, ylo, zlo, zlo + 3, best);
+    const int yhi = min(ylo + 3, g.ny - 1), zhi = min(zlo + 3, g.nz - 1);
+    const int ya = max(ylo, 0), za = max(zlo, 0);
+    float cov = FLT_MAX;
+    if (xlo > 0) cov = fminf(cov, qx - (g.ox + xlo * g.h));
+    if (xhi < g.nx - 1) cov = fminf(cov, (g.ox + (xhi + 1) * g.h) - qx);
+    if (ya > 0) cov = fminf(cov, qy - (g.oy + ya * g.h));
+    if (yhi < g.ny - 1) cov = fminf(cov, (g.oy + (yhi + 1) * g.h) - qy);
+    if (za > 0) cov = fminf(cov, qz - (g.oz + za * g.h));
+    if (zhi < g.nz - 1) cov = fminf(cov, (g.oz + (zhi + 1) * g.h) - qz);
+    if (cov == FLT_MAX) return true;
+    cov = fmaxf(cov - g.eps, 0.0f);
+    return best.d2 < cov * cov;
+}
+
 __device__ __forceinline__ Nearest grid_nn1_auto(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                  const GridDesc& g, float qx, float qy, float qz) {
     Nearest best;
-    if (!grid_nn1_fast(pts, start, g, qx, qy, qz, best)) best = grid_nn1(pts, start, g, qx, qy, qz);
-    return best;
+    if (grid_nn1_fast(pts, start, g, qx, qy, qz, best)) return best;
+    if (grid_nn1_block4(pts, start, g, qx, qy, qz, best)) return best;
+    // the block covers the rings r <= 1 of the own cell completely
+    const Nearest seed = best;
+    return grid_nn1(pts, start, g, qx, qy, qz, &seed, 2);
 }
 
 }  // namespace sp

@@ -247,9 +247,9 @@ struct KParams {
 };
 
 // Sum NV lane values over the workgroup in a fixed order and let lane e < NV of wave 0 write partial[e].
-template <int NV>
+template <int NV, int BLOCK = kBlock>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cnt, float* __restrict__ partial) {
-    __shared__ float red[kBlock / kWave][kPartial];
+    __shared__ float red[BLOCK / kWave][kPartial];
     const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int e = 0; e < NV; ++e) acc[e] = wave_sum(acc[e]);
@@ -263,12 +263,12 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cn
     if (threadIdx.x < NV) {
         float s = 0.0f;
 #pragma unroll
-        for (int w = 0; w < kBlock / kWave; ++w) s += red[w][threadIdx.x];
+        for (int w = 0; w < BLOCK / kWave; ++w) s += red[w][threadIdx.x];
         partial[threadIdx.x] = s;
     } else if (threadIdx.x == NV) {
         unsigned c = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / kWave; ++w) c += __float_as_uint(red[w][NV]);
+        for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][NV]);
         partial[NV] = __uint_as_float(c);
     }
 }
@@ -347,15 +347,15 @@ struct GnArgs {  // optional fused Gauss-Newton step (single-GPU loops): T == nu
 __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, float lambda, float crit_rot,
                                                float crit_trans, float* delta_out8, bool fold_inlier, LdltScratch& w);
 
-__global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float* __restrict__ partials,
-                                                                     unsigned nblocks, int nv,
-                                                                     sp_linearized* __restrict__ out, GnArgs gn) {
-    __shared__ float red[kFinalThreads / 32][kPartial];
-    __shared__ LdltScratch ldlt_ws;
+// Sum `rows` partial rows with a 1024-lane workgroup in a fixed order: lane = (part, slot); the 32 parts cover
+// contiguous row ranges (independent loads, added in row order), then lanes 0..31 add the 32 parts in order.
+// On return (after a barrier) red[0][e] holds the totals; slot nv is the uint32 count.
+__device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ partials, unsigned rows, int nv,
+                                                 float (*red)[kPartial]) {
     constexpr unsigned kParts = kFinalThreads / 32;
     const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const unsigned per = (nblocks + kParts - 1) / kParts;
-    const unsigned lo = part * per, hi = min(nblocks, lo + per);
+    const unsigned per = (rows + kParts - 1) / kParts;
+    const unsigned lo = part * per, hi = min(rows, lo + per);
     float s = 0.0f;
     unsigned c = 0;
     const bool is_count = ((int)e == nv);
@@ -377,24 +377,37 @@ __global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float
         red[0][e] = is_count ? __uint_as_float(ct) : t;
     }
     __syncthreads();
+}
+
+// totals (21 upper-triangle H, 6 b, error | error only) + count -> sp_linearized
+__device__ __forceinline__ void unpack_totals(const float* tot, int nv, sp_linearized* out) {
+    if (nv == kAcc - 1) {
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int cc = a; cc < 6; ++cc) {
+                const float v = tot[k++];
+                out->H[a * 6 + cc] = v;
+                out->H[cc * 6 + a] = v;
+            }
+        for (int a = 0; a < 6; ++a) out->b[a] = tot[21 + a];
+        out->error = tot[27];
+    } else {
+        out->error = tot[0];
+    }
+    const unsigned cnt = __float_as_uint(tot[nv]);
+    out->inlier = cnt;
+    out->inlier_lo = (float)(cnt & 4095u);
+    out->inlier_hi = (float)(cnt >> 12);
+}
+
+__global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float* __restrict__ partials,
+                                                                     unsigned nblocks, int nv,
+                                                                     sp_linearized* __restrict__ out, GnArgs gn) {
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ LdltScratch ldlt_ws;
+    reduce_rows_1024(partials, nblocks, nv, red);
     if (threadIdx.x == 0) {
-        if (nv == kAcc - 1) {
-            int k = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int cc = a; cc < 6; ++cc) {
-                    const float v = red[0][k++];
-                    out->H[a * 6 + cc] = v;
-                    out->H[cc * 6 + a] = v;
-                }
-            for (int a = 0; a < 6; ++a) out->b[a] = red[0][21 + a];
-            out->error = red[0][27];
-        } else {
-            out->error = red[0][0];
-        }
-        const unsigned cnt = __float_as_uint(red[0][nv]);
-        out->inlier = cnt;
-        out->inlier_lo = (float)(cnt & 4095u);
-        out->inlier_hi = (float)(cnt >> 12);
+        unpack_totals(red[0], nv, out);
         if (gn.T) gn_update_impl(out, gn.T, gn.lambda, gn.crit_rot, gn.crit_trans, gn.delta_out8, false, ldlt_ws);
     }
 }
@@ -529,6 +542,91 @@ struct FusedParams {
     float* nn_d2;
 };
 
+// One source point of the fused iteration: q = T p -> exact NN on the target grid -> linearise -> accumulate.
+template <int LOSS, bool FAST_NN, int DBG>
+__device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
+                                            unsigned& cnt) {
+    const float4 s = P.src[i];
+    float qx, qy, qz;
+    transform_point(T, s.x, s.y, s.z, qx, qy, qz);
+    Nearest nn;
+    if (DBG == 2) {  // timing experiment: no search, a nearby fake winner
+        nn.pos = min(i, P.g.n - 1); const float4 tp = P.tpts[nn.pos];
+        nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = (int)nn.pos; nn.d2 = 0.0f;
+    } else {
+        if (DBG == 3) {  // timing experiment: 2x2x2 block, then the unseeded ring walk
+            if (!grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn)) nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+        } else
+        nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+    }
+    if (DBG == 1 || DBG == 3) { acc[27] += nn.d2 + nn.x; ++cnt; return; }  // timing experiment: search only
+    if (P.nn_idx) {
+        const unsigned o = P.perm[i];
+        P.nn_idx[o] = nn.idx;
+        P.nn_d2[o] = nn.d2;
+    }
+    if (nn.idx < 0 || nn.d2 > P.max_d2) return;
+    const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
+    const Sym3 Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
+    const float r0 = nn.x - qx, r1 = nn.y - qy, r2 = nn.z - qz;
+    // Source-frame form of factor.hpp:239-278. With S = skew(p), J = [R S | -R] and M = (Ct' + R Cs' R^T)^-1:
+    //   N := R^T M R = (Cs' + R^T Ct' R)^-1,  v := R^T r,  u := N v,  G := S N
+    //   H = [[-G S, G], [G^T, N]],   b = [u x p, -u],   e = v . u
+    // (same mathematics as J^T M J / J^T M r, about half the multiply-adds).
+    const float (&R)[3][3] = T.R;
+    float W[3][3];  // W = Ct' R
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        W[0][j] = chain3(Ct.xx, R[0][j], Ct.xy, R[1][j], Ct.xz, R[2][j]);
+        W[1][j] = chain3(Ct.xy, R[0][j], Ct.yy, R[1][j], Ct.yz, R[2][j]);
+        W[2][j] = chain3(Ct.xz, R[0][j], Ct.yz, R[1][j], Ct.zz, R[2][j]);
+    }
+    Mat3 A;  // Cs' + R^T Ct' R (symmetric)
+    A.m[0][0] = chain3(R[0][0], W[0][0], R[1][0], W[1][0], R[2][0], W[2][0]) + Cs.xx;
+    A.m[0][1] = chain3(R[0][0], W[0][1], R[1][0], W[1][1], R[2][0], W[2][1]) + Cs.xy;
+    A.m[0][2] = chain3(R[0][0], W[0][2], R[1][0], W[1][2], R[2][0], W[2][2]) + Cs.xz;
+    A.m[1][1] = chain3(R[0][1], W[0][1], R[1][1], W[1][1], R[2][1], W[2][1]) + Cs.yy;
+    A.m[1][2] = chain3(R[0][1], W[0][2], R[1][1], W[1][2], R[2][1], W[2][2]) + Cs.yz;
+    A.m[2][2] = chain3(R[0][2], W[0][2], R[1][2], W[1][2], R[2][2], W[2][2]) + Cs.zz;
+    // symmetric inverse by the adjugate; Zero when |det| < 1e-6 (eigen_utils::inverse, eigen_utils.hpp:403-423;
+    // det is invariant under the rotation)
+    const float c00 = fmaf(A.m[1][1], A.m[2][2], -A.m[1][2] * A.m[1][2]);
+    const float c01 = fmaf(A.m[0][2], A.m[1][2], -A.m[0][1] * A.m[2][2]);
+    const float c02 = fmaf(A.m[0][1], A.m[1][2], -A.m[0][2] * A.m[1][1]);
+    const float det = fmaf(A.m[0][0], c00, fmaf(A.m[0][1], c01, A.m[0][2] * c02));
+    const float inv_det = fabsf(det) < 1e-6f ? 0.0f : 1.0f / det;
+    const float n00 = c00 * inv_det, n01 = c01 * inv_det, n02 = c02 * inv_det;
+    const float n11 = fmaf(A.m[0][0], A.m[2][2], -A.m[0][2] * A.m[0][2]) * inv_det;
+    const float n12 = fmaf(A.m[0][1], A.m[0][2], -A.m[0][0] * A.m[1][2]) * inv_det;
+    const float n22 = fmaf(A.m[0][0], A.m[1][1], -A.m[0][1] * A.m[0][1]) * inv_det;
+    const float v0 = chain3(R[0][0], r0, R[1][0], r1, R[2][0], r2);
+    const float v1 = chain3(R[0][1], r0, R[1][1], r1, R[2][1], r2);
+    const float v2 = chain3(R[0][2], r0, R[1][2], r1, R[2][2], r2);
+    const float u0 = chain3(n00, v0, n01, v1, n02, v2);
+    const float u1 = chain3(n01, v0, n11, v1, n12, v2);
+    const float u2 = chain3(n02, v0, n12, v1, n22, v2);
+    const float sq = chain3(v0, u0, v1, u1, v2, u2);
+    const float rn = sqrtf(sq);
+    const float w = robust_weight<LOSS>(rn, P.scale);
+    const float px = s.x, py = s.y, pz = s.z;
+    // G = S N, rows: p x (columns of N)
+    const float g00 = fmaf(py, n02, -pz * n01), g01 = fmaf(py, n12, -pz * n11), g02 = fmaf(py, n22, -pz * n12);
+    const float g10 = fmaf(pz, n00, -px * n02), g11 = fmaf(pz, n01, -px * n12), g12 = fmaf(pz, n02, -px * n22);
+    const float g20 = fmaf(px, n01, -py * n00), g21 = fmaf(px, n11, -py * n01), g22 = fmaf(px, n12, -py * n02);
+    // H_rr = -G S (symmetric)
+    const float h00 = fmaf(g02, py, -g01 * pz), h01 = fmaf(g00, pz, -g02 * px), h02 = fmaf(g01, px, -g00 * py);
+    const float h11 = fmaf(g10, pz, -g12 * px), h12 = fmaf(g11, px, -g10 * py), h22 = fmaf(g21, px, -g20 * py);
+    acc[0] += w * h00; acc[1] += w * h01; acc[2] += w * h02; acc[3] += w * g00; acc[4] += w * g01; acc[5] += w * g02;
+    acc[6] += w * h11; acc[7] += w * h12; acc[8] += w * g10; acc[9] += w * g11; acc[10] += w * g12;
+    acc[11] += w * h22; acc[12] += w * g20; acc[13] += w * g21; acc[14] += w * g22;
+    acc[15] += w * n00; acc[16] += w * n01; acc[17] += w * n02; acc[18] += w * n11; acc[19] += w * n12; acc[20] += w * n22;
+    // b = [u x p, -u]
+    acc[21] += w * fmaf(u1, pz, -u2 * py); acc[22] += w * fmaf(u2, px, -u0 * pz); acc[23] += w * fmaf(u0, py, -u1 * px);
+    acc[24] += w * -u0; acc[25] += w * -u1; acc[26] += w * -u2;
+    acc[27] += robust_error<LOSS>(rn, P.scale);
+    ++cnt;
+}
+
 template <int LOSS, bool FAST_NN, int DBG = 0>
 __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float* __restrict__ partials) {
     const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
@@ -536,85 +634,144 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
 #pragma unroll
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
     unsigned cnt = 0;
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock) {
-        const float4 s = P.src[i];
-        float qx, qy, qz;
-        transform_point(T, s.x, s.y, s.z, qx, qy, qz);
-        Nearest nn;
-        if (DBG == 2) {  // timing experiment: no search, a nearby fake winner
-            nn.pos = min(i, P.g.n - 1); const float4 tp = P.tpts[nn.pos];
-            nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = (int)nn.pos; nn.d2 = 0.0f;
-        } else {
-            nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
-        }
-        if (DBG == 1) { acc[27] += nn.d2 + nn.x; ++cnt; continue; }  // timing experiment: search only
-        if (P.nn_idx) {
-            const unsigned o = P.perm[i];
-            P.nn_idx[o] = nn.idx;
-            P.nn_d2[o] = nn.d2;
-        }
-        if (nn.idx < 0 || nn.d2 > P.max_d2) continue;
-        const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
-        const Sym3 Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
-        const float r0 = nn.x - qx, r1 = nn.y - qy, r2 = nn.z - qz;
-        // Source-frame form of factor.hpp:239-278. With S = skew(p), J = [R S | -R] and M = (Ct' + R Cs' R^T)^-1:
-        //   N := R^T M R = (Cs' + R^T Ct' R)^-1,  v := R^T r,  u := N v,  G := S N
-        //   H = [[-G S, G], [G^T, N]],   b = [u x p, -u],   e = v . u
-        // (same mathematics as J^T M J / J^T M r, about half the multiply-adds).
-        const float (&R)[3][3] = T.R;
-        float W[3][3];  // W = Ct' R
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            W[0][j] = chain3(Ct.xx, R[0][j], Ct.xy, R[1][j], Ct.xz, R[2][j]);
-            W[1][j] = chain3(Ct.xy, R[0][j], Ct.yy, R[1][j], Ct.yz, R[2][j]);
-            W[2][j] = chain3(Ct.xz, R[0][j], Ct.yz, R[1][j], Ct.zz, R[2][j]);
-        }
-        Mat3 A;  // Cs' + R^T Ct' R (symmetric)
-        A.m[0][0] = chain3(R[0][0], W[0][0], R[1][0], W[1][0], R[2][0], W[2][0]) + Cs.xx;
-        A.m[0][1] = chain3(R[0][0], W[0][1], R[1][0], W[1][1], R[2][0], W[2][1]) + Cs.xy;
-        A.m[0][2] = chain3(R[0][0], W[0][2], R[1][0], W[1][2], R[2][0], W[2][2]) + Cs.xz;
-        A.m[1][1] = chain3(R[0][1], W[0][1], R[1][1], W[1][1], R[2][1], W[2][1]) + Cs.yy;
-        A.m[1][2] = chain3(R[0][1], W[0][2], R[1][1], W[1][2], R[2][1], W[2][2]) + Cs.yz;
-        A.m[2][2] = chain3(R[0][2], W[0][2], R[1][2], W[1][2], R[2][2], W[2][2]) + Cs.zz;
-        // symmetric inverse by the adjugate; Zero when |det| < 1e-6 (eigen_utils::inverse, eigen_utils.hpp:403-423;
-        // det is invariant under the rotation)
-        const float c00 = fmaf(A.m[1][1], A.m[2][2], -A.m[1][2] * A.m[1][2]);
-        const float c01 = fmaf(A.m[0][2], A.m[1][2], -A.m[0][1] * A.m[2][2]);
-        const float c02 = fmaf(A.m[0][1], A.m[1][2], -A.m[0][2] * A.m[1][1]);
-        const float det = fmaf(A.m[0][0], c00, fmaf(A.m[0][1], c01, A.m[0][2] * c02));
-        const float inv_det = fabsf(det) < 1e-6f ? 0.0f : 1.0f / det;
-        const float n00 = c00 * inv_det, n01 = c01 * inv_det, n02 = c02 * inv_det;
-        const float n11 = fmaf(A.m[0][0], A.m[2][2], -A.m[0][2] * A.m[0][2]) * inv_det;
-        const float n12 = fmaf(A.m[0][1], A.m[0][2], -A.m[0][0] * A.m[1][2]) * inv_det;
-        const float n22 = fmaf(A.m[0][0], A.m[1][1], -A.m[0][1] * A.m[0][1]) * inv_det;
-        const float v0 = chain3(R[0][0], r0, R[1][0], r1, R[2][0], r2);
-        const float v1 = chain3(R[0][1], r0, R[1][1], r1, R[2][1], r2);
-        const float v2 = chain3(R[0][2], r0, R[1][2], r1, R[2][2], r2);
-        const float u0 = chain3(n00, v0, n01, v1, n02, v2);
-        const float u1 = chain3(n01, v0, n11, v1, n12, v2);
-        const float u2 = chain3(n02, v0, n12, v1, n22, v2);
-        const float sq = chain3(v0, u0, v1, u1, v2, u2);
-        const float rn = sqrtf(sq);
-        const float w = robust_weight<LOSS>(rn, P.scale);
-        const float px = s.x, py = s.y, pz = s.z;
-        // G = S N, rows: p x (columns of N)
-        const float g00 = fmaf(py, n02, -pz * n01), g01 = fmaf(py, n12, -pz * n11), g02 = fmaf(py, n22, -pz * n12);
-        const float g10 = fmaf(pz, n00, -px * n02), g11 = fmaf(pz, n01, -px * n12), g12 = fmaf(pz, n02, -px * n22);
-        const float g20 = fmaf(px, n01, -py * n00), g21 = fmaf(px, n11, -py * n01), g22 = fmaf(px, n12, -py * n02);
-        // H_rr = -G S (symmetric)
-        const float h00 = fmaf(g02, py, -g01 * pz), h01 = fmaf(g00, pz, -g02 * px), h02 = fmaf(g01, px, -g00 * py);
-        const float h11 = fmaf(g10, pz, -g12 * px), h12 = fmaf(g11, px, -g10 * py), h22 = fmaf(g21, px, -g20 * py);
-        acc[0] += w * h00; acc[1] += w * h01; acc[2] += w * h02; acc[3] += w * g00; acc[4] += w * g01; acc[5] += w * g02;
-        acc[6] += w * h11; acc[7] += w * h12; acc[8] += w * g10; acc[9] += w * g11; acc[10] += w * g12;
-        acc[11] += w * h22; acc[12] += w * g20; acc[13] += w * g21; acc[14] += w * g22;
-        acc[15] += w * n00; acc[16] += w * n01; acc[17] += w * n02; acc[18] += w * n11; acc[19] += w * n12; acc[20] += w * n22;
-        // b = [u x p, -u]
-        acc[21] += w * fmaf(u1, pz, -u2 * py); acc[22] += w * fmaf(u2, px, -u0 * pz); acc[23] += w * fmaf(u0, py, -u1 * px);
-        acc[24] += w * -u0; acc[25] += w * -u1; acc[26] += w * -u2;
-        acc[27] += robust_error<LOSS>(rn, P.scale);
-        ++cnt;
-    }
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock)
+        fused_point<LOSS, FAST_NN, DBG>(P, T, i, acc, cnt);
     block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Whole alignment on the device (Registration::align's Gauss-Newton loop, registration.hpp:229-276, one launch per
+// iteration and no second kernel in between): launch k first finishes iteration k-1 — EVERY workgroup sums the
+// previous launch's <= 256 partial rows (32 KB, L2-resident, fixed order) and solves the same 6x6 system, so all of
+// them hold the identical new pose without a grid-wide synchronisation — and then linearises at that pose.
+// Partials and the small state block ping-pong between launches; workgroup 0 publishes state / system / delta.
+// Once is_converged() holds, the remaining launches return immediately (the reference breaks out of its loop).
+constexpr int kAlignBlock = 1024;      // 16 waves: one workgroup per CU at 4 waves/SIMD -> 256 partial rows
+constexpr int kAlignMaxBlocks = 256;
+
+struct AlignState {
+    float T[16];
+    float delta[8];
+    unsigned converged;   // is_converged() held for the step that produced T
+    unsigned iterations;  // Gauss-Newton steps applied so far
+    unsigned pad[2];
+};
+
+struct AlignArgs {
+    const float* T_init;         // read by launch 0
+    const AlignState* state_in;  // launches k > 0
+    AlignState* state_out;
+    const float* prev_partials;
+    unsigned prev_rows;
+    int has_prev;
+    float lambda, crit_rot, crit_trans;
+    sp_linearized* lin_out;      // system of the last finished iteration (may be null)
+};
+
+// Finishes iteration k-1 (or loads the initial pose) and leaves the pose in sT (LDS). Returns false when this launch
+// has nothing more to do.
+__device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ sp_linearized slin;
+    __shared__ float sdelta[8];
+    __shared__ unsigned sconv;
+    __shared__ LdltScratch ldlt_ws;
+    if (A.has_prev) {
+        if (A.state_in->converged) {  // uniform over the grid
+            if (blockIdx.x == 0 && threadIdx.x == 0) *A.state_out = *A.state_in;
+            return false;
+        }
+        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red);
+        if (threadIdx.x == 0) {
+            unpack_totals(red[0], kAcc - 1, &slin);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sT[i] = A.state_in->T[i];
+            gn_update_impl(&slin, sT, A.lambda, A.crit_rot, A.crit_trans, sdelta, false, ldlt_ws);
+            sconv = sdelta[6] > 0.5f ? 1u : 0u;
+            if (blockIdx.x == 0) {
+                AlignState* so = A.state_out;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) so->T[i] = sT[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) so->delta[i] = sdelta[i];
+                so->converged = sconv;
+                so->iterations = A.state_in->iterations + 1;
+                if (A.lin_out) *A.lin_out = slin;
+            }
+        }
+        __syncthreads();
+        return sconv == 0;  // converged: no further linearisation (registration.hpp:266-268)
+    }
+    if (threadIdx.x < 16) sT[threadIdx.x] = A.T_init[threadIdx.x];
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        AlignState* so = A.state_out;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) so->T[i] = sT[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) so->delta[i] = 0.0f;
+        so->converged = 0;
+        so->iterations = 0;
+    }
+    return true;
+}
+
+template <int LOSS, bool FAST_NN>
+__global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, AlignArgs A,
+                                                                 float* __restrict__ partials) {
+    __shared__ float sT[16];
+    if (!align_prologue(A, sT)) return;
+    // the pose is uniform: move it to scalar registers (it would otherwise occupy 12 VGPRs for the whole loop)
+    Rigid T = load_rigid_colmajor(sT);
+    auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T.R[r][c] = uniform(T.R[r][c]);
+        T.t[r] = uniform(T.t[r]);
+    }
+    float acc[kAcc - 1];
+#pragma unroll
+    for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
+    unsigned cnt = 0;
+    for (unsigned i = blockIdx.x * kAlignBlock + threadIdx.x; i < P.n; i += gridDim.x * kAlignBlock)
+        fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt);
+    block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
+}
+
+// After the last launch: finish the last iteration (unless an earlier one converged) and publish the results.
+__global__ __launch_bounds__(kFinalThreads) void align_finish_kernel(const float* __restrict__ partials, unsigned rows,
+                                                                     const AlignState* __restrict__ state_in,
+                                                                     float lambda, float crit_rot, float crit_trans,
+                                                                     float* __restrict__ T_out,
+                                                                     sp_linearized* __restrict__ lin_out,
+                                                                     float* __restrict__ delta_out8,
+                                                                     uint32_t* __restrict__ iterations_out) {
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ sp_linearized slin;
+    __shared__ float sT[16];
+    __shared__ float sdelta[8];
+    __shared__ LdltScratch ldlt_ws;
+    const bool conv = state_in->converged != 0;
+    if (!conv) reduce_rows_1024(partials, rows, kAcc - 1, red);
+    if (threadIdx.x == 0) {
+        unsigned iters = state_in->iterations;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sT[i] = state_in->T[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sdelta[i] = state_in->delta[i];
+        if (!conv) {
+            unpack_totals(red[0], kAcc - 1, &slin);
+            gn_update_impl(&slin, sT, lambda, crit_rot, crit_trans, sdelta, false, ldlt_ws);
+            if (lin_out) *lin_out = slin;
+            ++iters;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T_out[i] = sT[i];
+        if (delta_out8)
+            for (int i = 0; i < 8; ++i) delta_out8[i] = sdelta[i];
+        if (iterations_out) *iterations_out = iters;
+    }
 }
 
 unsigned reduce_grid(size_t n) {
@@ -925,6 +1082,33 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
     return launch_status();
 }
 
+namespace sp {
+namespace {
+FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source* source, const sp_factor_params* params,
+                              const float* transT, int transT_on_device, int32_t* nn_idx_out, float* nn_d2_out) {
+    const size_t n = source->n;
+    FusedParams P;
+    P.src = source->pts;
+    P.scovp = source->covp;
+    P.tpts = target->grid->d_pts;
+    P.tstart = target->grid->d_start;
+    P.tcovp = target->covp;
+    P.g = grid_desc(target->grid);
+    P.n = (unsigned)n;
+    P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
+    P.scale = params->robust_scale;
+    for (int i = 0; i < 16; ++i) P.T_val.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    if (transT && !transT_on_device)
+        for (int i = 0; i < 16; ++i) P.T_val.m[i] = transT[i];
+    P.T_dev = transT_on_device ? transT : nullptr;
+    P.perm = source->perm;
+    P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
+    P.nn_d2 = nn_d2_out;
+    return P;
+}
+}  // namespace
+}  // namespace sp
+
 extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT,
                                        int transT_on_device, const sp_factor_params* params, const sp_gn_params* gn,
                                        int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* out, float* delta_out8,
@@ -946,23 +1130,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
     }
-    FusedParams P;
-    P.src = source->pts;
-    P.scovp = source->covp;
-    P.tpts = target->grid->d_pts;
-    P.tstart = target->grid->d_start;
-    P.tcovp = target->covp;
-    P.g = grid_desc(target->grid);
-    P.n = (unsigned)n;
-    P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
-    P.scale = params->robust_scale;
-    for (int i = 0; i < 16; ++i) P.T_val.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
-    if (transT && !transT_on_device)
-        for (int i = 0; i < 16; ++i) P.T_val.m[i] = transT[i];
-    P.T_dev = transT_on_device ? transT : nullptr;
-    P.perm = source->perm;
-    P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
-    P.nn_d2 = nn_d2_out;
+    const FusedParams P = make_fused_params(target, source, params, transT, transT_on_device, nn_idx_out, nn_d2_out);
     const unsigned grid = reduce_grid(n);
     float* partials = static_cast<float*>(workspace);
     // Unsorted lanes touch unrelated cells: the ring walk (fewest cache lines per query) wins. Cell-sorted lanes share
@@ -972,6 +1140,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     if (!(g_fused_stage_mask & 1)) {}                                                   \
     else if (g_fused_stage_mask & 4) gicp_fused_kernel<LOSS_NONE, true, 1><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (g_fused_stage_mask & 8) gicp_fused_kernel<LOSS_NONE, true, 2><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (g_fused_stage_mask & 16) gicp_fused_kernel<LOSS_NONE, true, 3><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else gicp_fused_kernel<L, false><<<grid, kBlock, 0, st>>>(P, partials)
     switch (params->robust_type) {
@@ -989,6 +1158,70 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     return launch_status();
 }
 // Measurement hook (not part of the stable surface): which of the two launches sp_gicp_iteration_fused issues.
+extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                                  const sp_factor_params* params, const sp_gn_params* gn, int max_iterations,
+                                  int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
+                                  uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (!target || !source || !params || !gn || !transT_device) return SP_ERR_INVALID_ARGUMENT;
+    if (params->reg_type != SP_REG_GICP) {
+        sp_set_error("[sp_gicp_align_fused] only RegType::GICP has a prepared/fused form");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    const size_t n = source->n;
+    if (n == 0 || max_iterations <= 0) {
+        if (lin_out && hipMemsetAsync(lin_out, 0, sizeof(sp_linearized), st) != hipSuccess) return SP_ERR_HIP;
+        if (delta_out8 && hipMemsetAsync(delta_out8, 0, 8 * sizeof(float), st) != hipSuccess) return SP_ERR_HIP;
+        if (iterations_out && hipMemsetAsync(iterations_out, 0, sizeof(uint32_t), st) != hipSuccess) return SP_ERR_HIP;
+        return SP_OK;
+    }
+    if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
+        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
+    // workspace: partial rows A | partial rows B | state A | state B
+    float* part[2] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + (size_t)kAlignMaxBlocks * kPartial};
+    AlignState* state = reinterpret_cast<AlignState*>(static_cast<float*>(workspace) + 2 * (size_t)kAlignMaxBlocks * kPartial);
+    unsigned grid = div_up(n, kAlignBlock);
+    if (grid > (unsigned)kAlignMaxBlocks) grid = kAlignMaxBlocks;
+    const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
+    for (int k = 0; k < max_iterations; ++k) {
+        AlignArgs A;
+        A.T_init = transT_device;
+        A.state_in = &state[(k + 1) & 1];
+        A.state_out = &state[k & 1];
+        A.prev_partials = part[(k + 1) & 1];
+        A.prev_rows = grid;
+        A.has_prev = k > 0;
+        A.lambda = gn->lambda;
+        A.crit_rot = gn->crit_rotation;
+        A.crit_trans = gn->crit_translation;
+        A.lin_out = lin_out;
+        float* out = part[k & 1];
+#define SP_LAUNCH_ALIGN(L)                                                                            \
+    if (!(g_fused_stage_mask & 1)) {}                                                                 \
+    else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);                   \
+    else gicp_align_kernel<L, false><<<grid, kAlignBlock, 0, st>>>(P, A, out)
+        switch (params->robust_type) {
+            case SP_LOSS_NONE: SP_LAUNCH_ALIGN(LOSS_NONE); break;
+            case SP_LOSS_HUBER: SP_LAUNCH_ALIGN(LOSS_HUBER); break;
+            case SP_LOSS_TUKEY: SP_LAUNCH_ALIGN(LOSS_TUKEY); break;
+            case SP_LOSS_CAUCHY: SP_LAUNCH_ALIGN(LOSS_CAUCHY); break;
+            case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_ALIGN(LOSS_GEMAN_MCCLURE); break;
+            default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
+        }
+#undef SP_LAUNCH_ALIGN
+    }
+    const int last = max_iterations - 1;
+    if (g_fused_stage_mask & 2)
+        align_finish_kernel<<<1, kFinalThreads, 0, st>>>(part[last & 1], grid, &state[last & 1], gn->lambda, gn->crit_rotation,
+                                                     gn->crit_translation, transT_device, lin_out, delta_out8,
+                                                     iterations_out);
+    return launch_status();
+}
+
 extern "C" void sp_debug_set_fused_stage_mask(int mask) { g_fused_stage_mask = mask; }
 // Tuning hook (not part of the stable surface): choose the NN walk used inside the fused kernel.
 extern "C" void sp_debug_set_fused_fast_nn(int mode) { g_fused_fast_nn = mode; }

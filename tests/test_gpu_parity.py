@@ -513,6 +513,22 @@ def test_grid_knn_edge_cases(sp, orc):
     assert int(r.indices[0, 0]) == 0 and abs(float(r.distances[0, 0]) - 3.0) < 1e-6
 
 
+@pytest.mark.parametrize("ppc", [0.02, 0.5, 4.0])
+def test_grid_nn1_staged_walk_far_queries(sp, orc, ppc):
+    # k = 1 goes 2x2x2 block -> batched 4x4x4 block -> seeded ring walk; queries far from every target point (between two
+    # clusters, outside the bounding box, very sparse grids) exercise the later stages. Bit-exact vs brute force.
+    g = orc.rng(91)
+    a = g.uniform_points(6000, 2.0)
+    b = g.uniform_points(6000, 2.0) + np.float32([9.0, 7.0, 5.0, 0.0])
+    tgt = np.concatenate([a, b])
+    qry = np.concatenate([g.uniform_points(3000, 14.0), g.uniform_points(1000, 2.0), a[:500] + np.float32([1e-3, 0, 0, 0])])
+    grid = sp.GridKNN.build(dev(tgt), points_per_cell=ppc)
+    r = grid.knn_search(dev(qry), 1)
+    oi, od = orc.knn_bruteforce(qry, tgt, 1)
+    assert np.array_equal(r.distances.cpu().numpy(), od)
+    assert np.array_equal(r.indices.cpu().numpy(), oi)
+
+
 def test_grid_knn_1m_matches_kdtree(sp, orc):
     from sycl_points_amd.synthetic import gicp_pair
 
@@ -591,6 +607,53 @@ def test_fused_loop_equals_generic_loop_and_oracle(sp, orc, gicp20k):
     assert np.abs(Tf - ref["T"]).max() < 1e-5
     assert reg._read_lin(lin).inlier == ref["inlier"]
     assert float(delta[7]) == 1.0
+
+
+@pytest.mark.parametrize("loss", ["NONE", "HUBER"])
+def test_align_fused_one_call_loop(sp, orc, gicp20k, loss):
+    """sp_gicp_align_fused (reduction + solve as the prologue of the next launch, convergence on the device) against
+    the two-launch fixed-length loop and the oracle, incl. the reference's early exit (registration.hpp:266-268)."""
+    from oracle.pyoracle import LOSS, RegParams
+
+    src, scov, tgt, tcov, T_gt = gicp20k
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    grid = sp.GridKNN.build(Tg.points)
+    prep = sp.PreparedTarget(grid, Tg.covs)
+    # fixed length (criteria 0): equals the per-iteration launches to rounding (different partial-row shape)
+    p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=8, robust_type=loss,
+                              robust_default_scale=0.5)
+    reg = sp.Registration(p)
+    T_dev, lin, delta = reg.align_fused_loop(S, prep, iterations=8, write_neighbors=True)
+    T_one = reg.T_from_device(T_dev)
+    assert int(reg._iters_dev[0]) == 8
+    nn_one = reg.neighbors.indices.clone()
+    reg2 = sp.Registration(p)
+    T_dev2, lin2, _ = reg2.align_fused_loop(S, prep, iterations=8, per_iteration_launches=True, write_neighbors=True)
+    assert np.abs(T_one - reg2.T_from_device(T_dev2)).max() < 2e-6
+    assert torch.equal(nn_one, reg2.neighbors.indices)
+    a, b = reg._read_lin(lin), reg2._read_lin(lin2)
+    assert a.inlier == b.inlier
+    Ha, Hb = np.array(a.H, np.float32), np.array(b.H, np.float32)
+    assert np.allclose(Ha, Hb, atol=2e-5 * np.abs(Hb).max())
+    ref = orc.registration_align(RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=8,
+                                                    robust_type=LOSS[loss], robust_default_scale=0.5), src, scov, tgt, tcov)
+    assert np.abs(T_one - ref["T"]).max() < 1e-5
+    # with criteria: the device loop stops where the reference's does, later launches are no-ops
+    pc = sp.RegistrationParams(criteria_translation=1e-4, criteria_rotation=1e-4, max_iterations=30, robust_type=loss,
+                               robust_default_scale=0.5)
+    regc = sp.Registration(pc)
+    T_devc, linc, deltac = regc.align_fused_loop(S, prep)
+    refc = orc.registration_align(RegParams.defaults(crit_translation=1e-4, crit_rotation=1e-4, max_iterations=30,
+                                                     robust_type=LOSS[loss], robust_default_scale=0.5), src, scov, tgt, tcov)
+    assert refc["converged"] and float(deltac[6]) == 1.0
+    assert int(regc._iters_dev[0]) == refc["iterations"] + 1  # result.iterations is the index of the last iteration
+    assert np.abs(regc.T_from_device(T_devc) - refc["T"]).max() < 1e-5
+    assert regc._read_lin(linc).inlier == refc["inlier"]
+    # max_iterations = 0: nothing changes
+    T0 = dev(np.eye(4, dtype=np.float32).reshape(-1))
+    regc.align_fused_loop(S, prep, iterations=0, T_dev=T0)
+    assert torch.equal(T0.cpu(), torch.eye(4).reshape(-1))
 
 
 # ------------------------------------------------------------------ tile self-kNN (+ fused covariance / normals)
