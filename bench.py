@@ -44,6 +44,9 @@ def parse():
                     help="fused: GridKNN + prepared covariances, NN+K11 in one kernel; generic: KNNBase search + K11")
     ap.add_argument("--nn", choices=["grid", "kdtree"], default="grid", help="KNNBase used by --path generic")
     ap.add_argument("--ppc", type=float, default=0.5, help="GridKNN points per cell for the in-loop k=1 search")
+    ap.add_argument("--source-order", choices=["grid", "random"], default="grid",
+                    help="grid: the source is stored in the cell order of a grid on itself (what voxel downsampling "
+                         "yields; done in set-up). random: as generated; every alignment then sorts it by target cell")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline workload")
     return ap.parse_args()
@@ -82,6 +85,11 @@ def main():
     Tg.covs = sp.GridKNN.build(Tg.points, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
     lo, hi = shard_range(n_total, rank, world)
     S_all = to_dev(src)
+    if args.source_order == "grid":
+        # The reference's pipeline hands align() a voxel-downsampled scan, i.e. a cloud sorted by voxel key
+        # (voxel_downsampling.hpp:146-288). The synthetic cloud is in random order, so it is put into the cell order of
+        # a grid built on itself here, in the untimed pre-processing next to its covariances; alignments then need no sort.
+        S_all = S_all[sp.GridKNN.build(S_all, points_per_cell=1.0).order()].contiguous()
     covs_all = sp.GridKNN.build(S_all, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
     S = sp.PointCloudShared(S_all[lo:hi].contiguous(), covs=covs_all[lo:hi].contiguous(), device=dev)
     del S_all, covs_all
@@ -92,6 +100,7 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
+    SORT_MODE = "presorted" if args.source_order == "grid" else True
     params = sp.RegistrationParams(reg_type="GICP", optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
                                    criteria_translation=0.0, criteria_rotation=0.0)
     reg = sp.Registration(params)
@@ -102,7 +111,8 @@ def main():
 
     def align_chunk(iters, first):
         if args.path == "fused":
-            reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta, prepare=first)
+            reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta, prepare=first,
+                                 sort_by_cell=SORT_MODE)
         else:
             reg.align_device_loop(S, Tg, knn, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta)
 
@@ -141,7 +151,7 @@ def main():
     pose_err = float(np.abs(T_final - T_gt).max())
 
     # ---- per-kernel durations over one alignment, by HIP events on the launch stream (rank 0's numbers are reported)
-    kern = kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n_local)
+    kern = kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n_local, SORT_MODE)
 
     if rank == 0:
         dom = max((k for k in kern if kern[k].get("per_iteration", True)), key=lambda k: kern[k]["ms"])
@@ -163,6 +173,8 @@ def main():
                                    f"max_corr 2.0, robust NONE, {ITERS_PER_ALIGN} iterations per alignment",
                        "source_points_per_gpu": n_gpu, "target_points": n_total, "path": args.path,
                        "nn": "grid(k=1)" if (args.path == "fused" or args.nn == "grid") else "kdtree(k=1)",
+                       "source_order": ("cell order of a grid on the source (set-up), no per-alignment sort"
+                                        if args.source_order == "grid" else "random; sorted by target cell in every alignment"),
                        "sharding": "source tile-sharded, target replicated" if world > 1 else "none"},
             "iterations_per_sec": args.steps / elapsed,
             "pose_max_abs_err_vs_ground_truth": pose_err,
@@ -193,7 +205,7 @@ def measured_traffic(kernel):
         return None
 
 
-def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n, reps=3):
+def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n, sort_mode, reps=3):
     """Average launch duration of the hot kernel(s) over ONE ALIGNMENT (20 poses, from the identity guess to
     convergence), measured with HIP events recorded on the stream the kernels are launched on (the C ABI is handed
     torch's current stream). For the fused path the second launch (partial sums + solve) is masked off while the first
@@ -224,7 +236,7 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
                                              ITERS_PER_ALIGN, None, None, sp._ptr(lin), sp._ptr(delta), sp._ptr(iters_dev),
                                              sp._ptr(ws), ws.numel(), sp._stream()))
 
-        reg.align_fused_loop(S, prep, iterations=0, T_dev=T_dev, delta_dev=delta, prepare=True)
+        reg.align_fused_loop(S, prep, iterations=0, T_dev=T_dev, delta_dev=delta, prepare=True, sort_by_cell=sort_mode)
         align_launches()
         torch.cuda.synchronize()
         # (a) the 20 per-iteration launches of one alignment, back to back, without the finish kernel: every launch
@@ -259,9 +271,10 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
                                       "per_iteration": False,
                                       "note": "once per alignment (incl. a 64-byte pose copy): last iteration's partial "
                                               "sums + solve + outputs"}
-        ms3 = timed(lambda: reg._psrc.prepare(prep, S, T_ident, True))
+        ms3 = timed(lambda: reg._psrc.prepare(prep, S, T_ident, sort_mode))
         res["source_prepare"] = {"ms": ms3, "bytes": 112 * n, "GBps": 112 * n / (ms3 * 1e-3) / 1e9, "per_iteration": False,
-                                 "note": "once per alignment: cell-order sort + gather + plane-regularised covariances"}
+                                 "note": "once per alignment: " + ("" if sort_mode == "presorted" else "cell-order sort + ") +
+                                         "gather + plane-regularised source covariances"}
     else:
         T_dev.copy_(T_ident)
         tot_nn = tot_k11 = 0.0

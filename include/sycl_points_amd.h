@@ -83,6 +83,11 @@ int sp_grid_create(const float* points, size_t n, float cell_size, float points_
 void sp_grid_destroy(sp_grid* grid);
 size_t sp_grid_size(const sp_grid* grid);
 float sp_grid_cell_size(const sp_grid* grid);
+/* idx_out[i] = original index of the i-th point in the grid's cell order (z-major, then y, then x; stable inside a cell).
+ * A cloud stored in this order (it is also the order VoxelGrid::downsampling produces, voxel_downsampling.hpp:146-288:
+ * sorted by voxel key) keeps neighbouring lanes on neighbouring cells of ANY grid it is later searched against, so
+ * sp_gicp_source_prepare can skip its per-alignment sort (SP_SOURCE_PRESORTED). */
+int sp_grid_order(const sp_grid* grid, uint32_t* idx_out, void* stream);
 int sp_grid_search(const sp_grid* grid, const float* queries, size_t nq, size_t k, const float* transT,
                    int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
 
@@ -208,9 +213,14 @@ int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn
  *                           (xx,xy,xz,yy | yz,zz,0,0) and stored in the cell order of `grid` (which must have been built
  *                           on the target points and must outlive the object); sp_gicp_target_update recomputes in place.
  *   sp_gicp_source_create : buffers for a prepared source of up to n_max points (allocates).
- *   sp_gicp_source_prepare: (enqueue only) packed plane-regularised source covariances and, when sort_by_cell != 0,
- *                           the source reordered by the target-grid cell that transT*p falls into, so that
- *                           consecutive lanes walk consecutive cells of a grid row (their loads share cache lines).
+ *   sp_gicp_source_prepare: (enqueue only) packed plane-regularised source covariances. sort_by_cell selects how
+ *                           neighbouring lanes get neighbouring cells (their loads then share cache lines):
+ *                             SP_SOURCE_ORDER_UNKNOWN (0) keep the caller's order, assume nothing (ring-walk search);
+ *                             SP_SOURCE_SORT (1) reorder by the target-grid cell that transT*p falls into
+ *                               (two Onesweep passes per alignment);
+ *                             SP_SOURCE_PRESORTED (2) keep the caller's order, which is already spatially coherent —
+ *                               sp_grid_order of any grid on the source, or the output order of voxel downsampling —
+ *                               no sort, block-walk search: the fastest combination.
  *                           The order only changes which lane handles which point, never a result.
  *   sp_gicp_iteration_fused: per source point q = T p -> exact NN on the grid -> linearise with the packed
  *                           covariances -> reduce to *out. If nn_idx_out/nn_d2_out are non-NULL the correspondences
@@ -223,6 +233,7 @@ int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn
 typedef struct sp_gicp_target sp_gicp_target;
 typedef struct sp_gicp_source sp_gicp_source;
 typedef struct sp_gn_params { float lambda, crit_rotation, crit_translation; } sp_gn_params;
+enum { SP_SOURCE_ORDER_UNKNOWN = 0, SP_SOURCE_SORT = 1, SP_SOURCE_PRESORTED = 2 };
 int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream, sp_gicp_target** out);
 int sp_gicp_target_update(sp_gicp_target* target, const float* tgt_covs, void* stream);
 void sp_gicp_target_destroy(sp_gicp_target* target);

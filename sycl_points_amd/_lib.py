@@ -57,6 +57,7 @@ SIGNATURES = {
     "sp_grid_create": (_i, [_vp, _sz, _f, _f, _vp, C.POINTER(_vp)]),
     "sp_grid_destroy": (None, [_vp]),
     "sp_grid_size": (_sz, [_vp]),
+    "sp_grid_order": (_i, [_vp, _vp, _vp]),
     "sp_grid_cell_size": (_f, [_vp]),
     "sp_grid_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
     "sp_grid_self_workspace_bytes": (_sz, [_vp]),

@@ -16,6 +16,9 @@ import torch
 from . import _lib
 from ._lib import FactorParams, GnParams, Linearized, SpError, check
 
+# sp_gicp_source_prepare's sort_by_cell: False keep order / True sort per alignment / "presorted" (GridKNN.order() or
+# voxel-downsampling output order): keep order, block-walk search
+_SOURCE_ORDER = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, "presorted": 2}
 REG = {"POINT_TO_POINT": 0, "POINT_TO_PLANE": 1, "POINT_TO_DISTRIBUTION": 2, "GICP": 3, "GENZ": 4}
 LOSS = {"NONE": 0, "HUBER": 1, "TUKEY": 2, "CAUCHY": 3, "GEMAN_MCCLURE": 4}
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -72,6 +75,13 @@ class PointCloudShared:
 
     def size(self):
         return int(self.points.shape[0])
+
+    def reordered(self, perm):
+        """A copy with every attribute gathered through `perm` (e.g. GridKNN.order())."""
+        g = lambda t: None if t is None else t[perm].contiguous()
+        return PointCloudShared(g(self.points), covs=g(self.covs), normals=g(self.normals), rgb=g(self.rgb),
+                                intensities=g(self.intensities), timestamp_offsets=g(self.timestamp_offsets),
+                                device=self.device)
 
     def has_cov(self):
         return self.covs is not None and self.covs.shape[0] == self.points.shape[0]
@@ -235,6 +245,13 @@ class GridKNN(KNNBase):
 
     def cell_size(self):
         return float(_lib.lib().sp_grid_cell_size(self._h))
+
+    def order(self):
+        """Original indices of the points in this grid's cell order (int64 tensor, usable for tensor indexing). A source
+        cloud stored in this order needs no per-alignment sort (align_fused_loop(sort_by_cell="presorted"))."""
+        out = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        check(_lib.lib().sp_grid_order(self._h, _ptr(out), _stream()))
+        return out.long()
 
     def __del__(self):
         try:
@@ -495,7 +512,7 @@ class PreparedSource:
                              "pre-computed before performing GICP matching.")
         tp, on_dev, keep = _trans_arg(transT)
         check(_lib.lib().sp_gicp_source_prepare(self._h, prepared_target._h, _ptr(source.points), _ptr(source.covs),
-                                                source.size(), tp, on_dev, 1 if sort_by_cell else 0, _stream()))
+                                                source.size(), tp, on_dev, _SOURCE_ORDER[sort_by_cell], _stream()))
         self.n = source.size()
 
     def __del__(self):

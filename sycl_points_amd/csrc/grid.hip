@@ -28,6 +28,10 @@ void sp_set_error(const char* msg);
 
 static int g_self_knn_mode = 0;  // tuning hook: 0 wave-cooperative kernel, 1 lane-per-query tile kernel (k <= 10)
 
+// rocPRIM picks a merge sort (about 15 launches, 155 us per 1M pairs) up to 1M items; Onesweep with the key bits
+// actually used (3 passes for a 22-bit cell id) is 3x faster at this size.
+using OnesweepSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 namespace sp {
 namespace {
 
@@ -901,7 +905,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     size_t tmp_bytes = 0;
     unsigned end_bit = 1;
     while ((1ull << end_bit) <= g->ncells && end_bit < 32) ++end_bit;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
+    (void)rocprim::radix_sort_pairs<OnesweepSort>(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
     e = hipMalloc(&keys_in, n * 4);
     if (e == hipSuccess) e = hipMalloc(&keys_out, n * 4);
     if (e == hipSuccess) e = hipMalloc(&vals_in, n * 4);
@@ -913,7 +917,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
         GridDesc gd{g->inv_h, g->h, g->eps, g->org[0], g->org[1], g->org[2], g->dims[0], g->dims[1], g->dims[2],
                     (unsigned)n};
         cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in);
-        e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
+        e = rocprim::radix_sort_pairs<OnesweepSort>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
     }
     if (e == hipSuccess) {
         gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
@@ -947,6 +951,24 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
 
 extern "C" size_t sp_grid_size(const sp_grid* g) { return g ? g->n : 0; }
 extern "C" float sp_grid_cell_size(const sp_grid* g) { return g ? g->h : 0.0f; }
+
+namespace sp {
+namespace {
+__global__ __launch_bounds__(kBlock) void grid_order_kernel(const float4* __restrict__ pts, unsigned n,
+                                                            uint32_t* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = __float_as_uint(pts[i].w);
+}
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_grid_order(const sp_grid* grid, uint32_t* idx_out, void* stream) {
+    if (!grid || (!idx_out && grid->n)) return SP_ERR_INVALID_ARGUMENT;
+    if (grid->n == 0) return SP_OK;
+    sp::grid_order_kernel<<<sp::div_up(grid->n, sp::kBlock), sp::kBlock, 0, sp::as_stream(stream)>>>(
+        grid->d_pts, (unsigned)grid->n, idx_out);
+    return sp::launch_status();
+}
 
 extern "C" int sp_grid_search(const sp_grid* grid, const float* queries, size_t nq, size_t k, const float* transT,
                               int transT_on_device, int32_t* idx_out, float* d2_out, void* stream) {

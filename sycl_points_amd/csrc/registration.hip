@@ -521,6 +521,21 @@ __global__ __launch_bounds__(kBlock) void gather_points_kernel(const float4* __r
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = pts[order ? order[i] : i];
 }
+// gather_points + prepare_cov for the source in one pass over the permutation
+__global__ __launch_bounds__(kBlock) void prepare_source_kernel(const float4* __restrict__ pts,
+                                                                const float4* __restrict__ covs,
+                                                                const unsigned* __restrict__ order, unsigned n,
+                                                                float4* __restrict__ out_pts,
+                                                                float4* __restrict__ out_covp) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned src = order[i];
+    const float4 p = pts[src];
+    const Mat3 P = plane_regularize(load_cov3(covs + 4 * (size_t)src));
+    out_pts[i] = p;
+    out_covp[2 * (size_t)i] = make_float4(P.m[0][0], (P.m[0][1] + P.m[1][0]) * 0.5f, (P.m[0][2] + P.m[2][0]) * 0.5f, P.m[1][1]);
+    out_covp[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], 0.0f, 0.0f);
+}
 __global__ __launch_bounds__(kBlock) void iota_kernel(unsigned* __restrict__ v, unsigned n) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) v[i] = i;
@@ -948,6 +963,10 @@ extern "C" int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, f
 
 // ------------------------------------------------------------------ prepared / fused path (C ABI)
 #include <rocprim/device/device_radix_sort.hpp>
+// rocPRIM picks a merge sort (about 15 launches, 155 us per 1M pairs) up to 1M items; Onesweep with the key bits
+// actually used (3 passes for a 22-bit cell id) is 3x faster at this size.
+using OnesweepSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 
 struct sp_gicp_target {
     const sp_grid* grid = nullptr;  // borrowed: must outlive this object
@@ -1022,7 +1041,7 @@ extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     sp_gicp_source* s = new sp_gicp_source();
     s->n_max = n_max;
     const size_t n = n_max ? n_max : 1;
-    (void)rocprim::radix_sort_pairs(nullptr, s->sort_tmp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+    (void)rocprim::radix_sort_pairs<OnesweepSort>(nullptr, s->sort_tmp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
                                     (unsigned*)nullptr, n, 0, 32, (hipStream_t)0);
     hipError_t e = hipMalloc(&s->pts, n * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->covp, n * 2 * sizeof(float4));
@@ -1059,7 +1078,7 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
     hipStream_t st = as_stream(stream);
     const float4* pts = reinterpret_cast<const float4*>(src_points);
     const unsigned nb = div_up(n, kBlock);
-    if (sort_by_cell) {
+    if (sort_by_cell == SP_SOURCE_SORT) {
         Mat4Arg tv;
         for (int i = 0; i < 16; ++i) tv.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
         if (transT && !transT_on_device)
@@ -1070,15 +1089,18 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
         unsigned end_bit = 1;
         while ((1ull << end_bit) <= target->grid->ncells && end_bit < 32) ++end_bit;
         size_t tmp = s->sort_tmp_bytes;
-        const hipError_t e = rocprim::radix_sort_pairs(s->sort_tmp, tmp, s->keys_in, s->keys_out, s->vals_in, s->perm, n,
-                                                       0, end_bit, st);
+        // Only locality matters, not a total order: the top 16 key bits put every run of 32 consecutive cells of an
+        // x-row (one 128-byte line of cell extents, ~16 points) together — two Onesweep passes instead of three.
+        // The sort is stable, so the order is deterministic.
+        const unsigned begin_bit = end_bit > 16 ? end_bit - 16 : 0;
+        const hipError_t e = rocprim::radix_sort_pairs<OnesweepSort>(s->sort_tmp, tmp, s->keys_in, s->keys_out,
+                                                                     s->vals_in, s->perm, n, begin_bit, end_bit, st);
         if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
     } else {
         iota_kernel<<<nb, kBlock, 0, st>>>(s->perm, (unsigned)n);
     }
-    gather_points_kernel<<<nb, kBlock, 0, st>>>(pts, s->perm, (unsigned)n, s->pts);
-    prepare_cov_kernel<<<nb, kBlock, 0, st>>>(reinterpret_cast<const float4*>(src_covs), (unsigned)n, nullptr, s->perm,
-                                              s->covp);
+    prepare_source_kernel<<<nb, kBlock, 0, st>>>(pts, reinterpret_cast<const float4*>(src_covs), s->perm, (unsigned)n,
+                                                 s->pts, s->covp);
     return launch_status();
 }
 
