@@ -154,65 +154,110 @@ __device__ __forceinline__ Nearest grid_nn1(const float4* __restrict__ pts, cons
 // Fast path for k = 1: scan only the 2x2x2 block of cells nearest to the query (own cell plus the neighbour on the
 // nearer side of each axis): 4 x-rows of at most 2 cells, 8 independent extent loads up front, no per-row pruning.
 // Every point within `cov` (>= h/2 away from the grid boundary cases) of the query lies in that block, so the result
-// is exact whenever the winner is closer than cov; otherwise the caller falls back to the full ring walk (grid_nn1).
+// is exact whenever the winner is closer than cov; otherwise the caller falls back to the later stages.
+// The walk is split into stages (extents -> flatten -> candidate batches -> exactness) so that a caller can interleave
+// the stages of several queries and keep all their loads in flight together.
+struct FastFlat {           // the four x-row ranges as one candidate list
+    unsigned o0, o1, o2, o3;  // position of candidate jj in range r = o_r + jj (o_r = first position - first number)
+    unsigned c1, c2, c3, total;
+};
+
+// Stage 1: the block and its 8 extent loads. Along each axis, with t = fractional position of the query in its (clamped)
+// cell: the block is {cell-1, cell} when t < 0.5, else {cell, cell+1} (clipped to the grid), and its nearest face that
+// is not the grid boundary is max(t, 1-t) >= 0.5 cells away; cov_cells = the minimum over the axes (conservative when
+// clipping removed the face). A non-finite query reads cell 0 and gets an empty list from fast_flatten.
+__device__ __forceinline__ void fast_extents(const unsigned* __restrict__ start, const GridDesc& g, float qx, float qy,
+                                             float qz, unsigned (&s)[4], unsigned (&e)[4], float& cov_cells) {
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    const float cxf = fminf(fmaxf(floorf(fx), 0.0f), (float)(g.nx - 1));
+    const float cyf = fminf(fmaxf(floorf(fy), 0.0f), (float)(g.ny - 1));
+    const float czf = fminf(fmaxf(floorf(fz), 0.0f), (float)(g.nz - 1));
+    const float tx = fx - cxf, ty = fy - cyf, tz = fz - czf;
+    const bool lx = tx < 0.5f, ly = ty < 0.5f, lz = tz < 0.5f;
+    const int cx = (int)cxf, cy = (int)cyf, cz = (int)czf;
+    const int xa = max(cx - (lx ? 1 : 0), 0), xb = min(cx + (lx ? 0 : 1), g.nx - 1);
+    const int ya = max(cy - (ly ? 1 : 0), 0), yb = min(cy + (ly ? 0 : 1), g.ny - 1);
+    const int za = max(cz - (lz ? 1 : 0), 0), zb = min(cz + (lz ? 0 : 1), g.nz - 1);
+    cov_cells = fminf(fminf(lx ? 1.0f - tx : tx, ly ? 1.0f - ty : ty), lz ? 1.0f - tz : tz);
+    // extents of the (up to) four rows; a row that does not exist repeats an existing one with an empty range
+    const unsigned r00 = ((unsigned)za * g.ny + ya) * g.nx + xa;
+    const unsigned dy = yb != ya ? (unsigned)g.nx : 0u, dz = zb != za ? (unsigned)g.ny * g.nx : 0u;
+    const unsigned w = (unsigned)(xb - xa) + 1u;
+    const unsigned r01 = r00 + dy, r10 = r00 + dz, r11 = r10 + dy;
+    s[0] = start[r00]; e[0] = start[r00 + w];
+    s[1] = start[r01]; e[1] = start[r01 + w];
+    s[2] = start[r10]; e[2] = start[r10 + w];
+    s[3] = start[r11]; e[3] = start[r11 + w];
+    if (dy == 0u) { e[1] = s[1]; e[3] = s[3]; }
+    if (dz == 0u) { e[2] = s[2]; e[3] = s[3]; }
+}
+
+// Stage 2: flatten the four ranges into one list.
+__device__ __forceinline__ FastFlat fast_flatten(const unsigned (&s)[4], const unsigned (&e)[4], bool usable) {
+    FastFlat f;
+    const unsigned n0 = e[0] - s[0], n1 = e[1] - s[1], n2 = e[2] - s[2], n3 = e[3] - s[3];
+    f.c1 = n0; f.c2 = n0 + n1; f.c3 = f.c2 + n2;
+    f.o0 = s[0]; f.o1 = s[1] - f.c1; f.o2 = s[2] - f.c2; f.o3 = s[3] - f.c3;
+    f.total = usable ? f.c3 + n3 : 0u;
+    return f;
+}
+__device__ __forceinline__ unsigned fast_pos(const FastFlat& f, unsigned jj) {
+    return jj + (jj < f.c1 ? f.o0 : (jj < f.c2 ? f.o1 : (jj < f.c3 ? f.o2 : f.o3)));
+}
+
+// Stage 3: candidates [base, base + B) as B INDEPENDENT 16-byte loads (one memory round trip for almost every query
+// instead of one per row and per pair of points) ...
+template <int B>
+__device__ __forceinline__ void fast_load(const float4* __restrict__ pts, const FastFlat& f, unsigned base,
+                                          float4 (&cand)[B]) {
+#pragma unroll
+    for (int j = 0; j < B; ++j) cand[j] = pts[fast_pos(f, min(base + j, f.total - 1))];
+}
+// ... and their evaluation, branch-free: the (distance, index)-lexicographic minimum is the minimum of the 64-bit key
+// (distance bits : index) — distances are non-negative floats, whose bit patterns order like the values; a NaN distance
+// orders above every number and never wins, as with `d < best`. `bj` tracks the winner's number in the list.
+__device__ __forceinline__ unsigned long long nn_key(float d2, int idx) {
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)idx;
+}
+template <int B>
+__device__ __forceinline__ void fast_eval(const FastFlat& f, unsigned base, const float4 (&cand)[B], float qx, float qy,
+                                          float qz, unsigned long long& best_key, unsigned& bj) {
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const float d = dist2(qx, qy, qz, cand[j].x, cand[j].y, cand[j].z);
+        unsigned long long key = nn_key(d, __float_as_int(cand[j].w));
+        key = (base + j < f.total) ? key : ~0ull;
+        const bool better = key < best_key;
+        best_key = better ? key : best_key;
+        bj = better ? base + j : bj;
+    }
+}
+
 // Returns true when the answer in `best` is proven exact.
 __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                               const GridDesc& g, float qx, float qy, float qz, Nearest& best) {
     best.d2 = FLT_MAX; best.idx = -1; best.pos = 0; best.x = best.y = best.z = 0.0f;
-    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return true;
-    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-    const int cx = (int)fminf(fmaxf(floorf(fx), 0.0f), (float)(g.nx - 1));
-    const int cy = (int)fminf(fmaxf(floorf(fy), 0.0f), (float)(g.ny - 1));
-    const int cz = (int)fminf(fmaxf(floorf(fz), 0.0f), (float)(g.nz - 1));
-    const int sx = (fx - (float)cx < 0.5f) ? -1 : 1, sy = (fy - (float)cy < 0.5f) ? -1 : 1,
-              sz = (fz - (float)cz < 0.5f) ? -1 : 1;
-    const int xa = max(min(cx, cx + sx), 0), xb = min(max(cx, cx + sx), g.nx - 1);
-    const int ya = max(min(cy, cy + sy), 0), yb = min(max(cy, cy + sy), g.ny - 1);
-    const int za = max(min(cz, cz + sz), 0), zb = min(max(cz, cz + sz), g.nz - 1);
-    // extents of the (up to) four rows; a row that does not exist repeats an existing one with an empty range
+    const bool usable = isfinite(qx) && isfinite(qy) && isfinite(qz) && g.n != 0;
+    if (!usable) return true;
     unsigned s[4], e[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int y = (r & 1) ? yb : ya, z = (r & 2) ? zb : za;
-        const bool dup = ((r & 1) && yb == ya) || ((r & 2) && zb == za);
-        const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
-        const unsigned s0 = start[row + xa], e0 = start[row + xb + 1];
-        s[r] = s0;
-        e[r] = dup ? s0 : e0;
-    }
-    // Flatten the four ranges into one candidate list and fetch it in batches of 8 INDEPENDENT 16-byte loads
-    // (one memory round trip for almost every query instead of one per row and per pair of points).
-    const unsigned n0 = e[0] - s[0], n1 = e[1] - s[1], n2 = e[2] - s[2], n3 = e[3] - s[3];
-    const unsigned c1 = n0, c2 = n0 + n1, c3 = n0 + n1 + n2, total = c3 + n3;
-    for (unsigned base = 0; base < total; base += 8) {
+    float cov_cells;
+    fast_extents(start, g, qx, qy, qz, s, e, cov_cells);
+    const FastFlat f = fast_flatten(s, e, true);
+    unsigned long long key = nn_key(FLT_MAX, -1);  // nothing found: {FLT_MAX, -1}
+    unsigned bj = 0;
+    for (unsigned base = 0; base < f.total; base += 8) {
         float4 cand[8];
-        unsigned cpos[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned jj = min(base + j, total - 1);
-            const unsigned pos = jj < c1 ? s[0] + jj : (jj < c2 ? s[1] + (jj - c1) : (jj < c3 ? s[2] + (jj - c2) : s[3] + (jj - c3)));
-            cpos[j] = pos;
-            cand[j] = pts[pos];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d = dist2(qx, qy, qz, cand[j].x, cand[j].y, cand[j].z);
-            const int pi = __float_as_int(cand[j].w);
-            const bool valid = base + j < total;
-            if (valid && (d < best.d2 || (d == best.d2 && pi < best.idx))) {
-                best.d2 = d; best.idx = pi; best.pos = cpos[j]; best.x = cand[j].x; best.y = cand[j].y; best.z = cand[j].z;
-            }
-        }
+        fast_load<8>(pts, f, base, cand);
+        fast_eval<8>(f, base, cand, qx, qy, qz, key, bj);
     }
-    float cov = FLT_MAX;
-    if (xa > 0) cov = fminf(cov, qx - (g.ox + xa * g.h));
-    if (xb < g.nx - 1) cov = fminf(cov, (g.ox + (xb + 1) * g.h) - qx);
-    if (ya > 0) cov = fminf(cov, qy - (g.oy + ya * g.h));
-    if (yb < g.ny - 1) cov = fminf(cov, (g.oy + (yb + 1) * g.h) - qy);
-    if (za > 0) cov = fminf(cov, qz - (g.oz + za * g.h));
-    if (zb < g.nz - 1) cov = fminf(cov, (g.oz + (zb + 1) * g.h) - qz);
-    if (cov == FLT_MAX) return true;  // the block is the whole grid
-    cov = fmaxf(cov - g.eps, 0.0f);
+    if (key != nn_key(FLT_MAX, -1)) {
+        best.pos = fast_pos(f, bj);
+        const float4 w = pts[best.pos];  // the winner again (an L1 hit): cheaper than carrying x,y,z through every compare
+        best.x = w.x; best.y = w.y; best.z = w.z;
+        best.idx = __float_as_int(w.w);
+        best.d2 = __uint_as_float((unsigned)(key >> 32));
+    }
+    const float cov = fmaxf(cov_cells * g.h - g.eps, 0.0f);
     return best.d2 < cov * cov;  // strict: an unseen point at exactly this distance could win a tie
 }
 
@@ -301,14 +346,20 @@ __device__ __forceinline__ bool grid_nn1_block4(const float4* __restrict__ pts, 
     return best.d2 < cov * cov;
 }
 
+// Stages after an inexact fast result (`best` holds its upper bound or {FLT_MAX, -1}).
+__device__ __forceinline__ void grid_nn1_later_stages(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                      const GridDesc& g, float qx, float qy, float qz, Nearest& best) {
+    if (grid_nn1_block4(pts, start, g, qx, qy, qz, best)) return;
+    // the block covers the rings r <= 1 of the own cell completely
+    const Nearest seed = best;
+    best = grid_nn1(pts, start, g, qx, qy, qz, &seed, 2);
+}
+
 __device__ __forceinline__ Nearest grid_nn1_auto(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                  const GridDesc& g, float qx, float qy, float qz) {
     Nearest best;
-    if (grid_nn1_fast(pts, start, g, qx, qy, qz, best)) return best;
-    if (grid_nn1_block4(pts, start, g, qx, qy, qz, best)) return best;
-    // the block covers the rings r <= 1 of the own cell completely
-    const Nearest seed = best;
-    return grid_nn1(pts, start, g, qx, qy, qz, &seed, 2);
+    if (!grid_nn1_fast(pts, start, g, qx, qy, qz, best)) grid_nn1_later_stages(pts, start, g, qx, qy, qz, best);
+    return best;
 }
 
 }  // namespace sp

@@ -557,32 +557,11 @@ struct FusedParams {
     float* nn_d2;
 };
 
-// One source point of the fused iteration: q = T p -> exact NN on the target grid -> linearise -> accumulate.
-template <int LOSS, bool FAST_NN, int DBG>
-__device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
-                                            unsigned& cnt) {
-    const float4 s = P.src[i];
-    float qx, qy, qz;
-    transform_point(T, s.x, s.y, s.z, qx, qy, qz);
-    Nearest nn;
-    if (DBG == 2) {  // timing experiment: no search, a nearby fake winner
-        nn.pos = min(i, P.g.n - 1); const float4 tp = P.tpts[nn.pos];
-        nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = (int)nn.pos; nn.d2 = 0.0f;
-    } else {
-        if (DBG == 3) {  // timing experiment: 2x2x2 block, then the unseeded ring walk
-            if (!grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn)) nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
-        } else
-        nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
-    }
-    if (DBG == 1 || DBG == 3) { acc[27] += nn.d2 + nn.x; ++cnt; return; }  // timing experiment: search only
-    if (P.nn_idx) {
-        const unsigned o = P.perm[i];
-        P.nn_idx[o] = nn.idx;
-        P.nn_d2[o] = nn.d2;
-    }
-    if (nn.idx < 0 || nn.d2 > P.max_d2) return;
-    const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
-    const Sym3 Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
+// Linearisation of one correspondence (source point s with q = T s, winner nn, packed covariances) and accumulation.
+template <int LOSS>
+__device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T, const float4 s, float qx, float qy,
+                                           float qz, const Nearest& nn, const Sym3& Cs, const Sym3& Ct,
+                                           float (&acc)[kAcc - 1], unsigned& cnt) {
     const float r0 = nn.x - qx, r1 = nn.y - qy, r2 = nn.z - qz;
     // Source-frame form of factor.hpp:239-278. With S = skew(p), J = [R S | -R] and M = (Ct' + R Cs' R^T)^-1:
     //   N := R^T M R = (Cs' + R^T Ct' R)^-1,  v := R^T r,  u := N v,  G := S N
@@ -640,6 +619,35 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
     acc[24] += w * -u0; acc[25] += w * -u1; acc[26] += w * -u2;
     acc[27] += robust_error<LOSS>(rn, P.scale);
     ++cnt;
+}
+
+// One source point of the fused iteration: q = T p -> exact NN on the target grid -> linearise -> accumulate.
+template <int LOSS, bool FAST_NN, int DBG>
+__device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
+                                            unsigned& cnt) {
+    const float4 s = P.src[i];
+    float qx, qy, qz;
+    transform_point(T, s.x, s.y, s.z, qx, qy, qz);
+    Nearest nn;
+    if (DBG == 2) {  // timing experiment: no search, a nearby fake winner
+        nn.pos = min(i, P.g.n - 1); const float4 tp = P.tpts[nn.pos];
+        nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = (int)nn.pos; nn.d2 = 0.0f;
+    } else {
+        if (DBG == 3) {  // timing experiment: 2x2x2 block, then the unseeded ring walk
+            if (!grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn)) nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+        } else
+        nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+    }
+    if (DBG == 1 || DBG == 3) { acc[27] += nn.d2 + nn.x; ++cnt; return; }  // timing experiment: search only
+    if (P.nn_idx) {
+        const unsigned o = P.perm[i];
+        P.nn_idx[o] = nn.idx;
+        P.nn_d2[o] = nn.d2;
+    }
+    if (nn.idx < 0 || nn.d2 > P.max_d2) return;
+    const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
+    const Sym3 Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
+    fused_math<LOSS>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
 }
 
 template <int LOSS, bool FAST_NN, int DBG = 0>
@@ -746,10 +754,11 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
         T.t[r] = uniform(T.t[r]);
     }
     float acc[kAcc - 1];
+    unsigned cnt = 0;
+    const unsigned stride = gridDim.x * kAlignBlock;
 #pragma unroll
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
-    unsigned cnt = 0;
-    for (unsigned i = blockIdx.x * kAlignBlock + threadIdx.x; i < P.n; i += gridDim.x * kAlignBlock)
+    for (unsigned i = blockIdx.x * kAlignBlock + threadIdx.x; i < P.n; i += stride)
         fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt);
     block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
 }
