@@ -758,7 +758,11 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     const unsigned stride = gridDim.x * kAlignBlock;
 #pragma unroll
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
-    for (unsigned i = blockIdx.x * kAlignBlock + threadIdx.x; i < P.n; i += stride)
+    // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD one contiguous eighth of the
+    // (cell-ordered) source: the target cells it reads then stay in that XCD's own L2 from one grid row / layer to the next
+    unsigned tile = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
         fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt);
     block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
 }
