@@ -7,7 +7,7 @@ passes (they do not fit one pass on gfx950), with --kernel-trace only; both are 
 (FETCH_SIZE reads exactly half for WIDE COALESCED streaming reads) does not transfer to gather-shaped kernels, so, as the
 guide prescribes for other access shapes, the read side is CALIBRATED on a known byte count in the same access pattern:
 prepare_cov_kernel gathers one 64-byte covariance row per lane through an index (the shape of the fused kernel's loads)
-and reads a known n x (64 + 4 or 16) bytes. factor = known / FETCH_SIZE; WRITE_SIZE is exact for 16-byte stores (checked:
+and reads a known n x (64 + 16) bytes. factor = known / FETCH_SIZE; WRITE_SIZE is exact for 16-byte stores (checked:
 prepare_cov writes exactly n x 32 bytes). bytes = factor * FETCH_SIZE * 1024 + WRITE_SIZE * 1024, per launch. This script never touches the GPU itself; rocprofv3 wraps `python3 bench.py` directly.
 """
 import collections
@@ -32,7 +32,12 @@ def run_pass(counter):
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "40", "--warmup", "20"]
     subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    f = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[-1]
+    return read_pass(counter)
+
+
+def read_pass(counter):
+    d = os.path.join(OUT, counter)
+    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -44,11 +49,14 @@ def run_pass(counter):
 
 
 def main():
-    fetch = run_pass("FETCH_SIZE")
-    write = run_pass("WRITE_SIZE")
+    if "--reuse" in sys.argv:  # recompute from CSVs already under gpurun_out/pmc_traffic (no GPU needed)
+        fetch, write = read_pass("FETCH_SIZE"), read_pass("WRITE_SIZE")
+    else:
+        fetch = run_pass("FETCH_SIZE")
+        write = run_pass("WRITE_SIZE")
     out = {}
     n = 1_000_000
-    known_prepare_read = n * (64 + (4 + 16) / 2.0)  # half the launches index through perm (4 B), half through grid points (16 B)
+    known_prepare_read = n * (64 + 16)  # prepare_cov_kernel (target side): one 64-B covariance row gathered through the index in a 16-B grid point
     factor = known_prepare_read / (fetch["prepare_cov_kernel"][0] * 1024.0)
     for k in KERNELS:
         if k in fetch and k in write:
@@ -58,7 +66,7 @@ def main():
                       "read_calibration_factor": factor,
                       "hbm_bytes_per_launch": factor * f_kib * 1024.0 + w_kib * 1024.0,
                       "uncorrected_bytes_per_launch": f_kib * 1024.0 + w_kib * 1024.0,
-                      "correction": "read side calibrated on prepare_cov_kernel (known n*(64+10) B, same gather shape); "
+                      "correction": "read side calibrated on prepare_cov_kernel (known n*(64+16) B, same gather shape); "
                                     "WRITE_SIZE exact"}
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
