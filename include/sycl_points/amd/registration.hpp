@@ -10,6 +10,7 @@
 // is a GridKNN and the factor is GICP, the iteration uses the prepared / fused kernel (sp_gicp_iteration_fused).
 #pragma once
 #include <cctype>
+#include <cstring>
 #include <functional>
 #include <iostream>
 #include <tuple>
@@ -125,7 +126,7 @@ public:
         hip_check(hipMalloc(&lin_dev_, sizeof(sp_linearized)), "hipMalloc");
         ws_bytes_ = sp_gicp_workspace_bytes(0);
         hip_check(hipMalloc(&ws_, ws_bytes_), "hipMalloc");
-        hip_check(hipMalloc(&T_dev_, 16 * sizeof(float) + 8 * sizeof(float)), "hipMalloc");
+        hip_check(hipMalloc(&T_dev_, (16 + 8 + 4) * sizeof(float)), "hipMalloc");  // pose | delta[8] | iterations
     }
     ~Registration() {
         if (psrc_) sp_gicp_source_destroy(psrc_);
@@ -174,6 +175,11 @@ public:
         const auto* grid = dynamic_cast<const knn::GridKNN*>(&target_knn);
         const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size();
         if (fused) prepare_fused(source, target, *grid, initial_guess);
+        // GICP + Gauss-Newton on a GridKNN: the whole loop runs on the device (one launch per iteration, convergence
+        // test included), the host reads the result back once — same arithmetic as the loop below.
+        if (fused && params_.optimization_method == OptimizationMethod::GAUSS_NEWTON && !params_.verbose &&
+            params_.max_iterations > 0)
+            return align_on_device(source.size(), initial_guess, robust_scale);
 
         for (size_t iter = 0; iter < params_.max_iterations; ++iter) {
             const LinearizedResult lin = fused ? linearize_fused(source.size(), result.T.matrix(), robust_scale)
@@ -193,6 +199,10 @@ public:
         }
         return result;
     }
+
+    /// MI355X extension: tell align() that source clouds arrive spatially ordered (GridKNN::order() / voxel-downsampled
+    /// clouds), so the prepared path skips its per-alignment sort (SP_SOURCE_PRESORTED).
+    void set_source_presorted(bool v) { source_presorted_ = v; }
 
     /// registration.hpp:312-331 (degenerate regularisation is default-off and not built)
     LinearizedResult compute_linearized_result(const PointCloudShared& source, const PointCloudShared& target,
@@ -284,8 +294,34 @@ private:
             psrc_cap_ = source.size();
         }
         throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, source.points_device(), source.covs_device(), source.size(),
-                                              T0.data(), 0, /*sort_by_cell=*/1, queue_.stream()));
+                                              T0.data(), 0, source_presorted_ ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT, queue_.stream()));
         neighbors_.indices == nullptr ? neighbors_.allocate(queue_, source.size(), 1) : neighbors_.resize(source.size(), 1);
+    }
+    RegistrationResult align_on_device(size_t N, const TransformMatrix& initial_guess, float robust_scale) {
+        const sp_factor_params fp = factor_params(robust_scale);
+        const sp_gn_params gn{params_.gn.lambda, params_.criteria.rotation, params_.criteria.translation};
+        float* delta_dev = T_dev_ + 16;
+        uint32_t* iters_dev = reinterpret_cast<uint32_t*>(T_dev_ + 24);
+        hip_check(hipMemcpyAsync(T_dev_, initial_guess.data(), 16 * sizeof(float), hipMemcpyHostToDevice, queue_.stream()), "H2D");
+        throw_on_error(sp_gicp_align_fused(ptgt_, psrc_, T_dev_, &fp, &gn, (int)params_.max_iterations,
+                                           neighbors_.indices->device_data_for_write(N),
+                                           neighbors_.distances->device_data_for_write(N), lin_dev_, delta_dev, iters_dev,
+                                           ws_, ws_bytes_, queue_.stream()));
+        float host[28];
+        hip_check(hipMemcpyAsync(host, T_dev_, sizeof host, hipMemcpyDeviceToHost, queue_.stream()), "D2H");
+        const sp_linearized h = read_lin();  // synchronises the stream
+        const LinearizedResult lin = to_result(h);
+        RegistrationResult result;
+        TransformMatrix T;
+        for (int i = 0; i < 16; ++i) T.data()[i] = host[i];
+        result.T.matrix() = T;
+        uint32_t iters;
+        std::memcpy(&iters, &host[24], sizeof iters);
+        result.iterations = iters > 0 ? iters - 1 : 0;  // index of the last iteration (registration.hpp:822)
+        result.converged = host[16 + 6] > 0.5f;
+        result.H = lin.H; result.b = lin.b; result.error = lin.error; result.inlier = lin.inlier;
+        result.H_raw = lin.H; result.b_raw = lin.b; result.error_raw = lin.error;
+        return result;
     }
     LinearizedResult linearize_fused(size_t N, const TransformMatrix& T, float robust_scale) {
         const sp_factor_params fp = factor_params(robust_scale);
@@ -372,6 +408,7 @@ private:
     size_t psrc_cap_ = 0;
     sp_gicp_target* ptgt_ = nullptr;
     const sp_grid* ptgt_grid_ = nullptr;
+    bool source_presorted_ = false;
 };
 
 // ------------------------------------------------------------------------------------------------ pipeline wrappers

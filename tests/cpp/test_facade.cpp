@@ -218,6 +218,37 @@ static void registration_matches_oracle() {
     CHECK(max_abs_diff(r_host.T.matrix(), ref.T) < 1e-5f);
     CHECK(max_abs_diff(r_grid.T.matrix(), T_gt.data()) < 5e-4f);
     CHECK(r_tree.inlier == ref.inlier && r_grid.inlier == ref.inlier && host_knn.calls == 12);
+    // the GridKNN + GICP + Gauss-Newton route runs the whole loop on the device (sp_gicp_align_fused); it must stop where
+    // the reference's loop stops (criteria != 0) and agree with the host-driven loop (verbose forces that one)
+    {
+        alg::registration::RegistrationParams pc = p;
+        pc.max_iterations = 30;
+        pc.criteria.translation = 1e-4f;
+        pc.criteria.rotation = 1e-4f;
+        orc_reg_params opc = op;
+        opc.max_iterations = 30; opc.crit_translation = 1e-4f; opc.crit_rotation = 1e-4f;
+        orc_reg_result refc;
+        orc_registration_align(&opc, reinterpret_cast<const float*>(source.points->data()),
+                               reinterpret_cast<const float*>(source.covs->data()), n,
+                               reinterpret_cast<const float*>(target.points->data()),
+                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &refc, nullptr, nullptr, nullptr, 0);
+        alg::registration::Registration regc(*Q, pc);
+        const auto rc = regc.align(source, target, *grid);
+        CHECK(rc.converged && refc.converged);
+        CHECK((int)rc.iterations == refc.iterations);
+        CHECK(max_abs_diff(rc.T.matrix(), refc.T) < 1e-5f);
+        CHECK(rc.inlier == refc.inlier);
+        regc.set_source_presorted(true);  // only changes which lane handles which point
+        const auto rp = regc.align(source, target, *grid);
+        CHECK(max_abs_diff(rp.T.matrix(), refc.T) < 1e-5f && rp.iterations == rc.iterations);
+        alg::registration::RegistrationParams pv = pc;
+        pv.verbose = true;
+        alg::registration::Registration regv(*Q, pv);
+        std::streambuf* old = std::cout.rdbuf(nullptr);  // silence the per-iteration lines
+        const auto rv = regv.align(source, target, *grid);
+        std::cout.rdbuf(old);
+        CHECK(max_abs_diff(rv.T.matrix(), rc.T.matrix().data()) < 2e-6f && rv.iterations == rc.iterations);
+    }
     // LM + Geman-McClure through the annealing pipeline (example_registration.cpp:31-45), against the oracle's restatement
     alg::registration::RegistrationPipelineParams pp;
     pp.registration.max_iterations = 10;

@@ -656,6 +656,39 @@ def test_align_fused_one_call_loop(sp, orc, gicp20k, loss):
     assert torch.equal(T0.cpu(), torch.eye(4).reshape(-1))
 
 
+def test_grid_order_and_presorted_source(sp, orc, gicp20k):
+    """sp_grid_order is the grid's cell-order permutation; a source stored in that order aligns without the per-alignment
+    sort (SP_SOURCE_PRESORTED) to the same pose, and reports its neighbours in the caller's (reordered) indexing."""
+    from oracle.pyoracle import RegParams
+
+    src, scov, tgt, tcov, T_gt = gicp20k
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    order = sp.GridKNN.build(S.points, points_per_cell=1.0).order()
+    assert sorted(order.cpu().tolist()) == list(range(len(src)))
+    S2 = S.reordered(order)
+    assert torch.equal(S2.points, S.points[order]) and torch.equal(S2.covs, S.covs[order])
+    grid = sp.GridKNN.build(Tg.points)
+    prep = sp.PreparedTarget(grid, Tg.covs)
+    p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=8)
+    ref = orc.registration_align(RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=8), src, scov,
+                                 tgt, tcov)
+    poses = {}
+    for mode, cloud in ((True, S), ("presorted", S2), (False, S2)):
+        reg = sp.Registration(p)
+        T_dev, lin, _ = reg.align_fused_loop(cloud, prep, sort_by_cell=mode, write_neighbors=True)
+        poses[mode] = reg.T_from_device(T_dev)
+        assert np.abs(poses[mode] - ref["T"]).max() < 1e-5
+        assert reg._read_lin(lin).inlier == ref["inlier"]
+        # neighbours of the last linearisation, against brute force at the pose they were searched at
+        nn = reg.neighbors.indices.cpu().numpy().ravel()
+        T7 = orc.registration_align(RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=7), src, scov,
+                                    tgt, tcov)["T"]
+        pts = cloud.points.cpu().numpy()
+        oi, _ = orc.knn_bruteforce(orc.transform_points(pts, T7), tgt, 1)
+        assert (nn == oi.ravel()).mean() > 0.999  # the pose differs from the oracle's by rounding only
+
+
 # ------------------------------------------------------------------ tile self-kNN (+ fused covariance / normals)
 @pytest.mark.parametrize("k", [4, 10, 20])
 @pytest.mark.parametrize("shape", ["uniform", "clustered"])
