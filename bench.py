@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--source-order", choices=["grid", "random"], default="grid",
                     help="grid: the source is stored in the cell order of a grid on itself (what voxel downsampling "
                          "yields; done in set-up). random: as generated; every alignment then sorts it by target cell")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="rehearsal: run the multi-GPU code path (RCCL all-reduce of the 192-byte system every iteration) "
+                         "with a world of one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline workload")
     return ap.parse_args()
@@ -64,9 +67,11 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import sycl_points_amd.api as sp
     from sycl_points_amd import _lib
@@ -107,7 +112,7 @@ def main():
     T_dev = torch.zeros(16, dtype=torch.float32, device=dev)
     T_ident = torch.eye(4, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     delta = torch.zeros(8, dtype=torch.float32, device=dev)
-    group = dist.group.WORLD if world > 1 else None
+    group = dist.group.WORLD if (world > 1 or args.force_sharded) else None
 
     def align_chunk(iters, first):
         if args.path == "fused":
@@ -188,7 +193,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -261,6 +261,24 @@ int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* sour
                         const sp_factor_params* params, const sp_gn_params* gn, int max_iterations,
                         int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
                         uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same loop one launch at a time, for callers that put something between the launches — on several GPUs (source
+ * tile-sharded, target replicated) an all-reduce:
+ *   for k in 0 .. max_iterations-1:  sp_gicp_align_step(k)                       (enqueue launch k)
+ *                                    all-reduce(sum) sp_gicp_align_rows(ws, k)   (32 KB of float32, in place, same stream order)
+ *   sp_gicp_align_finish(last_k = max_iterations-1)
+ * With rows_all_reduced != 0 the inlier counts travel in the rows as float VALUES (exact: < 2^24 per row) so that a float
+ * all-reduce sums them; every rank then finishes iteration k in launch k+1's prologue from identical rows and holds the
+ * identical pose — one collective and one launch per iteration, no separate reduction or solve kernel. All ranks must
+ * pass the same rows_all_reduced, and must all-reduce all of sp_gicp_align_rows' floats (rows a rank does not use are
+ * zeroed by step 0). transT_device must not be written between step 0 and finish. */
+int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                       const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
+                       int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+float* sp_gicp_align_rows(void* workspace, int k, size_t* n_floats_out);
+int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn, int last_k,
+                         int rows_all_reduced, sp_linearized* lin_out, float* delta_out8, uint32_t* iterations_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* Tuning hook, not part of the stable surface: NN walk used inside the fused kernel
  * (-1 automatic: 2x2x2 fast path iff the source is cell-sorted; 0 ring walk; 1 fast path). */
 void sp_debug_set_fused_fast_nn(int mode);

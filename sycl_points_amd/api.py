@@ -810,6 +810,27 @@ class Registration:
                                         ni, nd, _ptr(lin), _ptr(delta_dev), _ptr(self._iters_dev), _ptr(ws), ws.numel(),
                                         _stream()))
             return T_dev, lin, delta_dev
+        if sharded and not per_iteration_launches:
+            # one launch + one collective per iteration: the 32 KB of partial rows are all-reduced in place between
+            # launch k and launch k+1, whose prologue then finishes iteration k identically on every rank
+            if getattr(self, "_iters_dev", None) is None or self._iters_dev.device != dev:
+                self._iters_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            nf = C.c_size_t(0)
+            wsf = ws.view(torch.float32)
+            base = ws.data_ptr()
+            rows = []
+            for k in (0, 1):
+                off = (L.sp_gicp_align_rows(_ptr(ws), k, C.byref(nf)) - base) // 4
+                rows.append(wsf[off:off + nf.value])
+            wsp, linp, Tp, st = _ptr(ws), _ptr(lin), _ptr(T_dev), _stream()
+            for k in range(iters):
+                check(L.sp_gicp_align_step(prepared_target._h, self._psrc._h, Tp, C.byref(fp), C.byref(gn), k, 1, ni, nd,
+                                           linp, wsp, ws.numel(), st))
+                dist.all_reduce(rows[k & 1], op=dist.ReduceOp.SUM, group=group)
+            if iters > 0:
+                check(L.sp_gicp_align_finish(self._psrc._h, _ptr(T_dev), C.byref(gn), iters - 1, 1, _ptr(lin),
+                                             _ptr(delta_dev), _ptr(self._iters_dev), _ptr(ws), ws.numel(), _stream()))
+            return T_dev, lin, delta_dev
         for _ in range(iters):
             check(L.sp_gicp_iteration_fused(prepared_target._h, self._psrc._h, _ptr(T_dev), 1, C.byref(fp),
                                             None if sharded else C.byref(gn), ni, nd, _ptr(lin), _ptr(delta_dev),

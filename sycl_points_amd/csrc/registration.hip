@@ -247,8 +247,11 @@ struct KParams {
 };
 
 // Sum NV lane values over the workgroup in a fixed order and let lane e < NV of wave 0 write partial[e].
+// count_as_float: the count slot holds the VALUE as a float (exact below 2^24) instead of the uint32 bit pattern, so
+// that partial rows can be summed across ranks by a float all-reduce.
 template <int NV, int BLOCK = kBlock>
-__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cnt, float* __restrict__ partial) {
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cnt, float* __restrict__ partial,
+                                                   bool count_as_float = false) {
     __shared__ float red[BLOCK / kWave][kPartial];
     const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
@@ -269,7 +272,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cn
         unsigned c = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][NV]);
-        partial[NV] = __uint_as_float(c);
+        partial[NV] = count_as_float ? (float)c : __uint_as_float(c);
     }
 }
 
@@ -351,7 +354,7 @@ __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, flo
 // contiguous row ranges (independent loads, added in row order), then lanes 0..31 add the 32 parts in order.
 // On return (after a barrier) red[0][e] holds the totals; slot nv is the uint32 count.
 __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ partials, unsigned rows, int nv,
-                                                 float (*red)[kPartial]) {
+                                                 float (*red)[kPartial], bool count_is_float = false) {
     constexpr unsigned kParts = kFinalThreads / 32;
     const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;
     const unsigned per = (rows + kParts - 1) / kParts;
@@ -362,7 +365,7 @@ __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ parti
 #pragma unroll 8
     for (unsigned b = lo; b < hi; ++b) {
         const float v = partials[(size_t)b * kPartial + e];
-        if (is_count) c += __float_as_uint(v);
+        if (is_count) c += count_is_float ? (unsigned)v : __float_as_uint(v);
         else s += v;
     }
     red[part][e] = is_count ? __uint_as_float(c) : s;
@@ -689,6 +692,7 @@ struct AlignArgs {
     int has_prev;
     float lambda, crit_rot, crit_trans;
     sp_linearized* lin_out;      // system of the last finished iteration (may be null)
+    int count_is_float;          // partial rows are all-reduced between launches (multi-GPU): counts travel as floats
 };
 
 // Finishes iteration k-1 (or loads the initial pose) and leaves the pose in sT (LDS). Returns false when this launch
@@ -704,7 +708,7 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
             if (blockIdx.x == 0 && threadIdx.x == 0) *A.state_out = *A.state_in;
             return false;
         }
-        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red);
+        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0);
         if (threadIdx.x == 0) {
             unpack_totals(red[0], kAcc - 1, &slin);
 #pragma unroll
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
         fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt);
-    block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
+    block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, A.count_is_float != 0);
 }
 
 // After the last launch: finish the last iteration (unless an earlier one converged) and publish the results.
@@ -774,14 +778,15 @@ __global__ __launch_bounds__(kFinalThreads) void align_finish_kernel(const float
                                                                      float* __restrict__ T_out,
                                                                      sp_linearized* __restrict__ lin_out,
                                                                      float* __restrict__ delta_out8,
-                                                                     uint32_t* __restrict__ iterations_out) {
+                                                                     uint32_t* __restrict__ iterations_out,
+                                                                     int count_is_float) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ sp_linearized slin;
     __shared__ float sT[16];
     __shared__ float sdelta[8];
     __shared__ LdltScratch ldlt_ws;
     const bool conv = state_in->converged != 0;
-    if (!conv) reduce_rows_1024(partials, rows, kAcc - 1, red);
+    if (!conv) reduce_rows_1024(partials, rows, kAcc - 1, red, count_is_float != 0);
     if (threadIdx.x == 0) {
         unsigned iters = state_in->iterations;
 #pragma unroll
@@ -1193,6 +1198,113 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     return launch_status();
 }
 // Measurement hook (not part of the stable surface): which of the two launches sp_gicp_iteration_fused issues.
+namespace sp {
+namespace {
+struct AlignWs {  // workspace: partial rows A | partial rows B | state A | state B
+    float* part[2];
+    AlignState* state;
+};
+AlignWs align_ws(void* workspace) {
+    AlignWs w;
+    w.part[0] = static_cast<float*>(workspace);
+    w.part[1] = w.part[0] + (size_t)kAlignMaxBlocks * kPartial;
+    w.state = reinterpret_cast<AlignState*>(w.part[1] + (size_t)kAlignMaxBlocks * kPartial);
+    return w;
+}
+unsigned align_grid(size_t n) {
+    unsigned grid = div_up(n, kAlignBlock);
+    return grid > (unsigned)kAlignMaxBlocks ? (unsigned)kAlignMaxBlocks : (grid ? grid : 1u);
+}
+int align_check(const char* who, const sp_gicp_target* target, const sp_gicp_source* source, const sp_factor_params* params,
+                const sp_gn_params* gn, const float* T, void* workspace, size_t workspace_bytes) {
+    if (!target || !source || !params || !gn || !T) return SP_ERR_INVALID_ARGUMENT;
+    if (params->reg_type != SP_REG_GICP) {
+        sp_set_error("[sp_gicp_align_*] only RegType::GICP has a prepared/fused form");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(source->n)) {
+        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    (void)who;
+    return SP_OK;
+}
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                                 const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
+                                 int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    const int rc = align_check("step", target, source, params, gn, transT_device, workspace, workspace_bytes);
+    if (rc != SP_OK) return rc;
+    if (k < 0) return SP_ERR_INVALID_ARGUMENT;
+    const size_t n = source->n;
+    const AlignWs w = align_ws(workspace);
+    if (k == 0 && rows_all_reduced) {
+        // every rank all-reduces all kAlignMaxBlocks rows whatever its own tile size: rows a rank does not write stay zero
+        if (hipMemsetAsync(w.part[0], 0, 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != hipSuccess)
+            return SP_ERR_HIP;
+    }
+    const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
+    const unsigned grid = align_grid(n);
+    const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
+    AlignArgs A;
+    A.T_init = transT_device;
+    A.state_in = &w.state[(k + 1) & 1];
+    A.state_out = &w.state[k & 1];
+    A.prev_partials = w.part[(k + 1) & 1];
+    A.prev_rows = rows_all_reduced ? (unsigned)kAlignMaxBlocks : grid;
+    A.has_prev = k > 0;
+    A.lambda = gn->lambda;
+    A.crit_rot = gn->crit_rotation;
+    A.crit_trans = gn->crit_translation;
+    A.lin_out = lin_out;
+    A.count_is_float = rows_all_reduced ? 1 : 0;
+    float* out = w.part[k & 1];
+#define SP_LAUNCH_ALIGN(L)                                                                            \
+    if (!(g_fused_stage_mask & 1)) {}                                                                 \
+    else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);              \
+    else gicp_align_kernel<L, false><<<grid, kAlignBlock, 0, st>>>(P, A, out)
+    switch (params->robust_type) {
+        case SP_LOSS_NONE: SP_LAUNCH_ALIGN(LOSS_NONE); break;
+        case SP_LOSS_HUBER: SP_LAUNCH_ALIGN(LOSS_HUBER); break;
+        case SP_LOSS_TUKEY: SP_LAUNCH_ALIGN(LOSS_TUKEY); break;
+        case SP_LOSS_CAUCHY: SP_LAUNCH_ALIGN(LOSS_CAUCHY); break;
+        case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_ALIGN(LOSS_GEMAN_MCCLURE); break;
+        default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
+    }
+#undef SP_LAUNCH_ALIGN
+    return launch_status();
+}
+
+extern "C" float* sp_gicp_align_rows(void* workspace, int k, size_t* n_floats_out) {
+    if (n_floats_out) *n_floats_out = (size_t)sp::kAlignMaxBlocks * sp::kPartial;
+    if (!workspace || k < 0) return nullptr;
+    return sp::align_ws(workspace).part[k & 1];
+}
+
+extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn,
+                                   int last_k, int rows_all_reduced, sp_linearized* lin_out, float* delta_out8,
+                                   uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (!source || !transT_device || !gn || last_k < 0) return SP_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(source->n)) {
+        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    const AlignWs w = align_ws(workspace);
+    const unsigned rows = rows_all_reduced ? (unsigned)kAlignMaxBlocks : align_grid(source->n);
+    if (g_fused_stage_mask & 2)
+        align_finish_kernel<<<1, kFinalThreads, 0, st>>>(w.part[last_k & 1], rows, &w.state[last_k & 1], gn->lambda,
+                                                         gn->crit_rotation, gn->crit_translation, transT_device, lin_out,
+                                                         delta_out8, iterations_out, rows_all_reduced ? 1 : 0);
+    return launch_status();
+}
+
 extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                                   const sp_factor_params* params, const sp_gn_params* gn, int max_iterations,
                                   int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
@@ -1200,61 +1312,19 @@ extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_s
     using namespace sp;
     hipStream_t st = as_stream(stream);
     if (!target || !source || !params || !gn || !transT_device) return SP_ERR_INVALID_ARGUMENT;
-    if (params->reg_type != SP_REG_GICP) {
-        sp_set_error("[sp_gicp_align_fused] only RegType::GICP has a prepared/fused form");
-        return SP_ERR_INVALID_ARGUMENT;
-    }
-    const size_t n = source->n;
-    if (n == 0 || max_iterations <= 0) {
+    if (source->n == 0 || max_iterations <= 0) {
         if (lin_out && hipMemsetAsync(lin_out, 0, sizeof(sp_linearized), st) != hipSuccess) return SP_ERR_HIP;
         if (delta_out8 && hipMemsetAsync(delta_out8, 0, 8 * sizeof(float), st) != hipSuccess) return SP_ERR_HIP;
         if (iterations_out && hipMemsetAsync(iterations_out, 0, sizeof(uint32_t), st) != hipSuccess) return SP_ERR_HIP;
         return SP_OK;
     }
-    if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
-        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
-        return SP_ERR_INVALID_ARGUMENT;
-    }
-    const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
-    // workspace: partial rows A | partial rows B | state A | state B
-    float* part[2] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + (size_t)kAlignMaxBlocks * kPartial};
-    AlignState* state = reinterpret_cast<AlignState*>(static_cast<float*>(workspace) + 2 * (size_t)kAlignMaxBlocks * kPartial);
-    unsigned grid = div_up(n, kAlignBlock);
-    if (grid > (unsigned)kAlignMaxBlocks) grid = kAlignMaxBlocks;
-    const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
     for (int k = 0; k < max_iterations; ++k) {
-        AlignArgs A;
-        A.T_init = transT_device;
-        A.state_in = &state[(k + 1) & 1];
-        A.state_out = &state[k & 1];
-        A.prev_partials = part[(k + 1) & 1];
-        A.prev_rows = grid;
-        A.has_prev = k > 0;
-        A.lambda = gn->lambda;
-        A.crit_rot = gn->crit_rotation;
-        A.crit_trans = gn->crit_translation;
-        A.lin_out = lin_out;
-        float* out = part[k & 1];
-#define SP_LAUNCH_ALIGN(L)                                                                            \
-    if (!(g_fused_stage_mask & 1)) {}                                                                 \
-    else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);                   \
-    else gicp_align_kernel<L, false><<<grid, kAlignBlock, 0, st>>>(P, A, out)
-        switch (params->robust_type) {
-            case SP_LOSS_NONE: SP_LAUNCH_ALIGN(LOSS_NONE); break;
-            case SP_LOSS_HUBER: SP_LAUNCH_ALIGN(LOSS_HUBER); break;
-            case SP_LOSS_TUKEY: SP_LAUNCH_ALIGN(LOSS_TUKEY); break;
-            case SP_LOSS_CAUCHY: SP_LAUNCH_ALIGN(LOSS_CAUCHY); break;
-            case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_ALIGN(LOSS_GEMAN_MCCLURE); break;
-            default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
-        }
-#undef SP_LAUNCH_ALIGN
+        const int rc = sp_gicp_align_step(target, source, transT_device, params, gn, k, 0, nn_idx_out, nn_d2_out, lin_out,
+                                          workspace, workspace_bytes, stream);
+        if (rc != SP_OK) return rc;
     }
-    const int last = max_iterations - 1;
-    if (g_fused_stage_mask & 2)
-        align_finish_kernel<<<1, kFinalThreads, 0, st>>>(part[last & 1], grid, &state[last & 1], gn->lambda, gn->crit_rotation,
-                                                     gn->crit_translation, transT_device, lin_out, delta_out8,
-                                                     iterations_out);
-    return launch_status();
+    return sp_gicp_align_finish(source, transT_device, gn, max_iterations - 1, 0, lin_out, delta_out8, iterations_out,
+                                workspace, workspace_bytes, stream);
 }
 
 extern "C" void sp_debug_set_fused_stage_mask(int mask) { g_fused_stage_mask = mask; }

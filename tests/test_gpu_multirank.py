@@ -1,6 +1,8 @@
-"""N > 1 path with the real kernels: two ranks share the one GPU of the test box (gloo moves the 192-byte system, which
-is what RCCL does on a multi-GPU node), each linearises its tile of the source, the systems are summed and every rank
-solves identically on the device. The pose must equal the single-rank run to rounding, for both device loops."""
+"""N > 1 path with the real kernels: two ranks share the one GPU of the test box (gloo moves the partial rows / the
+192-byte system, which is what RCCL does on a multi-GPU node), each linearises its tile of the source, the sums are
+all-reduced and every rank solves identically on the device. The pose must equal the single-rank run to rounding, for the
+one-launch-per-iteration loop (partial rows all-reduced, solve in the next launch's prologue), the two-launch fused
+loop and the generic loop."""
 import os
 import socket
 
@@ -51,10 +53,15 @@ def _worker(rank, world, port, n, iters, out_path):
     T1, lin1, _ = reg.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD)
     torch.cuda.synchronize()
     inl = reg._read_lin(lin1).inlier
+    iters_done = int(reg._iters_dev[0])
     reg2 = sp.Registration(p)
     T2, _, _ = reg2.align_device_loop(Sh, Tg, grid, iterations=iters, group=dist.group.WORLD)
+    reg3 = sp.Registration(p)
+    T3, lin3, _ = reg3.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD, per_iteration_launches=True)
     torch.cuda.synchronize()
-    np.save(out_path % rank, np.concatenate([T1.cpu().numpy(), T2.cpu().numpy(), [np.float32(inl)]]))
+    inl3 = reg3._read_lin(lin3).inlier
+    np.save(out_path % rank, np.concatenate([T1.cpu().numpy(), T2.cpu().numpy(), [np.float32(inl)], T3.cpu().numpy(),
+                                             [np.float32(inl3), np.float32(iters_done)]]))
     dist.destroy_process_group()
 
 
@@ -74,5 +81,7 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path):
     single = T_single.cpu().numpy()
     assert np.abs(r0[:16] - single).max() < 2e-6    # fused loop, sharded vs not
     assert np.abs(r0[16:32] - single).max() < 2e-6  # generic loop, sharded
-    assert int(r0[32]) == n                          # inlier count summed exactly over ranks
+    assert int(r0[32]) == n                          # inlier count summed exactly over ranks (float rows)
+    assert np.abs(r0[33:49] - single).max() < 2e-6  # two-launch fused loop, sharded
+    assert int(r0[49]) == n and int(r0[50]) == iters
     assert np.abs(single.reshape(4, 4).T - T_gt).max() < 5e-4
