@@ -98,6 +98,101 @@ __global__ __launch_bounds__(kBlock) void knn_bf_kernel(const float4* __restrict
     }
 }
 
+// k = 1 in 3.5 VALU instructions per (query, target) pair instead of 9:
+//   * eight queries per lane as four packed pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 evaluate two distances per instruction
+//     (each component is the same IEEE operation chain as dist2, so the values are bit-identical);
+//   * the scan keeps only the running MINIMUM (v_pk_min_f32, no compare + two selects per pair) and, once per sub-block
+//     of 64 targets, which sub-block produced it (strict '<': the earliest one);
+//   * the winner's index is recovered afterwards by re-evaluating that one sub-block in order and taking the first target
+//     whose distance equals the minimum — the lowest index among equal distances, the reference's tie rule. NaN
+//     distances never win either form (minNum semantics / `d < best` false).
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kSub = 64;   // targets per tracked sub-block (kTile % kSub == 0)
+constexpr int kQ1 = 8;     // queries per lane (four packed pairs: four independent dependency chains per target)
+
+// The target's coordinates arrive as the two aligned register pairs of one ds_read_b128, so each broadcast is an
+// op_sel on the packed instruction instead of a v_mov.
+__device__ __forceinline__ v2f pk_dist2(v2f qx, v2f qy, v2f qz, v2f pxy, v2f pzw) {
+    const v2f dx = qx - __builtin_shufflevector(pxy, pxy, 0, 0), dy = qy - __builtin_shufflevector(pxy, pxy, 1, 1),
+              dz = qz - __builtin_shufflevector(pzw, pzw, 0, 0);
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
+__global__ __launch_bounds__(kBlock) void knn_bf_k1_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                           const float4* __restrict__ targets, unsigned nt,
+                                                           unsigned chunk, int32_t* __restrict__ idx_out,
+                                                           float* __restrict__ d2_out) {
+    __shared__ float4 tile[kTile];
+    const unsigned split = blockIdx.y;
+    const unsigned t_begin = split * chunk;
+    const unsigned t_end = min(nt, t_begin + chunk);
+    unsigned qid[kQ1];
+    v2f qx[kQ1 / 2], qy[kQ1 / 2], qz[kQ1 / 2], best[kQ1 / 2];
+    unsigned bsub[kQ1];
+#pragma unroll
+    for (int u = 0; u < kQ1; ++u) {
+        qid[u] = (blockIdx.x * kQ1 + u) * kBlock + threadIdx.x;
+        const float4 q = queries[min(qid[u], nq - 1)];
+        qx[u >> 1][u & 1] = q.x; qy[u >> 1][u & 1] = q.y; qz[u >> 1][u & 1] = q.z;
+        best[u >> 1][u & 1] = FLT_MAX;
+        bsub[u] = 0xFFFFFFFFu;
+    }
+    for (unsigned base = t_begin; base < t_end; base += kTile) {
+        const unsigned cnt = min((unsigned)kTile, t_end - base);
+        __syncthreads();
+        // pad the tile with copies of its first point: a duplicate cannot change the minimum
+        for (unsigned i = threadIdx.x; i < kTile; i += kBlock) tile[i] = targets[base + (i < cnt ? i : 0u)];
+        __syncthreads();
+        const unsigned nsub = (cnt + kSub - 1) / kSub;
+        for (unsigned sb = 0; sb < nsub; ++sb) {
+            v2f m[kQ1 / 2];
+#pragma unroll
+            for (int h = 0; h < kQ1 / 2; ++h) m[h] = v2f{FLT_MAX, FLT_MAX};
+#pragma unroll 4
+            for (int j = 0; j < kSub; ++j) {
+                const float4 p = tile[sb * kSub + j];  // same address in every lane: one broadcast LDS read
+                const v2f pxy = {p.x, p.y}, pzw = {p.z, p.w};
+#pragma unroll
+                for (int h = 0; h < kQ1 / 2; ++h)
+                    m[h] = __builtin_elementwise_min(m[h], pk_dist2(qx[h], qy[h], qz[h], pxy, pzw));
+            }
+            const unsigned where = base + sb * kSub;
+#pragma unroll
+            for (int u = 0; u < kQ1; ++u) {
+                const float mu = m[u >> 1][u & 1];
+                const bool better = mu < best[u >> 1][u & 1];
+                best[u >> 1][u & 1] = better ? mu : best[u >> 1][u & 1];
+                bsub[u] = better ? where : bsub[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kQ1; ++u) {
+        if (qid[u] >= nq) continue;
+        const float b = best[u >> 1][u & 1];
+        int idx = -1;
+        if (bsub[u] != 0xFFFFFFFFu) {
+            const float x = qx[u >> 1][u & 1], y = qy[u >> 1][u & 1], z = qz[u >> 1][u & 1];
+            const unsigned e = min(t_end, bsub[u] + kSub);
+            unsigned first = 0xFFFFFFFFu;  // lowest matching index: branch-free, 8 independent loads per step
+            for (unsigned j0 = bsub[u]; j0 < e; j0 += 8) {
+                float4 pp[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) pp[t] = targets[min(j0 + t, e - 1)];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const bool hit = (j0 + t < e) && dist2(x, y, z, pp[t].x, pp[t].y, pp[t].z) == b;
+                    first = min(first, hit ? j0 + t : 0xFFFFFFFFu);
+                }
+            }
+            idx = first == 0xFFFFFFFFu ? -1 : (int)first;
+        }
+        const size_t o = (size_t)split * nq + qid[u];
+        d2_out[o] = b;
+        idx_out[o] = idx;
+    }
+}
+
 // Merge nsplit sorted partial lists per query, in chunk order (ascending target index at equal distance).
 template <int KCAP>
 __global__ __launch_bounds__(kBlock) void knn_bf_merge_kernel(const int32_t* __restrict__ pidx,
@@ -132,7 +227,7 @@ struct BfPlan {
 
 BfPlan plan(size_t nq, size_t nt, size_t k) {
     BfPlan p;
-    p.qpt = (k == 1) ? 2 : 1;
+    p.qpt = (k == 1) ? kQ1 : 1;
     p.qblocks = div_up(nq, (size_t)kBlock * p.qpt);
     const unsigned max_split = div_up(nt, kTile);
     unsigned want = div_up((size_t)kNumCU * 4, p.qblocks);  // >= 4 workgroups per CU
@@ -163,6 +258,22 @@ int run(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t*
     if (p.nsplit > 1)
         knn_bf_merge_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(pidx, pd2, (unsigned)nq, (int)k, p.nsplit,
                                                                           idx, d2);
+    return launch_status();
+}
+
+int run_k1(const float* q, size_t nq, const float* t, size_t nt, int32_t* idx, float* d2, void* ws, const BfPlan& p,
+           hipStream_t st) {
+    int32_t* pidx = idx;
+    float* pd2 = d2;
+    if (p.nsplit > 1) {
+        pidx = static_cast<int32_t*>(ws);
+        pd2 = reinterpret_cast<float*>(pidx + (size_t)p.nsplit * nq);
+    }
+    knn_bf_k1_kernel<<<dim3(p.qblocks, p.nsplit), kBlock, 0, st>>>(reinterpret_cast<const float4*>(q), (unsigned)nq,
+                                                                   reinterpret_cast<const float4*>(t), (unsigned)nt,
+                                                                   p.chunk, pidx, pd2);
+    if (p.nsplit > 1)
+        knn_bf_merge_kernel<1><<<div_up(nq, kBlock), kBlock, 0, st>>>(pidx, pd2, (unsigned)nq, 1, p.nsplit, idx, d2);
     return launch_status();
 }
 
@@ -205,7 +316,7 @@ extern "C" int sp_knn_bruteforce(const float* queries, size_t nq, const float* t
         sp_set_error("[knn_search_bruteforce] workspace too small (sp_knn_bruteforce_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
     }
-    if (k == 1) return run<1, 2>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
+    if (k == 1) return run_k1(queries, nq, targets, nt, idx_out, d2_out, workspace, p, st);
     if (k <= 5) return run<5, 1>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
     if (k <= 10) return run<10, 1>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
     return run<20, 1>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, p, st);
