@@ -5,6 +5,7 @@
 //   algorithms/common/filter_by_flags.hpp        : filter::FilterByFlags
 //   algorithms/common/transform.hpp              : transform::transform, transform_copy
 #pragma once
+#include <cctype>
 #include <numeric>
 #include <random>
 
@@ -30,6 +31,21 @@ inline uint32_t read_u32(const void* dev, hipStream_t st) {
     return v;
 }
 }  // namespace detail
+
+// ================================================================================================ robust loss tags
+namespace robust {
+enum class RobustLossType { NONE, HUBER, TUKEY, CAUCHY, GEMAN_MCCLURE };  // robust/robust.hpp:13-19
+inline RobustLossType RobustLossType_from_string(const std::string& str) {
+    std::string u = str;
+    for (auto& c : u) c = (char)std::toupper((unsigned char)c);
+    if (u == "NONE") return RobustLossType::NONE;
+    if (u == "HUBER") return RobustLossType::HUBER;
+    if (u == "TUKEY") return RobustLossType::TUKEY;
+    if (u == "CAUCHY") return RobustLossType::CAUCHY;
+    if (u == "GEMAN_MCCLURE") return RobustLossType::GEMAN_MCCLURE;
+    throw std::runtime_error("[RobustLossType_from_string] Invalid RobustLossType str '" + str + "'");
+}
+}  // namespace robust
 
 // ================================================================================================ covariance
 namespace covariance {
@@ -66,6 +82,42 @@ inline sycl_utils::events estimate_async(const knn::KNNBase& knn, const PointClo
     knn::KNNResult neighbors;
     auto ev = knn.knn_search_async(points, k, neighbors, depends);
     return estimate_async(neighbors, points, ev.evs);
+}
+/// covariance.hpp:323-381 — M-estimated covariances (K8)
+inline sycl_utils::events estimate_robust_async(const sycl_utils::DeviceQueue& queue, const knn::KNNResult& neighbors,
+                                                const PointContainerShared& points, CovarianceContainerShared& covs,
+                                                robust::RobustLossType robust_type = robust::RobustLossType::CAUCHY,
+                                                float mad_scale = 1.0f, float min_robust_scale = 1.0f,
+                                                size_t robust_max_iterations = 1,
+                                                const std::vector<sycl_utils::event>& = {}) {
+    if (neighbors.k > 64) throw std::runtime_error("[covariance::estimate_robust_async] neighbor K is too large. MAX_K is 64");
+    const size_t N = points.size();
+    if (N == 0) { covs.resize(0); return sycl_utils::events(); }
+    throw_on_error(sp_cov_estimate_robust(reinterpret_cast<const float*>(points.device_data()), N,
+                                          neighbors.indices->device_data(), neighbors.k, int(robust_type), mad_scale,
+                                          min_robust_scale, robust_max_iterations,
+                                          reinterpret_cast<float*>(covs.device_data_for_write(N)), queue.stream()));
+    return sycl_utils::events(queue.stream());
+}
+/// covariance.hpp:383-390
+inline sycl_utils::events estimate_robust_async(const knn::KNNResult& neighbors, const PointCloudShared& points,
+                                                robust::RobustLossType robust_type = robust::RobustLossType::CAUCHY,
+                                                float mad_scale = 1.0f, float min_robust_scale = 1.0f,
+                                                size_t robust_max_iterations = 1,
+                                                const std::vector<sycl_utils::event>& depends = {}) {
+    return estimate_robust_async(points.queue, neighbors, *points.points, *points.covs, robust_type, mad_scale,
+                                 min_robust_scale, robust_max_iterations, depends);
+}
+/// covariance.hpp:400-411
+inline sycl_utils::events estimate_robust_async(const knn::KNNBase& knn, const PointCloudShared& points,
+                                                const size_t k_correspondences,
+                                                robust::RobustLossType robust_type = robust::RobustLossType::CAUCHY,
+                                                float mad_scale = 1.0f, float min_robust_scale = 1.0f,
+                                                size_t robust_max_iterations = 1,
+                                                const std::vector<sycl_utils::event>& depends = {}) {
+    knn::KNNResult neighbors;
+    auto ev = knn.knn_search_async(points, k_correspondences, neighbors, depends);
+    return estimate_robust_async(neighbors, points, robust_type, mad_scale, min_robust_scale, robust_max_iterations, ev.evs);
 }
 /// covariance.hpp:417-443
 inline sycl_utils::events estimate_normals_async(const knn::KNNResult& neighbors, const PointCloudShared& points,

@@ -20,19 +20,7 @@
 namespace sycl_points {
 namespace algorithms {
 
-namespace robust {
-enum class RobustLossType { NONE, HUBER, TUKEY, CAUCHY, GEMAN_MCCLURE };  // robust/robust.hpp:13-19
-inline RobustLossType RobustLossType_from_string(const std::string& str) {
-    std::string u = str;
-    for (auto& c : u) c = (char)std::toupper((unsigned char)c);
-    if (u == "NONE") return RobustLossType::NONE;
-    if (u == "HUBER") return RobustLossType::HUBER;
-    if (u == "TUKEY") return RobustLossType::TUKEY;
-    if (u == "CAUCHY") return RobustLossType::CAUCHY;
-    if (u == "GEMAN_MCCLURE") return RobustLossType::GEMAN_MCCLURE;
-    throw std::runtime_error("[RobustLossType_from_string] Invalid RobustLossType str '" + str + "'");
-}
-}  // namespace robust
+// robust::RobustLossType lives in features.hpp (covariance::estimate_robust_async needs it too)
 
 namespace registration {
 

@@ -105,6 +105,15 @@ int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_
 
 /* covariance::estimate_async (algorithms/feature/covariance.hpp:16-47, 260-311, kernel K5). */
 int sp_cov_estimate(const float* points, size_t n, const int32_t* knn_idx, size_t k, float* covs_out, void* stream);
+/* covariance::estimate_robust_async (feature/covariance.hpp:97-250, 323-381): M-estimated neighbourhood covariance —
+ * weighted estimate, Mahalanobis distances to it, their median (x mad_scale, floored at min_robust_scale) as the scale of
+ * the IRLS weights, robust_max_iterations times. k <= 64 ("neighbor K is too large. MAX_K is 64" -> SP_ERR_RUNTIME);
+ * robust_type SP_LOSS_NONE is sp_cov_estimate. */
+int sp_cov_estimate_robust(const float* points, size_t n, const int32_t* knn_idx, size_t k, int robust_type,
+                           float mad_scale, float min_robust_scale, size_t robust_max_iterations, float* covs_out,
+                           void* stream);
+/* covariance::kernel::normalize_covariance (feature/covariance.hpp:76-95) over a covariance array (in place allowed). */
+int sp_cov_normalize(const float* covs, size_t n, float* covs_out, void* stream);
 /* covariance::estimate_normals_async (covariance.hpp:49-65, 417-459, kernel K6). */
 int sp_normals_from_knn(const float* points, size_t n, const int32_t* knn_idx, size_t k, float* normals_out,
                         void* stream);

@@ -10,6 +10,7 @@
 #include "oracle_knn.hpp"
 #include "oracle_math.hpp"
 #include "oracle_registration.hpp"
+#include "oracle_robust_cov.hpp"
 
 using namespace oracle;
 
@@ -109,6 +110,16 @@ void orc_kdtree_remove_by_flags(void* nodes, size_t n_nodes, const uint8_t* flag
 void orc_cov_estimate(const float* pts, size_t n, const int32_t* idx, size_t k, float* covs) {
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < (long long)n; ++i) cov_estimate_one(covs + 16 * i, pts, k, idx, (size_t)i);
+}
+void orc_cov_estimate_robust(const float* pts, size_t n, const int32_t* idx, size_t k, int robust_type, float mad_scale,
+                             float min_robust_scale, size_t max_iter, float* covs) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i)
+        cov_estimate_robust_one(covs + 16 * i, pts, k, idx, (size_t)i, robust_type, mad_scale, min_robust_scale, max_iter);
+}
+void orc_cov_normalize(float* covs, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) normalize_covariance(covs + 16 * i);
 }
 void orc_normals_from_knn(const float* pts, size_t n, const int32_t* idx, size_t k, float* normals) {
 #pragma omp parallel for schedule(static)

@@ -216,6 +216,20 @@ class Oracle:
         self.lib.orc_cov_estimate(_p(pts), C.c_size_t(len(pts)), _p(idx, C.c_int32), C.c_size_t(idx.shape[1]), _p(covs))
         return covs
 
+    def cov_estimate_robust(self, pts, idx, robust_type="CAUCHY", mad_scale=1.0, min_robust_scale=1.0, max_iterations=1):
+        pts = _f(pts)
+        idx = np.ascontiguousarray(idx, np.int32)
+        covs = np.empty((len(pts), 16), np.float32)
+        self.lib.orc_cov_estimate_robust(_p(pts), C.c_size_t(len(pts)), _p(idx, C.c_int32), C.c_size_t(idx.shape[1]),
+                                         C.c_int(LOSS[robust_type]), C.c_float(mad_scale), C.c_float(min_robust_scale),
+                                         C.c_size_t(max_iterations), _p(covs))
+        return covs
+
+    def cov_normalize(self, covs):
+        out = _f(covs).copy()
+        self.lib.orc_cov_normalize(_p(out), C.c_size_t(len(out)))
+        return out
+
     def normals_from_knn(self, pts, idx):
         pts = _f(pts)
         idx = np.ascontiguousarray(idx, np.int32)

@@ -63,6 +63,8 @@ SIGNATURES = {
     "sp_grid_self_workspace_bytes": (_sz, [_vp]),
     "sp_grid_self_knn": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_cov_estimate": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "sp_cov_estimate_robust": (_i, [_vp, _sz, _vp, _sz, _i, _f, _f, _sz, _vp, _vp]),
+    "sp_cov_normalize": (_i, [_vp, _sz, _vp, _vp]),
     "sp_normals_from_knn": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "sp_normals_from_cov": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "sp_cov_update_plane": (_i, [_vp, _sz, _vp, _vp]),

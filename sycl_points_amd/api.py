@@ -328,6 +328,27 @@ class covariance:
         return covs
 
     @staticmethod
+    def estimate_robust(neighbors, points, robust_type="CAUCHY", mad_scale=1.0, min_robust_scale=1.0,
+                        robust_max_iterations=1):
+        """estimate_robust_async (covariance.hpp:323-381): M-estimated covariances, same layout as estimate()."""
+        p = _dev_f32(_points_of(points), 4)
+        idx = neighbors.indices if isinstance(neighbors, KNNResult) else neighbors
+        covs = torch.empty((p.shape[0], 16), dtype=torch.float32, device=p.device)
+        check(_lib.lib().sp_cov_estimate_robust(_ptr(p), p.shape[0], _ptr(idx), idx.shape[1] if idx.dim() == 2 else 0,
+                                                LOSS[robust_type], mad_scale, min_robust_scale, robust_max_iterations,
+                                                _ptr(covs), _stream()))
+        if isinstance(points, PointCloudShared):
+            points.covs = covs
+        return covs
+
+    @staticmethod
+    def normalize_covariance(covs):
+        """kernel::normalize_covariance over an array (covariance.hpp:76-95)"""
+        out = torch.empty_like(covs)
+        check(_lib.lib().sp_cov_normalize(_ptr(covs), covs.shape[0], _ptr(out), _stream()))
+        return out
+
+    @staticmethod
     def estimate_normals(neighbors, points):
         """estimate_normals_async (covariance.hpp:417-459)"""
         p = _dev_f32(_points_of(points), 4)

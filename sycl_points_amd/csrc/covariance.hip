@@ -108,6 +108,108 @@ __global__ __launch_bounds__(kBlock) void cov_plane_kernel(const float4* __restr
     store_cov(out + 4 * (size_t)i, P);
 }
 
+// ---- K8: M-estimated covariance (covariance.hpp:97-250, 323-381) and normalize_covariance (:76-95)
+// One lane per point, a literal restatement: weighted sums in neighbour order, Mahalanobis distances to the current
+// estimate, their median by insertion sort, IRLS weights, repeat. The two per-lane work arrays (weights / squared
+// distances, up to 64 entries each, indexed at run time) live in LDS as [entry][lane] columns — conflict-free, and a
+// private array indexed at run time would be placed in scratch memory.
+constexpr int kRobustBlock = 128;
+constexpr int kRobustMaxK = 64;
+
+__device__ __forceinline__ bool estimate_cov_weighted(const float4* __restrict__ pts, const int32_t* __restrict__ nbr,
+                                                      int k, const float* w /* LDS column, stride kRobustBlock */,
+                                                      Mat3& C, float& mx, float& my, float& mz) {
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    float oxx = 0.0f, oxy = 0.0f, oxz = 0.0f, oyy = 0.0f, oyz = 0.0f, ozz = 0.0f;
+    float tw = 0.0f;
+    unsigned cnt = 0;
+    for (int j = 0; j < k; ++j) {
+        const int idx = nbr[j];
+        if (idx < 0) continue;
+        const float4 p = pts[idx];
+        const float wj = w[j * kRobustBlock];
+        sx += p.x * wj; sy += p.y * wj; sz += p.z * wj;
+        oxx += (p.x * p.x) * wj; oxy += (p.x * p.y) * wj; oxz += (p.x * p.z) * wj;
+        oyy += (p.y * p.y) * wj; oyz += (p.y * p.z) * wj; ozz += (p.z * p.z) * wj;
+        ++cnt;
+        tw += wj;
+    }
+    if (cnt < 4 || tw < FLT_EPSILON) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) C.m[i][j] = (i == j) ? 1.0f : 0.0f;
+        return false;
+    }
+    const float inv = 1.0f / tw;
+    mx = sx * inv; my = sy * inv; mz = sz * inv;
+    const float cxx = oxx * inv - mx * mx, cxy = oxy * inv - mx * my, cxz = oxz * inv - mx * mz;
+    const float cyy = oyy * inv - my * my, cyz = oyz * inv - my * mz, czz = ozz * inv - mz * mz;
+    const float sxy = (cxy + cxy) * 0.5f, sxz = (cxz + cxz) * 0.5f, syz = (cyz + cyz) * 0.5f;
+    C.m[0][0] = cxx; C.m[0][1] = sxy; C.m[0][2] = sxz;
+    C.m[1][0] = sxy; C.m[1][1] = cyy; C.m[1][2] = syz;
+    C.m[2][0] = sxz; C.m[2][1] = syz; C.m[2][2] = czz;
+    return true;
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(kRobustBlock) void cov_robust_kernel(const float4* __restrict__ pts, unsigned n,
+                                                                  const int32_t* __restrict__ knn, int k,
+                                                                  float mad_scale, float min_scale, unsigned max_iter,
+                                                                  float4* __restrict__ covs) {
+    __shared__ float s_w[kRobustMaxK * kRobustBlock];
+    __shared__ float s_d[kRobustMaxK * kRobustBlock];
+    const unsigned i = blockIdx.x * kRobustBlock + threadIdx.x;
+    if (i >= n) return;
+    float* const w = s_w + threadIdx.x;
+    float* const d = s_d + threadIdx.x;
+    const int32_t* nbr = knn + (size_t)i * k;
+    for (int j = 0; j < k; ++j) { w[j * kRobustBlock] = 1.0f; d[j * kRobustBlock] = 0.0f; }
+    Mat3 C;
+    float mx = 0.0f, my = 0.0f, mz = 0.0f;
+    bool ok = estimate_cov_weighted(pts, nbr, k, w, C, mx, my, mz);
+    for (unsigned it = 0; ok && it < max_iter; ++it) {
+        const Mat3 Ci = inverse(C);
+        for (int j = 0; j < k; ++j) {
+            const int idx = nbr[j];
+            if (idx < 0) continue;
+            const float4 p = pts[idx];
+            const float d0 = p.x - mx, d1 = p.y - my, d2 = p.z - mz;
+            // dot<4>(diff, multiply<4,4>(cov_inv, diff)): fma chains from 0, the fourth terms are exact zeros
+            const float v0 = fmaf(Ci.m[0][2], d2, fmaf(Ci.m[0][1], d1, fmaf(Ci.m[0][0], d0, 0.0f)));
+            const float v1 = fmaf(Ci.m[1][2], d2, fmaf(Ci.m[1][1], d1, fmaf(Ci.m[1][0], d0, 0.0f)));
+            const float v2 = fmaf(Ci.m[2][2], d2, fmaf(Ci.m[2][1], d1, fmaf(Ci.m[2][0], d0, 0.0f)));
+            d[j * kRobustBlock] = fmaf(d2, v2, fmaf(d1, v1, fmaf(d0, v0, 0.0f)));
+        }
+        // compute_median (covariance.hpp:143-173): insertion sort of a copy (the weights array is the buffer)
+        for (int j = 0; j < k; ++j) w[j * kRobustBlock] = d[j * kRobustBlock];
+        for (int a = 1; a < k; ++a) {
+            const float key = w[a * kRobustBlock];
+            int j = a;
+            while (j > 0 && w[(j - 1) * kRobustBlock] > key) {
+                w[j * kRobustBlock] = w[(j - 1) * kRobustBlock];
+                --j;
+            }
+            w[j * kRobustBlock] = key;
+        }
+        const int mid = k / 2;
+        const float median = (k % 2 == 0) ? (w[(mid - 1) * kRobustBlock] + w[mid * kRobustBlock]) * 0.5f
+                                          : w[mid * kRobustBlock];
+        float scale = mad_scale * median;
+        if (scale < min_scale) scale = min_scale;
+        for (int j = 0; j < k; ++j) w[j * kRobustBlock] = robust_weight<LOSS>(d[j * kRobustBlock], scale);
+        ok = estimate_cov_weighted(pts, nbr, k, w, C, mx, my, mz);
+    }
+    store_cov(covs + 4 * (size_t)i, C);
+}
+
+__global__ __launch_bounds__(kBlock) void cov_normalize_kernel(const float4* __restrict__ covs, unsigned n,
+                                                               float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    store_cov(out + 4 * (size_t)i, normalize_cov(load_cov(covs + 4 * (size_t)i)));
+}
+
 }  // namespace
 }  // namespace sp
 
@@ -144,5 +246,42 @@ extern "C" int sp_cov_update_plane(const float* covs, size_t n, float* covs_out,
     if (n == 0) return SP_OK;
     cov_plane_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(covs),
                                                                           (unsigned)n, reinterpret_cast<float4*>(covs_out));
+    return launch_status();
+}
+
+extern "C" int sp_cov_estimate_robust(const float* points, size_t n, const int32_t* knn_idx, size_t k, int robust_type,
+                                      float mad_scale, float min_robust_scale, size_t robust_max_iterations,
+                                      float* covs_out, void* stream) {
+    using namespace sp;
+    if (k > (size_t)kRobustMaxK) {
+        sp_set_error("[covariance::estimate_robust_async] neighbor K is too large. MAX_K is 64");
+        return SP_ERR_RUNTIME;
+    }
+    if (n == 0) return SP_OK;
+    if (k == 0) return SP_ERR_INVALID_ARGUMENT;
+    if (robust_type == SP_LOSS_NONE) return sp_cov_estimate(points, n, knn_idx, k, covs_out, stream);
+    const unsigned grid = div_up(n, kRobustBlock);
+    hipStream_t st = as_stream(stream);
+    const float4* p = reinterpret_cast<const float4*>(points);
+    float4* c = reinterpret_cast<float4*>(covs_out);
+    const unsigned it = (unsigned)robust_max_iterations;
+#define SP_ROBUST(L) cov_robust_kernel<L><<<grid, kRobustBlock, 0, st>>>(p, (unsigned)n, knn_idx, (int)k, mad_scale, min_robust_scale, it, c)
+    switch (robust_type) {
+        case SP_LOSS_HUBER: SP_ROBUST(LOSS_HUBER); break;
+        case SP_LOSS_TUKEY: SP_ROBUST(LOSS_TUKEY); break;
+        case SP_LOSS_CAUCHY: SP_ROBUST(LOSS_CAUCHY); break;
+        case SP_LOSS_GEMAN_MCCLURE: SP_ROBUST(LOSS_GEMAN_MCCLURE); break;
+        default: sp_set_error("[covariance::estimate_robust_async] unknown robust loss type"); return SP_ERR_INVALID_ARGUMENT;
+    }
+#undef SP_ROBUST
+    return launch_status();
+}
+
+extern "C" int sp_cov_normalize(const float* covs, size_t n, float* covs_out, void* stream) {
+    using namespace sp;
+    if (n == 0) return SP_OK;
+    cov_normalize_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(covs),
+                                                                              (unsigned)n,
+                                                                              reinterpret_cast<float4*>(covs_out));
     return launch_status();
 }

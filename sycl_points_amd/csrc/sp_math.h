@@ -219,6 +219,37 @@ SP_HD Mat3 plane_regularize(const Mat3& C) {
     return matmul_bt(X, V);
 }
 
+// covariance::kernel::normalize_covariance (feature/covariance.hpp:76-95): eigenvalues of 1e3*C scaled by the largest,
+// the two smaller ones clamped to [1e-3, 1]; identity when the largest is below FLT_MIN.
+SP_HD Mat3 normalize_cov(const Mat3& C) {
+    Mat3 S;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) S.m[i][j] = C.m[i][j] * 1e3f;
+    float ev[3];
+    Mat3 V;
+    symmetric_eigen3(S, ev, V);
+    const float mx = ev[2];
+    Mat3 X;
+    if (mx < FLT_MIN) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) X.m[i][j] = (i == j) ? 1.0f : 0.0f;
+        return X;
+    }
+    auto clamp01 = [](float v) { return v < 1e-3f ? 1e-3f : (1.0f < v ? 1.0f : v); };  // std::clamp(v, 1e-3f, 1.0f)
+    const float e0 = clamp01(ev[0] / mx), e1 = clamp01(ev[1] / mx);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        X.m[i][0] = fmaf(V.m[i][0], e0, 0.0f);
+        X.m[i][1] = fmaf(V.m[i][1], e1, 0.0f);
+        X.m[i][2] = V.m[i][2];
+    }
+    return matmul_bt(X, V);
+}
+
 // ---------------------------------------------------------------- robust kernels (robust/robust.hpp:56-114)
 enum Loss : int { LOSS_NONE = 0, LOSS_HUBER = 1, LOSS_TUKEY = 2, LOSS_CAUCHY = 3, LOSS_GEMAN_MCCLURE = 4 };
 

@@ -2,6 +2,7 @@
 // own gtest files: cpp/tests/test_kdtree.cpp, test_downsampling_filters.cpp, test_preprocess_filter.cpp and the
 // KNNBase-injection idiom of test_registration_pipeline.cpp:16-61. The CPU oracle (oracle/, test infrastructure) is the
 // checker for registration. Runs on a GPU box; exit code 0 = all checks passed.
+#include <cstring>
 #include <cstdio>
 #include <random>
 
@@ -28,6 +29,8 @@ struct orc_reg_result { float T[16]; float H[36]; float b[6]; float error; uint3
 extern "C" {
 void orc_knn_bruteforce(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t* idx, float* d2);
 void orc_cov_estimate(const float* pts, size_t n, const int32_t* idx, size_t k, float* covs);
+void orc_cov_estimate_robust(const float* pts, size_t n, const int32_t* idx, size_t k, int robust_type, float mad_scale,
+                             float min_robust_scale, size_t max_iter, float* covs);
 void orc_registration_align(const orc_reg_params* P, const float* src, const float* src_cov, size_t ns, const float* tgt,
                             const float* tgt_cov, const float* tgt_nrm, size_t nt, const float* init_T16, int nn_mode,
                             orc_reg_result* out, float* trace_T, int* trace_n, const void* prebuilt_nodes,
@@ -194,6 +197,15 @@ static void registration_matches_oracle() {
         size_t diff = 0;
         for (size_t i = 0; i < n; ++i) diff += !((*t2.covs)[i] == (*target.covs)[i]);
         CHECK(diff <= n / 1000);  // only exact-distance ties may order differently
+        // M-estimated covariances through the same seam (covariance.hpp:323-411), against the oracle bit for bit
+        const auto nb = tree->knn_search(t2, 20);
+        alg::covariance::estimate_robust_async(nb, t2, alg::robust::RobustLossType::CAUCHY, 1.0f, 0.1f, 2).wait_and_throw();
+        std::vector<float> ref(16 * n);
+        orc_cov_estimate_robust(reinterpret_cast<const float*>(t2.points->data()), n, nb.indices->data(), 20, 3, 1.0f, 0.1f,
+                                2, ref.data());
+        size_t bad = 0;
+        for (size_t i = 0; i < n; ++i) bad += std::memcmp((*t2.covs)[i].data(), ref.data() + 16 * i, 64) != 0;
+        CHECK(bad == 0);
     }
     alg::registration::RegistrationParams p;
     p.max_iterations = 12;

@@ -467,6 +467,38 @@ def test_gicp_config4_1m(sp, orc):
     assert np.allclose(H, ref["H"], atol=2e-5 * np.abs(ref["H"]).max()) and g2.inlier == ref["inlier"]
 
 
+# ------------------------------------------------------------------ K8: M-estimated covariance, normalize_covariance
+@pytest.mark.parametrize("loss", ["HUBER", "TUKEY", "CAUCHY", "GEMAN_MCCLURE", "NONE"])
+@pytest.mark.parametrize("k", [10, 20, 33])
+def test_robust_covariance_bitexact(sp, orc, loss, k):
+    pts = cloud(orc, 21, 6000, 3.0)
+    pts[:3000, 2] *= 0.02  # a thin slab: strongly anisotropic neighbourhoods next to isotropic ones
+    oi, _ = orc.kdtree_knn(orc.kdtree_build(pts), pts, k)  # (the brute-force oracle stops at k = 20 like the reference)
+    oi = np.ascontiguousarray(oi)
+    oi[5, 7:] = -1         # fewer neighbours
+    oi[6, 3:] = -1         # < 4 neighbours: identity
+    idx = dev(oi)
+    for iters, mad, mn in ((1, 1.0, 1.0), (3, 2.5, 0.05)):
+        got = sp.covariance.estimate_robust(idx, dev(pts), loss, mad, mn, iters).cpu().numpy()
+        ref = orc.cov_estimate_robust(pts, oi, loss, mad, mn, iters)
+        assert np.array_equal(got, ref), (loss, k, iters, np.abs(got - ref).max())
+    plain = sp.covariance.estimate(idx, dev(pts)).cpu().numpy()
+    assert np.array_equal(sp.covariance.estimate_robust(idx, dev(pts), loss, 1.0, 1.0, 0).cpu().numpy(), plain)
+
+
+def test_robust_covariance_k_limit_and_normalize(sp, orc):
+    pts = cloud(orc, 22, 2000, 2.0)
+    oi, _ = orc.knn_bruteforce(pts, pts, 20)
+    with pytest.raises(sp.SpError):
+        sp.covariance.estimate_robust(dev(np.zeros((10, 65), np.int32)), dev(pts[:10]))
+    covs = orc.cov_estimate(pts, oi)
+    covs[3] = 0.0  # largest eigenvalue below FLT_MIN: identity block
+    got = sp.covariance.normalize_covariance(dev(covs)).cpu().numpy()
+    ref = orc.cov_normalize(covs)
+    assert np.abs(got - ref).max() < 2e-5  # through acosf / cosf (eigen-decomposition), like the normals
+    assert np.array_equal(got[3].reshape(4, 4)[:3, :3], np.eye(3, dtype=np.float32))
+
+
 # ------------------------------------------------------------------ GridKNN (MI355X-native KNNBase)
 @pytest.mark.parametrize("k", [1, 2, 5, 10, 20])
 @pytest.mark.parametrize("ppc", [0.3, 2.0, 8.0])

@@ -292,3 +292,26 @@ def test_random_sampling_deterministic(orc):
     b = orc.random_sampling_flags(42, 5, 2)
     assert a.sum() == 2 and np.array_equal(a, b)
     assert orc.random_sampling_flags(42, 3, 5).sum() == 3
+
+
+def test_robust_covariance_restatement_consistency(orc):
+    """covariance.hpp:182-250 has no known-answer test in the reference; what can be pinned on the CPU: zero IRLS
+    iterations (unit weights) reproduce covariance::kernel::estimate bit for bit, every result is symmetric, outliers
+    are down-weighted (the robust covariance of a plane patch with one far outlier has a smaller trace than the plain
+    one), and normalize_covariance yields eigenvalues in [1e-3, 1] with the largest equal to 1."""
+    g = orc.rng(5)
+    pts = g.uniform_points(800, 2.0)
+    pts[:, 2] *= 0.01
+    pts[0, 2] = 3.0  # one far outlier
+    oi, _ = orc.knn_bruteforce(pts, pts, 12)
+    oi[:, -1] = 0    # every neighbourhood contains the outlier
+    plain = orc.cov_estimate(pts, oi)
+    assert np.array_equal(orc.cov_estimate_robust(pts, oi, "CAUCHY", 1.0, 1.0, 0), plain)
+    rob = orc.cov_estimate_robust(pts, oi, "CAUCHY", 1.0, 1.0, 2)
+    c = rob.reshape(-1, 4, 4)[:, :3, :3]
+    assert np.array_equal(c, np.transpose(c, (0, 2, 1)))
+    tr_plain = np.trace(plain.reshape(-1, 4, 4)[:, :3, :3], axis1=1, axis2=2)
+    assert (np.trace(c, axis1=1, axis2=2)[1:] < tr_plain[1:]).mean() > 0.8
+    nc = orc.cov_normalize(plain).reshape(-1, 4, 4)[:, :3, :3].astype(np.float64)
+    ev = np.linalg.eigvalsh(nc)
+    assert np.abs(ev[:, 2] - 1.0).max() < 1e-4 and ev.min() > 1e-3 - 1e-5
