@@ -65,8 +65,13 @@ struct RegistrationOptimizationParams {
         size_t max_inner_iterations = 10;
         float lambda_factor = 2.0f, init_lambda = 1.0f, max_lambda = 1e3f, min_lambda = 1e-6f;
     };
+    struct Dogleg {  // registration_params.hpp:84-92
+        float initial_trust_region_radius = 1.0f, min_trust_region_radius = 1e-4f, max_trust_region_radius = 10.0f;
+        float eta1 = 0.25f, eta2 = 0.75f, gamma_decrease = 0.25f, gamma_increase = 2.0f;
+    };
     GaussNewton gn;
     LevenbergMarquardt lm;
+    Dogleg dogleg;
     OptimizationMethod optimization_method = OptimizationMethod::GAUSS_NEWTON;
 };
 struct RegistrationParams : public RegistrationFactorParams, public RegistrationOptimizationParams {
@@ -160,6 +165,7 @@ public:
         validate_params(source, target, params_);
         const float robust_scale = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
         float lm_lambda = params_.lm.init_lambda;
+        float trust_region_radius = params_.dogleg.initial_trust_region_radius;
         const auto* grid = dynamic_cast<const knn::GridKNN*>(&target_knn);
         const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size();
         if (fused) prepare_fused(source, target, *grid, initial_guess);
@@ -181,7 +187,8 @@ public:
                     optimize_gauss_newton(result, lin, iter);
                     break;
                 case OptimizationMethod::POWELL_DOGLEG:
-                    throw std::runtime_error("[Registration::align] POWELL_DOGLEG is not implemented in this build");
+                    optimize_powell_dogleg(source, target, result, lin, trust_region_radius, iter, robust_scale);
+                    break;
             }
             if (result.converged) break;
         }
@@ -382,6 +389,47 @@ private:
         result.iterations = iter;
         result.H = lin.H; result.b = lin.b;
         return updated;
+    }
+
+    bool optimize_powell_dogleg(const PointCloudShared& source, const PointCloudShared& target, RegistrationResult& result,
+                                const LinearizedResult& lin, float& trust_region_radius, size_t iter,
+                                float robust_scale) const {  // registration.hpp:897-965 (no MAP prior in this build)
+        result.H = lin.H; result.b = lin.b; result.error = lin.error; result.inlier = lin.inlier; result.iterations = iter;
+        const auto& dl = params_.dogleg;
+        const auto clamp_radius = [&](float r) { return std::clamp(r, dl.min_trust_region_radius, dl.max_trust_region_radius); };
+        trust_region_radius = clamp_radius(trust_region_radius);
+        float H36[36], g6[6], p6[6], step_norm = 0.0f, predicted = 0.0f;
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) H36[i * 6 + j] = lin.H(i, j);
+            g6[i] = lin.b(i);
+        }
+        sp_dogleg_step_host(H36, g6, trust_region_radius, p6, &step_norm, &predicted);  // dogleg_step.hpp:35-101
+        if (predicted <= 0.0f) {
+            trust_region_radius = clamp_radius(trust_region_radius * dl.gamma_decrease);
+            return false;
+        }
+        TransformMatrix E, new_T;
+        sp_se3_exp_host(p6, E.data());
+        const TransformMatrix cur = result.T.matrix();
+        sp_rigid_mul_host(cur.data(), E.data(), new_T.data());
+        const auto [new_error, inlier] = compute_error(source, target, new_T, robust_scale);
+        const float rho = (lin.error - new_error) / predicted;
+        if (params_.verbose)
+            std::cout << "iter [" << iter << "] radius: " << trust_region_radius << ", rho: " << rho << ", error: " << new_error
+                      << ", inlier: " << inlier << std::endl;
+        if (rho < dl.eta1) {
+            trust_region_radius = clamp_radius(trust_region_radius * dl.gamma_decrease);
+            return false;
+        }
+        const float nr = std::sqrt(p6[0] * p6[0] + p6[1] * p6[1] + p6[2] * p6[2]);
+        const float nt = std::sqrt(p6[3] * p6[3] + p6[4] * p6[4] + p6[5] * p6[5]);
+        result.converged = nr < params_.criteria.rotation && nt < params_.criteria.translation;  // is_converged (:407-410)
+        result.T.matrix() = new_T;
+        result.error = new_error;
+        result.inlier = inlier;
+        if (rho > dl.eta2 && step_norm >= trust_region_radius * 0.99f)
+            trust_region_radius = clamp_radius(trust_region_radius * dl.gamma_increase);
+        return true;
     }
 
     RegistrationParams params_;

@@ -311,6 +311,10 @@ int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, float lambda
 void sp_se3_exp_host(const float* twist6, float* T_out16);
 void sp_rigid_mul_host(const float* A16, const float* B16, float* out16);
 int sp_ldlt6_solve_host(const float* H36_rowmajor, const float* rhs6, float* x6);
+/* compute_dogleg_step<6> (algorithms/registration/dogleg_step.hpp:35-101), the step geometry of
+ * Registration::optimize_powell_dogleg (registration.hpp:897-965); trust-region bookkeeping stays with the caller. */
+void sp_dogleg_step_host(const float* H36_rowmajor, const float* g6, float trust_region_radius, float* p_out6,
+                         float* step_norm_out, float* predicted_reduction_out);
 
 #ifdef __cplusplus
 }

@@ -220,6 +220,8 @@ struct orc_reg_params {
     // annealing wrapper (pipeline/robust.hpp); auto_scale=0 -> plain align with robust_default_scale
     int auto_scale, auto_scaling_iter;
     float init_scale, min_scale;
+    // Powell dogleg (registration_params.hpp:84-92); dl_initial_radius == 0 keeps the reference defaults
+    float dl_initial_radius, dl_min_radius, dl_max_radius, dl_eta1, dl_eta2, dl_gamma_decrease, dl_gamma_increase;
 };
 struct orc_reg_result {
     float T[16];
@@ -245,6 +247,11 @@ void orc_registration_align(const orc_reg_params* P, const float* src, const flo
     p.lm_min_lambda = P->lm_min_lambda; p.lm_max_lambda = P->lm_max_lambda;
     p.lm_max_inner_iterations = (size_t)P->lm_max_inner_iterations;
     p.crit_translation = P->crit_translation; p.crit_rotation = P->crit_rotation;
+    if (P->dl_initial_radius > 0.0f) {
+        p.dl_initial_radius = P->dl_initial_radius; p.dl_min_radius = P->dl_min_radius; p.dl_max_radius = P->dl_max_radius;
+        p.dl_eta1 = P->dl_eta1; p.dl_eta2 = P->dl_eta2; p.dl_gamma_decrease = P->dl_gamma_decrease;
+        p.dl_gamma_increase = P->dl_gamma_increase;
+    }
     Cloud s, t;
     s.points = src; s.covs = src_cov; s.n = ns;
     t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm; t.n = nt;

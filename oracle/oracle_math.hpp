@@ -431,7 +431,7 @@ inline Mat4 isometry_mul(const Mat4& L, const Mat4& Rm) {
 // Eigen is third-party and unpinned in the reference (cpp/CMakeLists.txt:27): parity unpinned;
 // H + lambda*I is SPD on this path so pivot choice only changes rounding.
 // Returns false when a zero pivot with a non-zero column is met (Eigen: NumericalIssue).
-inline bool ldlt6_solve(const Mat6& A, const Vec6& b, Vec6& x) {
+inline bool ldlt6_solve(const Mat6& A, const Vec6& b, Vec6& x, float* dmin_out = nullptr) {
     constexpr int n = 6;
     float m[n][n];
     for (int i = 0; i < n; ++i)
@@ -469,6 +469,11 @@ inline bool ldlt6_solve(const Mat6& A, const Vec6& b, Vec6& x) {
             for (int i = k + 1; i < n; ++i)
                 if (m[i][k] != 0.0f) ok = false;
         }
+    }
+    if (dmin_out) {  // ldlt.vectorD().minCoeff()
+        float dm = m[0][0];
+        for (int i = 1; i < n; ++i) dm = std::min(dm, m[i][i]);
+        *dmin_out = dm;
     }
     if (!ok) { x = Vec6::Zero(); return false; }
     float y[n];

@@ -450,6 +450,9 @@ struct RegParams : FactorParams {  // registration_params.hpp:74-114
     int optimization_method = GAUSS_NEWTON;
     size_t max_iterations = 20;
     float crit_translation = 1e-3f, crit_rotation = 1e-3f;
+    // Dogleg (registration_params.hpp:84-92)
+    float dl_initial_radius = 1.0f, dl_min_radius = 1e-4f, dl_max_radius = 10.0f;
+    float dl_eta1 = 0.25f, dl_eta2 = 0.75f, dl_gamma_decrease = 0.25f, dl_gamma_increase = 2.0f;
 };
 
 struct RegResult {  // result.hpp:12-28
@@ -480,7 +483,84 @@ inline Mat6 add_lambda(const Mat6& H, float lambda) {
     return r;
 }
 
-// registration.hpp:201-276 with GN (:803-828) and LM (:830-895).  Degenerate regularisation and MAP prior are
+// dogleg_step.hpp:35-101 (Eigen's .norm() / .dot() / H*g restated as plain ascending sums: unpinned third-party order)
+struct DoglegStep {
+    Vec6 p = Vec6::Zero();
+    float step_norm = 0.0f, predicted_reduction = 0.0f;
+};
+inline float dot6(const Vec6& a, const Vec6& b) {
+    float s = 0.0f;
+    for (int i = 0; i < 6; ++i) s += a[i] * b[i];
+    return s;
+}
+inline Vec6 matvec6(const Mat6& H, const Vec6& v) {
+    Vec6 r;
+    for (int i = 0; i < 6; ++i) {
+        float s = 0.0f;
+        for (int j = 0; j < 6; ++j) s += H(i, j) * v[j];
+        r[i] = s;
+    }
+    return r;
+}
+inline DoglegStep compute_dogleg_step(const Mat6& H, const Vec6& g, float radius) {
+    DoglegStep r;
+    Vec6 p_gn = Vec6::Zero();
+    float norm_gn = 0.0f, dmin = 0.0f;
+    bool has_gn = false;
+    {
+        Vec6 sol;
+        if (ldlt6_solve(H, scale<6, 1>(g, -1.0f), sol, &dmin) && dmin > 0.0f) {
+            p_gn = sol;
+            norm_gn = std::sqrt(dot6(p_gn, p_gn));
+            has_gn = std::isfinite(norm_gn);
+        }
+    }
+    const float g2 = dot6(g, g);
+    const float gHg = dot6(g, matvec6(H, g));
+    Vec6 p_sd = scale<6, 1>(g, -1.0f);
+    if (gHg > std::numeric_limits<float>::epsilon()) {
+        const float alpha = g2 / gHg;
+        if (std::isfinite(alpha))
+            for (int i = 0; i < 6; ++i) p_sd[i] = -alpha * g[i];
+    }
+    const float norm_sd = std::sqrt(dot6(p_sd, p_sd));
+    if (has_gn && norm_gn <= radius) {
+        r.p = p_gn;
+        r.step_norm = norm_gn;
+    } else if (norm_sd >= radius) {
+        if (norm_sd > std::numeric_limits<float>::epsilon()) {
+            const float sc = radius / norm_sd;
+            for (int i = 0; i < 6; ++i) r.p[i] = sc * p_sd[i];
+        }
+        r.step_norm = radius;
+    } else if (has_gn) {
+        Vec6 diff;
+        for (int i = 0; i < 6; ++i) diff[i] = p_gn[i] - p_sd[i];
+        const float a = dot6(diff, diff);
+        const float b = 2.0f * dot6(p_sd, diff);
+        const float c = dot6(p_sd, p_sd) - radius * radius;
+        float disc = b * b - 4.0f * a * c;
+        disc = std::max(disc, 0.0f);
+        float tau = 0.0f;
+        if (a > std::numeric_limits<float>::epsilon()) tau = (-b + std::sqrt(disc)) / (2.0f * a);
+        tau = std::clamp(tau, 0.0f, 1.0f);
+        for (int i = 0; i < 6; ++i) r.p[i] = p_sd[i] + tau * diff[i];
+        r.step_norm = std::sqrt(dot6(r.p, r.p));
+    } else {
+        r.p = p_sd;
+        if (norm_sd > radius && norm_sd > std::numeric_limits<float>::epsilon()) {
+            const float sc = radius / norm_sd;
+            for (int i = 0; i < 6; ++i) r.p[i] *= sc;
+            r.step_norm = radius;
+        } else {
+            r.step_norm = norm_sd;
+        }
+    }
+    r.predicted_reduction = -(dot6(g, r.p) + 0.5f * dot6(r.p, matvec6(H, r.p)));
+    return r;
+}
+
+// registration.hpp:201-276 with GN (:803-828), LM (:830-895) and Powell dogleg (:897-965).  Degenerate regularisation and MAP prior are
 // default-off no-ops in the reference (degenerate_regularization.hpp:40, map_prior.hpp:15) and are not restated.
 inline RegResult align(const RegParams& params, const Cloud& source, const Cloud& target, const NearestFn& nearest,
                        const float* init_T_colmajor, float opt_robust_scale = -1.0f,
@@ -493,6 +573,7 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
     if (p.robust_type != LOSS_NONE && p.robust_default_scale <= 0.0f) p.robust_type = LOSS_NONE;  // :186-192
     const float robust_scale = opt_robust_scale > 0.0f ? opt_robust_scale : p.robust_default_scale;
     float lm_lambda = p.lm_init_lambda;
+    float trust_region_radius = p.dl_initial_radius;
     std::vector<int32_t> nn_idx(N);
     std::vector<float> nn_d2(N);
     float genz_alpha = 1.0f;
@@ -546,6 +627,35 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
             result.iterations = iter;
             result.H = lin.H;
             result.b = lin.b;
+        } else if (p.optimization_method == POWELL_DOGLEG) {  // registration.hpp:897-965
+            result.H = lin.H;
+            result.b = lin.b;
+            result.error = lin.error;
+            result.inlier = lin.inlier;
+            result.iterations = iter;
+            const auto clamp_radius = [&](float r) { return std::clamp(r, p.dl_min_radius, p.dl_max_radius); };
+            trust_region_radius = clamp_radius(trust_region_radius);
+            const DoglegStep dl = compute_dogleg_step(lin.H, lin.b, trust_region_radius);
+            if (dl.predicted_reduction <= 0.0f) {
+                trust_region_radius = clamp_radius(trust_region_radius * p.dl_gamma_decrease);
+            } else {
+                const Mat4 new_T = isometry_mul(result.T, se3_exp(dl.p));
+                float new_error;
+                uint32_t inl;
+                error_reduce(p, source, target, nn_idx.data(), nn_d2.data(), new_T.d, robust_scale, genz_alpha, new_error,
+                             inl);
+                const float rho = (lin.error - new_error) / dl.predicted_reduction;
+                if (rho < p.dl_eta1) {
+                    trust_region_radius = clamp_radius(trust_region_radius * p.dl_gamma_decrease);
+                } else {
+                    result.converged = is_converged(p, dl.p);
+                    result.T = new_T;
+                    result.error = new_error;
+                    result.inlier = inl;
+                    if (rho > p.dl_eta2 && dl.step_norm >= trust_region_radius * 0.99f)
+                        trust_region_radius = clamp_radius(trust_region_radius * p.dl_gamma_increase);
+                }
+            }
         }
         if (trace_T) trace_T->insert(trace_T->end(), result.T.d, result.T.d + 16);
         if (result.converged) break;

@@ -34,6 +34,8 @@ class RegParams(C.Structure):
         ("lm_max_lambda", C.c_float), ("lm_max_inner_iterations", C.c_int),
         ("crit_translation", C.c_float), ("crit_rotation", C.c_float),
         ("auto_scale", C.c_int), ("auto_scaling_iter", C.c_int), ("init_scale", C.c_float), ("min_scale", C.c_float),
+        ("dl_initial_radius", C.c_float), ("dl_min_radius", C.c_float), ("dl_max_radius", C.c_float),
+        ("dl_eta1", C.c_float), ("dl_eta2", C.c_float), ("dl_gamma_decrease", C.c_float), ("dl_gamma_increase", C.c_float),
     ]
 
     @staticmethod
@@ -43,7 +45,9 @@ class RegParams(C.Structure):
                       max_correspondence_distance=2.0, robust_default_scale=10.0, gn_lambda=1.0,
                       lm_init_lambda=1.0, lm_lambda_factor=2.0, lm_min_lambda=1e-6, lm_max_lambda=1e3,
                       lm_max_inner_iterations=10, crit_translation=1e-3, crit_rotation=1e-3,
-                      auto_scale=0, auto_scaling_iter=4, init_scale=10.0, min_scale=0.5)
+                      auto_scale=0, auto_scaling_iter=4, init_scale=10.0, min_scale=0.5,
+                      dl_initial_radius=1.0, dl_min_radius=1e-4, dl_max_radius=10.0, dl_eta1=0.25, dl_eta2=0.75,
+                      dl_gamma_decrease=0.25, dl_gamma_increase=2.0)
         for k, v in kw.items():
             setattr(p, k, v)
         return p

@@ -99,6 +99,7 @@ SIGNATURES = {
     "sp_se3_exp_host": (None, [_vp, _vp]),
     "sp_rigid_mul_host": (None, [_vp, _vp, _vp]),
     "sp_ldlt6_solve_host": (_i, [_vp, _vp, _vp]),
+    "sp_dogleg_step_host": (None, [_vp, _vp, _f, _vp, _vp, _vp]),
 }
 
 

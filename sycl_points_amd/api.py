@@ -561,6 +561,13 @@ class RegistrationParams:
     lm_init_lambda: float = 1.0
     lm_max_lambda: float = 1e3
     lm_min_lambda: float = 1e-6
+    dogleg_initial_trust_region_radius: float = 1.0  # registration_params.hpp:84-92
+    dogleg_min_trust_region_radius: float = 1e-4
+    dogleg_max_trust_region_radius: float = 10.0
+    dogleg_eta1: float = 0.25
+    dogleg_eta2: float = 0.75
+    dogleg_gamma_decrease: float = 0.25
+    dogleg_gamma_increase: float = 2.0
     max_iterations: int = 20
     criteria_translation: float = 1e-3
     criteria_rotation: float = 1e-3
@@ -703,6 +710,7 @@ class Registration:
         scale = robust_scale if robust_scale > 0 else p.robust_default_scale
         _, lin = self._buffers(source.points.device)
         lm_lambda = p.lm_init_lambda
+        radius = np.float32(p.dogleg_initial_trust_region_radius)
         T = _T16(result.T).copy().reshape(-1)  # column-major working copy
         delta8 = np.zeros(8, np.float32)
         for it in range(p.max_iterations):
@@ -720,6 +728,36 @@ class Registration:
                 result.converged = bool(delta8[6] > 0.5)
                 result.iterations, result.H, result.b = it, H, b
                 result.error, result.inlier = float(lr.error), int(lr.inlier)
+            elif p.optimization_method == "DOGLEG":  # optimize_powell_dogleg (registration.hpp:897-965)
+                f32 = np.float32
+                result.iterations, result.H, result.b = it, H, b
+                result.error, result.inlier = float(lr.error), int(lr.inlier)
+                clamp = lambda r: f32(min(max(r, f32(p.dogleg_min_trust_region_radius)),  # noqa: E731
+                                          f32(p.dogleg_max_trust_region_radius)))
+                radius = clamp(radius)
+                Hrow = np.ascontiguousarray(H)
+                p6, sn, pred = np.zeros(6, np.float32), C.c_float(0.0), C.c_float(0.0)
+                L.sp_dogleg_step_host(Hrow.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_float(radius),
+                                      p6.ctypes.data_as(C.c_void_p), C.byref(sn), C.byref(pred))
+                if pred.value <= 0.0:
+                    radius = clamp(f32(radius * f32(p.dogleg_gamma_decrease)))
+                else:
+                    E, Ttry = np.zeros(16, np.float32), np.zeros(16, np.float32)
+                    L.sp_se3_exp_host(p6.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p))
+                    L.sp_rigid_mul_host(T.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p),
+                                        Ttry.ctypes.data_as(C.c_void_p))
+                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale)
+                    rho = f32(f32(lr.error) - f32(new_error)) / f32(pred.value)
+                    if rho < p.dogleg_eta1:
+                        radius = clamp(f32(radius * f32(p.dogleg_gamma_decrease)))
+                    else:
+                        nr = np.sqrt(f32(p6[0] * p6[0] + p6[1] * p6[1] + p6[2] * p6[2]))
+                        nt = np.sqrt(f32(p6[3] * p6[3] + p6[4] * p6[4] + p6[5] * p6[5]))
+                        result.converged = bool(nr < p.criteria_rotation and nt < p.criteria_translation)
+                        T = Ttry
+                        result.error, result.inlier = float(new_error), inl
+                        if rho > p.dogleg_eta2 and sn.value >= radius * f32(0.99):
+                            radius = clamp(f32(radius * f32(p.dogleg_gamma_increase)))
             else:  # LM
                 current_error = np.float32(lr.error)
                 last_error = np.float32(FLT_MAX)

@@ -39,3 +39,11 @@ extern "C" int sp_ldlt6_solve_host(const float* H36_rowmajor, const float* rhs6,
     sp::LdltScratch w;
     return sp::ldlt6_solve(H36_rowmajor, rhs6, x6, w) ? SP_OK : SP_ERR_RUNTIME;
 }
+extern "C" void sp_dogleg_step_host(const float* H36_rowmajor, const float* g6, float trust_region_radius, float* p_out6,
+                                    float* step_norm_out, float* predicted_reduction_out) {
+    sp::LdltScratch w;
+    const sp::DoglegStep6 r = sp::dogleg_step6(H36_rowmajor, g6, trust_region_radius, w);
+    for (int i = 0; i < 6; ++i) p_out6[i] = r.p[i];
+    if (step_norm_out) *step_norm_out = r.step_norm;
+    if (predicted_reduction_out) *predicted_reduction_out = r.predicted_reduction;
+}

@@ -379,7 +379,7 @@ struct LdltScratch {
     float H[36];
     int perm[6];
 };
-SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch&) {
+SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch&, float* dmin_out = nullptr) {
     // Fully unrolled: every array index below is a compile-time constant after unrolling, so the 6x6 working set stays
     // in registers. The run-time pivot is applied with predicated swaps (`if (piv == p)`), which performs exactly the
     // arithmetic of the textbook loop form, in the same order.
@@ -435,6 +435,12 @@ SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch&)
                 if (m[i][k] != 0.0f) ok = false;
         }
     }
+    if (dmin_out) {  // ldlt.vectorD().minCoeff()
+        float dm = m[0][0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) dm = m[i][i] < dm ? m[i][i] : dm;
+        *dmin_out = dm;
+    }
     if (!ok) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = 0.0f;
@@ -466,6 +472,105 @@ SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch&)
         x[t] = v;
     }
     return true;
+}
+
+// compute_dogleg_step<6> (algorithms/registration/dogleg_step.hpp:35-101): Powell dogleg step for H p = -g inside a trust
+// region. Eigen's reductions (.norm(), .dot(), H * g) are restated as plain ascending sums — third-party arithmetic the
+// reference does not pin.
+struct DoglegStep6 {
+    float p[6];
+    float step_norm, predicted_reduction;
+};
+SP_HD float dot6(const float* a, const float* b) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += a[i] * b[i];
+    return s;
+}
+SP_HD void matvec6(const float* H, const float* v, float* out) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s += H[i * 6 + j] * v[j];
+        out[i] = s;
+    }
+}
+SP_HD DoglegStep6 dogleg_step6(const float* H, const float* g, float radius, LdltScratch& w) {
+    DoglegStep6 r;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.p[i] = 0.0f;
+    r.step_norm = 0.0f;
+    r.predicted_reduction = 0.0f;
+    float p_gn[6], ng[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { p_gn[i] = 0.0f; ng[i] = -g[i]; }
+    float norm_gn = 0.0f, dmin = 0.0f;
+    bool has_gn = false;
+    float sol[6];
+    if (ldlt6_solve(H, ng, sol, w, &dmin) && dmin > 0.0f) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p_gn[i] = sol[i];
+        norm_gn = sqrtf(dot6(p_gn, p_gn));
+        has_gn = fabsf(norm_gn) <= FLT_MAX;  // std::isfinite
+    }
+    const float g2 = dot6(g, g);
+    float Hg[6];
+    matvec6(H, g, Hg);
+    const float gHg = dot6(g, Hg);
+    float p_sd[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p_sd[i] = -g[i];
+    if (gHg > FLT_EPSILON) {
+        const float alpha = g2 / gHg;
+        if (fabsf(alpha) <= FLT_MAX) {  // std::isfinite
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p_sd[i] = -alpha * g[i];
+        }
+    }
+    const float norm_sd = sqrtf(dot6(p_sd, p_sd));
+    if (has_gn && norm_gn <= radius) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r.p[i] = p_gn[i];
+        r.step_norm = norm_gn;
+    } else if (norm_sd >= radius) {
+        if (norm_sd > FLT_EPSILON) {
+            const float sc = radius / norm_sd;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) r.p[i] = sc * p_sd[i];
+        }
+        r.step_norm = radius;
+    } else if (has_gn) {
+        float diff[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) diff[i] = p_gn[i] - p_sd[i];
+        const float a = dot6(diff, diff);
+        const float b = 2.0f * dot6(p_sd, diff);
+        const float c = dot6(p_sd, p_sd) - radius * radius;
+        float disc = b * b - 4.0f * a * c;
+        disc = disc < 0.0f ? 0.0f : disc;
+        float tau = 0.0f;
+        if (a > FLT_EPSILON) tau = (-b + sqrtf(disc)) / (2.0f * a);
+        tau = tau < 0.0f ? 0.0f : (1.0f < tau ? 1.0f : tau);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r.p[i] = p_sd[i] + tau * diff[i];
+        r.step_norm = sqrtf(dot6(r.p, r.p));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r.p[i] = p_sd[i];
+        if (norm_sd > radius && norm_sd > FLT_EPSILON) {
+            const float sc = radius / norm_sd;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) r.p[i] *= sc;
+            r.step_norm = radius;
+        } else {
+            r.step_norm = norm_sd;
+        }
+    }
+    float Hp[6];
+    matvec6(H, r.p, Hp);
+    r.predicted_reduction = -(dot6(g, r.p) + 0.5f * dot6(r.p, Hp));
+    return r;
 }
 
 }  // namespace sp

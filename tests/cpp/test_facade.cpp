@@ -24,6 +24,7 @@ struct orc_reg_params {
     float crit_translation, crit_rotation;
     int auto_scale, auto_scaling_iter;
     float init_scale, min_scale;
+    float dl_initial_radius, dl_min_radius, dl_max_radius, dl_eta1, dl_eta2, dl_gamma_decrease, dl_gamma_increase;  // 0: defaults
 };
 struct orc_reg_result { float T[16]; float H[36]; float b[6]; float error; uint32_t inlier; int iterations; int converged; };
 extern "C" {
@@ -260,6 +261,26 @@ static void registration_matches_oracle() {
         const auto rv = regv.align(source, target, *grid);
         std::cout.rdbuf(old);
         CHECK(max_abs_diff(rv.T.matrix(), rc.T.matrix().data()) < 2e-6f && rv.iterations == rc.iterations);
+    }
+    // Powell dogleg (registration.hpp:897-965) against the oracle's restatement
+    {
+        alg::registration::RegistrationParams pd = p;
+        pd.optimization_method = alg::registration::OptimizationMethod::POWELL_DOGLEG;
+        pd.dogleg.initial_trust_region_radius = 0.05f;  // small enough for the Cauchy / dogleg branches to be taken
+        orc_reg_params opd = op;
+        opd.optimization_method = 2;
+        opd.dl_initial_radius = 0.05f; opd.dl_min_radius = 1e-4f; opd.dl_max_radius = 10.0f; opd.dl_eta1 = 0.25f;
+        opd.dl_eta2 = 0.75f; opd.dl_gamma_decrease = 0.25f; opd.dl_gamma_increase = 2.0f;
+        orc_reg_result refd;
+        orc_registration_align(&opd, reinterpret_cast<const float*>(source.points->data()),
+                               reinterpret_cast<const float*>(source.covs->data()), n,
+                               reinterpret_cast<const float*>(target.points->data()),
+                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &refd, nullptr, nullptr, nullptr, 0);
+        alg::registration::Registration regd(*Q, pd);
+        const auto rd = regd.align(source, target, *tree);
+        CHECK(max_abs_diff(rd.T.matrix(), refd.T) < 1e-5f);
+        CHECK(rd.inlier == refd.inlier && (int)rd.iterations == refd.iterations);
+        CHECK(max_abs_diff(rd.T.matrix(), T_gt.data()) < 5e-4f);
     }
     // LM + Geman-McClure through the annealing pipeline (example_registration.cpp:31-45), against the oracle's restatement
     alg::registration::RegistrationPipelineParams pp;

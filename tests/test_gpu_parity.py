@@ -467,6 +467,28 @@ def test_gicp_config4_1m(sp, orc):
     assert np.allclose(H, ref["H"], atol=2e-5 * np.abs(ref["H"]).max()) and g2.inlier == ref["inlier"]
 
 
+@pytest.mark.parametrize("radius", [1.0, 0.05, 0.004])
+def test_align_powell_dogleg_matches_oracle(sp, orc, gicp20k, radius):
+    """optimize_powell_dogleg (registration.hpp:897-965): Gauss-Newton branch (large radius), dogleg / Cauchy branches and
+    radius growth (small radii), against the oracle's restatement."""
+    from oracle.pyoracle import OPT, RegParams
+
+    src, scov, tgt, tcov, T_gt = gicp20k
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    tree = sp.KDTree.build(tgt)
+    p = sp.RegistrationParams(optimization_method="DOGLEG", max_iterations=15, criteria_translation=1e-5,
+                              criteria_rotation=1e-5, dogleg_initial_trust_region_radius=radius)
+    got = sp.Registration(p).align(S, Tg, tree)
+    ref = orc.registration_align(RegParams.defaults(optimization_method=OPT["DOGLEG"], max_iterations=15,
+                                                    crit_translation=1e-5, crit_rotation=1e-5, dl_initial_radius=radius),
+                                 src, scov, tgt, tcov)
+    assert np.abs(got.T - ref["T"]).max() < 1e-5
+    assert got.iterations == ref["iterations"] and got.converged == ref["converged"] and got.inlier == ref["inlier"]
+    if radius >= 0.05:
+        assert np.abs(got.T - T_gt).max() < 5e-4
+
+
 # ------------------------------------------------------------------ K8: M-estimated covariance, normalize_covariance
 @pytest.mark.parametrize("loss", ["HUBER", "TUKEY", "CAUCHY", "GEMAN_MCCLURE", "NONE"])
 @pytest.mark.parametrize("k", [10, 20, 33])
