@@ -219,8 +219,12 @@ int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn
  * The reference recomputes covariance::kernel::update_covariance_plane for both covariances of every correspondence in
  * every iteration (factor.hpp:249-255). The result depends on the covariance alone, so here it is computed once:
  *   sp_gicp_target_create : plane-regularised target covariances, packed 8 floats per point
- *                           (xx,xy,xz,yy | yz,zz,0,0) and stored in the cell order of `grid` (which must have been built
+ *                           (xx,xy,xz,yy | yz,zz,rho^2,0) and stored in the cell order of `grid` (which must have been built
  *                           on the target points and must outlive the object); sp_gicp_target_update recomputes in place.
+ *                           rho = half the distance from the point to its nearest other target point (one k = 2
+ *                           self-search on the grid; create allocates and synchronises): the iteration kernel keeps a
+ *                           source point's previous correspondence t without searching when |T p - t| < rho_t, which
+ *                           proves t is still the exact nearest neighbour.
  *   sp_gicp_source_create : buffers for a prepared source of up to n_max points (allocates).
  *   sp_gicp_source_prepare: (enqueue only) packed plane-regularised source covariances. sort_by_cell selects how
  *                           neighbouring lanes get neighbouring cells (their loads then share cache lines):
@@ -294,6 +298,10 @@ void sp_debug_set_fused_fast_nn(int mode);
 /* Measurement hook: launches issued by sp_gicp_iteration_fused / sp_gicp_align_fused (bit 0 = per-iteration kernel,
  * bit 1 = final reduce + solve / finish kernel). */
 void sp_debug_set_fused_stage_mask(int mask);
+/* Tuning hook: 1 (default) carry a correspondence to the next iteration when it is provably unchanged (the query is
+ * closer to its previous winner than half that winner's distance to its nearest other target point); 0 always search.
+ * Takes effect at the next sp_gicp_target_update / sp_gicp_source_prepare. Results are identical either way. */
+void sp_debug_set_fused_reuse(int on);
 /* Tuning hook: self-kNN kernel (0 wave-cooperative, default; 1 lane-per-query tile kernel for k <= 10). */
 void sp_debug_set_self_knn_mode(int mode);
 

@@ -91,6 +91,7 @@ SIGNATURES = {
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_rows": (_vp, [_vp, _i, _vp]),
     "sp_gicp_align_finish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_debug_set_fused_reuse": (None, [_i]),
     "sp_debug_set_fused_fast_nn": (None, [_i]),
     "sp_debug_set_self_knn_mode": (None, [_i]),
     "sp_debug_set_fused_stage_mask": (None, [_i]),

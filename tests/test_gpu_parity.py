@@ -710,6 +710,43 @@ def test_align_fused_one_call_loop(sp, orc, gicp20k, loss):
     assert torch.equal(T0.cpu(), torch.eye(4).reshape(-1))
 
 
+def test_correspondence_reuse_is_exact(sp, orc, gicp20k):
+    """The iteration kernel keeps a correspondence without searching when the query is provably still nearest to its
+    previous winner (|q - t| < half of t's distance to its nearest other target point). Every output must be bit-identical
+    to the always-search path — also with duplicated target points (radius 0: never reused) and a target with one point."""
+    src, scov, tgt, tcov, T_gt = gicp20k
+    L = sp._lib.lib()
+    tgt2, tcov2 = np.concatenate([tgt, tgt[:500]]), np.concatenate([tcov, tcov[:500]])  # 500 exact duplicates
+    outs = []
+    for reuse in (1, 0):
+        L.sp_debug_set_fused_reuse(reuse)
+        try:
+            S = sp.PointCloudShared(dev(src), covs=dev(scov))
+            Tg = sp.PointCloudShared(dev(tgt2), covs=dev(tcov2))
+            grid = sp.GridKNN.build(Tg.points)
+            prep = sp.PreparedTarget(grid, Tg.covs)
+            p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=10)
+            reg = sp.Registration(p)
+            T_dev, lin, delta = reg.align_fused_loop(S, prep, write_neighbors=True)
+            outs.append((T_dev.cpu().numpy(), lin.cpu().numpy(), reg.neighbors.indices.cpu().numpy().copy(),
+                         reg.neighbors.distances.cpu().numpy().copy()))
+        finally:
+            L.sp_debug_set_fused_reuse(1)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    oi, od = orc.knn_bruteforce(orc.transform_points(src, orc.registration_align(
+        __import__("oracle.pyoracle", fromlist=["RegParams"]).RegParams.defaults(crit_translation=0.0, crit_rotation=0.0,
+                                                                                max_iterations=9), src, scov, tgt, tcov)["T"]),
+        tgt2, 1)
+    assert (outs[0][2].ravel() == oi.ravel()).mean() > 0.999  # lowest index among the duplicates, as brute force
+    one = sp.PointCloudShared(dev(tgt[:1]), covs=dev(tcov[:1]))
+    g1 = sp.GridKNN.build(one.points)
+    reg = sp.Registration(sp.RegistrationParams(max_iterations=3, max_correspondence_distance=100.0))
+    S = sp.PointCloudShared(dev(src[:256]), covs=dev(scov[:256]))
+    T_dev, lin, _ = reg.align_fused_loop(S, sp.PreparedTarget(g1, one.covs), write_neighbors=True)
+    assert (reg.neighbors.indices.cpu().numpy() == 0).all() and reg._read_lin(lin).inlier == 256
+
+
 def test_grid_order_and_presorted_source(sp, orc, gicp20k):
     """sp_grid_order is the grid's cell-order permutation; a source stored in that order aligns without the per-alignment
     sort (SP_SOURCE_PRESORTED) to the same pose, and reports its neighbours in the caller's (reordered) indexing."""
