@@ -568,7 +568,8 @@ struct FusedParams {
     Mat4Arg T_val;
     const float* T_dev;
     const unsigned* perm;  // prepared-source order -> original source index (for the optional neighbour outputs)
-    unsigned* last_pos;    // per prepared source point: grid position of its previous correspondence (or 0xFFFFFFFF)
+    float4* ccache;        // per prepared source point: its previous correspondence (point, covariance row), 3 x float4
+    int cache_valid;       // 0: first linearisation after sp_gicp_source_prepare, the cache holds nothing yet
     int32_t* nn_idx;
     float* nn_d2;
 };
@@ -656,27 +657,40 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         // Correspondences rarely change from one iteration to the next. The previous winner t is PROVABLY still the
         // nearest neighbour — same index, same distance as a fresh search — when |q - t| < rho_t, half the distance from t
         // to its nearest other target point: any other target u then has |q - u| >= |t - u| - |q - t| > 2 rho_t - rho_t >
-        // |q - t|. rho_t^2 (with a 1e-3 margin against rounding) travels in the spare slot of t's covariance row, so the
-        // test costs the loads the linearisation needs anyway, and a wave whose lanes all pass skips the search altogether.
-        // (A second certificate row with t's nearest neighbour's coordinates passes more queries but costs one more gather
-        // per point: measured slower, 29.1 against 28.0 us per launch.)
+        // |q - t|. Each source point therefore keeps a copy of its last correspondence IN SOURCE ORDER (t with its index,
+        // its packed covariance row carrying rho_t^2 with a 1e-3 margin against rounding, and its grid position): while
+        // correspondences hold, an iteration is a pure coalesced stream of 96 bytes per point (16 p + 32 Cs' + 48 copy)
+        // with no search and no gather, and a wave whose lanes all pass never enters the search code.
+        // (A second certificate with t's nearest neighbour's coordinates passes more queries but costs one more load per
+        // point: measured slower.)
         bool hit = false;
-        if (DBG == 0 && P.last_pos) {
-            const unsigned prev = P.last_pos[i];
-            if (prev != 0xFFFFFFFFu) {
-                const float4 tp = P.tpts[prev];
-                const float4 c0 = P.tcovp[2 * (size_t)prev], c1 = P.tcovp[2 * (size_t)prev + 1];
-                const float d = dist2(qx, qy, qz, tp.x, tp.y, tp.z);
-                if (d < c1.z) {
-                    hit = true;
-                    nn.d2 = d; nn.idx = __float_as_int(tp.w); nn.pos = prev; nn.x = tp.x; nn.y = tp.y; nn.z = tp.z;
-                    Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-                    have_ct = true;
-                }
+        float4* const row = (DBG == 0 && P.ccache) ? P.ccache + 3 * (size_t)i : nullptr;
+        if (row && P.cache_valid) {
+            const float4 tp = row[0], c0 = row[1], c1 = row[2];
+            const float d = dist2(qx, qy, qz, tp.x, tp.y, tp.z);
+            if (d < c1.z) {
+                hit = true;
+                nn.d2 = d; nn.idx = __float_as_int(tp.w); nn.pos = __float_as_uint(c1.w); nn.x = tp.x; nn.y = tp.y; nn.z = tp.z;
+                Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+                have_ct = true;
             }
         }
-        if (!hit) nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
-        if (DBG == 0 && P.last_pos) P.last_pos[i] = nn.idx >= 0 ? nn.pos : 0xFFFFFFFFu;
+        if (!hit) {
+            nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+            if (row) {
+                float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;  // nothing found: radius 0, searched again next time
+                if (nn.idx >= 0) {
+                    c0 = P.tcovp[2 * (size_t)nn.pos];
+                    c1 = P.tcovp[2 * (size_t)nn.pos + 1];
+                    Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+                    have_ct = true;
+                    c1.w = __uint_as_float(nn.pos);
+                }
+                row[0] = make_float4(nn.x, nn.y, nn.z, __int_as_float(nn.idx));
+                row[1] = c0;
+                row[2] = c1;
+            }
+        }
     }
     if (DBG == 1 || DBG == 3) { acc[27] += nn.d2 + nn.x; ++cnt; return; }  // timing experiment: search only
     if (P.nn_idx) {
@@ -1027,6 +1041,7 @@ struct sp_gicp_target {
     const sp_grid* grid = nullptr;  // borrowed: must outlive this object
     float4* covp = nullptr;         // 2 x float4 per target point, grid order: (xx,xy,xz,yy | yz,zz,rho^2,0)
     float* rho2 = nullptr;          // per target point (original order): squared safe radius of the reuse test
+    unsigned long long version = 0; // bumped by every sp_gicp_target_update (cached copies of rows become stale)
     size_t n = 0;
 };
 struct sp_gicp_source {
@@ -1034,7 +1049,10 @@ struct sp_gicp_source {
     float4* pts = nullptr;    // n points in prepared order
     float4* covp = nullptr;   // 2 x float4 per point, prepared order
     unsigned* perm = nullptr; // prepared position -> original index
-    unsigned* last_pos = nullptr;  // prepared position -> grid position of the previous correspondence
+    float4* ccache = nullptr;      // 3 x float4 per prepared point: its previous correspondence (see fused_point)
+    mutable bool cache_valid = false;  // set by the first linearisation after prepare
+    const sp_gicp_target* cache_target = nullptr;  // the copies are of this target ...
+    unsigned long long cache_version = 0;           // ... at this covariance version
     bool sorted = false;
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void* sort_tmp = nullptr;
@@ -1054,6 +1072,7 @@ extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, v
                      "before performing GICP matching.");
         return SP_ERR_RUNTIME;
     }
+    ++t->version;
     if (t->n == 0) return SP_OK;
     prepare_cov_kernel<<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(tgt_covs), (unsigned)t->n, t->grid->d_pts, nullptr, t->covp,
@@ -1113,7 +1132,7 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
 
 extern "C" void sp_gicp_source_destroy(sp_gicp_source* s) {
     if (!s) return;
-    (void)hipFree(s->pts); (void)hipFree(s->covp); (void)hipFree(s->perm); (void)hipFree(s->last_pos);
+    (void)hipFree(s->pts); (void)hipFree(s->covp); (void)hipFree(s->perm); (void)hipFree(s->ccache);
     (void)hipFree(s->keys_in); (void)hipFree(s->keys_out); (void)hipFree(s->vals_in); (void)hipFree(s->sort_tmp);
     delete s;
 }
@@ -1130,7 +1149,7 @@ extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     hipError_t e = hipMalloc(&s->pts, n * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->covp, n * 2 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->perm, n * 4);
-    if (e == hipSuccess) e = hipMalloc(&s->last_pos, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->ccache, n * 3 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->keys_in, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->keys_out, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->vals_in, n * 4);
@@ -1184,7 +1203,9 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
     } else {
         iota_kernel<<<nb, kBlock, 0, st>>>(s->perm, (unsigned)n);
     }
-    if (hipMemsetAsync(s->last_pos, 0xFF, n * 4, st) != hipSuccess) return SP_ERR_HIP;  // no previous correspondences
+    s->cache_valid = false;  // no previous correspondences
+    s->cache_target = target;
+    s->cache_version = target->version;
     prepare_source_kernel<<<nb, kBlock, 0, st>>>(pts, reinterpret_cast<const float4*>(src_covs), s->perm, (unsigned)n,
                                                  s->pts, s->covp);
     return launch_status();
@@ -1210,7 +1231,8 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
         for (int i = 0; i < 16; ++i) P.T_val.m[i] = transT[i];
     P.T_dev = transT_on_device ? transT : nullptr;
     P.perm = source->perm;
-    P.last_pos = (g_fused_reuse && target->rho2) ? source->last_pos : nullptr;
+    P.ccache = (g_fused_reuse && target->rho2) ? source->ccache : nullptr;
+    P.cache_valid = (source->cache_valid && source->cache_target == target && source->cache_version == target->version) ? 1 : 0;
     P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
     P.nn_d2 = nn_d2_out;
     return P;
@@ -1240,6 +1262,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         return SP_ERR_INVALID_ARGUMENT;
     }
     const FusedParams P = make_fused_params(target, source, params, transT, transT_on_device, nn_idx_out, nn_d2_out);
+    const bool fills_cache = P.ccache != nullptr && (g_fused_stage_mask & 1) && !(g_fused_stage_mask & 28);
     const unsigned grid = reduce_grid(n);
     float* partials = static_cast<float*>(workspace);
     // Unsorted lanes touch unrelated cells: the ring walk (fewest cache lines per query) wins. Cell-sorted lanes share
@@ -1261,6 +1284,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
 #undef SP_LAUNCH_FUSED
+    if (fills_cache) source->cache_valid = true;
     GnArgs ga{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
     if (gn) ga = GnArgs{transT, gn->lambda, gn->crit_rotation, gn->crit_translation, delta_out8};
     if (g_fused_stage_mask & 2) final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
@@ -1318,6 +1342,7 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
             return SP_ERR_HIP;
     }
     const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
+    const bool fills_cache = P.ccache != nullptr && (g_fused_stage_mask & 1);
     const unsigned grid = align_grid(n);
     const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
     AlignArgs A;
@@ -1346,6 +1371,7 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
 #undef SP_LAUNCH_ALIGN
+    if (fills_cache) source->cache_valid = true;
     return launch_status();
 }
 
