@@ -755,15 +755,19 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
     __shared__ unsigned sconv;
     __shared__ LdltScratch ldlt_ws;
     if (A.has_prev) {
-        if (A.state_in->converged) {  // uniform over the grid
+        // Every global load of the prologue is issued up front — the previous state (pose, flags) by lanes 16..33 next to
+        // the partial rows — so that the prologue is ONE memory round trip deep, not three (flag, rows, pose).
+        __shared__ unsigned sprev[2];
+        if (threadIdx.x >= 16 && threadIdx.x < 32) sT[threadIdx.x - 16] = A.state_in->T[threadIdx.x - 16];
+        if (threadIdx.x == 32) sprev[0] = A.state_in->converged;
+        if (threadIdx.x == 33) sprev[1] = A.state_in->iterations;
+        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0);  // (two barriers inside)
+        if (sprev[0]) {  // uniform over the grid: an earlier iteration converged, this launch has nothing to do
             if (blockIdx.x == 0 && threadIdx.x == 0) *A.state_out = *A.state_in;
             return false;
         }
-        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0);
         if (threadIdx.x == 0) {
             unpack_totals(red[0], kAcc - 1, &slin);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sT[i] = A.state_in->T[i];
             gn_update_impl(&slin, sT, A.lambda, A.crit_rot, A.crit_trans, sdelta, false, ldlt_ws);
             sconv = sdelta[6] > 0.5f ? 1u : 0u;
             if (blockIdx.x == 0) {
@@ -773,7 +777,7 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) so->delta[i] = sdelta[i];
                 so->converged = sconv;
-                so->iterations = A.state_in->iterations + 1;
+                so->iterations = sprev[1] + 1;
                 if (A.lin_out) *A.lin_out = slin;
             }
         }
