@@ -264,7 +264,8 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
         ms = tot / reps_a / ITERS_PER_ALIGN
         res["gicp_align_kernel"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9,
                                     "note": "per-iteration launch: sum of the previous launch's partial rows + 6x6 solve + "
-                                            "pose update (prologue), then NN(k=1) + linearise + workgroup reduction; mean "
+                                            "pose update (prologue), then per point: certified reuse of the previous correspondence or NN(k=1) search, "
+                                            "linearise, workgroup reduction; mean "
                                             "over the 20 launches of an alignment started at the identity"}
         # (b) the finish kernel alone
         L.sp_debug_set_fused_stage_mask(2)
