@@ -161,6 +161,7 @@ public:
         if (voxel_size <= 0.0f) throw std::invalid_argument("voxel_size must be positive");
         voxel_size_ = voxel_size;
         voxel_size_inv_ = 1.0f / voxel_size_;
+        have_key_box_ = false;  // the remembered key box is in units of the old voxel size
     }
     float get_voxel_size() const { return voxel_size_; }
     void set_min_voxel_count(const size_t n) { min_voxel_count_ = n; }
@@ -199,16 +200,37 @@ private:
              const TimestampContainerShared* ts, PointContainerShared& out_pts, RGBContainerShared* out_rgb,
              IntensityContainerShared* out_inten, TimestampContainerShared* out_ts) {
         const size_t ws_bytes = sp_voxel_downsample_workspace_bytes(N);
-        detail::DeviceScratch ws(ws_bytes), count(4);
+        detail::DeviceScratch ws(ws_bytes), info(32);  // voxel count | boxed-path status | this cloud's key box (6 ints)
         hipStream_t st = queue_.stream();
-        throw_on_error(sp_voxel_downsample(
-            pts, N, voxel_size_inv_, min_voxel_count_, rgb ? reinterpret_cast<const float*>(rgb->device_data()) : nullptr,
-            inten ? inten->device_data() : nullptr, ts ? ts->device_data() : nullptr,
-            reinterpret_cast<float*>(out_pts.device_data_for_write(N)),
-            rgb ? reinterpret_cast<float*>(out_rgb->device_data_for_write(N)) : nullptr,
-            inten ? out_inten->device_data_for_write(N) : nullptr, ts ? out_ts->device_data_for_write(N) : nullptr, nullptr,
-            static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
-        const size_t V = detail::read_u32(count.p, st);
+        uint32_t* info_dev = static_cast<uint32_t*>(info.p);
+        // The sort runs on keys compressed to the (widened) key box of the PREVIOUS cloud — scans of one sensor have similar
+        // extents; the device verifies that this cloud fits, otherwise the 64-bit sort is used: same results either way.
+        throw_on_error(sp_voxel_key_box(pts, N, voxel_size_inv_, reinterpret_cast<int32_t*>(info_dev + 2), st));
+        auto launch = [&](const int32_t* box) {
+            throw_on_error(sp_voxel_downsample_boxed(
+                pts, N, voxel_size_inv_, min_voxel_count_, rgb ? reinterpret_cast<const float*>(rgb->device_data()) : nullptr,
+                inten ? inten->device_data() : nullptr, ts ? ts->device_data() : nullptr,
+                reinterpret_cast<float*>(out_pts.device_data_for_write(N)),
+                rgb ? reinterpret_cast<float*>(out_rgb->device_data_for_write(N)) : nullptr,
+                inten ? out_inten->device_data_for_write(N) : nullptr, ts ? out_ts->device_data_for_write(N) : nullptr, nullptr,
+                info_dev, box, info_dev + 1, ws.p, ws_bytes, st));
+        };
+        launch(have_key_box_ ? key_box_ : nullptr);
+        int32_t h[8];
+        hip_check(hipMemcpyAsync(h, info.p, sizeof h, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        if (h[1] != 0) {  // the cloud left the remembered box
+            launch(nullptr);
+            hip_check(hipMemcpyAsync(h, info.p, 4, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipStreamSynchronize(st), "sync");
+        }
+        have_key_box_ = h[2] <= h[5] && h[3] <= h[6] && h[4] <= h[7];
+        for (int a = 0; a < 3 && have_key_box_; ++a) {
+            const int32_t margin = std::max<int32_t>(2, (h[5 + a] - h[2 + a] + 1) / 8);
+            key_box_[a] = std::max<int32_t>(h[2 + a] - margin, 0);
+            key_box_[3 + a] = std::min<int32_t>(h[5 + a] + margin, (1 << 21) - 1);
+        }
+        const size_t V = static_cast<uint32_t>(h[0]);
         out_pts.set_device_size(V);
         if (rgb) out_rgb->set_device_size(V);
         if (inten) out_inten->set_device_size(V);
@@ -217,6 +239,8 @@ private:
     sycl_utils::DeviceQueue queue_;
     float voxel_size_ = 1.0f, voxel_size_inv_ = 1.0f;
     size_t min_voxel_count_ = 1;
+    int32_t key_box_[6] = {0, 0, 0, 0, 0, 0};  // widened key box of the previous cloud (the compressed sort's guess)
+    bool have_key_box_ = false;
 };
 
 /// common/filter_by_flags.hpp:15-99 — stable compaction on the device (sp_compact_by_flags).

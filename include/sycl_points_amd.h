@@ -141,6 +141,20 @@ int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, siz
                         float* rgb_out, float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt,
                         uint32_t* n_out_dev, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same operation with the bounding box of the cloud's voxel coordinates known to the HOST (box6 = min x,y,z, max x,y,z
+ * of the 21-bit key fields; sp_voxel_key_box computes it on the device: read it back, or keep the previous scan's box and
+ * check *status_dev_opt). The keys are then compressed to the voxel's position in the box — same order — and sorted by
+ * exactly the bits the box needs (3 Onesweep passes for a 200^3 box instead of a 64-bit sort: the sort is most of the
+ * run time). Results are identical to sp_voxel_downsample. *status_dev_opt receives the number of valid points whose voxel
+ * lies outside the box: non-zero means the box did not cover the cloud and the outputs must be discarded. A NULL, empty or
+ * too large box (>= 2^32 - 1 cells) falls back to the 64-bit path. */
+int sp_voxel_key_box(const float* points, size_t n, float inv_voxel_size, int32_t* box6_dev, void* stream);
+int sp_voxel_downsample_boxed(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
+                              const float* rgb, const float* intensities, const float* timestamps, float* points_out,
+                              float* rgb_out, float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt,
+                              uint32_t* n_out_dev, const int32_t* box6_host, uint32_t* status_dev_opt, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------- transform */
 
 /* transform::transform_async (algorithms/common/transform.hpp:14-37, 45-94, kernel K14); in place allowed;

@@ -71,6 +71,8 @@ SIGNATURES = {
     "sp_voxel_keys": (_i, [_vp, _sz, _f, _vp, _vp]),
     "sp_voxel_downsample_workspace_bytes": (_sz, [_sz]),
     "sp_voxel_downsample": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_voxel_key_box": (_i, [_vp, _sz, _f, _vp, _vp]),
+    "sp_voxel_downsample_boxed": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_transform": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sp_box_filter_flags": (_i, [_vp, _sz, _f, _f, _vp, _vp]),
     "sp_compact_workspace_bytes": (_sz, [_sz]),

@@ -388,7 +388,8 @@ class VoxelGrid:
         if voxel_size <= 0.0:
             raise SpError(1, "voxel_size must be positive")
         self.voxel_size = float(voxel_size)
-        self.voxel_size_inv = float(np.float32(1.0) / np.float32(voxel_size))  # voxel_downsampling.hpp:27
+        self.voxel_size_inv = float(np.float32(1.0) / np.float32(voxel_size))
+        self._key_box = None  # the remembered key box is in units of the old voxel size  # voxel_downsampling.hpp:27
         self.min_voxel_count = 1
 
     def set_voxel_size(self, voxel_size):
@@ -409,9 +410,11 @@ class VoxelGrid:
         check(_lib.lib().sp_voxel_keys(_ptr(p), p.shape[0], self.voxel_size_inv, _ptr(keys), _stream()))
         return keys
 
-    def downsampling(self, cloud, return_keys=False):
-        """downsampling(cloud, result) (voxel_downsampling.hpp:64-79). Synchronises once to read the voxel count,
-        as the reference's host aggregation does."""
+    def downsampling(self, cloud, return_keys=False, boxed=True):
+        """downsampling(cloud, result) (voxel_downsampling.hpp:64-79). Synchronises to read the voxel count, as the
+        reference's host aggregation does. boxed=True sorts keys compressed to the (widened) bounding box of the PREVIOUS
+        cloud's voxel coordinates — scans of one sensor have similar extents — verifies on the device that the cloud fits,
+        and falls back to the 64-bit sort when it does not: identical results either way."""
         pc = cloud if isinstance(cloud, PointCloudShared) else PointCloudShared(cloud)
         p = _dev_f32(pc.points, 4)
         n = p.shape[0]
@@ -429,11 +432,31 @@ class VoxelGrid:
         o_i = torch.empty(n, dtype=torch.float32, device=p.device) if inten is not None else None
         o_t = torch.empty(n, dtype=torch.float32, device=p.device) if ts is not None else None
         o_k = torch.empty(n, dtype=torch.int64, device=p.device) if return_keys else None
-        n_out = torch.zeros(1, dtype=torch.int32, device=p.device)
-        check(L.sp_voxel_downsample(_ptr(p), n, self.voxel_size_inv, self.min_voxel_count, _ptr(rgb), _ptr(inten),
-                                    _ptr(ts), _ptr(o_p), _ptr(o_c), _ptr(o_i), _ptr(o_t), _ptr(o_k), _ptr(n_out),
-                                    _ptr(ws), nbytes, _stream()))
-        v = int(n_out.item())
+        # One read-back at the end: voxel count, boxed-path status, and this cloud's key box (6 ints), which the NEXT call
+        # uses, widened by a margin, to sort keys compressed to that box. A cloud that leaves the remembered box is
+        # detected (status != 0) and redone on the 64-bit path, so results never depend on the guess.
+        info = torch.zeros(8, dtype=torch.int32, device=p.device)
+        base = info.data_ptr()
+        check(L.sp_voxel_key_box(_ptr(p), n, self.voxel_size_inv, C.c_void_p(base + 8), _stream()))
+        guess = getattr(self, "_key_box", None) if boxed else None
+        args = (_ptr(p), n, self.voxel_size_inv, self.min_voxel_count, _ptr(rgb), _ptr(inten), _ptr(ts), _ptr(o_p), _ptr(o_c),
+                _ptr(o_i), _ptr(o_t), _ptr(o_k), C.c_void_p(base))
+        if guess is not None:
+            check(L.sp_voxel_downsample_boxed(*args, guess.ctypes.data_as(C.c_void_p), C.c_void_p(base + 4), _ptr(ws), nbytes,
+                                              _stream()))
+        else:
+            check(L.sp_voxel_downsample(*args, _ptr(ws), nbytes, _stream()))
+        counts = info.cpu().numpy()
+        if counts[1] != 0:  # the cloud left the remembered box
+            check(L.sp_voxel_downsample(*args, _ptr(ws), nbytes, _stream()))
+            counts[0] = info[:1].cpu().numpy()[0]
+        box = counts[2:8].astype(np.int64)
+        if boxed and (box[:3] <= box[3:]).all():
+            margin = np.maximum(2, (box[3:] - box[:3] + 1) // 8)
+            lo = np.maximum(box[:3] - margin, 0)
+            hi = np.minimum(box[3:] + margin, (1 << 21) - 1)
+            self._key_box = np.ascontiguousarray(np.concatenate([lo, hi]).astype(np.int32))
+        v = int(counts[0])
         out.points = o_p[:v]
         out.rgb = None if o_c is None else o_c[:v]
         out.intensities = None if o_i is None else o_i[:v]

@@ -44,6 +44,83 @@ __global__ __launch_bounds__(kBlock) void key_kernel(const float4* __restrict__ 
     }
 }
 
+// Voxel coordinates (the three 21-bit fields of the key) of a point, false when the key would be invalid.
+__device__ __forceinline__ bool voxel_coords(const float4 p, float inv, int& c0, int& c1, int& c2) {
+    constexpr int64_t mask = (1 << 21) - 1;
+    constexpr int64_t offset = 1 << 20;
+    if (!isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z)) return false;
+    const int64_t a = (int64_t)floorf(p.x * inv) + offset, b = (int64_t)floorf(p.y * inv) + offset,
+                  c = (int64_t)floorf(p.z * inv) + offset;
+    if (a < 0 || mask < a || b < 0 || mask < b || c < 0 || mask < c) return false;
+    c0 = (int)a; c1 = (int)b; c2 = (int)c;
+    return true;
+}
+
+// Bounding box of the voxel coordinates (integer atomics: order-independent). box = {min x,y,z, max x,y,z}.
+__global__ void box_init_kernel(int32_t* box) {
+    if (threadIdx.x < 3) box[threadIdx.x] = INT32_MAX;
+    else if (threadIdx.x < 6) box[threadIdx.x] = INT32_MIN;
+}
+__global__ __launch_bounds__(kBlock) void key_box_kernel(const float4* __restrict__ pts, unsigned n, float inv,
+                                                         int32_t* __restrict__ box) {
+    int lo0 = INT32_MAX, lo1 = INT32_MAX, lo2 = INT32_MAX, hi0 = INT32_MIN, hi1 = INT32_MIN, hi2 = INT32_MIN;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int c0, c1, c2;
+        if (voxel_coords(pts[i], inv, c0, c1, c2)) {
+            lo0 = min(lo0, c0); lo1 = min(lo1, c1); lo2 = min(lo2, c2);
+            hi0 = max(hi0, c0); hi1 = max(hi1, c1); hi2 = max(hi2, c2);
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        lo0 = min(lo0, __shfl_xor(lo0, off)); lo1 = min(lo1, __shfl_xor(lo1, off)); lo2 = min(lo2, __shfl_xor(lo2, off));
+        hi0 = max(hi0, __shfl_xor(hi0, off)); hi1 = max(hi1, __shfl_xor(hi1, off)); hi2 = max(hi2, __shfl_xor(hi2, off));
+    }
+    // one set of atomics per workgroup (a few hundred per launch): wave results meet in LDS first
+    __shared__ int red[kBlock / kWave][6];
+    const unsigned wave = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red[wave][0] = lo0; red[wave][1] = lo1; red[wave][2] = lo2;
+        red[wave][3] = hi0; red[wave][4] = hi1; red[wave][5] = hi2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = red[0][threadIdx.x];
+        for (unsigned w = 1; w < kBlock / kWave; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&box[threadIdx.x], v);
+        else atomicMax(&box[threadIdx.x], v);
+    }
+}
+
+// Compressed key: the position of the voxel in its bounding box, z-major like the 63-bit key, so the order is the same;
+// `invalid` (= number of cells of the box) sorts after every valid key. A point outside the box (the box did not come
+// from this cloud) is counted in *status and dropped.
+struct KeyBox {
+    int x0, y0, z0;
+    unsigned nx, ny, nz;
+    unsigned invalid;
+};
+__global__ __launch_bounds__(kBlock) void key32_kernel(const float4* __restrict__ pts, unsigned n, float inv, KeyBox b,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ status) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int c0, c1, c2;
+        uint32_t key = b.invalid;
+        if (voxel_coords(pts[i], inv, c0, c1, c2)) {
+            const unsigned x = (unsigned)(c0 - b.x0), y = (unsigned)(c1 - b.y0), z = (unsigned)(c2 - b.z0);
+            if (x < b.nx && y < b.ny && z < b.nz) key = (z * b.ny + y) * b.nx + x;
+            else if (status) atomicAdd(status, 1u);
+        }
+        keys[i] = key;
+        vals[i] = i;
+    }
+}
+__device__ __forceinline__ uint64_t expand_key(uint32_t k, const KeyBox& b) {
+    if (k >= b.invalid) return kInvalidKey;
+    const unsigned x = k % b.nx, yz = k / b.nx, y = yz % b.ny, z = yz / b.ny;
+    return (uint64_t)(x + (unsigned)b.x0) | ((uint64_t)(y + (unsigned)b.y0) << 21) | ((uint64_t)(z + (unsigned)b.z0) << 42);
+}
+
 // VoxelGrid::compute_median (voxel_downsampling.hpp:82-98) without a scratch array: the element of rank r in a run
 // is the one with exactly r elements ordered before it ((value, position) lexicographic). O(L^2) per run.
 __device__ float run_select(const float* __restrict__ inten, const uint32_t* __restrict__ sv, unsigned b, unsigned e,
@@ -70,14 +147,15 @@ struct AggPtrs {
 };
 
 // One lane per sorted position; the head lane of a run owns the whole run (voxel_downsampling.hpp:194-208,243-268).
-__global__ __launch_bounds__(kBlock) void aggregate_kernel(const uint64_t* __restrict__ sk,
+template <typename KEY>
+__global__ __launch_bounds__(kBlock) void aggregate_kernel(const KEY* __restrict__ sk, KEY invalid,
                                                            const uint32_t* __restrict__ sv, unsigned n,
                                                            const float4* __restrict__ pts, float min_count, AggPtrs a,
                                                            float4* __restrict__ t_pts, uint32_t* __restrict__ flag) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const uint64_t key = sk[i];
-    const bool head = key != kInvalidKey && (i == 0 || sk[i - 1] != key);
+    const KEY key = sk[i];
+    const bool head = key != invalid && (i == 0 || sk[i - 1] != key);
     uint32_t keep = 0;
     if (head) {
         float px = 0.0f, py = 0.0f, pz = 0.0f, pw = 0.0f;
@@ -106,9 +184,10 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const uint64_t* __res
     flag[i] = keep;
 }
 
+template <typename KEY>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restrict__ flag,
                                                          const uint32_t* __restrict__ pos, unsigned n,
-                                                         const uint64_t* __restrict__ sk,
+                                                         const KEY* __restrict__ sk, KeyBox box,
                                                          const float4* __restrict__ t_pts, AggPtrs a,
                                                          float4* __restrict__ o_pts, float4* __restrict__ o_rgb,
                                                          float* __restrict__ o_inten, float* __restrict__ o_ts,
@@ -121,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restr
         if (a.rgb) o_rgb[p] = a.t_rgb[i];
         if (a.inten) o_inten[p] = a.t_inten[i];
         if (a.ts) o_ts[p] = a.t_ts[i];
-        if (o_keys) o_keys[p] = sk[i];
+        if (o_keys) o_keys[p] = sizeof(KEY) == 8 ? (uint64_t)sk[i] : expand_key((uint32_t)sk[i], box);
     }
     if (i == n - 1) *n_out = p + f;
 }
@@ -143,6 +222,12 @@ VoxelWs voxel_ws(size_t n) {
     size_t sort_bytes = 0, scan_bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                                     (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
+    size_t sort32_bytes = 0;
+    (void)rocprim::radix_sort_pairs<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                               rocprim::default_config, 0>>(
+        nullptr, sort32_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
+        (hipStream_t)0);
+    if (sort32_bytes > sort_bytes) sort_bytes = sort32_bytes;
     (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n,
                                   rocprim::plus<uint32_t>(), (hipStream_t)0);
     w.prim_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
@@ -205,17 +290,22 @@ extern "C" int sp_voxel_keys(const float* points, size_t n, float inv_voxel_size
 
 extern "C" size_t sp_voxel_downsample_workspace_bytes(size_t n) { return n ? sp::voxel_ws(n).total : 0; }
 
-extern "C" int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
-                                   const float* rgb, const float* intensities, const float* timestamps,
-                                   float* points_out, float* rgb_out, float* intensities_out, float* timestamps_out,
-                                   uint64_t* keys_out_opt, uint32_t* n_out_dev, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
-    using namespace sp;
-    hipStream_t st = as_stream(stream);
+namespace sp {
+namespace {
+// rocPRIM picks a merge sort (block sort + 20 merge launches, 200 us per 1M 64-bit keys) up to 1M items; with the keys
+// compressed to the bits the cloud's bounding box needs, Onesweep does ceil(bits / 8) passes instead.
+using OnesweepSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
+int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count, const float* rgb,
+                          const float* intensities, const float* timestamps, float* points_out, float* rgb_out,
+                          float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt, uint32_t* n_out_dev,
+                          const int32_t* box6_host, uint32_t* status_dev, void* workspace, size_t workspace_bytes,
+                          hipStream_t st) {
     if (!(inv_voxel_size > 0.0f)) {
         sp_set_error("voxel_size must be positive");  // voxel_downsampling.hpp:23-25
         return SP_ERR_INVALID_ARGUMENT;
     }
+    if (status_dev && hipMemsetAsync(status_dev, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
     if (n == 0) return hip_status(hipMemsetAsync(n_out_dev, 0, 4, st));
     if (n >= (1ull << 32)) {
         sp_set_error("[VoxelGrid::downsampling] more than 2^32 points");
@@ -227,21 +317,12 @@ extern "C" int sp_voxel_downsample(const float* points, size_t n, float inv_voxe
         return SP_ERR_INVALID_ARGUMENT;
     }
     char* base = static_cast<char*>(workspace);
-    uint64_t* keys_in = (uint64_t*)(base + w.keys_in);
-    uint64_t* keys_sorted = (uint64_t*)(base + w.keys_out);
     uint32_t* vals_in = (uint32_t*)(base + w.vals_in);
     uint32_t* vals_sorted = (uint32_t*)(base + w.vals_out);
     uint32_t* flag = (uint32_t*)(base + w.flag);
     uint32_t* pos = (uint32_t*)(base + w.pos);
     float4* t_pts = (float4*)(base + w.t_pts);
     const float4* pts = reinterpret_cast<const float4*>(points);
-
-    key_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, keys_in, vals_in);
-    size_t prim_bytes = w.prim_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(base + w.prim, prim_bytes, keys_in, keys_sorted, vals_in, vals_sorted, n,
-                                             0, 64, st);
-    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
-
     AggPtrs a;
     a.rgb = reinterpret_cast<const float4*>(rgb);
     a.inten = intensities;
@@ -249,16 +330,92 @@ extern "C" int sp_voxel_downsample(const float* points, size_t n, float inv_voxe
     a.t_rgb = (float4*)(base + w.t_rgb);
     a.t_inten = (float*)(base + w.t_inten);
     a.t_ts = (float*)(base + w.t_ts);
-    aggregate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(keys_sorted, vals_sorted, (unsigned)n, pts,
-                                                           (float)min_voxel_count, a, t_pts, flag);
+
+    // compressed 32-bit keys when the caller knows the bounding box of the voxel coordinates and it has < 2^32 cells
+    KeyBox kb{0, 0, 0, 0, 0, 0, 0};
+    bool boxed = false;
+    if (box6_host && box6_host[0] <= box6_host[3] && box6_host[1] <= box6_host[4] && box6_host[2] <= box6_host[5]) {
+        const uint64_t nx = (uint64_t)((int64_t)box6_host[3] - box6_host[0] + 1), ny = (uint64_t)((int64_t)box6_host[4] - box6_host[1] + 1),
+                       nz = (uint64_t)((int64_t)box6_host[5] - box6_host[2] + 1);
+        if (nx < (1ull << 21) + 1 && ny < (1ull << 21) + 1 && nz < (1ull << 21) + 1 && nx * ny < (1ull << 32) &&
+            nx * ny * nz < 0xFFFFFFFFull) {
+            kb = KeyBox{box6_host[0], box6_host[1], box6_host[2], (unsigned)nx, (unsigned)ny, (unsigned)nz,
+                        (unsigned)(nx * ny * nz)};
+            boxed = true;
+        }
+    }
+    size_t prim_bytes = w.prim_bytes;
+    hipError_t e;
+    if (boxed) {
+        uint32_t* k_in = (uint32_t*)(base + w.keys_in);
+        uint32_t* k_sorted = (uint32_t*)(base + w.keys_out);
+        key32_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, status_dev);
+        unsigned end_bit = 1;
+        while ((1ull << end_bit) <= (uint64_t)kb.invalid && end_bit < 32) ++end_bit;  // `invalid` itself must be representable
+        e = rocprim::radix_sort_pairs<OnesweepSort>(base + w.prim, prim_bytes, k_in, k_sorted, vals_in, vals_sorted, n, 0,
+                                                    end_bit, st);
+        if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+        aggregate_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(k_sorted, kb.invalid, vals_sorted, (unsigned)n, pts,
+                                                                         (float)min_voxel_count, a, t_pts, flag);
+        prim_bytes = w.prim_bytes;
+        e = rocprim::exclusive_scan(base + w.prim, prim_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st);
+        if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+        scatter_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(
+            flag, pos, (unsigned)n, k_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
+            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+        return launch_status();
+    }
+    uint64_t* keys_in = (uint64_t*)(base + w.keys_in);
+    uint64_t* keys_sorted = (uint64_t*)(base + w.keys_out);
+    key_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, keys_in, vals_in);
+    e = rocprim::radix_sort_pairs(base + w.prim, prim_bytes, keys_in, keys_sorted, vals_in, vals_sorted, n, 0, 64, st);
+    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    aggregate_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(keys_sorted, kInvalidKey, vals_sorted, (unsigned)n, pts,
+                                                                     (float)min_voxel_count, a, t_pts, flag);
     prim_bytes = w.prim_bytes;
     e = rocprim::exclusive_scan(base + w.prim, prim_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st);
     if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
-    scatter_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(flag, pos, (unsigned)n, keys_sorted, t_pts, a,
-                                                         reinterpret_cast<float4*>(points_out),
-                                                         reinterpret_cast<float4*>(rgb_out), intensities_out,
-                                                         timestamps_out, keys_out_opt, n_out_dev);
+    scatter_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(
+        flag, pos, (unsigned)n, keys_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
+        reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
     return launch_status();
+}
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
+                                   const float* rgb, const float* intensities, const float* timestamps,
+                                   float* points_out, float* rgb_out, float* intensities_out, float* timestamps_out,
+                                   uint64_t* keys_out_opt, uint32_t* n_out_dev, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    return sp::voxel_downsample_impl(points, n, inv_voxel_size, min_voxel_count, rgb, intensities, timestamps, points_out,
+                                     rgb_out, intensities_out, timestamps_out, keys_out_opt, n_out_dev, nullptr, nullptr,
+                                     workspace, workspace_bytes, sp::as_stream(stream));
+}
+
+extern "C" int sp_voxel_key_box(const float* points, size_t n, float inv_voxel_size, int32_t* box6_dev, void* stream) {
+    using namespace sp;
+    if (!box6_dev) return SP_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    box_init_kernel<<<1, 64, 0, st>>>(box6_dev);
+    if (n) {
+        unsigned grid = div_up(n, kBlock * 16);  // >= 16 points per lane: a few hundred workgroups, a few hundred atomics
+        if (grid > 512u) grid = 512u;
+        key_box_kernel<<<grid ? grid : 1u, kBlock, 0, st>>>(reinterpret_cast<const float4*>(points), (unsigned)n,
+                                                            inv_voxel_size, box6_dev);
+    }
+    return launch_status();
+}
+
+extern "C" int sp_voxel_downsample_boxed(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
+                                         const float* rgb, const float* intensities, const float* timestamps,
+                                         float* points_out, float* rgb_out, float* intensities_out,
+                                         float* timestamps_out, uint64_t* keys_out_opt, uint32_t* n_out_dev,
+                                         const int32_t* box6_host, uint32_t* status_dev_opt, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    return sp::voxel_downsample_impl(points, n, inv_voxel_size, min_voxel_count, rgb, intensities, timestamps, points_out,
+                                     rgb_out, intensities_out, timestamps_out, keys_out_opt, n_out_dev, box6_host,
+                                     status_dev_opt, workspace, workspace_bytes, sp::as_stream(stream));
 }
 
 extern "C" int sp_box_filter_flags(const float* points, size_t n, float min_distance, float max_distance,

@@ -273,6 +273,50 @@ def test_voxel_known_answer_and_edges(sp, orc):
         sp.VoxelGrid(0.0)
 
 
+def test_voxel_boxed_path_equals_64bit_path(sp, orc):
+    """sp_voxel_downsample_boxed sorts keys compressed to the cloud's bounding box; every output (and the 63-bit keys) must
+    equal the 64-bit path, including clouds with invalid points, a box too large for 32 bits (falls back) and a stale
+    box (status != 0)."""
+    import ctypes as C
+
+    rs = np.random.RandomState(3)
+    n = 60000
+    for pts, vs in ((cloud(orc, 5, n, 8.0), 0.3), (cloud(orc, 6, n, 2000.0), 0.002)):  # second: > 2^32 cells -> fallback
+        pts = pts.copy()
+        pts[7, 1] = np.inf
+        pts[9, 0] = 3e9  # coordinate outside the 21-bit range: invalid key
+        inten = rs.uniform(0, 255, n).astype(np.float32)
+        pc = sp.PointCloudShared(dev(pts), intensities=dev(inten))
+        vg = sp.VoxelGrid(vs)
+        b, kb = vg.downsampling(pc, return_keys=True, boxed=False)
+        for _ in range(2):  # first call: no remembered box yet (64-bit sort); second call: compressed keys
+            a, ka = vg.downsampling(pc, return_keys=True, boxed=True)
+            assert torch.equal(ka, kb) and torch.equal(a.points, b.points) and torch.equal(a.intensities, b.intensities)
+        # a cloud that leaves the remembered box is redone on the 64-bit path
+        far = sp.PointCloudShared(dev(pts + np.float32([500.0, 0, 0, 0])), intensities=dev(inten))
+        c, kc = vg.downsampling(far, return_keys=True, boxed=True)
+        d, kd = sp.VoxelGrid(vs).downsampling(far, return_keys=True, boxed=False)
+        assert torch.equal(kc, kd) and torch.equal(c.points, d.points)
+    # a box that does not cover the cloud is reported, not silently accepted
+    L = sp._lib.lib()
+    pts = cloud(orc, 7, 5000, 4.0)
+    P = dev(pts)
+    nb = L.sp_voxel_downsample_workspace_bytes(5000)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    o = torch.empty((5000, 4), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    box = np.array([1 << 20, 1 << 20, 1 << 20, (1 << 20) + 3, (1 << 20) + 3, (1 << 20) + 3], np.int32)  # positive octant only
+    sp._lib.check(L.sp_voxel_downsample_boxed(sp._ptr(P), 5000, 1.0, 1, None, None, None, sp._ptr(o), None, None, None, None,
+                                              sp._ptr(cnt), box.ctypes.data_as(C.c_void_p), C.c_void_p(cnt.data_ptr() + 4),
+                                              sp._ptr(ws), nb, sp._stream()))
+    assert int(cnt[1]) > 0
+    boxd = torch.empty(6, dtype=torch.int32, device="cuda")
+    sp._lib.check(L.sp_voxel_key_box(sp._ptr(P), 5000, 1.0, sp._ptr(boxd), sp._stream()))
+    keys = sp.VoxelGrid(1.0).compute_voxel_bit(P).cpu().numpy().view(np.uint64)
+    f = [(keys >> s) & ((1 << 21) - 1) for s in (0, 21, 42)]
+    assert boxd.cpu().numpy().tolist() == [int(x.min()) for x in f] + [int(x.max()) for x in f]
+
+
 def test_voxel_config3_1m(sp, orc):
     # BASELINE config 3 at full size: 1M points, voxel 0.1; oracle keys everywhere, oracle means on the whole cloud
     pts = cloud(orc, 1234, 1000000, 10.0)
