@@ -5,6 +5,7 @@
 //   algorithms/knn/kdtree.hpp     : KDTree (host build with the reference's split rule, device search)
 //   + GridKNN: an MI355X-native KNNBase (device-built uniform grid), no counterpart file in the reference.
 #pragma once
+#include <atomic>
 #include "core.hpp"
 
 namespace sycl_points {
@@ -107,6 +108,9 @@ public:
         auto t = std::make_shared<KDTree>(q);
         throw_on_error(sp_kdtree_create(reinterpret_cast<const float*>(points.data()), points.size(), leaf_threshold,
                                         q.stream(), &t->tree_));
+        static std::atomic<uint64_t> next_id{1};
+        t->id_ = next_id.fetch_add(1);
+        t->size_ = points.size();
         return t;
     }
     static Ptr build(const sycl_utils::DeviceQueue& q, const PointCloudShared& cloud, size_t leaf_threshold = 16) {
@@ -145,10 +149,19 @@ public:
             throw std::runtime_error("[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.");
         throw_on_error(sp_kdtree_remove_by_flags(tree_, flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
         queue.wait();
+        pristine_ = false;
     }
+    /// Identity of the built tree (unique per build), its point count, and whether no node was ever removed — what
+    /// Registration::align needs to decide that a GridKNN on the same cloud answers the same nearest-neighbour queries.
+    uint64_t id() const { return id_; }
+    size_t size() const { return size_; }
+    bool pristine() const { return pristine_; }
 
 private:
     sp_kdtree* tree_ = nullptr;
+    uint64_t id_ = 0;
+    size_t size_ = 0;
+    bool pristine_ = true;
 };
 
 /// MI355X-native KNNBase: exact kNN on a device-built uniform grid (sp_grid_*). Bit-identical to
@@ -167,9 +180,12 @@ public:
                      float cell_size = 0.0f) {
         auto g = std::make_shared<GridKNN>(q);
         throw_on_error(sp_grid_create(cloud.points_device(), cloud.size(), cell_size, points_per_cell, q.stream(), &g->grid_));
+        static std::atomic<uint64_t> next_id{1};
+        g->id_ = next_id.fetch_add(1);
         return g;
     }
     const sp_grid* handle() const { return grid_; }
+    uint64_t id() const { return id_; }  ///< unique per build (a handle address can be reused after destruction)
     size_t size() const { return sp_grid_size(grid_); }
     float cell_size() const { return sp_grid_cell_size(grid_); }
 
@@ -188,6 +204,7 @@ public:
 
 private:
     sp_grid* grid_ = nullptr;
+    uint64_t id_ = 0;
 };
 
 }  // namespace knn

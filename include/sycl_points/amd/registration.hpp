@@ -167,6 +167,10 @@ public:
         float lm_lambda = params_.lm.init_lambda;
         float trust_region_radius = params_.dogleg.initial_trust_region_radius;
         const auto* grid = dynamic_cast<const knn::GridKNN*>(&target_knn);
+        // A caller that still hands over the reference's KDTree gets the same correspondences (exact nearest neighbours;
+        // only the order of exactly equidistant points can differ) from a GridKNN built on the target once per tree.
+        if (grid == nullptr && accelerate_kdtree_ && params_.reg_type == RegType::GICP)
+            if (const auto* kd = dynamic_cast<const knn::KDTree*>(&target_knn)) grid = grid_for(*kd, target);
         const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size();
         if (fused) prepare_fused(source, target, *grid, initial_guess);
         // GICP + Gauss-Newton on a GridKNN: the whole loop runs on the device (one launch per iteration, convergence
@@ -194,6 +198,10 @@ public:
         }
         return result;
     }
+
+    /// MI355X extension: when align() is given a KDTree (no nodes removed) and the factor is GICP, search on a GridKNN
+    /// built from the target instead (default on; results agree to rounding with the KD-tree path).
+    void set_accelerate_kdtree(bool v) { accelerate_kdtree_ = v; }
 
     /// MI355X extension: tell align() that source clouds arrive spatially ordered (GridKNN::order() / voxel-downsampled
     /// clouds), so the prepared path skips its per-alignment sort (SP_SOURCE_PRESORTED).
@@ -274,11 +282,11 @@ private:
     }
     void prepare_fused(const PointCloudShared& source, const PointCloudShared& target, const knn::GridKNN& grid,
                        const TransformMatrix& T0) {
-        if (ptgt_ == nullptr || ptgt_grid_ != grid.handle()) {
+        if (ptgt_ == nullptr || ptgt_grid_id_ != grid.id()) {
             if (ptgt_) sp_gicp_target_destroy(ptgt_);
             ptgt_ = nullptr;
             throw_on_error(sp_gicp_target_create(grid.handle(), target.covs_device(), target.size(), queue_.stream(), &ptgt_));
-            ptgt_grid_ = grid.handle();
+            ptgt_grid_id_ = grid.id();
         } else {
             throw_on_error(sp_gicp_target_update(ptgt_, target.covs_device(), queue_.stream()));
         }
@@ -291,6 +299,15 @@ private:
         throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, source.points_device(), source.covs_device(), source.size(),
                                               T0.data(), 0, source_presorted_ ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT, queue_.stream()));
         neighbors_.indices == nullptr ? neighbors_.allocate(queue_, source.size(), 1) : neighbors_.resize(source.size(), 1);
+    }
+    const knn::GridKNN* grid_for(const knn::KDTree& tree, const PointCloudShared& target) {
+        if (!tree.pristine() || tree.size() != target.size() || target.size() == 0) return nullptr;
+        if (kd_grid_ == nullptr || kd_grid_tree_id_ != tree.id()) {
+            if (ptgt_) { sp_gicp_target_destroy(ptgt_); ptgt_ = nullptr; ptgt_grid_id_ = 0; }  // it borrows the old grid
+            kd_grid_ = knn::GridKNN::build(queue_, target);
+            kd_grid_tree_id_ = tree.id();
+        }
+        return kd_grid_.get();
     }
     RegistrationResult align_on_device(size_t N, const TransformMatrix& initial_guess, float robust_scale) {
         const sp_factor_params fp = factor_params(robust_scale);
@@ -443,8 +460,11 @@ private:
     sp_gicp_source* psrc_ = nullptr;
     size_t psrc_cap_ = 0;
     sp_gicp_target* ptgt_ = nullptr;
-    const sp_grid* ptgt_grid_ = nullptr;
+    uint64_t ptgt_grid_id_ = 0;  // GridKNN::id() the prepared target was built on
     bool source_presorted_ = false;
+    bool accelerate_kdtree_ = true;
+    knn::GridKNN::Ptr kd_grid_;        // GridKNN standing in for the caller's KDTree (grid_for)
+    uint64_t kd_grid_tree_id_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------------ pipeline wrappers

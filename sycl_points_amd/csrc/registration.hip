@@ -530,12 +530,6 @@ __global__ __launch_bounds__(kBlock) void query_cell_kernel(const float4* __rest
     keys[i] = key;
     vals[i] = i;
 }
-__global__ __launch_bounds__(kBlock) void gather_points_kernel(const float4* __restrict__ pts,
-                                                               const unsigned* __restrict__ order, unsigned n,
-                                                               float4* __restrict__ out) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) out[i] = pts[order ? order[i] : i];
-}
 // gather_points + prepare_cov for the source in one pass over the permutation
 __global__ __launch_bounds__(kBlock) void prepare_source_kernel(const float4* __restrict__ pts,
                                                                 const float4* __restrict__ covs,

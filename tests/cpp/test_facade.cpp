@@ -223,6 +223,9 @@ static void registration_matches_oracle() {
     auto grid = alg::knn::GridKNN::build(*Q, target);
     HostBruteForceKNN host_knn(*Q, target);
     alg::registration::Registration reg(*Q, p);
+    const auto r_tree_grid = reg.align(source, target, *tree);     // a KDTree caller is served by an internal GridKNN
+    CHECK(max_abs_diff(r_tree_grid.T.matrix(), ref.T) < 1e-5f && r_tree_grid.inlier == ref.inlier);
+    reg.set_accelerate_kdtree(false);
     const auto r_tree = reg.align(source, target, *tree);          // generic path: KNNBase search + K11
     const auto r_grid = reg.align(source, target, *grid);          // fused path (GridKNN recognised)
     const auto r_host = reg.align(source, target, host_knn);       // injected host KNN through the same seam
