@@ -169,8 +169,12 @@ public:
         const auto* grid = dynamic_cast<const knn::GridKNN*>(&target_knn);
         // A caller that still hands over the reference's KDTree gets the same correspondences (exact nearest neighbours;
         // only the order of exactly equidistant points can differ) from a GridKNN built on the target once per tree.
-        if (grid == nullptr && accelerate_kdtree_ && params_.reg_type == RegType::GICP)
+        if (grid == nullptr && accelerate_kdtree_)
             if (const auto* kd = dynamic_cast<const knn::KDTree*>(&target_knn)) grid = grid_for(*kd, target);
+        // every factor type searches on the grid when there is one (4x faster per k = 1 search than the KD-tree kernel);
+        // GICP additionally fuses search and linearisation
+        const knn::KNNBase& nn = (grid != nullptr && grid->size() == target.size()) ? static_cast<const knn::KNNBase&>(*grid)
+                                                                                     : target_knn;
         const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size();
         if (fused) prepare_fused(source, target, *grid, initial_guess);
         // GICP + Gauss-Newton on a GridKNN: the whole loop runs on the device (one launch per iteration, convergence
@@ -181,7 +185,7 @@ public:
 
         for (size_t iter = 0; iter < params_.max_iterations; ++iter) {
             const LinearizedResult lin = fused ? linearize_fused(source.size(), result.T.matrix(), robust_scale)
-                                               : linearize_generic(source, target, target_knn, result.T.matrix(), robust_scale);
+                                               : linearize_generic(source, target, nn, result.T.matrix(), robust_scale);
             result.H_raw = lin.H; result.b_raw = lin.b; result.error_raw = lin.error;
             switch (params_.optimization_method) {
                 case OptimizationMethod::LEVENBERG_MARQUARDT:
