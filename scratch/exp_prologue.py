@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import os, sys; sys.path.insert(0,'.')
 import numpy as np, torch, ctypes as C
 import sycl_points_amd.api as sp
 from sycl_points_amd import _lib
@@ -34,3 +34,11 @@ t=[timed(run(k)) for k in (1,2,3,5,9)]
 print("launch counts 1,2,3,5,9 at the converged pose: %s us"%[round(x,1) for x in t])
 print("per extra launch (with prologue): %.1f us ; first launch (no prologue): %.1f us"%((t[4]-t[0])/8, t[0]))
 L.sp_debug_set_fused_stage_mask(3)
+if os.environ.get("SP_TM"):
+    import struct
+    L.sp_debug_set_fused_stage_mask(1)
+    run(4)(); torch.cuda.synchronize()
+    raw = ws.cpu().numpy().tobytes()
+    off = 2 * 256 * 32 * 4 + 2 * 112
+    t = struct.unpack("7Q", raw[off:off + 56])
+    print("memtime deltas in ticks: start->rows+reduce %d | unpack %d | solve %d | publish+barrier %d | main loop %d | final reduce %d ; total %d" % (tuple(t[i + 1] - t[i] for i in range(6)) + (t[6] - t[0],)))

@@ -354,8 +354,11 @@ __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, flo
 // Sum `rows` partial rows with a 1024-lane workgroup in a fixed order: lane = (part, slot); the 32 parts cover
 // contiguous row ranges (independent loads, added in row order), then lanes 0..31 add the 32 parts in order.
 // On return (after a barrier) red[0][e] holds the totals; slot nv is the uint32 count.
+// `after_loads` runs once the row loads have been issued (and before the first barrier): the per-iteration kernel stores
+// the previous state there, which it loaded BEFORE the rows, so that both arrive in the same memory round trip.
+template <typename Hook>
 __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ partials, unsigned rows, int nv,
-                                                 float (*red)[kPartial], bool count_is_float = false) {
+                                                 float (*red)[kPartial], bool count_is_float, Hook after_loads) {
     constexpr unsigned kParts = kFinalThreads / 32;
     const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;
     const unsigned per = (rows + kParts - 1) / kParts;
@@ -363,24 +366,45 @@ __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ parti
     float s = 0.0f;
     unsigned c = 0;
     const bool is_count = ((int)e == nv);
+    if (per <= 8) {  // at most 256 rows (the per-iteration kernel): all loads of a lane in flight at once
+        float v[8];
+#pragma unroll
+        for (unsigned j = 0; j < 8; ++j) v[j] = (lo + j < hi) ? partials[(size_t)(lo + j) * kPartial + e] : 0.0f;
+        after_loads();
+#pragma unroll
+        for (unsigned j = 0; j < 8; ++j) {
+            if (lo + j < hi) {
+                if (is_count) c += count_is_float ? (unsigned)v[j] : __float_as_uint(v[j]);
+                else s += v[j];
+            }
+        }
+    } else {
 #pragma unroll 8
-    for (unsigned b = lo; b < hi; ++b) {
-        const float v = partials[(size_t)b * kPartial + e];
-        if (is_count) c += count_is_float ? (unsigned)v : __float_as_uint(v);
-        else s += v;
+        for (unsigned b = lo; b < hi; ++b) {
+            const float v = partials[(size_t)b * kPartial + e];
+            if (is_count) c += count_is_float ? (unsigned)v : __float_as_uint(v);
+            else s += v;
+        }
+        after_loads();
     }
     red[part][e] = is_count ? __uint_as_float(c) : s;
     __syncthreads();
     if (threadIdx.x < 32) {
         float t = 0.0f;
         unsigned ct = 0;
+#pragma unroll
         for (unsigned p = 0; p < kParts; ++p) {
-            if (is_count) ct += __float_as_uint(red[p][e]);
-            else t += red[p][e];
+            const float v = red[p][e];
+            if (is_count) ct += __float_as_uint(v);
+            else t += v;
         }
         red[0][e] = is_count ? __uint_as_float(ct) : t;
     }
     __syncthreads();
+}
+__device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ partials, unsigned rows, int nv,
+                                                 float (*red)[kPartial], bool count_is_float = false) {
+    reduce_rows_1024(partials, rows, nv, red, count_is_float, [] {});
 }
 
 // totals (21 upper-triangle H, 6 b, error | error only) + count -> sp_linearized
@@ -749,13 +773,16 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
     __shared__ unsigned sconv;
     __shared__ LdltScratch ldlt_ws;
     if (A.has_prev) {
-        // Every global load of the prologue is issued up front — the previous state (pose, flags) by lanes 16..33 next to
-        // the partial rows — so that the prologue is ONE memory round trip deep, not three (flag, rows, pose).
+        // The previous state (pose, flags: lanes 0..17 of wave 0) is loaded BEFORE the partial rows and stored to LDS
+        // AFTER the row loads have been issued, so the prologue is ONE memory round trip deep, not three.
         __shared__ unsigned sprev[2];
-        if (threadIdx.x >= 16 && threadIdx.x < 32) sT[threadIdx.x - 16] = A.state_in->T[threadIdx.x - 16];
-        if (threadIdx.x == 32) sprev[0] = A.state_in->converged;
-        if (threadIdx.x == 33) sprev[1] = A.state_in->iterations;
-        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0);  // (two barriers inside)
+        float pre = 0.0f;
+        if (threadIdx.x < 18)
+            pre = reinterpret_cast<const float*>(A.state_in)[threadIdx.x < 16 ? threadIdx.x : threadIdx.x + 8];
+        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0, [&] {
+            if (threadIdx.x < 16) sT[threadIdx.x] = pre;
+            else if (threadIdx.x < 18) sprev[threadIdx.x - 16] = __float_as_uint(pre);  // converged, iterations
+        });
         if (sprev[0]) {  // uniform over the grid: an earlier iteration converged, this launch has nothing to do
             if (blockIdx.x == 0 && threadIdx.x == 0) *A.state_out = *A.state_in;
             return false;

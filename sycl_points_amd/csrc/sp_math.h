@@ -399,6 +399,11 @@ SP_HD bool ldlt6_solve(const float* H, const float* rhs, float* x, LdltScratch&,
 #pragma unroll
         for (int i = k + 1; i < 6; ++i)
             if (fabsf(m[i][i]) > best) { best = fabsf(m[i][i]); piv = i; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        // one lane runs this solver: make the pivot a scalar so that `piv == p` is a real (uniform) branch and only the
+        // taken swap executes, instead of every candidate swap being evaluated under a select
+        piv = __builtin_amdgcn_readfirstlane(piv);
+#endif
 #pragma unroll
         for (int p = k + 1; p < 6; ++p) {
             if (piv == p) {
