@@ -15,7 +15,7 @@
 void sp_set_error(const char* msg);
 
 static int g_fused_stage_mask = 3;  // measurement hook: bit 0 = fused kernel, bit 1 = final reduce (+ solve)
-static int g_fused_reuse = 1;  // tuning hook: carry correspondences between iterations when provably unchanged
+static int g_fused_reuse = 2;  // tuning hook: 0 always search, 1 reuse on the first certificate, 2 also the second
 static int g_fused_fast_nn = -1;  // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
 
 namespace sp {
@@ -525,13 +525,34 @@ __global__ __launch_bounds__(kBlock) void prepare_cov_kernel(const float4* __res
     out[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], rho2 ? rho2[src] : 0.0f, 0.0f);
 }
 
-// rho2[i] = (distance from target point i to its nearest OTHER target point / 2)^2, shrunk by 1e-3 to stay clear of
-// rounding. d2 holds the k = 2 self-kNN distances (row i, original order: the point itself at 0, then its nearest other
-// point; FLT_MAX when there is none).
-__global__ __launch_bounds__(kBlock) void safe_radius_kernel(const float* __restrict__ d2, unsigned n,
-                                                             float* __restrict__ rho2) {
+// Certificates of the correspondence reuse (fused_point), from one k = 3 self-search on the target grid (row i, original
+// order: the point itself at 0, its nearest other point u1, its second-nearest u2; -1 / FLT_MAX when missing):
+//   rho2[i]  = (d(t, u1) / 2)^2            first test:  |q - t|^2 < rho2            (stored in t's covariance row)
+//   nb[pos]  = (u1.xyz, (d(t, u2) / 2)^2)  second test: |q - t| < |q - u1| and |q - t|^2 < nb.w   (grid order)
+// both shrunk by 1e-3 to stay clear of rounding. inv maps an original index to its grid position.
+__global__ __launch_bounds__(kBlock) void inverse_order_kernel(const float4* __restrict__ gpts, unsigned n,
+                                                               unsigned* __restrict__ inv) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) rho2[i] = d2[2 * (size_t)i + 1] * (0.25f * (1.0f - 1e-3f));
+    if (i < n) inv[__float_as_uint(gpts[i].w)] = i;
+}
+__global__ __launch_bounds__(kBlock) void certificate_kernel(const float4* __restrict__ gpts, unsigned n,
+                                                             const int32_t* __restrict__ idx3,
+                                                             const float* __restrict__ d23,
+                                                             const unsigned* __restrict__ inv,
+                                                             float* __restrict__ rho2, float4* __restrict__ nb) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;  // grid position
+    if (i >= n) return;
+    const unsigned o = __float_as_uint(gpts[i].w);
+    constexpr float kShrink = 0.25f * (1.0f - 1e-3f);
+    rho2[o] = d23[3 * (size_t)o + 1] * kShrink;
+    const int u1 = idx3[3 * (size_t)o + 1];
+    float4 r = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);  // no other point: the distance test always passes
+    if (u1 >= 0) {
+        const float4 p = gpts[inv[u1]];
+        r.x = p.x; r.y = p.y; r.z = p.z;
+    }
+    r.w = d23[3 * (size_t)o + 2] * kShrink;
+    nb[i] = r;
 }
 
 // Source ordering: key = cell (of the TARGET grid) that T*p falls into, so that consecutive lanes of the fused
@@ -580,6 +601,7 @@ struct FusedParams {
     const float4* tpts;    // grid-ordered target points
     const unsigned* tstart;
     const float4* tcovp;   // grid-ordered prepared target covariances
+    const float4* tnb;     // grid order: second certificate of the reuse test (certificate_kernel), may be null
     GridDesc g;
     unsigned n;
     float max_d2, scale;
@@ -686,7 +708,16 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         if (row && P.cache_valid) {
             const float4 tp = row[0], c0 = row[1], c1 = row[2];
             const float d = dist2(qx, qy, qz, tp.x, tp.y, tp.z);
-            if (d < c1.z) {
+            bool pass = d < c1.z;
+            if (!pass && P.tnb && c1.z > 0.0f) {
+                // Second chance before a search (t has a close neighbour u1, so rho_t is tiny — such points would be searched in
+                // EVERY iteration and hold their whole workgroup back): t is also certified when |q - t| < |q - u1| and
+                // |q - t| < d(t, u2) / 2, u2 being t's second-nearest other point — every target u other than t and u1 then has
+                // |q - u| >= |t - u| - |q - t| >= d(t, u2) - |q - t| > |q - t|. One 16-byte gather instead of a search.
+                const float4 nb = P.tnb[__float_as_uint(c1.w)];
+                pass = d < nb.w && d < dist2(qx, qy, qz, nb.x, nb.y, nb.z);
+            }
+            if (pass) {
                 hit = true;
                 nn.d2 = d; nn.idx = __float_as_int(tp.w); nn.pos = __float_as_uint(c1.w); nn.x = tp.x; nn.y = tp.y; nn.z = tp.z;
                 Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
@@ -1066,6 +1097,7 @@ struct sp_gicp_target {
     const sp_grid* grid = nullptr;  // borrowed: must outlive this object
     float4* covp = nullptr;         // 2 x float4 per target point, grid order: (xx,xy,xz,yy | yz,zz,rho^2,0)
     float* rho2 = nullptr;          // per target point (original order): squared safe radius of the reuse test
+    float4* nb = nullptr;           // per target point (grid order): second certificate (nearest neighbour, second radius)
     unsigned long long version = 0; // bumped by every sp_gicp_target_update (cached copies of rows become stale)
     size_t n = 0;
 };
@@ -1088,6 +1120,7 @@ extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
     if (!t) return;
     if (t->covp) (void)hipFree(t->covp);
     if (t->rho2) (void)hipFree(t->rho2);
+    if (t->nb) (void)hipFree(t->nb);
     delete t;
 }
 extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, void* stream) {
@@ -1125,24 +1158,28 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
         }
     }
     if (n) {
-        // safe radii: one k = 2 self-search on the grid (the point itself, then its nearest other point), once per target
+        // certificates of the correspondence reuse: one k = 3 self-search on the grid, once per target
         hipStream_t st = as_stream(stream);
-        int32_t* idx2 = nullptr;
-        float* d22 = nullptr;
+        int32_t* idx3 = nullptr;
+        float* d23 = nullptr;
+        unsigned* inv = nullptr;
         void* ws = nullptr;
         const size_t ws_bytes = sp_grid_self_workspace_bytes(grid);
         hipError_t e = hipMalloc(&t->rho2, n * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&idx2, n * 2 * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&d22, n * 2 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&t->nb, n * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc(&idx3, n * 3 * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&d23, n * 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&inv, n * sizeof(unsigned));
         if (e == hipSuccess && ws_bytes) e = hipMalloc(&ws, ws_bytes);
         int rc2 = e == hipSuccess ? SP_OK : SP_ERR_HIP;
-        if (rc2 == SP_OK) rc2 = sp_grid_self_knn(grid, 2, idx2, d22, nullptr, nullptr, ws, ws_bytes, stream);
+        if (rc2 == SP_OK) rc2 = sp_grid_self_knn(grid, 3, idx3, d23, nullptr, nullptr, ws, ws_bytes, stream);
         if (rc2 == SP_OK) {
-            safe_radius_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(d22, (unsigned)n, t->rho2);
+            inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
+            certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb);
             rc2 = launch_status();
         }
         if (rc2 == SP_OK && hipStreamSynchronize(st) != hipSuccess) rc2 = SP_ERR_HIP;
-        (void)hipFree(idx2); (void)hipFree(d22); (void)hipFree(ws);
+        (void)hipFree(idx3); (void)hipFree(d23); (void)hipFree(inv); (void)hipFree(ws);
         if (rc2 != SP_OK) {
             if (e != hipSuccess) sp_set_error(hipGetErrorString(e));
             sp_gicp_target_destroy(t);
@@ -1247,6 +1284,7 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
     P.tpts = target->grid->d_pts;
     P.tstart = target->grid->d_start;
     P.tcovp = target->covp;
+    P.tnb = g_fused_reuse > 1 ? target->nb : nullptr;
     P.g = grid_desc(target->grid);
     P.n = (unsigned)n;
     P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
