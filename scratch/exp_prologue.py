@@ -40,5 +40,5 @@ if os.environ.get("SP_TM"):
     run(4)(); torch.cuda.synchronize()
     raw = ws.cpu().numpy().tobytes()
     off = 2 * 256 * 32 * 4 + 2 * 112
-    t = struct.unpack("7Q", raw[off:off + 56])
-    print("memtime deltas in ticks: start->rows+reduce %d | unpack %d | solve %d | publish+barrier %d | main loop %d | final reduce %d ; total %d" % (tuple(t[i + 1] - t[i] for i in range(6)) + (t[6] - t[0],)))
+    t = struct.unpack("34Q", raw[off:off + 34 * 8])
+    print("block 0, ticks from kernel-side start: prologue done %d ; per-wave main-loop end %s ; block reduce done %d" % (t[1] - t[0], [t[17 + w] - t[0] for w in range(16)], t[33] - t[0]))

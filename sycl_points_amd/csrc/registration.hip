@@ -256,9 +256,9 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cn
     __shared__ float red[BLOCK / kWave][kPartial];
     const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
-    for (int e = 0; e < NV; ++e) acc[e] = wave_sum(acc[e]);
-    cnt = wave_sum_u32(cnt);
-    if (lane == 0) {
+    for (int e = 0; e < NV; ++e) acc[e] = wave_sum_to_lane63(acc[e]);
+    cnt = wave_sum_u32_to_lane63(cnt);
+    if (lane == kWave - 1) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) red[wave][e] = acc[e];
         red[wave][NV] = __uint_as_float(cnt);

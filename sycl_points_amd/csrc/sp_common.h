@@ -41,6 +41,33 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
     return v;
 }
 
+// wave64 sum delivered to lane 63 only, on the VALU's DPP path (no LDS crossbar): an inclusive scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3. Six adds per value; `__shfl_xor` costs a ds_bpermute per step (measured: the 28-value
+// workgroup reduction at the end of the GICP kernels took 6 us of a 27 us launch with it). Fixed tree: reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_zero(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += __int_as_float(dpp_or_zero<0x111, 0xf>(__float_as_int(v)));  // row_shr:1
+    v += __int_as_float(dpp_or_zero<0x112, 0xf>(__float_as_int(v)));  // row_shr:2
+    v += __int_as_float(dpp_or_zero<0x114, 0xf>(__float_as_int(v)));  // row_shr:4
+    v += __int_as_float(dpp_or_zero<0x118, 0xf>(__float_as_int(v)));  // row_shr:8   -> lane 15 of every row: the row total
+    v += __int_as_float(dpp_or_zero<0x142, 0xa>(__float_as_int(v)));  // row_bcast:15 -> rows 1 and 3 add the row before
+    v += __int_as_float(dpp_or_zero<0x143, 0xc>(__float_as_int(v)));  // row_bcast:31 -> rows 2 and 3 add lane 31
+    return v;                                                          // lane 63: the wave total
+}
+__device__ __forceinline__ unsigned wave_sum_u32_to_lane63(unsigned v) {
+    v += (unsigned)dpp_or_zero<0x111, 0xf>((int)v);
+    v += (unsigned)dpp_or_zero<0x112, 0xf>((int)v);
+    v += (unsigned)dpp_or_zero<0x114, 0xf>((int)v);
+    v += (unsigned)dpp_or_zero<0x118, 0xf>((int)v);
+    v += (unsigned)dpp_or_zero<0x142, 0xa>((int)v);
+    v += (unsigned)dpp_or_zero<0x143, 0xc>((int)v);
+    return v;
+}
+
 struct Mat4Arg {  // a 4x4 passed by value in the kernarg segment (column-major)
     float m[16];
 };
