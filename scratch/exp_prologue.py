@@ -42,3 +42,15 @@ if os.environ.get("SP_TM"):
     off = 2 * 256 * 32 * 4 + 2 * 112
     t = struct.unpack("34Q", raw[off:off + 34 * 8])
     print("block 0, ticks from kernel-side start: prologue done %d ; per-wave main-loop end %s ; block reduce done %d" % (t[1] - t[0], [t[17 + w] - t[0] for w in range(16)], t[33] - t[0]))
+
+if os.environ.get("SP_TM0"):
+    import struct
+    L.sp_debug_set_fused_stage_mask(1)
+    reg._psrc.prepare(prep, S, Tid, "presorted")
+    Tc = Tid.clone()
+    _lib.check(L.sp_gicp_align_fused(prep._h,reg._psrc._h,sp._ptr(Tc),C.byref(fp),C.byref(gn),1,None,None,sp._ptr(lin),sp._ptr(delta),sp._ptr(it),sp._ptr(ws),ws.numel(),sp._stream()))
+    torch.cuda.synchronize()
+    raw = ws.cpu().numpy().tobytes()
+    off = 2 * 256 * 32 * 4 + 2 * 112
+    t = struct.unpack("34Q", raw[off:off + 34 * 8])
+    print("first launch (identity pose), block 0 ticks: loop start %s ; per-wave loop end %s ; reduce done %d" % ([t[1 + w] - t[0] for w in (0, 15)], [t[17 + w] - t[0] for w in range(16)], t[33] - t[0]))

@@ -854,7 +854,15 @@ template <int LOSS, bool FAST_NN>
 __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, AlignArgs A,
                                                                  float* __restrict__ partials) {
     __shared__ float sT[16];
+#ifdef SP_KERNEL_TIMING  // diagnostic build only (make timing): s_memtime stamps of workgroup 0, after the two state blocks
+    unsigned long long* tm =
+        reinterpret_cast<unsigned long long*>(const_cast<AlignState*>(A.state_in < A.state_out ? A.state_in : A.state_out) + 2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) tm[0] = __builtin_amdgcn_s_memtime();  // kernel-side start
+#endif
     if (!align_prologue(A, sT)) return;
+#ifdef SP_KERNEL_TIMING
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) tm[1 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime();  // prologue done
+#endif
     // the pose is uniform: move it to scalar registers (it would otherwise occupy 12 VGPRs for the whole loop)
     Rigid T = load_rigid_colmajor(sT);
     auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -875,7 +883,13 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
         fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt);
+#ifdef SP_KERNEL_TIMING
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) tm[17 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime();  // point loop done
+#endif
     block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, A.count_is_float != 0);
+#ifdef SP_KERNEL_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) tm[33] = __builtin_amdgcn_s_memtime();  // workgroup reduction done
+#endif
 }
 
 // After the last launch: finish the last iteration (unless an earlier one converged) and publish the results.
