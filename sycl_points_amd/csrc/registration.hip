@@ -426,6 +426,7 @@ __device__ __forceinline__ void unpack_totals(const float* tot, int nv, sp_linea
     out->inlier = cnt;
     out->inlier_lo = (float)(cnt & 4095u);
     out->inlier_hi = (float)(cnt >> 12);
+    out->pad[0] = out->pad[1] = 0.0f;
 }
 
 __global__ __launch_bounds__(kFinalThreads) void final_reduce_kernel(const float* __restrict__ partials,

@@ -754,6 +754,51 @@ def test_align_fused_one_call_loop(sp, orc, gicp20k, loss):
     assert torch.equal(T0.cpu(), torch.eye(4).reshape(-1))
 
 
+@pytest.mark.parametrize("case", [
+    dict(ns=1, nt=5000), dict(ns=63, nt=5000), dict(ns=1025, nt=3000), dict(ns=5000, nt=1),
+    dict(ns=4097, nt=7000, loss="CAUCHY", scale=0.3), dict(ns=3000, nt=9000, max_corr=0.12),
+    dict(ns=6000, nt=6000, init=[0.05, -0.03, 0.04, 0.4, -0.3, 0.2]), dict(ns=2500, nt=2500, max_corr=0.0005, iters=3),
+])
+def test_align_fused_stress_shapes_and_parameters(sp, orc, case):
+    """The one-call loop on awkward shapes (one point, not a multiple of the wave / workgroup size, one target point,
+    sources much smaller than the workgroup count), with a robust kernel, a tight correspondence gate (most points
+    rejected, even all), a far initial guess: same pose as the oracle, same inlier count, and bit-identical to the
+    always-search path."""
+    from oracle.pyoracle import LOSS, RegParams
+
+    ns, nt = case["ns"], case["nt"]
+    n = max(ns, nt)
+    src, scov, tgt, tcov, T_gt = gicp_inputs(orc, n, seed=77)
+    src, scov, tgt, tcov = src[:ns], scov[:ns], tgt[:nt], tcov[:nt]
+    loss, scale = case.get("loss", "NONE"), case.get("scale", 10.0)
+    max_corr, iters = case.get("max_corr", 2.0), case.get("iters", 6)
+    T0 = orc.se3_exp(case["init"]) if "init" in case else np.eye(4, dtype=np.float32)
+    ref = orc.registration_align(RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=iters,
+                                                    robust_type=LOSS[loss], robust_default_scale=scale,
+                                                    max_correspondence_distance=max_corr), src, scov, tgt, tcov, init_T=T0)
+    L = sp._lib.lib()
+    outs = []
+    for reuse in (2, 0):
+        L.sp_debug_set_fused_reuse(reuse)
+        try:
+            S = sp.PointCloudShared(dev(src), covs=dev(scov))
+            Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+            prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
+            p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters, robust_type=loss,
+                                      robust_default_scale=scale, max_correspondence_distance=max_corr)
+            reg = sp.Registration(p)
+            T_dev, lin, _ = reg.align_fused_loop(S, prep, initial_guess=T0, write_neighbors=True)
+            outs.append((reg.T_from_device(T_dev), reg._read_lin(lin).inlier, lin.cpu().numpy(),
+                         reg.neighbors.indices.cpu().numpy().copy()))
+        finally:
+            L.sp_debug_set_fused_reuse(2)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
+    assert np.array_equal(outs[0][3], outs[1][3])
+    assert outs[0][1] == ref["inlier"]
+    tol = 1e-5 if ref["inlier"] >= 6 else 1e-3  # (fewer inliers than unknowns: the damped system is all that is solved)
+    assert np.abs(outs[0][0] - ref["T"]).max() < tol
+
+
 def test_correspondence_reuse_is_exact(sp, orc, gicp20k):
     """The iteration kernel keeps a correspondence without searching when the query is provably still nearest to its
     previous winner (|q - t| < half of t's distance to its nearest other target point). Every output must be bit-identical
@@ -762,7 +807,7 @@ def test_correspondence_reuse_is_exact(sp, orc, gicp20k):
     L = sp._lib.lib()
     tgt2, tcov2 = np.concatenate([tgt, tgt[:500]]), np.concatenate([tcov, tcov[:500]])  # 500 exact duplicates
     outs = []
-    for reuse in (1, 0):
+    for reuse in (2, 1, 0):
         L.sp_debug_set_fused_reuse(reuse)
         try:
             S = sp.PointCloudShared(dev(src), covs=dev(scov))
@@ -775,9 +820,10 @@ def test_correspondence_reuse_is_exact(sp, orc, gicp20k):
             outs.append((T_dev.cpu().numpy(), lin.cpu().numpy(), reg.neighbors.indices.cpu().numpy().copy(),
                          reg.neighbors.distances.cpu().numpy().copy()))
         finally:
-            L.sp_debug_set_fused_reuse(1)
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
+            L.sp_debug_set_fused_reuse(2)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
     oi, od = orc.knn_bruteforce(orc.transform_points(src, orc.registration_align(
         __import__("oracle.pyoracle", fromlist=["RegParams"]).RegParams.defaults(crit_translation=0.0, crit_rotation=0.0,
                                                                                 max_iterations=9), src, scov, tgt, tcov)["T"]),
