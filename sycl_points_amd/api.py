@@ -846,13 +846,15 @@ class Registration:
 
     def align_fused_loop(self, source, prepared_target, initial_guess=None, iterations=None, robust_scale=-1.0,
                          group=None, T_dev=None, delta_dev=None, prepare=True, sort_by_cell=True,
-                         write_neighbors=False, per_iteration_launches=False):
+                         write_neighbors=False, per_iteration_launches=False, update_target=False):
         """The same fixed-length Gauss-Newton loop as align_device_loop on the prepared / fused path
         (sp_gicp_iteration_fused): one launch per iteration does NN + linearise + reduce, and, on a single GPU, the
         second (one-workgroup) launch also solves and updates the pose. On one GPU the default is
         sp_gicp_align_fused: the reduction + solve of iteration k-1 runs as the prologue of launch k, and once the
         convergence criteria hold the remaining launches return immediately (self._iters_dev holds the number of
-        steps applied); per_iteration_launches=True keeps the two-launch fixed-length form. With prepare=True (a new alignment) the
+        steps applied); per_iteration_launches=True keeps the two-launch fixed-length form. The prepared target is
+        target-side pre-processing like its grid (built once by PreparedTarget(...)): pass update_target=True, or call
+        prepared_target.update(covs), when the target's covariances have changed since. With prepare=True (a new alignment) the
         per-alignment preparation — plane regularisation of both clouds' covariances and the cell-order sort of the
         source at the initial pose — is enqueued first."""
         import torch.distributed as dist
@@ -875,7 +877,8 @@ class Registration:
             self._psrc = PreparedSource(n)
             prepare = True
         if prepare:
-            prepared_target.update()
+            if update_target:
+                prepared_target.update()
             self._psrc.prepare(prepared_target, source, T_dev, sort_by_cell)
         sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         fp = self._factor_params(scale)

@@ -269,14 +269,15 @@ __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, co
 template <int BATCH>
 __device__ __forceinline__ void grid_scan_rows8(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                 const GridDesc& g, float qx, float qy, float qz, int xlo, int xhi,
-                                                int ylo, int zA, int zB, Nearest& best) {
+                                                int ylo, int zA, int zB, Nearest& best, int ymax = 0x7fffffff,
+                                                int zmax = 0x7fffffff) {
     unsigned off[8], c[9];
     c[0] = 0;
     const float fxq = (qx - g.ox) * g.inv_h;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int y = ylo + (r & 3), z = (r & 4) ? zB : zA;
-        bool ok = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+        bool ok = y >= 0 && y < g.ny && z >= 0 && z < g.nz && y <= ymax && z <= zmax;
         const int yc = min(max(y, 0), g.ny - 1), zc = min(max(z, 0), g.nz - 1);
         const float dyz2 = gap2(qz, g.oz + zc * g.h, g.oz + (zc + 1) * g.h, g.eps) +
                            gap2(qy, g.oy + yc * g.h, g.oy + (yc + 1) * g.h, g.eps);
@@ -346,10 +347,37 @@ __device__ __forceinline__ bool grid_nn1_block4(const float4* __restrict__ pts, 
     return best.d2 < cov * cov;
 }
 
+// Third stage, when a candidate exists but is not proven nearest (queries that are far from every point: outside the
+// cloud's bounding box, or in a hole): every x-row of cells that the ball of radius sqrt(best) reaches, in groups of 4 x 2
+// rows through the same batched row scan. Exact by construction (the bound is a real point, every cell that intersects the
+// ball is either scanned or pruned against a bound that only shrinks) — and, unlike the ring walk, it never visits the
+// rows of a shell that the ball does not touch: for a query d outside the box the ball cuts only a thin cap of cells.
+// Returns false when the ball spans more than 16 rows in y or z (left to the ring walk).
+__device__ __forceinline__ bool grid_nn1_ball(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                              const GridDesc& g, float qx, float qy, float qz, Nearest& best) {
+    const float rad = (sqrtf(best.d2) * 1.000001f + 2.0f * g.eps) * g.inv_h;  // in cells, widened like the row trimming
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    auto lo_cell = [](float v, int n) { return (int)fminf(fmaxf(floorf(v), 0.0f), (float)(n - 1)); };
+    const int x0 = lo_cell(fx - rad, g.nx), x1 = lo_cell(fx + rad, g.nx);
+    const int y0 = lo_cell(fy - rad, g.ny), y1 = lo_cell(fy + rad, g.ny);
+    const int z0 = lo_cell(fz - rad, g.nz), z1 = lo_cell(fz + rad, g.nz);
+    if (y1 - y0 >= 16 || z1 - z0 >= 16) return false;
+    for (int z = z0; z <= z1; z += 2)
+        for (int y = y0; y <= y1; y += 4) {
+            const int yb = min(y + 3, y1), zb = min(z + 1, z1);
+            const float d = gap2(qy, g.oy + y * g.h, g.oy + (yb + 1) * g.h, g.eps) +
+                            gap2(qz, g.oz + z * g.h, g.oz + (zb + 1) * g.h, g.eps);
+            if (d > best.d2) continue;  // the whole 4 x 2 group of rows is out of reach
+            grid_scan_rows8<4>(pts, start, g, qx, qy, qz, x0, x1, y, z, z + 1, best, y1, z1);
+        }
+    return true;
+}
+
 // Stages after an inexact fast result (`best` holds its upper bound or {FLT_MAX, -1}).
 __device__ __forceinline__ void grid_nn1_later_stages(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                       const GridDesc& g, float qx, float qy, float qz, Nearest& best) {
     if (grid_nn1_block4(pts, start, g, qx, qy, qz, best)) return;
+    if (best.idx >= 0 && grid_nn1_ball(pts, start, g, qx, qy, qz, best)) return;
     // the block covers the rings r <= 1 of the own cell completely
     const Nearest seed = best;
     best = grid_nn1(pts, start, g, qx, qy, qz, &seed, 2);
