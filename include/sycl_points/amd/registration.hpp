@@ -53,11 +53,41 @@ struct RegistrationConvergenceCriteria {
 struct RegistrationFactorParams {
     struct Robust { robust::RobustLossType type = robust::RobustLossType::NONE; float default_scale = 10.0f; };
     struct GenZ { float planarity_threshold = 0.2f; };
+    struct RotationConstraint {  // registration_params.hpp:56-64
+        struct Robust { float default_scale = 10.0f; };
+        bool enable = false;
+        float weight = 1.0f;
+        Robust robust;
+    };
     RegType reg_type = RegType::GICP;
     float max_correspondence_distance = 2.0f;
     Robust robust;
+    RotationConstraint rotation_constraint;
     GenZ genz;
     bool verbose = false;
+};
+/// degenerate_regularization.hpp:14-46
+enum class DegenerateRegularizationType { none = 0, nl_reg };
+inline DegenerateRegularizationType DegenerateRegularizationType_from_string(const std::string& str) {
+    std::string u = str;
+    for (auto& c : u) c = (char)std::toupper((unsigned char)c);
+    if (u == "NONE") return DegenerateRegularizationType::none;
+    if (u == "NL-REG" || u == "NL_REG") return DegenerateRegularizationType::nl_reg;
+    throw std::runtime_error("[DegenerateRegularizationType_from_string] Invalid DegenerateRegularizationType str [" + str + "]");
+}
+struct DegenerateRegularizationParams {
+    DegenerateRegularizationType type = DegenerateRegularizationType::none;
+    float rot_eigenvalue_threshold = 10.0f;
+    float trans_eigenvalue_threshold = 1.0f;
+    float base_factor = 1.0f;
+};
+/// map_prior.hpp:14-35
+struct MapPriorParams {
+    bool enabled = false;
+    float rot_vel_sigma = 1.0f;
+    float trans_vel_sigma = 1.0f;
+    float rot_base_sigma = 3.16e-2f;
+    float trans_base_sigma = 1e-2f;
 };
 struct RegistrationOptimizationParams {
     struct GaussNewton { float lambda = 1.0f; };
@@ -78,6 +108,8 @@ struct RegistrationParams : public RegistrationFactorParams, public Registration
     using Criteria = RegistrationConvergenceCriteria;
     size_t max_iterations = 20;
     Criteria criteria;
+    DegenerateRegularizationParams degenerate_reg;  // registration_params.hpp:111-112
+    MapPriorParams map_prior;
 };
 
 /// linearized_result.hpp:12-24
@@ -129,6 +161,20 @@ public:
     Registration(const Registration&) = delete;
     Registration& operator=(const Registration&) = delete;
 
+    /// registration.hpp:124-126 / MapPrior::update (map_prior.hpp:97-174): once per frame, after motion prediction and
+    /// before align().
+    void set_map_prior_state(const RegistrationResult& prev_result, const Eigen::Isometry3f& T_pred) {
+        const sp_map_prior_params mp{params_.map_prior.enabled ? 1 : 0, params_.map_prior.rot_vel_sigma,
+                                     params_.map_prior.trans_vel_sigma, params_.map_prior.rot_base_sigma,
+                                     params_.map_prior.trans_base_sigma};
+        float H36[36];
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) H36[i * 6 + j] = prev_result.H_raw(i, j);
+        const TransformMatrix Tprev = prev_result.T.matrix(), Tpred = T_pred.matrix();
+        throw_on_error(sp_map_prior_update_host(&mp, H36, prev_result.error_raw, prev_result.inlier, Tprev.data(),
+                                                Tpred.data(), &map_prior_));
+    }
+
     /// registration.hpp:129-193
     void validate_params(const PointCloudShared& source, const PointCloudShared& target, RegistrationParams& params) const {
         if (params.reg_type == RegType::POINT_TO_PLANE && !target.has_normal()) {
@@ -149,6 +195,14 @@ public:
         if (params.reg_type == RegType::POINT_TO_DISTRIBUTION && !target.has_cov())
             throw std::runtime_error("[Registration::validate_params] Covariance matrices of target must be pre-computed "
                                      "before performing Point-to-Distribution ICP matching.");
+        if (params.rotation_constraint.enable) {
+            if (!source.has_cov())
+                throw std::runtime_error("[Registration::validate_params] Covariance matrices of source are required for "
+                                         "performing rotation constraint matching.");
+            if (!target.has_cov())
+                throw std::runtime_error("[Registration::validate_params] Covariance matrices of target are required for "
+                                         "performing rotation constraint matching.");
+        }
         if (params.robust.type != robust::RobustLossType::NONE && params.robust.default_scale <= 0.0f) {
             std::cout << "[Caution] `robust.default_scale` must be greater than zero. Disable robust loss." << std::endl;
             params.robust.type = robust::RobustLossType::NONE;
@@ -164,6 +218,9 @@ public:
         if (source.size() == 0) return result;
         validate_params(source, target, params_);
         const float robust_scale = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
+        rotation_robust_scale_ = options.rotation_robust_scale > 0.0f ? options.rotation_robust_scale
+                                                                      : params_.rotation_constraint.robust.default_scale;
+        const bool pose_terms = params_.degenerate_reg.type != DegenerateRegularizationType::none || prior_active();
         float lm_lambda = params_.lm.init_lambda;
         float trust_region_radius = params_.dogleg.initial_trust_region_radius;
         const auto* grid = dynamic_cast<const knn::GridKNN*>(&target_knn);
@@ -175,18 +232,22 @@ public:
         // GICP additionally fuses search and linearisation
         const knn::KNNBase& nn = (grid != nullptr && grid->size() == target.size()) ? static_cast<const knn::KNNBase&>(*grid)
                                                                                      : target_knn;
-        const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size();
+        // (the rotation constraint reads the raw covariances: it runs on the unfused kernels)
+        const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size() &&
+                           !params_.rotation_constraint.enable;
         if (fused) prepare_fused(source, target, *grid, initial_guess);
         // GICP + Gauss-Newton on a GridKNN: the whole loop runs on the device (one launch per iteration, convergence
         // test included), the host reads the result back once — same arithmetic as the loop below.
+        // (the host-side pose terms — degenerate regularisation, MAP prior — need the reduced system on the host)
         if (fused && params_.optimization_method == OptimizationMethod::GAUSS_NEWTON && !params_.verbose &&
-            params_.max_iterations > 0)
+            params_.max_iterations > 0 && !pose_terms)
             return align_on_device(source.size(), initial_guess, robust_scale);
 
         for (size_t iter = 0; iter < params_.max_iterations; ++iter) {
-            const LinearizedResult lin = fused ? linearize_fused(source.size(), result.T.matrix(), robust_scale)
-                                               : linearize_generic(source, target, nn, result.T.matrix(), robust_scale);
+            LinearizedResult lin = fused ? linearize_fused(source.size(), result.T.matrix(), robust_scale)
+                                         : linearize_generic(source, target, nn, result.T.matrix(), robust_scale);
             result.H_raw = lin.H; result.b_raw = lin.b; result.error_raw = lin.error;
+            if (pose_terms) apply_pose_terms(lin, result.T.matrix(), initial_guess);  // registration.hpp:249-253
             switch (params_.optimization_method) {
                 case OptimizationMethod::LEVENBERG_MARQUARDT:
                     optimize_levenberg_marquardt(source, target, result, lin, lm_lambda, iter, robust_scale);
@@ -211,11 +272,23 @@ public:
     /// clouds), so the prepared path skips its per-alignment sort (SP_SOURCE_PRESORTED).
     void set_source_presorted(bool v) { source_presorted_ = v; }
 
-    /// registration.hpp:312-331 (degenerate regularisation is default-off and not built)
+    /// registration.hpp:312-324: with the pose at the start of the optimisation window the degenerate regularisation
+    /// is applied to the result.
+    LinearizedResult compute_linearized_result(const PointCloudShared& source, const PointCloudShared& target,
+                                               const knn::KNNBase& target_knn, const TransformMatrix& pose,
+                                               const TransformMatrix& initial_pose,
+                                               const ExecutionOptions& options = ExecutionOptions()) {
+        LinearizedResult lin = compute_linearized_result(source, target, target_knn, pose, options);
+        regularize(lin, pose, initial_pose);
+        return lin;
+    }
+    /// registration.hpp:326-331 (without degenerate regularisation)
     LinearizedResult compute_linearized_result(const PointCloudShared& source, const PointCloudShared& target,
                                                const knn::KNNBase& target_knn, const TransformMatrix& pose,
                                                const ExecutionOptions& options = ExecutionOptions()) {
         const float s = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
+        rotation_robust_scale_ = options.rotation_robust_scale > 0.0f ? options.rotation_robust_scale
+                                                                      : params_.rotation_constraint.robust.default_scale;
         return linearize_generic(source, target, target_knn, pose, s);
     }
     /// registration.hpp:350-359
@@ -223,6 +296,8 @@ public:
                                                      const TransformMatrix& pose,
                                                      const ExecutionOptions& options = ExecutionOptions()) const {
         const float s = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
+        rotation_robust_scale_ = options.rotation_robust_scale > 0.0f ? options.rotation_robust_scale
+                                                                      : params_.rotation_constraint.robust.default_scale;
         return compute_error(source, target, pose, s);
     }
     /// registration.hpp:279-294
@@ -245,7 +320,44 @@ public:
 private:
     sp_factor_params factor_params(float robust_scale) const {
         return sp_factor_params{int(params_.reg_type), int(params_.robust.type), params_.max_correspondence_distance,
-                                robust_scale, genz_alpha_, params_.genz.planarity_threshold};
+                                robust_scale, genz_alpha_, params_.genz.planarity_threshold,
+                                params_.rotation_constraint.enable ? 1 : 0, params_.rotation_constraint.weight,
+                                rotation_robust_scale_};
+    }
+    bool prior_active() const { return params_.map_prior.enabled && map_prior_.has_prior != 0; }
+    float prior_error(const TransformMatrix& T) const {  // MapPrior::prior_error (map_prior.hpp:197-201)
+        return prior_active() ? sp_map_prior_apply_host(&map_prior_, T.data(), nullptr, nullptr, nullptr) : 0.0f;
+    }
+    void regularize(LinearizedResult& lin, const TransformMatrix& T, const TransformMatrix& T_initial) const {
+        if (params_.degenerate_reg.type == DegenerateRegularizationType::none) return;
+        const sp_degenerate_reg_params dr{int(params_.degenerate_reg.type), params_.degenerate_reg.rot_eigenvalue_threshold,
+                                          params_.degenerate_reg.trans_eigenvalue_threshold,
+                                          params_.degenerate_reg.base_factor};
+        float H36[36], b6[6];
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) H36[i * 6 + j] = lin.H(i, j);
+            b6[i] = lin.b(i);
+        }
+        throw_on_error(sp_degenerate_regularize_host(&dr, H36, b6, lin.inlier, T.data(), T_initial.data()));
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) lin.H(i, j) = H36[i * 6 + j];
+            lin.b(i) = b6[i];
+        }
+    }
+    /// DegenerateRegularization::regularize then MapPrior::apply on the reduced system (registration.hpp:249-253)
+    void apply_pose_terms(LinearizedResult& lin, const TransformMatrix& T, const TransformMatrix& T_initial) const {
+        regularize(lin, T, T_initial);
+        if (!prior_active()) return;
+        float H36[36], b6[6];
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) H36[i * 6 + j] = lin.H(i, j);
+            b6[i] = lin.b(i);
+        }
+        sp_map_prior_apply_host(&map_prior_, T.data(), H36, b6, &lin.error);
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) lin.H(i, j) = H36[i * 6 + j];
+            lin.b(i) = b6[i];
+        }
     }
     static LinearizedResult to_result(const sp_linearized& h) {
         LinearizedResult r;
@@ -394,7 +506,8 @@ private:
             const auto [delta, conv] = gn_step(lin, lambda, new_T);
             (void)delta;
             result.converged = conv;
-            const auto [new_error, inlier] = compute_error(source, target, new_T, robust_scale);
+            const auto [new_icp_error, inlier] = compute_error(source, target, new_T, robust_scale);
+            const float new_error = new_icp_error + prior_error(new_T);  // registration.hpp:854
             if (new_error <= current_error) {
                 result.T.matrix() = new_T; result.error = new_error; result.inlier = inlier; updated = true;
                 lambda = std::clamp(lambda / params_.lm.lambda_factor, params_.lm.min_lambda, params_.lm.max_lambda);
@@ -414,7 +527,7 @@ private:
 
     bool optimize_powell_dogleg(const PointCloudShared& source, const PointCloudShared& target, RegistrationResult& result,
                                 const LinearizedResult& lin, float& trust_region_radius, size_t iter,
-                                float robust_scale) const {  // registration.hpp:897-965 (no MAP prior in this build)
+                                float robust_scale) const {  // registration.hpp:897-965
         result.H = lin.H; result.b = lin.b; result.error = lin.error; result.inlier = lin.inlier; result.iterations = iter;
         const auto& dl = params_.dogleg;
         const auto clamp_radius = [&](float r) { return std::clamp(r, dl.min_trust_region_radius, dl.max_trust_region_radius); };
@@ -433,7 +546,8 @@ private:
         sp_se3_exp_host(p6, E.data());
         const TransformMatrix cur = result.T.matrix();
         sp_rigid_mul_host(cur.data(), E.data(), new_T.data());
-        const auto [new_error, inlier] = compute_error(source, target, new_T, robust_scale);
+        const auto [new_icp_error, inlier] = compute_error(source, target, new_T, robust_scale);
+        const float new_error = new_icp_error + prior_error(new_T);  // registration.hpp:933
         const float rho = (lin.error - new_error) / predicted;
         if (params_.verbose)
             std::cout << "iter [" << iter << "] radius: " << trust_region_radius << ", rho: " << rho << ", error: " << new_error
@@ -461,6 +575,8 @@ private:
     size_t ws_bytes_ = 0;
     float* T_dev_ = nullptr;
     float genz_alpha_ = 1.0f;
+    mutable float rotation_robust_scale_ = 10.0f;  // resolved per call from ExecutionOptions (registration.hpp:219-221)
+    sp_map_prior_state map_prior_{};               // MapPrior state (map_prior.hpp:203-210)
     sp_gicp_source* psrc_ = nullptr;
     size_t psrc_cap_ = 0;
     sp_gicp_target* ptgt_ = nullptr;

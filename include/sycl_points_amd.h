@@ -32,7 +32,7 @@ extern "C" {
 #define SP_ERR_RUNTIME 2          /* reference: std::runtime_error    */
 #define SP_ERR_HIP 3              /* reference: sycl::exception from wait_and_throw */
 
-#define SP_ABI_VERSION 1
+#define SP_ABI_VERSION 2
 int sp_abi_version(void);
 const char* sp_last_error(void);
 
@@ -202,6 +202,14 @@ typedef struct sp_factor_params { /* RegistrationFactorParams, registration_para
     float robust_scale;
     float genz_alpha;               /* Registration::genz_alpha_ (registration.hpp:370,519) */
     float genz_planarity_threshold; /* registration_params.hpp:52-54 */
+    /* RotationConstraint (registration_params.hpp:56-64; rotation_constraint.hpp:15-128): when enabled every inlier
+     * correspondence adds the Jensen-Bregman LogDet divergence of (R Cs R^T, Ct), weighted by
+     * rotation_constraint_weight and the robust kernel at rotation_robust_scale, to H, b and the error
+     * (registration.hpp:630-650, 758-766). Needs source and target covariances. Only the unfused entry points
+     * (sp_gicp_linearize / sp_gicp_error) carry the term; the prepared / one-call paths reject it. */
+    int rotation_constraint_enable;
+    float rotation_constraint_weight;
+    float rotation_robust_scale;
 } sp_factor_params;
 
 /* Registration::linearize_parallel_reduction_async (registration.hpp:513-664, kernel K11): for every source point
@@ -337,6 +345,47 @@ int sp_ldlt6_solve_host(const float* H36_rowmajor, const float* rhs6, float* x6)
  * Registration::optimize_powell_dogleg (registration.hpp:897-965); trust-region bookkeeping stays with the caller. */
 void sp_dogleg_step_host(const float* H36_rowmajor, const float* g6, float trust_region_radius, float* p_out6,
                          float* step_norm_out, float* predicted_reduction_out);
+
+/* ---- pose-space terms applied to the reduced system on the host, between the device reduction and the solve
+ * (Registration::align, registration.hpp:236-253). All matrices here are HOST memory; H row-major as in sp_linearized,
+ * poses column-major 4x4. */
+/* lie::se3_log (utils/eigen_utils.hpp:991-1034): rotation-first twist of a rigid transform. */
+void sp_se3_log_host(const float* T16, float* twist6);
+/* DegenerateRegularization::regularize (algorithms/registration/degenerate_regularization.hpp:41-110, NL-Reg): for the
+ * rotation and the translation 3x3 block of H, every eigen-direction whose eigenvalue / inlier is below its threshold
+ * gets a Tikhonov penalty base_factor * inlier * v v^T; H += P, b += P * se3_log(T_initial^-1 * T_current).
+ * Nothing happens for type NONE or inlier == 0. */
+enum { SP_DEGENERATE_REG_NONE = 0, SP_DEGENERATE_REG_NL_REG = 1 };
+typedef struct sp_degenerate_reg_params { /* DegenerateRegularizationParams, :41-46 */
+    int type;
+    float rot_eigenvalue_threshold;   /* 10.0 */
+    float trans_eigenvalue_threshold; /* 1.0 */
+    float base_factor;                /* 1.0 */
+} sp_degenerate_reg_params;
+int sp_degenerate_regularize_host(const sp_degenerate_reg_params* params, float* H36_rowmajor, float* b6,
+                                  uint32_t inlier, const float* T_current16, const float* T_initial16);
+/* MapPrior (algorithms/registration/map_prior.hpp:14-213). update (:97-174): from the previous frame's raw Hessian,
+ * raw error, inlier count and optimised pose, and the predicted pose of this frame, compute
+ * Omega = R - R (Ad^T (H_raw / s^2) Ad + R)^-1 R with R = Q^-1 the motion-adaptive process noise; state->has_prior
+ * stays 0 when the prior is disabled or cannot be formed. apply (:181-201): e = se3_log(T_pred^-1 T_est);
+ * returns the prior cost e^T Omega e / 2 (0 without a prior) and, when H/b are given, adds Omega, Omega e and the cost
+ * to H, b and *error. */
+typedef struct sp_map_prior_params { /* MapPriorParams, :14-35 */
+    int enabled;
+    float rot_vel_sigma;    /* 1.0 */
+    float trans_vel_sigma;  /* 1.0 */
+    float rot_base_sigma;   /* 3.16e-2 */
+    float trans_base_sigma; /* 1e-2 */
+} sp_map_prior_params;
+typedef struct sp_map_prior_state {
+    int has_prior;
+    float omega[36];      /* row-major */
+    float T_pred_inv[16]; /* column-major */
+} sp_map_prior_state;
+int sp_map_prior_update_host(const sp_map_prior_params* params, const float* H_raw36_rowmajor, float error_raw,
+                             uint32_t inlier, const float* T_prev16, const float* T_pred16, sp_map_prior_state* state);
+float sp_map_prior_apply_host(const sp_map_prior_state* state, const float* T_est16, float* H36_rowmajor, float* b6,
+                              float* error);
 
 #ifdef __cplusplus
 }

@@ -202,6 +202,72 @@ void orc_gicp_error(const float* src, const float* src_cov, size_t n, const floa
     error_reduce(make_fp(reg, loss, max_corr, 0.2f), s, t, nn_idx, nn_d2, T16, robust_scale, genz_alpha, e, inl);
     out2[0] = e; std::memcpy(out2 + 1, &inl, 4);
 }
+// K11 / K12 with the rotation-constraint term (registration.hpp:630-650, 758-766)
+void orc_gicp_linearize_rot(const float* src, const float* src_cov, size_t n, const float* tgt, const float* tgt_cov,
+                            const float* tgt_nrm, const int32_t* nn_idx, const float* nn_d2, const float* T16, float max_corr,
+                            int reg, int loss, float robust_scale, float genz_alpha, float rot_weight, float rot_scale,
+                            float* out44) {
+    Cloud s, t;
+    s.points = src; s.covs = src_cov; s.n = n;
+    t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm;
+    FactorParams fp = make_fp(reg, loss, max_corr, 0.2f);
+    fp.rot_enable = true; fp.rot_weight = rot_weight;
+    const Linearized L = linearize_reduce(fp, s, t, nn_idx, nn_d2, T16, robust_scale, genz_alpha, nullptr, rot_scale);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) out44[r * 6 + c] = L.H(r, c);
+    for (int r = 0; r < 6; ++r) out44[36 + r] = L.b[r];
+    out44[42] = L.error;
+    std::memcpy(out44 + 43, &L.inlier, 4);
+}
+void orc_gicp_error_rot(const float* src, const float* src_cov, size_t n, const float* tgt, const float* tgt_cov,
+                        const float* tgt_nrm, const int32_t* nn_idx, const float* nn_d2, const float* T16, float max_corr,
+                        int reg, int loss, float robust_scale, float genz_alpha, float rot_weight, float rot_scale,
+                        float* out2) {
+    Cloud s, t;
+    s.points = src; s.covs = src_cov; s.n = n;
+    t.points = tgt; t.covs = tgt_cov; t.normals = tgt_nrm;
+    FactorParams fp = make_fp(reg, loss, max_corr, 0.2f);
+    fp.rot_enable = true; fp.rot_weight = rot_weight;
+    float e; uint32_t inl;
+    error_reduce(fp, s, t, nn_idx, nn_d2, T16, robust_scale, genz_alpha, e, inl, rot_scale);
+    out2[0] = e; std::memcpy(out2 + 1, &inl, 4);
+}
+// degenerate_regularization.hpp:60-110. H36 column-major (symmetric anyway), in place.
+void orc_degenerate_regularize(int type, float rot_thr, float trans_thr, float base_factor, float* H36, float* b6,
+                               uint32_t inlier, const float* T_cur16, const float* T_init16) {
+    DegenerateRegParams p;
+    p.type = type; p.rot_eigenvalue_threshold = rot_thr; p.trans_eigenvalue_threshold = trans_thr; p.base_factor = base_factor;
+    Mat6 H; Vec6 b;
+    std::memcpy(H.d, H36, 144); std::memcpy(b.d, b6, 24);
+    degenerate_regularize(p, H, b, inlier, to_mat4(T_cur16), to_mat4(T_init16));
+    std::memcpy(H36, H.d, 144); std::memcpy(b6, b.d, 24);
+}
+// map_prior.hpp:97-174. sig4 = rot_vel, trans_vel, rot_base, trans_base. Returns has_prior.
+int orc_map_prior_update(const float* sig4, const float* H_raw36, float error_raw, uint32_t inlier, const float* T_prev16,
+                         const float* T_pred16, float* omega36, float* T_pred_inv16) {
+    MapPrior mp;
+    mp.params.enabled = true;
+    mp.params.rot_vel_sigma = sig4[0]; mp.params.trans_vel_sigma = sig4[1];
+    mp.params.rot_base_sigma = sig4[2]; mp.params.trans_base_sigma = sig4[3];
+    Mat6 H; std::memcpy(H.d, H_raw36, 144);
+    mp.update(H, error_raw, inlier, to_mat4(T_prev16), to_mat4(T_pred16));
+    std::memcpy(omega36, mp.Omega.d, 144);
+    std::memcpy(T_pred_inv16, mp.T_pred_inv.d, 64);
+    return mp.has_prior ? 1 : 0;
+}
+// map_prior.hpp:181-201. H/b/error updated in place; returns prior_error(T_est).
+float orc_map_prior_apply(const float* omega36, const float* T_pred_inv16, float* H36, float* b6, float* error,
+                          const float* T_est16) {
+    MapPrior mp;
+    mp.params.enabled = true; mp.has_prior = true;
+    std::memcpy(mp.Omega.d, omega36, 144); std::memcpy(mp.T_pred_inv.d, T_pred_inv16, 64);
+    if (H36) {
+        Mat6 H; Vec6 b;
+        std::memcpy(H.d, H36, 144); std::memcpy(b.d, b6, 24);
+        mp.apply(H, b, *error, to_mat4(T_est16));
+        std::memcpy(H36, H.d, 144); std::memcpy(b6, b.d, 24);
+    }
+    return mp.prior_error(to_mat4(T_est16));
+}
 void orc_icp_robust_weights(const float* src, const float* src_cov, size_t n, const float* tgt, const float* tgt_cov,
                             const float* tgt_nrm, const int32_t* nn_idx, const float* nn_d2, const float* T16, float max_corr,
                             int reg, int loss, float robust_scale, float* out) {
@@ -222,6 +288,14 @@ struct orc_reg_params {
     float init_scale, min_scale;
     // Powell dogleg (registration_params.hpp:84-92); dl_initial_radius == 0 keeps the reference defaults
     float dl_initial_radius, dl_min_radius, dl_max_radius, dl_eta1, dl_eta2, dl_gamma_decrease, dl_gamma_increase;
+    // default-off terms (all zero = off): rotation constraint, degenerate regularisation, MAP prior
+    int rot_enable;
+    float rot_weight, rot_robust_default_scale;
+    int dr_type;
+    float dr_rot_threshold, dr_trans_threshold, dr_base_factor;
+    int mp_active;          // a prior computed by orc_map_prior_update
+    float mp_omega[36];     // column-major
+    float mp_T_pred_inv[16];
 };
 struct orc_reg_result {
     float T[16];
@@ -231,6 +305,9 @@ struct orc_reg_result {
     uint32_t inlier;
     int iterations;
     int converged;
+    float H_raw[36];  // column-major
+    float b_raw[6];
+    float error_raw;
 };
 // nn_mode: 0 = KD-tree built on target (the reference's default KNNBase), 1 = brute force.
 // trace_T (optional, max_iterations*16 floats) receives the pose after every outer iteration; *trace_n their count.
@@ -251,6 +328,21 @@ void orc_registration_align(const orc_reg_params* P, const float* src, const flo
         p.dl_initial_radius = P->dl_initial_radius; p.dl_min_radius = P->dl_min_radius; p.dl_max_radius = P->dl_max_radius;
         p.dl_eta1 = P->dl_eta1; p.dl_eta2 = P->dl_eta2; p.dl_gamma_decrease = P->dl_gamma_decrease;
         p.dl_gamma_increase = P->dl_gamma_increase;
+    }
+    p.rot_enable = P->rot_enable != 0;
+    if (p.rot_enable) { p.rot_weight = P->rot_weight; p.rot_robust_default_scale = P->rot_robust_default_scale; }
+    p.degenerate_reg.type = P->dr_type;
+    if (P->dr_type) {
+        p.degenerate_reg.rot_eigenvalue_threshold = P->dr_rot_threshold;
+        p.degenerate_reg.trans_eigenvalue_threshold = P->dr_trans_threshold;
+        p.degenerate_reg.base_factor = P->dr_base_factor;
+    }
+    MapPrior prior;
+    if (P->mp_active) {
+        prior.params.enabled = true;
+        prior.has_prior = true;
+        std::memcpy(prior.Omega.d, P->mp_omega, 144);
+        std::memcpy(prior.T_pred_inv.d, P->mp_T_pred_inv, 64);
     }
     Cloud s, t;
     s.points = src; s.covs = src_cov; s.n = ns;
@@ -277,7 +369,10 @@ void orc_registration_align(const orc_reg_params* P, const float* src, const flo
     if (P->auto_scale)
         r = align_robust_annealing(p, s, t, nearest, init_T16, true, P->init_scale, P->min_scale, (size_t)P->auto_scaling_iter);
     else
-        r = align(p, s, t, nearest, init_T16, -1.0f, trace_T ? &trace : nullptr);
+        r = align(p, s, t, nearest, init_T16, -1.0f, trace_T ? &trace : nullptr, P->mp_active ? &prior : nullptr);
+    std::memcpy(out->H_raw, r.H_raw.d, 144);
+    std::memcpy(out->b_raw, r.b_raw.d, 24);
+    out->error_raw = r.error_raw;
     std::memcpy(out->T, r.T.d, 64);
     std::memcpy(out->H, r.H.d, 144);
     std::memcpy(out->b, r.b.d, 24);

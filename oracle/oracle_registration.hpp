@@ -16,6 +16,7 @@
 #include "oracle_features.hpp"
 #include "oracle_knn.hpp"
 #include "oracle_math.hpp"
+#include "oracle_reg_terms.hpp"
 
 namespace oracle {
 
@@ -289,12 +290,16 @@ struct Linearized {  // linearized_result.hpp:12-24
     uint32_t inlier = 0;
 };
 
-struct FactorParams {  // registration_params.hpp:46-71 (rotation constraint: out of scope, default off)
+struct FactorParams {  // registration_params.hpp:46-71
     int reg_type = GICP;
     float max_correspondence_distance = 2.0f;
     int robust_type = LOSS_NONE;
     float robust_default_scale = 10.0f;
     float genz_planarity_threshold = 0.2f;
+    // RotationConstraint (registration_params.hpp:56-64)
+    bool rot_enable = false;
+    float rot_weight = 1.0f;
+    float rot_robust_default_scale = 10.0f;
 };
 
 constexpr size_t REDUCE_BLOCK = 1024;
@@ -316,7 +321,7 @@ inline float compute_genz_alpha(const Cloud& target, const int32_t* nn_idx, cons
 // registration.hpp:513-664 (K11).  Optional per-point outputs (H 36 row-major, b 6, err 1, flag 1 = 44 floats)
 inline Linearized linearize_reduce(const FactorParams& fp, const Cloud& source, const Cloud& target, const int32_t* nn_idx,
                                    const float* nn_d2, const float* T_colmajor, float robust_scale, float genz_alpha,
-                                   float* per_point = nullptr) {
+                                   float* per_point = nullptr, float rotation_robust_scale = 10.0f) {
     const size_t N = source.n;
     const Mat4 T = to_mat4(T_colmajor);
     const float max_d2 = fp.max_correspondence_distance * fp.max_correspondence_distance;
@@ -344,14 +349,25 @@ inline Linearized linearize_reduce(const FactorParams& fp, const Cloud& source, 
             const float w = robust_weight(fp.robust_type, residual_norm, robust_scale);
             float e = robust_error(fp.robust_type, residual_norm, robust_scale);
             if (fp.reg_type == GENZ) e = genz_weight * e;
+            // rotation constraint term (registration.hpp:630-650): added to this point's totals before the reduction
+            RotTerm rot;
+            float rot_scale_w = 0.0f;
+            if (fp.rot_enable) {
+                rot = linearize_rotation_constraint(scov, tcov, T);
+                const float rn_rot = std::sqrt(rot.squared_error);
+                rot_scale_w = fp.rot_weight * robust_weight(fp.robust_type, rn_rot, rotation_robust_scale);
+                e += fp.rot_weight * robust_error(fp.robust_type, rn_rot, rotation_robust_scale);
+            }
             for (int r = 0; r < 6; ++r)
                 for (int c = 0; c < 6; ++c) {
-                    const float v = w * lin.H(r, c);
+                    float v = w * lin.H(r, c);
+                    if (fp.rot_enable && r < 3 && c < 3) v += rot_scale_w * rot.H[r][c];
                     acc[r * 6 + c] += v;
                     if (per_point) per_point[i * 44 + r * 6 + c] = v;
                 }
             for (int r = 0; r < 6; ++r) {
-                const float v = w * lin.b[r];
+                float v = w * lin.b[r];
+                if (fp.rot_enable && r < 3) v += rot_scale_w * rot.b[r];
                 acc[36 + r] += v;
                 if (per_point) per_point[i * 44 + 36 + r] = v;
             }
@@ -381,7 +397,7 @@ inline Linearized linearize_reduce(const FactorParams& fp, const Cloud& source, 
 // registration.hpp:678-777 (K12)
 inline void error_reduce(const FactorParams& fp, const Cloud& source, const Cloud& target, const int32_t* nn_idx,
                          const float* nn_d2, const float* T_colmajor, float robust_scale, float genz_alpha, float& error,
-                         uint32_t& inlier) {
+                         uint32_t& inlier, float rotation_robust_scale = 10.0f) {
     const size_t N = source.n;
     const Mat4 T = to_mat4(T_colmajor);
     const float max_d2 = fp.max_correspondence_distance * fp.max_correspondence_distance;
@@ -406,6 +422,10 @@ inline void error_reduce(const FactorParams& fp, const Cloud& source, const Clou
             const float rn = std::sqrt(sq);
             float e = robust_error(fp.robust_type, rn, robust_scale);
             if (fp.reg_type == GENZ) e = genz_weight * e;
+            if (fp.rot_enable) {  // registration.hpp:758-766
+                const float rn_rot = std::sqrt(rotation_constraint_error(scov, tcov, T));
+                e += fp.rot_weight * robust_error(fp.robust_type, rn_rot, rotation_robust_scale);
+            }
             acc += e;
             ++inl;
         }
@@ -453,6 +473,7 @@ struct RegParams : FactorParams {  // registration_params.hpp:74-114
     // Dogleg (registration_params.hpp:84-92)
     float dl_initial_radius = 1.0f, dl_min_radius = 1e-4f, dl_max_radius = 10.0f;
     float dl_eta1 = 0.25f, dl_eta2 = 0.75f, dl_gamma_decrease = 0.25f, dl_gamma_increase = 2.0f;
+    DegenerateRegParams degenerate_reg;  // registration_params.hpp:111
 };
 
 struct RegResult {  // result.hpp:12-28
@@ -463,6 +484,9 @@ struct RegResult {  // result.hpp:12-28
     Vec6 b = Vec6::Zero();
     float error = std::numeric_limits<float>::max();
     uint32_t inlier = 0;
+    Mat6 H_raw = Mat6::Zero();  // result.hpp: linearisation before regularisation / prior (registration.hpp:236-246)
+    Vec6 b_raw = Vec6::Zero();
+    float error_raw = std::numeric_limits<float>::max();
 };
 
 // The KNNBase seam (knn/knn.hpp:14-61): nearest neighbour of T*q for every source point.
@@ -564,14 +588,18 @@ inline DoglegStep compute_dogleg_step(const Mat6& H, const Vec6& g, float radius
 // default-off no-ops in the reference (degenerate_regularization.hpp:40, map_prior.hpp:15) and are not restated.
 inline RegResult align(const RegParams& params, const Cloud& source, const Cloud& target, const NearestFn& nearest,
                        const float* init_T_colmajor, float opt_robust_scale = -1.0f,
-                       std::vector<float>* trace_T = nullptr) {
+                       std::vector<float>* trace_T = nullptr, const MapPrior* map_prior = nullptr,
+                       float opt_rotation_robust_scale = -1.0f) {
     RegResult result;
     result.T = to_mat4(init_T_colmajor);
+    const Mat4 T_initial = result.T;
     const size_t N = source.n;
     if (N == 0) return result;
     RegParams p = params;
     if (p.robust_type != LOSS_NONE && p.robust_default_scale <= 0.0f) p.robust_type = LOSS_NONE;  // :186-192
     const float robust_scale = opt_robust_scale > 0.0f ? opt_robust_scale : p.robust_default_scale;
+    const float rot_scale = opt_rotation_robust_scale > 0.0f ? opt_rotation_robust_scale : p.rot_robust_default_scale;
+    const auto prior_error = [&](const Mat4& T) { return map_prior ? map_prior->prior_error(T) : 0.0f; };
     float lm_lambda = p.lm_init_lambda;
     float trust_region_radius = p.dl_initial_radius;
     std::vector<int32_t> nn_idx(N);
@@ -582,8 +610,13 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
         if (p.reg_type == GENZ)
             genz_alpha = compute_genz_alpha(target, nn_idx.data(), nn_d2.data(), N, p.max_correspondence_distance,
                                             p.genz_planarity_threshold);
-        const Linearized lin =
-            linearize_reduce(p, source, target, nn_idx.data(), nn_d2.data(), result.T.d, robust_scale, genz_alpha);
+        Linearized lin = linearize_reduce(p, source, target, nn_idx.data(), nn_d2.data(), result.T.d, robust_scale,
+                                          genz_alpha, nullptr, rot_scale);
+        result.H_raw = lin.H;  // registration.hpp:244-246
+        result.b_raw = lin.b;
+        result.error_raw = lin.error;
+        degenerate_regularize(p.degenerate_reg, lin.H, lin.b, lin.inlier, result.T, T_initial);  // :249-250
+        if (map_prior) map_prior->apply(lin.H, lin.b, lin.error, result.T);                      // :253
         if (p.optimization_method == GAUSS_NEWTON) {
             Vec6 delta;
             const bool ok = solve_linear_system(add_lambda(lin.H, p.gn_lambda), lin.b, delta);
@@ -605,7 +638,8 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
                 float new_error;
                 uint32_t inl;
                 error_reduce(p, source, target, nn_idx.data(), nn_d2.data(), new_T.d, robust_scale, genz_alpha, new_error,
-                             inl);
+                             inl, rot_scale);
+                new_error += prior_error(new_T);  // registration.hpp:854
                 if (new_error <= current_error) {
                     result.converged = is_converged(p, delta);
                     result.T = new_T;
@@ -643,7 +677,8 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
                 float new_error;
                 uint32_t inl;
                 error_reduce(p, source, target, nn_idx.data(), nn_d2.data(), new_T.d, robust_scale, genz_alpha, new_error,
-                             inl);
+                             inl, rot_scale);
+                new_error += prior_error(new_T);  // registration.hpp:933
                 const float rho = (lin.error - new_error) / dl.predicted_reduction;
                 if (rho < p.dl_eta1) {
                     trust_region_radius = clamp_radius(trust_region_radius * p.dl_gamma_decrease);

@@ -36,6 +36,11 @@ class RegParams(C.Structure):
         ("auto_scale", C.c_int), ("auto_scaling_iter", C.c_int), ("init_scale", C.c_float), ("min_scale", C.c_float),
         ("dl_initial_radius", C.c_float), ("dl_min_radius", C.c_float), ("dl_max_radius", C.c_float),
         ("dl_eta1", C.c_float), ("dl_eta2", C.c_float), ("dl_gamma_decrease", C.c_float), ("dl_gamma_increase", C.c_float),
+        # default-off terms: rotation constraint, degenerate regularisation (NL-Reg), MAP prior (see map_prior_update)
+        ("rot_enable", C.c_int), ("rot_weight", C.c_float), ("rot_robust_default_scale", C.c_float),
+        ("dr_type", C.c_int), ("dr_rot_threshold", C.c_float), ("dr_trans_threshold", C.c_float),
+        ("dr_base_factor", C.c_float),
+        ("mp_active", C.c_int), ("mp_omega", C.c_float * 36), ("mp_T_pred_inv", C.c_float * 16),
     ]
 
     @staticmethod
@@ -47,15 +52,24 @@ class RegParams(C.Structure):
                       lm_max_inner_iterations=10, crit_translation=1e-3, crit_rotation=1e-3,
                       auto_scale=0, auto_scaling_iter=4, init_scale=10.0, min_scale=0.5,
                       dl_initial_radius=1.0, dl_min_radius=1e-4, dl_max_radius=10.0, dl_eta1=0.25, dl_eta2=0.75,
-                      dl_gamma_decrease=0.25, dl_gamma_increase=2.0)
+                      dl_gamma_decrease=0.25, dl_gamma_increase=2.0,
+                      rot_enable=0, rot_weight=1.0, rot_robust_default_scale=10.0,
+                      dr_type=0, dr_rot_threshold=10.0, dr_trans_threshold=1.0, dr_base_factor=1.0, mp_active=0)
         for k, v in kw.items():
+            if k == "map_prior":  # (omega row-major 6x6, T_pred_inv row-major 4x4) from Oracle.map_prior_update
+                om, tinv = v
+                p.mp_active = 1
+                p.mp_omega = (C.c_float * 36)(*np.asarray(om, np.float32).T.ravel())
+                p.mp_T_pred_inv = (C.c_float * 16)(*np.asarray(tinv, np.float32).T.ravel())
+                continue
             setattr(p, k, v)
         return p
 
 
 class RegResult(C.Structure):
     _fields_ = [("T", C.c_float * 16), ("H", C.c_float * 36), ("b", C.c_float * 6), ("error", C.c_float),
-                ("inlier", C.c_uint32), ("iterations", C.c_int), ("converged", C.c_int)]
+                ("inlier", C.c_uint32), ("iterations", C.c_int), ("converged", C.c_int),
+                ("H_raw", C.c_float * 36), ("b_raw", C.c_float * 6), ("error_raw", C.c_float)]
 
 
 def _f(a):
@@ -344,6 +358,53 @@ class Oracle:
                                 C.c_float(robust_scale), C.c_float(genz_alpha), _p(out))
         return float(out[0]), int(out[1:2].view(np.uint32)[0])
 
+    def gicp_linearize_rot(self, src, src_cov, tgt, tgt_cov, tgt_nrm, nn_idx, nn_d2, T, max_corr=2.0, reg="GICP",
+                           loss="NONE", robust_scale=10.0, genz_alpha=1.0, rot_weight=1.0, rot_scale=10.0):
+        """K11 / K12 with the rotation-constraint term: returns (linearised dict, (error, inlier) of K12)."""
+        src, tgt = _f(src), _f(tgt)
+        src_cov, tgt_cov = _f(src_cov), _f(tgt_cov)
+        tgt_nrm = None if tgt_nrm is None else _f(tgt_nrm)
+        nn_idx = np.ascontiguousarray(nn_idx, np.int32).reshape(-1)
+        nn_d2 = _f(nn_d2).reshape(-1)
+        Tc = _f(np.asarray(T).T)
+        out = np.zeros(44, np.float32)
+        out2 = np.zeros(2, np.float32)
+        args = (_p(src), _p(src_cov), C.c_size_t(len(src)), _p(tgt), _p(tgt_cov), _p(tgt_nrm), _p(nn_idx, C.c_int32),
+                _p(nn_d2), _p(Tc), C.c_float(max_corr), REG[reg], LOSS[loss], C.c_float(robust_scale),
+                C.c_float(genz_alpha), C.c_float(rot_weight), C.c_float(rot_scale))
+        self.lib.orc_gicp_linearize_rot(*args, _p(out))
+        self.lib.orc_gicp_error_rot(*args, _p(out2))
+        res = {"H": out[:36].reshape(6, 6).copy(), "b": out[36:42].copy(), "error": float(out[42]),
+               "inlier": int(out[43:44].view(np.uint32)[0])}
+        return res, (float(out2[0]), int(out2[1:2].view(np.uint32)[0]))
+
+    def degenerate_regularize(self, H, b, inlier, T_cur, T_init, rot_thr=10.0, trans_thr=1.0, base_factor=1.0):
+        Hc = _f(np.asarray(H).T).copy()
+        bc = _f(b).copy()
+        self.lib.orc_degenerate_regularize(C.c_int(1), C.c_float(rot_thr), C.c_float(trans_thr), C.c_float(base_factor),
+                                           _p(Hc), _p(bc), C.c_uint32(inlier), _p(_f(np.asarray(T_cur).T)),
+                                           _p(_f(np.asarray(T_init).T)))
+        return Hc.T.copy(), bc
+
+    def map_prior_update(self, H_raw, error_raw, inlier, T_prev, T_pred, sigmas=(1.0, 1.0, 3.16e-2, 1e-2)):
+        """-> (has_prior, Omega 6x6, T_pred_inv 4x4); sigmas = rot_vel, trans_vel, rot_base, trans_base."""
+        om = np.zeros(36, np.float32)
+        tinv = np.zeros(16, np.float32)
+        sg = _f(sigmas)
+        has = self.lib.orc_map_prior_update(_p(sg), _p(_f(np.asarray(H_raw).T)), C.c_float(error_raw), C.c_uint32(inlier),
+                                            _p(_f(np.asarray(T_prev).T)), _p(_f(np.asarray(T_pred).T)), _p(om), _p(tinv))
+        return bool(has), om.reshape(6, 6).T.copy(), tinv.reshape(4, 4).T.copy()
+
+    def map_prior_apply(self, omega, T_pred_inv, H, b, error, T_est):
+        """-> (H + Omega, b + Omega e, error + e'Omega e / 2, prior_error(T_est))"""
+        Hc = _f(np.asarray(H).T).copy()
+        bc = _f(b).copy()
+        err = C.c_float(error)
+        self.lib.orc_map_prior_apply.restype = C.c_float
+        pe = self.lib.orc_map_prior_apply(_p(_f(np.asarray(omega).T)), _p(_f(np.asarray(T_pred_inv).T)), _p(Hc), _p(bc),
+                                          C.byref(err), _p(_f(np.asarray(T_est).T)))
+        return Hc.T.copy(), bc, float(err.value), float(pe)
+
     def icp_robust_weights(self, src, src_cov, tgt, tgt_cov, tgt_nrm, nn_idx, nn_d2, T, max_corr=2.0, reg="GICP",
                            loss="NONE", robust_scale=10.0):
         src, tgt = _f(src), _f(tgt)
@@ -377,7 +438,9 @@ class Oracle:
         out = {"T": np.array(res.T, np.float32).reshape(4, 4).T.copy(),
                "H": np.array(res.H, np.float32).reshape(6, 6).T.copy(), "b": np.array(res.b, np.float32),
                "error": float(res.error), "inlier": int(res.inlier), "iterations": int(res.iterations),
-               "converged": bool(res.converged)}
+               "converged": bool(res.converged),
+               "H_raw": np.array(res.H_raw, np.float32).reshape(6, 6).T.copy(), "b_raw": np.array(res.b_raw, np.float32),
+               "error_raw": float(res.error_raw)}
         if trace:
             out["trace"] = np.stack([tr[i].reshape(4, 4).T for i in range(trn.value)]) if trn.value else np.zeros((0, 4, 4))
         return out

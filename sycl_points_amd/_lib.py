@@ -29,7 +29,23 @@ class Linearized(C.Structure):  # sp_linearized
 
 class FactorParams(C.Structure):  # sp_factor_params
     _fields_ = [("reg_type", C.c_int), ("robust_type", C.c_int), ("max_correspondence_distance", C.c_float),
-                ("robust_scale", C.c_float), ("genz_alpha", C.c_float), ("genz_planarity_threshold", C.c_float)]
+                ("robust_scale", C.c_float), ("genz_alpha", C.c_float), ("genz_planarity_threshold", C.c_float),
+                ("rotation_constraint_enable", C.c_int), ("rotation_constraint_weight", C.c_float),
+                ("rotation_robust_scale", C.c_float)]
+
+
+class DegenerateRegParams(C.Structure):  # sp_degenerate_reg_params
+    _fields_ = [("type", C.c_int), ("rot_eigenvalue_threshold", C.c_float), ("trans_eigenvalue_threshold", C.c_float),
+                ("base_factor", C.c_float)]
+
+
+class MapPriorParams(C.Structure):  # sp_map_prior_params
+    _fields_ = [("enabled", C.c_int), ("rot_vel_sigma", C.c_float), ("trans_vel_sigma", C.c_float),
+                ("rot_base_sigma", C.c_float), ("trans_base_sigma", C.c_float)]
+
+
+class MapPriorState(C.Structure):  # sp_map_prior_state
+    _fields_ = [("has_prior", C.c_int), ("omega", C.c_float * 36), ("T_pred_inv", C.c_float * 16)]
 
 
 class GnParams(C.Structure):  # sp_gn_params
@@ -103,6 +119,10 @@ SIGNATURES = {
     "sp_rigid_mul_host": (None, [_vp, _vp, _vp]),
     "sp_ldlt6_solve_host": (_i, [_vp, _vp, _vp]),
     "sp_dogleg_step_host": (None, [_vp, _vp, _f, _vp, _vp, _vp]),
+    "sp_se3_log_host": (None, [_vp, _vp]),
+    "sp_degenerate_regularize_host": (_i, [_vp, _vp, _vp, C.c_uint32, _vp, _vp]),
+    "sp_map_prior_update_host": (_i, [_vp, _vp, _f, C.c_uint32, _vp, _vp, _vp]),
+    "sp_map_prior_apply_host": (_f, [_vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -135,7 +155,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.sp_abi_version() != 1:
+        if L.sp_abi_version() != 2:
             raise ImportError("libsycl_points_amd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FactorParams, GnParams, Linearized, SpError, check
+from ._lib import (DegenerateRegParams, FactorParams, GnParams, Linearized, MapPriorParams, MapPriorState, SpError,
+                   check)
 
 # sp_gicp_source_prepare's sort_by_cell: False keep order / True sort per alignment / "presorted" (GridKNN.order() or
 # voxel-downsampling output order): keep order, block-walk search
@@ -595,6 +596,19 @@ class RegistrationParams:
     criteria_translation: float = 1e-3
     criteria_rotation: float = 1e-3
     verbose: bool = False
+    # default-off terms
+    rotation_constraint_enable: bool = False  # registration_params.hpp:56-64
+    rotation_constraint_weight: float = 1.0
+    rotation_constraint_robust_default_scale: float = 10.0
+    degenerate_reg_type: str = "NONE"  # NONE | NL_REG (degenerate_regularization.hpp:41-46)
+    degenerate_reg_rot_eigenvalue_threshold: float = 10.0
+    degenerate_reg_trans_eigenvalue_threshold: float = 1.0
+    degenerate_reg_base_factor: float = 1.0
+    map_prior_enabled: bool = False  # map_prior.hpp:14-35
+    map_prior_rot_vel_sigma: float = 1.0
+    map_prior_trans_vel_sigma: float = 1.0
+    map_prior_rot_base_sigma: float = 3.16e-2
+    map_prior_trans_base_sigma: float = 1e-2
 
 
 @dataclass
@@ -607,6 +621,9 @@ class RegistrationResult:
     b: np.ndarray = field(default_factory=lambda: np.zeros(6, np.float32))
     error: float = FLT_MAX
     inlier: int = 0
+    H_raw: np.ndarray = field(default_factory=lambda: np.zeros((6, 6), np.float32))  # before regularisation / prior
+    b_raw: np.ndarray = field(default_factory=lambda: np.zeros(6, np.float32))
+    error_raw: float = FLT_MAX
 
 
 class Registration:
@@ -624,6 +641,28 @@ class Registration:
         self._ws = None
         self._lin = None
         self.genz_alpha = 1.0
+        self._rot_scale = self.params.rotation_constraint_robust_default_scale
+        self._map_prior = MapPriorState()
+
+    def set_map_prior_state(self, prev_result, T_pred):
+        """registration.hpp:124-126 / MapPrior::update (map_prior.hpp:97-174): call once per frame, after motion
+        prediction and before align(); `prev_result` is the previous frame's RegistrationResult."""
+        p = self.params
+        mp = MapPriorParams(int(p.map_prior_enabled), p.map_prior_rot_vel_sigma, p.map_prior_trans_vel_sigma,
+                            p.map_prior_rot_base_sigma, p.map_prior_trans_base_sigma)
+        Hraw = np.ascontiguousarray(prev_result.H_raw, np.float32)
+        Tprev, Tpred = _T16(prev_result.T).copy(), _T16(T_pred).copy()
+        check(_lib.lib().sp_map_prior_update_host(C.byref(mp), Hraw.ctypes.data_as(C.c_void_p),
+                                                  C.c_float(prev_result.error_raw), int(prev_result.inlier),
+                                                  Tprev.ctypes.data_as(C.c_void_p), Tpred.ctypes.data_as(C.c_void_p),
+                                                  C.byref(self._map_prior)))
+        return bool(self._map_prior.has_prior)
+
+    def _prior_error(self, T16):
+        if not (self.params.map_prior_enabled and self._map_prior.has_prior):
+            return np.float32(0.0)
+        return np.float32(_lib.lib().sp_map_prior_apply_host(C.byref(self._map_prior), T16.ctypes.data_as(C.c_void_p),
+                                                             None, None, None))
 
     # -- helpers
     def _buffers(self, device):
@@ -636,7 +675,8 @@ class Registration:
     def _factor_params(self, robust_scale):
         p = self.params
         return FactorParams(REG[p.reg_type], LOSS[p.robust_type], p.max_correspondence_distance, robust_scale,
-                            self.genz_alpha, p.genz_planarity_threshold)
+                            self.genz_alpha, p.genz_planarity_threshold, int(p.rotation_constraint_enable),
+                            p.rotation_constraint_weight, self._rot_scale)
 
     def _validate(self, source, target):
         p = self.params
@@ -657,6 +697,12 @@ class Registration:
         if p.reg_type == "POINT_TO_DISTRIBUTION" and not target.has_cov():
             raise SpError(2, "[Registration::validate_params] Covariance matrices of target must be pre-computed "
                              "before performing Point-to-Distribution ICP matching.")
+        if p.rotation_constraint_enable and not source.has_cov():
+            raise SpError(2, "[Registration::validate_params] Covariance matrices of source are required for "
+                             "performing rotation constraint matching.")
+        if p.rotation_constraint_enable and not target.has_cov():
+            raise SpError(2, "[Registration::validate_params] Covariance matrices of target are required for "
+                             "performing rotation constraint matching.")
         if p.robust_type != "NONE" and p.robust_default_scale <= 0.0:
             p.robust_type = "NONE"
 
@@ -686,21 +732,33 @@ class Registration:
         C.memmove(C.byref(out), h.ctypes.data, 192)
         return out
 
-    def compute_linearized_result(self, source, target, target_knn, pose, robust_scale=-1.0):
-        """registration.hpp:312-331 (without degenerate regularisation, which is default-off)."""
+    def compute_linearized_result(self, source, target, target_knn, pose, robust_scale=-1.0, rotation_robust_scale=-1.0,
+                                  initial_pose=None):
+        """registration.hpp:312-331; with `initial_pose` the degenerate regularisation is applied (:323)."""
         scale = robust_scale if robust_scale > 0 else self.params.robust_default_scale
+        self._rot_scale = (rotation_robust_scale if rotation_robust_scale > 0
+                           else self.params.rotation_constraint_robust_default_scale)
         _, lin = self._buffers(source.points.device)
         target_knn.nearest_neighbor_search_async(source, self.neighbors, pose)
         if self.params.reg_type == "GENZ":
             self.genz_alpha = self._genz_alpha(source, target)
         self._linearize("linearize", source, target, pose, scale, lin)
         r = self._read_lin(lin)
+        p = self.params
+        if initial_pose is not None and p.degenerate_reg_type.upper() != "NONE":
+            dreg = DegenerateRegParams(1, p.degenerate_reg_rot_eigenvalue_threshold,
+                                       p.degenerate_reg_trans_eigenvalue_threshold, p.degenerate_reg_base_factor)
+            Tc, Ti = _T16(pose).copy(), _T16(initial_pose).copy()
+            check(_lib.lib().sp_degenerate_regularize_host(C.byref(dreg), r.H, r.b, r.inlier,
+                                                           Tc.ctypes.data_as(C.c_void_p), Ti.ctypes.data_as(C.c_void_p)))
         return {"H": np.array(r.H, np.float32).reshape(6, 6), "b": np.array(r.b, np.float32), "error": float(r.error),
                 "inlier": int(r.inlier)}
 
-    def compute_error_frozen(self, source, target, pose, robust_scale=-1.0):
+    def compute_error_frozen(self, source, target, pose, robust_scale=-1.0, rotation_robust_scale=-1.0):
         """registration.hpp:350-359 — error at `pose` with the cached correspondences."""
         scale = robust_scale if robust_scale > 0 else self.params.robust_default_scale
+        self._rot_scale = (rotation_robust_scale if rotation_robust_scale > 0
+                           else self.params.rotation_constraint_robust_default_scale)
         _, lin = self._buffers(source.points.device)
         self._linearize("error", source, target, pose, scale, lin)
         r = self._read_lin(lin)
@@ -721,8 +779,10 @@ class Registration:
         return out
 
     # -- the reference's host-driven loop
-    def align(self, source, target, target_knn, initial_guess=None, robust_scale=-1.0):
-        """registration.hpp:201-276 with optimize_gauss_newton (:803-828) / optimize_levenberg_marquardt (:830-895)."""
+    def align(self, source, target, target_knn, initial_guess=None, robust_scale=-1.0, rotation_robust_scale=-1.0):
+        """registration.hpp:201-276 with optimize_gauss_newton (:803-828) / optimize_levenberg_marquardt (:830-895) /
+        optimize_powell_dogleg (:897-965); degenerate regularisation and the MAP prior act on the reduced system
+        between the device reduction and the solve (:236-253)."""
         L = _lib.lib()
         p = self.params
         result = RegistrationResult()
@@ -731,11 +791,18 @@ class Registration:
             return result
         self._validate(source, target)
         scale = robust_scale if robust_scale > 0 else p.robust_default_scale
+        self._rot_scale = (rotation_robust_scale if rotation_robust_scale > 0
+                           else p.rotation_constraint_robust_default_scale)
         _, lin = self._buffers(source.points.device)
         lm_lambda = p.lm_init_lambda
         radius = np.float32(p.dogleg_initial_trust_region_radius)
         T = _T16(result.T).copy().reshape(-1)  # column-major working copy
+        T_initial = T.copy()
         delta8 = np.zeros(8, np.float32)
+        dreg = DegenerateRegParams({"NONE": 0, "NL_REG": 1, "NL-REG": 1}[p.degenerate_reg_type.upper()],
+                                   p.degenerate_reg_rot_eigenvalue_threshold,
+                                   p.degenerate_reg_trans_eigenvalue_threshold, p.degenerate_reg_base_factor)
+        prior_on = p.map_prior_enabled and bool(self._map_prior.has_prior)
         for it in range(p.max_iterations):
             Tmat = T.reshape(4, 4).T
             target_knn.nearest_neighbor_search_async(source, self.neighbors, Tmat)
@@ -743,6 +810,16 @@ class Registration:
                 self.genz_alpha = self._genz_alpha(source, target)
             self._linearize("linearize", source, target, Tmat, scale, lin)
             lr = self._read_lin(lin)  # the reference's wait_and_throw + toCPU (registration.hpp:674-675)
+            result.H_raw = np.array(lr.H, np.float32).reshape(6, 6)  # registration.hpp:244-246
+            result.b_raw = np.array(lr.b, np.float32)
+            result.error_raw = float(lr.error)
+            if dreg.type:  # registration.hpp:249-250
+                check(L.sp_degenerate_regularize_host(C.byref(dreg), lr.H, lr.b, lr.inlier,
+                                                      T.ctypes.data_as(C.c_void_p), T_initial.ctypes.data_as(C.c_void_p)))
+            if prior_on:  # registration.hpp:253
+                err = C.c_float(lr.error)
+                L.sp_map_prior_apply_host(C.byref(self._map_prior), T.ctypes.data_as(C.c_void_p), lr.H, lr.b, C.byref(err))
+                lr.error = err.value
             H = np.array(lr.H, np.float32).reshape(6, 6)
             b = np.array(lr.b, np.float32)
             if p.optimization_method == "GN":
@@ -769,7 +846,9 @@ class Registration:
                     L.sp_se3_exp_host(p6.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p))
                     L.sp_rigid_mul_host(T.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p),
                                         Ttry.ctypes.data_as(C.c_void_p))
-                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale)
+                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale,
+                                                               self._rot_scale)
+                    new_error = f32(f32(new_error) + self._prior_error(Ttry))  # registration.hpp:933
                     rho = f32(f32(lr.error) - f32(new_error)) / f32(pred.value)
                     if rho < p.dogleg_eta1:
                         radius = clamp(f32(radius * f32(p.dogleg_gamma_decrease)))
@@ -790,8 +869,9 @@ class Registration:
                                         p.criteria_translation, delta8.ctypes.data_as(C.c_void_p))
                     conv = bool(delta8[6] > 0.5)
                     result.converged = conv
-                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale)
-                    new_error = np.float32(new_error)
+                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale,
+                                                               self._rot_scale)
+                    new_error = np.float32(np.float32(new_error) + self._prior_error(Ttry))  # registration.hpp:854
                     if new_error <= current_error:
                         result.converged, T = conv, Ttry
                         result.error, result.inlier = float(new_error), inl

@@ -237,12 +237,51 @@ __device__ __forceinline__ float error_point(const Rigid& T, const Corr& c, floa
     return planar ? plane() : chain3(r0, r0, r1, r1, r2, r2);
 }
 
+// Rotation constraint: Jensen-Bregman LogDet divergence between R Cs R^T and Ct (rotation_constraint.hpp:15-128).
+// D = max(log det((Cs' + Ct)/2) - (log det Cs + log det Ct)/2, 0) with determinants floored at 1e-10;
+// gradient g = R^T * (-vex([Cs', M^-1])) in the body frame; the term contributes J J^T to the rotation block of H,
+// D J to b[0..2] and D^2/2 as its squared error.
+struct RotTerm {
+    float D;
+    float J[3];
+};
+template <bool WITH_GRAD>
+__device__ __forceinline__ RotTerm rotation_divergence(const Rigid& T, const Mat3& Cs, const Mat3& Ct) {
+    Mat3 R;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R.m[i][j] = T.R[i][j];
+    const Mat3 Csp = matmul(R, matmul_bt(Cs, R));
+    Mat3 M;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M.m[i][j] = (Csp.m[i][j] + Ct.m[i][j]) * 0.5f;
+    const float log_det_M = logf(fmaxf(determinant(M), 1e-10f));
+    const float log_det_ref = 0.5f * (logf(fmaxf(determinant(Cs), 1e-10f)) + logf(fmaxf(determinant(Ct), 1e-10f)));
+    RotTerm out;
+    out.D = fmaxf(log_det_M - log_det_ref, 0.0f);
+    if (WITH_GRAD) {
+        const Mat3 Mi = inverse(M);
+        const Mat3 A = matmul(Csp, Mi), B = matmul(Mi, Csp);
+        const float g0 = -0.5f * ((A.m[2][1] - B.m[2][1]) - (A.m[1][2] - B.m[1][2]));
+        const float g1 = -0.5f * ((A.m[0][2] - B.m[0][2]) - (A.m[2][0] - B.m[2][0]));
+        const float g2 = -0.5f * ((A.m[1][0] - B.m[1][0]) - (A.m[0][1] - B.m[0][1]));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out.J[i] = chain3(R.m[0][i], g0, R.m[1][i], g1, R.m[2][i], g2);
+    }
+    return out;
+}
+
 struct KParams {
     const float4 *src, *scov, *tgt, *tcov, *tnrm;
     const int32_t* nn_idx;
     const float* nn_d2;
     unsigned n;
     float max_d2, scale, genz_alpha, genz_thr;
+    int rot_enable;  // rotation constraint (registration.hpp:559-561): weight and its own robust scale
+    float rot_weight, rot_scale;
     Mat4Arg T_val;
     const float* T_dev;
 };
@@ -292,13 +331,31 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(KParams P, float* __r
         const float w = robust_weight<LOSS>(pt.residual_norm, P.scale);
         float err = robust_error<LOSS>(pt.residual_norm, P.scale);
         if (REG == SP_REG_GENZ) err = pt.genz_weight * err;
+        float rw = 0.0f;  // rotation-constraint term of this correspondence (registration.hpp:630-650)
+        RotTerm rot;
+        rot.D = rot.J[0] = rot.J[1] = rot.J[2] = 0.0f;
+        if (P.rot_enable) {
+            const int ti = P.nn_idx[i];
+            rot = rotation_divergence<true>(T, load_cov3(P.scov + 4 * (size_t)i), load_cov3(P.tcov + 4 * (size_t)ti));
+            const float rn = sqrtf(0.5f * rot.D * rot.D);
+            rw = P.rot_weight * robust_weight<LOSS>(rn, P.rot_scale);
+            err += P.rot_weight * robust_error<LOSS>(rn, P.rot_scale);
+        }
         int e = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int cc = a; cc < 6; ++cc) acc[e++] += w * pt.H[a][cc];
+            for (int cc = a; cc < 6; ++cc) {
+                float v = w * pt.H[a][cc];
+                if (a < 3 && cc < 3) v += rw * (rot.J[a] * rot.J[cc]);
+                acc[e++] += v;
+            }
 #pragma unroll
-        for (int a = 0; a < 6; ++a) acc[21 + a] += w * pt.b[a];
+        for (int a = 0; a < 6; ++a) {
+            float v = w * pt.b[a];
+            if (a < 3) v += rw * (rot.D * rot.J[a]);
+            acc[21 + a] += v;
+        }
         acc[27] += err;
         ++cnt;
     }
@@ -317,6 +374,12 @@ __global__ __launch_bounds__(kBlock) void error_kernel(KParams P, float* __restr
         const float sq = error_point<REG>(T, c, P.genz_alpha, P.genz_thr, gw);
         float err = robust_error<LOSS>(sqrtf(sq), P.scale);
         if (REG == SP_REG_GENZ) err = gw * err;
+        if (P.rot_enable) {  // registration.hpp:758-766
+            const int ti = P.nn_idx[i];
+            const RotTerm rot =
+                rotation_divergence<false>(T, load_cov3(P.scov + 4 * (size_t)i), load_cov3(P.tcov + 4 * (size_t)ti));
+            err += P.rot_weight * robust_error<LOSS>(sqrtf(0.5f * rot.D * rot.D), P.rot_scale);
+        }
         acc[0] += err;
         ++cnt;
     }
@@ -951,6 +1014,9 @@ KParams make_params(const float* src, const float* scov, size_t n, const float* 
     P.scale = fp->robust_scale;
     P.genz_alpha = fp->genz_alpha;
     P.genz_thr = fp->genz_planarity_threshold;
+    P.rot_enable = fp->rotation_constraint_enable;
+    P.rot_weight = fp->rotation_constraint_weight;
+    P.rot_scale = fp->rotation_robust_scale;
     for (int i = 0; i < 16; ++i) P.T_val.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     if (T && !T_dev)
         for (int i = 0; i < 16; ++i) P.T_val.m[i] = T[i];
@@ -1006,6 +1072,16 @@ int validate(const sp_factor_params* fp, const float* scov, const float* tcov, c
     if (fp->reg_type == SP_REG_GENZ && (!tcov || !tnrm)) {
         sp_set_error("[Registration::validate_params] Covariance matrices and normals of target must be pre-computed "
                      "before performing GenZ-ICP matching.");
+        return SP_ERR_RUNTIME;
+    }
+    if (fp->rotation_constraint_enable && !scov) {
+        sp_set_error("[Registration::validate_params] Covariance matrices of source are required for performing "
+                     "rotation constraint matching.");
+        return SP_ERR_RUNTIME;
+    }
+    if (fp->rotation_constraint_enable && !tcov) {
+        sp_set_error("[Registration::validate_params] Covariance matrices of target are required for performing "
+                     "rotation constraint matching.");
         return SP_ERR_RUNTIME;
     }
     if (fp->reg_type == SP_REG_POINT_TO_PLANE && !tnrm) {
@@ -1329,6 +1405,10 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         sp_set_error("[sp_gicp_iteration_fused] only RegType::GICP has a prepared/fused form");
         return SP_ERR_INVALID_ARGUMENT;
     }
+    if (params->rotation_constraint_enable) {
+        sp_set_error("[sp_gicp_iteration_fused] the rotation constraint needs the raw covariances: use sp_gicp_linearize");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
     if (gn && !transT_on_device) {
         sp_set_error("[sp_gicp_iteration_fused] the fused Gauss-Newton update needs the pose on the device");
         return SP_ERR_INVALID_ARGUMENT;
@@ -1391,6 +1471,10 @@ int align_check(const char* who, const sp_gicp_target* target, const sp_gicp_sou
     if (!target || !source || !params || !gn || !T) return SP_ERR_INVALID_ARGUMENT;
     if (params->reg_type != SP_REG_GICP) {
         sp_set_error("[sp_gicp_align_*] only RegType::GICP has a prepared/fused form");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (params->rotation_constraint_enable) {
+        sp_set_error("[sp_gicp_align_*] the rotation constraint needs the raw covariances: use sp_gicp_linearize");
         return SP_ERR_INVALID_ARGUMENT;
     }
     if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(source->n)) {

@@ -25,8 +25,14 @@ struct orc_reg_params {
     int auto_scale, auto_scaling_iter;
     float init_scale, min_scale;
     float dl_initial_radius, dl_min_radius, dl_max_radius, dl_eta1, dl_eta2, dl_gamma_decrease, dl_gamma_increase;  // 0: defaults
+    int rot_enable; float rot_weight, rot_robust_default_scale;                  // rotation constraint (0: off)
+    int dr_type; float dr_rot_threshold, dr_trans_threshold, dr_base_factor;    // degenerate regularisation (0: off)
+    int mp_active; float mp_omega[36]; float mp_T_pred_inv[16];                  // MAP prior from orc_map_prior_update
 };
-struct orc_reg_result { float T[16]; float H[36]; float b[6]; float error; uint32_t inlier; int iterations; int converged; };
+struct orc_reg_result {
+    float T[16]; float H[36]; float b[6]; float error; uint32_t inlier; int iterations; int converged;
+    float H_raw[36]; float b_raw[6]; float error_raw;
+};
 extern "C" {
 void orc_knn_bruteforce(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t* idx, float* d2);
 void orc_cov_estimate(const float* pts, size_t n, const int32_t* idx, size_t k, float* covs);
@@ -37,6 +43,8 @@ void orc_registration_align(const orc_reg_params* P, const float* src, const flo
                             orc_reg_result* out, float* trace_T, int* trace_n, const void* prebuilt_nodes,
                             size_t prebuilt_n_nodes);
 void orc_se3_exp(const float* twist6, float* T16);
+int orc_map_prior_update(const float* sig4, const float* H_raw36, float error_raw, uint32_t inlier, const float* T_prev16,
+                         const float* T_pred16, float* omega36, float* T_pred_inv16);
 }
 
 using namespace sycl_points;
@@ -284,6 +292,60 @@ static void registration_matches_oracle() {
         CHECK(max_abs_diff(rd.T.matrix(), refd.T) < 1e-5f);
         CHECK(rd.inlier == refd.inlier && (int)rd.iterations == refd.iterations);
         CHECK(max_abs_diff(rd.T.matrix(), T_gt.data()) < 5e-4f);
+    }
+    // default-off terms together (rotation constraint, NL-Reg, MAP prior) with LM, against the oracle's restatement
+    {
+        alg::registration::RegistrationParams p0 = p;
+        p0.max_iterations = 3;
+        alg::registration::Registration reg0(*Q, p0);
+        const auto prev = reg0.align(source, target, *tree);
+        CHECK(prev.error_raw < std::numeric_limits<float>::max() && prev.H_raw(0, 0) > 0.0f);
+        const float dtw[6] = {0.002f, -0.001f, 0.001f, 0.01f, 0.0f, -0.005f};
+        TransformMatrix E;
+        orc_se3_exp(dtw, E.data());
+        Eigen::Isometry3f T_pred = prev.T * Eigen::Isometry3f(E);
+        alg::registration::RegistrationParams pt = p;
+        pt.optimization_method = alg::registration::OptimizationMethod::LEVENBERG_MARQUARDT;
+        pt.max_iterations = 8;
+        pt.rotation_constraint.enable = true;
+        pt.rotation_constraint.weight = 3.0f;
+        pt.degenerate_reg.type = alg::registration::DegenerateRegularizationType_from_string("NL-REG");
+        pt.degenerate_reg.rot_eigenvalue_threshold = 1e9f;  // every direction penalised: the selection cannot flip
+        pt.degenerate_reg.trans_eigenvalue_threshold = 1e9f;
+        pt.degenerate_reg.base_factor = 0.25f;
+        pt.map_prior.enabled = true;
+        alg::registration::Registration regt(*Q, pt);
+        regt.set_map_prior_state(prev, T_pred);
+        const TransformMatrix Tp = T_pred.matrix();
+        const auto rt = regt.align(source, target, *tree, Tp);
+        orc_reg_params ot = op;
+        ot.optimization_method = 1; ot.max_iterations = 8;
+        ot.rot_enable = 1; ot.rot_weight = 3.0f; ot.rot_robust_default_scale = 10.0f;
+        ot.dr_type = 1; ot.dr_rot_threshold = 1e9f; ot.dr_trans_threshold = 1e9f; ot.dr_base_factor = 0.25f;
+        const float sig[4] = {1.0f, 1.0f, 3.16e-2f, 1e-2f};
+        float Hraw[36];  // the oracle takes column-major; H_raw is symmetric
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) Hraw[j * 6 + i] = prev.H_raw(i, j);
+        const TransformMatrix Tprev = prev.T.matrix();
+        ot.mp_active = orc_map_prior_update(sig, Hraw, prev.error_raw, prev.inlier, Tprev.data(), Tp.data(), ot.mp_omega,
+                                            ot.mp_T_pred_inv);
+        CHECK(ot.mp_active == 1);
+        orc_reg_result reft;
+        orc_registration_align(&ot, reinterpret_cast<const float*>(source.points->data()),
+                               reinterpret_cast<const float*>(source.covs->data()), n,
+                               reinterpret_cast<const float*>(target.points->data()),
+                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, Tp.data(), 0, &reft, nullptr, nullptr, nullptr, 0);
+        CHECK(max_abs_diff(rt.T.matrix(), reft.T) < 1e-5f);
+        CHECK(rt.inlier == reft.inlier && (int)rt.iterations == reft.iterations);
+        CHECK(rt.H(0, 0) - rt.H_raw(0, 0) > 0.9f * 0.25f * float(rt.inlier));  // penalty (+ prior) in H, not in H_raw
+        CHECK(std::fabs(rt.H_raw(0, 0) - reft.H_raw[0]) <= 5e-5f * std::fabs(reft.H_raw[0]));
+        // without source covariances the rotation constraint is refused (registration.hpp:174-186)
+        PointCloudShared bare(*Q);
+        bare.resize_points(n);
+        for (size_t i = 0; i < n; ++i) (*bare.points)[i] = (*source.points)[i];
+        bool threw = false;
+        try { regt.align(bare, target, *tree); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
     }
     // LM + Geman-McClure through the annealing pipeline (example_registration.cpp:31-45), against the oracle's restatement
     alg::registration::RegistrationPipelineParams pp;

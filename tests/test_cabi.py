@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
-    assert _lib.lib().sp_abi_version() == 1
+    assert _lib.lib().sp_abi_version() == 2
 
 
 def test_sp_linearized_is_192_bytes():

@@ -533,6 +533,105 @@ def test_align_powell_dogleg_matches_oracle(sp, orc, gicp20k, radius):
         assert np.abs(got.T - T_gt).max() < 5e-4
 
 
+# ------------------------------------------------------------------ default-off registration terms
+@pytest.mark.parametrize("reg,loss", [("GICP", "NONE"), ("GICP", "HUBER"), ("POINT_TO_POINT", "CAUCHY"),
+                                      ("POINT_TO_DISTRIBUTION", "TUKEY")])
+def test_rotation_constraint_term_matches_oracle(sp, orc, gicp20k, reg, loss):
+    """K11 / K12 with the Jensen-Bregman LogDet rotation constraint (rotation_constraint.hpp:15-128,
+    registration.hpp:630-650, 758-766): per inlier correspondence, weighted, with its own robust scale."""
+    src, scov, tgt, tcov, _ = gicp20k
+    T = orc.se3_exp([0.08, -0.05, 0.06, 0.02, -0.01, 0.005])  # a visible rotation: the divergence is well above 0
+    idx, d2 = orc.kdtree_knn(orc.kdtree_build(tgt), src, 1, T)
+    d2 = d2.copy()
+    d2[::53] = 100.0
+    weight, rot_scale, scale = 60.0, 0.05, 0.5
+    ref, (oe, oinl) = orc.gicp_linearize_rot(src, scov, tgt, tcov, None, idx, d2, T, 2.0, reg, loss, scale, 1.0, weight,
+                                             rot_scale)
+    plain = orc.gicp_linearize(src, scov, tgt, tcov, None, idx, d2, T, 2.0, reg, loss, scale, 1.0)
+    assert np.abs(ref["H"][:3, :3] - plain["H"][:3, :3]).max() > 1e-3 * np.abs(plain["H"]).max()  # the term matters
+    assert np.array_equal(ref["H"][3:, 3:], plain["H"][3:, 3:])
+    reg_ = sp.Registration(sp.RegistrationParams(reg_type=reg, robust_type=loss, rotation_constraint_enable=True,
+                                                 rotation_constraint_weight=weight,
+                                                 rotation_constraint_robust_default_scale=rot_scale))
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    reg_.neighbors.indices, reg_.neighbors.distances = dev(idx), dev(d2)
+    _, lin = reg_._buffers(S.points.device)
+    reg_._linearize("linearize", S, Tg, T, scale, lin)
+    got = reg_._read_lin(lin)
+    H, b = np.array(got.H, np.float32).reshape(6, 6), np.array(got.b, np.float32)
+    hs = np.abs(ref["H"]).max()
+    assert got.inlier == ref["inlier"]
+    assert np.allclose(H, ref["H"], atol=3e-5 * hs), np.abs(H - ref["H"]).max() / hs
+    assert np.allclose(b, ref["b"], atol=3e-5 * max(np.abs(ref["b"]).max(), 1e-3 * hs))
+    assert abs(got.error - ref["error"]) <= 3e-5 * abs(ref["error"])
+    e, inl = reg_.compute_error_frozen(S, Tg, T, scale)
+    assert inl == oinl and abs(e - oe) <= 3e-5 * abs(oe)
+    # an explicit per-call scale overrides the default (ExecutionOptions::rotation_robust_scale)
+    e2, _ = reg_.compute_error_frozen(S, Tg, T, scale, rotation_robust_scale=10.0)
+    _, (oe2, _) = orc.gicp_linearize_rot(src, scov, tgt, tcov, None, idx, d2, T, 2.0, reg, loss, scale, 1.0, weight, 10.0)
+    assert abs(e2 - oe2) <= 3e-5 * abs(oe2)
+    # source covariances are required
+    with pytest.raises(sp.SpError):
+        reg_.align(sp.PointCloudShared(dev(src)), Tg, sp.KDTree.build(tgt))
+
+
+@pytest.mark.parametrize("method", ["GN", "LM", "DOGLEG"])
+def test_align_with_default_off_terms_matches_oracle(sp, orc, gicp20k, method):
+    """Registration::align with the rotation constraint, NL-Reg degenerate regularisation and a MAP prior all active
+    (registration.hpp:236-253, 854, 933) against the oracle's restatement of the same loop."""
+    from oracle.pyoracle import OPT, RegParams
+
+    src, scov, tgt, tcov, T_gt = gicp20k
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    tree = sp.KDTree.build(tgt)
+    # previous frame: a plain alignment, whose raw system feeds the prior of this frame
+    prev = sp.Registration(sp.RegistrationParams(max_iterations=3)).align(S, Tg, tree)
+    oprev = orc.registration_align(RegParams.defaults(max_iterations=3), src, scov, tgt, tcov)
+    assert np.abs(prev.H_raw - oprev["H_raw"]).max() <= 2e-5 * np.abs(oprev["H_raw"]).max()
+    assert abs(prev.error_raw - oprev["error_raw"]) <= 2e-5 * abs(oprev["error_raw"])
+    T_pred = orc.isometry_mul(prev.T, orc.se3_exp([0.002, -0.001, 0.001, 0.01, 0.0, -0.005]))
+    has, Om, Tinv = orc.map_prior_update(oprev["H_raw"], oprev["error_raw"], oprev["inlier"], oprev["T"], T_pred)
+    thr_rot = float(np.linalg.eigvalsh(oprev["H_raw"][:3, :3].astype(np.float64))[1] / oprev["inlier"]) * 1.001
+    thr_tr = float(np.linalg.eigvalsh(oprev["H_raw"][3:, 3:].astype(np.float64))[0] / oprev["inlier"]) * 1.5
+    p = sp.RegistrationParams(optimization_method=method, max_iterations=12, criteria_translation=1e-5,
+                              criteria_rotation=1e-5, rotation_constraint_enable=True, rotation_constraint_weight=3.0,
+                              degenerate_reg_type="NL_REG", degenerate_reg_rot_eigenvalue_threshold=thr_rot,
+                              degenerate_reg_trans_eigenvalue_threshold=thr_tr, degenerate_reg_base_factor=0.5,
+                              map_prior_enabled=True)
+    reg = sp.Registration(p)
+    assert reg.set_map_prior_state(prev, T_pred) and has
+    got = reg.align(S, Tg, tree, initial_guess=T_pred)
+    ref = orc.registration_align(
+        RegParams.defaults(optimization_method=OPT[method], max_iterations=12, crit_translation=1e-5, crit_rotation=1e-5,
+                           rot_enable=1, rot_weight=3.0, dr_type=1, dr_rot_threshold=thr_rot, dr_trans_threshold=thr_tr,
+                           dr_base_factor=0.5, map_prior=(Om, Tinv)),
+        src, scov, tgt, tcov, init_T=T_pred)
+    assert np.abs(got.T - ref["T"]).max() < 1e-5
+    assert got.iterations == ref["iterations"] and got.converged == ref["converged"] and got.inlier == ref["inlier"]
+    hs = np.abs(ref["H"]).max()
+    assert np.abs(got.H - ref["H"]).max() <= 5e-5 * hs            # regularised + prior system of the last iteration
+    assert np.abs(got.H_raw - ref["H_raw"]).max() <= 5e-5 * hs    # and the raw one
+    # the terms are really in: the penalty alone adds base_factor * inlier per penalised direction to the trace
+    assert np.trace(got.H - got.H_raw) > 0.5 * 0.5 * got.inlier
+    # each term alone is visible in the first iteration's system: the rotation constraint in the raw error (K11), the
+    # two host terms in H (after the raw system was recorded)
+    T1 = orc.isometry_mul(T_pred, orc.se3_exp([0.01, 0, 0, 0.02, 0, 0]))
+    two = sp.Registration(sp.RegistrationParams(max_iterations=1)).align(S, Tg, tree, initial_guess=T1)
+    for kw in (dict(rotation_constraint_enable=True, rotation_constraint_weight=3.0),
+               dict(degenerate_reg_type="NL_REG", degenerate_reg_rot_eigenvalue_threshold=thr_rot,
+                    degenerate_reg_trans_eigenvalue_threshold=thr_tr),
+               dict(map_prior_enabled=True)):
+        r1 = sp.Registration(sp.RegistrationParams(max_iterations=1, **kw))
+        r1.set_map_prior_state(prev, T_pred)
+        one = r1.align(S, Tg, tree, initial_guess=T1)
+        if "rotation_constraint_enable" in kw:
+            assert one.error_raw > two.error_raw * (1 + 1e-3), kw
+        else:
+            assert np.array_equal(one.H_raw, two.H_raw) and np.trace(one.H - two.H) > 1.0, kw
+
+
 # ------------------------------------------------------------------ K8: M-estimated covariance, normalize_covariance
 @pytest.mark.parametrize("loss", ["HUBER", "TUKEY", "CAUCHY", "GEMAN_MCCLURE", "NONE"])
 @pytest.mark.parametrize("k", [10, 20, 33])
