@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: run the multi-GPU code path (RCCL all-reduce of the 192-byte system every iteration) "
                          "with a world of one rank")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="sharded runs: issue every launch / collective from the host instead of replaying one "
+                         "captured hipGraph per alignment")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: build the clouds of an N-rank run (N x --points, config 5 density) and time "
                          "rank 0's tile against the full target, without the collective")
@@ -117,11 +120,12 @@ def main():
     T_ident = torch.eye(4, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     delta = torch.zeros(8, dtype=torch.float32, device=dev)
     group = dist.group.WORLD if (world > 1 or args.force_sharded) else None
+    use_graph = group is not None and not args.no_graph and os.environ.get("SP_BENCH_GRAPH", "1") == "1"
 
     def align_chunk(iters, first):
         if args.path == "fused":
             reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta, prepare=first,
-                                 sort_by_cell=SORT_MODE)
+                                 sort_by_cell=SORT_MODE, graph=use_graph)
         else:
             reg.align_device_loop(S, Tg, knn, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta)
 
@@ -140,6 +144,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_graph:
+        # set-up, like building the grid: capture the hipGraph of every chunk length the warm-up and the timed region
+        # will use (first call of a shape runs eagerly, the second is captured), so no capture falls into the timed region
+        for k in (args.warmup, args.steps):
+            for chunk in {ITERS_PER_ALIGN if k >= ITERS_PER_ALIGN else 0, k % ITERS_PER_ALIGN} - {0}:
+                for _ in range(2):
+                    T_dev.copy_(T_ident)
+                    align_chunk(chunk, True)
+        fence()
     run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
@@ -162,6 +175,7 @@ def main():
     # ---- per-kernel durations over one alignment, by HIP events on the launch stream (rank 0's numbers are reported)
     kern = kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n_local, SORT_MODE)
 
+    graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
         dom = max((k for k in kern if kern[k].get("per_iteration", True)), key=lambda k: kern[k]["ms"])
         out = {
@@ -186,7 +200,10 @@ def main():
                                              "safe radii); per alignment only the source is prepared",
                        "source_order": ("cell order of a grid on the source (set-up), no per-alignment sort"
                                         if args.source_order == "grid" else "random; sorted by target cell in every alignment"),
-                       "sharding": "source tile-sharded, target replicated" if world > 1 else "none"},
+                       "sharding": "source tile-sharded, target replicated" if world > 1 else "none",
+                       "launch": ("one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
+                                  else ("per-iteration launches + all-reduce from the host" if group is not None
+                                        else "one C call per alignment"))},
             "iterations_per_sec": args.steps / elapsed,
             "pose_max_abs_err_vs_ground_truth": pose_err,
             "inliers_last_iteration": int(lin.inlier),

@@ -926,7 +926,7 @@ class Registration:
 
     def align_fused_loop(self, source, prepared_target, initial_guess=None, iterations=None, robust_scale=-1.0,
                          group=None, T_dev=None, delta_dev=None, prepare=True, sort_by_cell=True,
-                         write_neighbors=False, per_iteration_launches=False, update_target=False):
+                         write_neighbors=False, per_iteration_launches=False, update_target=False, graph=False):
         """The same fixed-length Gauss-Newton loop as align_device_loop on the prepared / fused path
         (sp_gicp_iteration_fused): one launch per iteration does NN + linearise + reduce, and, on a single GPU, the
         second (one-workgroup) launch also solves and updates the pose. On one GPU the default is
@@ -987,14 +987,50 @@ class Registration:
             for k in (0, 1):
                 off = (L.sp_gicp_align_rows(_ptr(ws), k, C.byref(nf)) - base) // 4
                 rows.append(wsf[off:off + nf.value])
-            wsp, linp, Tp, st = _ptr(ws), _ptr(lin), _ptr(T_dev), _stream()
-            for k in range(iters):
-                check(L.sp_gicp_align_step(prepared_target._h, self._psrc._h, Tp, C.byref(fp), C.byref(gn), k, 1, ni, nd,
-                                           linp, wsp, ws.numel(), st))
-                dist.all_reduce(rows[k & 1], op=dist.ReduceOp.SUM, group=group)
-            if iters > 0:
-                check(L.sp_gicp_align_finish(self._psrc._h, _ptr(T_dev), C.byref(gn), iters - 1, 1, _ptr(lin),
-                                             _ptr(delta_dev), _ptr(self._iters_dev), _ptr(ws), ws.numel(), _stream()))
+            wsp, linp, Tp = _ptr(ws), _ptr(lin), _ptr(T_dev)
+
+            def enqueue():
+                st = _stream()
+                for k in range(iters):
+                    check(L.sp_gicp_align_step(prepared_target._h, self._psrc._h, Tp, C.byref(fp), C.byref(gn), k, 1, ni, nd,
+                                               linp, wsp, ws.numel(), st))
+                    dist.all_reduce(rows[k & 1], op=dist.ReduceOp.SUM, group=group)
+                if iters > 0:
+                    check(L.sp_gicp_align_finish(self._psrc._h, _ptr(T_dev), C.byref(gn), iters - 1, 1, _ptr(lin),
+                                                 _ptr(delta_dev), _ptr(self._iters_dev), _ptr(ws), ws.numel(), st))
+
+            if not graph:
+                enqueue()
+                return T_dev, lin, delta_dev
+            # The loop touches fixed buffers only (pose, partial rows, state), so launches + collectives of a whole
+            # alignment are captured once into a hipGraph and replayed: the host then issues one launch per alignment
+            # instead of 2 x iterations calls, and the GPU-side chain (kernel -> all-reduce -> kernel) is what is left.
+            key = (iters, prepared_target._h.value if hasattr(prepared_target._h, "value") else id(prepared_target),
+                   id(self._psrc), T_dev.data_ptr(), delta_dev.data_ptr(), ws.data_ptr(), lin.data_ptr(), ni, nd, n,
+                   scale, id(group))
+            graphs = self.__dict__.setdefault("_loop_graphs", {})
+            g = graphs.get(key)
+            if g is None:
+                enqueue()  # first alignment of this shape runs eagerly (RCCL warm-up), the second one is captured
+                graphs[key] = "warm"
+            elif g == "warm":
+                try:
+                    torch.cuda.synchronize()
+                    cg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cg):
+                        enqueue()
+                    graphs[key] = cg
+                    cg.replay()
+                except Exception as e:  # capture not supported for this collective / runtime: stay on eager launches
+                    graphs[key] = False
+                    import warnings
+                    warnings.warn(f"align_fused_loop: hipGraph capture failed ({e!r}); using per-call launches")
+                    torch.cuda.synchronize()
+                    enqueue()
+            elif g is False:
+                enqueue()
+            else:
+                g.replay()
             return T_dev, lin, delta_dev
         for _ in range(iters):
             check(L.sp_gicp_iteration_fused(prepared_target._h, self._psrc._h, _ptr(T_dev), 1, C.byref(fp),

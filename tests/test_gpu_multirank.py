@@ -85,3 +85,44 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path):
     assert np.abs(r0[33:49] - single).max() < 2e-6  # two-launch fused loop, sharded
     assert int(r0[49]) == n and int(r0[50]) == iters
     assert np.abs(single.reshape(4, 4).T - T_gt).max() < 5e-4
+
+
+def _graph_worker(rank, port, n, iters, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sp, S, Tg, _ = _make(n)
+    prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
+    p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters)
+    ident = torch.eye(4, dtype=torch.float32, device="cuda").reshape(-1).contiguous()
+    res = []
+    for use_graph in (False, True):
+        reg = sp.Registration(p)
+        T_dev = torch.zeros(16, dtype=torch.float32, device="cuda")
+        delta = torch.zeros(8, dtype=torch.float32, device="cuda")
+        for _ in range(4):  # eager, capture + replay, replay, replay
+            T_dev.copy_(ident)
+            reg.align_fused_loop(S, prep, iterations=iters, group=dist.group.WORLD, T_dev=T_dev, delta_dev=delta,
+                                 graph=use_graph)
+            torch.cuda.synchronize()
+            res.append(np.concatenate([T_dev.cpu().numpy(), [np.float32(reg._read_lin(reg._lin).inlier)]]))
+        live = [v for v in getattr(reg, "_loop_graphs", {}).values() if not isinstance(v, (str, bool))]
+        res.append(np.full(17, float(len(live)), np.float32))
+    np.save(out_path, np.stack(res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_loop_as_one_hipgraph_equals_per_call_launches(tmp_path):
+    """The sharded per-iteration loop (kernel, RCCL all-reduce of the partial rows, kernel, ...) captured once into a
+    hipGraph and replayed per alignment gives the same bits as issuing every launch and collective from the host."""
+    out = str(tmp_path / "graph.npy")
+    mp.spawn(_graph_worker, args=(_free_port(), 60000, 8, out), nprocs=1, join=True)
+    r = np.load(out)
+    eager, n_eager, graph, n_graph = r[0:4], r[4, 0], r[5:9], r[9, 0]
+    assert n_eager == 0 and n_graph == 1  # the graph path really replays a captured graph
+    for row in list(eager) + list(graph):
+        assert np.array_equal(row, eager[0])
+    assert int(eager[0][16]) == 60000
