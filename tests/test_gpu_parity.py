@@ -511,6 +511,62 @@ def test_gicp_config4_1m(sp, orc):
     assert np.allclose(H, ref["H"], atol=2e-5 * np.abs(ref["H"]).max()) and g2.inlier == ref["inlier"]
 
 
+def test_gicp_config5_8m_tiles(sp):
+    """BASELINE config 5 at full size on one GPU (8M vs 8M, R = 20): the one-call loop over the whole source converges to
+    the ground truth, and the linear system of the whole source equals the sum of its 8 tiles' systems (what the per-
+    iteration all-reduce adds up on an 8-GPU node) — size-independent properties, no oracle at this size."""
+    import ctypes as C
+
+    from sycl_points_amd.sharding import shard_range
+    from sycl_points_amd.synthetic import gicp_pair
+
+    n, world = 8000000, 8
+    src, tgt, T_gt = gicp_pair(n, 20.0)
+    Tg = sp.PointCloudShared(dev(tgt))
+    Tg.covs = sp.GridKNN.build(Tg.points, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
+    S_all = dev(src)
+    S_all = S_all[sp.GridKNN.build(S_all, points_per_cell=1.0).order()].contiguous()  # cell order, as bench.py stores it
+    covs = sp.GridKNN.build(S_all, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
+    S = sp.PointCloudShared(S_all, covs=covs)
+    grid = sp.GridKNN.build(Tg.points, points_per_cell=0.5)
+    prep = sp.PreparedTarget(grid, Tg.covs)
+    p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=20)
+    reg = sp.Registration(p)
+    T_dev, lin, delta = reg.align_fused_loop(S, prep, iterations=20, sort_by_cell="presorted")
+    T = reg.T_from_device(T_dev)
+    whole = reg._read_lin(lin)
+    assert whole.inlier == n
+    assert np.abs(T - T_gt).max() < 1e-4
+    assert np.abs(delta.cpu().numpy()[:6]).max() < 1e-5  # fixed point of the update
+
+    L = sp._lib.lib()
+
+    def system_of(cloud):
+        r = sp.Registration(p)
+        ws, ln = r._buffers(cloud.points.device)
+        ps = sp.PreparedSource(cloud.size())
+        ps.prepare(prep, cloud, T, sort_by_cell="presorted")
+        fp = r._factor_params(10.0)
+        Tc = np.ascontiguousarray(T.T).reshape(-1)
+        sp.check(L.sp_gicp_iteration_fused(prep._h, ps._h, Tc.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None, None, None,
+                                           sp._ptr(ln), None, sp._ptr(ws), ws.numel(), sp._stream()))
+        g = r._read_lin(ln)
+        return np.array(g.H, np.float64).reshape(6, 6), np.array(g.b, np.float64), float(g.error), int(g.inlier)
+
+    Hw, bw, ew, iw = system_of(S)
+    Hs, bs, es, is_ = np.zeros((6, 6)), np.zeros(6), 0.0, 0
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        tile = sp.PointCloudShared(S.points[lo:hi].contiguous(), covs=S.covs[lo:hi].contiguous())
+        H, b, e, i = system_of(tile)
+        Hs += H; bs += b; es += e; is_ += i
+    assert is_ == iw == n
+    assert np.abs(Hs - Hw).max() <= 2e-5 * np.abs(Hw).max()
+    assert abs(es - ew) <= 2e-5 * abs(ew)
+    # b is a sum of 8M signed terms that cancel at the optimum: compare against the scale of its terms, H's rows
+    assert np.abs(bs - bw).max() <= 2e-5 * np.abs(Hw).max() * 1e-2
+
+
 @pytest.mark.parametrize("radius", [1.0, 0.05, 0.004])
 def test_align_powell_dogleg_matches_oracle(sp, orc, gicp20k, radius):
     """optimize_powell_dogleg (registration.hpp:897-965): Gauss-Newton branch (large radius), dogleg / Cauchy branches and
