@@ -301,7 +301,7 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
                                       "note": "once per alignment (incl. a 64-byte pose copy): last iteration's partial "
                                               "sums + solve + outputs"}
         ms3 = timed(lambda: reg._psrc.prepare(prep, S, T_ident, sort_mode))
-        res["source_prepare"] = {"ms": ms3, "bytes": 112 * n, "GBps": 112 * n / (ms3 * 1e-3) / 1e9, "per_iteration": False,
+        res["source_prepare"] = {"ms": ms3, "bytes": 120 * n, "GBps": 120 * n / (ms3 * 1e-3) / 1e9, "per_iteration": False,
                                  "note": "once per alignment: " + ("" if sort_mode == "presorted" else "cell-order sort + ") +
                                          "gather + plane-regularised source covariances"}
     else:

@@ -643,16 +643,22 @@ __global__ __launch_bounds__(kBlock) void query_cell_kernel(const float4* __rest
 __global__ __launch_bounds__(kBlock) void prepare_source_kernel(const float4* __restrict__ pts,
                                                                 const float4* __restrict__ covs,
                                                                 const unsigned* __restrict__ order, unsigned n,
-                                                                float4* __restrict__ out_pts,
-                                                                float4* __restrict__ out_covp) {
+                                                                unsigned stride, float* __restrict__ out_pts,
+                                                                float* __restrict__ out_covp) {
+    // Output as planes (x | y | z and xx | xy | xz | yy | yz | zz, `stride` floats apart): the per-iteration kernel is
+    // bound by the bytes it streams, and the planes carry 36 bytes per point where float4 rows carry 48.
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned src = order[i];
     const float4 p = pts[src];
     const Mat3 P = plane_regularize(load_cov3(covs + 4 * (size_t)src));
-    out_pts[i] = p;
-    out_covp[2 * (size_t)i] = make_float4(P.m[0][0], (P.m[0][1] + P.m[1][0]) * 0.5f, (P.m[0][2] + P.m[2][0]) * 0.5f, P.m[1][1]);
-    out_covp[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], 0.0f, 0.0f);
+    out_pts[i] = p.x; out_pts[stride + i] = p.y; out_pts[2 * (size_t)stride + i] = p.z;
+    out_covp[i] = P.m[0][0];
+    out_covp[stride + i] = (P.m[0][1] + P.m[1][0]) * 0.5f;
+    out_covp[2 * (size_t)stride + i] = (P.m[0][2] + P.m[2][0]) * 0.5f;
+    out_covp[3 * (size_t)stride + i] = P.m[1][1];
+    out_covp[4 * (size_t)stride + i] = (P.m[1][2] + P.m[2][1]) * 0.5f;
+    out_covp[5 * (size_t)stride + i] = P.m[2][2];
 }
 __global__ __launch_bounds__(kBlock) void iota_kernel(unsigned* __restrict__ v, unsigned n) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
@@ -660,8 +666,9 @@ __global__ __launch_bounds__(kBlock) void iota_kernel(unsigned* __restrict__ v, 
 }
 
 struct FusedParams {
-    const float4* src;
-    const float4* scovp;
+    const float* src;      // prepared source: planes x | y | z, sstride floats apart
+    const float* scovp;    // prepared source covariances: planes xx | xy | xz | yy | yz | zz
+    unsigned sstride;
     const float4* tpts;    // grid-ordered target points
     const unsigned* tstart;
     const float4* tcovp;   // grid-ordered prepared target covariances
@@ -746,7 +753,7 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
 template <int LOSS, bool FAST_NN, int DBG>
 __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
                                             unsigned& cnt) {
-    const float4 s = P.src[i];
+    const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
     float qx, qy, qz;
     transform_point(T, s.x, s.y, s.z, qx, qy, qz);
     Nearest nn;
@@ -763,7 +770,7 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         // to its nearest other target point: any other target u then has |q - u| >= |t - u| - |q - t| > 2 rho_t - rho_t >
         // |q - t|. Each source point therefore keeps a copy of its last correspondence IN SOURCE ORDER (t with its index,
         // its packed covariance row carrying rho_t^2 with a 1e-3 margin against rounding, and its grid position): while
-        // correspondences hold, an iteration is a pure coalesced stream of 96 bytes per point (16 p + 32 Cs' + 48 copy)
+        // correspondences hold, an iteration is a pure coalesced stream of 84 bytes per point (12 p + 24 Cs' as planes + 48 copy)
         // with no search and no gather, and a wave whose lanes all pass never enters the search code.
         // (A second certificate with t's nearest neighbour's coordinates passes more queries but costs one more load per
         // point: measured slower.)
@@ -812,7 +819,9 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         P.nn_d2[o] = nn.d2;
     }
     if (nn.idx < 0 || nn.d2 > P.max_d2) return;
-    const Sym3 Cs = load_sym(P.scovp + 2 * (size_t)i);
+    const float* const cp = P.scovp + i;
+    const size_t st = P.sstride;
+    const Sym3 Cs{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
     if (!have_ct) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
     fused_math<LOSS>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
 }
@@ -1299,8 +1308,8 @@ extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     const size_t n = n_max ? n_max : 1;
     (void)rocprim::radix_sort_pairs<OnesweepSort>(nullptr, s->sort_tmp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
                                     (unsigned*)nullptr, n, 0, 32, (hipStream_t)0);
-    hipError_t e = hipMalloc(&s->pts, n * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc(&s->covp, n * 2 * sizeof(float4));
+    hipError_t e = hipMalloc(&s->pts, (n + 64) * sizeof(float4));  // planes, each padded to a multiple of 64 floats
+    if (e == hipSuccess) e = hipMalloc(&s->covp, (n + 64) * 2 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->perm, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->ccache, n * 3 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->keys_in, n * 4);
@@ -1360,7 +1369,8 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
     s->cache_target = target;
     s->cache_version = target->version;
     prepare_source_kernel<<<nb, kBlock, 0, st>>>(pts, reinterpret_cast<const float4*>(src_covs), s->perm, (unsigned)n,
-                                                 s->pts, s->covp);
+                                                 (unsigned)((n + 63) / 64 * 64), reinterpret_cast<float*>(s->pts),
+                                                 reinterpret_cast<float*>(s->covp));
     return launch_status();
 }
 
@@ -1370,8 +1380,9 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
                               const float* transT, int transT_on_device, int32_t* nn_idx_out, float* nn_d2_out) {
     const size_t n = source->n;
     FusedParams P;
-    P.src = source->pts;
-    P.scovp = source->covp;
+    P.src = reinterpret_cast<const float*>(source->pts);
+    P.scovp = reinterpret_cast<const float*>(source->covp);
+    P.sstride = (unsigned)((n + 63) / 64 * 64);
     P.tpts = target->grid->d_pts;
     P.tstart = target->grid->d_start;
     P.tcovp = target->covp;
