@@ -53,6 +53,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="sharded runs: issue every launch / collective from the host instead of replaying one "
                          "captured hipGraph per alignment")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's tile to run")
+    ap.add_argument("--shard-chunk", type=int, default=1024,
+                    help="N > 1: the (spatially ordered) source is dealt to the ranks in chunks of this many consecutive "
+                         "points, round-robin (every rank sees the same mix of converged and still-moving regions); 0: one "
+                         "contiguous tile per rank (a spatial slab)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: build the clouds of an N-rank run (N x --points, config 5 density) and time "
                          "rank 0's tile against the full target, without the collective")
@@ -81,7 +86,7 @@ def main():
 
     import sycl_points_amd.api as sp
     from sycl_points_amd import _lib
-    from sycl_points_amd.sharding import shard_range
+    from sycl_points_amd.sharding import shard_indices
     from sycl_points_amd.synthetic import gicp_pair
 
     n_gpu = args.points
@@ -95,7 +100,8 @@ def main():
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     Tg = sp.PointCloudShared(to_dev(tgt), device=dev)
     Tg.covs = sp.GridKNN.build(Tg.points, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
-    lo, hi = shard_range(n_total, rank, shards)
+    tile = torch.from_numpy(shard_indices(n_total, rank if shards == world else args.emulate_rank, shards,
+                                          args.shard_chunk)).to(dev)
     S_all = to_dev(src)
     if args.source_order == "grid":
         # The reference's pipeline hands align() a voxel-downsampled scan, i.e. a cloud sorted by voxel key
@@ -103,7 +109,7 @@ def main():
         # a grid built on itself here, in the untimed pre-processing next to its covariances; alignments then need no sort.
         S_all = S_all[sp.GridKNN.build(S_all, points_per_cell=1.0).order()].contiguous()
     covs_all = sp.GridKNN.build(S_all, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
-    S = sp.PointCloudShared(S_all[lo:hi].contiguous(), covs=covs_all[lo:hi].contiguous(), device=dev)
+    S = sp.PointCloudShared(S_all[tile].contiguous(), covs=covs_all[tile].contiguous(), device=dev)
     del S_all, covs_all
     n_local = S.size()
     grid = sp.GridKNN.build(Tg.points, points_per_cell=args.ppc) if (args.path == "fused" or args.nn == "grid") else None
@@ -200,7 +206,9 @@ def main():
                                              "safe radii); per alignment only the source is prepared",
                        "source_order": ("cell order of a grid on the source (set-up), no per-alignment sort"
                                         if args.source_order == "grid" else "random; sorted by target cell in every alignment"),
-                       "sharding": "source tile-sharded, target replicated" if world > 1 else "none",
+                       "sharding": ((f"source dealt to the ranks in chunks of {args.shard_chunk} consecutive points"
+                                     if args.shard_chunk > 0 else "source in contiguous tiles") +
+                                    ", target replicated" if shards > 1 else "none"),
                        "launch": ("one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
                                   else ("per-iteration launches + all-reduce from the host" if group is not None
                                         else "one C call per alignment"))},

@@ -13,6 +13,22 @@ def shard_range(n_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_indices(n_total, rank, world, chunk=1024):
+    """Source indices of `rank`: chunks of `chunk` consecutive points of the (spatially ordered) source, dealt round-robin.
+
+    Contiguous tiles (shard_range) of a spatially ordered source are slabs of space: the slabs far from the rotation
+    centre keep searching for more iterations, and every all-reduce waits for the slowest rank. Dealing out chunks gives
+    every rank a uniform sample of the whole cloud — the same mix of converged and still-moving regions in every
+    iteration — while the points inside a chunk (a whole workgroup's worth) stay neighbours, which the search needs.
+    chunk <= 0 or >= n_total / world: the contiguous tile."""
+    if chunk <= 0 or chunk * world >= n_total:
+        lo, hi = shard_range(n_total, rank, world)
+        return np.arange(lo, hi, dtype=np.int64)
+    starts = np.arange(rank * chunk, n_total, world * chunk, dtype=np.int64)
+    idx = (starts[:, None] + np.arange(chunk, dtype=np.int64)[None, :]).reshape(-1)
+    return idx[idx < n_total]
+
+
 def split_count(count):
     """Inlier count as two floats that stay exact under a float sum over ranks (count = hi * 4096 + lo)."""
     return float(count & 4095), float(count >> 12)

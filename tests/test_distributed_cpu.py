@@ -15,6 +15,25 @@ import torch.multiprocessing as mp
 from sycl_points_amd import sharding
 
 
+def test_shard_indices_partition_the_source():
+    """Chunks of consecutive points dealt round-robin: every index exactly once, sizes within one chunk of each other,
+    chunks kept whole; chunk 0 (or too large for the cloud) is the contiguous tile."""
+    for n, w, c in ((8000000, 8, 1024), (1000003, 4, 1024), (70000, 8, 64), (1000, 3, 7), (5, 2, 1024), (100, 4, 0)):
+        parts = [sharding.shard_indices(n, r, w, c) for r in range(w)]
+        allidx = np.concatenate(parts)
+        assert len(allidx) == n and np.array_equal(np.sort(allidx), np.arange(n))
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= max(c, 1)
+        if 0 < c and c * w < n:
+            p0 = parts[1]
+            assert np.array_equal(p0[:c], np.arange(c, 2 * c))          # rank 1 starts with the second chunk
+            assert p0[c] == (w + 1) * c                                  # and continues one round later
+        else:
+            for r in range(w):
+                lo, hi = sharding.shard_range(n, r, w)
+                assert np.array_equal(parts[r], np.arange(lo, hi))
+
+
 def test_shard_ranges_cover_exactly():
     for n, w in ((10, 3), (1_000_000, 8), (7, 8), (0, 2), (8_000_001, 8)):
         r = [sharding.shard_range(n, k, w) for k in range(w)]
