@@ -436,6 +436,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
                                                                    const unsigned* __restrict__ start,
                                                                    const unsigned* __restrict__ unit_off, GridDesc g,
                                                                    int k, TileOut out) {
+    __shared__ float sm_terms[9][33];  // covariance terms of the k <= 20 neighbours (row stride 33: conflict-free columns)
     const unsigned unit = blockIdx.x;
     const unsigned rows = (unsigned)g.ny * g.nz;
     unsigned lo = 0, hi = rows;
@@ -599,14 +600,27 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
         }
         if (out.covs || out.normals) {
             const float4 np = pts[have ? best.pos : 0];
-            float sx = 0.0f, sy = 0.0f, sz = 0.0f, oxx = 0.0f, oxy = 0.0f, oxz = 0.0f, oyy = 0.0f, oyz = 0.0f, ozz = 0.0f;
             const unsigned cnt = (unsigned)__builtin_popcountll(__ballot(have));
-            for (unsigned t = 0; t < cnt; ++t) {  // ascending order, as covariance::kernel::estimate sums (all lanes redundantly)
-                const float x = bcast_f(np.x, (int)t), y = bcast_f(np.y, (int)t), z = bcast_f(np.z, (int)t);
-                sx += x; sy += y; sz += z;
-                oxx += x * x; oxy += x * y; oxz += x * z;
-                oyy += y * y; oyz += y * z; ozz += z * z;
+            // The nine sums of covariance::kernel::estimate, each in ascending neighbour order (its order): lane t < cnt
+            // forms the nine terms of its own neighbour once and parks them in LDS, then lane r < 9 adds up quantity r
+            // over t = 0 .. cnt-1 — 20 additions on nine lanes in parallel instead of 9 x 20 on every lane.
+            __syncthreads();  // (one wave per workgroup) the previous query's sums have been read
+            if (have) {
+                sm_terms[0][lane] = np.x; sm_terms[1][lane] = np.y; sm_terms[2][lane] = np.z;
+                sm_terms[3][lane] = np.x * np.x; sm_terms[4][lane] = np.x * np.y; sm_terms[5][lane] = np.x * np.z;
+                sm_terms[6][lane] = np.y * np.y; sm_terms[7][lane] = np.y * np.z; sm_terms[8][lane] = np.z * np.z;
             }
+            __syncthreads();
+            float acc9 = 0.0f;
+            {
+                const float* const col = sm_terms[lane < 9 ? lane : 0];
+#pragma unroll
+                for (int t = 0; t < 20; ++t)
+                    if ((unsigned)t < cnt) acc9 += col[t];  // cnt is wave-uniform: a scalar branch
+            }
+            const float sx = bcast_f(acc9, 0), sy = bcast_f(acc9, 1), sz = bcast_f(acc9, 2), oxx = bcast_f(acc9, 3),
+                        oxy = bcast_f(acc9, 4), oxz = bcast_f(acc9, 5), oyy = bcast_f(acc9, 6), oyz = bcast_f(acc9, 7),
+                        ozz = bcast_f(acc9, 8);
             Mat3 C;
             if (cnt < 4) {
                 C.m[0][0] = C.m[1][1] = C.m[2][2] = 1.0f;
