@@ -399,17 +399,30 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_tile_kernel(const float4*
 //     the same nine segments out of L1/L2;
 //   * results are ordered by (distance, original index): bit-identical to brute force; the covariance (optional) is
 //     accumulated over the list in ascending order exactly as covariance::kernel::estimate does.
+// A candidate is ordered by (squared distance, index): for non-negative floats the bit pattern orders like the value, so
+// the pair packs into one 64-bit key and "nearer, ties to the lower index" is a single unsigned compare.
 struct Cand {
-    float d;
-    int idx, pos;
+    unsigned long long key;  // (float bits of d2) << 32 | index
+    int pos;                 // position in grid order
 };
-__device__ __forceinline__ bool cand_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ unsigned long long cand_key(float d, int idx) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)idx;
+}
+__device__ __forceinline__ float key_d2(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(unsigned)k; }
+constexpr unsigned long long kNoCand = ((unsigned long long)0x7f7fffffu << 32) | 0x7fffffffu;  // (FLT_MAX, INT_MAX)
 // Broadcast from a wave-uniform lane: v_readlane_b32 (VALU -> SGPR), not the LDS crossbar a generic __shfl uses.
 __device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float bcast_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ unsigned long long bcast_k(unsigned long long v, int lane) {
+    return ((unsigned long long)(unsigned)bcast_i((int)(v >> 32), lane) << 32) | (unsigned)bcast_i((int)(unsigned)v, lane);
+}
 // Lane i receives lane i-1's value (lane 0 keeps its own): one DPP move, wave_shr:1 (gfx9 DPP control 0x138).
 __device__ __forceinline__ int shift_up1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ float shift_up1_f(float v) { return __int_as_float(shift_up1_i(__float_as_int(v))); }
+__device__ __forceinline__ unsigned long long shift_up1_k(unsigned long long v) {
+    return ((unsigned long long)(unsigned)shift_up1_i((int)(v >> 32)) << 32) | (unsigned)shift_up1_i((int)(unsigned)v);
+}
 
 __device__ __forceinline__ Cand bitonic_sort64(Cand v, unsigned lane) {
 #pragma unroll
@@ -417,19 +430,37 @@ __device__ __forceinline__ Cand bitonic_sort64(Cand v, unsigned lane) {
 #pragma unroll
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             Cand o;
-            o.d = __shfl_xor(v.d, stride, 64);
-            o.idx = __shfl_xor(v.idx, stride, 64);
+            o.key = ((unsigned long long)(unsigned)__shfl_xor((int)(v.key >> 32), stride, 64) << 32) |
+                    (unsigned)__shfl_xor((int)(unsigned)v.key, stride, 64);
             o.pos = __shfl_xor(v.pos, stride, 64);
-            const bool up = ((lane & size) == 0);          // ascending block?
-            const bool lower = ((lane & stride) == 0);     // this lane keeps the smaller of the pair in an ascending block
-            const bool o_less = cand_less(o.d, o.idx, v.d, v.idx);
-            const bool take = (lower == up) ? o_less : !o_less && !(o.d == v.d && o.idx == v.idx);
-            v.d = take ? o.d : v.d;
-            v.idx = take ? o.idx : v.idx;
+            const bool up = ((lane & size) == 0);       // ascending block?
+            const bool lower = ((lane & stride) == 0);  // this lane keeps the smaller of the pair in an ascending block
+            const bool take = (lower == up) ? (o.key < v.key) : (o.key > v.key);
+            v.key = take ? o.key : v.key;
             v.pos = take ? o.pos : v.pos;
         }
     }
     return v;
+}
+
+// One chunk of candidates (one per lane) against the sorted top-k in `best` (lane i = i-th best): every candidate nearer
+// than the current k-th is inserted at its rank, the entries behind it move up by one lane.
+__device__ __forceinline__ void insert_candidates(const Cand& c, Cand& best, unsigned long long& kth, int k,
+                                                  unsigned long long kmask, unsigned lane) {
+    unsigned long long m = __ballot(c.key < kth);
+    while (m) {
+        const int L = __builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned long long vk = bcast_k(c.key, L);
+        if (!(vk < kth)) continue;  // the k-th entry moved since the ballot
+        const int vp = bcast_i(c.pos, L);
+        const int rank = __builtin_popcountll(__ballot(best.key < vk) & kmask);  // entries that stay in front of the newcomer
+        const unsigned long long uk = shift_up1_k(best.key);
+        const int up = shift_up1_i(best.pos);
+        if ((int)lane == rank) { best.key = vk; best.pos = vp; }
+        else if ((int)lane > rank) { best.key = uk; best.pos = up; }
+        kth = bcast_k(best.key, k - 1);
+    }
 }
 
 __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4* __restrict__ pts,
@@ -488,9 +519,8 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
         }
         const unsigned total = seg_c[9];
         Cand best;  // lane i holds the i-th best
-        best.d = FLT_MAX; best.idx = 0x7fffffff; best.pos = -1;
-        float kth = FLT_MAX;
-        int kth_idx = 0x7fffffff;
+        best.key = kNoCand; best.pos = -1;
+        unsigned long long kth = kNoCand;  // key of the current k-th best (wave-uniform)
         auto fetch = [&](unsigned base, float4& p, unsigned& pos, bool& valid) {
             const unsigned f = base + lane;
             valid = f < total;
@@ -510,30 +540,13 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
             const bool valid = valid_next;
             if (base + 64 < total) fetch(base + 64, p_next, pos_next, valid_next);  // in flight while this chunk is merged
             Cand c;
-            c.d = valid ? dist2(qx, qy, qz, p.x, p.y, p.z) : FLT_MAX;
-            c.idx = valid ? __float_as_int(p.w) : 0x7fffffff;
+            c.key = valid ? cand_key(dist2(qx, qy, qz, p.x, p.y, p.z), __float_as_int(p.w)) : kNoCand;
             c.pos = (int)pos;
             if (base == 0) {
                 best = bitonic_sort64(c, lane);
-                kth = bcast_f(best.d, k - 1);
-                kth_idx = bcast_i(best.idx, k - 1);
+                kth = bcast_k(best.key, k - 1);
             } else {
-                unsigned long long m = __ballot(cand_less(c.d, c.idx, kth, kth_idx));
-                while (m) {
-                    const int L = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float vd = bcast_f(c.d, L);
-                    const int vi = bcast_i(c.idx, L), vp = bcast_i(c.pos, L);
-                    if (!cand_less(vd, vi, kth, kth_idx)) continue;  // the k-th entry moved since the ballot
-                    const unsigned long long before = __ballot(cand_less(best.d, best.idx, vd, vi)) & kmask;
-                    const int rank = __builtin_popcountll(before);  // entries that stay in front of the newcomer
-                    const float ud = shift_up1_f(best.d);
-                    const int ui = shift_up1_i(best.idx), up = shift_up1_i(best.pos);
-                    if ((int)lane == rank) { best.d = vd; best.idx = vi; best.pos = vp; }
-                    else if ((int)lane > rank) { best.d = ud; best.idx = ui; best.pos = up; }
-                    kth = bcast_f(best.d, k - 1);
-                    kth_idx = bcast_i(best.idx, k - 1);
-                }
+                insert_candidates(c, best, kth, k, kmask, lane);
             }
         }
         // Exactness: is the k-th neighbour inside the scanned block? If not (sparse neighbourhoods), keep adding rings
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
             if (cz + R < g.nz - 1) cov = fminf(cov, (g.oz + (cz + R + 1) * g.h) - qz);
             if (cov == FLT_MAX) break;  // the block is the whole grid
             cov = fmaxf(cov - g.eps, 0.0f);
-            if (kth < cov * cov) break;  // proven exact (strict: an unseen point at exactly kth could win a tie)
+            if (key_d2(kth) < cov * cov) break;  // proven exact (strict: an unseen point at exactly kth could win a tie)
             const int Rn = R + 1;        // add the shell at Chebyshev distance Rn
             const int z0 = max(cz - Rn, 0), z1 = min(cz + Rn, g.nz - 1), y0 = max(cy - Rn, 0), y1 = min(cy + Rn, g.ny - 1);
             const int x0 = max(cx - Rn, 0), x1 = min(cx + Rn, g.nx - 1);
@@ -569,34 +582,18 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
                             const bool valid = pos < e0;
                             const float4 p = pts[valid ? pos : e0 - 1];
                             Cand c;
-                            c.d = valid ? dist2(qx, qy, qz, p.x, p.y, p.z) : FLT_MAX;
-                            c.idx = valid ? __float_as_int(p.w) : 0x7fffffff;
+                            c.key = valid ? cand_key(dist2(qx, qy, qz, p.x, p.y, p.z), __float_as_int(p.w)) : kNoCand;
                             c.pos = (int)pos;
-                            unsigned long long m = __ballot(cand_less(c.d, c.idx, kth, kth_idx));
-                            while (m) {
-                                const int L = __builtin_ctzll(m);
-                                m &= m - 1;
-                                const float vd = bcast_f(c.d, L);
-                                const int vi = bcast_i(c.idx, L), vp = bcast_i(c.pos, L);
-                                if (!cand_less(vd, vi, kth, kth_idx)) continue;
-                                const unsigned long long before = __ballot(cand_less(best.d, best.idx, vd, vi)) & kmask;
-                                const int rank = __builtin_popcountll(before);
-                                const float ud = shift_up1_f(best.d);
-                                const int ui = shift_up1_i(best.idx), up = shift_up1_i(best.pos);
-                                if ((int)lane == rank) { best.d = vd; best.idx = vi; best.pos = vp; }
-                                else if ((int)lane > rank) { best.d = ud; best.idx = ui; best.pos = up; }
-                                kth = bcast_f(best.d, k - 1);
-                                kth_idx = bcast_i(best.idx, k - 1);
-                            }
+                            insert_candidates(c, best, kth, k, kmask, lane);
                         }
                     }
                 }
         }
-        const bool have = (int)lane < k && best.d != FLT_MAX;
+        const bool have = (int)lane < k && key_d2(best.key) != FLT_MAX;
         if (out.knn_idx && (int)lane < k) {
             const size_t o = (size_t)qorig * (size_t)k + lane;
-            out.knn_idx[o] = have ? best.idx : -1;
-            out.knn_d2[o] = best.d;
+            out.knn_idx[o] = have ? key_idx(best.key) : -1;
+            out.knn_d2[o] = key_d2(best.key);
         }
         if (out.covs || out.normals) {
             const float4 np = pts[have ? best.pos : 0];
