@@ -107,3 +107,10 @@ def test_synthetic_generator_is_the_reference_idiom(orc):
     src, tgt, T = gicp_pair(2000, 1.26)
     back = src[:, :3].astype(np.float64) @ T[:3, :3].T.astype(np.float64) + T[:3, 3]
     assert np.abs(back - tgt[:, :3]).max() < 0.05 and np.abs(back - tgt[:, :3]).std() < 0.01
+
+
+def test_build_entry_point_runs():
+    """__graft_entry__.build() (the driver's does-it-build check): compiles what is stale, loads the library, checks the ABI."""
+    import __graft_entry__ as g
+
+    g.build()
