@@ -1,5 +1,7 @@
 // C-ABI housekeeping: error message slot, device selection, host twins of the solver arithmetic.
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "sp_common.h"
 #include "sp_math.h"
@@ -9,6 +11,56 @@ thread_local std::string g_last_error;
 }
 
 void sp_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+
+namespace sp {
+namespace {
+struct PoolEntry { void* p; size_t bytes; int device; bool busy; };
+std::mutex g_pool_mutex;
+std::vector<PoolEntry> g_pool;
+constexpr size_t kKeep = 24;
+}  // namespace
+
+hipError_t scratch_acquire(void** ptr, size_t bytes) {
+    *ptr = nullptr;
+    if (bytes < 256) bytes = 256;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        PoolEntry* best = nullptr;
+        for (auto& e : g_pool)  // best fit among the idle buffers of this device, not more than 4x oversized
+            if (!e.busy && e.device == dev && e.bytes >= bytes && e.bytes <= 4 * bytes && (!best || e.bytes < best->bytes)) best = &e;
+        if (best) { best->busy = true; *ptr = best->p; return hipSuccess; }
+    }
+    void* p = nullptr;
+    const hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess) return err;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool.push_back(PoolEntry{p, bytes, dev, true});
+    *ptr = p;
+    return hipSuccess;
+}
+
+void scratch_release(void* ptr) {
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t idle = 0;
+        for (auto& e : g_pool) {
+            if (e.p == ptr) e.busy = false;
+            idle += e.busy ? 0 : 1;
+        }
+        if (idle > kKeep) {  // drop the smallest idle buffer
+            size_t k = g_pool.size();
+            for (size_t i = 0; i < g_pool.size(); ++i)
+                if (!g_pool[i].busy && (k == g_pool.size() || g_pool[i].bytes < g_pool[k].bytes)) k = i;
+            drop = g_pool[k].p;
+            g_pool.erase(g_pool.begin() + (long)k);
+        }
+    }
+    if (drop) (void)hipFree(drop);
+}
+}  // namespace sp
 
 extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
 extern "C" const char* sp_last_error(void) { return g_last_error.c_str(); }

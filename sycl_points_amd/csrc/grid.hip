@@ -846,6 +846,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     g->n = n;
     auto fail = [&](hipError_t e) {
         sp_set_error(hipGetErrorString(e));
+        (void)hipStreamSynchronize(st);  // nothing of this build may still be running when its scratch goes back to the pool
         sp_grid_destroy(g);
         return SP_ERR_HIP;
     };
@@ -858,8 +859,9 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     }
     const float4* pts = reinterpret_cast<const float4*>(points);
     // 1. bounding box of the finite points
-    unsigned* d_bbox = nullptr;
-    if ((e = hipMalloc(&d_bbox, 6 * sizeof(unsigned))) != hipSuccess) return fail(e);
+    ScratchBuf bbox_buf;
+    if ((e = bbox_buf.get(6 * sizeof(unsigned))) != hipSuccess) return fail(e);
+    unsigned* const d_bbox = bbox_buf.as<unsigned>();
     const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     unsigned h_bbox[6];
     e = hipMemcpyAsync(d_bbox, init, sizeof init, hipMemcpyHostToDevice, st);
@@ -868,7 +870,6 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
         e = hipMemcpyAsync(h_bbox, d_bbox, sizeof h_bbox, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_bbox);
     if (e != hipSuccess) return fail(e);
     float mn[3], mx[3];
     bool any = h_bbox[0] != 0xffffffffu;
@@ -910,20 +911,34 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     g->eps = 4.0e-6f * (scale + ext_max + h);  // bounds the float rounding of (p - org) * inv_h cell assignment
     for (int a = 0; a < 3; ++a) g->org[a] = mn[a];
 
-    // 3. sort points by cell id, gather, cell_start
+    // 3. sort points by cell id, gather, cell_start (temporaries from the scratch pool: idle again when this returns)
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;
-    void* tmp = nullptr;
+    ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp, b_units, b_stmp;
     size_t tmp_bytes = 0;
     unsigned end_bit = 1;
     while ((1ull << end_bit) <= g->ncells && end_bit < 32) ++end_bit;
     (void)rocprim::radix_sort_pairs<OnesweepSort>(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
-    e = hipMalloc(&keys_in, n * 4);
-    if (e == hipSuccess) e = hipMalloc(&keys_out, n * 4);
-    if (e == hipSuccess) e = hipMalloc(&vals_in, n * 4);
-    if (e == hipSuccess) e = hipMalloc(&vals_out, n * 4);
-    if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+    e = b_kin.get(n * 4);
+    if (e == hipSuccess) e = b_kout.get(n * 4);
+    if (e == hipSuccess) e = b_vin.get(n * 4);
+    if (e == hipSuccess) e = b_vout.get(n * 4);
+    if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(tmp_bytes, 16));
     if (e == hipSuccess) e = hipMalloc(&g->d_pts, n * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t));
+    keys_in = b_kin.as<unsigned>(); keys_out = b_kout.as<unsigned>(); vals_in = b_vin.as<unsigned>(); vals_out = b_vout.as<unsigned>();
+    void* const tmp = b_tmp.p;
+    const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
+    unsigned* units = nullptr;
+    void* stmp = nullptr;
+    size_t stmp_bytes = 0;
+    if (e == hipSuccess) {
+        (void)rocprim::exclusive_scan(nullptr, stmp_bytes, units, units, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+        e = b_units.get((rows + 1) * 4);
+        if (e == hipSuccess) e = hipMalloc(&g->d_unit_off, (rows + 1) * 4);
+        if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
+        units = b_units.as<unsigned>();
+        stmp = b_stmp.p;
+    }
     if (e == hipSuccess) {
         GridDesc gd{g->inv_h, g->h, g->eps, g->org[0], g->org[1], g->org[2], g->dims[0], g->dims[1], g->dims[2],
                     (unsigned)n};
@@ -934,27 +949,15 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
         gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
         cell_start_kernel<<<div_up(g->ncells + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
                                                                           g->d_start);
-        e = hipStreamSynchronize(st);
+        // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed (same stream: no sync between)
+        e = hipMemsetAsync(units, 0, (rows + 1) * 4, st);
     }
-    if (e == hipSuccess) {  // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed
-        const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
-        unsigned* units = nullptr;
-        void* stmp = nullptr;
-        size_t stmp_bytes = 0;
-        (void)rocprim::exclusive_scan(nullptr, stmp_bytes, units, units, 0u, rows + 1, rocprim::plus<unsigned>(), st);
-        e = hipMalloc(&units, (rows + 1) * 4);
-        if (e == hipSuccess) e = hipMalloc(&g->d_unit_off, (rows + 1) * 4);
-        if (e == hipSuccess) e = hipMalloc(&stmp, std::max<size_t>(stmp_bytes, 16));
-        if (e == hipSuccess) e = hipMemsetAsync(units, 0, (rows + 1) * 4, st);
-        if (e == hipSuccess) {
-            row_units_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
-            e = rocprim::exclusive_scan(stmp, stmp_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(units); (void)hipFree(stmp);
+    if (e == hipSuccess) {
+        row_units_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
+        e = rocprim::exclusive_scan(stmp, stmp_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
     }
-    (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(tmp);
+    if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the temporaries are idle from here on
     if (e != hipSuccess) return fail(e);
     *out = g;
     return SP_OK;
