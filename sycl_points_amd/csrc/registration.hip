@@ -1259,27 +1259,27 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
     }
     if (n) {
         // certificates of the correspondence reuse: one k = 3 self-search on the grid, once per target
+        // (temporaries from the library's scratch pool: idle again after the synchronisation below)
         hipStream_t st = as_stream(stream);
-        int32_t* idx3 = nullptr;
-        float* d23 = nullptr;
-        unsigned* inv = nullptr;
-        void* ws = nullptr;
+        ScratchBuf b_idx3, b_d23, b_inv, b_ws;
         const size_t ws_bytes = sp_grid_self_workspace_bytes(grid);
         hipError_t e = hipMalloc(&t->rho2, n * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&t->nb, n * sizeof(float4));
-        if (e == hipSuccess) e = hipMalloc(&idx3, n * 3 * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&d23, n * 3 * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&inv, n * sizeof(unsigned));
-        if (e == hipSuccess && ws_bytes) e = hipMalloc(&ws, ws_bytes);
+        if (e == hipSuccess) e = b_idx3.get(n * 3 * sizeof(int32_t));
+        if (e == hipSuccess) e = b_d23.get(n * 3 * sizeof(float));
+        if (e == hipSuccess) e = b_inv.get(n * sizeof(unsigned));
+        if (e == hipSuccess && ws_bytes) e = b_ws.get(ws_bytes);
+        int32_t* const idx3 = b_idx3.as<int32_t>();
+        float* const d23 = b_d23.as<float>();
+        unsigned* const inv = b_inv.as<unsigned>();
         int rc2 = e == hipSuccess ? SP_OK : SP_ERR_HIP;
-        if (rc2 == SP_OK) rc2 = sp_grid_self_knn(grid, 3, idx3, d23, nullptr, nullptr, ws, ws_bytes, stream);
+        if (rc2 == SP_OK) rc2 = sp_grid_self_knn(grid, 3, idx3, d23, nullptr, nullptr, b_ws.p, ws_bytes, stream);
         if (rc2 == SP_OK) {
             inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
             certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb);
             rc2 = launch_status();
         }
-        if (rc2 == SP_OK && hipStreamSynchronize(st) != hipSuccess) rc2 = SP_ERR_HIP;
-        (void)hipFree(idx3); (void)hipFree(d23); (void)hipFree(inv); (void)hipFree(ws);
+        if (hipStreamSynchronize(st) != hipSuccess && rc2 == SP_OK) rc2 = SP_ERR_HIP;
         if (rc2 != SP_OK) {
             if (e != hipSuccess) sp_set_error(hipGetErrorString(e));
             sp_gicp_target_destroy(t);
