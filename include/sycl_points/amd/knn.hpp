@@ -202,6 +202,20 @@ public:
         return sycl_utils::events(queue.stream());
     }
 
+    /// The grid's counterpart of KDTree::radius_search_async (kdtree.hpp:251-280): the max_k nearest within `radius`.
+    sycl_utils::events radius_search_async(const PointCloudShared& queries, const size_t max_k, const float radius,
+                                           KNNResult& result, const std::vector<sycl_utils::event>& = {},
+                                           const TransformMatrix& transT = TransformMatrix::Identity()) const {
+        const size_t nq = queries.size();
+        if (max_k > 20) throw std::runtime_error("[GridKNN::radius_search_async] `max_k` is too large (max 20).");
+        detail::prepare_result(queue, result, (nq && max_k) ? nq : 0, (nq && max_k) ? max_k : 0);
+        if (nq == 0 || max_k == 0) return sycl_utils::events();
+        throw_on_error(sp_grid_radius_search(grid_, queries.points_device(), nq, max_k, radius, transT.data(), 0,
+                                             result.indices->device_data_for_write(nq * max_k),
+                                             result.distances->device_data_for_write(nq * max_k), queue.stream()));
+        return sycl_utils::events(queue.stream());
+    }
+
 private:
     sp_grid* grid_ = nullptr;
     uint64_t id_ = 0;

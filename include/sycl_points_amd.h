@@ -90,6 +90,11 @@ float sp_grid_cell_size(const sp_grid* grid);
 int sp_grid_order(const sp_grid* grid, uint32_t* idx_out, void* stream);
 int sp_grid_search(const sp_grid* grid, const float* queries, size_t nq, size_t k, const float* transT,
                    int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
+/* The grid's counterpart of KDTree::radius_search_async (knn/kdtree.hpp:251-280, 574-719): the max_k nearest target
+ * points within `radius` of transT*q, ascending, padded with -1 / FLT_MAX; max_k <= 20 (SP_ERR_RUNTIME otherwise).
+ * Bit-identical to sp_kdtree_radius_search on tie-free data. */
+int sp_grid_radius_search(const sp_grid* grid, const float* queries, size_t nq, size_t max_k, float radius,
+                          const float* transT, int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
 
 /* Self-kNN of the cloud a grid was built on, with the covariance / normal estimation optionally fused in
  * (covariance::estimate_async(knn, points, k), feature/covariance.hpp:305-311, and estimate_normals_async(knn, ...),

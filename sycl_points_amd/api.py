@@ -294,6 +294,24 @@ class GridKNN(KNNBase):
         check(_lib.lib().sp_grid_search(self._h, _ptr(q), q.shape[0], k, tp, on_dev, _ptr(result.indices),
                                         _ptr(result.distances), _stream()))
 
+    def radius_search_async(self, queries, max_k, radius, result, transT=None):
+        """The grid's counterpart of KDTree::radius_search_async (kdtree.hpp:251-280): the max_k nearest within radius."""
+        q = _dev_f32(_points_of(queries), 4)
+        if max_k > 20:
+            raise SpError(2, "[GridKNN::radius_search_async] `max_k` is too large (max 20).")
+        if q.shape[0] == 0 or max_k == 0:
+            result.resize(0, 0, q.device)
+            return
+        result.resize(q.shape[0], max_k, q.device)
+        tp, on_dev, keep = _trans_arg(transT)
+        check(_lib.lib().sp_grid_radius_search(self._h, _ptr(q), q.shape[0], max_k, radius, tp, on_dev,
+                                               _ptr(result.indices), _ptr(result.distances), _stream()))
+
+    def radius_search(self, queries, max_k, radius, transT=None):
+        result = KNNResult()
+        self.radius_search_async(queries, max_k, radius, result, transT)
+        return result
+
 
 class BruteForceKNN(KNNBase):
     """A KNNBase over knn_search_bruteforce (the reference tests inject such host fakes through the same seam,

@@ -785,6 +785,15 @@ int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
     return launch_status();
 }
 
+// Radius search = the k nearest within the radius (knn/kdtree.hpp:574-719: a candidate enters when d <= radius^2 and
+// beats the k-th best): rows are ascending, so the entries beyond the radius are a suffix, turned into padding here.
+__global__ __launch_bounds__(kBlock) void radius_filter_kernel(int32_t* __restrict__ idx, float* __restrict__ d2, size_t total,
+                                                               float radius_sq) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    if (d2[i] > radius_sq) { idx[i] = -1; d2[i] = FLT_MAX; }
+}
+
 __global__ __launch_bounds__(kBlock) void grid_search_k1_kernel(const float4* __restrict__ pts,
                                                                 const unsigned* __restrict__ start, GridDesc g,
                                                                 const float4* __restrict__ queries, unsigned nq,
@@ -1034,4 +1043,20 @@ extern "C" int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out,
 }
 
 // Tuning hook, not part of the stable surface.
+extern "C" int sp_grid_radius_search(const sp_grid* grid, const float* queries, size_t nq, size_t max_k, float radius,
+                                     const float* transT, int transT_on_device, int32_t* idx_out, float* d2_out,
+                                     void* stream) {
+    using namespace sp;
+    if (max_k == 0 || nq == 0) return SP_OK;
+    if (max_k > 20) {
+        sp_set_error("[GridKNN::radius_search_async] `max_k` is too large (max 20).");
+        return SP_ERR_RUNTIME;
+    }
+    const int rc = sp_grid_search(grid, queries, nq, max_k, transT, transT_on_device, idx_out, d2_out, stream);
+    if (rc != SP_OK) return rc;
+    const size_t total = nq * max_k;
+    radius_filter_kernel<<<div_up(total, kBlock), kBlock, 0, as_stream(stream)>>>(idx_out, d2_out, total, radius * radius);
+    return launch_status();
+}
+
 extern "C" void sp_debug_set_self_knn_mode(int mode) { g_self_knn_mode = mode; }

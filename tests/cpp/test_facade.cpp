@@ -85,6 +85,18 @@ static void kdtree_grid_vs_bruteforce() {  // test_kdtree.cpp:301-317, 392-408
                    (*gr.indices)[i] == (*bf.indices)[i] && (*gr.distances)[i] == (*bf.distances)[i];
         CHECK(same);
     }
+    {   // radius search: the grid against the KD-tree kernel (kdtree.hpp:574-719)
+        alg::knn::KNNResult rk, rg;
+        tree->radius_search_async(query, 10, 3.0f, rk).wait_and_throw();
+        grid->radius_search_async(query, 10, 3.0f, rg).wait_and_throw();
+        bool same = rk.indices->size() == rg.indices->size();
+        size_t cut = 0;
+        for (size_t i = 0; same && i < rk.indices->size(); ++i) {
+            same = (*rk.indices)[i] == (*rg.indices)[i] && (*rk.distances)[i] == (*rg.distances)[i];
+            cut += (*rg.indices)[i] < 0;
+        }
+        CHECK(same && cut > 0);
+    }
     // SinglePoint (test_kdtree.cpp:358-389)
     PointCloudCPU one, q1;
     one.points->push_back(PointType(0, 0, 0, 1));

@@ -178,6 +178,26 @@ def test_kdtree_radius_and_remove_by_flags(sp, orc):
     assert np.array_equal(od, bd)
 
 
+def test_grid_radius_search_matches_kdtree_oracle(sp, orc):
+    """GridKNN::radius_search_async: the max_k nearest within the radius, bit-identical to the reference's KD-tree radius
+    search (kdtree.hpp:574-719) as the oracle restates it — with a query transform, radii that cut rows short, none or all."""
+    g = orc.rng(4321)
+    tgt = g.uniform_points(5000, 5.0)
+    qry = g.uniform_points(400, 5.5)
+    T = orc.se3_exp([0.03, -0.02, 0.01, 0.1, -0.05, 0.02])
+    grid = sp.GridKNN.build(dev(tgt))
+    nodes = orc.kdtree_build(tgt)
+    for max_k, radius in ((10, 0.8), (20, 0.5), (5, 0.05), (3, 100.0), (1, 0.3)):
+        res = grid.radius_search(dev(qry), max_k, radius, transT=T)
+        oi, od = orc.kdtree_radius(nodes, orc.transform_points(qry, T), max_k, radius)
+        assert np.array_equal(res.indices.cpu().numpy(), oi), (max_k, radius)
+        assert np.array_equal(res.distances.cpu().numpy(), od), (max_k, radius)
+    assert (grid.radius_search(dev(qry), 5, 0.05).indices.cpu().numpy() == -1).mean() > 0.5  # most rows are cut short
+    with pytest.raises(sp.SpError):
+        grid.radius_search(dev(qry), 21, 1.0)
+    assert grid.radius_search(dev(qry[:0]), 5, 1.0).indices.numel() == 0
+
+
 def test_kdtree_1m_k1_sampled(sp, orc):
     # full-size NN (1M targets): oracle KD-tree on a sample of queries + exactness property vs brute force on a sample
     g = orc.rng(1234)
