@@ -216,6 +216,16 @@ public:
         return sycl_utils::events(queue.stream());
     }
 
+    /// The grid's counterpart of KDTree::remove_nodes_by_flags (kdtree.hpp:282-284): flags 1 = keep, kept point p is
+    /// relabelled indices[p]. The grid gets a new identity (Registration re-prepares its target on the next align()).
+    void remove_nodes_by_flags(const shared_vector<uint8_t>& flags, const shared_vector<int32_t>& indices) {
+        if (flags.size() != indices.size())
+            throw std::runtime_error("[GridKNN::remove_nodes_by_flags] flags and indices must have the same size.");
+        throw_on_error(sp_grid_remove_by_flags(grid_, flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
+        static std::atomic<uint64_t> next_removed_id{1ull << 40};
+        id_ = next_removed_id.fetch_add(1);
+    }
+
 private:
     sp_grid* grid_ = nullptr;
     uint64_t id_ = 0;

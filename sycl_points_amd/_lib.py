@@ -77,6 +77,7 @@ SIGNATURES = {
     "sp_grid_cell_size": (_f, [_vp]),
     "sp_grid_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
     "sp_grid_radius_search": (_i, [_vp, _vp, _sz, _sz, _f, _vp, _i, _vp, _vp, _vp]),
+    "sp_grid_remove_by_flags": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "sp_grid_self_workspace_bytes": (_sz, [_vp]),
     "sp_grid_self_knn": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_cov_estimate": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),

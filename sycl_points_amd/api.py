@@ -312,6 +312,14 @@ class GridKNN(KNNBase):
         self.radius_search_async(queries, max_k, radius, result, transT)
         return result
 
+    def remove_nodes_by_flags(self, flags, indices):
+        """The grid's counterpart of KDTree::remove_nodes_by_flags (kdtree.hpp:282-284): flags 1 = keep; kept point p is
+        relabelled indices[p]. Prepared targets built on this grid must be re-created."""
+        if flags.shape[0] != indices.shape[0]:
+            raise SpError(2, "[GridKNN::remove_nodes_by_flags] flags and indices must have the same size.")
+        check(_lib.lib().sp_grid_remove_by_flags(self._h, _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
+        self.n = int(_lib.lib().sp_grid_size(self._h))
+
 
 class BruteForceKNN(KNNBase):
     """A KNNBase over knn_search_bruteforce (the reference tests inject such host fakes through the same seam,

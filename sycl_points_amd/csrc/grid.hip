@@ -973,6 +973,97 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     return SP_OK;
 }
 
+// ---- lazy delete (the grid's counterpart of KDTree::remove_nodes_by_flags, kdtree.hpp:282-284, 721-765) -------------
+// The cell order survives the removal of points, so nothing is re-sorted: kept points are compacted in place of order,
+// re-labelled with their new indices, and every cell's start becomes the number of kept points before its old start.
+namespace sp {
+namespace {
+__global__ __launch_bounds__(kBlock) void grid_keep_kernel(const float4* __restrict__ pts, unsigned n,
+                                                           const uint8_t* __restrict__ flags, unsigned n_flags,
+                                                           unsigned* __restrict__ keep) {
+    const unsigned pos = blockIdx.x * kBlock + threadIdx.x;
+    if (pos > n) return;
+    if (pos == n) { keep[pos] = 0; return; }  // the scan's last entry: the number of kept points
+    const int p = __float_as_int(pts[pos].w);
+    keep[pos] = (p >= 0 && ((unsigned)p >= n_flags || flags[p])) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void grid_compact_kernel(const float4* __restrict__ pts, unsigned n,
+                                                              const uint8_t* __restrict__ flags,
+                                                              const int32_t* __restrict__ new_idx, unsigned n_flags,
+                                                              const unsigned* __restrict__ scan, float4* __restrict__ out) {
+    const unsigned pos = blockIdx.x * kBlock + threadIdx.x;
+    if (pos >= n) return;
+    float4 s = pts[pos];
+    const int p = __float_as_int(s.w);
+    if (p < 0) return;
+    if ((unsigned)p < n_flags) {
+        if (!flags[p]) return;
+        s.w = __int_as_float(new_idx[p]);
+    }
+    out[scan[pos]] = s;
+}
+__global__ __launch_bounds__(kBlock) void grid_restart_kernel(const unsigned* __restrict__ old_start, size_t ncells,
+                                                              const unsigned* __restrict__ scan,
+                                                              unsigned* __restrict__ new_start) {
+    const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c <= ncells) new_start[c] = scan[old_start[c]];
+}
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const int32_t* new_indices, size_t n_flags,
+                                       void* stream) {
+    using namespace sp;
+    if (!g || (n_flags && (!flags || !new_indices))) return SP_ERR_INVALID_ARGUMENT;
+    const size_t n = g->n;
+    if (n == 0 || n_flags == 0) return SP_OK;
+    hipStream_t st = as_stream(stream);
+    ScratchBuf b_keep, b_scan, b_tmp, b_units, b_start;
+    float4* new_pts = nullptr;
+    size_t tmp_bytes = 0, tmp2_bytes = 0;
+    const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
+    unsigned* null_u = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, tmp_bytes, null_u, null_u, 0u, n + 1, rocprim::plus<unsigned>(), st);
+    (void)rocprim::exclusive_scan(nullptr, tmp2_bytes, null_u, null_u, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+    hipError_t e = b_keep.get((n + 1) * 4);
+    if (e == hipSuccess) e = b_scan.get((n + 1) * 4);
+    if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(std::max(tmp_bytes, tmp2_bytes), 16));
+    if (e == hipSuccess) e = b_units.get((rows + 1) * 4);
+    if (e == hipSuccess) e = b_start.get((g->ncells + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&new_pts, n * sizeof(float4));
+    auto fail = [&](hipError_t err) {
+        sp_set_error(hipGetErrorString(err));
+        (void)hipStreamSynchronize(st);
+        if (new_pts) (void)hipFree(new_pts);
+        return SP_ERR_HIP;
+    };
+    if (e != hipSuccess) return fail(e);
+    unsigned* const keep = b_keep.as<unsigned>();
+    unsigned* const scan = b_scan.as<unsigned>();
+    unsigned* const units = b_units.as<unsigned>();
+    unsigned* const new_start = b_start.as<unsigned>();
+    grid_keep_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(g->d_pts, (unsigned)n, flags, (unsigned)n_flags, keep);
+    e = rocprim::exclusive_scan(b_tmp.p, tmp_bytes, keep, scan, 0u, n + 1, rocprim::plus<unsigned>(), st);
+    if (e != hipSuccess) return fail(e);
+    grid_compact_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(g->d_pts, (unsigned)n, flags, new_indices, (unsigned)n_flags,
+                                                              scan, new_pts);
+    grid_restart_kernel<<<div_up(g->ncells + 1, kBlock), kBlock, 0, st>>>(g->d_start, g->ncells, scan, new_start);
+    unsigned kept = 0;
+    e = hipMemcpyAsync(&kept, scan + n, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->d_start, new_start, (g->ncells + 1) * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(units, 0, (rows + 1) * 4, st);
+    if (e != hipSuccess) return fail(e);
+    row_units_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
+    e = rocprim::exclusive_scan(b_tmp.p, tmp2_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(e);
+    (void)hipFree(g->d_pts);
+    g->d_pts = new_pts;
+    g->n = kept;
+    return SP_OK;
+}
+
 extern "C" size_t sp_grid_size(const sp_grid* g) { return g ? g->n : 0; }
 extern "C" float sp_grid_cell_size(const sp_grid* g) { return g ? g->h : 0.0f; }
 

@@ -97,6 +97,26 @@ static void kdtree_grid_vs_bruteforce() {  // test_kdtree.cpp:301-317, 392-408
         }
         CHECK(same && cut > 0);
     }
+    {   // lazy delete on both structures (test_kdtree.cpp:459-512): same neighbours of the kept points afterwards
+        shared_vector<uint8_t> flags(1000, uint8_t(1), *Q);
+        shared_vector<int32_t> new_idx(1000, int32_t(-1), *Q);
+        int32_t next = 0;
+        for (size_t i = 0; i < 1000; ++i) {
+            if (i % 10 == 0) flags[i] = 0;
+            else new_idx[i] = next++;
+        }
+        auto tree2 = alg::knn::KDTree::build(*Q, target);
+        auto grid2 = alg::knn::GridKNN::build(*Q, target, 2.0f);
+        tree2->remove_nodes_by_flags(flags, new_idx);
+        grid2->remove_nodes_by_flags(flags, new_idx);
+        CHECK(grid2->size() == 900);
+        auto kd = tree2->knn_search(query, 5);
+        auto gr = grid2->knn_search(query, 5);
+        bool same = true;
+        for (size_t i = 0; i < 100 * 5; ++i)
+            same = same && (*kd.indices)[i] == (*gr.indices)[i] && (*kd.distances)[i] == (*gr.distances)[i];
+        CHECK(same);
+    }
     // SinglePoint (test_kdtree.cpp:358-389)
     PointCloudCPU one, q1;
     one.points->push_back(PointType(0, 0, 0, 1));

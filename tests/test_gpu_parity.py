@@ -198,6 +198,45 @@ def test_grid_radius_search_matches_kdtree_oracle(sp, orc):
     assert grid.radius_search(dev(qry[:0]), 5, 1.0).indices.numel() == 0
 
 
+def test_grid_remove_nodes_by_flags(sp, orc):
+    """GridKNN::remove_nodes_by_flags (the grid's lazy delete, test_kdtree.cpp:459-512 for the KD-tree): afterwards the
+    grid answers exactly like a search over the kept points under their new indices — k-NN, k = 1 staged search, radius
+    search and the self-kNN tiling — and like the KD-tree after the same removal."""
+    g = orc.rng(99)
+    tgt = g.uniform_points(30000, 4.0)
+    flags = np.ones(len(tgt), np.uint8)
+    flags[::3] = 0
+    flags[1000:3000] = 0  # a removed region too: empty cells
+    new_idx = np.where(flags == 1, np.cumsum(flags) - 1, -1).astype(np.int32)
+    kept = tgt[flags == 1]
+    grid = sp.GridKNN.build(dev(tgt))
+    grid.remove_nodes_by_flags(dev(flags), dev(new_idx))
+    torch.cuda.synchronize()
+    qry = g.uniform_points(2000, 4.5)
+    for k in (1, 5, 20):
+        r = grid.knn_search(dev(qry), k)
+        bi, bd = orc.knn_bruteforce(qry, kept, k)
+        assert np.array_equal(r.indices.cpu().numpy(), bi) and np.array_equal(r.distances.cpu().numpy(), bd), k
+    nodes = orc.kdtree_build(tgt)
+    orc.kdtree_remove_by_flags(nodes, flags, new_idx)
+    oi, od = orc.kdtree_knn(nodes, qry, 10)
+    r = grid.knn_search(dev(qry), 10)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    rr = grid.radius_search(dev(qry), 8, 0.3)
+    oi, od = orc.kdtree_radius(nodes, qry, 8, 0.3)
+    assert np.array_equal(rr.indices.cpu().numpy(), oi) and np.array_equal(rr.distances.cpu().numpy(), od)
+    # the self-kNN tiling was rebuilt: neighbour lists of the kept points among themselves
+    knn, _, _ = grid.self_knn(6, want_knn=True, want_covs=False)
+    bi, bd = orc.knn_bruteforce(kept, kept, 6)
+    assert np.array_equal(knn.indices.cpu().numpy(), bi) and np.array_equal(knn.distances.cpu().numpy(), bd)
+    # removing everything leaves an empty, usable grid
+    grid.remove_nodes_by_flags(dev(np.zeros(len(kept), np.uint8)), dev(np.full(len(kept), -1, np.int32)))
+    r = grid.knn_search(dev(qry[:10]), 3)
+    assert (r.indices.cpu().numpy() == -1).all()
+    with pytest.raises(sp.SpError):
+        grid.remove_nodes_by_flags(dev(np.zeros(4, np.uint8)), dev(np.zeros(5, np.int32)))
+
+
 def test_kdtree_1m_k1_sampled(sp, orc):
     # full-size NN (1M targets): oracle KD-tree on a sample of queries + exactness property vs brute force on a sample
     g = orc.rng(1234)
