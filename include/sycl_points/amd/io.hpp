@@ -17,9 +17,93 @@ public:
         const auto dot = filename.find_last_of('.');
         std::string ext = dot == std::string::npos ? "" : filename.substr(dot + 1);
         for (auto& c : ext) c = (char)std::tolower((unsigned char)c);
-        if (ext != "ply") throw std::runtime_error("[PointCloudReader::readFile] only PLY is supported in this build: " + filename);
         (void)read_rgb;
-        return readPLY(filename, read_intensity);
+        if (ext == "ply") return readPLY(filename, read_intensity);
+        if (ext == "pcd") return readPCD(filename, read_intensity);
+        throw std::runtime_error("[PointCloudReader::readFile] Unsupported file format: " + filename);
+    }
+
+    /// PCD (io/point_cloud_reader.hpp:278-492): header FIELDS / SIZE / TYPE / COUNT / WIDTH / HEIGHT / POINTS / DATA,
+    /// `DATA ascii` or `DATA binary` (little endian rows of the declared fields). x, y, z are required; `intensity`
+    /// is read when asked for. `binary_compressed` is rejected (as in the reference, which only knows ascii and binary).
+    static PointCloudCPU readPCD(const std::string& filename, bool read_intensity = false) {
+        std::ifstream f(filename, std::ios::binary);
+        if (!f) throw std::runtime_error("[PointCloudReader::readPCD] cannot open " + filename);
+        struct Field { std::string name; size_t size = 4; char type = 'F'; size_t count = 1; };
+        std::vector<Field> fields;
+        size_t n_points = 0, width = 0, height = 1;
+        std::string line, data;
+        bool have_points = false;
+        while (std::getline(f, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream ss(line);
+            std::string key;
+            ss >> key;
+            if (key == "FIELDS") {
+                std::string name;
+                while (ss >> name) { Field fd; fd.name = name; fields.push_back(fd); }
+            } else if (key == "SIZE") {
+                for (auto& fd : fields) ss >> fd.size;
+            } else if (key == "TYPE") {
+                for (auto& fd : fields) ss >> fd.type;
+            } else if (key == "COUNT") {
+                for (auto& fd : fields) ss >> fd.count;
+            } else if (key == "WIDTH") {
+                ss >> width;
+            } else if (key == "HEIGHT") {
+                ss >> height;
+            } else if (key == "POINTS") {
+                ss >> n_points;
+                have_points = true;
+            } else if (key == "DATA") {
+                ss >> data;
+                break;  // DATA is the last header line
+            }
+        }
+        if (!have_points) n_points = width * height;
+        if (fields.empty() || data.empty()) throw std::runtime_error("[PointCloudReader::readPCD] Invalid PCD format: missing point data");
+        if (data != "ascii" && data != "binary")
+            throw std::runtime_error("[PointCloudReader::readPCD] unsupported DATA '" + data + "'");
+        int ix = -1, iy = -1, iz = -1, ii = -1;
+        std::vector<size_t> first(fields.size());  // index of a field's first value in a row's value list
+        size_t n_vals = 0, stride = 0;
+        for (size_t i = 0; i < fields.size(); ++i) {
+            first[i] = n_vals;
+            n_vals += fields[i].count;
+            stride += fields[i].size * fields[i].count;
+            if (fields[i].name == "x") ix = (int)first[i];
+            else if (fields[i].name == "y") iy = (int)first[i];
+            else if (fields[i].name == "z") iz = (int)first[i];
+            else if (fields[i].name == "intensity") ii = (int)first[i];
+        }
+        if (ix < 0 || iy < 0 || iz < 0) throw std::runtime_error("[PointCloudReader::readPCD] x/y/z fields missing");
+        PointCloudCPU cloud;
+        cloud.points->resize(n_points);
+        const bool want_i = read_intensity && ii >= 0;
+        if (want_i) cloud.intensities->resize(n_points);
+        std::vector<double> vals(n_vals);
+        if (data == "ascii") {
+            for (size_t v = 0; v < n_points; ++v) {
+                for (size_t k = 0; k < n_vals; ++k)
+                    if (!(f >> vals[k])) throw std::runtime_error("[PointCloudReader::readPCD] Error reading ascii PCD data");
+                store(cloud, v, vals, ix, iy, iz, want_i ? ii : -1);
+            }
+        } else {
+            std::vector<char> row(stride);
+            for (size_t v = 0; v < n_points; ++v) {
+                f.read(row.data(), (std::streamsize)stride);
+                if (!f) throw std::runtime_error("[PointCloudReader::readPCD] Error reading binary PCD data");
+                size_t off = 0, k = 0;
+                for (const auto& fd : fields)
+                    for (size_t c = 0; c < fd.count; ++c) {
+                        vals[k++] = decode_pcd(row.data() + off, fd.type, fd.size);
+                        off += fd.size;
+                    }
+                store(cloud, v, vals, ix, iy, iz, want_i ? ii : -1);
+            }
+        }
+        return cloud;
     }
 
     static PointCloudCPU readPLY(const std::string& filename, bool read_intensity = false) {
@@ -102,6 +186,12 @@ private:
         if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, p, 2); return v; }
         if (t == "uint" || t == "uint32") { uint32_t v; std::memcpy(&v, p, 4); return v; }
         int32_t v; std::memcpy(&v, p, 4); return v;
+    }
+    static double decode_pcd(const char* p, char type, size_t size) {  // TYPE F / I / U with SIZE 1, 2, 4, 8
+        if (type == 'F') return decode(p, size == 8 ? "double" : "float");
+        if (type == 'U') return decode(p, size == 1 ? "uchar" : size == 2 ? "ushort" : "uint");
+        if (size == 8) { int64_t v; std::memcpy(&v, p, 8); return (double)v; }
+        return decode(p, size == 1 ? "char" : size == 2 ? "short" : "int");
     }
     static void store(PointCloudCPU& c, size_t v, const std::vector<double>& vals, int ix, int iy, int iz, int ii) {
         (*c.points)[v] = PointType((float)vals[ix], (float)vals[iy], (float)vals[iz], 1.0f);

@@ -14,6 +14,8 @@
 #include "sycl_points/algorithms/knn/grid.hpp"
 #include "sycl_points/algorithms/knn/kdtree.hpp"
 #include "sycl_points/algorithms/registration/registration_pipeline.hpp"
+#include "sycl_points/io/point_cloud_reader.hpp"
+#include <fstream>
 
 // ---- oracle (liboracle.so) entry points used as the checker
 struct orc_reg_params {
@@ -204,6 +206,43 @@ public:
     const PointCloudShared& target;
     mutable int calls = 0;
 };
+
+static void point_cloud_files() {  // io/point_cloud_reader.hpp: PLY (the bundled clouds) and PCD, ascii and binary
+    const char* dir = std::getenv("SP_GOLDEN_DIR");
+    if (dir) {
+        const PointCloudCPU src = PointCloudReader::readFile(std::string(dir) + "/source.ply");
+        CHECK(src.size() == 69792);  // cpp/data/source.ply
+    }
+    const float pts[3][4] = {{1.5f, -2.25f, 3.0f, 0.5f}, {0.0f, 1e-3f, -7.5f, 10.0f}, {100.0f, 200.0f, -300.0f, 255.0f}};
+    {
+        std::ofstream o("/tmp/sp_test_ascii.pcd");
+        o << "# .PCD v0.7\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH 3\nHEIGHT 1\n"
+             "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS 3\nDATA ascii\n";
+        for (auto& p : pts) o << p[0] << " " << p[1] << " " << p[2] << " " << p[3] << "\n";
+    }
+    {
+        std::ofstream o("/tmp/sp_test_binary.pcd", std::ios::binary);
+        o << "VERSION 0.7\nFIELDS x y z rgb intensity\nSIZE 4 4 4 4 4\nTYPE F F F U F\nCOUNT 1 1 1 1 1\nWIDTH 3\nHEIGHT 1\nPOINTS 3\nDATA binary\n";
+        for (auto& p : pts) {
+            const uint32_t rgb = 0x00ff8800u;
+            o.write(reinterpret_cast<const char*>(p), 12);
+            o.write(reinterpret_cast<const char*>(&rgb), 4);
+            o.write(reinterpret_cast<const char*>(&p[3]), 4);
+        }
+    }
+    for (const char* name : {"/tmp/sp_test_ascii.pcd", "/tmp/sp_test_binary.pcd"}) {
+        const PointCloudCPU c = PointCloudReader::readFile(name, false, true);
+        CHECK(c.size() == 3 && c.intensities->size() == 3);
+        bool same = c.size() == 3;
+        for (size_t i = 0; same && i < 3; ++i)
+            same = (*c.points)[i].x() == pts[i][0] && (*c.points)[i].y() == pts[i][1] && (*c.points)[i].z() == pts[i][2] &&
+                   (*c.points)[i].w() == 1.0f && (*c.intensities)[i] == pts[i][3];
+        CHECK(same);
+    }
+    bool threw = false;
+    try { PointCloudReader::readFile("/tmp/sp_test_ascii.xyz"); } catch (const std::runtime_error&) { threw = true; }
+    CHECK(threw);
+}
 
 static float max_abs_diff(const TransformMatrix& A, const float* colmajor16) {
     float m = 0;
@@ -414,6 +453,7 @@ int main() {
     RUN(kdtree_grid_vs_bruteforce);
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
+    RUN(point_cloud_files);
     RUN(registration_matches_oracle);
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed == 0 ? 0 : 1;

@@ -19,7 +19,8 @@ def _build():
 
 def test_cpp_facade_suite():
     _build()
-    r = subprocess.run([os.path.join(CPP, "test_facade")], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, SP_GOLDEN_DIR=os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    r = subprocess.run([os.path.join(CPP, "test_facade")], capture_output=True, text=True, timeout=600, env=env)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert " 0 failed" in r.stdout
