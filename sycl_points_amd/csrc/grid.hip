@@ -836,9 +836,10 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
 
 extern "C" void sp_grid_destroy(sp_grid* g) {
     if (!g) return;
-    if (g->d_pts) (void)hipFree(g->d_pts);
-    if (g->d_start) (void)hipFree(g->d_start);
-    if (g->d_unit_off) (void)hipFree(g->d_unit_off);
+    (void)hipDeviceSynchronize();  // nothing may still be reading the arrays when they go back to the pool
+    sp::pooled_free(g->d_pts);
+    sp::pooled_free(g->d_start);
+    sp::pooled_free(g->d_unit_off);
     delete g;
 }
 
@@ -862,7 +863,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     };
     hipError_t e;
     if (n == 0) {
-        if ((e = hipMalloc(&g->d_start, 2 * sizeof(uint32_t))) != hipSuccess) return fail(e);
+        if ((e = pooled_alloc(&g->d_start, 2 * sizeof(uint32_t))) != hipSuccess) return fail(e);
         if ((e = hipMemsetAsync(g->d_start, 0, 2 * sizeof(uint32_t), st)) != hipSuccess) return fail(e);
         *out = g;
         return SP_OK;
@@ -933,8 +934,8 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     if (e == hipSuccess) e = b_vin.get(n * 4);
     if (e == hipSuccess) e = b_vout.get(n * 4);
     if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(tmp_bytes, 16));
-    if (e == hipSuccess) e = hipMalloc(&g->d_pts, n * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = pooled_alloc(&g->d_pts, n * sizeof(float4));
+    if (e == hipSuccess) e = pooled_alloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t));
     keys_in = b_kin.as<unsigned>(); keys_out = b_kout.as<unsigned>(); vals_in = b_vin.as<unsigned>(); vals_out = b_vout.as<unsigned>();
     void* const tmp = b_tmp.p;
     const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
@@ -944,7 +945,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     if (e == hipSuccess) {
         (void)rocprim::exclusive_scan(nullptr, stmp_bytes, units, units, 0u, rows + 1, rocprim::plus<unsigned>(), st);
         e = b_units.get((rows + 1) * 4);
-        if (e == hipSuccess) e = hipMalloc(&g->d_unit_off, (rows + 1) * 4);
+        if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4);
         if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
         units = b_units.as<unsigned>();
         stmp = b_stmp.p;
@@ -1030,11 +1031,11 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(std::max(tmp_bytes, tmp2_bytes), 16));
     if (e == hipSuccess) e = b_units.get((rows + 1) * 4);
     if (e == hipSuccess) e = b_start.get((g->ncells + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&new_pts, n * sizeof(float4));
+    if (e == hipSuccess) e = pooled_alloc(&new_pts, n * sizeof(float4));
     auto fail = [&](hipError_t err) {
         sp_set_error(hipGetErrorString(err));
         (void)hipStreamSynchronize(st);
-        if (new_pts) (void)hipFree(new_pts);
+        pooled_free(new_pts);
         return SP_ERR_HIP;
     };
     if (e != hipSuccess) return fail(e);
@@ -1058,7 +1059,8 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(e);
-    (void)hipFree(g->d_pts);
+    (void)hipDeviceSynchronize();  // readers of the old array on other streams
+    pooled_free(g->d_pts);
     g->d_pts = new_pts;
     g->n = kept;
     return SP_OK;

@@ -1218,9 +1218,10 @@ struct sp_gicp_source {
 
 extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
     if (!t) return;
-    if (t->covp) (void)hipFree(t->covp);
-    if (t->rho2) (void)hipFree(t->rho2);
-    if (t->nb) (void)hipFree(t->nb);
+    (void)hipDeviceSynchronize();  // nothing may still be reading the arrays when they go back to the pool
+    sp::pooled_free(t->covp);
+    sp::pooled_free(t->rho2);
+    sp::pooled_free(t->nb);
     delete t;
 }
 extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, void* stream) {
@@ -1250,7 +1251,7 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
     t->grid = grid;
     t->n = n;
     if (n) {
-        const hipError_t e = hipMalloc(&t->covp, n * 2 * sizeof(float4));
+        const hipError_t e = pooled_alloc(&t->covp, n * 2 * sizeof(float4));
         if (e != hipSuccess) {
             sp_set_error(hipGetErrorString(e));
             sp_gicp_target_destroy(t);
@@ -1263,8 +1264,8 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
         hipStream_t st = as_stream(stream);
         ScratchBuf b_idx3, b_d23, b_inv, b_ws;
         const size_t ws_bytes = sp_grid_self_workspace_bytes(grid);
-        hipError_t e = hipMalloc(&t->rho2, n * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&t->nb, n * sizeof(float4));
+        hipError_t e = pooled_alloc(&t->rho2, n * sizeof(float));
+        if (e == hipSuccess) e = pooled_alloc(&t->nb, n * sizeof(float4));
         if (e == hipSuccess) e = b_idx3.get(n * 3 * sizeof(int32_t));
         if (e == hipSuccess) e = b_d23.get(n * 3 * sizeof(float));
         if (e == hipSuccess) e = b_inv.get(n * sizeof(unsigned));

@@ -33,9 +33,13 @@ inline unsigned stream_grid(size_t n, int block = kBlock, int per_thread = 1) {
 // workspaces, a few counters) are idle again when the build returns (it synchronises its stream), so they are kept and
 // handed to the next build instead of going back to hipFree / hipMalloc, which cost ~0.1 ms apiece on this runtime
 // (eleven of them made a 1M-point grid build 1.9 ms for 0.2 ms of kernels). Bounded: at most kKeep idle buffers are kept,
-// the smallest is dropped first. Objects that outlive the call (the grid's own arrays) are ordinary allocations.
+// the smallest is dropped first. The arrays of objects that outlive the call (a grid, a prepared target) come from the same
+// pool through pooled_alloc / pooled_free: their destroy waits for the device to go idle (what hipFree does implicitly)
+// before the buffers are offered to the next build.
 hipError_t scratch_acquire(void** ptr, size_t bytes);  // capi_common.hip
 void scratch_release(void* ptr);
+template <class T> hipError_t pooled_alloc(T** ptr, size_t bytes) { return scratch_acquire(reinterpret_cast<void**>(ptr), bytes); }
+inline void pooled_free(void* ptr) { if (ptr) scratch_release(ptr); }  // caller: the device is idle (hipDeviceSynchronize)
 struct ScratchBuf {  // RAII handle
     void* p = nullptr;
     hipError_t get(size_t bytes) { return scratch_acquire(&p, bytes); }
