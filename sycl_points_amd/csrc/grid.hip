@@ -500,13 +500,13 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
             xb = min(cx + 1, g.nx - 1);
             unsigned c = 0;
             int r = 0;
-            // centre row first, then the rest: the nearest candidates arrive early and keep later insertions rare
+            // centre row first, then the four rows that share a face with it, then the four corner rows: the nearest
+            // candidates arrive early, the k-th best tightens fast and later chunks insert little
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
+            for (int ring = 0; ring < 3; ++ring)
                 for (int z = za; z <= zb; ++z)
                     for (int y = ya; y <= yb; ++y) {
-                        const bool centre = (z == rz && y == ry);
-                        if ((pass == 0) != centre) continue;
+                        if (abs(z - rz) + abs(y - ry) != ring) continue;
                         const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
                         const unsigned s0 = start[rr + xa], e0 = start[rr + xb + 1];
                         seg_s[r] = s0;
