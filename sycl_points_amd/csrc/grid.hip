@@ -483,10 +483,9 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
     const unsigned nq = min(64u, row_e - qs);
     const unsigned lane = threadIdx.x;
     const float4 myq = pts[min(qs + lane, row_e - 1)];
-    const int ya = max(ry - 1, 0), yb = min(ry + 1, g.ny - 1), za = max(rz - 1, 0), zb = min(rz + 1, g.nz - 1);
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
 
-    int cur_cx = -1;
+    int cur_cx = -1, cur_variant = -1;
     unsigned seg_s[9], seg_c[10];  // start of each segment, running candidate counts (seg_c[9] = total)
     int xa = 0, xb = 0;
     for (unsigned j = 0; j < nq; ++j) {
@@ -494,26 +493,33 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
         const float qx = bcast_f(myq.x, (int)j), qy = bcast_f(myq.y, (int)j), qz = bcast_f(myq.z, (int)j);
         const unsigned qorig = (unsigned)bcast_i(__float_as_int(myq.w), (int)j);
         const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx);
-        if (cx != cur_cx) {  // wave-uniform: new cell, new segments
+        // which half of its cell the query is in, per axis: the rows on that side come first
+        const int sy = ((qy - g.oy) * g.inv_h - (float)ry < 0.5f) ? -1 : 1, sz = ((qz - g.oz) * g.inv_h - (float)rz < 0.5f) ? -1 : 1;
+        const int variant = (sy > 0 ? 1 : 0) | (sz > 0 ? 2 : 0);
+        if (cx != cur_cx || variant != cur_variant) {  // wave-uniform: new cell or new side, new segments
             cur_cx = cx;
+            cur_variant = variant;
             xa = max(cx - 1, 0);
             xb = min(cx + 1, g.nx - 1);
             unsigned c = 0;
             int r = 0;
-            // centre row first, then the four rows that share a face with it, then the four corner rows: the nearest
-            // candidates arrive early, the k-th best tightens fast and later chunks insert little
+            // centre row, the two face rows on the query's side, the corner row between them, the two far face rows, the
+            // other corners: the nearest candidates arrive early, the k-th best tightens fast, later chunks insert little
+            constexpr int kDy[9] = {0, 1, 0, 1, -1, 0, 1, -1, -1}, kDz[9] = {0, 0, 1, 1, 0, -1, -1, 1, -1};
 #pragma unroll
-            for (int ring = 0; ring < 3; ++ring)
-                for (int z = za; z <= zb; ++z)
-                    for (int y = ya; y <= yb; ++y) {
-                        if (abs(z - rz) + abs(y - ry) != ring) continue;
-                        const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
-                        const unsigned s0 = start[rr + xa], e0 = start[rr + xb + 1];
-                        seg_s[r] = s0;
-                        seg_c[r] = c;
-                        c += e0 - s0;
-                        ++r;
-                    }
+            for (int o = 0; o < 9; ++o) {
+                const int y = ry + kDy[o] * sy, z = rz + kDz[o] * sz;
+                unsigned s0 = 0, e0 = 0;
+                if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                    const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
+                    s0 = start[rr + xa];
+                    e0 = start[rr + xb + 1];
+                }
+                seg_s[r] = s0;
+                seg_c[r] = c;
+                c += e0 - s0;
+                ++r;
+            }
             for (; r < 9; ++r) { seg_s[r] = 0; seg_c[r] = c; }
             seg_c[9] = c;
         }
