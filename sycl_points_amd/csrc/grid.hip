@@ -575,6 +575,11 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
             const int x0 = max(cx - Rn, 0), x1 = min(cx + Rn, g.nx - 1);
             for (int z = z0; z <= z1; ++z)
                 for (int y = y0; y <= y1; ++y) {
+                    // only the part of the shell the ball of the current k-th distance reaches (the k-th best moves as
+                    // candidates are inserted; the test uses its current value)
+                    const float dyz2 = gap2(qz, g.oz + z * g.h, g.oz + (z + 1) * g.h, g.eps) +
+                                       gap2(qy, g.oy + y * g.h, g.oy + (y + 1) * g.h, g.eps);
+                    if (dyz2 > key_d2(kth)) continue;
                     const bool shell_row = (z == cz - Rn) || (z == cz + Rn) || (y == cy - Rn) || (y == cy + Rn);
                     const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
                     for (int sgi = 0; sgi < (shell_row ? 1 : 2); ++sgi) {
@@ -582,6 +587,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
                         if (shell_row) { sxa = x0; sxb = x1; }
                         else if (sgi == 0) { sxa = sxb = cx - Rn; if (sxa < 0) continue; }
                         else { sxa = sxb = cx + Rn; if (sxb > g.nx - 1) continue; }
+                        if (dyz2 + gap2(qx, g.ox + sxa * g.h, g.ox + (sxb + 1) * g.h, g.eps) > key_d2(kth)) continue;
                         const unsigned s0 = start[rr + sxa], e0 = start[rr + sxb + 1];
                         for (unsigned base = s0; base < e0; base += 64) {
                             const unsigned pos = base + lane;
