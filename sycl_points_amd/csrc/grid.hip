@@ -294,8 +294,12 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_tile_kernel(const float4*
     float kth = FLT_MAX;
     int kth_idx = -1;
 
-    for (int z = za; z <= zb; ++z)
+    // the queries' own row first, then the four rows sharing a face with it, then the corner rows: the k-th best is tight
+    // before the far rows arrive and they rarely take the insertion branch (which costs the whole wave when any lane takes it)
+    for (int ring = 0; ring < 3; ++ring)
+      for (int z = za; z <= zb; ++z)
         for (int y = ya; y <= yb; ++y) {
+            if (abs(z - rz) + abs(y - ry) != ring) continue;
             const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
             const unsigned s = start[rr + xa], e = start[rr + xb + 1];
             for (unsigned base = s; base < e; base += kWave) {
