@@ -26,7 +26,7 @@
 
 void sp_set_error(const char* msg);
 
-static int g_self_knn_mode = 0;  // tuning hook: 0 by k (lane-per-query tile kernel up to k = 5, wave-cooperative above), 1 tile kernel (k <= 10), 2 wave kernel
+static int g_self_knn_mode = 0;  // tuning hook: 0 by k (lane-per-query tile kernel up to k = 6, wave-cooperative above), 1 tile kernel (k <= 10), 2 wave kernel
 
 // rocPRIM picks a merge sort (about 15 launches, 155 us per 1M pairs) up to 1M items; Onesweep with the key bits
 // actually used (3 passes for a 22-bit cell id) is 3x faster at this size.
@@ -791,8 +791,8 @@ int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
     const GridDesc g = grid_desc(gr);
     if (hipMemsetAsync(out.todo_count, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
     if (gr->n_units) {
-        // lane-per-query tile kernel for short lists (k = 3 on 1M points: 0.70 ms against 1.94 ms; it loses from k ~ 8 up)
-        if (KCAP <= 10 && (g_self_knn_mode == 1 || (g_self_knn_mode == 0 && k <= 5)))
+        // lane-per-query tile kernel for short lists (k = 3 on 1M points: 0.70 ms against 1.94 ms; it loses from k = 7 up: scratch/selfknn_modes.py)
+        if (KCAP <= 10 && (g_self_knn_mode == 1 || (g_self_knn_mode == 0 && k <= 6)))
             grid_self_knn_tile_kernel<KCAP><<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
         else
             grid_self_knn_wave_kernel<<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
