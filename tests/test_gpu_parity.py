@@ -237,6 +237,33 @@ def test_grid_remove_nodes_by_flags(sp, orc):
         grid.remove_nodes_by_flags(dev(np.zeros(4, np.uint8)), dev(np.zeros(5, np.int32)))
 
 
+def test_buffer_pool_reuse_across_sizes(sp, orc):
+    """Structure builds take their buffers from a pool inside the library (csrc/sp_common.h): many builds and destroys of
+    different sizes, interleaved and with objects alive in between, must keep answering exactly."""
+    g = orc.rng(2024)
+    alive = []
+    for it, n in enumerate([5000, 300, 20000, 1, 7000, 64, 12000, 5000, 2, 9000, 150, 20000]):
+        tgt = g.uniform_points(n, 3.0)
+        qry = g.uniform_points(200, 3.2)
+        grid = sp.GridKNN.build(dev(tgt), points_per_cell=[0.5, 2.0, 6.0][it % 3])
+        k = min(5, n)
+        r = grid.knn_search(dev(qry), k)
+        bi, bd = orc.knn_bruteforce(qry, tgt, k)
+        assert np.array_equal(r.indices.cpu().numpy(), bi) and np.array_equal(r.distances.cpu().numpy(), bd), (it, n)
+        if n >= 64:
+            knn, covs, _ = grid.self_knn(min(10, n), want_knn=True, want_covs=True)
+            si, sd = orc.knn_bruteforce(tgt, tgt, min(10, n))
+            assert np.array_equal(knn.indices.cpu().numpy(), si), (it, n)
+            prep = sp.PreparedTarget(grid, covs)
+            alive.append((grid, prep, tgt, qry))
+        if it % 4 == 3:
+            alive = alive[-1:]  # destroy most of what is alive: their arrays go back to the pool
+    for grid, prep, tgt, qry in alive:  # survivors still answer from their own, untouched arrays
+        r = grid.knn_search(dev(qry), 3)
+        bi, bd = orc.knn_bruteforce(qry, tgt, 3)
+        assert np.array_equal(r.indices.cpu().numpy(), bi) and np.array_equal(r.distances.cpu().numpy(), bd)
+
+
 def test_kdtree_1m_k1_sampled(sp, orc):
     # full-size NN (1M targets): oracle KD-tree on a sample of queries + exactness property vs brute force on a sample
     g = orc.rng(1234)
