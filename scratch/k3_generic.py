@@ -1,0 +1,17 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import sycl_points_amd.api as sp
+from sycl_points_amd.synthetic import Mt19937Cloud
+pts=torch.from_numpy(Mt19937Cloud(1234).uniform_points(1000000,10.0)).cuda()
+def t(fn,reps=5):
+    fn(); torch.cuda.synchronize()
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)/reps
+for ppc in (0.5,2.0):
+    g=sp.GridKNN.build(pts,points_per_cell=ppc)
+    order=g.order()
+    sorted_pts=pts[order].contiguous()
+    print("ppc",ppc,"generic k=3 (queries in original order) %.3f ms | (queries in cell order) %.3f ms | self_knn k=3 %.3f ms"%(
+        t(lambda: g.knn_search(pts,3)), t(lambda: g.knn_search(sorted_pts,3)), t(lambda: g.self_knn(3,want_knn=True))))
