@@ -336,8 +336,8 @@ void sp_debug_set_fused_stage_mask(int mask);
  * closer to its previous winner than half that winner's distance to its nearest other target point); 0 always search.
  * Takes effect at the next sp_gicp_target_update / sp_gicp_source_prepare. Results are identical either way. */
 void sp_debug_set_fused_reuse(int on);
-/* Tuning hook: self-kNN kernel (0 chosen by k, default: lane-per-query tile kernel up to k = 6, wave-cooperative above;
- * 1 tile kernel whenever k <= 10; 2 wave-cooperative kernel). Results are identical. */
+/* Tuning hook: self-kNN kernel (0 chosen by k, default: lane per point for k <= 10, wave-cooperative above;
+ * 1 LDS-tile kernel (k <= 10); 2 wave-cooperative kernel). Results are identical. */
 void sp_debug_set_self_knn_mode(int mode);
 
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
