@@ -17,6 +17,7 @@ def orc():
 @pytest.fixture(scope="module")
 def L():
     from sycl_points_amd import _lib
+    _lib.build()  # hipcc cross-compiles without a GPU; nothing happens when the library is current
     return _lib.lib()
 
 
