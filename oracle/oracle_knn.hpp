@@ -70,6 +70,7 @@ inline float dist_bruteforce(const float* q, const float* t) {
 inline void knn_bruteforce(const float* queries, size_t nq, const float* targets, size_t nt, size_t k, int32_t* idx_out,
                            float* d2_out) {
     constexpr size_t MAX_K = 20;
+    if (k == 0 || k > MAX_K) return;  // the reference has no check and overruns kD/kI; callers (pyoracle) raise instead
 #pragma omp parallel for schedule(static)
     for (long long qi = 0; qi < (long long)nq; ++qi) {
         const float* query = queries + 4 * qi;

@@ -184,6 +184,10 @@ class Oracle:
 
     # ---- knn
     def knn_bruteforce(self, q, t, k):
+        # knn/bruteforce.hpp:46-48 keeps `float kDistances[MAX_K = 20]` with no check on k; the restatement keeps the same
+        # fixed arrays, so a larger k would overrun the stack here exactly as it does in the reference. Refuse it.
+        if not 1 <= k <= 20:
+            raise ValueError(f"oracle knn_bruteforce: k = {k} outside the reference's MAX_K = 20 arrays (use kdtree_knn)")
         q, t = _f(q), _f(t)
         idx = np.empty((len(q), k), np.int32)
         d2 = np.empty((len(q), k), np.float32)
