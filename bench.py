@@ -2,17 +2,25 @@
 """GICP hot-path benchmark (BASELINE.json: "GICP iterations/sec & correspondences/sec at 1M pts").
 
 A step = one GICP iteration over the rank's source shard: nearest neighbour (k=1, query transformed by the current
-pose) -> linearise + reduce -> [all-reduce of the 192-byte system over ranks] -> 6x6 solve + pose update, all on the
+pose) -> linearise + reduce -> [all-reduce of the linear system over ranks] -> 6x6 solve + pose update, all on the
 device with inputs resident in HBM. Steps run in alignments of 20 iterations from the identity initial guess
-(BASELINE config 4: GICP, GN lambda=1, max_corr 2.0, robust NONE, convergence criteria 0); the per-alignment
-preparation (plane-regularised covariances of both clouds, cell-order sort of the source) is INSIDE the timed region,
-once per alignment. NN-structure build and k=20 covariances are untimed set-up ("preprocessing timed
-separately"), as KDTree::build and covariance estimation are separate stages in the reference's own flow.
-N = 1: 1M-vs-1M clouds (config 4). N > 1: config 5 generalised — N x 1M source points tile-sharded 1M per GPU,
+(BASELINE config 4: GICP, GN lambda=1, max_corr 2.0, robust NONE, convergence criteria 0).
+INSIDE the timed region, once per alignment: the source-side preparation (plane-regularised source covariances; with
+--source-order random also the sort of the source by target cell). Untimed set-up ("preprocessing timed
+separately", as KDTree::build and covariance estimation are separate stages in the reference's own flow): the clouds,
+their k=20 covariances, the target's NN structure (grid) and everything that depends on the target alone — its
+plane-regularised covariance rows and reuse certificates (sp_gicp_target_create) — and, with the default
+--source-order grid, storing the source in cell order (what voxel downsampling hands to align()).
+N = 1: 1M-vs-1M clouds (config 4). N > 1: config 5 generalised — N x 1M source points sharded 1M per GPU,
 target (N x 1M points, same density) replicated on every GPU: weak scaling.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel and
-`cpu_baseline` (the CPU oracle timed on the same workload, rank 0, N = 1 only).
+The block of --steps steps is timed --repeats times (each block bracketed by a barrier + synchronize on both sides);
+`ms_per_step` / `value` come from the MEDIAN block, so a 20-step run is not one 0.7 ms sample.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel,
+`launch_classes` (the launches of one alignment split into searching / steady, each with its algorithmic and
+measured-traffic fraction of the HBM peak), `until_converged` (an alignment with the reference's default criteria
+1e-3: what a caller of align() gets) and `cpu_baseline` (the CPU oracle timed on the same workload, rank 0, N = 1 only).
 """
 import argparse
 import ctypes as C
@@ -39,6 +47,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=31,
+                    help="the block of --steps steps is timed this many times; the median block is reported")
     ap.add_argument("--points", type=int, default=PER_GPU_POINTS, help="source points per GPU (default: the config)")
     ap.add_argument("--path", choices=["fused", "generic"], default="fused",
                     help="fused: GridKNN + prepared covariances, NN+K11 in one kernel; generic: KNNBase search + K11")
@@ -176,14 +186,17 @@ def main():
         fence()
     run_steps(args.warmup)
     fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    blocks = []
+    for _ in range(max(1, args.repeats)):  # every block: EXACTLY --steps steps between two barrier + synchronize fences
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        blocks.append(time.perf_counter() - t0)
+    if world > 1:  # a block takes as long as its slowest rank
+        tmax = torch.tensor(blocks, dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        blocks = [float(x) for x in tmax.tolist()]
+    elapsed = float(np.median(blocks))
 
     # ---- correctness of what was timed: pose after a full alignment vs the ground truth used to make the data
     T_dev.copy_(T_ident)
@@ -195,6 +208,10 @@ def main():
 
     # ---- per-kernel durations over one alignment, by HIP events on the launch stream (rank 0's numbers are reported)
     kern = kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n_local, SORT_MODE)
+    launches = classes = converged = None
+    if args.path == "fused" and group is None:
+        launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
+        converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE)
 
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
@@ -207,6 +224,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "timed_blocks": {"n": len(blocks), "statistic": "median", "min_ms_per_step": 1e3 * min(blocks) / args.steps,
+                             "max_ms_per_step": 1e3 * max(blocks) / args.steps},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -232,6 +251,9 @@ def main():
             "inliers_last_iteration": int(lin.inlier),
             "setup_s": t_setup,
             "kernels": kern,
+            "launches_of_one_alignment": launches,
+            "launch_classes": classes,
+            "until_converged": converged,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom), "algorithmic_bytes_per_launch": kern[dom]["bytes"]},
@@ -254,6 +276,85 @@ def measured_traffic(kernel):
         return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def class_traffic(cls):
+    """Measured HBM bytes per launch of one class of gicp_align_kernel launches (profiles/traffic.json, per-dispatch PMC)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get("gicp_align_kernel", {}).get("classes", {}).get(cls, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n, reps=7):
+    """Duration of EACH of the 20 launches of one alignment (identity guess, criteria 0), by HIP events recorded between
+    the launches on the launch stream, and how many source points each launch had to search for (device-side log,
+    csrc/sp_internal.h). A launch is 'searching' when more than 1 % of its points were searched — the first poses of an
+    alignment — and 'steady' otherwise (correspondences carried over by certificate: a pure stream). The device queue is
+    pre-filled behind a spin kernel so that the host's launch rate does not show up as gaps between the events."""
+    L = _lib.lib()
+    ws, lin = reg._buffers(T_dev.device)
+    fp = reg._factor_params(reg.params.robust_default_scale)
+    gn = _lib.GnParams(reg.params.gn_lambda, 0.0, 0.0)
+    nlog = C.c_size_t(0)
+    log_ptr = L.sp_internal_align_searched_log(sp._ptr(ws), C.byref(nlog))
+    log_off = log_ptr - ws.data_ptr()
+    us = np.zeros((reps, ITERS_PER_ALIGN))
+    for r in range(reps):
+        T_dev.copy_(T_ident)
+        reg._psrc.prepare(prep, reg._bench_source, T_dev, reg._bench_sort_mode)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(ITERS_PER_ALIGN + 1)]
+        torch.cuda._sleep(3_000_000)  # ~1.5 ms: the 20 launches + 21 events are all enqueued before the first one starts
+        ev[0].record()
+        for k in range(ITERS_PER_ALIGN):
+            _lib.check(L.sp_gicp_align_step(prep._h, reg._psrc._h, sp._ptr(T_dev), C.byref(fp), C.byref(gn), k, 0, None,
+                                            None, sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+            ev[k + 1].record()
+        _lib.check(L.sp_gicp_align_finish(reg._psrc._h, sp._ptr(T_dev), C.byref(gn), ITERS_PER_ALIGN - 1, 0, sp._ptr(lin),
+                                          sp._ptr(delta), None, sp._ptr(ws), ws.numel(), sp._stream()))
+        torch.cuda.synchronize()
+        us[r] = [1e3 * ev[k].elapsed_time(ev[k + 1]) for k in range(ITERS_PER_ALIGN)]
+    searched = ws[log_off:log_off + 4 * ITERS_PER_ALIGN].view(torch.int32).cpu().numpy().astype(np.int64)
+    med = np.median(us, axis=0)
+    launches = [{"k": k, "us": round(float(med[k]), 2), "searched_points": int(searched[k])} for k in range(ITERS_PER_ALIGN)]
+    classes = {}
+    for name, sel in (("searching", searched > 0.01 * n), ("steady", searched <= 0.01 * n)):
+        if not sel.any():
+            continue
+        t = float(med[sel].mean()) * 1e-6
+        traffic = class_traffic(name)
+        classes[name] = {"launches": int(sel.sum()), "mean_us": round(t * 1e6, 2),
+                         "algorithmic_bytes_per_launch": BYTES_ITER * n,
+                         "frac_of_hbm_peak_algorithmic": BYTES_ITER * n / t / 1e9 / HBM_PEAK_GBS,
+                         "measured_hbm_bytes_per_launch": traffic,
+                         "frac_of_hbm_peak_measured_traffic": (traffic / t / 1e9 / HBM_PEAK_GBS) if traffic else None}
+    return launches, classes
+
+
+def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reps=31):
+    """What a caller of align() gets: ONE alignment with the reference's default convergence criteria (1e-3 / 1e-3,
+    registration_params.hpp:94-96) from the identity guess, timed whole (source preparation + max_iterations launches, the
+    ones after convergence returning at once, + finish) with HIP events; correspondences/s = points x executed iterations
+    / that time. Median over `reps` alignments."""
+    p = sp.RegistrationParams(reg_type="GICP", optimization_method="GN", max_iterations=ITERS_PER_ALIGN)
+    reg = sp.Registration(p)
+    ms = []
+    for _ in range(reps + 2):
+        T_dev.copy_(T_ident)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reg.align_fused_loop(S, prep, T_dev=T_dev, delta_dev=delta, prepare=True, sort_by_cell=sort_mode)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    ms = float(np.median(ms[2:]))
+    iters = int(reg._iters_dev[0])
+    return {"criteria_rotation": p.criteria_rotation, "criteria_translation": p.criteria_translation,
+            "iterations_executed": iters, "converged": bool(float(delta[6]) > 0.5), "ms_per_alignment": ms,
+            "correspondences_per_s": n * iters / (ms * 1e-3), "alignments_timed": reps,
+            "note": "includes the per-alignment source preparation and the launches after convergence (they return at once)"}
 
 
 def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n, sort_mode, reps=3):
@@ -288,11 +389,12 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
                                              sp._ptr(ws), ws.numel(), sp._stream()))
 
         reg.align_fused_loop(S, prep, iterations=0, T_dev=T_dev, delta_dev=delta, prepare=True, sort_by_cell=sort_mode)
+        reg._bench_source, reg._bench_sort_mode = S, sort_mode
         align_launches()
         torch.cuda.synchronize()
         # (a) the 20 per-iteration launches of one alignment, back to back, without the finish kernel: every launch
         #     after the first starts from the pose the previous one's partial sums give, exactly as in the timed loop
-        L.sp_debug_set_fused_stage_mask(1)
+        reg._set_source_option("stage_mask", 1)
         T_dev.copy_(T_ident)
         torch.cuda.synchronize()
         reps_a = 5
@@ -314,11 +416,11 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
                                             "linearise, workgroup reduction; mean "
                                             "over the 20 launches of an alignment started at the identity"}
         # (b) the finish kernel alone
-        L.sp_debug_set_fused_stage_mask(2)
+        reg._set_source_option("stage_mask", 2)
         align_launches()
         torch.cuda.synchronize()
         ms2 = timed(align_launches)
-        L.sp_debug_set_fused_stage_mask(3)
+        reg._set_source_option("stage_mask", 3)
         res["align_finish_kernel"] = {"ms": ms2, "bytes": 256 * 128, "GBps": 256 * 128 / (ms2 * 1e-3) / 1e9,
                                       "per_iteration": False,
                                       "note": "once per alignment (incl. a 64-byte pose copy): last iteration's partial "

@@ -326,20 +326,6 @@ float* sp_gicp_align_rows(void* workspace, int k, size_t* n_floats_out);
 int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn, int last_k,
                          int rows_all_reduced, sp_linearized* lin_out, float* delta_out8, uint32_t* iterations_out,
                          void* workspace, size_t workspace_bytes, void* stream);
-/* Tuning hook, not part of the stable surface: NN walk used inside the fused kernel
- * (-1 automatic: 2x2x2 fast path iff the source is cell-sorted; 0 ring walk; 1 fast path). */
-void sp_debug_set_fused_fast_nn(int mode);
-/* Measurement hook: launches issued by sp_gicp_iteration_fused / sp_gicp_align_fused (bit 0 = per-iteration kernel,
- * bit 1 = final reduce + solve / finish kernel). */
-void sp_debug_set_fused_stage_mask(int mask);
-/* Tuning hook: 1 (default) carry a correspondence to the next iteration when it is provably unchanged (the query is
- * closer to its previous winner than half that winner's distance to its nearest other target point); 0 always search.
- * Takes effect at the next sp_gicp_target_update / sp_gicp_source_prepare. Results are identical either way. */
-void sp_debug_set_fused_reuse(int on);
-/* Tuning hook: self-kNN kernel (0 chosen by k, default: lane per point for k <= 10, wave-cooperative above;
- * 1 LDS-tile kernel (k <= 10); 2 wave-cooperative kernel). Results are identical. */
-void sp_debug_set_self_knn_mode(int mode);
-
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
  * iteration loop can stay on the stream with no host round trip:
  *   delta = LDLT(H + lambda*I).solve(-b);  T <- T * se3_exp(delta);  delta_out[0..5] = delta,

@@ -30,7 +30,7 @@ def run_pass(counter):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "40", "--warmup", "20"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "40", "--warmup", "20", "--repeats", "3"]
     subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return read_pass(counter)
 
@@ -76,14 +76,20 @@ def main():
             # 2 x 47.4 MiB = 99.4 MB against the 96 B/point the kernel is known to stream). Launches that search (the first
             # poses of an alignment: cache rows rewritten, WRITE_SIZE in the tens of MiB) are gather-shaped: calibrated
             # factor. Both in KiB as the counters report.
-            steady = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w) if b < 1024.0]
-            search = [(GATHER_FACTOR * a + b) * 1024.0 for a, b in zip(f, w) if b >= 1024.0]
+            # (a searched point rewrites its 48-byte cache row: 480 KiB of writes = 1 % of 1M points searched, the same
+            # threshold bench.py's launch_classes uses on the device-side searched-point count)
+            steady = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w) if b < 480.0]
+            search = [(GATHER_FACTOR * a + b) * 1024.0 for a, b in zip(f, w) if b >= 480.0]
             allb = steady + search
             out[key] = {"launches": len(allb), "hbm_bytes_per_launch": sum(allb) / len(allb),
                         "steady_state_launches": len(steady),
                         "steady_state_hbm_bytes_per_launch": sum(steady) / max(len(steady), 1),
                         "searching_launches": len(search),
                         "searching_hbm_bytes_per_launch": sum(search) / max(len(search), 1),
+                        "classes": {"steady": {"launches": len(steady),
+                                               "hbm_bytes_per_launch": sum(steady) / max(len(steady), 1)},
+                                    "searching": {"launches": len(search),
+                                                  "hbm_bytes_per_launch": sum(search) / max(len(search), 1)}},
                         "FETCH_SIZE_KiB_per_launch": sum(f) / len(f), "WRITE_SIZE_KiB_per_launch": sum(w) / len(w),
                         "correction": "steady-state launches: FETCH_SIZE x 2 (wide coalesced stream, guide's gfx950 rule); "
                                       "searching launches: FETCH_SIZE x 1.13 (gather-shaped, calibrated); WRITE_SIZE exact"}

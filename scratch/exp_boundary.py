@@ -28,7 +28,7 @@ for margin in (0.0, 0.5, 1.0):
     reg.align_fused_loop(S,prep,iterations=20,T_dev=Tid.clone(),delta_dev=delta,sort_by_cell="presorted")
     ws,lin=reg._buffers(S.points.device); fp=reg._factor_params(10.0); gn=_lib.GnParams(1.0,0.0,0.0)
     it=torch.zeros(1,dtype=torch.int32,device='cuda')
-    L.sp_debug_set_fused_stage_mask(1)
+    reg._set_source_option("stage_mask", 1)
     def run(k):
         def f():
             reg._psrc.prepare(prep,S,Tid,"presorted")
@@ -37,6 +37,6 @@ for margin in (0.0, 0.5, 1.0):
         return f
     t0=timed(run(0) if False else (lambda: (reg._psrc.prepare(prep,S,Tid,"presorted"), Tid.clone())))
     t1=timed(run(1)); t2=timed(run(2))
-    L.sp_debug_set_fused_stage_mask(3)
+    reg._set_source_option("stage_mask", 3)
     ns=int(keep.sum())
     print("source margin %.1f m inside the target box: %d points ; launch 0: %.1f us (%.1f us per 1M points) ; launch 1: %.1f us (%.1f per 1M)"%(margin,ns,t1-t0,(t1-t0)*1e6/ns,t2-t1,(t2-t1)*1e6/ns),flush=True)

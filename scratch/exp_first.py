@@ -32,11 +32,11 @@ for ppc in [float(a) for a in sys.argv[1:]] or [0.5]:
     for its,Td in poses:
         out=[]
         for mask,name in ((1,"full"),(5,"NN staged"),(17,"NN fast+ring"),(9,"math only")):
-            L.sp_debug_set_fused_stage_mask(mask)
+            reg._set_source_option("stage_mask", mask)
             out.append("%s %.1f"%(name,timed(lambda: it(Td))))
-        L.sp_debug_set_fused_stage_mask(1)
+        reg._set_source_option("stage_mask", 1)
         iters_dev=torch.zeros(1,dtype=torch.int32,device='cuda'); gn=_lib.GnParams(1.0,0.0,0.0)
         def al(Td=Td): _lib.check(L.sp_gicp_align_fused(prep._h,reg._psrc._h,sp._ptr(Td),C.byref(fp),C.byref(gn),1,None,None,sp._ptr(lin),sp._ptr(delta),sp._ptr(iters_dev),sp._ptr(ws),ws.numel(),sp._stream()))
         out.append("align-kernel(no prologue) %.1f"%timed(al))
         print("ppc %.2f pose after %2d iterations: "%(ppc,its)+" | ".join(out)+" us",flush=True)
-    L.sp_debug_set_fused_stage_mask(3)
+    reg._set_source_option("stage_mask", 3)

@@ -21,7 +21,7 @@ for ppc in (0.5,1.0,2.0,4.0):
   prep=sp.PreparedTarget(grid,Tg.covs)
   for sort in (False,True):
     for fast in (0,1):
-        L.sp_debug_set_fused_fast_nn(fast)
+        reg._set_source_option("fast_nn", fast)
         reg=sp.Registration(p)
         Tid=dev(np.eye(4,dtype=np.float32).reshape(-1)); Td=Tid.clone(); delta=torch.zeros(8,device='cuda')
         def one_align():
@@ -30,4 +30,4 @@ for ppc in (0.5,1.0,2.0,4.0):
         tp=timed(lambda: reg._psrc.prepare(prep,S,Tid,sort))
         t1=timed(lambda: reg.align_fused_loop(S,prep,iterations=1,T_dev=Td,delta_dev=delta,prepare=False))
         print("ppc %.1f sort %d fast %d: alignment %.0f us = %.1f us/iter | src prepare %.1f us | converged iteration %.1f us | err %.1e"%(ppc,sort,fast,t,t/20,tp,t1,np.abs(reg.T_from_device(Td)-T).max()),flush=True)
-L.sp_debug_set_fused_fast_nn(-1)
+reg._set_source_option("fast_nn", -1)

@@ -32,6 +32,6 @@ def one_align():
     Td.copy_(Tid); reg.align_fused_loop(S,prep,iterations=20,T_dev=Td,delta_dev=delta)
 t=timed(one_align,reps=10); print("alignment %.0f us = %.1f us/iter, err %.1e"%(t,t/20,np.abs(reg.T_from_device(Td)-T).max()))
 for mask,name in ((1,"full kernel"),(5,"NN only"),(9,"math+stream only (no search)")):
-    L.sp_debug_set_fused_stage_mask(mask)
+    reg._set_source_option("stage_mask", mask)
     print("%-32s %.1f us"%(name, timed(lambda: it(None))))
-L.sp_debug_set_fused_stage_mask(3)
+reg._set_source_option("stage_mask", 3)

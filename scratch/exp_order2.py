@@ -27,7 +27,7 @@ def cell_order(P, ppc):
     return torch.argsort(key,stable=True)
 def run(name,Sx,sort,fast):
     reg=sp.Registration(p)
-    L.sp_debug_set_fused_fast_nn(fast)
+    reg._set_source_option("fast_nn", fast)
     def one():
         Td=Tid.clone(); reg.align_fused_loop(Sx,prep,iterations=20,T_dev=Td,delta_dev=delta,sort_by_cell=sort); return Td
     Td=one(); err=np.abs(reg.T_from_device(Td)-T).max()
@@ -41,4 +41,4 @@ for ppc in (8.0,2.0,0.5):
     perm=cell_order(S.points,ppc)
     S2=sp.PointCloudShared(S.points[perm].contiguous(),covs=S.covs[perm].contiguous())
     run("source-grid order ppc %.1f, fast nn"%ppc,S2,False,1)
-L.sp_debug_set_fused_fast_nn(-1)
+reg._set_source_option("fast_nn", -1)

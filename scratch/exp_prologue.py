@@ -24,7 +24,7 @@ Tid=dev(np.eye(4,dtype=np.float32).reshape(-1)); delta=torch.zeros(8,device='cud
 Td=Tid.clone(); reg.align_fused_loop(S,prep,iterations=20,T_dev=Td,delta_dev=delta,sort_by_cell="presorted")
 ws,lin=reg._buffers(S.points.device); fp=reg._factor_params(10.0); gn=_lib.GnParams(1.0,0.0,0.0)
 it=torch.zeros(1,dtype=torch.int32,device='cuda')
-L.sp_debug_set_fused_stage_mask(1)
+reg._set_source_option("stage_mask", 1)
 def run(k):
     def f():
         Tc=Td.clone()
@@ -33,10 +33,10 @@ def run(k):
 t=[timed(run(k)) for k in (1,2,3,5,9)]
 print("launch counts 1,2,3,5,9 at the converged pose: %s us"%[round(x,1) for x in t])
 print("per extra launch (with prologue): %.1f us ; first launch (no prologue): %.1f us"%((t[4]-t[0])/8, t[0]))
-L.sp_debug_set_fused_stage_mask(3)
+reg._set_source_option("stage_mask", 3)
 if os.environ.get("SP_TM"):
     import struct
-    L.sp_debug_set_fused_stage_mask(1)
+    reg._set_source_option("stage_mask", 1)
     run(4)(); torch.cuda.synchronize()
     raw = ws.cpu().numpy().tobytes()
     off = 2 * 256 * 32 * 4 + 2 * 112
@@ -45,7 +45,7 @@ if os.environ.get("SP_TM"):
 
 if os.environ.get("SP_TM0"):
     import struct
-    L.sp_debug_set_fused_stage_mask(1)
+    reg._set_source_option("stage_mask", 1)
     reg._psrc.prepare(prep, S, Tid, "presorted")
     Tc = Tid.clone()
     _lib.check(L.sp_gicp_align_fused(prep._h,reg._psrc._h,sp._ptr(Tc),C.byref(fp),C.byref(gn),1,None,None,sp._ptr(lin),sp._ptr(delta),sp._ptr(it),sp._ptr(ws),ws.numel(),sp._stream()))

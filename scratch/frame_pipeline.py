@@ -36,9 +36,9 @@ print("self kNN k=3 on the ppc 6 grid    %.3f ms"%wall(lambda: g6.self_knn(3,wan
 g2=sp.GridKNN.build(tp,points_per_cell=2.0)
 print("self kNN k=3 on a ppc 2 grid      %.3f ms"%wall(lambda: g2.self_knn(3,want_knn=True,want_covs=False)))
 from sycl_points_amd import _lib
-L=_lib.lib(); L.sp_debug_set_self_knn_mode(1)
+[x._set_option('self_knn_mode',1) for x in (g,g2,g6)]
 print("mode 1 (lane per query): k=3 ppc 0.5 %.3f ms | ppc 2 %.3f ms | ppc 6 %.3f ms"%(wall(lambda: g.self_knn(3,want_knn=True,want_covs=False)),wall(lambda: g2.self_knn(3,want_knn=True,want_covs=False)),wall(lambda: g6.self_knn(3,want_knn=True,want_covs=False))))
 a=g.self_knn(3,want_knn=True,want_covs=False)[0]
-L.sp_debug_set_self_knn_mode(0)
+[x._set_option('self_knn_mode',0) for x in (g,g2,g6)]
 b=g.self_knn(3,want_knn=True,want_covs=False)[0]
 print("same neighbours:", bool((a.indices==b.indices).all()), bool((a.distances==b.distances).all()))

@@ -16,9 +16,9 @@ for ppc in (2.0,6.0):
     for k in (3,6,10):
         out=[]; res=[]
         for mode in (0,1,2):
-            L.sp_debug_set_self_knn_mode(mode)
+            g._set_option('self_knn_mode',mode)
             out.append(t(lambda: g.self_knn(k,want_knn=True,want_covs=True)))
             r=g.self_knn(k,want_knn=True,want_covs=True); res.append((r[0].indices.clone(),r[0].distances.clone(),r[1].clone()))
-        L.sp_debug_set_self_knn_mode(0)
+        g._set_option('self_knn_mode',0)
         same=all(torch.equal(res[0][j],res[m][j]) for m in (1,2) for j in range(3))
         print("ppc %.1f k=%2d  kNN+cov: lane %.3f ms  tile %.3f ms  wave %.3f ms   identical: %s"%(ppc,k,out[0],out[1],out[2],same))

@@ -111,10 +111,6 @@ SIGNATURES = {
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_rows": (_vp, [_vp, _i, _vp]),
     "sp_gicp_align_finish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "sp_debug_set_fused_reuse": (None, [_i]),
-    "sp_debug_set_fused_fast_nn": (None, [_i]),
-    "sp_debug_set_self_knn_mode": (None, [_i]),
-    "sp_debug_set_fused_stage_mask": (None, [_i]),
     "sp_gn_update": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp]),
     "sp_gn_update_host": (_i, [_vp, _vp, _f, _f, _f, _vp]),
     "sp_se3_exp_host": (None, [_vp, _vp]),
@@ -126,6 +122,16 @@ SIGNATURES = {
     "sp_map_prior_update_host": (_i, [_vp, _vp, _f, C.c_uint32, _vp, _vp, _vp]),
     "sp_map_prior_apply_host": (_f, [_vp, _vp, _vp, _vp, _vp]),
 }
+
+
+# csrc/sp_internal.h: per-handle measurement / tuning switches, exported for tests/, bench.py and scratch/ — not part of the
+# C ABI, so not in the table above (tests/test_cabi.py checks that the public header does not mention them)
+INTERNAL_SIGNATURES = {
+    "sp_internal_source_option": (_i, [_vp, _i, _i]),
+    "sp_internal_grid_option": (_i, [_vp, _i, _i]),
+    "sp_internal_align_searched_log": (_vp, [_vp, _vp]),
+}
+INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3}
 
 
 def build(force=False):
@@ -153,7 +159,7 @@ def lib():
         import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
 
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(INTERNAL_SIGNATURES.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

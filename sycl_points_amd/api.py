@@ -244,6 +244,10 @@ class GridKNN(KNNBase):
         check(_lib.lib().sp_grid_create(_ptr(p), p.shape[0], cell_size, points_per_cell, _stream(), C.byref(h)))
         return GridKNN(h, p.shape[0], p.device)
 
+    def _set_option(self, name, value):
+        """csrc/sp_internal.h tuning switch of this grid (tests / scratch only)."""
+        check(_lib.lib().sp_internal_grid_option(self._h, _lib.INTERNAL_OPTION[name], int(value)))
+
     def cell_size(self):
         return float(_lib.lib().sp_grid_cell_size(self._h))
 
@@ -577,6 +581,10 @@ class PreparedSource:
         self._h = h
         self.n_max = n_max
 
+    def _set_option(self, name, value):
+        """csrc/sp_internal.h measurement / tuning switch of this prepared source (tests / bench / scratch only)."""
+        check(_lib.lib().sp_internal_source_option(self._h, _lib.INTERNAL_OPTION[name], int(value)))
+
     def prepare(self, prepared_target, source, transT=None, sort_by_cell=True):
         if not source.has_cov():
             raise SpError(2, "[Registration::validate_params] Covariance matrices of source and target must be "
@@ -669,6 +677,21 @@ class Registration:
         self.genz_alpha = 1.0
         self._rot_scale = self.params.rotation_constraint_robust_default_scale
         self._map_prior = MapPriorState()
+        self._psrc = None
+        self._source_options = {}  # csrc/sp_internal.h switches applied to the prepared source (tests / bench only)
+
+    def _set_source_option(self, name, value):
+        self._source_options[name] = int(value)
+        if self._psrc is not None:
+            self._psrc._set_option(name, value)
+
+    def _prepared_source(self, n):
+        if self._psrc is None or self._psrc.n_max < n:
+            self._psrc = PreparedSource(n)
+            for k, v in self._source_options.items():
+                self._psrc._set_option(k, v)
+            return self._psrc, True
+        return self._psrc, False
 
     def set_map_prior_state(self, prev_result, T_pred):
         """registration.hpp:124-126 / MapPrior::update (map_prior.hpp:97-174): call once per frame, after motion
@@ -979,8 +1002,7 @@ class Registration:
             T_dev = torch.from_numpy(_T16(T0).reshape(-1).copy()).to(dev)
         if delta_dev is None:
             delta_dev = torch.zeros(8, dtype=torch.float32, device=dev)
-        if getattr(self, "_psrc", None) is None or self._psrc.n_max < n:
-            self._psrc = PreparedSource(n)
+        if self._prepared_source(n)[1]:
             prepare = True
         if prepare:
             if update_target:

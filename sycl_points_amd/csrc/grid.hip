@@ -26,7 +26,7 @@
 
 void sp_set_error(const char* msg);
 
-static int g_self_knn_mode = 0;  // tuning hook: 0 by k (lane per point for k <= 10, wave-cooperative above), 1 LDS-tile kernel (k <= 10), 2 wave kernel
+#include "sp_internal.h"
 
 // rocPRIM picks a merge sort (about 15 launches, 155 us per 1M pairs) up to 1M items; Onesweep with the key bits
 // actually used (3 passes for a 22-bit cell id) is 3x faster at this size.
@@ -887,13 +887,13 @@ template <int KCAP>
 int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
     const GridDesc g = grid_desc(gr);
     if (hipMemsetAsync(out.todo_count, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
-    if (KCAP <= 10 && g_self_knn_mode == 0) {  // short lists: lane per point, exact without a to-do pass
+    if (KCAP <= 10 && gr->self_knn_mode == 0) {  // short lists: lane per point, exact without a to-do pass
         grid_self_knn_lane_kernel<KCAP><<<div_up(gr->n, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
         return launch_status();
     }
     if (gr->n_units) {
         // lane-per-query tile kernel for short lists (k = 3 on 1M points: 0.70 ms against 1.94 ms; it loses from k = 7 up: scratch/selfknn_modes.py)
-        if (KCAP <= 10 && (g_self_knn_mode == 1 || (g_self_knn_mode == 0 && k <= 6)))
+        if (KCAP <= 10 && (gr->self_knn_mode == 1 || (gr->self_knn_mode == 0 && k <= 6)))
             grid_self_knn_tile_kernel<KCAP><<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
         else
             grid_self_knn_wave_kernel<<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
@@ -1269,4 +1269,9 @@ extern "C" int sp_grid_radius_search(const sp_grid* grid, const float* queries, 
     return launch_status();
 }
 
-extern "C" void sp_debug_set_self_knn_mode(int mode) { g_self_knn_mode = mode; }
+// Per-handle tuning switch (sp_internal.h): exported for tests/ and scratch/ only.
+extern "C" int sp_internal_grid_option(sp_grid* grid, int option, int value) {
+    if (!grid || option != SP_INTERNAL_SELF_KNN_MODE) return SP_ERR_INVALID_ARGUMENT;
+    grid->self_knn_mode = value;
+    return SP_OK;
+}

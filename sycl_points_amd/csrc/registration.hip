@@ -14,9 +14,7 @@
 
 void sp_set_error(const char* msg);
 
-static int g_fused_stage_mask = 3;  // measurement hook: bit 0 = fused kernel, bit 1 = final reduce (+ solve)
-static int g_fused_reuse = 2;  // tuning hook: 0 always search, 1 reuse on the first certificate, 2 also the second
-static int g_fused_fast_nn = -1;  // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
+#include "sp_internal.h"
 
 namespace sp {
 namespace {
@@ -289,18 +287,22 @@ struct KParams {
 // Sum NV lane values over the workgroup in a fixed order and let lane e < NV of wave 0 write partial[e].
 // count_as_float: the count slot holds the VALUE as a float (exact below 2^24) instead of the uint32 bit pattern, so
 // that partial rows can be summed across ranks by a float all-reduce.
+// `extra` is a second integer (the number of points this launch had to search for, fused kernels only); its sum goes to slot
+// NV + 1 as a float VALUE (exact below 2^24), so it survives the float row sums of the next prologue / an all-reduce.
 template <int NV, int BLOCK = kBlock>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cnt, float* __restrict__ partial,
-                                                   bool count_as_float = false) {
+                                                   bool count_as_float = false, unsigned extra = 0) {
     __shared__ float red[BLOCK / kWave][kPartial];
     const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int e = 0; e < NV; ++e) acc[e] = wave_sum_to_lane63(acc[e]);
     cnt = wave_sum_u32_to_lane63(cnt);
+    extra = wave_sum_u32_to_lane63(extra);
     if (lane == kWave - 1) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) red[wave][e] = acc[e];
         red[wave][NV] = __uint_as_float(cnt);
+        red[wave][NV + 1] = __uint_as_float(extra);
     }
     __syncthreads();
     if (threadIdx.x < NV) {
@@ -313,6 +315,11 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cn
 #pragma unroll
         for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][NV]);
         partial[NV] = count_as_float ? (float)c : __uint_as_float(c);
+    } else if (threadIdx.x == NV + 1) {
+        unsigned c = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][NV + 1]);
+        partial[NV + 1] = (float)c;
     }
 }
 
@@ -753,7 +760,7 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
 // One source point of the fused iteration: q = T p -> exact NN on the target grid -> linearise -> accumulate.
 template <int LOSS, bool FAST_NN, int DBG>
 __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
-                                            unsigned& cnt) {
+                                            unsigned& cnt, unsigned& searched) {
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
     float qx, qy, qz;
     transform_point(T, s.x, s.y, s.z, qx, qy, qz);
@@ -797,6 +804,7 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
             }
         }
         if (!hit) {
+            ++searched;
             nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
             if (row) {
                 float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;  // nothing found: radius 0, searched again next time
@@ -833,10 +841,10 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
     float acc[kAcc - 1];
 #pragma unroll
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
-    unsigned cnt = 0;
+    unsigned cnt = 0, searched = 0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock)
-        fused_point<LOSS, FAST_NN, DBG>(P, T, i, acc, cnt);
-    block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
+        fused_point<LOSS, FAST_NN, DBG>(P, T, i, acc, cnt, searched);
+    block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -848,13 +856,15 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
 // Once is_converged() holds, the remaining launches return immediately (the reference breaks out of its loop).
 constexpr int kAlignBlock = 1024;      // 16 waves: one workgroup per CU at 4 waves/SIMD -> 256 partial rows
 constexpr int kAlignMaxBlocks = 256;
+constexpr int kSearchedLog = 64;       // launches of an alignment whose searched-point counts are kept (measurement)
 
 struct AlignState {
     float T[16];
     float delta[8];
     unsigned converged;   // is_converged() held for the step that produced T
     unsigned iterations;  // Gauss-Newton steps applied so far
-    unsigned pad[2];
+    unsigned searched;    // source points the last finished launch had to search for (the others reused their correspondence)
+    unsigned pad;
 };
 
 struct AlignArgs {
@@ -867,6 +877,8 @@ struct AlignArgs {
     float lambda, crit_rot, crit_trans;
     sp_linearized* lin_out;      // system of the last finished iteration (may be null)
     int count_is_float;          // partial rows are all-reduced between launches (multi-GPU): counts travel as floats
+    unsigned* searched_log;      // [launch index] -> points that launch searched for (written by the next launch / finish)
+    int k;                       // index of this launch in its alignment
 };
 
 // Finishes iteration k-1 (or loads the initial pose) and leaves the pose in sT (LDS). Returns false when this launch
@@ -904,6 +916,8 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
                 for (int i = 0; i < 8; ++i) so->delta[i] = sdelta[i];
                 so->converged = sconv;
                 so->iterations = sprev[1] + 1;
+                so->searched = (unsigned)red[0][kAcc];
+                if (A.searched_log && A.k > 0 && A.k <= kSearchedLog) A.searched_log[A.k - 1] = so->searched;
                 if (A.lin_out) *A.lin_out = slin;
             }
         }
@@ -920,6 +934,7 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
         for (int i = 0; i < 8; ++i) so->delta[i] = 0.0f;
         so->converged = 0;
         so->iterations = 0;
+        so->searched = 0;
     }
     return true;
 }
@@ -947,7 +962,7 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
         T.t[r] = uniform(T.t[r]);
     }
     float acc[kAcc - 1];
-    unsigned cnt = 0;
+    unsigned cnt = 0, searched = 0;
     const unsigned stride = gridDim.x * kAlignBlock;
 #pragma unroll
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
@@ -956,11 +971,12 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     unsigned tile = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-        fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt);
+        fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt, searched);
 #ifdef SP_KERNEL_TIMING
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) tm[17 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime();  // point loop done
 #endif
-    block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, A.count_is_float != 0);
+    block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, A.count_is_float != 0,
+                                              searched);
 #ifdef SP_KERNEL_TIMING
     if (blockIdx.x == 0 && threadIdx.x == 0) tm[33] = __builtin_amdgcn_s_memtime();  // workgroup reduction done
 #endif
@@ -974,7 +990,8 @@ __global__ __launch_bounds__(kFinalThreads) void align_finish_kernel(const float
                                                                      sp_linearized* __restrict__ lin_out,
                                                                      float* __restrict__ delta_out8,
                                                                      uint32_t* __restrict__ iterations_out,
-                                                                     int count_is_float) {
+                                                                     int count_is_float, unsigned* searched_log,
+                                                                     int last_k) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ sp_linearized slin;
     __shared__ float sT[16];
@@ -992,6 +1009,7 @@ __global__ __launch_bounds__(kFinalThreads) void align_finish_kernel(const float
             unpack_totals(red[0], kAcc - 1, &slin);
             gn_update_impl(&slin, sT, lambda, crit_rot, crit_trans, sdelta, false, ldlt_ws);
             if (lin_out) *lin_out = slin;
+            if (searched_log && last_k < kSearchedLog) searched_log[last_k] = (unsigned)red[0][kAcc];
             ++iters;
         }
 #pragma unroll
@@ -1212,6 +1230,10 @@ struct sp_gicp_source {
     const sp_gicp_target* cache_target = nullptr;  // the copies are of this target ...
     unsigned long long cache_version = 0;           // ... at this covariance version
     bool sorted = false;
+    // measurement / tuning switches (sp_internal.h; not part of the C ABI), per prepared source:
+    int opt_stage_mask = 3;  // bit 0 = per-iteration kernel, bit 1 = final reduce (+ solve) / finish kernel
+    int opt_reuse = 2;       // 0 always search, 1 reuse on the first certificate, 2 also the second
+    int opt_fast_nn = -1;    // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -1235,8 +1257,7 @@ extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, v
     ++t->version;
     if (t->n == 0) return SP_OK;
     prepare_cov_kernel<<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(tgt_covs), (unsigned)t->n, t->grid->d_pts, nullptr, t->covp,
-        g_fused_reuse ? t->rho2 : nullptr);
+        reinterpret_cast<const float4*>(tgt_covs), (unsigned)t->n, t->grid->d_pts, nullptr, t->covp, t->rho2);
     return launch_status();
 }
 extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream,
@@ -1389,7 +1410,7 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
     P.tpts = target->grid->d_pts;
     P.tstart = target->grid->d_start;
     P.tcovp = target->covp;
-    P.tnb = g_fused_reuse > 1 ? target->nb : nullptr;
+    P.tnb = source->opt_reuse > 1 ? target->nb : nullptr;
     P.g = grid_desc(target->grid);
     P.n = (unsigned)n;
     P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
@@ -1399,7 +1420,7 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
         for (int i = 0; i < 16; ++i) P.T_val.m[i] = transT[i];
     P.T_dev = transT_on_device ? transT : nullptr;
     P.perm = source->perm;
-    P.ccache = (g_fused_reuse && target->rho2) ? source->ccache : nullptr;
+    P.ccache = (source->opt_reuse && target->rho2) ? source->ccache : nullptr;
     P.cache_valid = (source->cache_valid && source->cache_target == target && source->cache_version == target->version) ? 1 : 0;
     P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
     P.nn_d2 = nn_d2_out;
@@ -1434,17 +1455,17 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         return SP_ERR_INVALID_ARGUMENT;
     }
     const FusedParams P = make_fused_params(target, source, params, transT, transT_on_device, nn_idx_out, nn_d2_out);
-    const bool fills_cache = P.ccache != nullptr && (g_fused_stage_mask & 1) && !(g_fused_stage_mask & 28);
+    const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1) && !(source->opt_stage_mask & 28);
     const unsigned grid = reduce_grid(n);
     float* partials = static_cast<float*>(workspace);
     // Unsorted lanes touch unrelated cells: the ring walk (fewest cache lines per query) wins. Cell-sorted lanes share
     // their lines: the branch-light 2x2x2 walk wins (profiles/README.md, r01_c).
-    const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
+    const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
 #define SP_LAUNCH_FUSED(L)                                                              \
-    if (!(g_fused_stage_mask & 1)) {}                                                   \
-    else if (g_fused_stage_mask & 4) gicp_fused_kernel<LOSS_NONE, true, 1><<<grid, kBlock, 0, st>>>(P, partials);   \
-    else if (g_fused_stage_mask & 8) gicp_fused_kernel<LOSS_NONE, true, 2><<<grid, kBlock, 0, st>>>(P, partials);   \
-    else if (g_fused_stage_mask & 16) gicp_fused_kernel<LOSS_NONE, true, 3><<<grid, kBlock, 0, st>>>(P, partials);   \
+    if (!(source->opt_stage_mask & 1)) {}                                                   \
+    else if (source->opt_stage_mask & 4) gicp_fused_kernel<LOSS_NONE, true, 1><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (source->opt_stage_mask & 8) gicp_fused_kernel<LOSS_NONE, true, 2><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (source->opt_stage_mask & 16) gicp_fused_kernel<LOSS_NONE, true, 3><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else gicp_fused_kernel<L, false><<<grid, kBlock, 0, st>>>(P, partials)
     switch (params->robust_type) {
@@ -1459,21 +1480,23 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     if (fills_cache) source->cache_valid = true;
     GnArgs ga{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
     if (gn) ga = GnArgs{transT, gn->lambda, gn->crit_rotation, gn->crit_translation, delta_out8};
-    if (g_fused_stage_mask & 2) final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
+    if (source->opt_stage_mask & 2) final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
     return launch_status();
 }
 // Measurement hook (not part of the stable surface): which of the two launches sp_gicp_iteration_fused issues.
 namespace sp {
 namespace {
-struct AlignWs {  // workspace: partial rows A | partial rows B | state A | state B
+struct AlignWs {  // workspace: partial rows A | partial rows B | state A | state B | (timing stamps) | searched log
     float* part[2];
     AlignState* state;
+    unsigned* searched_log;  // kSearchedLog entries
 };
 AlignWs align_ws(void* workspace) {
     AlignWs w;
     w.part[0] = static_cast<float*>(workspace);
     w.part[1] = w.part[0] + (size_t)kAlignMaxBlocks * kPartial;
     w.state = reinterpret_cast<AlignState*>(w.part[1] + (size_t)kAlignMaxBlocks * kPartial);
+    w.searched_log = reinterpret_cast<unsigned*>(w.state + 8);  // (state + 2 .. : stamps of the SP_KERNEL_TIMING build)
     return w;
 }
 unsigned align_grid(size_t n) {
@@ -1518,9 +1541,9 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
             return SP_ERR_HIP;
     }
     const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
-    const bool fills_cache = P.ccache != nullptr && (g_fused_stage_mask & 1);
+    const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1);
     const unsigned grid = align_grid(n);
-    const bool fast = g_fused_fast_nn < 0 ? source->sorted : (g_fused_fast_nn != 0);
+    const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
     AlignArgs A;
     A.T_init = transT_device;
     A.state_in = &w.state[(k + 1) & 1];
@@ -1533,9 +1556,11 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     A.crit_trans = gn->crit_translation;
     A.lin_out = lin_out;
     A.count_is_float = rows_all_reduced ? 1 : 0;
+    A.searched_log = w.searched_log;
+    A.k = k;
     float* out = w.part[k & 1];
 #define SP_LAUNCH_ALIGN(L)                                                                            \
-    if (!(g_fused_stage_mask & 1)) {}                                                                 \
+    if (!(source->opt_stage_mask & 1)) {}                                                                 \
     else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);              \
     else gicp_align_kernel<L, false><<<grid, kAlignBlock, 0, st>>>(P, A, out)
     switch (params->robust_type) {
@@ -1569,10 +1594,11 @@ extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_
     }
     const AlignWs w = align_ws(workspace);
     const unsigned rows = rows_all_reduced ? (unsigned)kAlignMaxBlocks : align_grid(source->n);
-    if (g_fused_stage_mask & 2)
+    if (source->opt_stage_mask & 2)
         align_finish_kernel<<<1, kFinalThreads, 0, st>>>(w.part[last_k & 1], rows, &w.state[last_k & 1], gn->lambda,
                                                          gn->crit_rotation, gn->crit_translation, transT_device, lin_out,
-                                                         delta_out8, iterations_out, rows_all_reduced ? 1 : 0);
+                                                         delta_out8, iterations_out, rows_all_reduced ? 1 : 0,
+                                                         w.searched_log, last_k);
     return launch_status();
 }
 
@@ -1598,7 +1624,19 @@ extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_s
                                 workspace, workspace_bytes, stream);
 }
 
-extern "C" void sp_debug_set_fused_stage_mask(int mask) { g_fused_stage_mask = mask; }
-extern "C" void sp_debug_set_fused_reuse(int on) { g_fused_reuse = on; }
-// Tuning hook (not part of the stable surface): choose the NN walk used inside the fused kernel.
-extern "C" void sp_debug_set_fused_fast_nn(int mode) { g_fused_fast_nn = mode; }
+// Measurement (sp_internal.h): entry k = source points launch k of the last alignment searched for (the rest reused their
+// correspondence); entries of launches that did not run (converged earlier) keep their previous value.
+extern "C" const uint32_t* sp_internal_align_searched_log(void* workspace, size_t* n_entries_out) {
+    if (n_entries_out) *n_entries_out = sp::kSearchedLog;
+    return workspace ? sp::align_ws(workspace).searched_log : nullptr;
+}
+// Per-handle measurement / tuning switches (sp_internal.h): exported for tests/, bench.py and scratch/ only.
+extern "C" int sp_internal_source_option(sp_gicp_source* s, int option, int value) {
+    if (!s) return SP_ERR_INVALID_ARGUMENT;
+    switch (option) {
+        case SP_INTERNAL_FUSED_STAGE_MASK: s->opt_stage_mask = value; return SP_OK;
+        case SP_INTERNAL_FUSED_REUSE: s->opt_reuse = value; s->cache_valid = false; return SP_OK;
+        case SP_INTERNAL_FUSED_FAST_NN: s->opt_fast_nn = value; return SP_OK;
+    }
+    return SP_ERR_INVALID_ARGUMENT;
+}

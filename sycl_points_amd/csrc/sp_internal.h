@@ -1,0 +1,41 @@
+/*
+ * Internal measurement / tuning switches of libsycl_points_amd.so — NOT part of the C ABI (include/sycl_points_amd.h).
+ *
+ * They exist for tests/ (bit-identity of every shortcut against the path without it), bench.py (timing one launch of a
+ * pair) and scratch/. Every switch lives in the handle it acts on: nothing here is process-global, so a caller that never
+ * includes this header can never be affected by one that does. Results are identical under every setting except
+ * SP_INTERNAL_FUSED_STAGE_MASK, which drops launches.
+ */
+#ifndef SP_INTERNAL_H
+#define SP_INTERNAL_H
+
+#include "../../include/sycl_points_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    /* sp_gicp_source: launches issued by sp_gicp_iteration_fused / sp_gicp_align_* for this source
+     * (bit 0 = per-iteration kernel, bit 1 = final reduce + solve / finish kernel; bits 2..4 timing experiments). Default 3. */
+    SP_INTERNAL_FUSED_STAGE_MASK = 0,
+    /* sp_gicp_source: 2 (default) carry a correspondence to the next iteration when either certificate proves it unchanged,
+     * 1 first certificate only, 0 always search. Takes effect at once (the cache is dropped). */
+    SP_INTERNAL_FUSED_REUSE = 1,
+    /* sp_gicp_source: NN walk inside the fused kernel: -1 (default) 2x2x2 fast path iff the source is cell-sorted,
+     * 0 ring walk, 1 fast path. */
+    SP_INTERNAL_FUSED_FAST_NN = 2,
+    /* sp_grid: self-kNN kernel: 0 (default) chosen by k, 1 LDS-tile kernel (k <= 10), 2 wave-cooperative kernel. */
+    SP_INTERNAL_SELF_KNN_MODE = 3
+};
+
+int sp_internal_source_option(sp_gicp_source* source, int option, int value);
+int sp_internal_grid_option(sp_grid* grid, int option, int value);
+/* Device pointer to the per-launch log of an sp_gicp_align_* workspace: entry k = number of source points launch k had to
+ * search for (the others reused their previous correspondence by certificate). *n_entries_out = entries kept (64). */
+const uint32_t* sp_internal_align_searched_log(void* workspace, size_t* n_entries_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SP_INTERNAL_H */

@@ -33,6 +33,9 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in the header but not exported: {missing}"
     assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
     assert _lib.lib().sp_abi_version() == 2
+    # measurement / tuning switches are per handle and live in csrc/sp_internal.h, not in the public header
+    assert not [s for s in syms if s.startswith(("sp_debug", "sp_internal"))]
+    assert all(hasattr(lib, s) for s in _lib.INTERNAL_SIGNATURES)
 
 
 def test_sp_linearized_is_192_bytes():

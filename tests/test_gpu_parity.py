@@ -902,20 +902,17 @@ def test_fused_iteration_matches_oracle_linear_system(sp, orc, gicp20k, loss, so
     reg = sp.Registration(sp.RegistrationParams(max_correspondence_distance=0.05, robust_type=loss,
                                                 criteria_translation=0.0, criteria_rotation=0.0))
     L = sp._lib.lib()
-    L.sp_debug_set_fused_fast_nn(1 if fast else 0)
-    try:
-        ws, lin = reg._buffers(S.points.device)
-        psrc = sp.PreparedSource(len(src))
-        psrc.prepare(prep, S, T, sort_by_cell=sort)
-        fp = reg._factor_params(0.5)
-        reg.neighbors.resize(len(src), 1, S.points.device)
-        Tc = np.ascontiguousarray(T.T).reshape(-1)
-        sp.check(L.sp_gicp_iteration_fused(prep._h, psrc._h, Tc.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None,
-                                           sp._ptr(reg.neighbors.indices), sp._ptr(reg.neighbors.distances), sp._ptr(lin),
-                                           None, sp._ptr(ws), ws.numel(), sp._stream()))
-        got = reg._read_lin(lin)
-    finally:
-        L.sp_debug_set_fused_fast_nn(-1)
+    ws, lin = reg._buffers(S.points.device)
+    psrc = sp.PreparedSource(len(src))
+    psrc._set_option("fast_nn", 1 if fast else 0)  # csrc/sp_internal.h: per-handle, nothing to restore
+    psrc.prepare(prep, S, T, sort_by_cell=sort)
+    fp = reg._factor_params(0.5)
+    reg.neighbors.resize(len(src), 1, S.points.device)
+    Tc = np.ascontiguousarray(T.T).reshape(-1)
+    sp.check(L.sp_gicp_iteration_fused(prep._h, psrc._h, Tc.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None,
+                                       sp._ptr(reg.neighbors.indices), sp._ptr(reg.neighbors.distances), sp._ptr(lin),
+                                       None, sp._ptr(ws), ws.numel(), sp._stream()))
+    got = reg._read_lin(lin)
     # correspondences come back in ORIGINAL source order whatever the internal order
     assert np.array_equal(reg.neighbors.indices.cpu().numpy(), idx) and np.array_equal(reg.neighbors.distances.cpu().numpy(), d2)
     H = np.array(got.H, np.float32).reshape(6, 6)
@@ -1017,22 +1014,18 @@ def test_align_fused_stress_shapes_and_parameters(sp, orc, case):
     ref = orc.registration_align(RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=iters,
                                                     robust_type=LOSS[loss], robust_default_scale=scale,
                                                     max_correspondence_distance=max_corr), src, scov, tgt, tcov, init_T=T0)
-    L = sp._lib.lib()
     outs = []
     for reuse in (2, 0):
-        L.sp_debug_set_fused_reuse(reuse)
-        try:
-            S = sp.PointCloudShared(dev(src), covs=dev(scov))
-            Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
-            prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
-            p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters, robust_type=loss,
-                                      robust_default_scale=scale, max_correspondence_distance=max_corr)
-            reg = sp.Registration(p)
-            T_dev, lin, _ = reg.align_fused_loop(S, prep, initial_guess=T0, write_neighbors=True)
-            outs.append((reg.T_from_device(T_dev), reg._read_lin(lin).inlier, lin.cpu().numpy(),
-                         reg.neighbors.indices.cpu().numpy().copy()))
-        finally:
-            L.sp_debug_set_fused_reuse(2)
+        S = sp.PointCloudShared(dev(src), covs=dev(scov))
+        Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+        prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
+        p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters, robust_type=loss,
+                                  robust_default_scale=scale, max_correspondence_distance=max_corr)
+        reg = sp.Registration(p)
+        reg._set_source_option("reuse", reuse)
+        T_dev, lin, _ = reg.align_fused_loop(S, prep, initial_guess=T0, write_neighbors=True)
+        outs.append((reg.T_from_device(T_dev), reg._read_lin(lin).inlier, lin.cpu().numpy(),
+                     reg.neighbors.indices.cpu().numpy().copy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
     assert np.array_equal(outs[0][3], outs[1][3])
     assert outs[0][1] == ref["inlier"]
@@ -1045,23 +1038,19 @@ def test_correspondence_reuse_is_exact(sp, orc, gicp20k):
     previous winner (|q - t| < half of t's distance to its nearest other target point). Every output must be bit-identical
     to the always-search path — also with duplicated target points (radius 0: never reused) and a target with one point."""
     src, scov, tgt, tcov, T_gt = gicp20k
-    L = sp._lib.lib()
     tgt2, tcov2 = np.concatenate([tgt, tgt[:500]]), np.concatenate([tcov, tcov[:500]])  # 500 exact duplicates
     outs = []
     for reuse in (2, 1, 0):
-        L.sp_debug_set_fused_reuse(reuse)
-        try:
-            S = sp.PointCloudShared(dev(src), covs=dev(scov))
-            Tg = sp.PointCloudShared(dev(tgt2), covs=dev(tcov2))
-            grid = sp.GridKNN.build(Tg.points)
-            prep = sp.PreparedTarget(grid, Tg.covs)
-            p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=10)
-            reg = sp.Registration(p)
-            T_dev, lin, delta = reg.align_fused_loop(S, prep, write_neighbors=True)
-            outs.append((T_dev.cpu().numpy(), lin.cpu().numpy(), reg.neighbors.indices.cpu().numpy().copy(),
-                         reg.neighbors.distances.cpu().numpy().copy()))
-        finally:
-            L.sp_debug_set_fused_reuse(2)
+        S = sp.PointCloudShared(dev(src), covs=dev(scov))
+        Tg = sp.PointCloudShared(dev(tgt2), covs=dev(tcov2))
+        grid = sp.GridKNN.build(Tg.points)
+        prep = sp.PreparedTarget(grid, Tg.covs)
+        p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=10)
+        reg = sp.Registration(p)
+        reg._set_source_option("reuse", reuse)
+        T_dev, lin, delta = reg.align_fused_loop(S, prep, write_neighbors=True)
+        outs.append((T_dev.cpu().numpy(), lin.cpu().numpy(), reg.neighbors.indices.cpu().numpy().copy(),
+                     reg.neighbors.distances.cpu().numpy().copy()))
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert np.array_equal(a, b)
