@@ -78,7 +78,9 @@ def main():
             # factor. Both in KiB as the counters report.
             # (a searched point rewrites its 48-byte cache row: 480 KiB of writes = 1 % of 1M points searched, the same
             # threshold bench.py's launch_classes uses on the device-side searched-point count)
-            steady = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w) if b < 480.0]
+            # launches that return at once (an earlier iteration converged: bench.py's until_converged leg) fetch < 1 MiB
+            # and belong to neither class
+            steady = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w) if b < 480.0 and a >= 1024.0]
             search = [(GATHER_FACTOR * a + b) * 1024.0 for a, b in zip(f, w) if b >= 480.0]
             allb = steady + search
             out[key] = {"launches": len(allb), "hbm_bytes_per_launch": sum(allb) / len(allb),
