@@ -32,7 +32,7 @@ extern "C" {
 #define SP_ERR_RUNTIME 2          /* reference: std::runtime_error    */
 #define SP_ERR_HIP 3              /* reference: sycl::exception from wait_and_throw */
 
-#define SP_ABI_VERSION 2
+#define SP_ABI_VERSION 3
 int sp_abi_version(void);
 const char* sp_last_error(void);
 
@@ -385,6 +385,49 @@ int sp_map_prior_update_host(const sp_map_prior_params* params, const float* H_r
                              uint32_t inlier, const float* T_prev16, const float* T_pred16, sp_map_prior_state* state);
 float sp_map_prior_apply_host(const sp_map_prior_state* state, const float* T_est16, float* H36_rowmajor, float* b6,
                               float* error);
+
+/* ------------------------------------------------------------------------------------- voxel hash map */
+
+/* VoxelHashMap (algorithms/mapping/voxel_hash_map.hpp:22-1072): submap accumulation keyed by compute_voxel_bit
+ * (sp_voxel_keys' key). The table (double hashing, 100 probes, capacities from the reference's prime list, rehash when
+ * voxel_num / capacity exceeds the threshold) lives in HBM and is owned by the object; per voxel it keeps the sums of the
+ * map-frame points, of log(R C R^T) (log-Euclidean covariance mean), of rgb and of intensity, a count and the time stamp of
+ * its last update.
+ *   sp_vhm_create        constructor (:28-36); voxel_size <= 0 -> SP_ERR_INVALID_ARGUMENT (std::invalid_argument, :41-43)
+ *   sp_vhm_set / _get    set_voxel_size / set_max_staleness / set_remove_old_data_cycle / set_rehash_threshold /
+ *                        set_min_num_point and their getters (:38-80)
+ *   sp_vhm_clear         clear (:83-113)
+ *   sp_vhm_add_point_cloud  add_point_cloud (:117-141): [rehash] -> integrate the cloud (device points in the SENSOR frame,
+ *                        optional covariances / rgb / intensities; sensor_pose_host16 = column-major 4x4 in the map frame)
+ *                        -> [remove_old_data every remove_old_data_cycle calls] -> ++staleness counter. Accumulation uses
+ *                        relaxed device-scope atomics, as the reference does: counts are exact, float sums agree to rounding.
+ *   sp_vhm_downsampling  downsampling (:146-190): voxels with count >= min_num_point whose centroid lies in the axis-aligned
+ *                        box center +- distance -> mean point (w = 1), exp of the mean log-covariance, mean rgb / intensity,
+ *                        in table-slot order (deterministic for a given table; the reference's order is that of an atomic
+ *                        counter). Attribute outputs are written only when the map holds that attribute (sp_vhm_info); out
+ *                        arrays must hold sp_vhm_info(SP_VHM_INFO_VOXEL_NUM) entries. keys_out_opt: the voxel keys.
+ *   sp_vhm_overlap_ratio compute_overlap_ratio (:196-246)
+ *   sp_vhm_remove_old_data remove_old_data (:248, 788-843)
+ * Like the reference's methods these calls wait for their kernels (voxel counts are read back by the host). */
+typedef struct sp_voxel_hash_map sp_voxel_hash_map;
+enum { SP_VHM_VOXEL_SIZE = 0, SP_VHM_MAX_STALENESS = 1, SP_VHM_REMOVE_OLD_DATA_CYCLE = 2, SP_VHM_REHASH_THRESHOLD = 3,
+       SP_VHM_MIN_NUM_POINT = 4 };
+enum { SP_VHM_INFO_VOXEL_NUM = 0, SP_VHM_INFO_CAPACITY = 1, SP_VHM_INFO_STALENESS_COUNTER = 2, SP_VHM_INFO_HAS_COV = 3,
+       SP_VHM_INFO_HAS_RGB = 4, SP_VHM_INFO_HAS_INTENSITY = 5 };
+int sp_vhm_create(float voxel_size, void* stream, sp_voxel_hash_map** out);
+void sp_vhm_destroy(sp_voxel_hash_map* map);
+int sp_vhm_set(sp_voxel_hash_map* map, int param, float value);
+float sp_vhm_get(const sp_voxel_hash_map* map, int param);
+size_t sp_vhm_info(const sp_voxel_hash_map* map, int what);
+int sp_vhm_clear(sp_voxel_hash_map* map, void* stream);
+int sp_vhm_add_point_cloud(sp_voxel_hash_map* map, const float* points, const float* covs, const float* rgb,
+                           const float* intensities, size_t n, const float* sensor_pose_host16, void* stream);
+int sp_vhm_downsampling(sp_voxel_hash_map* map, const float* center_host3, float distance, float* points_out,
+                        float* covs_out, float* rgb_out, float* intensities_out, uint64_t* keys_out_opt,
+                        size_t out_capacity, size_t* n_out_host, void* stream);
+int sp_vhm_overlap_ratio(const sp_voxel_hash_map* map, const float* points, size_t n, const float* sensor_pose_host16,
+                         float* ratio_out_host, void* stream);
+int sp_vhm_remove_old_data(sp_voxel_hash_map* map, void* stream);
 
 #ifdef __cplusplus
 }

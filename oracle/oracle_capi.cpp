@@ -11,6 +11,7 @@
 #include "oracle_math.hpp"
 #include "oracle_registration.hpp"
 #include "oracle_robust_cov.hpp"
+#include "oracle_voxel_hash_map.hpp"
 
 using namespace oracle;
 
@@ -378,6 +379,52 @@ void orc_registration_align(const orc_reg_params* P, const float* src, const flo
     std::memcpy(out->b, r.b.d, 24);
     out->error = r.error; out->inlier = r.inlier; out->iterations = (int)r.iterations; out->converged = r.converged ? 1 : 0;
     if (trace_T) { std::memcpy(trace_T, trace.data(), trace.size() * 4); *trace_n = (int)(trace.size() / 16); }
+}
+
+
+// ---- VoxelHashMap (algorithms/mapping/voxel_hash_map.hpp). param: 0 voxel_size, 1 max_staleness, 2 remove_old_data_cycle,
+// 3 rehash_threshold, 4 min_num_point. info: 0 voxel_num, 1 capacity, 2 staleness_counter, 3 has_cov, 4 has_rgb, 5 has_intensity.
+void* orc_vhm_new(float voxel_size) { return voxel_size > 0.0f ? new VoxelHashMap(voxel_size) : nullptr; }
+void orc_vhm_free(void* m) { delete static_cast<VoxelHashMap*>(m); }
+void orc_vhm_clear(void* m) { static_cast<VoxelHashMap*>(m)->clear(); }
+void orc_vhm_set(void* m, int param, float v) {
+    auto& M = *static_cast<VoxelHashMap*>(m);
+    if (param == 0) { M.voxel_size = v; M.voxel_size_inv = 1.0f / v; }
+    else if (param == 1) M.max_staleness = (uint32_t)v;
+    else if (param == 2) M.remove_old_data_cycle = (uint32_t)v;
+    else if (param == 3) M.rehash_threshold = v;
+    else if (param == 4) M.min_num_point = (uint32_t)v;
+}
+size_t orc_vhm_info(void* m, int what) {
+    auto& M = *static_cast<VoxelHashMap*>(m);
+    switch (what) {
+        case 0: return M.voxel_num;
+        case 1: return M.capacity;
+        case 2: return M.staleness_counter;
+        case 3: return M.has_cov;
+        case 4: return M.has_rgb;
+        case 5: return M.has_intensity;
+    }
+    return 0;
+}
+void orc_vhm_add(void* m, const float* pts, const float* covs, const float* rgb, const float* inten, size_t n, const float* pose16) {
+    static_cast<VoxelHashMap*>(m)->add_point_cloud(pts, covs, rgb, inten, n, pose16);
+}
+size_t orc_vhm_downsampling(void* m, const float* center3, float distance, float* pts_out, float* cov_out, float* rgb_out,
+                            float* inten_out, uint64_t* keys_out) {
+    return static_cast<VoxelHashMap*>(m)->downsampling(center3, distance, pts_out, cov_out, rgb_out, inten_out, keys_out);
+}
+float orc_vhm_overlap_ratio(void* m, const float* pts, size_t n, const float* pose16) {
+    return static_cast<VoxelHashMap*>(m)->overlap_ratio(pts, n, pose16);
+}
+void orc_vhm_remove_old_data(void* m) { static_cast<VoxelHashMap*>(m)->remove_old_data(); }
+void orc_log_spd3(const float* A9_colmajor, float* out9) {
+    Mat3 A; std::memcpy(A.d, A9_colmajor, 36);
+    const Mat3 r = log_spd_3x3(A); std::memcpy(out9, r.d, 36);
+}
+void orc_exp_spd3(const float* A9_colmajor, float* out9) {
+    Mat3 A; std::memcpy(A.d, A9_colmajor, 36);
+    const Mat3 r = exp_spd_3x3(A); std::memcpy(out9, r.d, 36);
 }
 
 }  // extern "C"

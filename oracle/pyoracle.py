@@ -424,6 +424,21 @@ class Oracle:
                                         LOSS[loss], C.c_float(robust_scale), _p(out))
         return out
 
+    def voxel_hash_map(self, voxel_size):
+        return OracleVoxelHashMap(self, voxel_size)
+
+    def log_spd3(self, A):
+        A = _f(np.asarray(A).T)
+        out = np.zeros((3, 3), np.float32)
+        self.lib.orc_log_spd3(_p(A), _p(out))
+        return out.T.copy()
+
+    def exp_spd3(self, A):
+        A = _f(np.asarray(A).T)
+        out = np.zeros((3, 3), np.float32)
+        self.lib.orc_exp_spd3(_p(A), _p(out))
+        return out.T.copy()
+
     def registration_align(self, params, src, src_cov, tgt, tgt_cov, tgt_nrm=None, init_T=None, nn_mode="kdtree",
                            trace=False, nodes=None):
         src, tgt = _f(src), _f(tgt)
@@ -448,6 +463,73 @@ class Oracle:
         if trace:
             out["trace"] = np.stack([tr[i].reshape(4, 4).T for i in range(trn.value)]) if trn.value else np.zeros((0, 4, 4))
         return out
+
+
+class OracleVoxelHashMap:
+    """algorithms/mapping/voxel_hash_map.hpp restated (oracle/oracle_voxel_hash_map.hpp). Poses are row-major 4x4 numpy."""
+    PARAM = {"voxel_size": 0, "max_staleness": 1, "remove_old_data_cycle": 2, "rehash_threshold": 3, "min_num_point": 4}
+    INFO = {"voxel_num": 0, "capacity": 1, "staleness_counter": 2, "has_cov": 3, "has_rgb": 4, "has_intensity": 5}
+
+    def __init__(self, orc, voxel_size):
+        L = orc.lib
+        L.orc_vhm_new.restype = C.c_void_p
+        L.orc_vhm_new.argtypes = [C.c_float]
+        L.orc_vhm_info.restype = C.c_size_t
+        L.orc_vhm_info.argtypes = [C.c_void_p, C.c_int]
+        L.orc_vhm_set.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.orc_vhm_downsampling.restype = C.c_size_t
+        L.orc_vhm_overlap_ratio.restype = C.c_float
+        for f in (L.orc_vhm_free, L.orc_vhm_clear, L.orc_vhm_remove_old_data):
+            f.argtypes = [C.c_void_p]
+        if not voxel_size > 0.0:
+            raise ValueError("voxel_size must be positive.")  # voxel_hash_map.hpp:41-43: std::invalid_argument
+        self.orc = orc
+        self.h = C.c_void_p(L.orc_vhm_new(voxel_size))
+
+    def set(self, name, value):
+        self.orc.lib.orc_vhm_set(self.h, self.PARAM[name], float(value))
+
+    def info(self, name):
+        return int(self.orc.lib.orc_vhm_info(self.h, self.INFO[name]))
+
+    def clear(self):
+        self.orc.lib.orc_vhm_clear(self.h)
+
+    def add_point_cloud(self, pts, pose=None, covs=None, rgb=None, intensities=None):
+        pts = _f(pts).reshape(-1, 4)
+        covs = None if covs is None else _f(covs)
+        rgb = None if rgb is None else _f(rgb)
+        inten = None if intensities is None else _f(intensities)
+        Tc = _f(np.eye(4) if pose is None else np.asarray(pose).T)
+        self.orc.lib.orc_vhm_add(self.h, _p(pts), _p(covs), _p(rgb), _p(inten), C.c_size_t(len(pts)), _p(Tc))
+
+    def downsampling(self, center=(0.0, 0.0, 0.0), distance=100.0):
+        cap = max(self.info("voxel_num"), 1)
+        pts = np.zeros((cap, 4), np.float32)
+        cov = np.zeros((cap, 16), np.float32)
+        rgb = np.zeros((cap, 4), np.float32)
+        inten = np.zeros(cap, np.float32)
+        keys = np.zeros(cap, np.uint64)
+        c = _f(center)
+        n = self.orc.lib.orc_vhm_downsampling(self.h, _p(c), C.c_float(distance), _p(pts), _p(cov), _p(rgb), _p(inten),
+                                              _p(keys, C.c_uint64))
+        return {"points": pts[:n], "covs": cov[:n] if self.info("has_cov") else None,
+                "rgb": rgb[:n] if self.info("has_rgb") else None,
+                "intensities": inten[:n] if self.info("has_intensity") else None, "keys": keys[:n]}
+
+    def overlap_ratio(self, pts, pose=None):
+        pts = _f(pts).reshape(-1, 4)
+        Tc = _f(np.eye(4) if pose is None else np.asarray(pose).T)
+        return float(self.orc.lib.orc_vhm_overlap_ratio(self.h, _p(pts), C.c_size_t(len(pts)), _p(Tc)))
+
+    def remove_old_data(self):
+        self.orc.lib.orc_vhm_remove_old_data(self.h)
+
+    def __del__(self):
+        try:
+            self.orc.lib.orc_vhm_free(self.h)
+        except Exception:
+            pass
 
 
 class _Rng:

@@ -121,6 +121,16 @@ SIGNATURES = {
     "sp_degenerate_regularize_host": (_i, [_vp, _vp, _vp, C.c_uint32, _vp, _vp]),
     "sp_map_prior_update_host": (_i, [_vp, _vp, _f, C.c_uint32, _vp, _vp, _vp]),
     "sp_map_prior_apply_host": (_f, [_vp, _vp, _vp, _vp, _vp]),
+    "sp_vhm_create": (_i, [_f, _vp, C.POINTER(_vp)]),
+    "sp_vhm_destroy": (None, [_vp]),
+    "sp_vhm_set": (_i, [_vp, _i, _f]),
+    "sp_vhm_get": (_f, [_vp, _i]),
+    "sp_vhm_info": (_sz, [_vp, _i]),
+    "sp_vhm_clear": (_i, [_vp, _vp]),
+    "sp_vhm_add_point_cloud": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "sp_vhm_downsampling": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
+    "sp_vhm_overlap_ratio": (_i, [_vp, _vp, _sz, _vp, C.POINTER(_f), _vp]),
+    "sp_vhm_remove_old_data": (_i, [_vp, _vp]),
 }
 
 
@@ -163,7 +173,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.sp_abi_version() != 2:
+        if L.sp_abi_version() != 3:
             raise ImportError("libsycl_points_amd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -546,6 +546,88 @@ def compact_by_flags(rows, flags, want_indices=False):
     return (out[:v], idx) if want_indices else out[:v]
 
 
+class VoxelHashMap:
+    """algorithms/mapping/voxel_hash_map.hpp:22-250 over the sp_vhm_* entry points: submap accumulation in HBM.
+    add_point_cloud takes a PointCloudShared in the sensor frame and the sensor pose (4x4, map frame); downsampling
+    returns a PointCloudShared of the voxel means inside the query box (plus `.voxel_keys`, the keys in output order)."""
+    _PARAM = {"voxel_size": 0, "max_staleness": 1, "remove_old_data_cycle": 2, "rehash_threshold": 3, "min_num_point": 4}
+    _INFO = {"voxel_num": 0, "capacity": 1, "staleness_counter": 2, "has_cov": 3, "has_rgb": 4, "has_intensity": 5}
+
+    def __init__(self, voxel_size, device="cuda"):
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        check(_lib.lib().sp_vhm_create(float(voxel_size), _stream(), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_vhm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _set(self, name, value):
+        check(_lib.lib().sp_vhm_set(self._h, self._PARAM[name], float(value)))
+
+    def _get(self, name):
+        return float(_lib.lib().sp_vhm_get(self._h, self._PARAM[name]))
+
+    def info(self, name):
+        return int(_lib.lib().sp_vhm_info(self._h, self._INFO[name]))
+
+    def set_voxel_size(self, v): self._set("voxel_size", v)  # noqa: E704
+    def get_voxel_size(self): return self._get("voxel_size")  # noqa: E704
+    def set_max_staleness(self, v): self._set("max_staleness", v)  # noqa: E704
+    def get_max_staleness(self): return int(self._get("max_staleness"))  # noqa: E704
+    def set_remove_old_data_cycle(self, v): self._set("remove_old_data_cycle", v)  # noqa: E704
+    def get_remove_old_data_cycle(self): return int(self._get("remove_old_data_cycle"))  # noqa: E704
+    def set_rehash_threshold(self, v): self._set("rehash_threshold", v)  # noqa: E704
+    def get_rehash_threshold(self): return self._get("rehash_threshold")  # noqa: E704
+    def set_min_num_point(self, v): self._set("min_num_point", v)  # noqa: E704
+    def get_min_num_point(self): return int(self._get("min_num_point"))  # noqa: E704
+
+    def clear(self):
+        check(_lib.lib().sp_vhm_clear(self._h, _stream()))
+
+    def add_point_cloud(self, cloud, sensor_pose=None):
+        T = _T16(identity() if sensor_pose is None else sensor_pose).copy()
+        n = cloud.size()
+        check(_lib.lib().sp_vhm_add_point_cloud(
+            self._h, _ptr(cloud.points) if n else None, _ptr(cloud.covs) if (n and cloud.has_cov()) else None,
+            _ptr(cloud.rgb) if (n and cloud.has_rgb()) else None,
+            _ptr(cloud.intensities) if (n and cloud.has_intensity()) else None, n, T.ctypes.data_as(C.c_void_p), _stream()))
+
+    def downsampling(self, center=(0.0, 0.0, 0.0), distance=100.0):
+        cap = self.info("voxel_num")
+        dev = self.device
+        pts = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
+        covs = torch.empty((max(cap, 1), 16), dtype=torch.float32, device=dev) if self.info("has_cov") else None
+        rgb = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev) if self.info("has_rgb") else None
+        inten = torch.empty(max(cap, 1), dtype=torch.float32, device=dev) if self.info("has_intensity") else None
+        keys = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        c = np.asarray(center, np.float32).copy()
+        n_out = C.c_size_t(0)
+        check(_lib.lib().sp_vhm_downsampling(self._h, c.ctypes.data_as(C.c_void_p), float(distance), _ptr(pts), _ptr(covs),
+                                             _ptr(rgb), _ptr(inten), _ptr(keys), cap, C.byref(n_out), _stream()))
+        n = n_out.value
+        out = PointCloudShared(pts[:n], covs=None if covs is None else covs[:n], rgb=None if rgb is None else rgb[:n],
+                               intensities=None if inten is None else inten[:n], device=dev)
+        out.voxel_keys = keys[:n]
+        return out
+
+    def compute_overlap_ratio(self, cloud, sensor_pose=None):
+        T = _T16(identity() if sensor_pose is None else sensor_pose).copy()
+        r = C.c_float(0.0)
+        n = cloud.size()
+        check(_lib.lib().sp_vhm_overlap_ratio(self._h, _ptr(cloud.points) if n else None, n, T.ctypes.data_as(C.c_void_p),
+                                              C.byref(r), _stream()))
+        return float(r.value)
+
+    def remove_old_data(self):
+        check(_lib.lib().sp_vhm_remove_old_data(self._h, _stream()))
+
+
 class PreparedTarget:
     """Plane-regularised target covariances stored in the cell order of a GridKNN (sp_gicp_target_*): the target half of
     the prepared / fused GICP iteration. Holds a reference to the grid, which it borrows."""

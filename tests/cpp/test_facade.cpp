@@ -2,6 +2,7 @@
 // own gtest files: cpp/tests/test_kdtree.cpp, test_downsampling_filters.cpp, test_preprocess_filter.cpp and the
 // KNNBase-injection idiom of test_registration_pipeline.cpp:16-61. The CPU oracle (oracle/, test infrastructure) is the
 // checker for registration. Runs on a GPU box; exit code 0 = all checks passed.
+#include <array>
 #include <cstring>
 #include <cstdio>
 #include <random>
@@ -14,7 +15,9 @@
 #include "sycl_points/algorithms/knn/grid.hpp"
 #include "sycl_points/algorithms/knn/kdtree.hpp"
 #include "sycl_points/algorithms/registration/registration_pipeline.hpp"
+#include "sycl_points/algorithms/mapping/voxel_hash_map.hpp"
 #include "sycl_points/io/point_cloud_reader.hpp"
+#include "sycl_points/io/point_cloud_writer.hpp"
 #include <fstream>
 
 // ---- oracle (liboracle.so) entry points used as the checker
@@ -446,6 +449,95 @@ static void registration_matches_oracle() {
     CHECK(sampled.get_registration_input_point_cloud()->size() == 1000);
 }
 
+// algorithms/mapping/voxel_hash_map.hpp through the facade, on the reference's own cases
+// (cpp/tests/test_voxel_hash_map.cpp:98-147, 149-193, 315-344, 380-419, 455-502)
+static void voxel_hash_map_known_answers() {
+    auto make = [&](std::initializer_list<std::array<float, 3>> pts) {
+        PointCloudCPU c;
+        for (const auto& p : pts) c.points->emplace_back(p[0], p[1], p[2], 1.0f);
+        return c;
+    };
+    bool threw = false;
+    try { alg::mapping::VoxelHashMap bad(*Q, 0.0f); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    {
+        alg::mapping::VoxelHashMap map(*Q, 0.1f);
+        const PointCloudShared cloud(*Q, make({{0.02f, 0.02f, 0.0f}, {0.03f, 0.04f, 0.0f}, {0.11f, 0.02f, 0.0f}, {0.12f, 0.03f, 0.0f}}));
+        map.add_point_cloud(cloud, Eigen::Isometry3f::Identity());
+        PointCloudShared result(*Q);
+        map.downsampling(result, Eigen::Vector3f(0.f, 0.f, 0.f));
+        CHECK(result.size() == 2);
+        if (result.size() == 2) {
+            std::vector<PointType> v{(*result.points)[0], (*result.points)[1]};
+            if (v[0].x() > v[1].x()) std::swap(v[0], v[1]);
+            CHECK(std::fabs(v[0].x() - 0.025f) < 1e-5f && std::fabs(v[0].y() - 0.03f) < 1e-5f && v[0].w() == 1.0f);
+            CHECK(std::fabs(v[1].x() - 0.115f) < 1e-5f && std::fabs(v[1].y() - 0.025f) < 1e-5f);
+        }
+        CHECK(!result.has_cov() && !result.has_rgb() && !result.has_intensity());
+    }
+    {
+        alg::mapping::VoxelHashMap map(*Q, 0.5f);
+        PointCloudCPU c = make({{0.f, 0.f, 0.f}, {0.1f, 0.f, 0.f}});
+        c.rgb->emplace_back(0.2f, 0.4f, 0.6f, 1.0f);
+        c.rgb->emplace_back(0.6f, 0.2f, 0.0f, 1.0f);
+        *c.intensities = {10.0f, 20.0f};
+        map.add_point_cloud(PointCloudShared(*Q, c), Eigen::Isometry3f::Identity());
+        PointCloudShared result(*Q);
+        map.downsampling(result, Eigen::Vector3f(0.f, 0.f, 0.f));
+        CHECK(result.size() == 1 && result.has_rgb() && result.has_intensity());
+        if (result.size() == 1 && result.has_rgb() && result.has_intensity()) {
+            const RGBType col = (*result.rgb)[0];
+            CHECK(std::fabs(col.x() - 0.4f) < 1e-5f && std::fabs(col.y() - 0.3f) < 1e-5f && std::fabs(col.z() - 0.3f) < 1e-5f &&
+                  std::fabs(col.w() - 1.0f) < 1e-5f);
+            CHECK(std::fabs((*result.intensities)[0] - 15.0f) < 1e-5f && std::fabs((*result.points)[0].x() - 0.05f) < 1e-5f);
+        }
+    }
+    {
+        alg::mapping::VoxelHashMap map(*Q, 0.2f);
+        map.set_min_num_point(2);
+        CHECK(map.get_min_num_point() == 2 && map.get_voxel_size() == 0.2f && map.get_max_staleness() == 100);
+        map.add_point_cloud(PointCloudShared(*Q, make({{0.01f, 0.01f, 0.f}, {0.02f, 0.01f, 0.f}, {0.30f, 0.30f, 0.f}})),
+                            Eigen::Isometry3f::Identity());
+        PointCloudShared result(*Q);
+        map.downsampling(result, Eigen::Vector3f(0.f, 0.f, 0.f));
+        CHECK(result.size() == 1 && std::fabs((*result.points)[0].x() - 0.015f) < 1e-5f);
+    }
+    {
+        alg::mapping::VoxelHashMap map(*Q, 0.5f);
+        const PointCloudShared map_cloud(*Q, make({{0.1f, 0.1f, 0.0f}, {1.1f, 0.0f, 0.0f}}));
+        map.add_point_cloud(map_cloud, Eigen::Isometry3f::Identity());
+        const PointCloudShared query(*Q, make({{-0.9f, 0.1f, 0.0f}, {0.1f, 0.0f, 0.0f}, {1.0f, 0.0f, 0.0f}}));
+        Eigen::Isometry3f pose = Eigen::Isometry3f::Identity();
+        pose.matrix()(0, 3) = 1.0f;
+        CHECK(std::fabs(map.compute_overlap_ratio(query, pose) - 2.0f / 3.0f) < 1e-5f);
+        map.set_min_num_point(2);
+        CHECK(std::fabs(map.compute_overlap_ratio(query, pose)) < 1e-5f);
+        map.add_point_cloud(map_cloud, Eigen::Isometry3f::Identity());
+        CHECK(std::fabs(map.compute_overlap_ratio(query, pose) - 2.0f / 3.0f) < 1e-5f);
+    }
+    {
+        alg::mapping::VoxelHashMap map(*Q, 1.0f);
+        map.set_rehash_threshold(0.0f);
+        map.add_point_cloud(PointCloudShared(*Q, make({{0.5f, 0.5f, 0.5f}, {10.5f, 0.5f, 0.5f}, {20.5f, 0.5f, 0.5f}})),
+                            Eigen::Isometry3f::Identity());
+        map.add_point_cloud(PointCloudShared(*Q, make({{30.5f, 0.5f, 0.5f}, {40.5f, 0.5f, 0.5f}})), Eigen::Isometry3f::Identity());
+        PointCloudShared result(*Q);
+        map.downsampling(result, Eigen::Vector3f(0.f, 0.f, 0.f));
+        CHECK(result.size() == 5);
+        // written from shared memory and read back (io/point_cloud_writer.hpp on a PointCloudShared, test_file_io.cpp:107-128)
+        PointCloudWriter::writeFile("/tmp/sp_vhm_result.pcd", result, true);
+        const PointCloudCPU back = PointCloudReader::readFile("/tmp/sp_vhm_result.pcd");
+        bool same = back.size() == result.size();
+        for (size_t i = 0; same && i < back.size(); ++i)
+            same = (*back.points)[i].x() == (*result.points)[i].x() && (*back.points)[i].y() == (*result.points)[i].y() &&
+                   (*back.points)[i].z() == (*result.points)[i].z();
+        CHECK(same);
+        map.clear();
+        map.downsampling(result, Eigen::Vector3f(0.f, 0.f, 0.f));
+        CHECK(result.size() == 0);
+    }
+}
+
 int main() {
     sycl_utils::DeviceQueue queue(0);
     Q = &queue;
@@ -454,6 +546,7 @@ int main() {
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
     RUN(point_cloud_files);
+    RUN(voxel_hash_map_known_answers);
     RUN(registration_matches_oracle);
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed == 0 ? 0 : 1;
