@@ -233,8 +233,9 @@ public:
         const knn::KNNBase& nn = (grid != nullptr && grid->size() == target.size()) ? static_cast<const knn::KNNBase&>(*grid)
                                                                                      : target_knn;
         // (the rotation constraint reads the raw covariances: it runs on the unfused kernels)
-        const bool fused = grid != nullptr && params_.reg_type == RegType::GICP && grid->size() == target.size() &&
-                           !params_.rotation_constraint.enable;
+        const bool fused = grid != nullptr && grid->size() == target.size() && !params_.rotation_constraint.enable &&
+                           (params_.reg_type == RegType::GICP || params_.reg_type == RegType::POINT_TO_DISTRIBUTION);
+        fused_loop_active_ = fused;  // the LM / dog-leg trial steps then read the frozen correspondences from the cache
         if (fused) prepare_fused(source, target, *grid, initial_guess);
         // GICP + Gauss-Newton on a GridKNN: the whole loop runs on the device (one launch per iteration, convergence
         // test included), the host reads the result back once — same arithmetic as the loop below.
@@ -298,6 +299,7 @@ public:
         const float s = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
         rotation_robust_scale_ = options.rotation_robust_scale > 0.0f ? options.rotation_robust_scale
                                                                       : params_.rotation_constraint.robust.default_scale;
+        fused_loop_active_ = false;  // the public entry evaluates the neighbours of the last search, not the cache
         return compute_error(source, target, pose, s);
     }
     /// registration.hpp:279-294
@@ -403,9 +405,9 @@ private:
             ptgt_ = nullptr;
             throw_on_error(sp_gicp_target_create(grid.handle(), target.covs_device(), target.size(), queue_.stream(), &ptgt_));
             ptgt_grid_id_ = grid.id();
-        } else {
-            throw_on_error(sp_gicp_target_update(ptgt_, target.covs_device(), queue_.stream()));
         }
+        // rows of the factor asked for: plane(Ct) for GICP, inverse(Ct) for point-to-distribution (factor.hpp:311-317)
+        throw_on_error(sp_gicp_target_prepare(ptgt_, target.covs_device(), int(params_.reg_type), queue_.stream()));
         if (psrc_ == nullptr || psrc_cap_ < source.size()) {
             if (psrc_) sp_gicp_source_destroy(psrc_);
             psrc_ = nullptr;
@@ -454,6 +456,7 @@ private:
     LinearizedResult linearize_fused(size_t N, const TransformMatrix& T, float robust_scale) {
         const sp_factor_params fp = factor_params(robust_scale);
         TransformMatrix Tc = T;
+        lin_T_ = T;  // the pose the correspondences are frozen at (compute_error on the prepared path)
         throw_on_error(sp_gicp_iteration_fused(ptgt_, psrc_, Tc.data(), 0, &fp, nullptr,
                                                neighbors_.indices->device_data_for_write(N),
                                                neighbors_.distances->device_data_for_write(N), lin_dev_, nullptr, ws_,
@@ -463,6 +466,12 @@ private:
     std::tuple<float, uint32_t> compute_error(const PointCloudShared& source, const PointCloudShared& target,
                                               const TransformMatrix& T, float robust_scale) const {
         const sp_factor_params fp = factor_params(robust_scale);
+        if (fused_loop_active_) {  // K12 over the correspondence cache: no gathers, no eigen-decompositions
+            throw_on_error(sp_gicp_error_prepared(ptgt_, psrc_, lin_T_.data(), T.data(), 0, &fp, lin_dev_, ws_, ws_bytes_,
+                                                  queue_.stream()));
+            const sp_linearized h = read_lin();
+            return {h.error, h.inlier};
+        }
         throw_on_error(sp_gicp_error(source.points_device(), source.covs_device(), source.size(), target.points_device(),
                                      target.covs_device(), target.normals_device(), neighbors_.indices->device_data(),
                                      neighbors_.distances->device_data(), T.data(), 0, &fp, lin_dev_, ws_, ws_bytes_,
@@ -583,6 +592,8 @@ private:
     uint64_t ptgt_grid_id_ = 0;  // GridKNN::id() the prepared target was built on
     bool source_presorted_ = false;
     bool accelerate_kdtree_ = true;
+    mutable bool fused_loop_active_ = false;  // align() is running its optimiser loop on the prepared path
+    TransformMatrix lin_T_ = TransformMatrix::Identity();  // pose of the last fused linearisation
     knn::GridKNN::Ptr kd_grid_;        // GridKNN standing in for the caller's KDTree (grid_for)
     uint64_t kd_grid_tree_id_ = 0;
 };

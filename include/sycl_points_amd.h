@@ -276,13 +276,20 @@ int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn
  *                           and updates the DEVICE pose transT in place, writing delta_out8 as sp_gn_update does; with
  *                           gn == NULL the caller all-reduces *out over ranks and calls sp_gn_update.
  * Same mathematics as sp_grid_search + sp_gicp_linearize; rounding differs (symmetric packing, upper-triangle H,
- * summation order). reg_type must be SP_REG_GICP; every robust loss is supported. */
+ * summation order). reg_type must be SP_REG_GICP or SP_REG_POINT_TO_DISTRIBUTION (the one the target was prepared for,
+ * sp_gicp_target_prepare); every robust loss is supported. */
 typedef struct sp_gicp_target sp_gicp_target;
 typedef struct sp_gicp_source sp_gicp_source;
 typedef struct sp_gn_params { float lambda, crit_rotation, crit_translation; } sp_gn_params;
 enum { SP_SOURCE_ORDER_UNKNOWN = 0, SP_SOURCE_SORT = 1, SP_SOURCE_PRESORTED = 2 };
 int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream, sp_gicp_target** out);
 int sp_gicp_target_update(sp_gicp_target* target, const float* tgt_covs, void* stream);
+/* The same, choosing the factor the rows serve: SP_REG_GICP (what create makes: V diag(1e-3,1,1) V^T of the covariance) or
+ * SP_REG_POINT_TO_DISTRIBUTION (linearize_point_to_distribution, factor.hpp:311-373: the information matrix itself,
+ * inverse(Ct) of the RAW covariance, Zero when |det| < 1e-6, so the iteration inverts nothing per point and reads no source
+ * covariance — sp_gicp_source_prepare then accepts src_covs == NULL). sp_gicp_target_update keeps the current choice. The
+ * iteration / align / error entry points require params->reg_type to match (SP_ERR_INVALID_ARGUMENT otherwise). */
+int sp_gicp_target_prepare(sp_gicp_target* target, const float* tgt_covs, int reg_type, void* stream);
 void sp_gicp_target_destroy(sp_gicp_target* target);
 int sp_gicp_source_create(size_t n_max, sp_gicp_source** out);
 int sp_gicp_source_prepare(sp_gicp_source* source, const sp_gicp_target* target, const float* src_points,
@@ -293,6 +300,16 @@ int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* 
                             int transT_on_device, const sp_factor_params* params, const sp_gn_params* gn,
                             int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* out, float* delta_out8,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Registration::compute_error_parallel_reduction (registration.hpp:678-777, kernel K12) on the prepared path: the error of
+ * the factor at transT_trial with the correspondences FROZEN at those of the last linearisation of `source` against
+ * `target` (sp_gicp_iteration_fused / sp_gicp_align_*), read from the source's correspondence cache — what the trial steps
+ * of optimize_levenberg_marquardt (:830-895) and optimize_powell_dogleg (:897-965) call per step. transT_lin_host is the
+ * pose of that linearisation (host, column-major): the inlier gate nn_d2 <= max_corr^2 is evaluated there, as the
+ * reference's frozen distances are. out->error / out->inlier (H, b are not written). SP_ERR_RUNTIME when nothing has
+ * been linearised since sp_gicp_source_prepare. workspace: sp_gicp_workspace_bytes(n). */
+int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gicp_source* source, const float* transT_lin_host,
+                           const float* transT_trial, int trial_on_device, const sp_factor_params* params,
+                           sp_linearized* out, void* workspace, size_t workspace_bytes, void* stream);
 /* Registration::align's whole Gauss-Newton loop (registration.hpp:229-276) enqueued by ONE call, one kernel launch per
  * iteration plus one at the end: launch k first finishes iteration k-1 (every workgroup sums the previous launch's
  * partial rows in the same fixed order and solves the same 6x6 system, T <- T * se3_exp(delta)), then linearises at the

@@ -102,6 +102,8 @@ SIGNATURES = {
     "sp_genz_counts": (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp, _vp]),
     "sp_gicp_target_create": (_i, [_vp, _vp, _sz, _vp, C.POINTER(_vp)]),
     "sp_gicp_target_update": (_i, [_vp, _vp, _vp]),
+    "sp_gicp_target_prepare": (_i, [_vp, _vp, _i, _vp]),
+    "sp_gicp_error_prepared": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _sz, _vp]),
     "sp_gicp_target_destroy": (None, [_vp]),
     "sp_gicp_source_create": (_i, [_sz, C.POINTER(_vp)]),
     "sp_gicp_source_prepare": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _vp]),

@@ -632,17 +632,22 @@ class PreparedTarget:
     """Plane-regularised target covariances stored in the cell order of a GridKNN (sp_gicp_target_*): the target half of
     the prepared / fused GICP iteration. Holds a reference to the grid, which it borrows."""
 
-    def __init__(self, grid, covs):
+    def __init__(self, grid, covs, reg_type="GICP"):
         self.grid = grid
         self.covs = _dev_f32(covs, 16)
+        self.reg_type = reg_type
         h = C.c_void_p()
         check(_lib.lib().sp_gicp_target_create(grid._h, _ptr(self.covs), self.covs.shape[0], _stream(), C.byref(h)))
         self._h = h
+        if reg_type != "GICP":  # POINT_TO_DISTRIBUTION: the rows hold inverse(Ct) (sp_gicp_target_prepare)
+            check(_lib.lib().sp_gicp_target_prepare(self._h, _ptr(self.covs), REG[reg_type], _stream()))
 
-    def update(self, covs=None):
+    def update(self, covs=None, reg_type=None):
         if covs is not None:
             self.covs = _dev_f32(covs, 16)
-        check(_lib.lib().sp_gicp_target_update(self._h, _ptr(self.covs), _stream()))
+        if reg_type is not None:
+            self.reg_type = reg_type
+        check(_lib.lib().sp_gicp_target_prepare(self._h, _ptr(self.covs), REG[self.reg_type], _stream()))
 
     def __del__(self):
         try:
@@ -668,11 +673,13 @@ class PreparedSource:
         check(_lib.lib().sp_internal_source_option(self._h, _lib.INTERNAL_OPTION[name], int(value)))
 
     def prepare(self, prepared_target, source, transT=None, sort_by_cell=True):
-        if not source.has_cov():
+        p2d = getattr(prepared_target, "reg_type", "GICP") == "POINT_TO_DISTRIBUTION"  # no source covariance in that factor
+        if not source.has_cov() and not p2d:
             raise SpError(2, "[Registration::validate_params] Covariance matrices of source and target must be "
                              "pre-computed before performing GICP matching.")
         tp, on_dev, keep = _trans_arg(transT)
-        check(_lib.lib().sp_gicp_source_prepare(self._h, prepared_target._h, _ptr(source.points), _ptr(source.covs),
+        check(_lib.lib().sp_gicp_source_prepare(self._h, prepared_target._h, _ptr(source.points),
+                                                _ptr(source.covs if source.has_cov() else None),
                                                 source.size(), tp, on_dev, _SOURCE_ORDER[sort_by_cell], _stream()))
         self.n = source.size()
 
@@ -925,9 +932,68 @@ class Registration:
         self._rot_scale = (rotation_robust_scale if rotation_robust_scale > 0
                            else p.rotation_constraint_robust_default_scale)
         _, lin = self._buffers(source.points.device)
+        T = _T16(result.T).copy().reshape(-1)  # column-major working copy
+
+        def linearize_at(Tcol):
+            Tmat = Tcol.reshape(4, 4).T
+            target_knn.nearest_neighbor_search_async(source, self.neighbors, Tmat)
+            if p.reg_type == "GENZ":
+                self.genz_alpha = self._genz_alpha(source, target)
+            self._linearize("linearize", source, target, Tmat, scale, lin)
+            return self._read_lin(lin)  # the reference's wait_and_throw + toCPU (registration.hpp:674-675)
+
+        def error_at(Tcol, Tlin_col):
+            return self.compute_error_frozen(source, target, Tcol.reshape(4, 4).T, scale, self._rot_scale)
+
+        return self._host_loop(result, T, linearize_at, error_at, scale)
+
+    def align_prepared(self, source, prepared_target, initial_guess=None, robust_scale=-1.0, sort_by_cell=True):
+        """Registration::align (registration.hpp:201-276) with every optimiser (GN / LM / DOGLEG) on the PREPARED path:
+        each outer iteration linearises with the fused kernel (sp_gicp_iteration_fused: search or certified reuse +
+        linearise + reduce), and the trial steps of LM (:830-895) and dog-leg (:897-965) evaluate the frozen-correspondence
+        error with sp_gicp_error_prepared — a coalesced stream over the correspondence cache instead of the generic K12's
+        gathers and two eigen-decompositions per point. GICP and POINT_TO_DISTRIBUTION (the prepared target's reg_type)."""
+        L = _lib.lib()
+        p = self.params
+        result = RegistrationResult()
+        result.T = identity() if initial_guess is None else np.array(initial_guess, np.float32)
+        n = source.size()
+        if n == 0:
+            return result
+        if p.reg_type not in ("GICP", "POINT_TO_DISTRIBUTION") or p.rotation_constraint_enable:
+            raise SpError(1, "align_prepared: GICP / POINT_TO_DISTRIBUTION without the rotation constraint")
+        if prepared_target.reg_type != p.reg_type:
+            raise SpError(1, "align_prepared: the prepared target holds the rows of another reg_type")
+        if p.robust_type != "NONE" and p.robust_default_scale <= 0.0:
+            p.robust_type = "NONE"
+        scale = robust_scale if robust_scale > 0 else p.robust_default_scale
+        ws, lin = self._buffers(source.points.device)
+        T = _T16(result.T).copy().reshape(-1)
+        psrc, _ = self._prepared_source(n)
+        psrc.prepare(prepared_target, source, result.T, sort_by_cell)
+        fp = self._factor_params(scale)
+
+        def linearize_at(Tcol):
+            check(L.sp_gicp_iteration_fused(prepared_target._h, psrc._h, Tcol.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None,
+                                            None, None, _ptr(lin), None, _ptr(ws), ws.numel(), _stream()))
+            return self._read_lin(lin)
+
+        def error_at(Tcol, Tlin_col):
+            check(L.sp_gicp_error_prepared(prepared_target._h, psrc._h, Tlin_col.ctypes.data_as(C.c_void_p),
+                                           Tcol.ctypes.data_as(C.c_void_p), 0, C.byref(fp), _ptr(lin), _ptr(ws), ws.numel(),
+                                           _stream()))
+            r = self._read_lin(lin)
+            return float(r.error), int(r.inlier)
+
+        return self._host_loop(result, T, linearize_at, error_at, scale)
+
+    def _host_loop(self, result, T, linearize_at, error_at, scale):
+        """The optimiser loop of Registration::align shared by the generic and the prepared path: `linearize_at(T)` returns
+        the reduced system at pose T (column-major 16 floats), `error_at(T_trial, T_lin)` the frozen-correspondence error."""
+        L = _lib.lib()
+        p = self.params
         lm_lambda = p.lm_init_lambda
         radius = np.float32(p.dogleg_initial_trust_region_radius)
-        T = _T16(result.T).copy().reshape(-1)  # column-major working copy
         T_initial = T.copy()
         delta8 = np.zeros(8, np.float32)
         dreg = DegenerateRegParams({"NONE": 0, "NL_REG": 1, "NL-REG": 1}[p.degenerate_reg_type.upper()],
@@ -935,12 +1001,7 @@ class Registration:
                                    p.degenerate_reg_trans_eigenvalue_threshold, p.degenerate_reg_base_factor)
         prior_on = p.map_prior_enabled and bool(self._map_prior.has_prior)
         for it in range(p.max_iterations):
-            Tmat = T.reshape(4, 4).T
-            target_knn.nearest_neighbor_search_async(source, self.neighbors, Tmat)
-            if p.reg_type == "GENZ":
-                self.genz_alpha = self._genz_alpha(source, target)
-            self._linearize("linearize", source, target, Tmat, scale, lin)
-            lr = self._read_lin(lin)  # the reference's wait_and_throw + toCPU (registration.hpp:674-675)
+            lr = linearize_at(T)
             result.H_raw = np.array(lr.H, np.float32).reshape(6, 6)  # registration.hpp:244-246
             result.b_raw = np.array(lr.b, np.float32)
             result.error_raw = float(lr.error)
@@ -977,8 +1038,7 @@ class Registration:
                     L.sp_se3_exp_host(p6.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p))
                     L.sp_rigid_mul_host(T.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p),
                                         Ttry.ctypes.data_as(C.c_void_p))
-                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale,
-                                                               self._rot_scale)
+                    new_error, inl = error_at(Ttry, T)
                     new_error = f32(f32(new_error) + self._prior_error(Ttry))  # registration.hpp:933
                     rho = f32(f32(lr.error) - f32(new_error)) / f32(pred.value)
                     if rho < p.dogleg_eta1:
@@ -1000,8 +1060,7 @@ class Registration:
                                         p.criteria_translation, delta8.ctypes.data_as(C.c_void_p))
                     conv = bool(delta8[6] > 0.5)
                     result.converged = conv
-                    new_error, inl = self.compute_error_frozen(source, target, Ttry.reshape(4, 4).T, scale,
-                                                               self._rot_scale)
+                    new_error, inl = error_at(Ttry, T)
                     new_error = np.float32(np.float32(new_error) + self._prior_error(Ttry))  # registration.hpp:854
                     if new_error <= current_error:
                         result.converged, T = conv, Ttry
@@ -1072,8 +1131,8 @@ class Registration:
 
         L = _lib.lib()
         p = self.params
-        if p.reg_type != "GICP" or p.optimization_method != "GN":
-            raise SpError(1, "align_fused_loop implements GICP with the Gauss-Newton optimiser")
+        if p.reg_type not in ("GICP", "POINT_TO_DISTRIBUTION") or p.optimization_method != "GN":
+            raise SpError(1, "align_fused_loop implements GICP / POINT_TO_DISTRIBUTION with the Gauss-Newton optimiser")
         iters = p.max_iterations if iterations is None else iterations
         scale = robust_scale if robust_scale > 0 else p.robust_default_scale
         dev = source.points.device

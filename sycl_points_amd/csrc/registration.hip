@@ -581,6 +581,9 @@ __device__ __forceinline__ Sym3 load_sym(const float4* __restrict__ p) {
     return Sym3{a.x, a.y, a.z, a.w, b.x, b.y};
 }
 
+// P2D: the row holds the information matrix of point-to-distribution itself, inverse(Ct) of the RAW covariance
+// (compute_target_mahalanobis, factor.hpp:311-317; Zero when |det| < 1e-6 as eigen_utils::inverse returns), symmetrised.
+template <bool P2D>
 __global__ __launch_bounds__(kBlock) void prepare_cov_kernel(const float4* __restrict__ covs, unsigned n,
                                                              const float4* __restrict__ order_pts,
                                                              const unsigned* __restrict__ order_idx,
@@ -590,7 +593,8 @@ __global__ __launch_bounds__(kBlock) void prepare_cov_kernel(const float4* __res
     if (i >= n) return;
     // row i of the output belongs to the point whose original index is order_pts[i].w / order_idx[i] (or i itself)
     const unsigned src = order_pts ? __float_as_uint(order_pts[i].w) : (order_idx ? order_idx[i] : i);
-    const Mat3 P = plane_regularize(load_cov3(covs + 4 * (size_t)src));
+    const Mat3 C = load_cov3(covs + 4 * (size_t)src);
+    const Mat3 P = P2D ? inverse(C) : plane_regularize(C);
     out[2 * (size_t)i] = make_float4(P.m[0][0], (P.m[0][1] + P.m[1][0]) * 0.5f, (P.m[0][2] + P.m[2][0]) * 0.5f, P.m[1][1]);
     // third slot of the second half-row (target side only): the point's squared safe radius (fused_point)
     out[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], rho2 ? rho2[src] : 0.0f, 0.0f);
@@ -659,8 +663,9 @@ __global__ __launch_bounds__(kBlock) void prepare_source_kernel(const float4* __
     if (i >= n) return;
     const unsigned src = order[i];
     const float4 p = pts[src];
-    const Mat3 P = plane_regularize(load_cov3(covs + 4 * (size_t)src));
     out_pts[i] = p.x; out_pts[stride + i] = p.y; out_pts[2 * (size_t)stride + i] = p.z;
+    if (!covs) return;  // point-to-distribution: the covariance planes are never read
+    const Mat3 P = plane_regularize(load_cov3(covs + 4 * (size_t)src));
     out_covp[i] = P.m[0][0];
     out_covp[stride + i] = (P.m[0][1] + P.m[1][0]) * 0.5f;
     out_covp[2 * (size_t)stride + i] = (P.m[0][2] + P.m[2][0]) * 0.5f;
@@ -694,10 +699,14 @@ struct FusedParams {
 };
 
 // Linearisation of one correspondence (source point s with q = T s, winner nn, packed covariances) and accumulation.
-template <int LOSS>
+// P2D (linearize_point_to_distribution, factor.hpp:311-354): Ct is the target's information matrix M = inverse(Ct_raw)
+// (prepared once per target) and there is no source covariance: N = R^T M R, nothing to invert per point.
+// ERR_ONLY (calculate_gicp_error / calculate_point_to_distribution_error, factor.hpp:280-306, 356-373): only the robust
+// error and the count, into acc[0] — the K12 of a trial pose (sp_gicp_error_prepared).
+template <int LOSS, bool P2D = false, bool ERR_ONLY = false, int NACC = kAcc - 1>
 __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T, const float4 s, float qx, float qy,
                                            float qz, const Nearest& nn, const Sym3& Cs, const Sym3& Ct,
-                                           float (&acc)[kAcc - 1], unsigned& cnt) {
+                                           float (&acc)[NACC], unsigned& cnt) {
     const float r0 = nn.x - qx, r1 = nn.y - qy, r2 = nn.z - qz;
     // Source-frame form of factor.hpp:239-278. With S = skew(p), J = [R S | -R] and M = (Ct' + R Cs' R^T)^-1:
     //   N := R^T M R = (Cs' + R^T Ct' R)^-1,  v := R^T r,  u := N v,  G := S N
@@ -711,24 +720,29 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
         W[1][j] = chain3(Ct.xy, R[0][j], Ct.yy, R[1][j], Ct.yz, R[2][j]);
         W[2][j] = chain3(Ct.xz, R[0][j], Ct.yz, R[1][j], Ct.zz, R[2][j]);
     }
-    Mat3 A;  // Cs' + R^T Ct' R (symmetric)
-    A.m[0][0] = chain3(R[0][0], W[0][0], R[1][0], W[1][0], R[2][0], W[2][0]) + Cs.xx;
-    A.m[0][1] = chain3(R[0][0], W[0][1], R[1][0], W[1][1], R[2][0], W[2][1]) + Cs.xy;
-    A.m[0][2] = chain3(R[0][0], W[0][2], R[1][0], W[1][2], R[2][0], W[2][2]) + Cs.xz;
-    A.m[1][1] = chain3(R[0][1], W[0][1], R[1][1], W[1][1], R[2][1], W[2][1]) + Cs.yy;
-    A.m[1][2] = chain3(R[0][1], W[0][2], R[1][1], W[1][2], R[2][1], W[2][2]) + Cs.yz;
-    A.m[2][2] = chain3(R[0][2], W[0][2], R[1][2], W[1][2], R[2][2], W[2][2]) + Cs.zz;
-    // symmetric inverse by the adjugate; Zero when |det| < 1e-6 (eigen_utils::inverse, eigen_utils.hpp:403-423;
-    // det is invariant under the rotation)
-    const float c00 = fmaf(A.m[1][1], A.m[2][2], -A.m[1][2] * A.m[1][2]);
-    const float c01 = fmaf(A.m[0][2], A.m[1][2], -A.m[0][1] * A.m[2][2]);
-    const float c02 = fmaf(A.m[0][1], A.m[1][2], -A.m[0][2] * A.m[1][1]);
-    const float det = fmaf(A.m[0][0], c00, fmaf(A.m[0][1], c01, A.m[0][2] * c02));
-    const float inv_det = fabsf(det) < 1e-6f ? 0.0f : 1.0f / det;
-    const float n00 = c00 * inv_det, n01 = c01 * inv_det, n02 = c02 * inv_det;
-    const float n11 = fmaf(A.m[0][0], A.m[2][2], -A.m[0][2] * A.m[0][2]) * inv_det;
-    const float n12 = fmaf(A.m[0][1], A.m[0][2], -A.m[0][0] * A.m[1][2]) * inv_det;
-    const float n22 = fmaf(A.m[0][0], A.m[1][1], -A.m[0][1] * A.m[0][1]) * inv_det;
+    Mat3 A;  // Cs' + R^T Ct' R (symmetric); P2D: R^T M R
+    A.m[0][0] = chain3(R[0][0], W[0][0], R[1][0], W[1][0], R[2][0], W[2][0]) + (P2D ? 0.0f : Cs.xx);
+    A.m[0][1] = chain3(R[0][0], W[0][1], R[1][0], W[1][1], R[2][0], W[2][1]) + (P2D ? 0.0f : Cs.xy);
+    A.m[0][2] = chain3(R[0][0], W[0][2], R[1][0], W[1][2], R[2][0], W[2][2]) + (P2D ? 0.0f : Cs.xz);
+    A.m[1][1] = chain3(R[0][1], W[0][1], R[1][1], W[1][1], R[2][1], W[2][1]) + (P2D ? 0.0f : Cs.yy);
+    A.m[1][2] = chain3(R[0][1], W[0][2], R[1][1], W[1][2], R[2][1], W[2][2]) + (P2D ? 0.0f : Cs.yz);
+    A.m[2][2] = chain3(R[0][2], W[0][2], R[1][2], W[1][2], R[2][2], W[2][2]) + (P2D ? 0.0f : Cs.zz);
+    float n00, n01, n02, n11, n12, n22;
+    if (P2D) {
+        n00 = A.m[0][0]; n01 = A.m[0][1]; n02 = A.m[0][2]; n11 = A.m[1][1]; n12 = A.m[1][2]; n22 = A.m[2][2];
+    } else {
+        // symmetric inverse by the adjugate; Zero when |det| < 1e-6 (eigen_utils::inverse, eigen_utils.hpp:403-423;
+        // det is invariant under the rotation)
+        const float c00 = fmaf(A.m[1][1], A.m[2][2], -A.m[1][2] * A.m[1][2]);
+        const float c01 = fmaf(A.m[0][2], A.m[1][2], -A.m[0][1] * A.m[2][2]);
+        const float c02 = fmaf(A.m[0][1], A.m[1][2], -A.m[0][2] * A.m[1][1]);
+        const float det = fmaf(A.m[0][0], c00, fmaf(A.m[0][1], c01, A.m[0][2] * c02));
+        const float inv_det = fabsf(det) < 1e-6f ? 0.0f : 1.0f / det;
+        n00 = c00 * inv_det; n01 = c01 * inv_det; n02 = c02 * inv_det;
+        n11 = fmaf(A.m[0][0], A.m[2][2], -A.m[0][2] * A.m[0][2]) * inv_det;
+        n12 = fmaf(A.m[0][1], A.m[0][2], -A.m[0][0] * A.m[1][2]) * inv_det;
+        n22 = fmaf(A.m[0][0], A.m[1][1], -A.m[0][1] * A.m[0][1]) * inv_det;
+    }
     const float v0 = chain3(R[0][0], r0, R[1][0], r1, R[2][0], r2);
     const float v1 = chain3(R[0][1], r0, R[1][1], r1, R[2][1], r2);
     const float v2 = chain3(R[0][2], r0, R[1][2], r1, R[2][2], r2);
@@ -737,6 +751,10 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
     const float u2 = chain3(n02, v0, n12, v1, n22, v2);
     const float sq = chain3(v0, u0, v1, u1, v2, u2);
     const float rn = sqrtf(sq);
+    if constexpr (ERR_ONLY) {
+        acc[0] += robust_error<LOSS>(rn, P.scale);
+        ++cnt;
+    } else {
     const float w = robust_weight<LOSS>(rn, P.scale);
     const float px = s.x, py = s.y, pz = s.z;
     // G = S N, rows: p x (columns of N)
@@ -755,10 +773,11 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
     acc[24] += w * -u0; acc[25] += w * -u1; acc[26] += w * -u2;
     acc[27] += robust_error<LOSS>(rn, P.scale);
     ++cnt;
+    }
 }
 
 // One source point of the fused iteration: q = T p -> exact NN on the target grid -> linearise -> accumulate.
-template <int LOSS, bool FAST_NN, int DBG>
+template <int LOSS, bool FAST_NN, int DBG, bool P2D = false>
 __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
                                             unsigned& cnt, unsigned& searched) {
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
@@ -830,12 +849,13 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
     if (nn.idx < 0 || nn.d2 > P.max_d2) return;
     const float* const cp = P.scovp + i;
     const size_t st = P.sstride;
-    const Sym3 Cs{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
+    Sym3 Cs{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (!P2D) Cs = Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
     if (!have_ct) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
-    fused_math<LOSS>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
+    fused_math<LOSS, P2D>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
 }
 
-template <int LOSS, bool FAST_NN, int DBG = 0>
+template <int LOSS, bool FAST_NN, int DBG = 0, bool P2D = false>
 __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float* __restrict__ partials) {
     const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
     float acc[kAcc - 1];
@@ -843,8 +863,43 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
     unsigned cnt = 0, searched = 0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock)
-        fused_point<LOSS, FAST_NN, DBG>(P, T, i, acc, cnt, searched);
+        fused_point<LOSS, FAST_NN, DBG, P2D>(P, T, i, acc, cnt, searched);
     block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
+}
+
+// K12 on the prepared path (Registration::compute_error_parallel_reduction, registration.hpp:678-777, as the LM and
+// dog-leg trial steps call it, :854, :933): the error at a TRIAL pose with the correspondences FROZEN at those of the last
+// linearisation. They are not re-read from neighbour arrays: the correspondence cache (source order, filled or confirmed by
+// that linearisation) already holds every point's winner and its prepared covariance row, so a trial step is one coalesced
+// stream of 36 + 48 bytes per point — no search, no gather, no eigen-decomposition (the generic sp_gicp_error gathers
+// 168 B per point and decomposes two covariances per point). The inlier gate uses the distance at the LINEARISATION pose
+// T_lin (nn_d2 in the reference), recomputed here with the search's own arithmetic, i.e. the same bits.
+template <int LOSS, bool P2D>
+__global__ __launch_bounds__(kBlock) void error_prepared_kernel(FusedParams P, Mat4Arg T_lin_val, float* __restrict__ partials) {
+    const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);  // trial pose
+    const Rigid TL = load_rigid_colmajor(T_lin_val.m);
+    float acc[1] = {0.0f};
+    unsigned cnt = 0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock) {
+        const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
+        const float4* const row = P.ccache + 3 * (size_t)i;
+        const float4 tp = row[0], c0 = row[1], c1 = row[2];
+        if (__float_as_int(tp.w) < 0) continue;  // no neighbour found
+        float lx, ly, lz;
+        transform_point(TL, s.x, s.y, s.z, lx, ly, lz);
+        if (dist2(lx, ly, lz, tp.x, tp.y, tp.z) > P.max_d2) continue;  // registration.hpp:716-718
+        float qx, qy, qz;
+        transform_point(T, s.x, s.y, s.z, qx, qy, qz);
+        Nearest nn;
+        nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = __float_as_int(tp.w); nn.pos = 0; nn.d2 = 0.0f;
+        const float* const cp = P.scovp + i;
+        const size_t st = P.sstride;
+        Sym3 Cs{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (!P2D) Cs = Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
+        const Sym3 Ct{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+        fused_math<LOSS, P2D, true, 1>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
+    }
+    block_reduce_store<1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -939,7 +994,7 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
     return true;
 }
 
-template <int LOSS, bool FAST_NN>
+template <int LOSS, bool FAST_NN, bool P2D = false>
 __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, AlignArgs A,
                                                                  float* __restrict__ partials) {
     __shared__ float sT[16];
@@ -971,7 +1026,7 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     unsigned tile = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-        fused_point<LOSS, FAST_NN, 0>(P, T, i, acc, cnt, searched);
+        fused_point<LOSS, FAST_NN, 0, P2D>(P, T, i, acc, cnt, searched);
 #ifdef SP_KERNEL_TIMING
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) tm[17 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime();  // point loop done
 #endif
@@ -1218,6 +1273,7 @@ struct sp_gicp_target {
     float* rho2 = nullptr;          // per target point (original order): squared safe radius of the reuse test
     float4* nb = nullptr;           // per target point (grid order): second certificate (nearest neighbour, second radius)
     unsigned long long version = 0; // bumped by every sp_gicp_target_update (cached copies of rows become stale)
+    int reg_type = SP_REG_GICP;     // what the rows hold: plane(Ct) for GICP, inverse(Ct) for POINT_TO_DISTRIBUTION
     size_t n = 0;
 };
 struct sp_gicp_source {
@@ -1247,18 +1303,34 @@ extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
     sp::pooled_free(t->nb);
     delete t;
 }
-extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, void* stream) {
+extern "C" int sp_gicp_target_prepare(sp_gicp_target* t, const float* tgt_covs, int reg_type, void* stream) {
     using namespace sp;
     if (!t || !tgt_covs) {
-        sp_set_error("[Registration::validate_params] Covariance matrices of source and target must be pre-computed "
-                     "before performing GICP matching.");
+        sp_set_error(reg_type == SP_REG_POINT_TO_DISTRIBUTION
+                         ? "[Registration::validate_params] Covariance matrices of target must be pre-computed before "
+                           "performing Point-to-Distribution ICP matching."
+                         : "[Registration::validate_params] Covariance matrices of source and target must be pre-computed "
+                           "before performing GICP matching.");
         return SP_ERR_RUNTIME;
     }
+    if (reg_type != SP_REG_GICP && reg_type != SP_REG_POINT_TO_DISTRIBUTION) {
+        sp_set_error("[sp_gicp_target_prepare] only RegType::GICP and RegType::POINT_TO_DISTRIBUTION have a prepared form");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
     ++t->version;
+    t->reg_type = reg_type;
     if (t->n == 0) return SP_OK;
-    prepare_cov_kernel<<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(tgt_covs), (unsigned)t->n, t->grid->d_pts, nullptr, t->covp, t->rho2);
+    const float4* covs = reinterpret_cast<const float4*>(tgt_covs);
+    if (reg_type == SP_REG_GICP)
+        prepare_cov_kernel<false><<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(covs, (unsigned)t->n, t->grid->d_pts,
+                                                                                          nullptr, t->covp, t->rho2);
+    else
+        prepare_cov_kernel<true><<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(covs, (unsigned)t->n, t->grid->d_pts,
+                                                                                         nullptr, t->covp, t->rho2);
     return launch_status();
+}
+extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, void* stream) {
+    return sp_gicp_target_prepare(t, tgt_covs, t ? t->reg_type : SP_REG_GICP, stream);
 }
 extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream,
                                      sp_gicp_target** out) {
@@ -1357,7 +1429,7 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
         sp_set_error("[sp_gicp_source_prepare] more points than the object was created for");
         return SP_ERR_INVALID_ARGUMENT;
     }
-    if (!src_covs && n) {
+    if (!src_covs && n && target->reg_type == SP_REG_GICP) {  // point-to-distribution has no source covariance
         sp_set_error("[Registration::validate_params] Covariance matrices of source and target must be pre-computed "
                      "before performing GICP matching.");
         return SP_ERR_RUNTIME;
@@ -1392,7 +1464,8 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
     s->cache_valid = false;  // no previous correspondences
     s->cache_target = target;
     s->cache_version = target->version;
-    prepare_source_kernel<<<nb, kBlock, 0, st>>>(pts, reinterpret_cast<const float4*>(src_covs), s->perm, (unsigned)n,
+    prepare_source_kernel<<<nb, kBlock, 0, st>>>(pts, target->reg_type == SP_REG_GICP ? reinterpret_cast<const float4*>(src_covs) : nullptr,
+                                                 s->perm, (unsigned)n,
                                                  (unsigned)((n + 63) / 64 * 64), reinterpret_cast<float*>(s->pts),
                                                  reinterpret_cast<float*>(s->covp));
     return launch_status();
@@ -1420,11 +1493,36 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
         for (int i = 0; i < 16; ++i) P.T_val.m[i] = transT[i];
     P.T_dev = transT_on_device ? transT : nullptr;
     P.perm = source->perm;
-    P.ccache = (source->opt_reuse && target->rho2) ? source->ccache : nullptr;
-    P.cache_valid = (source->cache_valid && source->cache_target == target && source->cache_version == target->version) ? 1 : 0;
+    // the cache rows are always written (sp_gicp_error_prepared reads the frozen correspondences from them); the reuse
+    // switch only decides whether a later linearisation may trust them instead of searching
+    P.ccache = target->rho2 ? source->ccache : nullptr;
+    P.cache_valid = (source->opt_reuse && source->cache_valid && source->cache_target == target &&
+                     source->cache_version == target->version) ? 1 : 0;
     P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
     P.nn_d2 = nn_d2_out;
     return P;
+}
+}  // namespace
+}  // namespace sp
+
+namespace sp {
+namespace {
+// The prepared forms exist for RegType::GICP and POINT_TO_DISTRIBUTION; the target's rows must be of the factor asked for.
+int check_prepared_reg(const char* who, const sp_gicp_target* target, const sp_factor_params* params) {
+    if (params->reg_type != SP_REG_GICP && params->reg_type != SP_REG_POINT_TO_DISTRIBUTION) {
+        sp_set_error("[sp_gicp_*] only RegType::GICP and RegType::POINT_TO_DISTRIBUTION have a prepared/fused form");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (params->reg_type != target->reg_type) {
+        sp_set_error("[sp_gicp_*] the prepared target holds the rows of another RegType: call sp_gicp_target_prepare");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (params->rotation_constraint_enable) {
+        sp_set_error("[sp_gicp_*] the rotation constraint needs the raw covariances: use sp_gicp_linearize");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    (void)who;
+    return SP_OK;
 }
 }  // namespace
 }  // namespace sp
@@ -1436,14 +1534,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     using namespace sp;
     hipStream_t st = as_stream(stream);
     if (!target || !source || !params || !out) return SP_ERR_INVALID_ARGUMENT;
-    if (params->reg_type != SP_REG_GICP) {
-        sp_set_error("[sp_gicp_iteration_fused] only RegType::GICP has a prepared/fused form");
-        return SP_ERR_INVALID_ARGUMENT;
-    }
-    if (params->rotation_constraint_enable) {
-        sp_set_error("[sp_gicp_iteration_fused] the rotation constraint needs the raw covariances: use sp_gicp_linearize");
-        return SP_ERR_INVALID_ARGUMENT;
-    }
+    if (const int rc = check_prepared_reg("iteration_fused", target, params); rc != SP_OK) return rc;
     if (gn && !transT_on_device) {
         sp_set_error("[sp_gicp_iteration_fused] the fused Gauss-Newton update needs the pose on the device");
         return SP_ERR_INVALID_ARGUMENT;
@@ -1461,12 +1552,15 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     // Unsorted lanes touch unrelated cells: the ring walk (fewest cache lines per query) wins. Cell-sorted lanes share
     // their lines: the branch-light 2x2x2 walk wins (profiles/README.md, r01_c).
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
+    const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_FUSED(L)                                                              \
     if (!(source->opt_stage_mask & 1)) {}                                                   \
     else if (source->opt_stage_mask & 4) gicp_fused_kernel<LOSS_NONE, true, 1><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (source->opt_stage_mask & 8) gicp_fused_kernel<LOSS_NONE, true, 2><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (source->opt_stage_mask & 16) gicp_fused_kernel<LOSS_NONE, true, 3><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (fast && p2d) gicp_fused_kernel<L, true, 0, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (p2d) gicp_fused_kernel<L, false, 0, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else gicp_fused_kernel<L, false><<<grid, kBlock, 0, st>>>(P, partials)
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_FUSED(LOSS_NONE); break;
@@ -1506,14 +1600,7 @@ unsigned align_grid(size_t n) {
 int align_check(const char* who, const sp_gicp_target* target, const sp_gicp_source* source, const sp_factor_params* params,
                 const sp_gn_params* gn, const float* T, void* workspace, size_t workspace_bytes) {
     if (!target || !source || !params || !gn || !T) return SP_ERR_INVALID_ARGUMENT;
-    if (params->reg_type != SP_REG_GICP) {
-        sp_set_error("[sp_gicp_align_*] only RegType::GICP has a prepared/fused form");
-        return SP_ERR_INVALID_ARGUMENT;
-    }
-    if (params->rotation_constraint_enable) {
-        sp_set_error("[sp_gicp_align_*] the rotation constraint needs the raw covariances: use sp_gicp_linearize");
-        return SP_ERR_INVALID_ARGUMENT;
-    }
+    if (const int rc = check_prepared_reg(who, target, params); rc != SP_OK) return rc;
     if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(source->n)) {
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
@@ -1523,6 +1610,46 @@ int align_check(const char* who, const sp_gicp_target* target, const sp_gicp_sou
 }
 }  // namespace
 }  // namespace sp
+
+extern "C" int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gicp_source* source, const float* transT_lin_host,
+                                      const float* transT_trial, int trial_on_device, const sp_factor_params* params,
+                                      sp_linearized* out, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (!target || !source || !params || !out || !transT_lin_host) return SP_ERR_INVALID_ARGUMENT;
+    if (const int rc = check_prepared_reg("error_prepared", target, params); rc != SP_OK) return rc;
+    const size_t n = source->n;
+    if (n == 0) return hip_status(hipMemsetAsync(out, 0, sizeof(sp_linearized), st));
+    if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
+        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (!source->cache_valid || source->cache_target != target || source->cache_version != target->version) {
+        sp_set_error("[sp_gicp_error_prepared] no frozen correspondences: linearise first (sp_gicp_iteration_fused / "
+                     "sp_gicp_align_*) with this target");  // compute_error_frozen needs the neighbours of a linearisation
+        return SP_ERR_RUNTIME;
+    }
+    const FusedParams P = make_fused_params(target, source, params, transT_trial, trial_on_device, nullptr, nullptr);
+    Mat4Arg TL;
+    for (int i = 0; i < 16; ++i) TL.m[i] = transT_lin_host[i];
+    const unsigned grid = reduce_grid(n);
+    float* partials = static_cast<float*>(workspace);
+    const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
+#define SP_LAUNCH_ERR(L)                                                                       \
+    if (p2d) error_prepared_kernel<L, true><<<grid, kBlock, 0, st>>>(P, TL, partials);        \
+    else error_prepared_kernel<L, false><<<grid, kBlock, 0, st>>>(P, TL, partials)
+    switch (params->robust_type) {
+        case SP_LOSS_NONE: SP_LAUNCH_ERR(LOSS_NONE); break;
+        case SP_LOSS_HUBER: SP_LAUNCH_ERR(LOSS_HUBER); break;
+        case SP_LOSS_TUKEY: SP_LAUNCH_ERR(LOSS_TUKEY); break;
+        case SP_LOSS_CAUCHY: SP_LAUNCH_ERR(LOSS_CAUCHY); break;
+        case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_ERR(LOSS_GEMAN_MCCLURE); break;
+        default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
+    }
+#undef SP_LAUNCH_ERR
+    final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, 1, out, GnArgs{nullptr, 0.0f, 0.0f, 0.0f, nullptr});
+    return launch_status();
+}
 
 extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                                  const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
@@ -1559,9 +1686,12 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     A.searched_log = w.searched_log;
     A.k = k;
     float* out = w.part[k & 1];
+    const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_ALIGN(L)                                                                            \
     if (!(source->opt_stage_mask & 1)) {}                                                                 \
+    else if (fast && p2d) gicp_align_kernel<L, true, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);     \
     else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);              \
+    else if (p2d) gicp_align_kernel<L, false, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);         \
     else gicp_align_kernel<L, false><<<grid, kAlignBlock, 0, st>>>(P, A, out)
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_ALIGN(LOSS_NONE); break;

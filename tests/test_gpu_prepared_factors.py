@@ -1,0 +1,168 @@
+"""Prepared / fused forms of what BASELINE config 4 ("GICP (point-to-distribution)") and config 1 (LM + Geman-McClure)
+name: POINT_TO_DISTRIBUTION in the fused kernels (linearize_point_to_distribution, factor.hpp:311-373) and the prepared K12
+(sp_gicp_error_prepared, registration.hpp:678-777) that keeps the LM / dog-leg trial steps (:830-965) on the device path.
+Checker: the oracle, whose GICP / P2D core is pinned by tests/test_oracle_gicp_f64.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def sp():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    import sycl_points_amd.api as api
+
+    return api
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def inputs(orc, n, density_scale=1.0, seed=1234):
+    """density_scale 1: BASELINE config-4 density (k = 20 covariances with det ~ 1e-6: inverse(Ct) is Zero for part of the
+    cloud, as eigen_utils::inverse prescribes); 8: a sparser cloud whose covariances are all well inside the invertible range."""
+    from sycl_points_amd.synthetic import gicp_pair
+
+    r = 10.0 * (n * density_scale / 1e6) ** (1.0 / 3.0)
+    src, tgt, T_gt = gicp_pair(n, r, seed)
+    ti, _ = orc.kdtree_knn(orc.kdtree_build(tgt), tgt, 20)
+    si, _ = orc.kdtree_knn(orc.kdtree_build(src), src, 20)
+    return src, orc.cov_estimate(src, si), tgt, orc.cov_estimate(tgt, ti), T_gt
+
+
+@pytest.fixture(scope="module", params=[1.0, 8.0], ids=["config4-density", "sparse"])
+def clouds(orc, request):
+    return inputs(orc, 20000, request.param)
+
+
+@pytest.mark.parametrize("loss", ["NONE", "HUBER", "GEMAN_MCCLURE"])
+def test_p2d_fused_iteration_matches_oracle(sp, orc, clouds, loss):
+    src, scov, tgt, tcov, T_gt = clouds
+    T = orc.se3_exp([0.004, -0.01, 0.008, 0.02, -0.01, 0.005])
+    max_corr = 0.05 if np.abs(tgt[:, :3]).max() < 5 else 0.1  # rejects part of the correspondences
+    idx, d2 = orc.knn_bruteforce(orc.transform_points(src, T), tgt, 1)
+    ref = orc.gicp_linearize(src, None, tgt, tcov, None, idx, d2, T, max_corr, "POINT_TO_DISTRIBUTION", loss, 0.5)
+    assert 0 < ref["inlier"] < len(src)
+    S = sp.PointCloudShared(dev(src))  # point-to-distribution needs no source covariance (factor.hpp:311-317)
+    prep = sp.PreparedTarget(sp.GridKNN.build(dev(tgt)), dev(tcov), reg_type="POINT_TO_DISTRIBUTION")
+    reg = sp.Registration(sp.RegistrationParams(reg_type="POINT_TO_DISTRIBUTION", max_correspondence_distance=max_corr,
+                                                robust_type=loss))
+    L = sp._lib.lib()
+    ws, lin = reg._buffers(S.points.device)
+    psrc = sp.PreparedSource(len(src))
+    psrc.prepare(prep, S, T, sort_by_cell=True)
+    fp = reg._factor_params(0.5)
+    reg.neighbors.resize(len(src), 1, S.points.device)
+    Tc = np.ascontiguousarray(T.T).reshape(-1)
+    sp.check(L.sp_gicp_iteration_fused(prep._h, psrc._h, Tc.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None,
+                                       sp._ptr(reg.neighbors.indices), sp._ptr(reg.neighbors.distances), sp._ptr(lin), None,
+                                       sp._ptr(ws), ws.numel(), sp._stream()))
+    got = reg._read_lin(lin)
+    assert np.array_equal(reg.neighbors.indices.cpu().numpy(), idx)
+    H = np.array(got.H, np.float32).reshape(6, 6)
+    hs = np.abs(ref["H"]).max()
+    assert got.inlier == ref["inlier"]
+    assert np.abs(H - ref["H"]).max() <= 2e-5 * hs and np.array_equal(H, H.T)
+    assert np.abs(np.array(got.b) - ref["b"]).max() <= 2e-5 * max(np.abs(ref["b"]).max(), 1e-3 * hs)
+    assert abs(got.error - ref["error"]) <= 2e-5 * abs(ref["error"])
+    # a target prepared for GICP refuses the other factor, and the other way round (rows of the wrong kind)
+    gicp_prep = sp.PreparedTarget(prep.grid, dev(tcov))
+    with pytest.raises(sp.SpError):
+        sp.check(L.sp_gicp_iteration_fused(gicp_prep._h, psrc._h, Tc.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None, None,
+                                           None, sp._ptr(lin), None, sp._ptr(ws), ws.numel(), sp._stream()))
+
+
+@pytest.mark.parametrize("reg_type", ["GICP", "POINT_TO_DISTRIBUTION"])
+def test_one_call_loop_p2d_and_gicp_match_oracle(sp, orc, clouds, reg_type):
+    from oracle.pyoracle import REG, RegParams
+
+    src, scov, tgt, tcov, T_gt = clouds
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(dev(tgt)), dev(tcov), reg_type=reg_type)
+    p = sp.RegistrationParams(reg_type=reg_type, criteria_translation=1e-4, criteria_rotation=1e-4, max_iterations=30)
+    reg = sp.Registration(p)
+    T_dev, lin, delta = reg.align_fused_loop(S, prep)
+    ref = orc.registration_align(RegParams.defaults(reg_type=REG[reg_type], crit_translation=1e-4, crit_rotation=1e-4,
+                                                    max_iterations=30), src, scov, tgt, tcov)
+    assert ref["converged"] and float(delta[6]) == 1.0
+    assert int(reg._iters_dev[0]) == ref["iterations"] + 1
+    assert np.abs(reg.T_from_device(T_dev) - ref["T"]).max() < 1e-5
+    assert reg._read_lin(lin).inlier == ref["inlier"]
+    assert np.abs(ref["T"] - T_gt).max() < 5e-3
+
+
+@pytest.mark.parametrize("reg_type", ["GICP", "POINT_TO_DISTRIBUTION"])
+@pytest.mark.parametrize("loss", ["NONE", "GEMAN_MCCLURE"])
+def test_error_prepared_matches_oracle_k12(sp, orc, clouds, reg_type, loss):
+    src, scov, tgt, tcov, T_gt = clouds
+    T_lin = orc.se3_exp([0.004, -0.01, 0.008, 0.02, -0.01, 0.005])
+    max_corr = 0.05 if np.abs(tgt[:, :3]).max() < 5 else 0.1
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(dev(tgt)), dev(tcov), reg_type=reg_type)
+    reg = sp.Registration(sp.RegistrationParams(reg_type=reg_type, max_correspondence_distance=max_corr, robust_type=loss))
+    L = sp._lib.lib()
+    ws, lin = reg._buffers(S.points.device)
+    psrc = sp.PreparedSource(len(src))
+    psrc.prepare(prep, S, T_lin, sort_by_cell=True)
+    fp = reg._factor_params(0.5)
+    Tl = np.ascontiguousarray(T_lin.T).reshape(-1)
+    with pytest.raises(sp.SpError):  # nothing linearised yet: no frozen correspondences
+        sp.check(L.sp_gicp_error_prepared(prep._h, psrc._h, Tl.ctypes.data_as(C.c_void_p), Tl.ctypes.data_as(C.c_void_p), 0,
+                                          C.byref(fp), sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+    reg.neighbors.resize(len(src), 1, S.points.device)
+    sp.check(L.sp_gicp_iteration_fused(prep._h, psrc._h, Tl.ctypes.data_as(C.c_void_p), 0, C.byref(fp), None,
+                                       sp._ptr(reg.neighbors.indices), sp._ptr(reg.neighbors.distances), sp._ptr(lin), None,
+                                       sp._ptr(ws), ws.numel(), sp._stream()))
+    idx, d2 = reg.neighbors.indices.cpu().numpy(), reg.neighbors.distances.cpu().numpy()
+    for twist in ([0.0] * 6, [0.002, 0.001, -0.003, 0.01, 0.02, -0.01], [-0.01, 0.004, 0.002, -0.03, 0.0, 0.02]):
+        T_trial = orc.isometry_mul(T_lin, orc.se3_exp(twist))  # T <- T exp(delta), as a trial step makes it
+        Tt = np.ascontiguousarray(T_trial.T).reshape(-1)
+        sp.check(L.sp_gicp_error_prepared(prep._h, psrc._h, Tl.ctypes.data_as(C.c_void_p), Tt.ctypes.data_as(C.c_void_p), 0,
+                                          C.byref(fp), sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+        got = reg._read_lin(lin)
+        err, inl = orc.gicp_error(src, scov, tgt, tcov, None, idx, d2, T_trial, max_corr, reg_type, loss, 0.5)
+        assert 0 < inl < len(src) and got.inlier == inl
+        assert abs(got.error - err) <= 2e-5 * abs(err)
+
+
+CASES = [
+    dict(opt="LM", reg_type="GICP", loss="GEMAN_MCCLURE", scale=0.5),   # BASELINE config 1's optimiser + kernel
+    dict(opt="LM", reg_type="POINT_TO_DISTRIBUTION", loss="NONE", scale=10.0),
+    dict(opt="DOGLEG", reg_type="GICP", loss="HUBER", scale=0.5),
+    dict(opt="DOGLEG", reg_type="POINT_TO_DISTRIBUTION", loss="NONE", scale=10.0),
+    dict(opt="GN", reg_type="POINT_TO_DISTRIBUTION", loss="CAUCHY", scale=0.3),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['opt']}-{c['reg_type']}-{c['loss']}")
+def test_align_prepared_matches_oracle_and_generic(sp, orc, clouds, case):
+    """Registration::align with LM / dog-leg / GN on the prepared path (fused linearise + sp_gicp_error_prepared for every
+    trial step) against the oracle: same pose to 1e-5, same iteration count, same convergence flag; and against the generic
+    path (KNNBase search + K11 + generic K12)."""
+    from oracle.pyoracle import LOSS, OPT, REG, RegParams
+
+    src, scov, tgt, tcov, T_gt = clouds
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    grid = sp.GridKNN.build(Tg.points)
+    prep = sp.PreparedTarget(grid, Tg.covs, reg_type=case["reg_type"])
+    T0 = orc.se3_exp([0.01, -0.005, 0.02, 0.05, -0.04, 0.03])
+    p = sp.RegistrationParams(reg_type=case["reg_type"], robust_type=case["loss"], robust_default_scale=case["scale"],
+                              optimization_method=case["opt"], max_iterations=25)
+    ref = orc.registration_align(RegParams.defaults(reg_type=REG[case["reg_type"]], robust_type=LOSS[case["loss"]],
+                                                    robust_default_scale=case["scale"],
+                                                    optimization_method=OPT[case["opt"]], max_iterations=25),
+                                 src, scov, tgt, tcov, init_T=T0)
+    res = sp.Registration(p).align_prepared(S, prep, initial_guess=T0)
+    assert res.converged == ref["converged"] and res.iterations == ref["iterations"]
+    assert np.abs(res.T - ref["T"]).max() < 1e-5, np.abs(res.T - ref["T"]).max()
+    assert res.inlier == ref["inlier"]
+    assert abs(res.error - ref["error"]) <= 1e-4 * abs(ref["error"])
+    gen = sp.Registration(p).align(S, Tg, grid, initial_guess=T0)
+    assert gen.iterations == res.iterations and np.abs(gen.T - res.T).max() < 2e-6
