@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--path", choices=["fused", "generic"], default="fused",
                     help="fused: GridKNN + prepared covariances, NN+K11 in one kernel; generic: KNNBase search + K11")
     ap.add_argument("--nn", choices=["grid", "kdtree"], default="grid", help="KNNBase used by --path generic")
+    ap.add_argument("--reg", choices=["gicp", "p2d"], default="gicp",
+                    help="factor: gicp = RegType::GICP (the reference's default and what config 1 uses); p2d = "
+                         "RegType::POINT_TO_DISTRIBUTION (factor.hpp:311-373), the reading of BASELINE config 4's "
+                         "'GICP (point-to-distribution)' — both run on the prepared / fused path")
     ap.add_argument("--ppc", type=float, default=0.5, help="GridKNN points per cell for the in-loop k=1 search")
     ap.add_argument("--source-order", choices=["grid", "random"], default="grid",
                     help="grid: the source is stored in the cell order of a grid on itself (what voxel downsampling "
@@ -124,12 +128,13 @@ def main():
     n_local = S.size()
     grid = sp.GridKNN.build(Tg.points, points_per_cell=args.ppc) if (args.path == "fused" or args.nn == "grid") else None
     knn = grid if (args.path == "fused" or args.nn == "grid") else sp.KDTree.build(tgt)
-    prep = sp.PreparedTarget(grid, Tg.covs) if args.path == "fused" else None
+    REG_TYPE = {"gicp": "GICP", "p2d": "POINT_TO_DISTRIBUTION"}[args.reg]
+    prep = sp.PreparedTarget(grid, Tg.covs, reg_type=REG_TYPE) if args.path == "fused" else None
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     SORT_MODE = "presorted" if args.source_order == "grid" else True
-    params = sp.RegistrationParams(reg_type="GICP", optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
+    params = sp.RegistrationParams(reg_type=REG_TYPE, optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
                                    criteria_translation=0.0, criteria_rotation=0.0)
     reg = sp.Registration(params)
     T_dev = torch.zeros(16, dtype=torch.float32, device=dev)
@@ -211,7 +216,7 @@ def main():
     launches = classes = converged = None
     if args.path == "fused" and group is None:
         launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
-        converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE)
+        converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE)
 
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
@@ -231,10 +236,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GICP {n_total}-vs-{n_total} uniform-random clouds (BASELINE config "
+            "config": {"workload": f"{'GICP' if args.reg == 'gicp' else 'point-to-distribution ICP'} {n_total}-vs-{n_total} "
+                                   f"uniform-random clouds (BASELINE config "
                                    f"{'4' if world == 1 else '5 generalised'}), k=20 covariances, GN lambda=1, "
                                    f"max_corr 2.0, robust NONE, {ITERS_PER_ALIGN} iterations per alignment",
-                       "source_points_per_gpu": n_gpu, "target_points": n_total, "path": args.path,
+                       "source_points_per_gpu": n_gpu, "target_points": n_total, "path": args.path, "reg_type": REG_TYPE,
                        "nn": "grid(k=1)" if (args.path == "fused" or args.nn == "grid") else "kdtree(k=1)",
                        "target_preparation": "once, in set-up with its NN structure (grid build, plane-regularised covariances, "
                                              "safe radii); per alignment only the source is prepared",
@@ -259,7 +265,7 @@ def main():
                          "traffic": measured_traffic(dom), "algorithmic_bytes_per_launch": kern[dom]["bytes"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, REG_TYPE)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_sharded:
         dist.barrier()
@@ -333,12 +339,12 @@ def launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n, reps=7)
     return launches, classes
 
 
-def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reps=31):
+def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reg_type="GICP", reps=31):
     """What a caller of align() gets: ONE alignment with the reference's default convergence criteria (1e-3 / 1e-3,
     registration_params.hpp:94-96) from the identity guess, timed whole (source preparation + max_iterations launches, the
     ones after convergence returning at once, + finish) with HIP events; correspondences/s = points x executed iterations
     / that time. Median over `reps` alignments."""
-    p = sp.RegistrationParams(reg_type="GICP", optimization_method="GN", max_iterations=ITERS_PER_ALIGN)
+    p = sp.RegistrationParams(reg_type=reg_type, optimization_method="GN", max_iterations=ITERS_PER_ALIGN)
     reg = sp.Registration(p)
     ms = []
     for _ in range(reps + 2):
@@ -444,11 +450,11 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
     return res
 
 
-def cpu_baseline(n_cpu):
+def cpu_baseline(n_cpu, reg_type="GICP"):
     """The CPU oracle (kind "port": our restatement of the reference's algorithms, OpenMP over points, all host cores)
     on the same workload: n_cpu-vs-n_cpu points at config-4 density, alignments of 20 GN iterations with KD-tree NN,
     repeated for >= 12 s. KD-tree build and covariances are outside the timed loop, as on the GPU side."""
-    from oracle.pyoracle import Oracle, RegParams
+    from oracle.pyoracle import REG, Oracle, RegParams
     from sycl_points_amd.synthetic import gicp_pair
 
     orc = Oracle()
@@ -458,7 +464,7 @@ def cpu_baseline(n_cpu):
     ti, _ = orc.kdtree_knn(nodes_t, tgt, 20)
     si, _ = orc.kdtree_knn(orc.kdtree_build(src), src, 20)
     scov, tcov = orc.cov_estimate(src, si), orc.cov_estimate(tgt, ti)
-    p = RegParams.defaults(crit_translation=0.0, crit_rotation=0.0, max_iterations=ITERS_PER_ALIGN)
+    p = RegParams.defaults(reg_type=REG[reg_type], crit_translation=0.0, crit_rotation=0.0, max_iterations=ITERS_PER_ALIGN)
     orc.registration_align(p, src[:2000], scov[:2000], tgt, tcov, nodes=nodes_t)  # warm-up
     t0 = time.perf_counter()
     runs = 0
@@ -470,7 +476,7 @@ def cpu_baseline(n_cpu):
     dt = time.perf_counter() - t0
     return {"value": n_cpu * ITERS_PER_ALIGN * runs / dt, "unit": "correspondences/s", "cores": orc.num_threads(),
             "kind": "port",
-            "sample": f"{runs} alignments x {ITERS_PER_ALIGN} iterations of GICP {n_cpu}-vs-{n_cpu} (config-4 density, "
+            "sample": f"{runs} alignments x {ITERS_PER_ALIGN} iterations of {reg_type} {n_cpu}-vs-{n_cpu} (config-4 density, "
                       f"KD-tree NN k=1 + linearise per iteration), {dt:.1f} s"}
 
 
