@@ -14,7 +14,19 @@ void sp_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
 
 namespace sp {
 namespace {
-struct PoolEntry { void* p; size_t bytes; int device; bool busy; };
+struct PoolEntry {
+    void* p; size_t bytes; int device; bool busy;
+    std::vector<hipEvent_t> pending;  // work that may still touch p (scratch_release_after); empty: idle
+};
+// true once every pending event has completed (they are destroyed then); never blocks
+bool entry_idle(PoolEntry& e) {
+    while (!e.pending.empty()) {
+        if (hipEventQuery(e.pending.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
+        (void)hipEventDestroy(e.pending.back());
+        e.pending.pop_back();
+    }
+    return true;
+}
 std::mutex g_pool_mutex;
 std::vector<PoolEntry> g_pool;
 constexpr size_t kKeep = 24;
@@ -29,36 +41,62 @@ hipError_t scratch_acquire(void** ptr, size_t bytes) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         PoolEntry* best = nullptr;
         for (auto& e : g_pool)  // best fit among the idle buffers of this device, not more than 4x oversized
-            if (!e.busy && e.device == dev && e.bytes >= bytes && e.bytes <= 4 * bytes && (!best || e.bytes < best->bytes)) best = &e;
+            if (!e.busy && e.device == dev && e.bytes >= bytes && e.bytes <= 4 * bytes && (!best || e.bytes < best->bytes) &&
+                entry_idle(e))
+                best = &e;
         if (best) { best->busy = true; *ptr = best->p; return hipSuccess; }
     }
     void* p = nullptr;
     const hipError_t err = hipMalloc(&p, bytes);
     if (err != hipSuccess) return err;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    g_pool.push_back(PoolEntry{p, bytes, dev, true});
+    g_pool.push_back(PoolEntry{p, bytes, dev, true, {}});
     *ptr = p;
     return hipSuccess;
 }
 
-void scratch_release(void* ptr) {
+namespace {
+void release_impl(void* ptr, std::vector<hipEvent_t>&& pending) {
     void* drop = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         size_t idle = 0;
         for (auto& e : g_pool) {
-            if (e.p == ptr) e.busy = false;
+            if (e.p == ptr) { e.busy = false; e.pending = std::move(pending); }
             idle += e.busy ? 0 : 1;
         }
-        if (idle > kKeep) {  // drop the smallest idle buffer
+        if (idle > kKeep) {  // drop the smallest buffer that is really idle (hipFree of a buffer in use would wait for it)
             size_t k = g_pool.size();
             for (size_t i = 0; i < g_pool.size(); ++i)
-                if (!g_pool[i].busy && (k == g_pool.size() || g_pool[i].bytes < g_pool[k].bytes)) k = i;
-            drop = g_pool[k].p;
-            g_pool.erase(g_pool.begin() + (long)k);
+                if (!g_pool[i].busy && (k == g_pool.size() || g_pool[i].bytes < g_pool[k].bytes) && entry_idle(g_pool[i])) k = i;
+            if (k != g_pool.size()) {
+                drop = g_pool[k].p;
+                g_pool.erase(g_pool.begin() + (long)k);
+            }
         }
     }
     if (drop) (void)hipFree(drop);
+}
+}  // namespace
+
+void scratch_release(void* ptr) { release_impl(ptr, {}); }
+
+void scratch_release_after(void* ptr, const StreamSet& streams) {
+    std::vector<hipEvent_t> pending;
+    bool ok = !streams.overflow;
+    for (int i = 0; ok && i < streams.n; ++i) {
+        hipEvent_t ev = nullptr;
+        ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (ok && hipEventRecord(ev, streams.s[i]) != hipSuccess) { (void)hipEventDestroy(ev); ok = false; }
+        if (ok) pending.push_back(ev);
+    }
+    if (!ok) {  // too many streams to track, or an event could not be recorded: the device-wide wait instead
+        (void)hipGetLastError();
+        for (hipEvent_t ev : pending) (void)hipEventDestroy(ev);
+        pending.clear();
+        (void)hipDeviceSynchronize();
+    }
+    release_impl(ptr, std::move(pending));
 }
 }  // namespace sp
 

@@ -953,10 +953,10 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
 
 extern "C" void sp_grid_destroy(sp_grid* g) {
     if (!g) return;
-    (void)hipDeviceSynchronize();  // nothing may still be reading the arrays when they go back to the pool
-    sp::pooled_free(g->d_pts);
-    sp::pooled_free(g->d_start);
-    sp::pooled_free(g->d_unit_off);
+    // the arrays go back to the pool tagged with an event per stream they were used on (no device-wide wait)
+    sp::pooled_free_after(g->d_pts, g->streams);
+    sp::pooled_free_after(g->d_start, g->streams);
+    sp::pooled_free_after(g->d_unit_off, g->streams);
     delete g;
 }
 
@@ -972,6 +972,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     hipStream_t st = as_stream(stream);
     sp_grid* g = new sp_grid();
     g->n = n;
+    g->streams.note(st);
     auto fail = [&](hipError_t e) {
         sp_set_error(hipGetErrorString(e));
         (void)hipStreamSynchronize(st);  // nothing of this build may still be running when its scratch goes back to the pool
@@ -1136,6 +1137,7 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     const size_t n = g->n;
     if (n == 0 || n_flags == 0) return SP_OK;
     hipStream_t st = as_stream(stream);
+    g->streams.note(st);
     ScratchBuf b_keep, b_scan, b_tmp, b_units, b_start;
     float4* new_pts = nullptr;
     size_t tmp_bytes = 0, tmp2_bytes = 0;
@@ -1176,8 +1178,7 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(e);
-    (void)hipDeviceSynchronize();  // readers of the old array on other streams
-    pooled_free(g->d_pts);
+    pooled_free_after(g->d_pts, g->streams);  // readers of the old array on other streams: the pool waits for them
     g->d_pts = new_pts;
     g->n = kept;
     return SP_OK;
@@ -1199,6 +1200,7 @@ __global__ __launch_bounds__(kBlock) void grid_order_kernel(const float4* __rest
 extern "C" int sp_grid_order(const sp_grid* grid, uint32_t* idx_out, void* stream) {
     if (!grid || (!idx_out && grid->n)) return SP_ERR_INVALID_ARGUMENT;
     if (grid->n == 0) return SP_OK;
+    grid->streams.note(sp::as_stream(stream));
     sp::grid_order_kernel<<<sp::div_up(grid->n, sp::kBlock), sp::kBlock, 0, sp::as_stream(stream)>>>(
         grid->d_pts, (unsigned)grid->n, idx_out);
     return sp::launch_status();
@@ -1217,6 +1219,7 @@ extern "C" int sp_grid_search(const sp_grid* grid, const float* queries, size_t 
     }
     if (nq == 0) return SP_OK;
     hipStream_t st = as_stream(stream);
+    grid->streams.note(st);
     if (k == 1) return launch<1>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     if (k <= 10) return launch<10>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     return launch<20>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
@@ -1248,6 +1251,7 @@ extern "C" int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out,
     out.todo_count = static_cast<unsigned*>(workspace);
     out.todo = out.todo_count + 2;
     hipStream_t st = as_stream(stream);
+    grid->streams.note(st);
     if (k <= 10) return launch_self<10>(grid, (int)k, out, st);
     return launch_self<20>(grid, (int)k, out, st);
 }

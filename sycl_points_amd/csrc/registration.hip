@@ -1275,6 +1275,8 @@ struct sp_gicp_target {
     unsigned long long version = 0; // bumped by every sp_gicp_target_update (cached copies of rows become stale)
     int reg_type = SP_REG_GICP;     // what the rows hold: plane(Ct) for GICP, inverse(Ct) for POINT_TO_DISTRIBUTION
     size_t n = 0;
+    mutable sp::StreamSet streams;  // streams the rows (and the borrowed grid) have been used on
+    void note(hipStream_t st) const { streams.note(st); if (grid) grid->streams.note(st); }
 };
 struct sp_gicp_source {
     size_t n_max = 0, n = 0;
@@ -1297,10 +1299,10 @@ struct sp_gicp_source {
 
 extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
     if (!t) return;
-    (void)hipDeviceSynchronize();  // nothing may still be reading the arrays when they go back to the pool
-    sp::pooled_free(t->covp);
-    sp::pooled_free(t->rho2);
-    sp::pooled_free(t->nb);
+    // back to the pool tagged with an event per stream the rows were used on: no device-wide wait in a destructor
+    sp::pooled_free_after(t->covp, t->streams);
+    sp::pooled_free_after(t->rho2, t->streams);
+    sp::pooled_free_after(t->nb, t->streams);
     delete t;
 }
 extern "C" int sp_gicp_target_prepare(sp_gicp_target* t, const float* tgt_covs, int reg_type, void* stream) {
@@ -1320,6 +1322,7 @@ extern "C" int sp_gicp_target_prepare(sp_gicp_target* t, const float* tgt_covs, 
     ++t->version;
     t->reg_type = reg_type;
     if (t->n == 0) return SP_OK;
+    t->note(as_stream(stream));
     const float4* covs = reinterpret_cast<const float4*>(tgt_covs);
     if (reg_type == SP_REG_GICP)
         prepare_cov_kernel<false><<<div_up(t->n, kBlock), kBlock, 0, as_stream(stream)>>>(covs, (unsigned)t->n, t->grid->d_pts,
@@ -1344,6 +1347,7 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
     sp_gicp_target* t = new sp_gicp_target();
     t->grid = grid;
     t->n = n;
+    t->note(as_stream(stream));
     if (n) {
         const hipError_t e = pooled_alloc(&t->covp, n * 2 * sizeof(float4));
         if (e != hipSuccess) {
@@ -1545,6 +1549,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
     }
+    target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT, transT_on_device, nn_idx_out, nn_d2_out);
     const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1) && !(source->opt_stage_mask & 28);
     const unsigned grid = reduce_grid(n);
@@ -1629,6 +1634,7 @@ extern "C" int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gic
                      "sp_gicp_align_*) with this target");  // compute_error_frozen needs the neighbours of a linearisation
         return SP_ERR_RUNTIME;
     }
+    target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT_trial, trial_on_device, nullptr, nullptr);
     Mat4Arg TL;
     for (int i = 0; i < 16; ++i) TL.m[i] = transT_lin_host[i];
@@ -1667,6 +1673,7 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
         if (hipMemsetAsync(w.part[0], 0, 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != hipSuccess)
             return SP_ERR_HIP;
     }
+    target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
     const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1);
     const unsigned grid = align_grid(n);

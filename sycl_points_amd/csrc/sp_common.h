@@ -39,7 +39,30 @@ inline unsigned stream_grid(size_t n, int block = kBlock, int per_thread = 1) {
 hipError_t scratch_acquire(void** ptr, size_t bytes);  // capi_common.hip
 void scratch_release(void* ptr);
 template <class T> hipError_t pooled_alloc(T** ptr, size_t bytes) { return scratch_acquire(reinterpret_cast<void**>(ptr), bytes); }
-inline void pooled_free(void* ptr) { if (ptr) scratch_release(ptr); }  // caller: the device is idle (hipDeviceSynchronize)
+inline void pooled_free(void* ptr) { if (ptr) scratch_release(ptr); }  // caller: nothing on the device still uses ptr
+
+// The streams an object's arrays have been used on (every entry point notes its stream): when the object is destroyed its
+// buffers go back to the pool TAGGED with one event per stream (recorded then), and the pool hands a buffer out again only
+// once its events have completed — no hipDeviceSynchronize in a destructor, so destroying an object neither stalls other
+// streams nor breaks a stream capture that is running beside it. More than kMax distinct streams: the destroy path falls
+// back to the device-wide wait.
+struct StreamSet {
+    static constexpr int kMax = 8;
+    hipStream_t s[kMax];
+    int n = 0;
+    bool overflow = false;
+    void note(hipStream_t st) {
+        for (int i = 0; i < n; ++i)
+            if (s[i] == st) return;
+        if (n < kMax) s[n++] = st; else overflow = true;
+    }
+    void merge(const StreamSet& o) {
+        for (int i = 0; i < o.n; ++i) note(o.s[i]);
+        overflow = overflow || o.overflow;
+    }
+};
+void scratch_release_after(void* ptr, const StreamSet& streams);  // capi_common.hip
+inline void pooled_free_after(void* ptr, const StreamSet& streams) { if (ptr) scratch_release_after(ptr, streams); }
 struct ScratchBuf {  // RAII handle
     void* p = nullptr;
     hipError_t get(size_t bytes) { return scratch_acquire(&p, bytes); }

@@ -135,3 +135,34 @@ def test_normals_per_point_bound(sp, orc):
     score = err * relgap  # error in units of 1 / relative gap
     assert score[ok].max() <= 2e-6, (score[ok].max(), err[ok].max())
     assert np.abs(np.linalg.norm(nrm[:, :3], axis=1) - 1.0).max() < 1e-5
+
+
+def test_destroy_does_not_stall_or_break_a_capture(sp):
+    """sp_grid_destroy / sp_gicp_target_destroy hand their arrays back to the library's pool tagged with an event per
+    stream they were used on instead of calling hipDeviceSynchronize(): destroying an object while ANOTHER stream is being
+    captured into a hipGraph must leave that capture valid, and a buffer must not be handed out again before the work that
+    used it has finished (the new grid built right after gives correct neighbours)."""
+    n = 200_000
+    rs = np.random.RandomState(3)
+    pts = np.ones((n, 4), np.float32)
+    pts[:, :3] = rs.uniform(-5, 5, (n, 3)).astype(np.float32)
+    P = dev(pts)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        old = sp.GridKNN.build(P, points_per_cell=2.0)
+        ref = old.knn_search(sp.PointCloudShared(P), 3)  # enqueued on the side stream
+    a = torch.zeros(1 << 20, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):  # the current stream is capturing ...
+        a.add_(1.0)
+        del old  # ... while a grid used on the side stream is destroyed (sp_grid_destroy)
+        a.mul_(2.0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(a[0]) == 2.0 and float(a[-1]) == 2.0
+    # the pool must not recycle the destroyed grid's arrays before the side stream's search has read them
+    new = sp.GridKNN.build(P, points_per_cell=2.0)
+    again = new.knn_search(sp.PointCloudShared(P), 3)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.indices, again.indices) and torch.equal(ref.distances, again.distances)
+    assert bool((ref.indices[:, 0] == torch.arange(n, device="cuda")).all())
