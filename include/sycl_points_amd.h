@@ -330,7 +330,7 @@ int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* sour
  *   for k in 0 .. max_iterations-1:  sp_gicp_align_step(k)                       (enqueue launch k)
  *                                    all-reduce(sum) sp_gicp_align_rows(ws, k)   (32 KB of float32, in place, same stream order)
  *   sp_gicp_align_finish(last_k = max_iterations-1)
- * With rows_all_reduced != 0 the inlier counts travel in the rows as float VALUES (exact: < 2^24 per row) so that a float
+ * With rows_all_reduced == 1 the inlier counts travel in the rows as float VALUES (exact: < 2^24 per row) so that a float
  * all-reduce sums them; every rank then finishes iteration k in launch k+1's prologue from identical rows and holds the
  * identical pose — one collective and one launch per iteration, no separate reduction or solve kernel. All ranks must
  * pass the same rows_all_reduced, and must all-reduce all of sp_gicp_align_rows' floats (rows a rank does not use are
@@ -340,6 +340,12 @@ int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* sourc
                        int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
                        size_t workspace_bytes, void* stream);
 float* sp_gicp_align_rows(void* workspace, int k, size_t* n_floats_out);
+/* rows_all_reduced == 2 (the form sp_gicp_align_sharded uses): the launch reduces its own partial rows to ONE 128-byte row
+ * inside the kernel — every workgroup stores its row write-through and takes an agent-scope ticket; the last arriver sums
+ * the rows in the fixed order of the single-GPU prologue (bit-identical to it) — and the caller all-reduces just
+ * sp_gicp_align_row(ws, k): 28 sums, the inlier count as two exactly-summable floats (hi * 4096 + lo), the searched-point
+ * count. The next launch reads that row instead of summing 256. */
+float* sp_gicp_align_row(void* workspace, int k, size_t* n_floats_out);
 int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn, int last_k,
                          int rows_all_reduced, sp_linearized* lin_out, float* delta_out8, uint32_t* iterations_out,
                          void* workspace, size_t workspace_bytes, void* stream);
@@ -402,6 +408,36 @@ int sp_map_prior_update_host(const sp_map_prior_params* params, const float* H_r
                              uint32_t inlier, const float* T_prev16, const float* T_pred16, sp_map_prior_state* state);
 float sp_map_prior_apply_host(const sp_map_prior_state* state, const float* T_est16, float* H36_rowmajor, float* b6,
                               float* error);
+
+/* ----------------------------------------------------------------------------------------- multi-GPU */
+
+/* One process per GPU; the source cloud is sharded over the ranks, the target (points, covariances, grid, prepared rows)
+ * is replicated. The exchange is RCCL over xGMI, bound at run time (dlopen librccl.so.1): on a machine
+ * without RCCL these entry points return SP_ERR_RUNTIME and everything else still works.
+ *   sp_comm_unique_id   ncclGetUniqueId: SP_COMM_ID_BYTES bytes, made by ONE rank and handed to the others out of band
+ *                       (MPI_Bcast, a torch.distributed broadcast, a file)
+ *   sp_comm_create      ncclCommInitRank on the calling thread's current device; collective over the `world` callers
+ *   sp_allreduce_rows   sum over the ranks, in place, of launch k's fan-in row (sp_gicp_align_row): 128 bytes
+ *   sp_allreduce_f32    the same for any float buffer (e.g. the 192-byte system of the generic loop, 2 scalars of an LM step)
+ *   sp_allgather        ncclAllGather of bytes_per_rank bytes per rank (target covariances of a pre-loop sharded by query)
+ *   sp_gicp_align_sharded  sp_gicp_align_fused with the source sharded over `comm`: per iteration one launch
+ *                       (sp_gicp_align_step, rows_all_reduced = 2) + one sp_allreduce_rows, then sp_gicp_align_finish; every
+ *                       rank ends with the identical pose. Only enqueues (hipGraph-capturable). All ranks must pass the same
+ *                       params, gn and max_iterations; a rank with an empty shard still calls it. */
+#define SP_COMM_ID_BYTES 128
+typedef struct sp_comm sp_comm;
+int sp_comm_unique_id(void* id_out);
+int sp_comm_create(const void* id, int rank, int world, sp_comm** out);
+void sp_comm_destroy(sp_comm* comm);
+int sp_comm_rank(const sp_comm* comm);
+int sp_comm_world(const sp_comm* comm);
+int sp_allreduce_rows(sp_comm* comm, void* workspace, int k, void* stream);
+int sp_allreduce_f32(sp_comm* comm, float* buf, size_t n_floats, void* stream);
+int sp_allgather(sp_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int sp_gicp_align_sharded(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                          const sp_factor_params* params, const sp_gn_params* gn, int max_iterations, sp_comm* comm,
+                          int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
+                          uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------- voxel hash map */
 

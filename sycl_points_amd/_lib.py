@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsycl_points_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SP_OK, SP_ERR_INVALID_ARGUMENT, SP_ERR_RUNTIME, SP_ERR_HIP = 0, 1, 2, 3
+COMM_ID_BYTES = 128  # SP_COMM_ID_BYTES
 
 
 class SpError(RuntimeError):
@@ -112,6 +113,16 @@ SIGNATURES = {
     "sp_gicp_align_fused": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_rows": (_vp, [_vp, _i, _vp]),
+    "sp_gicp_align_row": (_vp, [_vp, _i, _vp]),
+    "sp_comm_unique_id": (_i, [_vp]),
+    "sp_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "sp_comm_destroy": (None, [_vp]),
+    "sp_comm_rank": (_i, [_vp]),
+    "sp_comm_world": (_i, [_vp]),
+    "sp_allreduce_rows": (_i, [_vp, _vp, _i, _vp]),
+    "sp_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "sp_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "sp_gicp_align_sharded": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_finish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gn_update": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp]),
     "sp_gn_update_host": (_i, [_vp, _vp, _f, _f, _f, _vp]),

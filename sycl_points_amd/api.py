@@ -546,6 +546,52 @@ def compact_by_flags(rows, flags, want_indices=False):
     return (out[:v], idx) if want_indices else out[:v]
 
 
+class Communicator:
+    """sp_comm: the library's own RCCL communicator (one process per GPU). The 128-byte unique id is made by rank 0
+    (sp_comm_unique_id) and handed to the other ranks through whatever channel the application has — here a
+    torch.distributed broadcast over an existing process group (any backend)."""
+
+    def __init__(self, handle, rank, world):
+        self._h, self.rank, self.world = handle, rank, world
+
+    @staticmethod
+    def from_process_group(group=None, device=None):
+        import torch.distributed as dist
+
+        L = _lib.lib()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if (device is None and backend == "nccl") else (device or "cpu")
+        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+            check(L.sp_comm_unique_id(buf))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(dev)
+        dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(ident.cpu().tolist())
+        h = C.c_void_p()
+        check(L.sp_comm_create(raw, rank, world, C.byref(h)))  # collective: every rank of the group gets here
+        return Communicator(h, rank, world)
+
+    def all_reduce(self, t):
+        """In-place float32 sum over the ranks on the current stream (sp_allreduce_f32)."""
+        check(_lib.lib().sp_allreduce_f32(self._h, _ptr(t), t.numel(), _stream()))
+        return t
+
+    def all_gather(self, send, recv):
+        check(_lib.lib().sp_allgather(self._h, _ptr(send), _ptr(recv), send.numel() * send.element_size(), _stream()))
+        return recv
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_comm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class VoxelHashMap:
     """algorithms/mapping/voxel_hash_map.hpp:22-250 over the sp_vhm_* entry points: submap accumulation in HBM.
     add_point_cloud takes a PointCloudShared in the sensor frame and the sensor pose (4x4, map frame); downsampling
@@ -1116,7 +1162,8 @@ class Registration:
 
     def align_fused_loop(self, source, prepared_target, initial_guess=None, iterations=None, robust_scale=-1.0,
                          group=None, T_dev=None, delta_dev=None, prepare=True, sort_by_cell=True,
-                         write_neighbors=False, per_iteration_launches=False, update_target=False, graph=False):
+                         write_neighbors=False, per_iteration_launches=False, update_target=False, graph=False,
+                         comm=None, exchange="row"):
         """The same fixed-length Gauss-Newton loop as align_device_loop on the prepared / fused path
         (sp_gicp_iteration_fused): one launch per iteration does NN + linearise + reduce, and, on a single GPU, the
         second (one-workgroup) launch also solves and updates the pose. On one GPU the default is
@@ -1149,7 +1196,8 @@ class Registration:
             if update_target:
                 prepared_target.update()
             self._psrc.prepare(prepared_target, source, T_dev, sort_by_cell)
-        sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        sharded = (comm is not None or group is not None or
+                   (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1))
         fp = self._factor_params(scale)
         gn = GnParams(p.gn_lambda, p.criteria_rotation, p.criteria_translation)
         if write_neighbors:
@@ -1165,27 +1213,37 @@ class Registration:
                                         _stream()))
             return T_dev, lin, delta_dev
         if sharded and not per_iteration_launches:
-            # one launch + one collective per iteration: the 32 KB of partial rows are all-reduced in place between
-            # launch k and launch k+1, whose prologue then finishes iteration k identically on every rank
+            # one launch + one collective per iteration. exchange="row" (default): the launch reduces its partial rows to
+            # ONE 128-byte row inside the kernel (fan-in, rows_all_reduced = 2) and only that row is all-reduced;
+            # exchange="rows": the 32 KB of partial rows are all-reduced (round 1's form, kept for comparison). Launch k+1's
+            # prologue then finishes iteration k identically on every rank. With `comm` (the library's own RCCL
+            # communicator) the whole loop is ONE C call, sp_gicp_align_sharded.
             if getattr(self, "_iters_dev", None) is None or self._iters_dev.device != dev:
                 self._iters_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            mode = 2 if (exchange == "row" or comm is not None) else 1
             nf = C.c_size_t(0)
             wsf = ws.view(torch.float32)
             base = ws.data_ptr()
             rows = []
             for k in (0, 1):
-                off = (L.sp_gicp_align_rows(_ptr(ws), k, C.byref(nf)) - base) // 4
+                fn = L.sp_gicp_align_row if mode == 2 else L.sp_gicp_align_rows
+                off = (fn(_ptr(ws), k, C.byref(nf)) - base) // 4
                 rows.append(wsf[off:off + nf.value])
             wsp, linp, Tp = _ptr(ws), _ptr(lin), _ptr(T_dev)
 
             def enqueue():
                 st = _stream()
+                if comm is not None:
+                    check(L.sp_gicp_align_sharded(prepared_target._h, self._psrc._h, Tp, C.byref(fp), C.byref(gn), iters,
+                                                  comm._h, ni, nd, linp, _ptr(delta_dev), _ptr(self._iters_dev), wsp,
+                                                  ws.numel(), st))
+                    return
                 for k in range(iters):
-                    check(L.sp_gicp_align_step(prepared_target._h, self._psrc._h, Tp, C.byref(fp), C.byref(gn), k, 1, ni, nd,
+                    check(L.sp_gicp_align_step(prepared_target._h, self._psrc._h, Tp, C.byref(fp), C.byref(gn), k, mode, ni, nd,
                                                linp, wsp, ws.numel(), st))
                     dist.all_reduce(rows[k & 1], op=dist.ReduceOp.SUM, group=group)
                 if iters > 0:
-                    check(L.sp_gicp_align_finish(self._psrc._h, _ptr(T_dev), C.byref(gn), iters - 1, 1, _ptr(lin),
+                    check(L.sp_gicp_align_finish(self._psrc._h, _ptr(T_dev), C.byref(gn), iters - 1, mode, _ptr(lin),
                                                  _ptr(delta_dev), _ptr(self._iters_dev), _ptr(ws), ws.numel(), st))
 
             if not graph:
@@ -1196,7 +1254,7 @@ class Registration:
             # instead of 2 x iterations calls, and the GPU-side chain (kernel -> all-reduce -> kernel) is what is left.
             key = (iters, prepared_target._h.value if hasattr(prepared_target._h, "value") else id(prepared_target),
                    id(self._psrc), T_dev.data_ptr(), delta_dev.data_ptr(), ws.data_ptr(), lin.data_ptr(), ni, nd, n,
-                   scale, id(group))
+                   scale, id(group), id(comm), mode)
             graphs = self.__dict__.setdefault("_loop_graphs", {})
             g = graphs.get(key)
             if g is None:

@@ -289,7 +289,18 @@ struct KParams {
 // that partial rows can be summed across ranks by a float all-reduce.
 // `extra` is a second integer (the number of points this launch had to search for, fused kernels only); its sum goes to slot
 // NV + 1 as a float VALUE (exact below 2^24), so it survives the float row sums of the next prologue / an all-reduce.
-template <int NV, int BLOCK = kBlock>
+// SC1: the row is stored write-through at agent scope (global_store ... sc1) because another workgroup of the SAME launch
+// will read it (the fan-in of the sharded loop, fanin_reduce below); plain stores otherwise.
+template <bool SC1>
+__device__ __forceinline__ void store_row_word(float* p, float v) {
+    if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool SC1>
+__device__ __forceinline__ float load_row_word(const float* p) {
+    return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <int NV, int BLOCK = kBlock, bool SC1 = false>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cnt, float* __restrict__ partial,
                                                    bool count_as_float = false, unsigned extra = 0) {
     __shared__ float red[BLOCK / kWave][kPartial];
@@ -309,17 +320,17 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], unsigned cn
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < BLOCK / kWave; ++w) s += red[w][threadIdx.x];
-        partial[threadIdx.x] = s;
+        store_row_word<SC1>(partial + threadIdx.x, s);
     } else if (threadIdx.x == NV) {
         unsigned c = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][NV]);
-        partial[NV] = count_as_float ? (float)c : __uint_as_float(c);
+        store_row_word<SC1>(partial + NV, count_as_float ? (float)c : __uint_as_float(c));
     } else if (threadIdx.x == NV + 1) {
         unsigned c = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][NV + 1]);
-        partial[NV + 1] = (float)c;
+        store_row_word<SC1>(partial + NV + 1, (float)c);
     }
 }
 
@@ -426,7 +437,7 @@ __host__ __device__ inline void gn_update_impl(sp_linearized* lin, float* T, flo
 // On return (after a barrier) red[0][e] holds the totals; slot nv is the uint32 count.
 // `after_loads` runs once the row loads have been issued (and before the first barrier): the per-iteration kernel stores
 // the previous state there, which it loaded BEFORE the rows, so that both arrive in the same memory round trip.
-template <typename Hook>
+template <bool SC1 = false, typename Hook>
 __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ partials, unsigned rows, int nv,
                                                  float (*red)[kPartial], bool count_is_float, Hook after_loads) {
     constexpr unsigned kParts = kFinalThreads / 32;
@@ -439,7 +450,8 @@ __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ parti
     if (per <= 8) {  // at most 256 rows (the per-iteration kernel): all loads of a lane in flight at once
         float v[8];
 #pragma unroll
-        for (unsigned j = 0; j < 8; ++j) v[j] = (lo + j < hi) ? partials[(size_t)(lo + j) * kPartial + e] : 0.0f;
+        for (unsigned j = 0; j < 8; ++j)
+            v[j] = (lo + j < hi) ? load_row_word<SC1>(partials + (size_t)(lo + j) * kPartial + e) : 0.0f;
         after_loads();
 #pragma unroll
         for (unsigned j = 0; j < 8; ++j) {
@@ -451,7 +463,7 @@ __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ parti
     } else {
 #pragma unroll 8
         for (unsigned b = lo; b < hi; ++b) {
-            const float v = partials[(size_t)b * kPartial + e];
+            const float v = load_row_word<SC1>(partials + (size_t)b * kPartial + e);
             if (is_count) c += count_is_float ? (unsigned)v : __float_as_uint(v);
             else s += v;
         }
@@ -472,9 +484,10 @@ __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ parti
     }
     __syncthreads();
 }
+template <bool SC1 = false>
 __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ partials, unsigned rows, int nv,
                                                  float (*red)[kPartial], bool count_is_float = false) {
-    reduce_rows_1024(partials, rows, nv, red, count_is_float, [] {});
+    reduce_rows_1024<SC1>(partials, rows, nv, red, count_is_float, [] {});
 }
 
 // totals (21 upper-triangle H, 6 b, error | error only) + count -> sp_linearized
@@ -934,7 +947,17 @@ struct AlignArgs {
     int count_is_float;          // partial rows are all-reduced between launches (multi-GPU): counts travel as floats
     unsigned* searched_log;      // [launch index] -> points that launch searched for (written by the next launch / finish)
     int k;                       // index of this launch in its alignment
+    // Fan-in (sharded loop, one 128-byte row per rank): the workgroup whose arrival ticket is the last sums this launch's
+    // rows in the prologue's fixed order and writes ONE row; the caller all-reduces it over the ranks and the next launch
+    // reads it instead of summing 256 rows.
+    int fanin;
+    float* fan_row_out;          // this launch's row (kFanRow floats)
+    const float* fan_row_in;     // the previous launch's row, all-reduced over the ranks
+    unsigned* fan_counter;       // arrival tickets; 0 when a launch starts, reset by the last arriver
 };
+// Row of the fan-in: 0..27 the sums, 28 / 29 the inlier count as two floats that stay exact under a float sum over ranks
+// (count = hi * 4096 + lo, as sp_linearized carries it), 30 the searched-point count (a float value), 31 unused.
+constexpr int kFanRow = 32;
 
 // Finishes iteration k-1 (or loads the initial pose) and leaves the pose in sT (LDS). Returns false when this launch
 // has nothing more to do.
@@ -951,10 +974,25 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
         float pre = 0.0f;
         if (threadIdx.x < 18)
             pre = reinterpret_cast<const float*>(A.state_in)[threadIdx.x < 16 ? threadIdx.x : threadIdx.x + 8];
-        reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0, [&] {
+        if (A.fanin) {
+            // the previous launch's last-arriving workgroup already summed its rows (fanin_reduce) and the caller all-reduced
+            // that ONE row over the ranks: 32 words to read instead of 32 KB to sum
+            const float rv = threadIdx.x < kFanRow ? A.fan_row_in[threadIdx.x] : 0.0f;
             if (threadIdx.x < 16) sT[threadIdx.x] = pre;
-            else if (threadIdx.x < 18) sprev[threadIdx.x - 16] = __float_as_uint(pre);  // converged, iterations
-        });
+            else if (threadIdx.x < 18) sprev[threadIdx.x - 16] = __float_as_uint(pre);
+            if (threadIdx.x < kFanRow) red[1][threadIdx.x] = rv;
+            __syncthreads();
+            if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
+            else if (threadIdx.x == kAcc - 1)  // the count, folded as integers: exact (gn_update_impl's rule)
+                red[0][kAcc - 1] = __uint_as_float((unsigned)red[1][kAcc] * 4096u + (unsigned)red[1][kAcc - 1]);
+            else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points (a float value)
+            __syncthreads();
+        } else {
+            reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0, [&] {
+                if (threadIdx.x < 16) sT[threadIdx.x] = pre;
+                else if (threadIdx.x < 18) sprev[threadIdx.x - 16] = __float_as_uint(pre);  // converged, iterations
+            });
+        }
         if (sprev[0]) {  // uniform over the grid: an earlier iteration converged, this launch has nothing to do
             if (blockIdx.x == 0 && threadIdx.x == 0) *A.state_out = *A.state_in;
             return false;
@@ -994,6 +1032,40 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
     return true;
 }
 
+// Fan-in of one launch's partial rows to ONE row (MI355X_MICROARCH.md "fanin", cdna_hip_programming.md Guideline 16, the
+// counter form with sc1 loads in place of an acquire; every condition of its table row holds):
+//   * every word of the rows was stored write-through (store_row_word<true>: global_store ... sc1) by lanes of wave 0,
+//   * wave 0 drains its stores (s_waitcnt vmcnt(0)) and only then lane 0 takes an agent-scope ticket,
+//   * the workgroup whose ticket is the last one learns it from the value its add returned, tells its other waves through
+//     LDS + barrier, and reads every row with sc1 loads (never a plain load of another workgroup's bytes),
+//   * no fence, no spin: a workgroup either leaves or sums — nothing waits for a workgroup that has not been dispatched.
+// The sum is reduce_rows_1024's fixed order over the same `grid` rows the next launch's prologue would sum on one GPU: the
+// row is bit-identical to that 256-row sum. The last arriver resets the ticket counter for the next launch.
+__device__ __forceinline__ void fanin_reduce(const AlignArgs& A, const float* __restrict__ partials) {
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ unsigned s_last;
+    if (threadIdx.x < kWave) {  // the storing lanes (0 .. kAcc) all sit in wave 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(A.fan_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = ticket == gridDim.x - 1 ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;  // uniform per workgroup
+    reduce_rows_1024<true>(partials, gridDim.x, kAcc - 1, red, false);
+    if (threadIdx.x < kFanRow) {
+        const unsigned cnt = __float_as_uint(red[0][kAcc - 1]);
+        float v = 0.0f;
+        if (threadIdx.x < kAcc - 1) v = red[0][threadIdx.x];
+        else if (threadIdx.x == kAcc - 1) v = (float)(cnt & 4095u);
+        else if (threadIdx.x == kAcc) v = (float)(cnt >> 12);
+        else if (threadIdx.x == kAcc + 1) v = red[0][kAcc];
+        A.fan_row_out[threadIdx.x] = v;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(A.fan_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int LOSS, bool FAST_NN, bool P2D = false>
 __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, AlignArgs A,
                                                                  float* __restrict__ partials) {
@@ -1030,8 +1102,13 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
 #ifdef SP_KERNEL_TIMING
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) tm[17 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime();  // point loop done
 #endif
-    block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, A.count_is_float != 0,
-                                              searched);
+    if (A.fanin) {
+        block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
+        fanin_reduce(A, partials);
+    } else {
+        block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, A.count_is_float != 0,
+                                                  searched);
+    }
 #ifdef SP_KERNEL_TIMING
     if (blockIdx.x == 0 && threadIdx.x == 0) tm[33] = __builtin_amdgcn_s_memtime();  // workgroup reduction done
 #endif
@@ -1046,14 +1123,22 @@ __global__ __launch_bounds__(kFinalThreads) void align_finish_kernel(const float
                                                                      float* __restrict__ delta_out8,
                                                                      uint32_t* __restrict__ iterations_out,
                                                                      int count_is_float, unsigned* searched_log,
-                                                                     int last_k) {
+                                                                     int last_k, const float* __restrict__ fan_row) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ sp_linearized slin;
     __shared__ float sT[16];
     __shared__ float sdelta[8];
     __shared__ LdltScratch ldlt_ws;
     const bool conv = state_in->converged != 0;
-    if (!conv) reduce_rows_1024(partials, rows, kAcc - 1, red, count_is_float != 0);
+    if (!conv && fan_row) {  // the last launch's fan-in row, all-reduced over the ranks (see align_prologue)
+        if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = fan_row[threadIdx.x];
+        else if (threadIdx.x == kAcc - 1)
+            red[0][kAcc - 1] = __uint_as_float((unsigned)fan_row[kAcc] * 4096u + (unsigned)fan_row[kAcc - 1]);
+        else if (threadIdx.x == kAcc) red[0][kAcc] = fan_row[kAcc + 1];
+        __syncthreads();
+    } else if (!conv) {
+        reduce_rows_1024(partials, rows, kAcc - 1, red, count_is_float != 0);
+    }
     if (threadIdx.x == 0) {
         unsigned iters = state_in->iterations;
 #pragma unroll
@@ -1589,6 +1674,8 @@ struct AlignWs {  // workspace: partial rows A | partial rows B | state A | stat
     float* part[2];
     AlignState* state;
     unsigned* searched_log;  // kSearchedLog entries
+    float* fan_row[2];       // fan-in rows (kFanRow floats each), ping-pong like the partial rows
+    unsigned* fan_counter;   // arrival tickets of the fan-in
 };
 AlignWs align_ws(void* workspace) {
     AlignWs w;
@@ -1596,6 +1683,9 @@ AlignWs align_ws(void* workspace) {
     w.part[1] = w.part[0] + (size_t)kAlignMaxBlocks * kPartial;
     w.state = reinterpret_cast<AlignState*>(w.part[1] + (size_t)kAlignMaxBlocks * kPartial);
     w.searched_log = reinterpret_cast<unsigned*>(w.state + 8);  // (state + 2 .. : stamps of the SP_KERNEL_TIMING build)
+    w.fan_row[0] = reinterpret_cast<float*>(w.searched_log + kSearchedLog);
+    w.fan_row[1] = w.fan_row[0] + kFanRow;
+    w.fan_counter = reinterpret_cast<unsigned*>(w.fan_row[1] + kFanRow);
     return w;
 }
 unsigned align_grid(size_t n) {
@@ -1668,10 +1758,13 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     if (k < 0) return SP_ERR_INVALID_ARGUMENT;
     const size_t n = source->n;
     const AlignWs w = align_ws(workspace);
-    if (k == 0 && rows_all_reduced) {
+    if (k == 0 && rows_all_reduced == 1) {
         // every rank all-reduces all kAlignMaxBlocks rows whatever its own tile size: rows a rank does not write stay zero
         if (hipMemsetAsync(w.part[0], 0, 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != hipSuccess)
             return SP_ERR_HIP;
+    }
+    if (k == 0 && rows_all_reduced == 2) {  // fan-in: ticket counter (and the rows, for a launch that returns at once)
+        if (hipMemsetAsync(w.fan_row[0], 0, (2 * kFanRow + 4) * sizeof(float), st) != hipSuccess) return SP_ERR_HIP;
     }
     target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
@@ -1683,15 +1776,19 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     A.state_in = &w.state[(k + 1) & 1];
     A.state_out = &w.state[k & 1];
     A.prev_partials = w.part[(k + 1) & 1];
-    A.prev_rows = rows_all_reduced ? (unsigned)kAlignMaxBlocks : grid;
+    A.prev_rows = rows_all_reduced == 1 ? (unsigned)kAlignMaxBlocks : grid;
     A.has_prev = k > 0;
     A.lambda = gn->lambda;
     A.crit_rot = gn->crit_rotation;
     A.crit_trans = gn->crit_translation;
     A.lin_out = lin_out;
-    A.count_is_float = rows_all_reduced ? 1 : 0;
+    A.count_is_float = rows_all_reduced == 1 ? 1 : 0;
     A.searched_log = w.searched_log;
     A.k = k;
+    A.fanin = rows_all_reduced == 2 ? 1 : 0;
+    A.fan_row_out = w.fan_row[k & 1];
+    A.fan_row_in = w.fan_row[(k + 1) & 1];
+    A.fan_counter = w.fan_counter;
     float* out = w.part[k & 1];
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_ALIGN(L)                                                                            \
@@ -1718,6 +1815,11 @@ extern "C" float* sp_gicp_align_rows(void* workspace, int k, size_t* n_floats_ou
     if (!workspace || k < 0) return nullptr;
     return sp::align_ws(workspace).part[k & 1];
 }
+extern "C" float* sp_gicp_align_row(void* workspace, int k, size_t* n_floats_out) {
+    if (n_floats_out) *n_floats_out = (size_t)sp::kFanRow;
+    if (!workspace || k < 0) return nullptr;
+    return sp::align_ws(workspace).fan_row[k & 1];
+}
 
 extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn,
                                    int last_k, int rows_all_reduced, sp_linearized* lin_out, float* delta_out8,
@@ -1730,12 +1832,13 @@ extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_
         return SP_ERR_INVALID_ARGUMENT;
     }
     const AlignWs w = align_ws(workspace);
-    const unsigned rows = rows_all_reduced ? (unsigned)kAlignMaxBlocks : align_grid(source->n);
+    const unsigned rows = rows_all_reduced == 1 ? (unsigned)kAlignMaxBlocks : align_grid(source->n);
     if (source->opt_stage_mask & 2)
         align_finish_kernel<<<1, kFinalThreads, 0, st>>>(w.part[last_k & 1], rows, &w.state[last_k & 1], gn->lambda,
                                                          gn->crit_rotation, gn->crit_translation, transT_device, lin_out,
-                                                         delta_out8, iterations_out, rows_all_reduced ? 1 : 0,
-                                                         w.searched_log, last_k);
+                                                         delta_out8, iterations_out, rows_all_reduced == 1 ? 1 : 0,
+                                                         w.searched_log, last_k,
+                                                         rows_all_reduced == 2 ? w.fan_row[last_k & 1] : nullptr);
     return launch_status();
 }
 

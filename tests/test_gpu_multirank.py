@@ -50,7 +50,11 @@ def _worker(rank, world, port, n, iters, out_path):
     prep = sp.PreparedTarget(grid, Tg.covs)
     p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters)
     reg = sp.Registration(p)
-    T1, lin1, _ = reg.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD)
+    T1, lin1, _ = reg.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD)  # fan-in row exchange (default)
+    regr = sp.Registration(p)
+    T1r, _, _ = regr.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD, exchange="rows")  # 32 KB rows
+    torch.cuda.synchronize()
+    assert float((T1 - T1r).abs().max()) < 2e-6
     torch.cuda.synchronize()
     inl = reg._read_lin(lin1).inlier
     iters_done = int(reg._iters_dev[0])
@@ -126,3 +130,71 @@ def test_sharded_loop_as_one_hipgraph_equals_per_call_launches(tmp_path):
     for row in list(eager) + list(graph):
         assert np.array_equal(row, eager[0])
     assert int(eager[0][16]) == 60000
+
+
+def _fanin_worker(rank, port, sizes, iters, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    import sycl_points_amd.api as sp_api
+
+    comm = sp_api.Communicator.from_process_group(dist.group.WORLD)  # the library's own RCCL communicator (one rank)
+    assert comm.world == 1 and comm.rank == 0
+    rows = []
+    for n in sizes:
+        sp, S, Tg, _ = _make(n)
+        order = sp.GridKNN.build(S.points, points_per_cell=1.0).order()
+        S = S.reordered(order)
+        prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points, points_per_cell=0.5), Tg.covs)
+        p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters)
+        ident = torch.eye(4, dtype=torch.float32, device="cuda").reshape(-1).contiguous()
+
+        def run(**kw):
+            reg = sp.Registration(p)
+            T_dev = ident.clone()
+            delta = torch.zeros(8, dtype=torch.float32, device="cuda")
+            out = []
+            for _ in range(3):  # repeated alignments: the ticket counter must come back to zero every launch
+                T_dev.copy_(ident)
+                _, lin, _ = reg.align_fused_loop(S, prep, iterations=iters, T_dev=T_dev, delta_dev=delta,
+                                                 sort_by_cell="presorted", **kw)
+                torch.cuda.synchronize()
+                out.append(np.concatenate([T_dev.cpu().numpy(), lin.cpu().numpy(), delta.cpu().numpy(),
+                                           [np.float32(int(reg._iters_dev[0]))]]))
+            return out
+
+        single = run()                                              # one C call, every workgroup sums the 256 rows
+        row_gloo = run(group=dist.group.WORLD, exchange="row")      # fan-in row, all-reduced by torch.distributed
+        row_rccl = run(comm=comm)                                   # sp_gicp_align_sharded: fan-in row + sp_allreduce_rows
+        row_graph = run(comm=comm, graph=True)                      # the same, captured into one hipGraph and replayed
+        rows.append(np.stack(single + row_gloo + row_rccl + row_graph))
+    # sp_allreduce_f32 / sp_allgather with one rank: identity
+    t = torch.arange(48, dtype=torch.float32, device="cuda")
+    comm.all_reduce(t)
+    g = torch.zeros(48, dtype=torch.float32, device="cuda")
+    comm.all_gather(t, g)
+    torch.cuda.synchronize()
+    assert torch.equal(t, torch.arange(48, dtype=torch.float32, device="cuda")) and torch.equal(g, t)
+    np.save(out_path, np.stack(rows))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_fanin_row_equals_the_256_row_sum_bit_for_bit(tmp_path):
+    """rows_all_reduced = 2: the last-arriving workgroup of a launch sums that launch's partial rows (sc1 stores, agent-scope
+    ticket, sc1 loads — no fence) in the fixed order of the single-GPU prologue. With one rank the all-reduce is the
+    identity, so pose, linear system, delta and iteration count of the sharded loop must equal the one-call single-GPU loop
+    BIT FOR BIT — any stale or torn row read by the fan-in would change a sum. 1M points (256 workgroups, every CU), a size
+    that leaves the last workgroups nearly empty (uneven arrival), and a small cloud (fewer workgroups than CUs); through
+    torch.distributed, through the library's own RCCL communicator (sp_gicp_align_sharded), and replayed from a hipGraph."""
+    out = str(tmp_path / "fanin.npy")
+    sizes = (1_000_000, 263_173, 5_000)
+    mp.spawn(_fanin_worker, args=(_free_port(), sizes, 12, out), nprocs=1, join=True)
+    r = np.load(out)  # [size][12 runs][row]
+    for si, n in enumerate(sizes):
+        ref = r[si][0]
+        assert int(ref[-1]) == 12 and int(np.frombuffer(ref[16 + 43:16 + 44].tobytes(), np.uint32)[0]) == n
+        for run in r[si][1:]:
+            assert np.array_equal(run, ref), f"n = {n}: sharded fan-in differs from the single-GPU loop"
