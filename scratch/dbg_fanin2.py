@@ -1,0 +1,38 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C, numpy as np, torch, torch.distributed as dist
+os.environ["MASTER_ADDR"]="127.0.0.1"; os.environ["MASTER_PORT"]="29612"; os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY","0")
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=0, world_size=1)
+import sycl_points_amd.api as sp
+from sycl_points_amd import _lib
+from sycl_points_amd.synthetic import gicp_pair
+L=_lib.lib()
+comm = sp.Communicator.from_process_group(dist.group.WORLD)
+n=200000; iters=8
+src,tgt,T=gicp_pair(n,10.0*(n/1e6)**(1/3))
+dev=lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+Tg=sp.PointCloudShared(dev(tgt)); Tg.covs=sp.GridKNN.build(Tg.points,points_per_cell=6.0).self_knn(20,want_knn=False,want_covs=True)[1]
+S=sp.PointCloudShared(dev(src)); S.covs=sp.GridKNN.build(S.points,points_per_cell=6.0).self_knn(20,want_knn=False,want_covs=True)[1]
+prep=sp.PreparedTarget(sp.GridKNN.build(Tg.points,points_per_cell=0.5),Tg.covs)
+p=sp.RegistrationParams(criteria_translation=0.0,criteria_rotation=0.0,max_iterations=iters)
+ident=torch.eye(4,device="cuda").reshape(-1).contiguous()
+reg=sp.Registration(p); T_dev=ident.clone(); delta=torch.zeros(8,device="cuda")
+reg.align_fused_loop(S,prep,iterations=iters,T_dev=T_dev,delta_dev=delta); torch.cuda.synchronize(); ref=T_dev.cpu().numpy().copy()
+ws,lin=reg._buffers(S.points.device); fp=reg._factor_params(10.0); gn=_lib.GnParams(1.0,0.0,0.0)
+itd=torch.zeros(1,dtype=torch.int32,device="cuda")
+def enqueue(variant):
+    st=sp._stream()
+    for k in range(iters):
+        _lib.check(L.sp_gicp_align_step(prep._h,reg._psrc._h,sp._ptr(T_dev),C.byref(fp),C.byref(gn),k,2,None,None,sp._ptr(lin),sp._ptr(ws),ws.numel(),st))
+        if variant=="allreduce": _lib.check(L.sp_allreduce_rows(comm._h,sp._ptr(ws),k,st))
+    _lib.check(L.sp_gicp_align_finish(reg._psrc._h,sp._ptr(T_dev),C.byref(gn),iters-1,2,sp._ptr(lin),sp._ptr(delta),sp._ptr(itd),sp._ptr(ws),ws.numel(),st))
+for variant in ("none","allreduce"):
+    out=[]
+    T_dev.copy_(ident); reg._psrc.prepare(prep,S,T_dev,True); enqueue(variant); torch.cuda.synchronize(); out.append(float(np.abs(T_dev.cpu().numpy()-ref).max()))
+    T_dev.copy_(ident); reg._psrc.prepare(prep,S,T_dev,True); torch.cuda.synchronize()
+    g=torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g): enqueue(variant)
+    for r in range(4):
+        T_dev.copy_(ident); reg._psrc.prepare(prep,S,T_dev,True)
+        g.replay(); torch.cuda.synchronize(); out.append(float(np.abs(T_dev.cpu().numpy()-ref).max()))
+    print(variant,out,flush=True)

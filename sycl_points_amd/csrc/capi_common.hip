@@ -29,14 +29,34 @@ bool entry_idle(PoolEntry& e) {
 }
 std::mutex g_pool_mutex;
 std::vector<PoolEntry> g_pool;
+std::vector<void*> g_to_free;  // surplus buffers: freed by the next scratch_acquire (an allocating call), never by a release
 constexpr size_t kKeep = 24;
 }  // namespace
+
+namespace {
+__global__ void zero_words_kernel(uint32_t* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+int zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!p || bytes == 0) return SP_OK;
+    const size_t n = (bytes + 3) / 4;
+    const unsigned blocks = n <= 256 ? 1u : (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    zero_words_kernel<<<blocks, n <= 64 ? 64 : 256, 0, st>>>(static_cast<uint32_t*>(p), n);
+    return launch_status();
+}
 
 hipError_t scratch_acquire(void** ptr, size_t bytes) {
     *ptr = nullptr;
     if (bytes < 256) bytes = 256;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    std::vector<void*> surplus;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        surplus.swap(g_to_free);
+    }
+    for (void* q : surplus) (void)hipFree(q);
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         PoolEntry* best = nullptr;
@@ -65,17 +85,22 @@ void release_impl(void* ptr, std::vector<hipEvent_t>&& pending) {
             if (e.p == ptr) { e.busy = false; e.pending = std::move(pending); }
             idle += e.busy ? 0 : 1;
         }
-        if (idle > kKeep) {  // drop the smallest buffer that is really idle (hipFree of a buffer in use would wait for it)
+        if (idle > kKeep) {  // drop the smallest buffer that is known to be idle (hipFree of a buffer in use would wait for it).
+            // No hipEventQuery here: a release may run in a destructor while another stream is being captured, and on ROCm 7.2
+            // hipEventQuery invalidates a global-mode capture (hipEventCreate / hipEventRecord on another stream do not;
+            // scratch/dbg_capture.py). Entries with pending events are settled by the next scratch_acquire.
             size_t k = g_pool.size();
             for (size_t i = 0; i < g_pool.size(); ++i)
-                if (!g_pool[i].busy && (k == g_pool.size() || g_pool[i].bytes < g_pool[k].bytes) && entry_idle(g_pool[i])) k = i;
+                if (!g_pool[i].busy && g_pool[i].pending.empty() && (k == g_pool.size() || g_pool[i].bytes < g_pool[k].bytes)) k = i;
             if (k != g_pool.size()) {
                 drop = g_pool[k].p;
                 g_pool.erase(g_pool.begin() + (long)k);
             }
         }
+        // hipFree is a device-wide wait and, like hipEventQuery, invalidates a capture running on another stream: a release
+        // (destructor) only queues the buffer; the next acquire — a call that allocates and synchronises anyway — frees it
+        if (drop) g_to_free.push_back(drop);
     }
-    if (drop) (void)hipFree(drop);
 }
 }  // namespace
 

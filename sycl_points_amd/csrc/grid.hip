@@ -886,7 +886,7 @@ __global__ void fill_todo_kernel(unsigned* todo, unsigned* count, unsigned n) {
 template <int KCAP>
 int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
     const GridDesc g = grid_desc(gr);
-    if (hipMemsetAsync(out.todo_count, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
+    if (zero_async(out.todo_count, 4, st) != SP_OK) return SP_ERR_HIP;
     if (KCAP <= 10 && gr->self_knn_mode == 0) {  // short lists: lane per point, exact without a to-do pass
         grid_self_knn_lane_kernel<KCAP><<<div_up(gr->n, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
         return launch_status();

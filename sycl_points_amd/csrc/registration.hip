@@ -1266,7 +1266,7 @@ int run_reduction(Which which, const float* src, const float* scov, size_t n, co
     const int v = validate(fp, scov, tcov, tnrm);
     if (v != SP_OK) return v;
     if (n >= (1ull << 32)) { sp_set_error("[Registration] more than 2^32 source points"); return SP_ERR_INVALID_ARGUMENT; }
-    if (n == 0) return hip_status(hipMemsetAsync(out, 0, sizeof(sp_linearized), st));
+    if (n == 0) return zero_async(out, sizeof(sp_linearized), st);
     if (!ws || ws_bytes < sp_gicp_workspace_bytes(n)) {
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
@@ -1324,7 +1324,7 @@ extern "C" int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, cons
                               float planarity_threshold, uint32_t* counts_out, void* stream) {
     using namespace sp;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(counts_out, 0, 8, st) != hipSuccess) return SP_ERR_HIP;
+    if (zero_async(counts_out, 8, st) != SP_OK) return SP_ERR_HIP;
     if (n == 0) return SP_OK;
     genz_counts_kernel<<<reduce_grid(n), kBlock, 0, st>>>(reinterpret_cast<const float4*>(tgt_covs), nn_idx, nn_d2,
                                                           (unsigned)n, max_corr * max_corr, planarity_threshold,
@@ -1629,7 +1629,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         return SP_ERR_INVALID_ARGUMENT;
     }
     const size_t n = source->n;
-    if (n == 0) return hip_status(hipMemsetAsync(out, 0, sizeof(sp_linearized), st));
+    if (n == 0) return zero_async(out, sizeof(sp_linearized), st);
     if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
@@ -1714,7 +1714,7 @@ extern "C" int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gic
     if (!target || !source || !params || !out || !transT_lin_host) return SP_ERR_INVALID_ARGUMENT;
     if (const int rc = check_prepared_reg("error_prepared", target, params); rc != SP_OK) return rc;
     const size_t n = source->n;
-    if (n == 0) return hip_status(hipMemsetAsync(out, 0, sizeof(sp_linearized), st));
+    if (n == 0) return zero_async(out, sizeof(sp_linearized), st);
     if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
@@ -1760,11 +1760,10 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     const AlignWs w = align_ws(workspace);
     if (k == 0 && rows_all_reduced == 1) {
         // every rank all-reduces all kAlignMaxBlocks rows whatever its own tile size: rows a rank does not write stay zero
-        if (hipMemsetAsync(w.part[0], 0, 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != hipSuccess)
-            return SP_ERR_HIP;
+        if (zero_async(w.part[0], 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != SP_OK) return SP_ERR_HIP;
     }
     if (k == 0 && rows_all_reduced == 2) {  // fan-in: ticket counter (and the rows, for a launch that returns at once)
-        if (hipMemsetAsync(w.fan_row[0], 0, (2 * kFanRow + 4) * sizeof(float), st) != hipSuccess) return SP_ERR_HIP;
+        if (zero_async(w.fan_row[0], (2 * kFanRow + 4) * sizeof(float), st) != SP_OK) return SP_ERR_HIP;
     }
     target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
@@ -1850,9 +1849,9 @@ extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_s
     hipStream_t st = as_stream(stream);
     if (!target || !source || !params || !gn || !transT_device) return SP_ERR_INVALID_ARGUMENT;
     if (source->n == 0 || max_iterations <= 0) {
-        if (lin_out && hipMemsetAsync(lin_out, 0, sizeof(sp_linearized), st) != hipSuccess) return SP_ERR_HIP;
-        if (delta_out8 && hipMemsetAsync(delta_out8, 0, 8 * sizeof(float), st) != hipSuccess) return SP_ERR_HIP;
-        if (iterations_out && hipMemsetAsync(iterations_out, 0, sizeof(uint32_t), st) != hipSuccess) return SP_ERR_HIP;
+        if (zero_async(lin_out, sizeof(sp_linearized), st) != SP_OK) return SP_ERR_HIP;
+        if (zero_async(delta_out8, 8 * sizeof(float), st) != SP_OK) return SP_ERR_HIP;
+        if (zero_async(iterations_out, sizeof(uint32_t), st) != SP_OK) return SP_ERR_HIP;
         return SP_OK;
     }
     for (int k = 0; k < max_iterations; ++k) {

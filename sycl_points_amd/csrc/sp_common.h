@@ -29,6 +29,12 @@ inline unsigned stream_grid(size_t n, int block = kBlock, int per_thread = 1) {
     return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
+// Zero `bytes` bytes (a multiple of 4) at p with a KERNEL. Every enqueue-only entry point uses this instead of
+// hipMemsetAsync: on ROCm 7.2 a memset NODE of a captured hipGraph was observed (tests/test_gpu_multirank.py, the fan-in
+// ticket counter; also the 64 KB row reset of the rows_all_reduced = 1 loop) not to be ordered before the kernel node that
+// follows it in the captured stream when the graph is replayed — eager launches and the first replay hide it.
+int zero_async(void* p, size_t bytes, hipStream_t st);  // capi_common.hip; returns SP_OK / SP_ERR_HIP
+
 // Device scratch for the structure builds (sp_grid_create and friends): the temporaries of a build (sort keys, rocPRIM
 // workspaces, a few counters) are idle again when the build returns (it synchronises its stream), so they are kept and
 // handed to the next build instead of going back to hipFree / hipMalloc, which cost ~0.1 ms apiece on this runtime

@@ -305,8 +305,8 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
         sp_set_error("voxel_size must be positive");  // voxel_downsampling.hpp:23-25
         return SP_ERR_INVALID_ARGUMENT;
     }
-    if (status_dev && hipMemsetAsync(status_dev, 0, 4, st) != hipSuccess) return SP_ERR_HIP;
-    if (n == 0) return hip_status(hipMemsetAsync(n_out_dev, 0, 4, st));
+    if (zero_async(status_dev, 4, st) != SP_OK) return SP_ERR_HIP;
+    if (n == 0) return zero_async(n_out_dev, 4, st);
     if (n >= (1ull << 32)) {
         sp_set_error("[VoxelGrid::downsampling] more than 2^32 points");
         return SP_ERR_INVALID_ARGUMENT;
@@ -438,7 +438,7 @@ extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes,
                                    size_t workspace_bytes, void* stream) {
     using namespace sp;
     hipStream_t st = as_stream(stream);
-    if (n == 0) return hip_status(hipMemsetAsync(n_out_dev, 0, 4, st));
+    if (n == 0) return zero_async(n_out_dev, 4, st);
     if (row_bytes % 4 != 0 || n >= (1ull << 31)) {
         sp_set_error("[FilterByFlags] row_bytes must be a multiple of 4 and n < 2^31");
         return SP_ERR_INVALID_ARGUMENT;
