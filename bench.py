@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: run the multi-GPU code path (RCCL all-reduce of the 192-byte system every iteration) "
                          "with a world of one rank")
+    ap.add_argument("--exchange", choices=["rccl-row", "torch-row", "torch-rows"], default="rccl-row",
+                    help="sharded runs: what moves the linear system between the ranks every iteration. rccl-row: the 128-byte "
+                         "fan-in row through the library's own RCCL communicator (sp_gicp_align_sharded, the C ABI path); "
+                         "torch-row: the same row through torch.distributed; torch-rows: round 1's 32 KB of partial rows")
     ap.add_argument("--no-graph", action="store_true",
                     help="sharded runs: issue every launch / collective from the host instead of replaying one "
                          "captured hipGraph per alignment")
@@ -82,6 +86,12 @@ def parse():
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout. Libraries below print there too (RCCL writes a version banner to stdout when a
+    # communicator is created): everything written to fd 1 from here on goes to stderr, and the line is written to the real
+    # stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -142,11 +152,19 @@ def main():
     delta = torch.zeros(8, dtype=torch.float32, device=dev)
     group = dist.group.WORLD if (world > 1 or args.force_sharded) else None
     use_graph = group is not None and not args.no_graph and os.environ.get("SP_BENCH_GRAPH", "1") == "1"
+    comm = None
+    if group is not None and args.exchange == "rccl-row" and args.path == "fused":
+        try:
+            comm = sp.Communicator.from_process_group(group)
+        except Exception as e:  # no RCCL behind the C ABI on this machine: torch.distributed moves the row instead
+            if rank == 0:
+                print(f"bench: sp_comm unavailable ({e!r}); exchanging the row through torch.distributed", file=sys.stderr)
+    exchange = "rows" if args.exchange == "torch-rows" else "row"
 
     def align_chunk(iters, first):
         if args.path == "fused":
             reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta, prepare=first,
-                                 sort_by_cell=SORT_MODE, graph=use_graph)
+                                 sort_by_cell=SORT_MODE, graph=use_graph, comm=comm, exchange=exchange)
         else:
             reg.align_device_loop(S, Tg, knn, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta)
 
@@ -249,6 +267,10 @@ def main():
                        "sharding": ((f"source dealt to the ranks in chunks of {args.shard_chunk} consecutive points"
                                      if args.shard_chunk > 0 else "source in contiguous tiles") +
                                     ", target replicated" if shards > 1 else "none"),
+                       "exchange": (None if group is None else
+                                    ("128-byte fan-in row per iteration, " if exchange == "row" else "32 KB of partial rows per iteration, ") +
+                                    ("sp_gicp_align_sharded over the library's RCCL communicator" if comm is not None
+                                     else "torch.distributed all-reduce")),
                        "launch": ("one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
                                   else ("per-iteration launches + all-reduce from the host" if group is not None
                                         else "one C call per alignment"))},
@@ -266,7 +288,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, REG_TYPE)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -150,6 +150,31 @@ struct DeviceQueue {
     template <typename T> void clear_accessed_by_host(const T*, size_t) const {}
 };
 
+/// MI355X extension: RAII handle of the library's RCCL communicator (sp_comm), one process per GPU. Rank 0
+/// makes the 128-byte id (Communicator::unique_id) and hands it to the other ranks through the application's own channel
+/// (MPI_Bcast, a file, ...); every rank then constructs Communicator(id, rank, world) — a collective call.
+class Communicator {
+public:
+    static std::vector<unsigned char> unique_id() {
+        std::vector<unsigned char> id(SP_COMM_ID_BYTES);
+        throw_on_error(sp_comm_unique_id(id.data()));
+        return id;
+    }
+    Communicator(const std::vector<unsigned char>& id, int rank, int world) {
+        if (id.size() != SP_COMM_ID_BYTES) throw std::invalid_argument("[Communicator] the id must be SP_COMM_ID_BYTES bytes");
+        throw_on_error(sp_comm_create(id.data(), rank, world, &h_));
+    }
+    ~Communicator() { sp_comm_destroy(h_); }
+    Communicator(const Communicator&) = delete;
+    Communicator& operator=(const Communicator&) = delete;
+    sp_comm* handle() const { return h_; }
+    int rank() const { return sp_comm_rank(h_); }
+    int world() const { return sp_comm_world(h_); }
+
+private:
+    sp_comm* h_ = nullptr;
+};
+
 /// The reference's `sycl::event`: here the stream the work was enqueued on (all work of a cloud shares one in-order
 /// stream, so "depends on these events" is already implied by enqueue order; the type exists for source compatibility).
 struct event {

@@ -243,6 +243,9 @@ public:
         if (fused && params_.optimization_method == OptimizationMethod::GAUSS_NEWTON && !params_.verbose &&
             params_.max_iterations > 0 && !pose_terms)
             return align_on_device(source.size(), initial_guess, robust_scale);
+        if (comm_ != nullptr)
+            throw std::runtime_error("[Registration::align] a communicator is set: only the device-resident Gauss-Newton loop "
+                                     "(GICP / POINT_TO_DISTRIBUTION on a GridKNN, no host-side pose terms) is sharded");
 
         for (size_t iter = 0; iter < params_.max_iterations; ++iter) {
             LinearizedResult lin = fused ? linearize_fused(source.size(), result.T.matrix(), robust_scale)
@@ -264,6 +267,14 @@ public:
         }
         return result;
     }
+
+    /// MI355X extension: with a communicator set, `source` is THIS rank's shard of the source cloud (target, its
+    /// covariances and its KNN structure are replicated on every rank) and align() runs the Gauss-Newton loop through
+    /// sp_gicp_align_sharded: one launch and one 128-byte RCCL all-reduce per iteration, the identical pose on every rank.
+    /// Applies where align() runs entirely on the device (GICP / POINT_TO_DISTRIBUTION on a GridKNN or an accelerated KDTree,
+    /// Gauss-Newton, no host-side pose terms); every other configuration throws, since a rank-local result would silently
+    /// differ between ranks. nullptr (default): single GPU.
+    void set_communicator(sp_comm* comm) { comm_ = comm; }
 
     /// MI355X extension: when align() is given a KDTree (no nodes removed) and the factor is GICP, search on a GridKNN
     /// built from the target instead (default on; results agree to rounding with the KD-tree path).
@@ -433,10 +444,16 @@ private:
         float* delta_dev = T_dev_ + 16;
         uint32_t* iters_dev = reinterpret_cast<uint32_t*>(T_dev_ + 24);
         hip_check(hipMemcpyAsync(T_dev_, initial_guess.data(), 16 * sizeof(float), hipMemcpyHostToDevice, queue_.stream()), "H2D");
-        throw_on_error(sp_gicp_align_fused(ptgt_, psrc_, T_dev_, &fp, &gn, (int)params_.max_iterations,
-                                           neighbors_.indices->device_data_for_write(N),
-                                           neighbors_.distances->device_data_for_write(N), lin_dev_, delta_dev, iters_dev,
-                                           ws_, ws_bytes_, queue_.stream()));
+        if (comm_ != nullptr)  // source sharded over the ranks: one 128-byte all-reduce per iteration
+            throw_on_error(sp_gicp_align_sharded(ptgt_, psrc_, T_dev_, &fp, &gn, (int)params_.max_iterations, comm_,
+                                                 neighbors_.indices->device_data_for_write(N),
+                                                 neighbors_.distances->device_data_for_write(N), lin_dev_, delta_dev,
+                                                 iters_dev, ws_, ws_bytes_, queue_.stream()));
+        else
+            throw_on_error(sp_gicp_align_fused(ptgt_, psrc_, T_dev_, &fp, &gn, (int)params_.max_iterations,
+                                               neighbors_.indices->device_data_for_write(N),
+                                               neighbors_.distances->device_data_for_write(N), lin_dev_, delta_dev, iters_dev,
+                                               ws_, ws_bytes_, queue_.stream()));
         float host[28];
         hip_check(hipMemcpyAsync(host, T_dev_, sizeof host, hipMemcpyDeviceToHost, queue_.stream()), "D2H");
         const sp_linearized h = read_lin();  // synchronises the stream
@@ -591,6 +608,7 @@ private:
     sp_gicp_target* ptgt_ = nullptr;
     uint64_t ptgt_grid_id_ = 0;  // GridKNN::id() the prepared target was built on
     bool source_presorted_ = false;
+    sp_comm* comm_ = nullptr;  // borrowed (set_communicator)
     bool accelerate_kdtree_ = true;
     mutable bool fused_loop_active_ = false;  // align() is running its optimiser loop on the prepared path
     TransformMatrix lin_T_ = TransformMatrix::Identity();  // pose of the last fused linearisation

@@ -538,6 +538,54 @@ static void voxel_hash_map_known_answers() {
     }
 }
 
+// Registration::align with the source sharded over a communicator (here a world of one rank: the all-reduce is the identity,
+// so the sharded loop — fan-in row + sp_allreduce_rows per iteration — must reproduce the single-GPU result bit for bit)
+static void sharded_align_one_rank() {
+    const size_t n = 30000;
+    std::mt19937 gen(99);
+    std::uniform_real_distribution<float> U(-3.0f, 3.0f);
+    std::normal_distribution<float> N(0.0f, 0.004f);
+    PointCloudCPU tc, sc;
+    float twist[6] = {0.01f, -0.02f, 0.015f, 0.03f, -0.02f, 0.01f}, Tgt[16];
+    sp_se3_exp_host(twist, Tgt);
+    Eigen::Isometry3f Tg;
+    for (int i = 0; i < 16; ++i) Tg.matrix().data()[i] = Tgt[i];
+    const Eigen::Isometry3f Tinv = Tg.inverse();
+    for (size_t i = 0; i < n; ++i) {
+        const PointType p(U(gen), U(gen), U(gen), 1.0f);
+        tc.points->push_back(p);
+        const auto& M = Tinv.matrix();
+        sc.points->emplace_back(M(0, 0) * p.x() + M(0, 1) * p.y() + M(0, 2) * p.z() + M(0, 3) + N(gen),
+                                M(1, 0) * p.x() + M(1, 1) * p.y() + M(1, 2) * p.z() + M(1, 3) + N(gen),
+                                M(2, 0) * p.x() + M(2, 1) * p.y() + M(2, 2) * p.z() + M(2, 3) + N(gen), 1.0f);
+    }
+    PointCloudShared target(*Q, tc), source(*Q, sc);
+    auto tgrid = alg::knn::GridKNN::build(*Q, target);
+    auto sgrid = alg::knn::GridKNN::build(*Q, source);
+    alg::covariance::estimate_async(*tgrid, target, 10).wait_and_throw();
+    alg::covariance::estimate_async(*sgrid, source, 10).wait_and_throw();
+    alg::registration::RegistrationParams params;
+    params.max_iterations = 15;
+    alg::registration::Registration single(*Q, params), sharded(*Q, params);
+    const auto a = single.align(source, target, *tgrid);
+    sycl_utils::Communicator comm(sycl_utils::Communicator::unique_id(), 0, 1);
+    CHECK(comm.rank() == 0 && comm.world() == 1);
+    sharded.set_communicator(comm.handle());
+    const auto b = sharded.align(source, target, *tgrid);
+    CHECK(a.converged && b.converged && a.iterations == b.iterations && a.inlier == b.inlier);
+    bool same = true;
+    for (int i = 0; i < 16; ++i) same = same && a.T.matrix().data()[i] == b.T.matrix().data()[i];
+    CHECK(same);
+    CHECK(max_abs_diff(a.T.matrix(), Tgt) < 2e-3f);
+    // a configuration that would leave the ranks with different results is refused, not run rank-locally
+    params.optimization_method = alg::registration::OptimizationMethod::LEVENBERG_MARQUARDT;
+    alg::registration::Registration lm(*Q, params);
+    lm.set_communicator(comm.handle());
+    bool threw = false;
+    try { lm.align(source, target, *tgrid); } catch (const std::runtime_error&) { threw = true; }
+    CHECK(threw);
+}
+
 int main() {
     sycl_utils::DeviceQueue queue(0);
     Q = &queue;
@@ -547,6 +595,7 @@ int main() {
     RUN(preprocess_filter);
     RUN(point_cloud_files);
     RUN(voxel_hash_map_known_answers);
+    RUN(sharded_align_one_rank);
     RUN(registration_matches_oracle);
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed == 0 ? 0 : 1;
