@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 rm -rf /tmp/tr_vox
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tr_vox -- python3 $GRAFT_REPO_ROOT/scratch/voxel_only.py > /dev/null 2>&1)
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_vox -- python3 $GRAFT_REPO_ROOT/scratch/voxel_only.py > /dev/null 2>&1)
 python3 - <<PY
 import csv,glob
 f=glob.glob("/tmp/tr_vox/**/*kernel_trace.csv",recursive=True)[0]
