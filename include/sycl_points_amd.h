@@ -113,6 +113,22 @@ size_t sp_grid_self_workspace_bytes(const sp_grid* grid);
 int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, float* covs_out, float* normals_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for the queries at grid positions [pos_first, pos_first + pos_count) only (position = index in the grid's cell
+ * order, sp_grid_order); the other rows of the outputs are left untouched. This is how the pre-loop (k = 20 neighbours +
+ * covariances of the target) is sharded by query over the ranks of a multi-GPU run: every rank holds the
+ * whole grid, searches 1/N of the positions, and the covariance rows are exchanged with one all-gather:
+ *   sp_grid_gather_rows   rows of this rank's positions, caller's order -> position order (a contiguous chunk to send)
+ *   sp_allgather          (multi-GPU section)
+ *   sp_grid_scatter_rows  position order -> caller's order, for all positions
+ * row_bytes must be a multiple of 16 (a covariance row is 64, a point / normal 16). */
+int sp_grid_self_knn_range(const sp_grid* grid, size_t k, size_t pos_first, size_t pos_count, int32_t* idx_out,
+                           float* d2_out, float* covs_out, float* normals_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int sp_grid_gather_rows(const sp_grid* grid, const void* rows, size_t row_bytes, size_t pos_first, size_t pos_count,
+                        void* out_by_position, void* stream);
+int sp_grid_scatter_rows(const sp_grid* grid, const void* in_by_position, size_t row_bytes, size_t pos_first,
+                         size_t pos_count, void* rows, void* stream);
+
 /* ------------------------------------------------------------------------------ covariance / normals */
 
 /* covariance::estimate_async (algorithms/feature/covariance.hpp:16-47, 260-311, kernel K5). */

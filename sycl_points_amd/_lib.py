@@ -81,6 +81,9 @@ SIGNATURES = {
     "sp_grid_remove_by_flags": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "sp_grid_self_workspace_bytes": (_sz, [_vp]),
     "sp_grid_self_knn": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_grid_self_knn_range": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_grid_gather_rows": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    "sp_grid_scatter_rows": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "sp_cov_estimate": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "sp_cov_estimate_robust": (_i, [_vp, _sz, _vp, _sz, _i, _f, _f, _sz, _vp, _vp]),
     "sp_cov_normalize": (_i, [_vp, _sz, _vp, _vp]),

@@ -232,6 +232,7 @@ struct TileOut {
     float4* normals;   // [n] (may be null)
     unsigned* todo;    // queries (positions in grid order) the ring walk must finish
     unsigned* todo_count;
+    unsigned pos_lo, pos_hi;  // only the queries at grid positions [pos_lo, pos_hi) are searched (sp_grid_self_knn_range)
 };
 
 // covariance::kernel::estimate (feature/covariance.hpp:16-47) over the neighbour list in ascending order, reading
@@ -321,8 +322,9 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_tile_kernel(const float4*
     const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
     const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
     const unsigned qe = min(qs + 64u, row_e);
+    if (qe <= out.pos_lo || qs >= out.pos_hi) return;  // wave-uniform: the unit lies outside the requested range
     const unsigned lane = threadIdx.x;
-    const bool active = qs + lane < qe;
+    const bool active = qs + lane < qe && qs + lane >= out.pos_lo && qs + lane < out.pos_hi;
     const float4 q = pts[min(qs + lane, qe - 1)];
     // x-span of the unit's queries (cells are ascending along the row)
     const float4 qf = pts[qs], ql = pts[qe - 1];
@@ -407,8 +409,8 @@ template <int KCAP>
 __global__ __launch_bounds__(kBlock) void grid_self_knn_lane_kernel(const float4* __restrict__ pts,
                                                                     const unsigned* __restrict__ start, GridDesc g, int k,
                                                                     TileOut out) {
-    const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
-    if (qi >= g.n) return;
+    const unsigned qi = out.pos_lo + blockIdx.x * kBlock + threadIdx.x;
+    if (qi >= out.pos_hi) return;
     const float4 q = pts[qi];
     const float qx = q.x, qy = q.y, qz = q.z;
     float bd[KCAP];
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
     const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
     const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
     const unsigned nq = min(64u, row_e - qs);
+    if (qs + nq <= out.pos_lo || qs >= out.pos_hi) return;  // the unit lies outside the requested range
     const unsigned lane = threadIdx.x;
     const float4 myq = pts[min(qs + lane, row_e - 1)];
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -590,6 +593,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
     unsigned seg_s[9], seg_c[10];  // start of each segment, running candidate counts (seg_c[9] = total)
     int xa = 0, xb = 0;
     for (unsigned j = 0; j < nq; ++j) {
+        if (qs + j < out.pos_lo || qs + j >= out.pos_hi) continue;  // wave-uniform
         // the query, made wave-uniform
         const float qx = bcast_f(myq.x, (int)j), qy = bcast_f(myq.y, (int)j), qz = bcast_f(myq.z, (int)j);
         const unsigned qorig = (unsigned)bcast_i(__float_as_int(myq.w), (int)j);
@@ -888,7 +892,7 @@ int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
     const GridDesc g = grid_desc(gr);
     if (zero_async(out.todo_count, 4, st) != SP_OK) return SP_ERR_HIP;
     if (KCAP <= 10 && gr->self_knn_mode == 0) {  // short lists: lane per point, exact without a to-do pass
-        grid_self_knn_lane_kernel<KCAP><<<div_up(gr->n, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
+        grid_self_knn_lane_kernel<KCAP><<<div_up(out.pos_hi - out.pos_lo, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
         return launch_status();
     }
     if (gr->n_units) {
@@ -1229,6 +1233,13 @@ extern "C" size_t sp_grid_self_workspace_bytes(const sp_grid* grid) { return gri
 
 extern "C" int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, float* covs_out,
                                 float* normals_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return sp_grid_self_knn_range(grid, k, 0, grid ? grid->n : 0, idx_out, d2_out, covs_out, normals_out, workspace,
+                                  workspace_bytes, stream);
+}
+
+extern "C" int sp_grid_self_knn_range(const sp_grid* grid, size_t k, size_t pos_first, size_t pos_count, int32_t* idx_out,
+                                      float* d2_out, float* covs_out, float* normals_out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
     using namespace sp;
     if (!grid || k == 0) {
         sp_set_error("[GridKNN::self_knn] null grid or k == 0");
@@ -1238,7 +1249,11 @@ extern "C" int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out,
         sp_set_error("[GridKNN::knn_search_async] `k` is too large (max 20).");
         return SP_ERR_RUNTIME;
     }
-    if (grid->n == 0) return SP_OK;
+    if (pos_first > grid->n || pos_count > grid->n - pos_first) {
+        sp_set_error("[GridKNN::self_knn] position range outside the grid");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (grid->n == 0 || pos_count == 0) return SP_OK;
     if (!workspace || workspace_bytes < sp_grid_self_workspace_bytes(grid)) {
         sp_set_error("[GridKNN::self_knn] workspace too small (sp_grid_self_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
@@ -1250,6 +1265,8 @@ extern "C" int sp_grid_self_knn(const sp_grid* grid, size_t k, int32_t* idx_out,
     out.normals = reinterpret_cast<float4*>(normals_out);
     out.todo_count = static_cast<unsigned*>(workspace);
     out.todo = out.todo_count + 2;
+    out.pos_lo = (unsigned)pos_first;
+    out.pos_hi = (unsigned)(pos_first + pos_count);
     hipStream_t st = as_stream(stream);
     grid->streams.note(st);
     if (k <= 10) return launch_self<10>(grid, (int)k, out, st);
@@ -1278,4 +1295,49 @@ extern "C" int sp_internal_grid_option(sp_grid* grid, int option, int value) {
     if (!grid || option != SP_INTERNAL_SELF_KNN_MODE) return SP_ERR_INVALID_ARGUMENT;
     grid->self_knn_mode = value;
     return SP_OK;
+}
+
+// Rows between the caller's (original) order and the grid's position order, for clouds whose per-point results are computed
+// by ranges of grid positions on different ranks (sp_grid_self_knn_range) and exchanged with one all-gather.
+namespace sp {
+namespace {
+template <bool TO_POSITIONS>
+__global__ __launch_bounds__(kBlock) void grid_rows_kernel(const float4* __restrict__ pts, unsigned pos_lo, unsigned count,
+                                                           unsigned quads, const float4* __restrict__ in,
+                                                           float4* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (size_t)count * quads) return;
+    const unsigned j = (unsigned)(t / quads), q = (unsigned)(t % quads);
+    const unsigned orig = __float_as_uint(pts[pos_lo + j].w);
+    if (TO_POSITIONS) out[(size_t)j * quads + q] = in[(size_t)orig * quads + q];
+    else out[(size_t)orig * quads + q] = in[(size_t)j * quads + q];
+}
+int grid_rows(const sp_grid* grid, const void* in, size_t row_bytes, size_t pos_first, size_t pos_count, void* out,
+              bool to_positions, hipStream_t st) {
+    if (!grid || (pos_count && (!in || !out))) return SP_ERR_INVALID_ARGUMENT;
+    if (row_bytes == 0 || row_bytes % 16 != 0 || pos_first > grid->n || pos_count > grid->n - pos_first) {
+        sp_set_error("[GridKNN] rows must be a multiple of 16 bytes and the position range inside the grid");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (pos_count == 0) return SP_OK;
+    grid->streams.note(st);
+    const unsigned quads = (unsigned)(row_bytes / 16);
+    const size_t total = pos_count * quads;
+    if (to_positions)
+        grid_rows_kernel<true><<<div_up(total, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)pos_first, (unsigned)pos_count, quads,
+                                                                        static_cast<const float4*>(in), static_cast<float4*>(out));
+    else
+        grid_rows_kernel<false><<<div_up(total, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)pos_first, (unsigned)pos_count, quads,
+                                                                         static_cast<const float4*>(in), static_cast<float4*>(out));
+    return launch_status();
+}
+}  // namespace
+}  // namespace sp
+extern "C" int sp_grid_gather_rows(const sp_grid* grid, const void* rows, size_t row_bytes, size_t pos_first, size_t pos_count,
+                                   void* out_by_position, void* stream) {
+    return sp::grid_rows(grid, rows, row_bytes, pos_first, pos_count, out_by_position, true, sp::as_stream(stream));
+}
+extern "C" int sp_grid_scatter_rows(const sp_grid* grid, const void* in_by_position, size_t row_bytes, size_t pos_first,
+                                    size_t pos_count, void* rows, void* stream) {
+    return sp::grid_rows(grid, in_by_position, row_bytes, pos_first, pos_count, rows, false, sp::as_stream(stream));
 }

@@ -166,3 +166,39 @@ def test_destroy_does_not_stall_or_break_a_capture(sp):
     torch.cuda.synchronize()
     assert torch.equal(ref.indices, again.indices) and torch.equal(ref.distances, again.distances)
     assert bool((ref.indices[:, 0] == torch.arange(n, device="cuda")).all())
+
+
+@pytest.mark.parametrize("k,ppc", [(20, 6.0), (10, 2.0), (4, 1.0)])
+def test_self_knn_by_position_ranges_equals_whole_cloud(sp, k, ppc):
+    """sp_grid_self_knn_range (the query-sharded pre-loop of a multi-GPU run): searching the grid positions in eight ranges,
+    one after the other into the same output arrays, gives exactly what the whole-cloud call gives — neighbours, distances,
+    covariances — for the wave-cooperative (k > 10), lane-per-point (k <= 10) and LDS-tile (k <= 6) kernels, including
+    ranges that cut 64-query units in the middle; sp_grid_gather_rows / sp_grid_scatter_rows invert each other."""
+    n = 300_007
+    rs = np.random.RandomState(11)
+    pts = np.ones((n, 4), np.float32)
+    pts[:, :3] = rs.uniform(-6, 6, (n, 3)).astype(np.float32)
+    P = dev(pts)
+    grid = sp.GridKNN.build(P, points_per_cell=ppc)
+    res, covs, _ = grid.self_knn(k, want_knn=True, want_covs=True)
+    L = sp._lib.lib()
+    idx = torch.full((n, k), -7, dtype=torch.int32, device="cuda")
+    d2 = torch.full((n, k), -7.0, dtype=torch.float32, device="cuda")
+    cv = torch.full((n, 16), -7.0, dtype=torch.float32, device="cuda")
+    nbytes = L.sp_grid_self_workspace_bytes(grid._h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    bounds = [0, 1, 37_001, 37_002, 100_000, 163_840, 250_000, 299_999, n]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        sp.check(L.sp_grid_self_knn_range(grid._h, k, a, b - a, sp._ptr(idx), sp._ptr(d2), sp._ptr(cv), None, sp._ptr(ws), nbytes,
+                                          sp._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(idx, res.indices) and torch.equal(d2, res.distances) and torch.equal(cv, covs)
+    with pytest.raises(sp.SpError):
+        sp.check(L.sp_grid_self_knn_range(grid._h, k, n - 5, 6, sp._ptr(idx), sp._ptr(d2), sp._ptr(cv), None, sp._ptr(ws), nbytes,
+                                          sp._stream()))
+    by_pos = torch.empty((n, 16), dtype=torch.float32, device="cuda")
+    back = torch.empty((n, 16), dtype=torch.float32, device="cuda")
+    sp.check(L.sp_grid_gather_rows(grid._h, sp._ptr(covs), 64, 0, n, sp._ptr(by_pos), sp._stream()))
+    sp.check(L.sp_grid_scatter_rows(grid._h, sp._ptr(by_pos), 64, 0, n, sp._ptr(back), sp._stream()))
+    order = grid.order()
+    assert torch.equal(by_pos, covs[order]) and torch.equal(back, covs)

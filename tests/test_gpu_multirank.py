@@ -64,6 +64,18 @@ def _worker(rank, world, port, n, iters, out_path):
     T3, lin3, _ = reg3.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD, per_iteration_launches=True)
     torch.cuda.synchronize()
     inl3 = reg3._read_lin(lin3).inlier
+    # pre-loop sharded by query: each rank computes the k = 20 covariances of half of the target's grid positions, one
+    # all-gather shares them; every row must equal the covariance the whole-cloud kernel computes, bit for bit
+    g6 = sp.GridKNN.build(Tg.points, points_per_cell=6.0)
+    full = g6.self_knn(20, want_knn=False, want_covs=True)[1]
+    shared = g6.covariances_sharded(20, rank, world, lambda send, recv: dist.all_gather_into_tensor(recv, send))
+    torch.cuda.synchronize()
+    assert torch.equal(shared, full)
+    g2 = sp.GridKNN.build(Tg.points[:5001].contiguous(), points_per_cell=2.0)  # short lists (lane kernel), odd size
+    full2 = g2.self_knn(7, want_knn=False, want_covs=True)[1]
+    shared2 = g2.covariances_sharded(7, rank, world, lambda send, recv: dist.all_gather_into_tensor(recv, send))
+    torch.cuda.synchronize()
+    assert torch.equal(shared2, full2)
     np.save(out_path % rank, np.concatenate([T1.cpu().numpy(), T2.cpu().numpy(), [np.float32(inl)], T3.cpu().numpy(),
                                              [np.float32(inl3), np.float32(iters_done)]]))
     dist.destroy_process_group()
