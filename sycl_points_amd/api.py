@@ -287,6 +287,30 @@ class GridKNN(KNNBase):
         self._keep = ws
         return res, covs, nrm
 
+    def covariances_sharded(self, k, rank, world, all_gather):
+        """The pre-loop of a multi-GPU run sharded by query: this rank computes the k-neighbour covariances
+        of the grid positions [rank * c, (rank + 1) * c), c = ceil(n / world) (sp_grid_self_knn_range), the chunks — made
+        contiguous by sp_grid_gather_rows — are exchanged by `all_gather(send, recv)` (Communicator.all_gather, or a
+        torch.distributed all_gather_into_tensor), and sp_grid_scatter_rows puts all n rows back into the cloud's order.
+        Bit-identical to self_knn(k, want_covs=True) of the whole cloud."""
+        L = _lib.lib()
+        dev = self.device
+        n = self.n
+        c = (n + world - 1) // world
+        first = min(rank * c, n)
+        count = min(c, n - first)
+        covs = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        nbytes = L.sp_grid_self_workspace_bytes(self._h)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        check(L.sp_grid_self_knn_range(self._h, k, first, count, None, None, _ptr(covs), None, _ptr(ws), nbytes, _stream()))
+        send = torch.zeros((c, 16), dtype=torch.float32, device=dev)  # equal chunks; the last rank's tail stays zero
+        check(L.sp_grid_gather_rows(self._h, _ptr(covs), 64, first, count, _ptr(send), _stream()))
+        recv = torch.empty((world * c, 16), dtype=torch.float32, device=dev)
+        all_gather(send, recv)
+        check(L.sp_grid_scatter_rows(self._h, _ptr(recv), 64, 0, n, _ptr(covs), _stream()))
+        self._keep = (ws, send, recv)
+        return covs
+
     def knn_search_async(self, queries, k, result, transT=None):
         q = _dev_f32(_points_of(queries), 4)
         if k > 20:
