@@ -123,7 +123,17 @@ def main():
     src, tgt, T_gt = gicp_pair(n_total, rng_range)
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     Tg = sp.PointCloudShared(to_dev(tgt), device=dev)
-    Tg.covs = sp.GridKNN.build(Tg.points, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
+    g6 = sp.GridKNN.build(Tg.points, points_per_cell=6.0)
+    preloop = None
+    if world > 1:
+        # pre-loop sharded by query: each rank computes the k = 20 covariances of 1/N of the target's grid
+        # positions, one all-gather shares the rows (torch.distributed here: the library's communicator is created below)
+        Tg.covs = g6.covariances_sharded(20, rank, world, lambda send, recv: dist.all_gather_into_tensor(recv, send))
+    else:
+        Tg.covs = g6.self_knn(20, want_knn=False, want_covs=True)[1]
+        if shards > 1:  # rehearsal: what ONE rank of the N-rank run would spend on its share of the pre-loop
+            preloop = preloop_times(sp, _lib, torch, g6, Tg.covs, args.emulate_rank, shards)
+    del g6
     tile = torch.from_numpy(shard_indices(n_total, rank if shards == world else args.emulate_rank, shards,
                                           args.shard_chunk)).to(dev)
     S_all = to_dev(src)
@@ -278,6 +288,7 @@ def main():
             "pose_max_abs_err_vs_ground_truth": pose_err,
             "inliers_last_iteration": int(lin.inlier),
             "setup_s": t_setup,
+            "preloop_per_rank": preloop,
             "kernels": kern,
             "launches_of_one_alignment": launches,
             "launch_classes": classes,
@@ -305,6 +316,41 @@ def measured_traffic(kernel):
         return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def preloop_times(sp, _lib, torch, g6, covs_full, rank, world):
+    """Pre-loop (k = 20 neighbours + covariances of the replicated target) sharded by query: time of this rank's range
+    (sp_grid_self_knn_range) and of the row re-ordering either side of the all-gather, against the whole-cloud call every
+    rank made in round 1. The all-gather itself (64 B x n rows over xGMI) cannot be measured on one GPU."""
+    L = _lib.lib()
+    n = g6.n
+    c = (n + world - 1) // world
+    first, count = min(rank * c, n), min(c, n - min(rank * c, n))
+    nbytes = L.sp_grid_self_workspace_bytes(g6._h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=covs_full.device)
+    covs = torch.empty_like(covs_full)
+    send = torch.zeros((c, 16), dtype=torch.float32, device=covs_full.device)
+    recv = torch.zeros((world * c, 16), dtype=torch.float32, device=covs_full.device)
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    whole = timed(lambda: _lib.check(L.sp_grid_self_knn(g6._h, 20, None, None, sp._ptr(covs), None, sp._ptr(ws), nbytes, sp._stream())))
+    part = timed(lambda: _lib.check(L.sp_grid_self_knn_range(g6._h, 20, first, count, None, None, sp._ptr(covs), None, sp._ptr(ws),
+                                                             nbytes, sp._stream())))
+    gat = timed(lambda: _lib.check(L.sp_grid_gather_rows(g6._h, sp._ptr(covs), 64, first, count, sp._ptr(send), sp._stream())))
+    sca = timed(lambda: _lib.check(L.sp_grid_scatter_rows(g6._h, sp._ptr(recv), 64, 0, n, sp._ptr(covs), sp._stream())))
+    return {"target_points": n, "ranks": world, "whole_cloud_ms": whole, "this_rank_range_ms": part, "gather_rows_ms": gat,
+            "scatter_rows_ms": sca, "all_gather_bytes_received_per_rank": 64 * c * (world - 1),
+            "all_gather_ms_at_7x153GBps_links": 64 * c * (world - 1) / (7 * 153e9) * 1e3}
 
 
 def class_traffic(cls):
