@@ -733,28 +733,30 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
         W[1][j] = chain3(Ct.xy, R[0][j], Ct.yy, R[1][j], Ct.yz, R[2][j]);
         W[2][j] = chain3(Ct.xz, R[0][j], Ct.yz, R[1][j], Ct.zz, R[2][j]);
     }
-    Mat3 A;  // Cs' + R^T Ct' R (symmetric); P2D: R^T M R
-    A.m[0][0] = chain3(R[0][0], W[0][0], R[1][0], W[1][0], R[2][0], W[2][0]) + (P2D ? 0.0f : Cs.xx);
-    A.m[0][1] = chain3(R[0][0], W[0][1], R[1][0], W[1][1], R[2][0], W[2][1]) + (P2D ? 0.0f : Cs.xy);
-    A.m[0][2] = chain3(R[0][0], W[0][2], R[1][0], W[1][2], R[2][0], W[2][2]) + (P2D ? 0.0f : Cs.xz);
-    A.m[1][1] = chain3(R[0][1], W[0][1], R[1][1], W[1][1], R[2][1], W[2][1]) + (P2D ? 0.0f : Cs.yy);
-    A.m[1][2] = chain3(R[0][1], W[0][2], R[1][1], W[1][2], R[2][1], W[2][2]) + (P2D ? 0.0f : Cs.yz);
-    A.m[2][2] = chain3(R[0][2], W[0][2], R[1][2], W[1][2], R[2][2], W[2][2]) + (P2D ? 0.0f : Cs.zz);
+    // A = Cs' + R^T Ct' R (symmetric); P2D: R^T M R with no source term, and A is N itself
+    const float g00 = chain3(R[0][0], W[0][0], R[1][0], W[1][0], R[2][0], W[2][0]);
+    const float g01 = chain3(R[0][0], W[0][1], R[1][0], W[1][1], R[2][0], W[2][1]);
+    const float g02 = chain3(R[0][0], W[0][2], R[1][0], W[1][2], R[2][0], W[2][2]);
+    const float g11 = chain3(R[0][1], W[0][1], R[1][1], W[1][1], R[2][1], W[2][1]);
+    const float g12 = chain3(R[0][1], W[0][2], R[1][1], W[1][2], R[2][1], W[2][2]);
+    const float g22 = chain3(R[0][2], W[0][2], R[1][2], W[1][2], R[2][2], W[2][2]);
     float n00, n01, n02, n11, n12, n22;
-    if (P2D) {
-        n00 = A.m[0][0]; n01 = A.m[0][1]; n02 = A.m[0][2]; n11 = A.m[1][1]; n12 = A.m[1][2]; n22 = A.m[2][2];
+    if constexpr (P2D) {
+        n00 = g00; n01 = g01; n02 = g02; n11 = g11; n12 = g12; n22 = g22;
     } else {
+        const float a00 = g00 + Cs.xx, a01 = g01 + Cs.xy, a02 = g02 + Cs.xz, a11 = g11 + Cs.yy, a12 = g12 + Cs.yz,
+                    a22 = g22 + Cs.zz;
         // symmetric inverse by the adjugate; Zero when |det| < 1e-6 (eigen_utils::inverse, eigen_utils.hpp:403-423;
         // det is invariant under the rotation)
-        const float c00 = fmaf(A.m[1][1], A.m[2][2], -A.m[1][2] * A.m[1][2]);
-        const float c01 = fmaf(A.m[0][2], A.m[1][2], -A.m[0][1] * A.m[2][2]);
-        const float c02 = fmaf(A.m[0][1], A.m[1][2], -A.m[0][2] * A.m[1][1]);
-        const float det = fmaf(A.m[0][0], c00, fmaf(A.m[0][1], c01, A.m[0][2] * c02));
+        const float c00 = fmaf(a11, a22, -a12 * a12);
+        const float c01 = fmaf(a02, a12, -a01 * a22);
+        const float c02 = fmaf(a01, a12, -a02 * a11);
+        const float det = fmaf(a00, c00, fmaf(a01, c01, a02 * c02));
         const float inv_det = fabsf(det) < 1e-6f ? 0.0f : 1.0f / det;
         n00 = c00 * inv_det; n01 = c01 * inv_det; n02 = c02 * inv_det;
-        n11 = fmaf(A.m[0][0], A.m[2][2], -A.m[0][2] * A.m[0][2]) * inv_det;
-        n12 = fmaf(A.m[0][1], A.m[0][2], -A.m[0][0] * A.m[1][2]) * inv_det;
-        n22 = fmaf(A.m[0][0], A.m[1][1], -A.m[0][1] * A.m[0][1]) * inv_det;
+        n11 = fmaf(a00, a22, -a02 * a02) * inv_det;
+        n12 = fmaf(a01, a02, -a00 * a12) * inv_det;
+        n22 = fmaf(a00, a11, -a01 * a01) * inv_det;
     }
     const float v0 = chain3(R[0][0], r0, R[1][0], r1, R[2][0], r2);
     const float v1 = chain3(R[0][1], r0, R[1][1], r1, R[2][1], r2);
@@ -862,8 +864,8 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
     if (nn.idx < 0 || nn.d2 > P.max_d2) return;
     const float* const cp = P.scovp + i;
     const size_t st = P.sstride;
-    Sym3 Cs{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (!P2D) Cs = Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
+    const Sym3 Cs = P2D ? Sym3{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}
+                        : Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
     if (!have_ct) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
     fused_math<LOSS, P2D>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
 }
