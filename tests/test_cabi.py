@@ -38,6 +38,24 @@ def test_library_exports_every_declared_symbol():
     assert all(hasattr(lib, s) for s in _lib.INTERNAL_SIGNATURES)
 
 
+def test_benchmarked_kernel_does_not_spill():
+    """The per-iteration kernel of the benchmarked path (GICP, robust NONE, fast nearest neighbour) is tuned to the 128
+    VGPRs a 1024-thread workgroup allows; a spill costs a measured +1 us and ~1 MB of scratch writes per launch
+    (profiles/README.md). The build keeps the compiler's resource report: hold it to zero VGPR spills."""
+    from sycl_points_amd import _lib
+
+    _lib.build()
+    report = os.path.join(ROOT, "sycl_points_amd", "lib", "registration.resources.txt")
+    if not os.path.exists(report):  # a library built before the report existed: rebuild that one object
+        import subprocess
+        csrc = os.path.join(ROOT, "sycl_points_amd", "csrc")
+        os.utime(os.path.join(csrc, "registration.hip"))
+        subprocess.run(["make", "-C", csrc, "-s", "-j8"], check=True)
+    rows = [l for l in open(report) if "gicp_align_kernelILi0ELb1ELb0" in l]
+    assert len(rows) == 1, rows
+    assert "VGPRs: 128" in rows[0] and "VGPRs Spill: 0" in rows[0], rows[0]
+
+
 def test_sp_linearized_is_192_bytes():
     from sycl_points_amd import _lib
 
