@@ -6,6 +6,8 @@
 // in registers. Chunks write partial top-k lists; a second tiny kernel merges them in chunk order, which keeps
 // the reference's tie rule (strict '<': the lowest target index wins) exactly.
 // The bound is fp32 VALU, not HBM: 9 VALU ops per (query, target) pair, HBM traffic is O(nq + nt).
+// k = 1 has its own packed-fp32 kernel (3.5 instructions per pair); k > 1 on >= 16 tiles of targets runs it as pass A of a
+// bound-then-collect scheme (8.5 -> 4.0 ms at 100k x 100k, k = 20; see knn_bf_bounded_kernel).
 #include "sp_common.h"
 #include "sp_math.h"
 
@@ -118,6 +120,8 @@ __device__ __forceinline__ v2f pk_dist2(v2f qx, v2f qy, v2f qz, v2f pxy, v2f pzw
     return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
 }
 
+// MIN_ONLY: the chunk minimum alone (pass A of the two-pass k > 1 path below), no index recovery.
+template <bool MIN_ONLY = false>
 __global__ __launch_bounds__(kBlock) void knn_bf_k1_kernel(const float4* __restrict__ queries, unsigned nq,
                                                            const float4* __restrict__ targets, unsigned nt,
                                                            unsigned chunk, int32_t* __restrict__ idx_out,
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_k1_kernel(const float4* __restr
     for (int u = 0; u < kQ1; ++u) {
         if (qid[u] >= nq) continue;
         const float b = best[u >> 1][u & 1];
+        if (MIN_ONLY) { d2_out[(size_t)split * nq + qid[u]] = b; continue; }
         int idx = -1;
         if (bsub[u] != 0xFFFFFFFFu) {
             const float x = qx[u >> 1][u & 1], y = qy[u >> 1][u & 1], z = qz[u >> 1][u & 1];
@@ -218,6 +223,106 @@ __global__ __launch_bounds__(kBlock) void knn_bf_merge_kernel(const int32_t* __r
 #pragma unroll
     for (int i = 0; i < KCAP; ++i)
         if (i < k) { d2_out[o + i] = bd[i]; idx_out[o + i] = bi[i]; }
+}
+
+// ---- k > 1 on large problems: bound first, then collect ------------------------------------------------------------
+// The sorted insertion costs ~5 instructions per list slot and, in a stream of n targets, a query inserts about
+// k ln(n / k) times (170 at k = 20, n = 100 k): with 64 lanes x 2 queries per wave almost a quarter of the targets send the
+// wave through the insertion code. So the scan is done twice, both times at packed-fp32 rate:
+//   pass A  the k = 1 kernel over G >= k chunks of the targets: G chunk minima per query. Their k-th smallest, tau, is the
+//           distance of a real target and at least k targets are within it (one per chunk), so the k-th neighbour is too.
+//   pass B  distances again, two queries per lane (one packed pair); four targets are folded with v_pk_min and tested
+//           against the bound once: only a group holding a target with d <= tau (about k + G/k of the n) enters the
+//           exact per-target compare and the sorted insertion. Same strict '<' in ascending target order, same chunk-order
+//           merge: lists are bit-identical to the single-pass kernel's.
+__global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __restrict__ chunk_min, unsigned nq, int k,
+                                                              unsigned nchunks, float* __restrict__ bound) {
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nq) return;
+    float bd[20];
+    int bi[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
+    float kth = FLT_MAX;
+    for (unsigned c = 0; c < nchunks; ++c) {
+        const float d = chunk_min[(size_t)c * nq + q];
+        if (d < kth) topk_insert<20>(bd, bi, k, d, 0, kth);
+    }
+    // `d < bound` must admit d == tau; a query without k finite chunk minima (NaN / overflowing coordinates) is not bounded
+    bound[q] = kth < FLT_MAX ? fminf(nextafterf(kth, FLT_MAX), FLT_MAX) : FLT_MAX;
+}
+
+constexpr int kGroup = 4;  // targets folded per bound test (kTile % kGroup == 0)
+
+template <int KCAP>
+__global__ __launch_bounds__(kBlock) void knn_bf_bounded_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                                const float4* __restrict__ targets, unsigned nt, int k,
+                                                                unsigned chunk, const float* __restrict__ bound,
+                                                                int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    __shared__ float4 tile[kTile];
+    const unsigned split = blockIdx.y;
+    const unsigned t_begin = split * chunk;
+    const unsigned t_end = min(nt, t_begin + chunk);
+    unsigned qid[2];
+    v2f qx, qy, qz;
+    float cap[2], kth[2];
+    float bd[2][KCAP];
+    int bi[2][KCAP];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qid[u] = (blockIdx.x * 2 + u) * kBlock + threadIdx.x;
+        const unsigned qc = min(qid[u], nq - 1);
+        const float4 q = queries[qc];
+        qx[u] = q.x; qy[u] = q.y; qz[u] = q.z;
+        cap[u] = bound[qc];
+        kth[u] = cap[u];
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) { bd[u][i] = FLT_MAX; bi[u][i] = -1; }
+    }
+    for (unsigned base = t_begin; base < t_end; base += kTile) {
+        const unsigned cnt = min((unsigned)kTile, t_end - base);
+        __syncthreads();
+        // the tail of the last tile is padded with a point 1e18 away (finite distance, beyond every real bound; the
+        // exact path below checks the index as well)
+        for (unsigned i = threadIdx.x; i < kTile; i += kBlock)
+            tile[i] = i < cnt ? targets[base + i] : make_float4(1e18f, 1e18f, 1e18f, 0.0f);
+        __syncthreads();
+        const unsigned ngroups = (cnt + kGroup - 1) / kGroup;
+#pragma unroll 2
+        for (unsigned g = 0; g < ngroups; ++g) {
+            v2f d[kGroup];
+#pragma unroll
+            for (int t = 0; t < kGroup; ++t) {
+                const float4 p = tile[g * kGroup + t];  // same address in every lane: one broadcast LDS read
+                d[t] = pk_dist2(qx, qy, qz, v2f{p.x, p.y}, v2f{p.z, p.w});
+            }
+            const v2f m = __builtin_elementwise_min(__builtin_elementwise_min(d[0], d[1]),
+                                                    __builtin_elementwise_min(d[2], d[3]));
+            if (m[0] < kth[0] || m[1] < kth[1]) {
+#pragma unroll
+                for (int t = 0; t < kGroup; ++t) {
+                    const unsigned j = g * kGroup + t;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (j < cnt && d[t][u] < kth[u]) {
+                            float list_kth;
+                            topk_insert<KCAP>(bd[u], bi[u], k, d[t][u], (int)(base + j), list_kth);
+                            kth[u] = fminf(list_kth, cap[u]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (qid[u] < nq) {
+            const size_t o = ((size_t)split * nq + qid[u]) * (size_t)k;
+#pragma unroll
+            for (int i = 0; i < KCAP; ++i)
+                if (i < k) { d2_out[o + i] = bd[u][i]; idx_out[o + i] = bi[u][i]; }
+        }
+    }
 }
 
 struct BfPlan {
@@ -269,11 +374,65 @@ int run_k1(const float* q, size_t nq, const float* t, size_t nt, int32_t* idx, f
         pidx = static_cast<int32_t*>(ws);
         pd2 = reinterpret_cast<float*>(pidx + (size_t)p.nsplit * nq);
     }
-    knn_bf_k1_kernel<<<dim3(p.qblocks, p.nsplit), kBlock, 0, st>>>(reinterpret_cast<const float4*>(q), (unsigned)nq,
+    knn_bf_k1_kernel<false><<<dim3(p.qblocks, p.nsplit), kBlock, 0, st>>>(reinterpret_cast<const float4*>(q), (unsigned)nq,
                                                                    reinterpret_cast<const float4*>(t), (unsigned)nt,
                                                                    p.chunk, pidx, pd2);
     if (p.nsplit > 1)
         knn_bf_merge_kernel<1><<<div_up(nq, kBlock), kBlock, 0, st>>>(pidx, pd2, (unsigned)nq, 1, p.nsplit, idx, d2);
+    return launch_status();
+}
+
+// Plans and workspace of the two-pass path (k > 1). Used when the targets split into at least k chunks of whole LDS tiles.
+struct BoundedPlan {
+    bool use;
+    BfPlan a, b;                                       // pass A = the k = 1 kernel over G chunks; pass B = two queries per lane
+    size_t off_min, off_bound, off_lists, bytes;  // workspace layout
+};
+
+BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
+    BoundedPlan P{};
+    if (k < 2 || nt < (size_t)16 * kTile) return P;
+    P.a.qpt = kQ1;
+    P.a.qblocks = div_up(nq, (size_t)kBlock * kQ1);
+    P.a.chunk = div_up(div_up(nt, (size_t)64), kTile) * kTile;
+    P.a.nsplit = div_up(nt, P.a.chunk);
+    if (P.a.nsplit < k) return P;
+    P.b.qpt = 2;
+    P.b.qblocks = div_up(nq, (size_t)kBlock * 2);
+    unsigned want = div_up((size_t)kNumCU * 4, P.b.qblocks);
+    const unsigned max_split = div_up(nt, kTile);
+    if (want < 1) want = 1;
+    if (want > max_split) want = max_split;
+    P.b.chunk = div_up(div_up(nt, want), kTile) * kTile;
+    P.b.nsplit = div_up(nt, P.b.chunk);
+    P.use = true;
+    P.off_min = 0;
+    P.off_bound = P.off_min + (size_t)P.a.nsplit * nq * 4;
+    P.off_lists = (P.off_bound + nq * 4 + 15) & ~(size_t)15;
+    P.bytes = P.off_lists + (P.b.nsplit > 1 ? (size_t)P.b.nsplit * nq * k * 8 : 0);
+    return P;
+}
+
+template <int KCAP>
+int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t* idx, float* d2, void* ws,
+                const BoundedPlan& P, hipStream_t st) {
+    char* w = static_cast<char*>(ws);
+    float* amin = reinterpret_cast<float*>(w + P.off_min);
+    float* bound = reinterpret_cast<float*>(w + P.off_bound);
+    const float4* q4 = reinterpret_cast<const float4*>(q);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    knn_bf_k1_kernel<true><<<dim3(P.a.qblocks, P.a.nsplit), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, nullptr, amin);
+    knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, P.a.nsplit, bound);
+    int32_t* pidx = idx;
+    float* pd2 = d2;
+    if (P.b.nsplit > 1) {
+        pidx = reinterpret_cast<int32_t*>(w + P.off_lists);
+        pd2 = reinterpret_cast<float*>(pidx + (size_t)P.b.nsplit * nq * k);
+    }
+    knn_bf_bounded_kernel<KCAP><<<dim3(P.b.qblocks, P.b.nsplit), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, (int)k,
+                                                                                  P.b.chunk, bound, pidx, pd2);
+    if (P.b.nsplit > 1)
+        knn_bf_merge_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(pidx, pd2, (unsigned)nq, (int)k, P.b.nsplit, idx, d2);
     return launch_status();
 }
 
@@ -287,6 +446,8 @@ __global__ void fill_empty_kernel(int32_t* idx, float* d2, size_t n) {
 
 extern "C" size_t sp_knn_bruteforce_workspace_bytes(size_t nq, size_t nt, size_t k) {
     if (nq == 0 || nt == 0 || k == 0) return 0;
+    const sp::BoundedPlan bp = sp::plan_bounded(nq, nt, k);
+    if (bp.use) return bp.bytes;
     const sp::BfPlan p = sp::plan(nq, nt, k);
     return p.nsplit > 1 ? (size_t)p.nsplit * nq * k * 8 : 0;
 }
@@ -310,6 +471,16 @@ extern "C" int sp_knn_bruteforce(const float* queries, size_t nq, const float* t
     if (nt == 0) {  // no targets: every slot keeps its initial -1 / FLT_MAX (knn/result.hpp:21-27)
         fill_empty_kernel<<<div_up(nq * k, kBlock), kBlock, 0, st>>>(idx_out, d2_out, nq * k);
         return launch_status();
+    }
+    const BoundedPlan bp = plan_bounded(nq, nt, k);
+    if (bp.use) {
+        if (workspace == nullptr || workspace_bytes < bp.bytes) {
+            sp_set_error("[knn_search_bruteforce] workspace too small (sp_knn_bruteforce_workspace_bytes)");
+            return SP_ERR_INVALID_ARGUMENT;
+        }
+        if (k <= 5) return run_bounded<5>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, bp, st);
+        if (k <= 10) return run_bounded<10>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, bp, st);
+        return run_bounded<20>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, bp, st);
     }
     const BfPlan p = plan(nq, nt, k);
     if (p.nsplit > 1 && (workspace == nullptr || workspace_bytes < (size_t)p.nsplit * nq * k * 8)) {

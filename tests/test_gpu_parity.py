@@ -87,6 +87,45 @@ def test_bruteforce_config2_100k_k1(sp, orc):
     assert (idx >= 0).all() and (idx < 100000).all()
 
 
+@pytest.mark.parametrize("k", [2, 5, 10, 20])
+def test_bruteforce_two_pass_path_matches_oracle_bitwise(sp, orc, k):
+    # >= 16 LDS tiles of targets and at least k chunks: the bound-then-collect path (knn_bruteforce.hip). Every fourth target
+    # is a duplicate of an earlier one (ties across tiles and chunks, lowest index first), the target count is ragged, a
+    # query far outside the cloud and one with a NaN coordinate ride along.
+    g = orc.rng(99)
+    base = g.uniform_points(30001, 10.0)
+    tgt = np.concatenate([base, base[::3][:10000], g.uniform_points(7, 10.0)])
+    qry = np.concatenate([g.uniform_points(1500, 10.0), base[:200], np.float32([[500.0, -300.0, 40.0, 1.0]])])
+    r = sp.knn_search_bruteforce(dev(qry), dev(tgt), k)
+    oi, od = orc.knn_bruteforce(qry, tgt, k)
+    assert np.array_equal(r.indices.cpu().numpy(), oi)
+    assert np.array_equal(r.distances.cpu().numpy(), od)
+    bad = qry[:64].copy()
+    bad[5, 1] = np.nan
+    r = sp.knn_search_bruteforce(dev(bad), dev(tgt), k)
+    oi, od = orc.knn_bruteforce(bad, tgt, k)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+
+
+def test_bruteforce_config2_size_k20(sp, orc):
+    # 100k x 100k at k = 20 (the reference's MAX_K): oracle on a 500-query sample, size-independent properties on all
+    # (ascending distances, distance == distance to the reported index, no index twice).
+    g = orc.rng(4321)
+    tgt = g.uniform_points(100000, 10.0)
+    qry = g.uniform_points(100000, 10.0)
+    r = sp.knn_search_bruteforce(dev(qry), dev(tgt), 20)
+    idx = r.indices.cpu().numpy()
+    d2 = r.distances.cpu().numpy()
+    sel = np.arange(0, 100000, 200)
+    oi, od = orc.knn_bruteforce(qry[sel], tgt, 20)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(d2[sel], od)
+    assert (np.diff(d2, axis=1) >= 0).all() and (idx >= 0).all() and (idx < 100000).all()
+    diff = qry[:, None, :3].astype(np.float64)[::10] - tgt[idx[::10], :3].astype(np.float64)
+    assert np.allclose((diff**2).sum(2), d2[::10], rtol=1e-5)
+    srt = np.sort(idx, axis=1)
+    assert (np.diff(srt, axis=1) > 0).all()
+
+
 # ------------------------------------------------------------------ K2/K3/K4 KD-tree
 @pytest.mark.parametrize("k", [1, 3, 5, 10, 20, 30])
 def test_kdtree_matches_oracle_bitwise(sp, orc, k):
