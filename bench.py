@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: build the clouds of an N-rank run (N x --points, config 5 density) and time "
                          "rank 0's tile against the full target, without the collective")
+    ap.add_argument("--internal", action="append", default=[], metavar="NAME=VALUE",
+                    help="measurement only: a per-handle switch of csrc/sp_internal.h on the prepared source, e.g. reuse=0 "
+                         "(every launch searches every point); such a line is not a benchmark result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline workload")
     return ap.parse_args()
@@ -157,6 +160,9 @@ def main():
     params = sp.RegistrationParams(reg_type=REG_TYPE, optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
                                    criteria_translation=0.0, criteria_rotation=0.0)
     reg = sp.Registration(params)
+    for kv in args.internal:
+        name, value = kv.split("=")
+        reg._set_source_option(name, int(value))
     T_dev = torch.zeros(16, dtype=torch.float32, device=dev)
     T_ident = torch.eye(4, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     delta = torch.zeros(8, dtype=torch.float32, device=dev)

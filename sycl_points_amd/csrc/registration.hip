@@ -839,19 +839,29 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         }
         if (!hit) {
             ++searched;
+#if defined(SP_EXP) && (SP_EXP & 4)   // measurement build: first stage only, exact or not
+            grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+#else
             nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+#endif
             if (row) {
                 float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;  // nothing found: radius 0, searched again next time
                 if (nn.idx >= 0) {
+#if defined(SP_EXP) && (SP_EXP & 2)   // measurement build: no gather of the winner's prepared row
+                    c0 = make_float4(1.0f, 0.0f, 0.0f, 1.0f); c1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+#else
                     c0 = P.tcovp[2 * (size_t)nn.pos];
                     c1 = P.tcovp[2 * (size_t)nn.pos + 1];
+#endif
                     Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
                     have_ct = true;
                     c1.w = __uint_as_float(nn.pos);
                 }
+#if !(defined(SP_EXP) && (SP_EXP & 1))  // measurement build: no refresh of the cache row
                 row[0] = make_float4(nn.x, nn.y, nn.z, __int_as_float(nn.idx));
                 row[1] = c0;
                 row[2] = c1;
+#endif
             }
         }
     }
