@@ -199,6 +199,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- N > 1: the exchange is checked BEFORE anything is timed. One eager alignment must land on the ground truth on every
+    # rank; if the library's own RCCL communicator does not deliver that (it cannot be rehearsed with more than one rank on
+    # the one-GPU test box), the row travels through torch.distributed instead and the line says so.
+    exchange_fallback = None
+    if group is not None and world > 1 and args.path == "fused":
+        def exchange_ok():
+            T_dev.copy_(T_ident)
+            reg.align_fused_loop(S, prep, iterations=ITERS_PER_ALIGN, group=group, T_dev=T_dev, delta_dev=delta, prepare=True,
+                                 sort_by_cell=SORT_MODE, graph=False, comm=comm, exchange=exchange)
+            torch.cuda.synchronize()
+            err = np.abs(reg.T_from_device(T_dev) - T_gt).max()
+            ok = torch.tensor([1.0 if (np.isfinite(err) and err < 1e-3) else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            return ok.item() > 0.5, float(err)
+        good, err = exchange_ok()
+        if not good and comm is not None:
+            exchange_fallback = f"sp_comm exchange gave pose error {err:.3g} on an eager alignment; using torch.distributed"
+            comm = None
+            good, err = exchange_ok()
+        if not good:
+            raise RuntimeError(f"sharded alignment does not reach the ground truth (max abs pose error {err:.3g})")
+        if rank == 0 and exchange_fallback:
+            print("bench: " + exchange_fallback, file=sys.stderr, flush=True)
+
     if use_graph:
         # set-up, like building the grid: capture the hipGraph of every chunk length the warm-up and the timed region
         # will use (first call of a shape runs eagerly, the second is captured), so no capture falls into the timed region
@@ -287,6 +311,7 @@ def main():
                                     ("128-byte fan-in row per iteration, " if exchange == "row" else "32 KB of partial rows per iteration, ") +
                                     ("sp_gicp_align_sharded over the library's RCCL communicator" if comm is not None
                                      else "torch.distributed all-reduce")),
+                       "exchange_fallback": exchange_fallback,
                        "launch": ("one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
                                   else ("per-iteration launches + all-reduce from the host" if group is not None
                                         else "one C call per alignment"))},
