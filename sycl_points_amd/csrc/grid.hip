@@ -23,6 +23,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "grid_device.h"
+#include "radix_sort.h"
 
 void sp_set_error(const char* msg);
 
@@ -1050,7 +1051,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     size_t tmp_bytes = 0;
     unsigned end_bit = 1;
     while ((1ull << end_bit) <= g->ncells && end_bit < 32) ++end_bit;
-    (void)rocprim::radix_sort_pairs<OnesweepSort>(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
+    tmp_bytes = radix_sort_u32_workspace_bytes(n);  // radix_sort.hip
     e = b_kin.get(n * 4);
     if (e == hipSuccess) e = b_kout.get(n * 4);
     if (e == hipSuccess) e = b_vin.get(n * 4);
@@ -1076,7 +1077,10 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
         GridDesc gd{g->inv_h, g->h, g->eps, g->org[0], g->org[1], g->org[2], g->dims[0], g->dims[1], g->dims[2],
                     (unsigned)n};
         cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in);
-        e = rocprim::radix_sort_pairs<OnesweepSort>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
+        bool in_b = false;
+        if (radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, n, end_bit, tmp, tmp_bytes, &in_b, st) != SP_OK)
+            e = hipErrorUnknown;
+        if (!in_b) { keys_out = keys_in; vals_out = vals_in; }  // the passes ping-pong: the sorted pairs are where the last one wrote
     }
     if (e == hipSuccess) {
         gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);

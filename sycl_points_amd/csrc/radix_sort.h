@@ -1,0 +1,14 @@
+// Stable LSD radix sort of (u32 key, u32 value) pairs on the low `bits` bits of the key (radix_sort.hip). Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace sp {
+size_t radix_sort_u32_workspace_bytes(size_t n);
+// Sorts in ceil(bits / 8) passes that ping-pong between the (a) and (b) buffers; both are overwritten. *result_in_b tells
+// where the sorted pairs are. Only enqueues on `st`. Keys must be < 2^bits where bits < 32 (higher bits are ignored).
+int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
+                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st);
+}  // namespace sp

@@ -1,0 +1,231 @@
+// Stable LSD radix sort of (u32 key, u32 value) pairs for gfx950 — the sort behind the voxel keys (voxel.hip), the cell
+// ids of the grid build (grid.hip) and the per-alignment cell order of an unsorted source (registration.hip).
+//
+// Why not the library sort: at the sizes of this path (1 M pairs, 22-24 key bits) rocPRIM's Onesweep spends 27 us per
+// 8-bit pass plus a histogram kernel and five buffer fills — 110-125 us per sort (profiles/r01_l_kernel_stats_bench_stages.csv)
+// for 16 MB of traffic per pass. Here a pass is three small launches and no fill:
+//   rs_count_kernel    per tile of 2048 keys: digit histogram in LDS -> tile_hist[digit][tile]
+//   rs_scan_kernel     one workgroup per digit: the exclusive scan over the tiles of its row, and the row's total
+//   rs_scatter_kernel  per tile: every key gets its stable rank among the tile's keys of the same digit (wave match-any by
+//                      eight ballots, per-wave counters in LDS, wave order = memory order), the tile is reordered by digit in
+//                      LDS, and runs of equal digit leave as contiguous, coalesced stores
+// No spinning, no cross-workgroup ordering inside a launch (nothing can hang), deterministic, stable.
+#include "radix_sort.h"
+
+#include "sp_common.h"
+#include "sp_internal.h"
+
+namespace sp {
+namespace {
+
+constexpr int kRsThreads = 512;             // 8 waves
+constexpr int kRsWaves = kRsThreads / 64;
+constexpr int kRsItems = 4;                 // keys per lane (tile = 2048 keys: two workgroups per CU at 1 M keys)
+constexpr int kRsTile = kRsThreads * kRsItems;
+constexpr int kRsBins = 256;                // 8-bit digits
+constexpr int kRsScanThreads = 256;
+
+// tile_hist is stored [digit][tile]: the scan over the tiles of a digit reads one contiguous row.
+__global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const uint32_t* __restrict__ keys, unsigned n, unsigned shift,
+                                                              unsigned mask, unsigned tiles, unsigned* __restrict__ tile_hist) {
+    __shared__ unsigned h[kRsWaves][kRsBins];  // one histogram per wave: eight times less contention on a popular digit
+    for (unsigned i = threadIdx.x; i < kRsWaves * kRsBins; i += kRsThreads) (&h[0][0])[i] = 0u;
+    __syncthreads();
+    const unsigned base = blockIdx.x * kRsTile, w = threadIdx.x >> 6;
+    uint32_t k[kRsItems];
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        const unsigned e = base + c * kRsThreads + threadIdx.x;
+        k[c] = e < n ? keys[e] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        const unsigned e = base + c * kRsThreads + threadIdx.x;
+        const bool valid = e < n;
+        const unsigned d = (k[c] >> shift) & mask;
+        const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+        const unsigned long long vm = __ballot(valid);
+        if (__ballot(valid && d != d0) == 0ull) {  // the high digits of a compact key range: the whole wave agrees
+            if ((threadIdx.x & 63u) == 0u && vm) h[w][d0] += (unsigned)__builtin_popcountll(vm);
+        } else if (valid) {
+            atomicAdd(&h[w][d], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kRsBins) {
+        unsigned v = 0;
+#pragma unroll
+        for (int i = 0; i < kRsWaves; ++i) v += h[i][threadIdx.x];
+        tile_hist[(size_t)threadIdx.x * tiles + blockIdx.x] = v;
+    }
+}
+
+// Exclusive scan of one value per lane over a workgroup of NW waves (wave scan by shuffles + the wave totals in LDS);
+// *total_out = the sum over the workgroup.
+template <int NW>
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* wave_tot /* [NW] */, unsigned* total_out) {
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off, 64);
+        if ((int)lane >= off) inc += o;
+    }
+    if (lane == 63u) wave_tot[w] = inc;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const unsigned t = wave_tot[i];
+        before += (unsigned)i < w ? t : 0u;
+        all += t;
+    }
+    __syncthreads();
+    if (total_out) *total_out = all;
+    return before + inc - v;
+}
+
+// One workgroup per digit: the exclusive scan over the tiles of the digit's row, and the row's total (the scatter kernel
+// turns the 256 totals into the digits' starting positions itself: no global atomics, nothing to clear between passes).
+__global__ __launch_bounds__(kRsScanThreads) void rs_scan_kernel(unsigned* __restrict__ tile_hist, unsigned tiles,
+                                                                 unsigned* __restrict__ digit_total) {
+    __shared__ unsigned wave_tot[kRsScanThreads / 64];
+    const unsigned d = blockIdx.x;
+    unsigned carry = 0;
+    unsigned* const row = tile_hist + (size_t)d * tiles;
+    for (unsigned t0 = 0; t0 < tiles; t0 += kRsScanThreads) {
+        const unsigned t = t0 + threadIdx.x;
+        const unsigned c = t < tiles ? row[t] : 0u;
+        unsigned chunk;
+        const unsigned ex = block_excl_scan<kRsScanThreads / 64>(c, wave_tot, &chunk);
+        if (t < tiles) row[t] = carry + ex;
+        carry += chunk;
+    }
+    if (threadIdx.x == 0) digit_total[d] = carry;
+}
+
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
+                                                                const uint32_t* __restrict__ vin,
+                                                                uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                                unsigned n, unsigned shift, unsigned mask, unsigned tiles,
+                                                                const unsigned* __restrict__ tile_off,
+                                                                const unsigned* __restrict__ digit_total) {
+    __shared__ unsigned cnt[kRsWaves][kRsBins];  // per wave: keys of each digit seen so far -> then the wave's offset in the digit
+    __shared__ unsigned tstart[kRsBins];         // tile-local position of the digit's first key
+    __shared__ unsigned dbase[kRsBins];          // global position of the digit's first key of this tile
+    __shared__ unsigned wave_tot[kRsWaves];
+    __shared__ uint32_t lk[kRsTile], lv[kRsTile];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const unsigned base = blockIdx.x * kRsTile;
+    const unsigned m = min((unsigned)kRsTile, n - base);
+    for (unsigned i = tid; i < kRsWaves * kRsBins; i += kRsThreads) (&cnt[0][0])[i] = 0u;
+    {   // where this tile's first key of digit `tid` goes: the keys of smaller digits + the same digit in earlier tiles
+        const unsigned before = block_excl_scan<kRsWaves>(tid < kRsBins ? digit_total[tid] : 0u, wave_tot, nullptr);
+        if (tid < kRsBins) dbase[tid] = before + tile_off[(size_t)tid * tiles + blockIdx.x];
+    }
+    __syncthreads();
+    // wave w owns the keys [w * 512, (w + 1) * 512) of the tile, 64 at a time: memory order = (wave, chunk, lane)
+    uint32_t k[kRsItems], v[kRsItems];
+    unsigned rank[kRsItems];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    volatile unsigned* const my_cnt = cnt[w];
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        const unsigned e = w * (kRsTile / kRsWaves) + c * 64 + lane;
+        k[c] = e < m ? kin[base + e] : 0u;
+        v[c] = e < m ? vin[base + e] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        const unsigned e = w * (kRsTile / kRsWaves) + c * 64 + lane;
+        const bool valid = e < m;
+        const unsigned d = (k[c] >> shift) & mask;
+        unsigned long long peers = __ballot(valid);  // lanes of this chunk holding the same digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long mm = __ballot(bit);
+            peers &= bit ? mm : ~mm;
+        }
+        const unsigned old = my_cnt[d];  // read by every lane BEFORE the digit's first lane bumps it (LDS ops of a wave are in order)
+        const unsigned lower = (unsigned)__builtin_popcountll(peers & lt);
+        rank[c] = old + lower;
+        if (valid && lower == 0u) my_cnt[d] = old + (unsigned)__builtin_popcountll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {   // digit tid: totals of the waves -> each wave's offset inside the digit, and the digit's place in the tile
+        unsigned tot = 0;
+        if (tid < kRsBins) {
+#pragma unroll
+            for (int i = 0; i < kRsWaves; ++i) { const unsigned c = cnt[i][tid]; cnt[i][tid] = tot; tot += c; }
+        }
+        const unsigned ex = block_excl_scan<kRsWaves>(tot, wave_tot, nullptr);  // (lanes >= 256 contribute 0; two barriers inside)
+        if (tid < kRsBins) tstart[tid] = ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        const unsigned e = w * (kRsTile / kRsWaves) + c * 64 + lane;
+        if (e < m) {
+            const unsigned d = (k[c] >> shift) & mask;
+            const unsigned pos = tstart[d] + cnt[w][d] + rank[c];
+            lk[pos] = k[c];
+            lv[pos] = v[c];
+        }
+    }
+    __syncthreads();
+    for (unsigned j = tid; j < m; j += kRsThreads) {
+        const uint32_t kk = lk[j];
+        const unsigned d = (kk >> shift) & mask;
+        const unsigned dst = dbase[d] + (j - tstart[d]);
+        kout[dst] = kk;
+        vout[dst] = lv[j];
+    }
+}
+
+}  // namespace
+
+// tile histograms [256][tiles] + the 256 digit totals
+size_t radix_sort_u32_workspace_bytes(size_t n) {
+    return ((size_t)div_up(n ? n : 1, (size_t)kRsTile) * kRsBins + kRsBins) * sizeof(unsigned);
+}
+
+int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
+                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st) {
+    *result_in_b = false;
+    if (n == 0 || bits == 0) return SP_OK;
+    if (n >= (1ull << 32) - kRsTile || bits > 32 || !workspace || workspace_bytes < radix_sort_u32_workspace_bytes(n))
+        return SP_ERR_INVALID_ARGUMENT;
+    const unsigned tiles = div_up(n, (size_t)kRsTile);
+    unsigned* const tile_hist = static_cast<unsigned*>(workspace);
+    unsigned* const digit_total = tile_hist + (size_t)tiles * kRsBins;
+    uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+    bool in_b = false;
+    for (unsigned shift = 0; shift < bits; shift += 8) {
+        const unsigned width = bits - shift < 8 ? bits - shift : 8;
+        const unsigned mask = (1u << width) - 1u;
+        rs_count_kernel<<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+        rs_scan_kernel<<<kRsBins, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
+        rs_scatter_kernel<<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
+                                                        digit_total);
+        uint32_t* t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+        in_b = !in_b;
+    }
+    *result_in_b = in_b;
+    return launch_status();
+}
+
+}  // namespace sp
+
+extern "C" size_t sp_internal_radix_sort_workspace_bytes(size_t n) { return sp::radix_sort_u32_workspace_bytes(n); }
+extern "C" int sp_internal_radix_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n,
+                                          unsigned bits, void* workspace, size_t workspace_bytes, int* result_in_b_out,
+                                          void* stream) {
+    bool in_b = false;
+    const int rc = sp::radix_sort_pairs_u32(keys_a, keys_b, vals_a, vals_b, n, bits, workspace, workspace_bytes, &in_b,
+                                            sp::as_stream(stream));
+    if (result_in_b_out) *result_in_b_out = in_b ? 1 : 0;
+    return rc;
+}

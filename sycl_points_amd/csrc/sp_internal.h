@@ -34,6 +34,12 @@ int sp_internal_grid_option(sp_grid* grid, int option, int value);
 /* Device pointer to the per-launch log of an sp_gicp_align_* workspace: entry k = number of source points launch k had to
  * search for (the others reused their previous correspondence by certificate). *n_entries_out = entries kept (64). */
 const uint32_t* sp_internal_align_searched_log(void* workspace, size_t* n_entries_out);
+/* The library's own stable radix sort of (u32 key, u32 value) pairs on the low `bits` key bits (csrc/radix_sort.hip), for its
+ * test: all pointers are device pointers, the four arrays are overwritten, *result_in_b_out (host) says which pair holds
+ * the sorted data. workspace: sp_internal_radix_sort_workspace_bytes(n). */
+size_t sp_internal_radix_sort_workspace_bytes(size_t n);
+int sp_internal_radix_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n,
+                               unsigned bits, void* workspace, size_t workspace_bytes, int* result_in_b_out, void* stream);
 
 #ifdef __cplusplus
 }

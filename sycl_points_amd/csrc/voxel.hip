@@ -14,6 +14,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include "radix_sort.h"
 #include "sp_common.h"
 #include "sp_math.h"
 
@@ -231,6 +232,7 @@ VoxelWs voxel_ws(size_t n) {
     (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n,
                                   rocprim::plus<uint32_t>(), (hipStream_t)0);
     w.prim_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    if (radix_sort_u32_workspace_bytes(n) > w.prim_bytes) w.prim_bytes = radix_sort_u32_workspace_bytes(n);
     w.prim = take(w.prim_bytes);
     w.total = o;
     return w;
@@ -352,9 +354,12 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
         key32_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, status_dev);
         unsigned end_bit = 1;
         while ((1ull << end_bit) <= (uint64_t)kb.invalid && end_bit < 32) ++end_bit;  // `invalid` itself must be representable
-        e = rocprim::radix_sort_pairs<OnesweepSort>(base + w.prim, prim_bytes, k_in, k_sorted, vals_in, vals_sorted, n, 0,
-                                                    end_bit, st);
-        if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+        bool in_b = false;  // the hand-written sort (radix_sort.hip) ping-pongs between the two buffer pairs
+        if (radix_sort_pairs_u32(k_in, k_sorted, vals_in, vals_sorted, n, end_bit, base + w.prim, w.prim_bytes, &in_b, st) != SP_OK) {
+            sp_set_error("[VoxelGrid::downsampling] radix sort failed");
+            return SP_ERR_HIP;
+        }
+        if (!in_b) { uint32_t* t = k_in; k_in = k_sorted; k_sorted = t; t = vals_in; vals_in = vals_sorted; vals_sorted = t; }
         aggregate_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(k_sorted, kb.invalid, vals_sorted, (unsigned)n, pts,
                                                                          (float)min_voxel_count, a, t_pts, flag);
         prim_bytes = w.prim_bytes;
