@@ -11,7 +11,7 @@
 // bit-identical to knn_search_bruteforce (bruteforce.hpp:24-96) for every input. (The KD-tree breaks exact ties by
 // visiting order instead; on tie-free data all three agree bit for bit.)
 //
-// Build (all on the device, deterministic): bounding box -> cell id per point -> radix sort (cell, index) ->
+// Build (all on the device, deterministic): bounding box -> cell id per point -> radix sort (cell, index; radix_sort.hip) ->
 // gather points into cell order as float4 {x,y,z,index-bits} -> cell_start[] by binary search.
 // Search: one query per lane, rings of cells around the query's cell; a row / cell is skipped when its box lies
 // farther than the current k-th distance; the search stops when the k-th distance is inside the scanned block.
@@ -19,7 +19,6 @@
 // neighbour.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "grid_device.h"
@@ -29,9 +28,8 @@ void sp_set_error(const char* msg);
 
 #include "sp_internal.h"
 
-// rocPRIM picks a merge sort (about 15 launches, 155 us per 1M pairs) up to 1M items; Onesweep with the key bits
-// actually used (3 passes for a 22-bit cell id) is 3x faster at this size.
-using OnesweepSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+// The (cell id, index) pairs are sorted by radix_sort.hip (3 passes for a 22-bit cell id: 63 us per 1M pairs; the library's
+// Onesweep took 110-125 us at this size, its merge sort 155 us).
 
 namespace sp {
 namespace {

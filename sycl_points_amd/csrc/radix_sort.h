@@ -7,8 +7,9 @@
 
 namespace sp {
 size_t radix_sort_u32_workspace_bytes(size_t n);
-// Sorts in ceil(bits / 8) passes that ping-pong between the (a) and (b) buffers; both are overwritten. *result_in_b tells
-// where the sorted pairs are. Only enqueues on `st`. Keys must be < 2^bits where bits < 32 (higher bits are ignored).
+// Sorts by the key bits [first_bit, bits) in ceil((bits - first_bit) / 8) passes that ping-pong between the (a) and (b)
+// buffers; both are overwritten. *result_in_b tells where the sorted pairs are. Only enqueues on `st`. Key bits at and above
+// `bits` are ignored, as are those below `first_bit` (a stable sort by the remaining ones).
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
-                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st);
+                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st, unsigned first_bit = 0);
 }  // namespace sp

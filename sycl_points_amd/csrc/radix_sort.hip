@@ -192,9 +192,9 @@ size_t radix_sort_u32_workspace_bytes(size_t n) {
 }
 
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
-                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st) {
+                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st, unsigned first_bit) {
     *result_in_b = false;
-    if (n == 0 || bits == 0) return SP_OK;
+    if (n == 0 || bits <= first_bit) return SP_OK;
     if (n >= (1ull << 32) - kRsTile || bits > 32 || !workspace || workspace_bytes < radix_sort_u32_workspace_bytes(n))
         return SP_ERR_INVALID_ARGUMENT;
     const unsigned tiles = div_up(n, (size_t)kRsTile);
@@ -202,7 +202,7 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
     unsigned* const digit_total = tile_hist + (size_t)tiles * kRsBins;
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
     bool in_b = false;
-    for (unsigned shift = 0; shift < bits; shift += 8) {
+    for (unsigned shift = first_bit; shift < bits; shift += 8) {
         const unsigned width = bits - shift < 8 ? bits - shift : 8;
         const unsigned mask = (1u << width) - 1u;
         rs_count_kernel<<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);

@@ -11,6 +11,7 @@
 // The factor arithmetic keeps the reference's fma chains (sp_math.h); structural zeros of the padded 4x4/4x6 types
 // are skipped, which leaves every finite result bit-identical.
 #include "grid_device.h"
+#include "radix_sort.h"
 
 void sp_set_error(const char* msg);
 
@@ -1358,11 +1359,6 @@ extern "C" int sp_gn_update_host(const sp_linearized* lin_host, float* T_host, f
 }
 
 // ------------------------------------------------------------------ prepared / fused path (C ABI)
-#include <rocprim/device/device_radix_sort.hpp>
-// rocPRIM picks a merge sort (about 15 launches, 155 us per 1M pairs) up to 1M items; Onesweep with the key bits
-// actually used (3 passes for a 22-bit cell id) is 3x faster at this size.
-using OnesweepSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-
 
 struct sp_gicp_target {
     const sp_grid* grid = nullptr;  // borrowed: must outlive this object
@@ -1503,8 +1499,7 @@ extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     sp_gicp_source* s = new sp_gicp_source();
     s->n_max = n_max;
     const size_t n = n_max ? n_max : 1;
-    (void)rocprim::radix_sort_pairs<OnesweepSort>(nullptr, s->sort_tmp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
-                                    (unsigned*)nullptr, n, 0, 32, (hipStream_t)0);
+    s->sort_tmp_bytes = radix_sort_u32_workspace_bytes(n);  // radix_sort.hip
     hipError_t e = hipMalloc(&s->pts, (n + 64) * sizeof(float4));  // planes, each padded to a multiple of 64 floats
     if (e == hipSuccess) e = hipMalloc(&s->covp, (n + 64) * 2 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->perm, n * 4);
@@ -1551,14 +1546,17 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
                                                  s->vals_in);
         unsigned end_bit = 1;
         while ((1ull << end_bit) <= target->grid->ncells && end_bit < 32) ++end_bit;
-        size_t tmp = s->sort_tmp_bytes;
         // Only locality matters, not a total order: the top 16 key bits put every run of 32 consecutive cells of an
-        // x-row (one 128-byte line of cell extents, ~16 points) together — two Onesweep passes instead of three.
+        // x-row (one 128-byte line of cell extents, ~16 points) together — two radix passes instead of three.
         // The sort is stable, so the order is deterministic.
         const unsigned begin_bit = end_bit > 16 ? end_bit - 16 : 0;
-        const hipError_t e = rocprim::radix_sort_pairs<OnesweepSort>(s->sort_tmp, tmp, s->keys_in, s->keys_out,
-                                                                     s->vals_in, s->perm, n, begin_bit, end_bit, st);
-        if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+        bool in_b = false;
+        if (radix_sort_pairs_u32(s->keys_in, s->keys_out, s->vals_in, s->perm, n, end_bit, s->sort_tmp, s->sort_tmp_bytes, &in_b,
+                                 st, begin_bit) != SP_OK) {
+            sp_set_error("[Registration] radix sort of the source failed");
+            return SP_ERR_HIP;
+        }
+        if (!in_b) { unsigned* t = s->perm; s->perm = s->vals_in; s->vals_in = t; }  // the sorted permutation is where the last pass wrote
     } else {
         iota_kernel<<<nb, kBlock, 0, st>>>(s->perm, (unsigned)n);
     }

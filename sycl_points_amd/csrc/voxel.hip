@@ -152,10 +152,10 @@ template <typename KEY>
 __global__ __launch_bounds__(kBlock) void aggregate_kernel(const KEY* __restrict__ sk, KEY invalid,
                                                            const uint32_t* __restrict__ sv, unsigned n,
                                                            const float4* __restrict__ pts, float min_count, AggPtrs a,
-                                                           float4* __restrict__ t_pts, uint32_t* __restrict__ flag) {
+                                                           float4* __restrict__ t_pts, uint32_t* __restrict__ flag,
+                                                           uint32_t* __restrict__ block_keep) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const KEY key = sk[i];
+    const KEY key = i < n ? sk[i] : invalid;
     const bool head = key != invalid && (i == 0 || sk[i - 1] != key);
     uint32_t keep = 0;
     if (head) {
@@ -182,20 +182,60 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const KEY* __restrict
             }
         }
     }
-    flag[i] = keep;
+    if (i < n) flag[i] = keep;
+    // voxels kept by this workgroup: the compaction needs no scan over the n flags, only over the workgroups' counts
+    const int kept = __syncthreads_count((int)keep);
+    if (threadIdx.x == 0) block_keep[blockIdx.x] = (uint32_t)kept;
 }
+
+// Exclusive scan of the workgroups' kept-voxel counts, in place (one workgroup; a few thousand values), and the total.
+__global__ __launch_bounds__(1024) void block_offsets_kernel(uint32_t* __restrict__ block_keep, unsigned nblocks,
+                                                             uint32_t* __restrict__ n_out) {
+    __shared__ unsigned wave_tot[16];
+    __shared__ unsigned s_carry;
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (unsigned b0 = 0; b0 < nblocks; b0 += 1024) {
+        const unsigned b = b0 + threadIdx.x;
+        const unsigned v = b < nblocks ? block_keep[b] : 0u;
+        unsigned inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off, 64);
+            if ((int)lane >= off) inc += o;
+        }
+        if (lane == 63u) wave_tot[w] = inc;
+        __syncthreads();
+        unsigned before = s_carry, all = 0;
+        for (unsigned i = 0; i < 16; ++i) { const unsigned t = wave_tot[i]; before += i < w ? t : 0u; all += t; }
+        if (b < nblocks) block_keep[b] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = s_carry;
+}
+
 
 template <typename KEY>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restrict__ flag,
-                                                         const uint32_t* __restrict__ pos, unsigned n,
+                                                         const uint32_t* __restrict__ block_off, unsigned n,
                                                          const KEY* __restrict__ sk, KeyBox box,
                                                          const float4* __restrict__ t_pts, AggPtrs a,
                                                          float4* __restrict__ o_pts, float4* __restrict__ o_rgb,
                                                          float* __restrict__ o_inten, float* __restrict__ o_ts,
-                                                         uint64_t* __restrict__ o_keys, uint32_t* __restrict__ n_out) {
+                                                         uint64_t* __restrict__ o_keys) {
+    __shared__ unsigned wave_kept[kBlock / 64];
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t f = flag[i], p = pos[i];
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t f = i < n ? flag[i] : 0u;
+    // position = kept voxels of the earlier workgroups + of the earlier waves of this one + of the earlier lanes of this wave
+    const unsigned long long m = __ballot(f != 0u);
+    if (lane == 0u) wave_kept[w] = (unsigned)__builtin_popcountll(m);
+    __syncthreads();
+    unsigned p = block_off[blockIdx.x] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    for (unsigned j = 0; j < w; ++j) p += wave_kept[j];
     if (f) {
         o_pts[p] = t_pts[i];
         if (a.rgb) o_rgb[p] = a.t_rgb[i];
@@ -203,7 +243,6 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restr
         if (a.ts) o_ts[p] = a.t_ts[i];
         if (o_keys) o_keys[p] = sizeof(KEY) == 8 ? (uint64_t)sk[i] : expand_key((uint32_t)sk[i], box);
     }
-    if (i == n - 1) *n_out = p + f;
 }
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -361,13 +400,11 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
         }
         if (!in_b) { uint32_t* t = k_in; k_in = k_sorted; k_sorted = t; t = vals_in; vals_in = vals_sorted; vals_sorted = t; }
         aggregate_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(k_sorted, kb.invalid, vals_sorted, (unsigned)n, pts,
-                                                                         (float)min_voxel_count, a, t_pts, flag);
-        prim_bytes = w.prim_bytes;
-        e = rocprim::exclusive_scan(base + w.prim, prim_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st);
-        if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+                                                                         (float)min_voxel_count, a, t_pts, flag, pos);
+        block_offsets_kernel<<<1, 1024, 0, st>>>(pos, div_up(n, kBlock), n_out_dev);
         scatter_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(
             flag, pos, (unsigned)n, k_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
-            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt);
         return launch_status();
     }
     uint64_t* keys_in = (uint64_t*)(base + w.keys_in);
@@ -376,13 +413,11 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
     e = rocprim::radix_sort_pairs(base + w.prim, prim_bytes, keys_in, keys_sorted, vals_in, vals_sorted, n, 0, 64, st);
     if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
     aggregate_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(keys_sorted, kInvalidKey, vals_sorted, (unsigned)n, pts,
-                                                                     (float)min_voxel_count, a, t_pts, flag);
-    prim_bytes = w.prim_bytes;
-    e = rocprim::exclusive_scan(base + w.prim, prim_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st);
-    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+                                                                     (float)min_voxel_count, a, t_pts, flag, pos);
+    block_offsets_kernel<<<1, 1024, 0, st>>>(pos, div_up(n, kBlock), n_out_dev);
     scatter_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(
         flag, pos, (unsigned)n, keys_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
-        reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+        reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt);
     return launch_status();
 }
 }  // namespace
