@@ -105,18 +105,32 @@ __global__ __launch_bounds__(kBlock) void gather_sorted_kernel(const float4* __r
     p.w = __uint_as_float(src);
     out[i] = p;
 }
-// start[c] = first sorted position whose key >= c  (c in [0, ncells]); keys ascending
+// start[c] = first sorted position whose key >= c  (c in [0, ncells]); keys ascending.
+// One lane per sorted position i in [0, n]: the cells in (key[i-1], key[i]] all start at i (position n closes the table up to
+// ncells). Gaps of a few cells — the usual case — are written by the lane itself; a long gap (empty space between surfaces)
+// is written by its whole wave, 64 cells per step. Coalesced key reads, near-coalesced table writes: 8 us per 1M points at
+// 0.5 points per cell, against 28 us for a binary search per cell.
 __global__ __launch_bounds__(kBlock) void cell_start_kernel(const unsigned* __restrict__ keys, unsigned n,
                                                             unsigned ncells, unsigned* __restrict__ start) {
-    const unsigned c = blockIdx.x * kBlock + threadIdx.x;
-    if (c > ncells) return;
-    unsigned lo = 0, hi = n;
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (keys[mid] < c) lo = mid + 1;
-        else hi = mid;
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned lane = threadIdx.x & (kWave - 1);
+    unsigned lo = 0, hi = 0;  // cells [lo, hi) start at position i
+    if (i <= n) {
+        lo = i == 0 ? 0u : min(keys[i - 1], ncells) + 1u;
+        hi = (i == n ? ncells : min(keys[i], ncells)) + 1u;
+        if (lo > hi) lo = hi;
     }
-    start[c] = lo;
+    const unsigned len = hi - lo;
+    if (len <= 8u)
+        for (unsigned c = lo; c < hi; ++c) start[c] = i;
+    unsigned long long m = __ballot(len > 8u);
+    while (m) {
+        const int L = __builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)lo, L), bhi = (unsigned)__builtin_amdgcn_readlane((int)hi, L);
+        const unsigned bi = (unsigned)__builtin_amdgcn_readlane((int)i, L);
+        for (unsigned c = blo + lane; c < bhi; c += kWave) start[c] = bi;
+    }
 }
 
 template <int KCAP>
@@ -218,12 +232,13 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
 // tests all of them with wave-uniform (broadcast) LDS reads — a brute force over a small local tile, with no
 // per-lane pointer chasing and no divergence except in the sorted insertion. A query whose k-th distance reaches
 // outside the scanned block (sparse regions) is appended to a to-do list and finished by the ring walk.
+// The work units of every x-row (ceil(points in the row / 64); entry `rows` = 0, so the scan that follows needs no memset).
+// (A hand-written single-workgroup scan of these ~16 k values took 16-45 us in three forms against 7.6 us for the library's.)
 __global__ void row_units_kernel(const unsigned* __restrict__ start, unsigned nx, unsigned rows,
                                  unsigned* __restrict__ units) {
     const unsigned r = blockIdx.x * kBlock + threadIdx.x;
-    if (r < rows) units[r] = (start[(size_t)(r + 1) * nx] - start[(size_t)r * nx] + 63u) / 64u;
+    if (r <= rows) units[r] = r < rows ? (start[(size_t)(r + 1) * nx] - start[(size_t)r * nx] + 63u) / 64u : 0u;
 }
-
 struct TileOut {
     int32_t* knn_idx;  // [n][k] original order (may be null)
     float* knn_d2;
@@ -1045,7 +1060,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
 
     // 3. sort points by cell id, gather, cell_start (temporaries from the scratch pool: idle again when this returns)
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;
-    ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp, b_units, b_stmp;
+    ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp;
     size_t tmp_bytes = 0;
     unsigned end_bit = 1;
     while ((1ull << end_bit) <= g->ncells && end_bit < 32) ++end_bit;
@@ -1063,6 +1078,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     unsigned* units = nullptr;
     void* stmp = nullptr;
     size_t stmp_bytes = 0;
+    ScratchBuf b_units, b_stmp;
     if (e == hipSuccess) {
         (void)rocprim::exclusive_scan(nullptr, stmp_bytes, units, units, 0u, rows + 1, rocprim::plus<unsigned>(), st);
         e = b_units.get((rows + 1) * 4);
@@ -1082,13 +1098,10 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     }
     if (e == hipSuccess) {
         gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
-        cell_start_kernel<<<div_up(g->ncells + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
+        cell_start_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
                                                                           g->d_start);
         // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed (same stream: no sync between)
-        e = hipMemsetAsync(units, 0, (rows + 1) * 4, st);
-    }
-    if (e == hipSuccess) {
-        row_units_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
+        row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
         e = rocprim::exclusive_scan(stmp, stmp_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
@@ -1177,9 +1190,8 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     unsigned kept = 0;
     e = hipMemcpyAsync(&kept, scan + n, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(g->d_start, new_start, (g->ncells + 1) * 4, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(units, 0, (rows + 1) * 4, st);
     if (e != hipSuccess) return fail(e);
-    row_units_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
+    row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
     e = rocprim::exclusive_scan(b_tmp.p, tmp2_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
