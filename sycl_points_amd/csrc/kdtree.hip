@@ -3,8 +3,8 @@
 //
 // Build: on the host, the reference's rule verbatim in behaviour (kdtree.hpp:62-91, 292-413): split axis = largest
 // range over a <=100-sample sweep, median by std::nth_element on the index array, leaves of <= leaf_threshold
-// points. The topology and the order of points inside a leaf are therefore the reference's; only the storage
-// differs, and is chosen for the GPU:
+// points. The topology and the order of points inside a leaf are therefore the reference's (the subtrees below the top
+// levels are built by several host threads, build_parallel below); only the storage differs, and is chosen for the GPU:
 //   * internal nodes: 32 B {x,y,z, idx | left, right, axis, -}, two 16-byte loads;
 //   * leaf points: float4 {x,y,z, idx-bits} in fixed-stride blocks of `leaf_threshold` slots (pad slots idx=-1),
 //     so a child code names its leaf block directly — no leaf-descriptor load on the dependent chain — and every
@@ -15,7 +15,9 @@
 // lives in LDS ([slot][lane], bank-conflict free); the near "stack" of the reference never holds more than one
 // entry, so it is a register. A point is valid iff idx >= 0 (see sp_kdtree_remove_by_flags in the C ABI header).
 #include <algorithm>
+#include <future>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "sp_common.h"
@@ -65,20 +67,16 @@ uint8_t find_axis_range(const float* pts, const std::vector<uint32_t>& gi, uint3
     return 2;
 }
 
-void build_host(const float* pts, size_t n, size_t leaf_threshold, std::vector<HostInternal>& internal,
-                std::vector<float4>& leaves, int& root) {
-    internal.clear();
-    leaves.clear();
-    root = kNone;
-    if (n == 0) return;
+// One subtree over gi[start .. end] into `internal` / `leaves` (appended; child codes are indices into THESE vectors),
+// iteratively, as the reference's build loop does (kdtree.hpp:292-413). Returns the code of the subtree's root.
+int build_range(const float* pts, std::vector<uint32_t>& gi, uint32_t start, uint32_t end, size_t leaf_threshold,
+                std::vector<HostInternal>& internal, std::vector<float4>& leaves) {
     const size_t stride = leaf_threshold;
-    std::vector<uint32_t> gi(n);
-    std::iota(gi.begin(), gi.end(), 0u);
+    int root = kNone;
     // child slots point into `internal`, which may reallocate: keep (node, side) instead of raw pointers
     struct Ref { int node; int side; uint32_t start, end; };
     std::vector<Ref> stack;
-    stack.push_back({-1, 0, 0u, (uint32_t)(n - 1)});
-    internal.reserve(n / (leaf_threshold / 2 + 1) + 16);
+    stack.push_back({-1, 0, start, end});
     auto set_child = [&](const Ref& r, int code) {
         if (r.node < 0) root = code;
         else if (r.side == 0) internal[r.node].left = code;
@@ -121,6 +119,87 @@ void build_host(const float* pts, size_t n, size_t leaf_threshold, std::vector<H
         if (task.start < median) stack.push_back({id, 0, task.start, median - 1});
         if (median < task.end) stack.push_back({id, 1, median + 1, task.end});
     }
+    return root;
+}
+
+// The reference builds on one host thread, and that build "dominates preprocessing at 1 M points" (139 ms here). The split of
+// a range depends only on the range, so the two halves below a node are independent: the top levels hand their left half
+// to another thread, every subtree is built into its own vectors and spliced behind its parent with its codes shifted.
+// Same nodes, same children, same order of points in every leaf — the topology (and therefore every search result, the
+// first-visited tie rule included) is the single-threaded build's; only the numbering of the nodes differs.
+struct SubTree {
+    std::vector<HostInternal> internal;
+    std::vector<float4> leaves;
+    int root = kNone;
+};
+
+int shifted(int code, int d_internal, int d_leaf) {
+    if (code >= 0) return code + d_internal;
+    if (code <= -2) return code - d_leaf;
+    return code;
+}
+void splice(SubTree& into, SubTree&& from, size_t stride, int* root_code_out) {
+    const int d_internal = (int)into.internal.size(), d_leaf = (int)(into.leaves.size() / stride);
+    for (HostInternal& nd : from.internal) {
+        nd.left = shifted(nd.left, d_internal, d_leaf);
+        nd.right = shifted(nd.right, d_internal, d_leaf);
+    }
+    *root_code_out = shifted(from.root, d_internal, d_leaf);
+    into.internal.insert(into.internal.end(), from.internal.begin(), from.internal.end());
+    into.leaves.insert(into.leaves.end(), from.leaves.begin(), from.leaves.end());
+}
+
+SubTree build_parallel(const float* pts, std::vector<uint32_t>& gi, uint32_t start, uint32_t end, size_t leaf_threshold,
+                       int spawn_levels) {
+    SubTree t;
+    const uint32_t size = end - start + 1;
+    if (spawn_levels <= 0 || size <= leaf_threshold || size < 32768u) {
+        t.root = build_range(pts, gi, start, end, leaf_threshold, t.internal, t.leaves);
+        return t;
+    }
+    const uint8_t axis = find_axis_range(pts, gi, start, end);
+    const uint32_t median = start + size / 2;
+    std::nth_element(gi.begin() + start, gi.begin() + median, gi.begin() + end + 1,
+                     [&](uint32_t a, uint32_t b) { return pts[4 * (size_t)a + axis] < pts[4 * (size_t)b + axis]; });
+    const uint32_t p = gi[median];
+    HostInternal node;
+    node.x = pts[4 * (size_t)p]; node.y = pts[4 * (size_t)p + 1]; node.z = pts[4 * (size_t)p + 2];
+    node.idx = (int32_t)p;
+    node.left = kNone; node.right = kNone;
+    node.axis = axis; node.pad = 0;
+    t.internal.push_back(node);
+    t.root = 0;
+    // size >= 32768 > 2: both halves exist
+    std::future<SubTree> left = std::async(std::launch::async, [&, start, median, spawn_levels] {
+        return build_parallel(pts, gi, start, median - 1, leaf_threshold, spawn_levels - 1);
+    });
+    SubTree right = build_parallel(pts, gi, median + 1, end, leaf_threshold, spawn_levels - 1);
+    SubTree l = left.get();
+    int code;
+    splice(t, std::move(l), leaf_threshold, &code);
+    t.internal[0].left = code;
+    splice(t, std::move(right), leaf_threshold, &code);
+    t.internal[0].right = code;
+    return t;
+}
+
+void build_host(const float* pts, size_t n, size_t leaf_threshold, std::vector<HostInternal>& internal,
+                std::vector<float4>& leaves, int& root) {
+    internal.clear();
+    leaves.clear();
+    root = kNone;
+    if (n == 0) return;
+    std::vector<uint32_t> gi(n);
+    std::iota(gi.begin(), gi.end(), 0u);
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads == 0) threads = 1;
+    if (threads > 16) threads = 16;  // a fair share of a multi-GPU host
+    int levels = 0;
+    while ((1u << levels) < threads) ++levels;  // 2^levels subtrees in flight
+    SubTree t = build_parallel(pts, gi, 0u, (uint32_t)(n - 1), leaf_threshold, levels);
+    internal = std::move(t.internal);
+    leaves = std::move(t.leaves);
+    root = t.root;
 }
 
 // Sorted insertion into the first k slots, strict '<' (kdtree.hpp:119-137): the first visited wins ties.
