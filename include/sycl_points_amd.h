@@ -287,7 +287,11 @@ int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn
  *                           The order only changes which lane handles which point, never a result.
  *   sp_gicp_iteration_fused: per source point q = T p -> exact NN on the grid -> linearise with the packed
  *                           covariances -> reduce to *out. If nn_idx_out/nn_d2_out are non-NULL the correspondences
- *                           are also written, in ORIGINAL source order (for sp_gicp_error / compute_error_frozen). If
+ *                           are also written, in ORIGINAL source order (for sp_gicp_error / compute_error_frozen); with
+ *                           NULL outputs (here and in sp_gicp_align_*) the search is bounded by
+ *                           max_correspondence_distance — a neighbour beyond it would be rejected anyway, so a source
+ *                           point without a correspondence costs one block of cells instead of a walk out to wherever its
+ *                           nearest target point is (clouds that only partly overlap). If
  *                           `gn` is non-NULL (single-GPU loops) the same launch also solves (H + lambda I) delta = -b
  *                           and updates the DEVICE pose transT in place, writing delta_out8 as sp_gn_update does; with
  *                           gn == NULL the caller all-reduces *out over ranks and calls sp_gn_update.

@@ -843,7 +843,17 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
 #if defined(SP_EXP) && (SP_EXP & 4)   // measurement build: first stage only, exact or not
             grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
 #else
-            nn = FAST_NN ? grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz) : grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
+            // Nobody reads the neighbours (no nn_idx output): a correspondence beyond max_correspondence_distance is rejected
+            // below whatever it is, so the search need not find it (grid_nn1_fast). The next float above max_d2 keeps a
+            // neighbour at exactly that distance.
+            const float bound2 = (P.nn_idx == nullptr && P.max_d2 < FLT_MAX) ? __uint_as_float(__float_as_uint(P.max_d2) + 1u) : FLT_MAX;
+            if (FAST_NN) {
+                nn = grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz, bound2);
+            } else {
+                Nearest seed;
+                seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f;
+                nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 0);
+            }
 #endif
             if (row) {
                 float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;  // nothing found: radius 0, searched again next time
