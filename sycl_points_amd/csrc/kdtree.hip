@@ -33,6 +33,7 @@ struct sp_kdtree {
     int root = -1;
     float4* d_internal = nullptr;  // 2 x float4 per node
     float4* d_leaf = nullptr;
+    mutable sp::StreamSet streams;  // every stream the arrays were used on (sp_common.h: event-tagged pool, no sync in destroy)
 };
 
 namespace sp {
@@ -153,7 +154,7 @@ SubTree build_parallel(const float* pts, std::vector<uint32_t>& gi, uint32_t sta
                        int spawn_levels) {
     SubTree t;
     const uint32_t size = end - start + 1;
-    if (spawn_levels <= 0 || size <= leaf_threshold || size < 32768u) {
+    if (spawn_levels <= 0 || size <= leaf_threshold || size < 2048u) {  // (a thread costs ~30 us to start: worth it from ~0.1 ms of work)
         t.root = build_range(pts, gi, start, end, leaf_threshold, t.internal, t.leaves);
         return t;
     }
@@ -169,7 +170,7 @@ SubTree build_parallel(const float* pts, std::vector<uint32_t>& gi, uint32_t sta
     node.axis = axis; node.pad = 0;
     t.internal.push_back(node);
     t.root = 0;
-    // size >= 32768 > 2: both halves exist
+    // size >= 2048 > 2: both halves exist
     std::future<SubTree> left = std::async(std::launch::async, [&, start, median, spawn_levels] {
         return build_parallel(pts, gi, start, median - 1, leaf_threshold, spawn_levels - 1);
     });
@@ -414,13 +415,14 @@ extern "C" int sp_kdtree_create(const float* points_host, size_t n, size_t leaf_
     t->n_leaves = (unsigned)(leaves.size() / leaf_threshold);
     t->root = root;
     hipStream_t st = as_stream(stream);
+    t->streams.note(st);
     hipError_t e = hipSuccess;
     if (!internal.empty()) {
-        e = hipMalloc(&t->d_internal, internal.size() * 32);
+        e = pooled_alloc(&t->d_internal, internal.size() * 32);  // (hipMalloc + hipFree are ~0.1-0.2 ms apiece on this runtime)
         if (e == hipSuccess) e = hipMemcpyAsync(t->d_internal, internal.data(), internal.size() * 32, hipMemcpyHostToDevice, st);
     }
     if (e == hipSuccess && !leaves.empty()) {
-        e = hipMalloc(&t->d_leaf, leaves.size() * 16);
+        e = pooled_alloc(&t->d_leaf, leaves.size() * 16);
         if (e == hipSuccess) e = hipMemcpyAsync(t->d_leaf, leaves.data(), leaves.size() * 16, hipMemcpyHostToDevice, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host vectors die at return
@@ -435,8 +437,8 @@ extern "C" int sp_kdtree_create(const float* points_host, size_t n, size_t leaf_
 
 extern "C" void sp_kdtree_destroy(sp_kdtree* t) {
     if (!t) return;
-    if (t->d_internal) (void)hipFree(t->d_internal);
-    if (t->d_leaf) (void)hipFree(t->d_leaf);
+    sp::pooled_free_after(t->d_internal, t->streams);
+    sp::pooled_free_after(t->d_leaf, t->streams);
     delete t;
 }
 
@@ -455,6 +457,7 @@ extern "C" int sp_kdtree_search(const sp_kdtree* tree, const float* queries, siz
     }
     if (nq == 0) return SP_OK;
     hipStream_t st = as_stream(stream);
+    tree->streams.note(st);
     if (tree->root == kNone) {
         fill_empty_kernel<<<div_up(nq * k, kBlock), kBlock, 0, st>>>(idx_out, d2_out, nq * k);
         return launch_status();
@@ -473,6 +476,7 @@ extern "C" int sp_kdtree_radius_search(const sp_kdtree* tree, const float* queri
     }
     if (nq == 0 || max_k == 0) return SP_OK;
     hipStream_t st = as_stream(stream);
+    tree->streams.note(st);
     if (tree->root == kNone) {
         fill_empty_kernel<<<div_up(nq * max_k, kBlock), kBlock, 0, st>>>(idx_out, d2_out, nq * max_k);
         return launch_status();
@@ -486,6 +490,7 @@ extern "C" int sp_kdtree_remove_by_flags(sp_kdtree* tree, const uint8_t* flags, 
     using namespace sp;
     if (!tree) return SP_ERR_INVALID_ARGUMENT;
     hipStream_t st = as_stream(stream);
+    tree->streams.note(st);
     if (tree->n_internal)
         remove_internal_kernel<<<div_up(tree->n_internal, kBlock), kBlock, 0, st>>>(tree->d_internal, tree->n_internal,
                                                                                     flags, new_indices, (unsigned)n_flags);
