@@ -20,6 +20,7 @@
 #include <initializer_list>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -114,6 +115,61 @@ inline void throw_on_error(int rc) {
 inline void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
+
+namespace detail {
+// The HBM mirrors of the containers (shared_vector) come from a small cache of idle device buffers: hipMalloc / hipFree cost
+// 0.1-0.2 ms apiece on this runtime, and a pipeline that builds a few point clouds per frame (the reference's example: twenty
+// attribute vectors per loop) spent more time there than in its kernels. A buffer is cached only after the device has gone
+// idle (what hipFree waits for too), so its next owner can use it at once. At most 48 buffers / 2 GiB are kept idle.
+struct DeviceBufferCache {
+    static void* acquire(size_t bytes, size_t* got) {
+        {
+            std::lock_guard<std::mutex> lock(mutex());
+            auto& idle = buffers();
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].second >= bytes && idle[i].second <= 2 * bytes + 4096 && (best == idle.size() || idle[i].second < idle[best].second))
+                    best = i;
+            if (best != idle.size()) {
+                void* p = idle[best].first;
+                *got = idle[best].second;
+                total() -= idle[best].second;
+                idle.erase(idle.begin() + (std::ptrdiff_t)best);
+                return p;
+            }
+        }
+        void* p = nullptr;
+        hip_check(hipMalloc(&p, bytes), "hipMalloc");
+        *got = bytes;
+        return p;
+    }
+    static void release(void* p, size_t bytes) {
+        if (!p) return;
+        (void)hipDeviceSynchronize();  // nothing in flight may still use it (hipFree would wait as well)
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lock(mutex());
+            auto& idle = buffers();
+            idle.emplace_back(p, bytes);
+            total() += bytes;
+            while (idle.size() > 48 || total() > (size_t(2) << 30)) {  // oldest first
+                drop.push_back(idle.front().first);
+                total() -= idle.front().second;
+                idle.erase(idle.begin());
+            }
+        }
+        for (void* d : drop) (void)hipFree(d);
+    }
+
+private:
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static size_t& total() { static size_t t = 0; return t; }
+    static std::vector<std::pair<void*, size_t>>& buffers() {
+        static auto* c = new std::vector<std::pair<void*, size_t>>();  // never destroyed: the HIP runtime may be gone by then
+        return *c;
+    }
+};
+}  // namespace detail
 
 namespace sycl_utils {
 
@@ -213,7 +269,7 @@ public:
         if (this != &o) { host_ = o.host(); host_dirty_ = true; dev_dirty_ = false; }
         return *this;
     }
-    ~shared_vector() { if (dev_) (void)hipFree(dev_); }
+    ~shared_vector() { if (dev_) detail::DeviceBufferCache::release(dev_, dev_bytes_); }
 
     // ---- host side (std::vector surface)
     size_t size() const { return size_override_ ? dev_size_ : host_.size(); }
@@ -256,14 +312,15 @@ private:
     void bind(const sycl_utils::DeviceQueue::StreamHolder& h) { stream_ = h.stream; }
     void ensure_capacity(size_t n) const {
         if (n <= dev_cap_) return;
-        T* nd = nullptr;
-        hip_check(hipMalloc(&nd, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc");
+        size_t got = 0;
+        T* nd = static_cast<T*>(detail::DeviceBufferCache::acquire(std::max<size_t>(n, 1) * sizeof(T), &got));
         if (dev_) {
             if (dev_dirty_ && dev_size_) hip_check(hipMemcpy(nd, dev_, std::min(dev_size_, n) * sizeof(T), hipMemcpyDeviceToDevice), "hipMemcpy");
-            (void)hipFree(dev_);
+            detail::DeviceBufferCache::release(dev_, dev_bytes_);
         }
         dev_ = nd;
-        dev_cap_ = n;
+        dev_bytes_ = got;
+        dev_cap_ = got / sizeof(T);
     }
     void sync_device() const {
         if (dev_dirty_) return;  // device is the newest copy
@@ -288,7 +345,7 @@ private:
 
     mutable std::vector<T> host_;
     mutable T* dev_ = nullptr;
-    mutable size_t dev_cap_ = 0, dev_size_ = 0;
+    mutable size_t dev_cap_ = 0, dev_size_ = 0, dev_bytes_ = 0;
     mutable bool host_dirty_ = true, dev_dirty_ = false, size_override_ = false;
     std::shared_ptr<sycl_utils::DeviceQueue::StreamHolder> queue_;
     hipStream_t stream_ = nullptr;
