@@ -233,7 +233,7 @@ __device__ __forceinline__ void best_insert(float (&bd)[KCAP], int (&bi)[KCAP], 
     }
 }
 
-template <int KCAP, bool RADIUS>
+template <int KCAP, bool RADIUS, bool BATCH_LEAF>
 __global__ __launch_bounds__(kBlock) void kdtree_search_kernel(const float4* __restrict__ internal,
                                                                const float4* __restrict__ leaf, int root,
                                                                unsigned stride, const float4* __restrict__ queries,
@@ -294,7 +294,19 @@ __global__ __launch_bounds__(kBlock) void kdtree_search_kernel(const float4* __r
             } else if (KCAP == 1) {
 #pragma unroll 4
                 for (unsigned s = 0; s < stride; ++s) visit(blk[s]);
-            } else {  // the insertion chain is long: keep one copy of it
+            } else if (BATCH_LEAF && KCAP <= 20 && stride == 16) {
+                // sorted lists, few queries (the launch is a latency chain, not a throughput problem: 69 k queries k = 10 0.77 ->
+                // 0.59 ms; at 1 M queries the eight copies of the insertion chain cost 6 %): fetch the block as independent loads,
+                // two batches of eight — one round trip each instead of sixteen behind sixteen data-dependent branches
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                    float4 slot[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) slot[s] = blk[half * 8 + s];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) visit(slot[s]);
+                }
+            } else {  // long lists / other leaf sizes: the insertion chain is long, keep one copy of it
 #pragma unroll 1
                 for (unsigned s = 0; s < stride; ++s) visit(blk[s]);
             }
@@ -372,9 +384,14 @@ int launch_search(const sp_kdtree* t, const float* q, size_t nq, size_t k, float
     for (int i = 0; i < 16; ++i) tv.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     if (T && !T_dev)
         for (int i = 0; i < 16; ++i) tv.m[i] = T[i];
-    kdtree_search_kernel<KCAP, RADIUS><<<div_up(nq, kBlock), kBlock, 0, st>>>(
-        t->d_internal, t->d_leaf, t->root, t->stride, reinterpret_cast<const float4*>(q), (unsigned)nq, (int)k,
-        radius_sq, tv, T_dev ? T : nullptr, idx, d2);
+    if (KCAP > 1 && KCAP <= 20 && nq < 200000)
+        kdtree_search_kernel<KCAP, RADIUS, true><<<div_up(nq, kBlock), kBlock, 0, st>>>(
+            t->d_internal, t->d_leaf, t->root, t->stride, reinterpret_cast<const float4*>(q), (unsigned)nq, (int)k,
+            radius_sq, tv, T_dev ? T : nullptr, idx, d2);
+    else
+        kdtree_search_kernel<KCAP, RADIUS, false><<<div_up(nq, kBlock), kBlock, 0, st>>>(
+            t->d_internal, t->d_leaf, t->root, t->stride, reinterpret_cast<const float4*>(q), (unsigned)nq, (int)k,
+            radius_sq, tv, T_dev ? T : nullptr, idx, d2);
     return launch_status();
 }
 
