@@ -1106,6 +1106,33 @@ def test_correspondence_reuse_is_exact(sp, orc, gicp20k):
     assert (reg.neighbors.indices.cpu().numpy() == 0).all() and reg._read_lin(lin).inlier == 256
 
 
+def test_search_bounded_by_max_correspondence_distance_is_exact(sp, orc, gicp20k):
+    """Without a neighbour output the fused kernels look for a neighbour only below max_correspondence_distance (a farther
+    one is rejected anyway; with partial overlap that search was most of an iteration). Partial overlap on purpose: a third
+    of the source shifted far outside the target, a tight distance. Pose and linear system must be bit-identical to the run
+    that writes the neighbours (unbounded search), for the sorted and the unsorted source path, and the inliers must be the
+    oracle's."""
+    src, scov, tgt, tcov, T_gt = gicp20k
+    src2 = src.copy()
+    src2[::3, :3] += np.float32([37.0, -21.0, 9.0])  # no target point within any useful distance of these
+    outs = []
+    for write, sort in ((True, True), (False, True), (True, False), (False, False)):
+        S = sp.PointCloudShared(dev(src2), covs=dev(scov))
+        Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+        prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
+        reg = sp.Registration(sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=6,
+                                                    max_correspondence_distance=0.3))
+        T_dev, lin, _ = reg.align_fused_loop(S, prep, write_neighbors=write, sort_by_cell=sort)
+        outs.append((T_dev.cpu().numpy().copy(), lin.cpu().numpy().copy(), reg._read_lin(lin).inlier))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[2][0], outs[3][0]) and np.array_equal(outs[2][1], outs[3][1])
+    assert 0 < outs[0][2] <= len(src) - len(src[::3])
+    T = np.array(outs[0][0], np.float32).reshape(4, 4).T
+    ref = orc.registration_align(__import__("oracle.pyoracle", fromlist=["RegParams"]).RegParams.defaults(
+        crit_translation=0.0, crit_rotation=0.0, max_iterations=6, max_correspondence_distance=0.3), src2, scov, tgt, tcov)
+    assert np.abs(T - ref["T"]).max() < 1e-5
+
+
 def test_grid_order_and_presorted_source(sp, orc, gicp20k):
     """sp_grid_order is the grid's cell-order permutation; a source stored in that order aligns without the per-alignment
     sort (SP_SOURCE_PRESORTED) to the same pose, and reports its neighbours in the caller's (reordered) indexing."""
