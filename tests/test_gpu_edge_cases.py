@@ -1,0 +1,89 @@
+"""Edge cases of the structure builds rewritten in round 2 (hand-written radix sort, gap-fill cell table, block-offset voxel
+compaction): tiny clouds, exactly one tile, clustered clouds with huge runs of empty cells, non-finite points, 8 M points.
+GridKNN must stay bit-identical to brute force; voxel downsampling to the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sp():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    import sycl_points_amd.api as api
+
+    return api
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 2047, 2048, 2049, 4097])
+def test_grid_on_tiny_and_tile_sized_clouds(sp, orc, n):
+    g = orc.rng(1000 + n)
+    tgt = g.uniform_points(n, 5.0)
+    qry = g.uniform_points(257, 6.0)
+    for ppc in (0.5, 6.0):
+        grid = sp.GridKNN.build(dev(tgt), points_per_cell=ppc)
+        k = min(3, n)
+        r = grid.knn_search(dev(qry), k)
+        oi, od = orc.knn_bruteforce(qry, tgt, k)
+        assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+
+
+def test_grid_on_two_distant_clusters_and_a_flat_cloud(sp, orc):
+    # almost every cell of the bounding box is empty: the cell table is one long gap between the clusters
+    g = orc.rng(77)
+    a, b = g.uniform_points(3000, 1.0), g.uniform_points(3000, 1.0)
+    b[:, :3] += np.float32([400.0, -250.0, 90.0])
+    tgt = np.concatenate([a, b])
+    qry = np.concatenate([g.uniform_points(200, 1.5), g.uniform_points(200, 1.5) + np.float32([400.0, -250.0, 90.0, 0.0]),
+                          np.float32([[200.0, -125.0, 45.0, 1.0]])])  # one query in the void between them
+    grid = sp.GridKNN.build(dev(tgt), points_per_cell=0.5)
+    r = grid.knn_search(dev(qry), 4)
+    oi, od = orc.knn_bruteforce(qry, tgt, 4)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    flat = g.uniform_points(5000, 10.0)
+    flat[:, 2] = 0.25  # a plane: the z extent is zero
+    grid = sp.GridKNN.build(dev(flat), points_per_cell=2.0)
+    r = grid.knn_search(dev(flat[:300]), 5)
+    oi, od = orc.knn_bruteforce(flat[:300], flat, 5)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+
+
+def test_voxel_downsampling_edge_sizes(sp, orc):
+    g = orc.rng(5)
+    for n, size in ((1, 0.1), (255, 0.1), (256, 0.1), (257, 5.0), (2049, 100.0), (50_000, 0.05)):
+        pts = g.uniform_points(n, 3.0)
+        vg = sp.VoxelGrid(size)
+        for _ in range(2):  # the second call sorts keys compressed to the first call's key box
+            out = vg.downsampling(dev(pts))
+            ref = orc.voxel_downsample(pts, size)["points"]
+            assert out.size() == len(ref) and np.array_equal(out.points.cpu().numpy(), ref)
+    # every point in one voxel (one run spanning many workgroups of the aggregation)
+    pts = g.uniform_points(10_000, 0.01)
+    vg = sp.VoxelGrid(10.0)
+    for _ in range(2):
+        out = vg.downsampling(dev(pts))
+        ref = orc.voxel_downsample(pts, 10.0)["points"]
+        assert out.size() == len(ref) and np.array_equal(out.points.cpu().numpy(), ref)
+
+
+def test_structures_at_8m_points(sp, orc):
+    # config-5 size on one GPU: 3907 sort tiles, 16 M cells; sampled against brute force on the host
+    g = orc.rng(8)
+    tgt = g.uniform_points(8_000_000, 20.0)
+    grid = sp.GridKNN.build(dev(tgt), points_per_cell=0.5)
+    qry = g.uniform_points(64, 20.0)
+    r = grid.knn_search(dev(qry), 2)
+    oi, od = orc.knn_bruteforce(qry, tgt, 2)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    vg = sp.VoxelGrid(0.1)
+    vg.downsampling(dev(tgt))  # (remembers the key box: the next call takes the compressed-key path)
+    out, keys = vg.downsampling(dev(tgt), return_keys=True)
+    k = keys.cpu().numpy()
+    assert (np.diff(k) > 0).all()  # ascending, no voxel twice
+    assert np.array_equal(np.unique(orc.voxel_keys(tgt, 0.1).astype(np.int64)), k)
