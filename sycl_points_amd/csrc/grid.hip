@@ -541,22 +541,44 @@ __device__ __forceinline__ unsigned long long shift_up1_k(unsigned long long v) 
     return ((unsigned long long)(unsigned)shift_up1_i((int)(v >> 32)) << 32) | (unsigned)shift_up1_i((int)(unsigned)v);
 }
 
-__device__ __forceinline__ Cand bitonic_sort64(Cand v, unsigned lane) {
-#pragma unroll
-    for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            Cand o;
-            o.key = ((unsigned long long)(unsigned)__shfl_xor((int)(v.key >> 32), stride, 64) << 32) |
-                    (unsigned)__shfl_xor((int)(unsigned)v.key, stride, 64);
-            o.pos = __shfl_xor(v.pos, stride, 64);
-            const bool up = ((lane & size) == 0);       // ascending block?
-            const bool lower = ((lane & stride) == 0);  // this lane keeps the smaller of the pair in an ascending block
-            const bool take = (lower == up) ? (o.key < v.key) : (o.key > v.key);
-            v.key = take ? o.key : v.key;
-            v.pos = take ? o.pos : v.pos;
-        }
+// The value of lane (i ^ STRIDE), for one 32-bit register. Strides below 16 stay inside a row of 16 lanes: DPP moves on the
+// VALU (quad_perm for 1 and 2, row_half_mirror + reversed quads for 4, row_ror:8 for 8) instead of ds_bpermute through the
+// LDS crossbar — 18 of the 21 stages of the 64-lane network, 54 of its 63 permutes.
+template <int STRIDE>
+__device__ __forceinline__ int xor_lane(int v) {
+    if (STRIDE == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+    if (STRIDE == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+    if (STRIDE == 4) {
+        const int m = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);        // row_half_mirror: i -> i ^ 7
+        return __builtin_amdgcn_update_dpp(m, m, 0x1B, 0xf, 0xf, false);                // quad_perm:[3,2,1,0]: ^ 3  => i ^ 4
     }
+    if (STRIDE == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);  // row_ror:8: i -> i ^ 8
+    return __shfl_xor(v, STRIDE, 64);
+}
+
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_step(Cand& v, unsigned lane) {
+    Cand o;
+    o.key = ((unsigned long long)(unsigned)xor_lane<STRIDE>((int)(v.key >> 32)) << 32) | (unsigned)xor_lane<STRIDE>((int)(unsigned)v.key);
+    o.pos = xor_lane<STRIDE>(v.pos);
+    const bool up = ((lane & SIZE) == 0);       // ascending block?
+    const bool lower = ((lane & STRIDE) == 0);  // this lane keeps the smaller of the pair in an ascending block
+    const bool take = (lower == up) ? (o.key < v.key) : (o.key > v.key);
+    v.key = take ? o.key : v.key;
+    v.pos = take ? o.pos : v.pos;
+}
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(Cand& v, unsigned lane) {
+    bitonic_step<SIZE, STRIDE>(v, lane);
+    if constexpr (STRIDE > 1) bitonic_merge<SIZE, STRIDE / 2>(v, lane);
+}
+__device__ __forceinline__ Cand bitonic_sort64(Cand v, unsigned lane) {
+    bitonic_merge<2, 1>(v, lane);
+    bitonic_merge<4, 2>(v, lane);
+    bitonic_merge<8, 4>(v, lane);
+    bitonic_merge<16, 8>(v, lane);
+    bitonic_merge<32, 16>(v, lane);
+    bitonic_merge<64, 32>(v, lane);
     return v;
 }
 
