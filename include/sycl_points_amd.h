@@ -172,7 +172,7 @@ int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, siz
 /* The same operation with the bounding box of the cloud's voxel coordinates known to the HOST (box6 = min x,y,z, max x,y,z
  * of the 21-bit key fields; sp_voxel_key_box computes it on the device: read it back, or keep the previous scan's box and
  * check *status_dev_opt). The keys are then compressed to the voxel's position in the box — same order — and sorted by
- * exactly the bits the box needs (3 Onesweep passes for a 200^3 box instead of a 64-bit sort: the sort is most of the
+ * exactly the bits the box needs (3 passes of the hand-written radix sort for a 200^3 box instead of a 64-bit sort: the sort is most of the
  * run time). Results are identical to sp_voxel_downsample. *status_dev_opt receives the number of valid points whose voxel
  * lies outside the box: non-zero means the box did not cover the cloud and the outputs must be discarded. A NULL, empty or
  * too large box (>= 2^32 - 1 cells) falls back to the 64-bit path. */
@@ -280,7 +280,7 @@ int sp_genz_counts(const float* tgt_covs, const int32_t* nn_idx, const float* nn
  *                           neighbouring lanes get neighbouring cells (their loads then share cache lines):
  *                             SP_SOURCE_ORDER_UNKNOWN (0) keep the caller's order, assume nothing (ring-walk search);
  *                             SP_SOURCE_SORT (1) reorder by the target-grid cell that transT*p falls into
- *                               (two Onesweep passes per alignment);
+ *                               (two radix-sort passes per alignment);
  *                             SP_SOURCE_PRESORTED (2) keep the caller's order, which is already spatially coherent —
  *                               sp_grid_order of any grid on the source, or the output order of voxel downsampling —
  *                               no sort, block-walk search: the fastest combination.
