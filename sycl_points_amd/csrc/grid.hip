@@ -546,13 +546,15 @@ __device__ __forceinline__ unsigned long long shift_up1_k(unsigned long long v) 
 // LDS crossbar — 18 of the 21 stages of the 64-lane network, 54 of its 63 permutes.
 template <int STRIDE>
 __device__ __forceinline__ int xor_lane(int v) {
-    if (STRIDE == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
-    if (STRIDE == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+    // (mov_dpp, not update_dpp(v, v, ...): every lane is written, and without an `old` operand the compiler neither copies the
+    // register first nor is kept from folding the move into the instruction that consumes it)
+    if (STRIDE == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+    if (STRIDE == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
     if (STRIDE == 4) {
-        const int m = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);        // row_half_mirror: i -> i ^ 7
-        return __builtin_amdgcn_update_dpp(m, m, 0x1B, 0xf, 0xf, false);                // quad_perm:[3,2,1,0]: ^ 3  => i ^ 4
+        const int m = __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);        // row_half_mirror: i -> i ^ 7
+        return __builtin_amdgcn_mov_dpp(m, 0x1B, 0xf, 0xf, true);                // quad_perm:[3,2,1,0]: ^ 3  => i ^ 4
     }
-    if (STRIDE == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);  // row_ror:8: i -> i ^ 8
+    if (STRIDE == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);  // row_ror:8: i -> i ^ 8
     return __shfl_xor(v, STRIDE, 64);
 }
 
