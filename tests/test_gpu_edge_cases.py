@@ -87,3 +87,18 @@ def test_structures_at_8m_points(sp, orc):
     k = keys.cpu().numpy()
     assert (np.diff(k) > 0).all()  # ascending, no voxel twice
     assert np.array_equal(np.unique(orc.voxel_keys(tgt, 0.1).astype(np.int64)), k)
+
+
+@pytest.mark.parametrize("k", [11, 16, 20])
+def test_self_knn_lists_with_duplicates_and_sparse_clouds(sp, orc, k):
+    # the wave-cooperative self-kNN (lane-minimum-first sort on DPP, stage directions as scalar lane masks): exact ties
+    # (duplicated points), a dense-ish cloud, and a cloud so sparse that most queries need the ring expansion / to-do pass
+    g = orc.rng(31 + k)
+    for n, r in ((20000, 5.0), (3000, 40.0)):
+        pts = g.uniform_points(n, r)
+        for cloud in (pts, np.concatenate([pts, pts[:500]])):
+            grid = sp.GridKNN.build(dev(cloud), points_per_cell=6.0)
+            res, covs, _ = grid.self_knn(k, want_knn=True, want_covs=True)
+            oi, od = orc.knn_bruteforce(cloud, cloud, k)
+            assert np.array_equal(res.indices.cpu().numpy(), oi) and np.array_equal(res.distances.cpu().numpy(), od)
+            assert np.array_equal(covs.cpu().numpy().reshape(-1, 16), np.asarray(orc.cov_estimate(cloud, oi), np.float32).reshape(-1, 16))
