@@ -102,3 +102,16 @@ def test_self_knn_lists_with_duplicates_and_sparse_clouds(sp, orc, k):
             oi, od = orc.knn_bruteforce(cloud, cloud, k)
             assert np.array_equal(res.indices.cpu().numpy(), oi) and np.array_equal(res.distances.cpu().numpy(), od)
             assert np.array_equal(covs.cpu().numpy().reshape(-1, 16), np.asarray(orc.cov_estimate(cloud, oi), np.float32).reshape(-1, 16))
+
+
+def test_grid_with_non_finite_points(sp, orc):
+    # non-finite points go to a trash cell past the grid (never searched): the gap-fill cell table must close exactly there
+    g = orc.rng(404)
+    tgt = g.uniform_points(6000, 8.0)
+    tgt[::17, 0] = np.nan
+    tgt[5::29, 2] = np.inf
+    qry = g.uniform_points(500, 8.0)
+    grid = sp.GridKNN.build(dev(tgt), points_per_cell=0.5)
+    r = grid.knn_search(dev(qry), 3)
+    oi, od = orc.knn_bruteforce(qry, tgt, 3)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
