@@ -202,3 +202,35 @@ def test_self_knn_by_position_ranges_equals_whole_cloud(sp, k, ppc):
     sp.check(L.sp_grid_scatter_rows(grid._h, sp._ptr(by_pos), 64, 0, n, sp._ptr(back), sp._stream()))
     order = grid.order()
     assert torch.equal(by_pos, covs[order]) and torch.equal(back, covs)
+
+
+@pytest.mark.parametrize("reg_type", ["GICP", "POINT_TO_DISTRIBUTION"])
+def test_full_oracle_alignment_config4_1m(sp, orc, config4, reg_type):
+    """north_star's criterion at the headline size, end to end: ONE full oracle alignment (KD-tree NN + K11 + LDL^T, 1M vs
+    1M, registration.hpp:201-276) against the benchmarked configuration (grid-ordered source, GridKNN 0.5 points per cell,
+    prepared rows, correspondence reuse, sp_gicp_align_fused) on the same inputs, for both readings of BASELINE config 4:
+      * 20 Gauss-Newton iterations with criteria 0: max |T_gpu - T_oracle| <= 1e-5, equal inlier count;
+      * the reference's default criteria (1e-3 / 1e-3): equal `iterations` and `converged`, pose within 1e-5."""
+    from oracle.pyoracle import REG, RegParams
+
+    n, src, tgt, T_gt, Tg, grid, prep_gicp = config4
+    prep = prep_gicp if reg_type == "GICP" else sp.PreparedTarget(grid, Tg.covs, reg_type=reg_type)
+    S_all = dev(src)
+    S_all = S_all[sp.GridKNN.build(S_all, points_per_cell=1.0).order()].contiguous()
+    covs = sp.GridKNN.build(S_all, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
+    S = sp.PointCloudShared(S_all, covs=covs)
+    s_np, sc_np, tc_np = S_all.cpu().numpy(), covs.cpu().numpy(), Tg.covs.cpu().numpy()
+    nodes = orc.kdtree_build(tgt)
+    for crit in (0.0, 1e-3):
+        p = sp.RegistrationParams(reg_type=reg_type, criteria_translation=crit, criteria_rotation=crit, max_iterations=20)
+        reg = sp.Registration(p)
+        T_dev, lin, delta = reg.align_fused_loop(S, prep, sort_by_cell="presorted")
+        torch.cuda.synchronize()
+        T = reg.T_from_device(T_dev)
+        op = RegParams.defaults(reg_type=REG[reg_type], crit_translation=crit, crit_rotation=crit, max_iterations=20)
+        ref = orc.registration_align(op, s_np, sc_np, tgt, tc_np, nodes=nodes)
+        assert np.abs(T - ref["T"]).max() <= 1e-5, (reg_type, crit, np.abs(T - ref["T"]).max())
+        assert reg._read_lin(lin).inlier == ref["inlier"]
+        assert int(reg._iters_dev[0]) == ref["iterations"]
+        assert bool(float(delta[6]) > 0.5) == ref["converged"]
+        assert np.abs(T - T_gt).max() < (1e-4 if reg_type == "GICP" else 1e-3)
