@@ -63,6 +63,31 @@ void orc_eigen3(const float* A_colmajor9, float* vals3, float* vecs_colmajor9) {
 }
 void orc_inverse3(const float* A, float* out) { Mat3 m; std::memcpy(m.d, A, 36); const Mat3 r = inverse(m); std::memcpy(out, r.d, 36); }
 float orc_det3(const float* A) { Mat3 m; std::memcpy(m.d, A, 36); return determinant(m); }
+// Small eigen_utils helpers used inside K11 (test_eigen_utils.cpp:471-595): op 0 dot<3>, 1 dot<4>, 2 cross, 3 outer<4>,
+// 4 transpose<3,3>, 5 transpose<4,6>, 6 ensure_symmetric<3>, 7 frobenius_norm<3,3>, 8 frobenius_norm<3> (vector),
+// 9 frobenius_norm_squared<3> (vector), 10 element_wise_multiply<3,3>, 11 element_wise_multiply<4,4>.
+// Operands and results are column-major, as everywhere in this file.
+void orc_eigen_util(int op, const float* a, const float* b, float* out) {
+    auto ld3 = [](const float* p) { Vec3 v; std::memcpy(v.d, p, 12); return v; };
+    auto ld4 = [](const float* p) { Vec4 v; std::memcpy(v.d, p, 16); return v; };
+    auto ldm3 = [](const float* p) { Mat3 m; std::memcpy(m.d, p, 36); return m; };
+    auto ldm4 = [](const float* p) { Mat4 m; std::memcpy(m.d, p, 64); return m; };
+    switch (op) {
+        case 0: out[0] = dot<3>(ld3(a), ld3(b)); break;
+        case 1: out[0] = dot<4>(ld4(a), ld4(b)); break;
+        case 2: { const Vec3 r = cross(ld3(a), ld3(b)); std::memcpy(out, r.d, 12); break; }
+        case 3: { const Mat4 r = outer<4>(ld4(a), ld4(b)); std::memcpy(out, r.d, 64); break; }
+        case 4: { const Mat3 r = transpose<3, 3>(ldm3(a)); std::memcpy(out, r.d, 36); break; }
+        case 5: { Mat<4, 6> m; std::memcpy(m.d, a, 96); const Mat<6, 4> r = transpose<4, 6>(m); std::memcpy(out, r.d, 96); break; }
+        case 6: { const Mat3 r = ensure_symmetric<3>(ldm3(a)); std::memcpy(out, r.d, 36); break; }
+        case 7: out[0] = frobenius_norm<3, 3>(ldm3(a)); break;
+        case 8: out[0] = norm<3>(ld3(a)); break;
+        case 9: out[0] = norm_squared<3>(ld3(a)); break;
+        case 10: { const Mat3 r = element_wise_multiply<3, 3>(ldm3(a), ldm3(b)); std::memcpy(out, r.d, 36); break; }
+        case 11: { const Mat4 r = element_wise_multiply<4, 4>(ldm4(a), ldm4(b)); std::memcpy(out, r.d, 64); break; }
+        default: break;
+    }
+}
 void orc_matmul4(const float* A, const float* B, float* out) {
     Mat4 a, b; std::memcpy(a.d, A, 64); std::memcpy(b.d, B, 64);
     const Mat4 r = matmul<4, 4, 4>(a, b); std::memcpy(out, r.d, 64);

@@ -137,6 +137,34 @@ Mat<N, N> outer(const Vec<N>& u, const Vec<N>& v) {
     }
     return r;
 }
+// eigen_utils.hpp:186-198
+template <int M, int N>
+Mat<M, N> element_wise_multiply(const Mat<M, N>& A, const Mat<M, N>& B) {
+    Mat<M, N> r;
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < M; ++i) r(i, j) = A(i, j) * B(i, j);
+    return r;
+}
+// eigen_utils.hpp:259-265  (plain products and one subtraction per component, no fma)
+inline Vec<3> cross(const Vec<3>& u, const Vec<3>& v) {
+    Vec<3> r;
+    r[0] = u[1] * v[2] - u[2] * v[1];
+    r[1] = u[2] * v[0] - u[0] * v[2];
+    r[2] = u[0] * v[1] - u[1] * v[0];
+    return r;
+}
+// eigen_utils.hpp:315-326, 343-345  (column-major fma chain over all elements)
+template <int M, int N>
+float frobenius_norm_squared(const Mat<M, N>& A) {
+    float r = 0.0f;
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < M; ++i) r = std::fmaf(A(i, j), A(i, j), r);
+    return r;
+}
+template <int M, int N>
+float frobenius_norm(const Mat<M, N>& A) {
+    return std::sqrt(frobenius_norm_squared<M, N>(A));
+}
 // eigen_utils.hpp:291-298
 template <int M>
 float trace(const Mat<M, M>& A) {

@@ -131,6 +131,23 @@ class Oracle:
         A = _f(np.asarray(A).T)
         return float(self.lib.orc_det3(_p(A)))
 
+    _EIGEN_UTIL = {"dot3": (0, ()), "dot4": (1, ()), "cross": (2, (3,)), "outer4": (3, (4, 4)), "transpose33": (4, (3, 3)),
+                   "transpose46": (5, (6, 4)), "ensure_symmetric3": (6, (3, 3)), "frobenius_norm33": (7, ()),
+                   "frobenius_norm3": (8, ()), "frobenius_norm_squared3": (9, ()), "cwise33": (10, (3, 3)),
+                   "cwise44": (11, (4, 4))}
+
+    def eigen_util(self, name, a, b=None):
+        """eigen_utils helpers (orc_eigen_util): operands / results as row-major numpy arrays."""
+        op, shape = self._EIGEN_UTIL[name]
+        col = lambda x: _f(np.asarray(x).T if np.ndim(x) == 2 else np.asarray(x))  # noqa: E731
+        a = col(a)
+        b = a if b is None else col(b)
+        out = np.zeros(max(int(np.prod(shape)), 1), np.float32)
+        self.lib.orc_eigen_util(C.c_int(op), _p(a), _p(b), _p(out))
+        if shape == ():
+            return float(out[0])
+        return out.reshape(shape[::-1]).T.copy() if len(shape) == 2 else out.copy()
+
     def matmul4(self, A, B):
         A = _f(np.asarray(A).T)
         B = _f(np.asarray(B).T)

@@ -218,6 +218,36 @@ def test_matmul(orc):
         assert np.allclose(orc.matmul4(A, B), A.astype(np.float64) @ B.astype(np.float64), atol=1e-4 * 400)
 
 
+def test_eigen_utils_small_helpers(orc):
+    """test_eigen_utils.cpp:471-595 — transpose (exact), dot<3>/<4>, cross, outer<4>, ensure_symmetric<3>, frobenius_norm
+    (3x3 and vector), frobenius_norm_squared, element_wise_multiply: 1000 random operands in [-10, 10] against the Eigen
+    expression each test compares with (here float64 numpy), BASE_EPSILON = 1e-5 in the reference's own terms (absolute on
+    values whose magnitude reaches 10 * 10 * 4: taken relative to that magnitude)."""
+    rs = np.random.RandomState(1234)
+    u = lambda *s: rs.uniform(-10, 10, s).astype(np.float32)  # noqa: E731
+    f64 = lambda x: np.asarray(x, np.float64)  # noqa: E731
+    for _ in range(1000):
+        A3, B3, A4, B4, A46 = u(3, 3), u(3, 3), u(4, 4), u(4, 4), u(4, 6)
+        a3, b3, a4, b4 = u(3), u(3), u(4), u(4)
+        assert np.array_equal(orc.eigen_util("transpose33", A3), A3.T)       # EXPECT_MATRIX_EXACT_EQ
+        assert np.array_equal(orc.eigen_util("transpose46", A46), A46.T)
+        assert abs(orc.eigen_util("dot3", a3, b3) - f64(a3) @ f64(b3)) <= 1e-5 * 300
+        assert abs(orc.eigen_util("dot4", a4, b4) - f64(a4) @ f64(b4)) <= 1e-5 * 400
+        assert np.abs(orc.eigen_util("cross", a3, b3) - np.cross(f64(a3), f64(b3))).max() <= 1e-5 * 200
+        assert np.abs(orc.eigen_util("outer4", a4, b4) - np.outer(f64(a4), f64(b4))).max() <= 1e-5 * 100
+        S = orc.eigen_util("ensure_symmetric3", A3)
+        assert np.abs(S - 0.5 * (f64(A3) + f64(A3).T)).max() <= 1e-5 and np.array_equal(S, S.T)
+        assert abs(orc.eigen_util("frobenius_norm33", A3) - np.linalg.norm(f64(A3))) <= 1e-5 * 30
+        assert abs(orc.eigen_util("frobenius_norm3", a3) - np.linalg.norm(f64(a3))) <= 1e-5 * 18
+        assert abs(orc.eigen_util("frobenius_norm_squared3", a3) - f64(a3) @ f64(a3)) <= 1e-5 * 300
+        assert np.abs(orc.eigen_util("cwise33", A3, B3) - f64(A3) * f64(B3)).max() <= 1e-5 * 100
+        assert np.abs(orc.eigen_util("cwise44", A4, B4) - f64(A4) * f64(B4)).max() <= 1e-5 * 100
+    # exact small cases (operation order of the restatement: products, one subtraction / fma chain from 0)
+    assert np.array_equal(orc.eigen_util("cross", [1, 0, 0], [0, 1, 0]), np.array([0, 0, 1], np.float32))
+    assert orc.eigen_util("dot3", [1, 2, 3], [4, 5, 6]) == 32.0
+    assert orc.eigen_util("frobenius_norm3", [3, 4, 0]) == 5.0
+
+
 def test_so3_se3_exp_log_roundtrip(orc):
     # test_eigen_utils.cpp:702-720
     rs = np.random.RandomState(1234)
