@@ -32,7 +32,7 @@ extern "C" {
 #define SP_ERR_RUNTIME 2          /* reference: std::runtime_error    */
 #define SP_ERR_HIP 3              /* reference: sycl::exception from wait_and_throw */
 
-#define SP_ABI_VERSION 3
+#define SP_ABI_VERSION 4
 int sp_abi_version(void);
 const char* sp_last_error(void);
 
@@ -330,31 +330,39 @@ int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gicp_source* 
 int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gicp_source* source, const float* transT_lin_host,
                            const float* transT_trial, int trial_on_device, const sp_factor_params* params,
                            sp_linearized* out, void* workspace, size_t workspace_bytes, void* stream);
-/* Registration::align's whole Gauss-Newton loop (registration.hpp:229-276) enqueued by ONE call, one kernel launch per
- * iteration plus one at the end: launch k first finishes iteration k-1 (every workgroup sums the previous launch's
- * partial rows in the same fixed order and solves the same 6x6 system, T <- T * se3_exp(delta)), then linearises at the
- * new pose. Once is_converged() (registration.hpp:407-410) holds, the remaining launches return at once, as the
- * reference breaks out of its loop. All pointers are device memory:
+/* Registration::align's whole Gauss-Newton loop (registration.hpp:229-276) enqueued by ONE call; pose, convergence flag and
+ * iteration count stay in a state block of the workspace, nothing is read back by the host. Per iteration:
+ *   [search launch]  the first sp_gicp_source_set_search_launches iterations of an alignment (default 6; cell-ordered sources
+ *                    of >= 100 000 points): the source points whose cached correspondence is not certified for this pose are
+ *                    compacted and searched on dense waves (exact 2x2x2 block, then the later stages for the unproven), the
+ *                    cache rows refreshed. It returns at once when the previous iteration searched < 1/128 of the points.
+ *   streaming launch every point: cached correspondence (certified, or on trust behind a search launch; stragglers are
+ *                    searched inline) -> linearise -> one partial row per workgroup; the last-arriving workgroup sums the
+ *                    rows in a fixed order, solves (H + lambda I) delta = -b, T <- T * se3_exp(delta) and publishes the
+ *                    next state. Sums and poses are bit-identical with and without search launches.
+ * Once is_converged() (registration.hpp:407-410) holds, the remaining launches return at once, as the reference breaks out
+ * of its loop. All pointers are device memory:
  *   transT_device  in: initial guess, out: final pose (column-major 4x4)
  *   lin_out        system of the last executed iteration (optional)
  *   delta_out8     its delta[6], converged flag, solve-ok flag (optional)
  *   iterations_out number of Gauss-Newton steps applied (optional); the reference's result.iterations is this - 1
  *   nn_idx_out / nn_d2_out: neighbours of the last linearisation, in original source order (optional, both or none)
- * Workspace: sp_gicp_workspace_bytes(n). Nothing is read back by the host; graph-capturable. */
+ * Workspace: sp_gicp_workspace_bytes(n). Graph-capturable. */
 int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                         const sp_factor_params* params, const sp_gn_params* gn, int max_iterations,
                         int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
                         uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream);
-/* The same loop one launch at a time, for callers that put something between the launches — on several GPUs (source
+/* The same loop one iteration at a time, for callers that put something between the iterations — on several GPUs (source
  * tile-sharded, target replicated) an all-reduce:
- *   for k in 0 .. max_iterations-1:  sp_gicp_align_step(k)                       (enqueue launch k)
+ *   for k in 0 .. max_iterations-1:  sp_gicp_align_step(k)                       (enqueue iteration k)
  *                                    all-reduce(sum) sp_gicp_align_rows(ws, k)   (32 KB of float32, in place, same stream order)
  *   sp_gicp_align_finish(last_k = max_iterations-1)
- * With rows_all_reduced == 1 the inlier counts travel in the rows as float VALUES (exact: < 2^24 per row) so that a float
- * all-reduce sums them; every rank then finishes iteration k in launch k+1's prologue from identical rows and holds the
- * identical pose — one collective and one launch per iteration, no separate reduction or solve kernel. All ranks must
- * pass the same rows_all_reduced, and must all-reduce all of sp_gicp_align_rows' floats (rows a rank does not use are
- * zeroed by step 0). transT_device must not be written between step 0 and finish. */
+ * rows_all_reduced == 0: one GPU, the loop of sp_gicp_align_fused. With rows_all_reduced != 0 the streaming launch leaves
+ * its sums for the collective, and step k + 1 (and finish) first enqueue a one-workgroup kernel that finishes iteration k
+ * from the all-reduced sums — the same sums and the same solve on every rank, hence the identical pose without a broadcast.
+ * rows_all_reduced == 1: all partial rows travel (inlier counts as float VALUES, exact: < 2^24 per row); every rank must
+ * all-reduce all of sp_gicp_align_rows' floats (rows a rank does not use are zeroed by step 0). All ranks must pass the same
+ * rows_all_reduced. transT_device must not be written between step 0 and finish. */
 int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                        const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
                        int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
@@ -362,13 +370,22 @@ int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* sourc
 float* sp_gicp_align_rows(void* workspace, int k, size_t* n_floats_out);
 /* rows_all_reduced == 2 (the form sp_gicp_align_sharded uses): the launch reduces its own partial rows to ONE 128-byte row
  * inside the kernel — every workgroup stores its row write-through and takes an agent-scope ticket; the last arriver sums
- * the rows in the fixed order of the single-GPU prologue (bit-identical to it) — and the caller all-reduces just
+ * the rows in the fixed order of the single-GPU loop (bit-identical to it) — and the caller all-reduces just
  * sp_gicp_align_row(ws, k): 28 sums, the inlier count as two exactly-summable floats (hi * 4096 + lo), the searched-point
- * count. The next launch reads that row instead of summing 256. */
+ * count. */
 float* sp_gicp_align_row(void* workspace, int k, size_t* n_floats_out);
 int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn, int last_k,
                          int rows_all_reduced, sp_linearized* lin_out, float* delta_out8, uint32_t* iterations_out,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* How many iterations at the start of an alignment get a dedicated search launch (see sp_gicp_align_fused; default 6, 0: the
+ * single-launch form of every iteration). A tuning knob: results do not depend on it. */
+int sp_gicp_source_set_search_launches(sp_gicp_source* source, int launches);
+/* Pose of the LAST LINEARISATION of an alignment enqueued through sp_gicp_align_* with last iteration index last_k (the
+ * pose before the final update; the pose at which convergence was detected when the loop stopped early): what the
+ * reference's neighbors_ are frozen at after align() (registration.hpp:229-234), i.e. the transT_lin of a following
+ * sp_gicp_error_prepared / Registration::compute_error_frozen. Copies 16 floats (column-major) to transT_lin_out (host or
+ * device memory) in stream order. */
+int sp_gicp_align_linearization_pose(const void* workspace, int last_k, float* transT_lin_out, void* stream);
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
  * iteration loop can stay on the stream with no host round trip:
  *   delta = LDLT(H + lambda*I).solve(-b);  T <- T * se3_exp(delta);  delta_out[0..5] = delta,

@@ -115,6 +115,8 @@ SIGNATURES = {
     "sp_gicp_iteration_fused": (_i, [_vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_fused": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_gicp_source_set_search_launches": (_i, [_vp, _i]),
+    "sp_gicp_align_linearization_pose": (_i, [_vp, _i, _vp, _vp]),
     "sp_gicp_align_rows": (_vp, [_vp, _i, _vp]),
     "sp_gicp_align_row": (_vp, [_vp, _i, _vp]),
     "sp_comm_unique_id": (_i, [_vp]),
@@ -159,7 +161,7 @@ INTERNAL_SIGNATURES = {
     "sp_internal_radix_sort_workspace_bytes": (_sz, [_sz]),
     "sp_internal_radix_sort_u32": (_i, [_vp, _vp, _vp, _vp, _sz, C.c_uint, _vp, _sz, _vp, _vp]),
 }
-INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3}
+INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3, "launch_select": 4}
 
 
 def build(force=False):
@@ -191,7 +193,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.sp_abi_version() != 3:
+        if L.sp_abi_version() != 4:
             raise ImportError("libsycl_points_amd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -614,6 +614,36 @@ __global__ __launch_bounds__(kBlock) void prepare_cov_kernel(const float4* __res
     out[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], rho2 ? rho2[src] : 0.0f, 0.0f);
 }
 
+// Block rows of a target (grid_device.h): four (lattice row key, position) pairs per cell-ordered point ...
+__global__ __launch_bounds__(kBlock) void block_key_kernel(const float4* __restrict__ gpts, unsigned n, BlockDesc b,
+                                                           unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = gpts[i];
+    const unsigned rows_y = (unsigned)b.ny + 1u;
+    const unsigned trash = (unsigned)b.nx * rows_y * ((unsigned)b.nz + 1u);  // non-finite points: past the table, never read
+    const bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    const int cx = ok ? cell_coord(p.x, b.ox, b.inv_h, b.nx) : 0, cy = ok ? cell_coord(p.y, b.oy, b.inv_h, b.ny) : 0,
+              cz = ok ? cell_coord(p.z, b.oz, b.inv_h, b.nz) : 0;
+#pragma unroll
+    for (unsigned c = 0; c < 4; ++c) {
+        const unsigned j = (unsigned)cy + (c & 1u), k = (unsigned)cz + (c >> 1);
+        keys[4 * (size_t)i + c] = ok ? (k * rows_y + j) * (unsigned)b.nx + (unsigned)cx : trash;
+        vals[4 * (size_t)i + c] = i;
+    }
+}
+// ... and, after the (stable) sort by key, the entries themselves
+__global__ __launch_bounds__(kBlock) void block_gather_kernel(const float4* __restrict__ gpts,
+                                                              const unsigned* __restrict__ order, unsigned m,
+                                                              float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const unsigned pos = order[i];
+    float4 p = gpts[pos];
+    p.w = __uint_as_float(pos);
+    out[i] = p;
+}
+
 // Certificates of the correspondence reuse (fused_point), from one k = 3 self-search on the target grid (row i, original
 // order: the point itself at 0, its nearest other point u1, its second-nearest u2; -1 / FLT_MAX when missing):
 //   rho2[i]  = (d(t, u1) / 2)^2            first test:  |q - t|^2 < rho2            (stored in t's covariance row)
@@ -700,6 +730,9 @@ struct FusedParams {
     const unsigned* tstart;
     const float4* tcovp;   // grid-ordered prepared target covariances
     const float4* tnb;     // grid order: second certificate of the reuse test (certificate_kernel), may be null
+    const float4* bpts;    // block rows of the target (grid_device.h), may be null
+    const unsigned* bstart;
+    BlockDesc b;
     GridDesc g;
     unsigned n;
     float max_d2, scale;
@@ -792,91 +825,99 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
     }
 }
 
-// One source point of the fused iteration: q = T p -> exact NN on the target grid -> linearise -> accumulate.
-template <int LOSS, bool FAST_NN, int DBG, bool P2D = false>
+// The cached correspondence of a source point: 3 x float4 in SOURCE order (sp_gicp_source::ccache)
+//   row[0] = (t.x, t.y, t.z, rho_t^2)                  what the reuse certificate needs comes first
+//   row[1] = (xx, xy, xz, yy)                          prepared covariance row of t ...
+//   row[2] = (yz, zz, index bits, grid position bits)  ... index -1 (and rho^2 = 0): nothing found, searched again next time
+// Written by whoever searched for the point (fused_point inline, or gicp_search_kernel); the winner's prepared row is
+// gathered here, next to the points the search has just scanned.
+__device__ __forceinline__ void store_correspondence(float4* __restrict__ row, const FusedParams& P, const Nearest& nn,
+                                                     Sym3& Ct) {
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+    if (nn.idx >= 0) {
+        const float4 c0 = P.tcovp[2 * (size_t)nn.pos], c1 = P.tcovp[2 * (size_t)nn.pos + 1];
+        r0 = make_float4(nn.x, nn.y, nn.z, c1.z);
+        r1 = c0;
+        r2 = make_float4(c1.x, c1.y, __int_as_float(nn.idx), __uint_as_float(nn.pos));
+        Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+    }
+    row[0] = r0;
+    row[1] = r1;
+    row[2] = r2;
+}
+
+// Reuse certificate. Correspondences rarely change from one iteration to the next. The previous winner t is PROVABLY still
+// the nearest neighbour — same index, same distance as a fresh search — when |q - t| < rho_t, half the distance from t to
+// its nearest other target point: any other target u then has |q - u| >= |t - u| - |q - t| > 2 rho_t - rho_t > |q - t|.
+// Second chance (t has a close neighbour u1, so rho_t is tiny — such points would be searched in EVERY iteration): t is
+// also certified when |q - t| < |q - u1| and |q - t| < d(t, u2) / 2, u2 being t's second-nearest other point — every target
+// u other than t and u1 then has |q - u| >= |t - u| - |q - t| >= d(t, u2) - |q - t| > |q - t|. One 16-byte gather.
+// (rho^2 carries a 1e-3 margin against rounding, certificate_kernel.)
+__device__ __forceinline__ bool certified(const FusedParams& P, float d, float rho2, float qx, float qy, float qz,
+                                          unsigned pos) {
+    if (d < rho2) return true;
+    if (!P.tnb || !(rho2 > 0.0f)) return false;
+    const float4 nb = P.tnb[pos];
+    return d < nb.w && d < dist2(qx, qy, qz, nb.x, nb.y, nb.z);
+}
+
+// The search of one query as the prepared paths run it. Nobody reads the neighbours when there is no nn_idx output: a
+// correspondence beyond max_correspondence_distance is rejected whatever it is, so the search need not find it. The next
+// float above max_d2 keeps a neighbour at exactly that distance.
+__device__ __forceinline__ float search_bound2(const FusedParams& P) {
+    return (P.nn_idx == nullptr && P.max_d2 < FLT_MAX) ? __uint_as_float(__float_as_uint(P.max_d2) + 1u) : FLT_MAX;
+}
+
+// One source point of the fused iteration: q = T p -> correspondence (cache row by certificate or on trust, else exact NN
+// on the target grid) -> linearise -> accumulate.
+// P.cache_valid: 0 the cache holds nothing (every point is searched), 1 a row is used when its certificate holds, 2 every row
+// is exact for THIS pose already (gicp_search_kernel ran before this launch): a pure coalesced stream of 84 bytes per point
+// (12 p + 24 Cs' as planes + 48 cache row), no search, no gather.
+template <int LOSS, bool FAST_NN, bool P2D = false, bool COMPACT_NN = false>
 __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
                                             unsigned& cnt, unsigned& searched) {
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
     float qx, qy, qz;
     transform_point(T, s.x, s.y, s.z, qx, qy, qz);
     Nearest nn;
-    Sym3 Ct;
-    bool have_ct = false;
-    if (DBG == 2) {  // timing experiment: no search, a nearby fake winner
-        nn.pos = min(i, P.g.n - 1); const float4 tp = P.tpts[nn.pos];
-        nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = (int)nn.pos; nn.d2 = 0.0f;
-    } else if (DBG == 3) {  // timing experiment: 2x2x2 block, then the unseeded ring walk
-        if (!grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn)) nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz);
-    } else {
-        // Correspondences rarely change from one iteration to the next. The previous winner t is PROVABLY still the
-        // nearest neighbour — same index, same distance as a fresh search — when |q - t| < rho_t, half the distance from t
-        // to its nearest other target point: any other target u then has |q - u| >= |t - u| - |q - t| > 2 rho_t - rho_t >
-        // |q - t|. Each source point therefore keeps a copy of its last correspondence IN SOURCE ORDER (t with its index,
-        // its packed covariance row carrying rho_t^2 with a 1e-3 margin against rounding, and its grid position): while
-        // correspondences hold, an iteration is a pure coalesced stream of 84 bytes per point (12 p + 24 Cs' as planes + 48 copy)
-        // with no search and no gather, and a wave whose lanes all pass never enters the search code.
-        // (A second certificate with t's nearest neighbour's coordinates passes more queries but costs one more load per
-        // point: measured slower.)
-        bool hit = false;
-        float4* const row = (DBG == 0 && P.ccache) ? P.ccache + 3 * (size_t)i : nullptr;
-        if (row && P.cache_valid) {
-            const float4 tp = row[0], c0 = row[1], c1 = row[2];
-            const float d = dist2(qx, qy, qz, tp.x, tp.y, tp.z);
-            bool pass = d < c1.z;
-            if (!pass && P.tnb && c1.z > 0.0f) {
-                // Second chance before a search (t has a close neighbour u1, so rho_t is tiny — such points would be searched in
-                // EVERY iteration and hold their whole workgroup back): t is also certified when |q - t| < |q - u1| and
-                // |q - t| < d(t, u2) / 2, u2 being t's second-nearest other point — every target u other than t and u1 then has
-                // |q - u| >= |t - u| - |q - t| >= d(t, u2) - |q - t| > |q - t|. One 16-byte gather instead of a search.
-                const float4 nb = P.tnb[__float_as_uint(c1.w)];
-                pass = d < nb.w && d < dist2(qx, qy, qz, nb.x, nb.y, nb.z);
-            }
-            if (pass) {
-                hit = true;
-                nn.d2 = d; nn.idx = __float_as_int(tp.w); nn.pos = __float_as_uint(c1.w); nn.x = tp.x; nn.y = tp.y; nn.z = tp.z;
-                Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-                have_ct = true;
-            }
-        }
-        if (!hit) {
-            ++searched;
-#if defined(SP_EXP) && (SP_EXP & 4)   // measurement build: first stage only, exact or not
-            grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
-#else
-            // Nobody reads the neighbours (no nn_idx output): a correspondence beyond max_correspondence_distance is rejected
-            // below whatever it is, so the search need not find it (grid_nn1_fast). The next float above max_d2 keeps a
-            // neighbour at exactly that distance.
-            const float bound2 = (P.nn_idx == nullptr && P.max_d2 < FLT_MAX) ? __uint_as_float(__float_as_uint(P.max_d2) + 1u) : FLT_MAX;
-            if (FAST_NN) {
-                nn = grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz, bound2);
-            } else {
-                Nearest seed;
-                seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f;
-                nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 0);
-            }
-#endif
-            if (row) {
-                float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;  // nothing found: radius 0, searched again next time
-                if (nn.idx >= 0) {
-#if defined(SP_EXP) && (SP_EXP & 2)   // measurement build: no gather of the winner's prepared row
-                    c0 = make_float4(1.0f, 0.0f, 0.0f, 1.0f); c1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
-#else
-                    c0 = P.tcovp[2 * (size_t)nn.pos];
-                    c1 = P.tcovp[2 * (size_t)nn.pos + 1];
-#endif
-                    Ct = Sym3{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-                    have_ct = true;
-                    c1.w = __uint_as_float(nn.pos);
-                }
-#if !(defined(SP_EXP) && (SP_EXP & 1))  // measurement build: no refresh of the cache row
-                row[0] = make_float4(nn.x, nn.y, nn.z, __int_as_float(nn.idx));
-                row[1] = c0;
-                row[2] = c1;
-#endif
-            }
+    Sym3 Ct{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool hit = false;
+    float4* const row = P.ccache ? P.ccache + 3 * (size_t)i : nullptr;
+    if (row && P.cache_valid) {
+        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        const float d = dist2(qx, qy, qz, r0.x, r0.y, r0.z);
+        const unsigned pos = __float_as_uint(r2.w);
+        if (P.cache_valid == 2 ? r0.w >= 0.0f : certified(P, d, r0.w, qx, qy, qz, pos)) {
+            hit = true;
+            nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
+            nn.d2 = nn.idx >= 0 ? d : FLT_MAX;
+            Ct = Sym3{r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
         }
     }
-    if (DBG == 1 || DBG == 3) { acc[27] += nn.d2 + nn.x; ++cnt; return; }  // timing experiment: search only
+    if (!hit) {
+        ++searched;
+        const float bound2 = search_bound2(P);
+        if (FAST_NN) {
+            if (COMPACT_NN) {
+                // the streaming launch of the device-resident loop: its searches are stragglers (the search launch takes the
+                // bulk), so the stages after the exact 2x2x2 block are the plain ring walk seeded with that block's winner —
+                // the same answer as the batched stages (exact, ties to the lowest index), in far fewer registers, which
+                // this kernel needs for its 28 accumulators
+                if (!grid_nn1_fast<4>(P.tpts, P.tstart, P.g, qx, qy, qz, nn, bound2)) {
+                    const Nearest seed = nn;
+                    nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 0);
+                }
+            } else {
+                nn = grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz, bound2);
+            }
+        } else {
+            Nearest seed;
+            seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f;
+            nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 0);
+        }
+        if (row) store_correspondence(row, P, nn, Ct);
+        else if (nn.idx >= 0) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
+    }
     if (P.nn_idx) {
         const unsigned o = P.perm[i];
         P.nn_idx[o] = nn.idx;
@@ -887,11 +928,10 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
     const size_t st = P.sstride;
     const Sym3 Cs = P2D ? Sym3{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}
                         : Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
-    if (!have_ct) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
     fused_math<LOSS, P2D>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
 }
 
-template <int LOSS, bool FAST_NN, int DBG = 0, bool P2D = false>
+template <int LOSS, bool FAST_NN, bool P2D = false>
 __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float* __restrict__ partials) {
     const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);
     float acc[kAcc - 1];
@@ -899,7 +939,7 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
     unsigned cnt = 0, searched = 0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock)
-        fused_point<LOSS, FAST_NN, DBG, P2D>(P, T, i, acc, cnt, searched);
+        fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
     block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
 }
 
@@ -911,23 +951,24 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
 // 168 B per point and decomposes two covariances per point). The inlier gate uses the distance at the LINEARISATION pose
 // T_lin (nn_d2 in the reference), recomputed here with the search's own arithmetic, i.e. the same bits.
 template <int LOSS, bool P2D>
-__global__ __launch_bounds__(kBlock) void error_prepared_kernel(FusedParams P, Mat4Arg T_lin_val, float* __restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void error_prepared_kernel(FusedParams P, Mat4Arg T_lin_val, const float* T_lin_dev,
+                                                                float* __restrict__ partials) {
     const Rigid T = load_rigid_colmajor(P.T_dev ? P.T_dev : P.T_val.m);  // trial pose
-    const Rigid TL = load_rigid_colmajor(T_lin_val.m);
+    const Rigid TL = load_rigid_colmajor(T_lin_dev ? T_lin_dev : T_lin_val.m);
     float acc[1] = {0.0f};
     unsigned cnt = 0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock) {
         const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
         const float4* const row = P.ccache + 3 * (size_t)i;
         const float4 tp = row[0], c0 = row[1], c1 = row[2];
-        if (__float_as_int(tp.w) < 0) continue;  // no neighbour found
+        if (__float_as_int(c1.z) < 0) continue;  // no neighbour found
         float lx, ly, lz;
         transform_point(TL, s.x, s.y, s.z, lx, ly, lz);
         if (dist2(lx, ly, lz, tp.x, tp.y, tp.z) > P.max_d2) continue;  // registration.hpp:716-718
         float qx, qy, qz;
         transform_point(T, s.x, s.y, s.z, qx, qy, qz);
         Nearest nn;
-        nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = __float_as_int(tp.w); nn.pos = 0; nn.d2 = 0.0f;
+        nn.x = tp.x; nn.y = tp.y; nn.z = tp.z; nn.idx = __float_as_int(c1.z); nn.pos = 0; nn.d2 = 0.0f;
         const float* const cp = P.scovp + i;
         const size_t st = P.sstride;
         Sym3 Cs{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -939,134 +980,149 @@ __global__ __launch_bounds__(kBlock) void error_prepared_kernel(FusedParams P, M
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Whole alignment on the device (Registration::align's Gauss-Newton loop, registration.hpp:229-276, one launch per
-// iteration and no second kernel in between): launch k first finishes iteration k-1 — EVERY workgroup sums the
-// previous launch's <= 256 partial rows (32 KB, L2-resident, fixed order) and solves the same 6x6 system, so all of
-// them hold the identical new pose without a grid-wide synchronisation — and then linearises at that pose.
-// Partials and the small state block ping-pong between launches; workgroup 0 publishes state / system / delta.
+// Whole alignment on the device (Registration::align's Gauss-Newton loop, registration.hpp:229-276), no host round trip:
+// pose, convergence flag and iteration count live in a small state block in HBM that ping-pongs between iterations.
+//
+//   iteration k = [ gicp_search_kernel ]  ->  gicp_align_kernel   (-> all-reduce -> align_solve_kernel, sharded runs)
+//
+// gicp_align_kernel streams the source once: per point the cached correspondence (certified, or on trust when the search
+// launch ran before it; stragglers are searched inline), linearisation, 28 sums in registers, one 32-float partial row per
+// workgroup. On one GPU the workgroup whose arrival ticket is the last one then finishes the iteration by itself: it sums the
+// launch's <= 256 rows in a fixed order, solves (H + lambda I) delta = -b, updates the pose and publishes the next state —
+// so the next launch starts from 18 words instead of summing 32 KB and solving a 6x6 system in every one of its workgroups.
 // Once is_converged() holds, the remaining launches return immediately (the reference breaks out of its loop).
+//
+// gicp_search_kernel (the first launches of an alignment, sp_gicp_source_set_search_launches): the points whose cached
+// correspondence is NOT certified for this iteration's pose are the expensive ones — a search is a chain of dependent
+// gathers, and inside the streaming kernel it runs in waves where only the uncertified lanes work, under a register
+// budget sized for 28 accumulators. Here they are compacted (per workgroup, through LDS) and the exact first block of each
+// is scanned on dense waves, two queries per lane in lockstep, from the target's block rows (grid_device.h: the block is ONE
+// contiguous run there). A winner that the block proves goes to the cache with its prepared rows; the rest (about one in
+// eight) is only marked, and the streaming launch walks the later stages for them beside its stream. The kernel refreshes
+// cache rows and nothing else; the streaming launch that follows linearises EVERY point in its usual order, so sums and
+// poses are bit-identical with and without it.
 constexpr int kAlignBlock = 1024;      // 16 waves: one workgroup per CU at 4 waves/SIMD -> 256 partial rows
 constexpr int kAlignMaxBlocks = 256;
-constexpr int kSearchedLog = 64;       // launches of an alignment whose searched-point counts are kept (measurement)
+constexpr int kSearchedLog = 64;       // launches of an alignment whose searched-point counts are kept
+constexpr int kSearchBlock = 256;
+constexpr int kSearchChunk = 512;      // source points per workgroup of the search launch (two per lane)
+constexpr int kSearchShards = 32;
+constexpr float kUnresolved = -1.0f;   // rho^2 of a cache row the search launch left to the streaming launch
+constexpr size_t kBlockRowsMinPoints = 65536;       // targets below this get no block rows (and no search launches)
+constexpr double kBlockRowsPointsPerCell = 2.0;
 
 struct AlignState {
-    float T[16];
+    float T[16];          // pose after the iterations finished so far
+    float T_lin[16];      // pose of the latest linearisation: the correspondence cache is exact for it
     float delta[8];
     unsigned converged;   // is_converged() held for the step that produced T
     unsigned iterations;  // Gauss-Newton steps applied so far
-    unsigned searched;    // source points the last finished launch had to search for (the others reused their correspondence)
+    unsigned searched;    // source points the last finished iteration had to search for (the others reused their correspondence)
     unsigned pad;
 };
+constexpr int kStateWords = sizeof(AlignState) / 4;
+constexpr int kStateFlagWord = 40;     // word index of AlignState::converged (iterations follows)
+static_assert(offsetof(AlignState, converged) == 4 * kStateFlagWord, "AlignState layout");
+
+enum { ALIGN_TAIL_SOLVE = 0, ALIGN_ROWS = 1, ALIGN_FANIN = 2 };
 
 struct AlignArgs {
-    const float* T_init;         // read by launch 0
-    const AlignState* state_in;  // launches k > 0
-    AlignState* state_out;
-    const float* prev_partials;
-    unsigned prev_rows;
+    const float* T_init;         // iteration 0
+    const AlignState* state_in;  // state after iteration k - 1 (k > 0)
+    AlignState* state_out;       // state after iteration k
     int has_prev;
     float lambda, crit_rot, crit_trans;
     sp_linearized* lin_out;      // system of the last finished iteration (may be null)
-    int count_is_float;          // partial rows are all-reduced between launches (multi-GPU): counts travel as floats
-    unsigned* searched_log;      // [launch index] -> points that launch searched for (written by the next launch / finish)
-    int k;                       // index of this launch in its alignment
-    // Fan-in (sharded loop, one 128-byte row per rank): the workgroup whose arrival ticket is the last sums this launch's
-    // rows in the prologue's fixed order and writes ONE row; the caller all-reduces it over the ranks and the next launch
-    // reads it instead of summing 256 rows.
-    int fanin;
-    float* fan_row_out;          // this launch's row (kFanRow floats)
-    const float* fan_row_in;     // the previous launch's row, all-reduced over the ranks
+    // How iteration k is finished: ALIGN_TAIL_SOLVE the launch's last-arriving workgroup sums its rows and solves (one GPU);
+    // ALIGN_FANIN that workgroup writes ONE 128-byte row, the caller all-reduces it over the ranks and align_solve_kernel
+    // finishes; ALIGN_ROWS the caller all-reduces all partial rows (counts travel as floats), then align_solve_kernel.
+    int mode;
+    unsigned* searched_log;      // [iteration] -> source points searched for
+    int k;                       // index of this iteration in its alignment
+    int search_launch;           // a gicp_search_kernel was enqueued for this iteration
+    unsigned min_defer;          // ... and it runs (and this launch trusts it) iff iteration k - 1 searched at least this many
+    float* fan_row_out;          // this iteration's row (kFanRow floats)
+    const float* fan_row_in;     // align_solve_kernel: the same row, all-reduced over the ranks
     unsigned* fan_counter;       // arrival tickets; 0 when a launch starts, reset by the last arriver
+    unsigned* search_shards;     // the search launch's counters (SearchArgs)
 };
 // Row of the fan-in: 0..27 the sums, 28 / 29 the inlier count as two floats that stay exact under a float sum over ranks
 // (count = hi * 4096 + lo, as sp_linearized carries it), 30 the searched-point count (a float value), 31 unused.
 constexpr int kFanRow = 32;
 
-// Finishes iteration k-1 (or loads the initial pose) and leaves the pose in sT (LDS). Returns false when this launch
-// has nothing more to do.
-__device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT) {
-    __shared__ float red[kFinalThreads / 32][kPartial];
-    __shared__ sp_linearized slin;
-    __shared__ float sdelta[8];
-    __shared__ unsigned sconv;
-    __shared__ LdltScratch ldlt_ws;
-    if (A.has_prev) {
-        // The previous state (pose, flags: lanes 0..17 of wave 0) is loaded BEFORE the partial rows and stored to LDS
-        // AFTER the row loads have been issued, so the prologue is ONE memory round trip deep, not three.
-        __shared__ unsigned sprev[2];
-        float pre = 0.0f;
-        if (threadIdx.x < 18)
-            pre = reinterpret_cast<const float*>(A.state_in)[threadIdx.x < 16 ? threadIdx.x : threadIdx.x + 8];
-        if (A.fanin) {
-            // the previous launch's last-arriving workgroup already summed its rows (fanin_reduce) and the caller all-reduced
-            // that ONE row over the ranks: 32 words to read instead of 32 KB to sum
-            const float rv = threadIdx.x < kFanRow ? A.fan_row_in[threadIdx.x] : 0.0f;
-            if (threadIdx.x < 16) sT[threadIdx.x] = pre;
-            else if (threadIdx.x < 18) sprev[threadIdx.x - 16] = __float_as_uint(pre);
-            if (threadIdx.x < kFanRow) red[1][threadIdx.x] = rv;
-            __syncthreads();
-            if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
-            else if (threadIdx.x == kAcc - 1)  // the count, folded as integers: exact (gn_update_impl's rule)
-                red[0][kAcc - 1] = __uint_as_float((unsigned)red[1][kAcc] * 4096u + (unsigned)red[1][kAcc - 1]);
-            else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points (a float value)
-            __syncthreads();
-        } else {
-            reduce_rows_1024(A.prev_partials, A.prev_rows, kAcc - 1, red, A.count_is_float != 0, [&] {
-                if (threadIdx.x < 16) sT[threadIdx.x] = pre;
-                else if (threadIdx.x < 18) sprev[threadIdx.x - 16] = __float_as_uint(pre);  // converged, iterations
-            });
+// Does the search launch of iteration k run? Uniform over both grids (the search kernel and the streaming kernel evaluate it
+// on the same data): always for k = 0; later only while the previous iteration still searched a noticeable share of its
+// points — afterwards the few stragglers are cheaper inline than two more launches.
+__device__ __forceinline__ bool search_launch_runs(const unsigned* searched_log, int k, unsigned min_defer) {
+    return k == 0 || (k <= kSearchedLog && searched_log[k - 1] >= min_defer);
+}
+
+// Pose (-> sT) and flags (-> sflag: converged, iterations) of this iteration. Returns false when an earlier iteration
+// converged: workgroup 0 then carries the state forward and the launch has nothing to do.
+__device__ __forceinline__ bool align_begin(const float* T_init, const AlignState* state_in, AlignState* state_out,
+                                            int has_prev, float* sT, unsigned* sflag, float* zero_row = nullptr) {
+    if (has_prev) {
+        if (threadIdx.x < 18) {
+            const unsigned v = reinterpret_cast<const unsigned*>(state_in)[threadIdx.x < 16 ? threadIdx.x
+                                                                                             : kStateFlagWord + threadIdx.x - 16];
+            if (threadIdx.x < 16) sT[threadIdx.x] = __uint_as_float(v);
+            else sflag[threadIdx.x - 16] = v;
         }
-        if (sprev[0]) {  // uniform over the grid: an earlier iteration converged, this launch has nothing to do
-            if (blockIdx.x == 0 && threadIdx.x == 0) *A.state_out = *A.state_in;
-            return false;
-        }
-        if (threadIdx.x == 0) {
-            unpack_totals(red[0], kAcc - 1, &slin);
-            gn_update_impl(&slin, sT, A.lambda, A.crit_rot, A.crit_trans, sdelta, false, ldlt_ws);
-            sconv = sdelta[6] > 0.5f ? 1u : 0u;
-            if (blockIdx.x == 0) {
-                AlignState* so = A.state_out;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) so->T[i] = sT[i];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) so->delta[i] = sdelta[i];
-                so->converged = sconv;
-                so->iterations = sprev[1] + 1;
-                so->searched = (unsigned)red[0][kAcc];
-                if (A.searched_log && A.k > 0 && A.k <= kSearchedLog) A.searched_log[A.k - 1] = so->searched;
-                if (A.lin_out) *A.lin_out = slin;
-            }
-        }
-        __syncthreads();
-        return sconv == 0;  // converged: no further linearisation (registration.hpp:266-268)
+    } else {
+        if (threadIdx.x < 16) sT[threadIdx.x] = T_init[threadIdx.x];
+        else if (threadIdx.x < 18) sflag[threadIdx.x - 16] = 0u;
     }
-    if (threadIdx.x < 16) sT[threadIdx.x] = A.T_init[threadIdx.x];
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        AlignState* so = A.state_out;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) so->T[i] = sT[i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) so->delta[i] = 0.0f;
-        so->converged = 0;
-        so->iterations = 0;
-        so->searched = 0;
+    if (sflag[0]) {  // uniform over the grid
+        if (blockIdx.x == 0 && state_out) {
+            if (threadIdx.x < kStateWords)
+                reinterpret_cast<unsigned*>(state_out)[threadIdx.x] = reinterpret_cast<const unsigned*>(state_in)[threadIdx.x];
+            if (zero_row && threadIdx.x < kFanRow) zero_row[threadIdx.x] = 0.0f;  // a finished rank adds nothing to the all-reduce
+        }
+        return false;
     }
     return true;
 }
 
-// Fan-in of one launch's partial rows to ONE row (MI355X_MICROARCH.md "fanin", cdna_hip_programming.md Guideline 16, the
-// counter form with sc1 loads in place of an acquire; every condition of its table row holds):
+// One thread: totals of iteration k (red0: 28 sums, the uint32 count, the searched count as a float value) at pose sT ->
+// solve_linear_system + pose update + is_converged (registration.hpp:791-828, 407-410) -> state after iteration k.
+__device__ __forceinline__ void align_finish_iteration(const AlignArgs& A, const float* red0, const float* sT,
+                                                       unsigned prev_iterations, unsigned searched, sp_linearized& slin,
+                                                       float* sTn, float* sdelta, LdltScratch& ldlt_ws) {
+    unpack_totals(red0, kAcc - 1, &slin);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sTn[i] = sT[i];
+    gn_update_impl(&slin, sTn, A.lambda, A.crit_rot, A.crit_trans, sdelta, false, ldlt_ws);
+    AlignState* so = A.state_out;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { so->T[i] = sTn[i]; so->T_lin[i] = sT[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) so->delta[i] = sdelta[i];
+    so->converged = sdelta[6] > 0.5f ? 1u : 0u;
+    so->iterations = prev_iterations + 1;
+    so->searched = searched;
+    so->pad = 0;
+    if (A.lin_out) *A.lin_out = slin;
+}
+
+// End of a streaming launch in the ALIGN_TAIL_SOLVE / ALIGN_FANIN modes (MI355X_MICROARCH.md "fanin",
+// cdna_hip_programming.md Guideline 16, the counter form with sc1 loads in place of an acquire; every condition of its table
+// row holds):
 //   * every word of the rows was stored write-through (store_row_word<true>: global_store ... sc1) by lanes of wave 0,
 //   * wave 0 drains its stores (s_waitcnt vmcnt(0)) and only then lane 0 takes an agent-scope ticket,
 //   * the workgroup whose ticket is the last one learns it from the value its add returned, tells its other waves through
 //     LDS + barrier, and reads every row with sc1 loads (never a plain load of another workgroup's bytes),
 //   * no fence, no spin: a workgroup either leaves or sums — nothing waits for a workgroup that has not been dispatched.
-// The sum is reduce_rows_1024's fixed order over the same `grid` rows the next launch's prologue would sum on one GPU: the
-// row is bit-identical to that 256-row sum. The last arriver resets the ticket counter for the next launch.
-__device__ __forceinline__ void fanin_reduce(const AlignArgs& A, const float* __restrict__ partials) {
+// The sum is reduce_rows_1024's fixed order over the launch's `grid` rows: bit-reproducible, and the same bits in both modes.
+// The last arriver resets the ticket counter for the next launch.
+__device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __restrict__ partials, const float* sT,
+                                           const unsigned* sflag, bool trusted) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ unsigned s_last;
+    __shared__ sp_linearized slin;
+    __shared__ float sTn[16];
+    __shared__ float sdelta[8];
+    __shared__ LdltScratch ldlt_ws;
     if (threadIdx.x < kWave) {  // the storing lanes (0 .. kAcc) all sit in wave 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
@@ -1077,14 +1133,38 @@ __device__ __forceinline__ void fanin_reduce(const AlignArgs& A, const float* __
     __syncthreads();
     if (!s_last) return;  // uniform per workgroup
     reduce_rows_1024<true>(partials, gridDim.x, kAcc - 1, red, false);
-    if (threadIdx.x < kFanRow) {
-        const unsigned cnt = __float_as_uint(red[0][kAcc - 1]);
-        float v = 0.0f;
-        if (threadIdx.x < kAcc - 1) v = red[0][threadIdx.x];
-        else if (threadIdx.x == kAcc - 1) v = (float)(cnt & 4095u);
-        else if (threadIdx.x == kAcc) v = (float)(cnt >> 12);
-        else if (threadIdx.x == kAcc + 1) v = red[0][kAcc];
-        A.fan_row_out[threadIdx.x] = v;
+    // points this iteration searched for: counted by the search launch when it ran (its shards are summed and cleared here),
+    // by this launch's lanes otherwise
+    const bool log_k = A.searched_log && A.k < kSearchedLog;
+    if (trusted) {
+        unsigned v = threadIdx.x < kSearchShards ? __hip_atomic_load(A.search_shards + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (threadIdx.x < kWave) {
+            v = wave_sum_u32(v);
+            if (threadIdx.x < kSearchShards) A.search_shards[threadIdx.x] = 0u;
+            if (threadIdx.x == 0) {
+                red[1][0] = __uint_as_float(v);
+                if (log_k) A.searched_log[A.k] = v;
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned searched_by_launch = trusted ? __float_as_uint(red[1][0]) : 0u;
+    if (A.mode == ALIGN_FANIN) {
+        if (threadIdx.x < kFanRow) {
+            const unsigned cnt = __float_as_uint(red[0][kAcc - 1]);
+            float v = 0.0f;
+            if (threadIdx.x < kAcc - 1) v = red[0][threadIdx.x];
+            else if (threadIdx.x == kAcc - 1) v = (float)(cnt & 4095u);
+            else if (threadIdx.x == kAcc) v = (float)(cnt >> 12);
+            else if (threadIdx.x == kAcc + 1) v = trusted ? (float)searched_by_launch : red[0][kAcc];
+            A.fan_row_out[threadIdx.x] = v;
+        }
+        if (threadIdx.x == 0 && !trusted && log_k) A.searched_log[A.k] = (unsigned)red[0][kAcc];
+    } else if (threadIdx.x == 0) {
+        unsigned searched = (unsigned)red[0][kAcc];
+        if (trusted) searched = searched_by_launch;
+        else if (log_k) A.searched_log[A.k] = searched;
+        align_finish_iteration(A, red[0], sT, sflag[1], searched, slin, sTn, sdelta, ldlt_ws);
     }
     if (threadIdx.x == 0) __hip_atomic_store(A.fan_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1093,15 +1173,13 @@ template <int LOSS, bool FAST_NN, bool P2D = false>
 __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, AlignArgs A,
                                                                  float* __restrict__ partials) {
     __shared__ float sT[16];
-#ifdef SP_KERNEL_TIMING  // diagnostic build only (make timing): s_memtime stamps of workgroup 0, after the two state blocks
-    unsigned long long* tm =
-        reinterpret_cast<unsigned long long*>(const_cast<AlignState*>(A.state_in < A.state_out ? A.state_in : A.state_out) + 2);
-    if (blockIdx.x == 0 && threadIdx.x == 0) tm[0] = __builtin_amdgcn_s_memtime();  // kernel-side start
-#endif
-    if (!align_prologue(A, sT)) return;
-#ifdef SP_KERNEL_TIMING
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) tm[1 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime();  // prologue done
-#endif
+    __shared__ unsigned sflag[2];
+    if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag,
+                     A.mode == ALIGN_FANIN ? A.fan_row_out : nullptr))
+        return;
+    // the search launch ran for this pose: every cache row is exact, nothing to certify or search
+    const bool trusted = A.search_launch && search_launch_runs(A.searched_log, A.k, A.min_defer);
+    if (trusted) P.cache_valid = 2;
     // the pose is uniform: move it to scalar registers (it would otherwise occupy 12 VGPRs for the whole loop)
     Rigid T = load_rigid_colmajor(sT);
     auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -1121,66 +1199,255 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     unsigned tile = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-        fused_point<LOSS, FAST_NN, 0, P2D>(P, T, i, acc, cnt, searched);
-#ifdef SP_KERNEL_TIMING
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) tm[17 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime();  // point loop done
-#endif
-    if (A.fanin) {
-        block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
-        fanin_reduce(A, partials);
+        fused_point<LOSS, FAST_NN, P2D, true>(P, T, i, acc, cnt, searched);
+    if (A.mode == ALIGN_ROWS) {
+        block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, true, searched);
     } else {
-        block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, A.count_is_float != 0,
-                                                  searched);
+        block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
+        align_tail(A, partials, sT, sflag, trusted);
     }
-#ifdef SP_KERNEL_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0) tm[33] = __builtin_amdgcn_s_memtime();  // workgroup reduction done
-#endif
 }
 
-// After the last launch: finish the last iteration (unless an earlier one converged) and publish the results.
-__global__ __launch_bounds__(kFinalThreads) void align_finish_kernel(const float* __restrict__ partials, unsigned rows,
-                                                                     const AlignState* __restrict__ state_in,
-                                                                     float lambda, float crit_rot, float crit_trans,
-                                                                     float* __restrict__ T_out,
-                                                                     sp_linearized* __restrict__ lin_out,
-                                                                     float* __restrict__ delta_out8,
-                                                                     uint32_t* __restrict__ iterations_out,
-                                                                     int count_is_float, unsigned* searched_log,
-                                                                     int last_k, const float* __restrict__ fan_row) {
+// Sharded runs: finishes iteration k on every rank from the all-reduced row (ALIGN_FANIN) or rows (ALIGN_ROWS) — the same
+// sums, the same solve, hence the identical pose on every rank without a broadcast. One workgroup.
+__global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A, const float* __restrict__ rows,
+                                                                    unsigned nrows) {
     __shared__ float red[kFinalThreads / 32][kPartial];
-    __shared__ sp_linearized slin;
     __shared__ float sT[16];
+    __shared__ unsigned sflag[2];
+    __shared__ sp_linearized slin;
+    __shared__ float sTn[16];
     __shared__ float sdelta[8];
     __shared__ LdltScratch ldlt_ws;
-    const bool conv = state_in->converged != 0;
-    if (!conv && fan_row) {  // the last launch's fan-in row, all-reduced over the ranks (see align_prologue)
-        if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = fan_row[threadIdx.x];
-        else if (threadIdx.x == kAcc - 1)
-            red[0][kAcc - 1] = __uint_as_float((unsigned)fan_row[kAcc] * 4096u + (unsigned)fan_row[kAcc - 1]);
-        else if (threadIdx.x == kAcc) red[0][kAcc] = fan_row[kAcc + 1];
+    if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag)) return;
+    if (A.mode == ALIGN_FANIN) {
+        if (threadIdx.x < kFanRow) red[1][threadIdx.x] = A.fan_row_in[threadIdx.x];
         __syncthreads();
-    } else if (!conv) {
-        reduce_rows_1024(partials, rows, kAcc - 1, red, count_is_float != 0);
+        if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
+        else if (threadIdx.x == kAcc - 1)  // the count, folded as integers: exact
+            red[0][kAcc - 1] = __uint_as_float((unsigned)red[1][kAcc] * 4096u + (unsigned)red[1][kAcc - 1]);
+        else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points, all ranks (a float value)
+        __syncthreads();
+    } else {
+        reduce_rows_1024(rows, nrows, kAcc - 1, red, true);
     }
     if (threadIdx.x == 0) {
-        unsigned iters = state_in->iterations;
+        const unsigned searched = (unsigned)red[0][kAcc];
+        if (A.mode == ALIGN_ROWS && A.searched_log && A.k < kSearchedLog) A.searched_log[A.k] = searched;
+        align_finish_iteration(A, red[0], sT, sflag[1], searched, slin, sTn, sdelta, ldlt_ws);
+    }
+}
+
+// After the last iteration: the results out of the state block.
+__global__ void align_publish_kernel(const AlignState* __restrict__ state, float* __restrict__ T_out,
+                                     float* __restrict__ delta_out8, uint32_t* __restrict__ iterations_out) {
+    if (threadIdx.x < 16) T_out[threadIdx.x] = state->T[threadIdx.x];
+    else if (threadIdx.x < 24 && delta_out8) delta_out8[threadIdx.x - 16] = state->delta[threadIdx.x - 16];
+    else if (threadIdx.x == 24 && iterations_out) *iterations_out = state->iterations;
+}
+
+struct SearchArgs {
+    const float* T_init;
+    const AlignState* state_in;
+    int has_prev;
+    const unsigned* searched_log;
+    unsigned* search_shards;  // kSearchShards counters: points this launch searched for (summed and cleared by the streaming launch)
+    int k;
+    unsigned min_defer;
+};
+
+// One workgroup = kSearchChunk consecutive source points, two per lane. A search is a chain of dependent gathers (point ->
+// run extent -> candidates -> winner's rows), and a workgroup is as many memory round trips deep as its longest lane
+// whatever its size: the kernel then takes that long however few points need a search. So every stage is run for BOTH of a
+// lane's queries before the next one starts — their loads are in flight together and a stage costs one round trip per
+// workgroup, not one per query — and nothing deeper than the first block is walked here.
+__global__ __launch_bounds__(kSearchBlock) void gicp_search_kernel(FusedParams P, SearchArgs A) {
+    constexpr int Q = kSearchChunk / kSearchBlock;  // queries per lane and stage
+    __shared__ float sT[16];
+    __shared__ unsigned sflag[2];
+    __shared__ unsigned q1[kSearchChunk];  // uncertified points of this chunk
+    __shared__ unsigned n1;
+    if (threadIdx.x == 32) n1 = 0;
+    if (!align_begin(A.T_init, A.state_in, nullptr, A.has_prev, sT, sflag)) return;
+    if (!search_launch_runs(A.searched_log, A.k, A.min_defer)) return;  // uniform: the streaming launch searches inline
+    Rigid T = load_rigid_colmajor(sT);
+    auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sT[i] = state_in->T[i];
+    for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sdelta[i] = state_in->delta[i];
-        if (!conv) {
-            unpack_totals(red[0], kAcc - 1, &slin);
-            gn_update_impl(&slin, sT, lambda, crit_rot, crit_trans, sdelta, false, ldlt_ws);
-            if (lin_out) *lin_out = slin;
-            if (searched_log && last_k < kSearchedLog) searched_log[last_k] = (unsigned)red[0][kAcc];
-            ++iters;
+        for (int c = 0; c < 3; ++c) T.R[r][c] = uniform(T.R[r][c]);
+        T.t[r] = uniform(T.t[r]);
+    }
+    const unsigned base = blockIdx.x * kSearchChunk;
+    const unsigned lane = threadIdx.x & (kWave - 1);
+    const unsigned last = P.n - 1;  // P.n >= 1 (the launch has a workgroup)
+    // wave-aggregated append to a queue in LDS: one LDS atomic per wave, lanes take consecutive slots
+    auto append = [&](bool want, unsigned* counter) -> unsigned {
+        const unsigned long long mask = __ballot(want);
+        const int leader = mask ? __builtin_ctzll(mask) : 0;
+        unsigned b = 0;
+        if (mask != 0ull && lane == (unsigned)leader) b = atomicAdd(counter, (unsigned)__popcll(mask));
+        b = (unsigned)__shfl((int)b, leader, kWave);
+        return b + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    };
+    // ---- 1. which points need a search: all of them while the cache is empty, else those whose certificate fails at this pose
+    {
+        unsigned i[Q];
+        bool fail[Q];
+        float4 r0[Q];
+        float sx[Q], sy[Q], sz[Q];
+        unsigned pos[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            i[j] = base + j * kSearchBlock + threadIdx.x;
+            fail[j] = i[j] < P.n;
+            pos[j] = 0;
+            if (P.cache_valid) {
+                const unsigned ic = min(i[j], last);
+                r0[j] = P.ccache[3 * (size_t)ic];
+                sx[j] = P.src[ic]; sy[j] = P.src[P.sstride + ic]; sz[j] = P.src[2 * (size_t)P.sstride + ic];
+                if (P.tnb) pos[j] = __float_as_uint(reinterpret_cast<const float*>(P.ccache + 3 * (size_t)ic + 2)[3]);
+            }
+        }
+        if (P.cache_valid) {
+            float qx[Q], qy[Q], qz[Q], d[Q];
+            bool second[Q];
+            float4 nb[Q];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                transform_point(T, sx[j], sy[j], sz[j], qx[j], qy[j], qz[j]);
+                d[j] = dist2(qx[j], qy[j], qz[j], r0[j].x, r0[j].y, r0[j].z);
+                const bool pass = d[j] < r0[j].w;
+                second[j] = fail[j] && !pass && P.tnb && r0[j].w > 0.0f;  // the second certificate: one more gather
+                fail[j] = fail[j] && !pass;
+                if (second[j]) nb[j] = P.tnb[pos[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+                if (second[j] && d[j] < nb[j].w && d[j] < dist2(qx[j], qy[j], qz[j], nb[j].x, nb[j].y, nb[j].z)) fail[j] = false;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) T_out[i] = sT[i];
-        if (delta_out8)
-            for (int i = 0; i < 8; ++i) delta_out8[i] = sdelta[i];
-        if (iterations_out) *iterations_out = iters;
+        for (int j = 0; j < Q; ++j) {
+            const unsigned slot = append(fail[j], &n1);
+            if (fail[j]) q1[slot] = i[j];
+        }
     }
+    __syncthreads();
+    const unsigned c1 = n1;
+    if (c1 == 0u) return;  // uniform per workgroup: every point of this chunk is certified
+    const float bound2 = search_bound2(P);
+    const unsigned long long none = nn_key(bound2, -1);
+    // ---- 2. the exact 2x2x2 block of every queued point as ONE contiguous run of the target's block rows, Q queries per
+    //         lane in lockstep: proven winners go to the cache with their prepared rows, the others are queued with their bound
+    {
+        unsigned i[Q];
+        bool act[Q];
+        float qx[Q], qy[Q], qz[Q], cov[Q];
+        unsigned rs[Q], re[Q];
+        {
+            float sx[Q], sy[Q], sz[Q];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const unsigned e = j * kSearchBlock + threadIdx.x;
+                act[j] = e < c1;
+                i[j] = act[j] ? q1[e] : 0u;
+                sx[j] = P.src[i[j]]; sy[j] = P.src[P.sstride + i[j]]; sz[j] = P.src[2 * (size_t)P.sstride + i[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                transform_point(T, sx[j], sy[j], sz[j], qx[j], qy[j], qz[j]);
+                const bool usable = act[j] && isfinite(qx[j]) && isfinite(qy[j]) && isfinite(qz[j]);
+                // (a non-finite or idle query reads the first run and is given an empty one)
+                block_extent(P.bstart, P.b, usable ? qx[j] : P.b.ox, usable ? qy[j] : P.b.oy, usable ? qz[j] : P.b.oz, rs[j], re[j],
+                             cov[j]);
+                act[j] = usable;
+            }
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+                if (!act[j]) re[j] = rs[j];
+        }
+        // (squared distance, position) as one 64-bit key: its minimum is the nearest candidate. Exactly equidistant candidates
+        // must resolve to the lowest ORIGINAL index like every other search here; the key would pick the lowest position, so a
+        // tie at the running minimum is flagged and settled below (it takes duplicate target points to get there).
+        unsigned long long key[Q];
+        bool tie[Q];
+        unsigned most = 0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { key[j] = none; tie[j] = false; most = max(most, re[j] - rs[j]); }
+        constexpr int B = 8;  // candidates per query and round trip
+        const unsigned bend = 4u * P.g.n - 1u;
+        for (unsigned b0 = 0; b0 < most; b0 += B) {
+            float4 cand[Q][B];
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+#pragma unroll
+                for (int c = 0; c < B; ++c) cand[j][c] = P.bpts[min(rs[j] + b0 + c, bend)];
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+#pragma unroll
+                for (int c = 0; c < B; ++c) {
+                    const float d = dist2(qx[j], qy[j], qz[j], cand[j][c].x, cand[j][c].y, cand[j][c].z);
+                    unsigned long long k2 = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cand[j][c].w);
+                    k2 = (rs[j] + b0 + c < re[j]) ? k2 : ~0ull;
+                    const unsigned hi_new = (unsigned)(k2 >> 32), hi_old = (unsigned)(key[j] >> 32);
+                    tie[j] = hi_new < hi_old ? false : (tie[j] || (hi_new == hi_old && k2 != ~0ull && key[j] != none));
+                    key[j] = k2 < key[j] ? k2 : key[j];
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            if (tie[j]) {  // rare: among the candidates at the winning distance take the lowest original index
+                const unsigned dbits = (unsigned)(key[j] >> 32);
+                int best_idx = 0x7fffffff;
+                unsigned best_pos = (unsigned)key[j];
+                for (unsigned b = rs[j]; b < re[j]; ++b) {
+                    const float4 c = P.bpts[b];
+                    if (__float_as_uint(dist2(qx[j], qy[j], qz[j], c.x, c.y, c.z)) != dbits) continue;
+                    const int idx = __float_as_int(P.tpts[__float_as_uint(c.w)].w);
+                    if (idx < best_idx) { best_idx = idx; best_pos = __float_as_uint(c.w); }
+                }
+                key[j] = ((unsigned long long)dbits << 32) | best_pos;
+            }
+        }
+        // winners: the point (x, y, z, index) and, when it is proven, its prepared rows — one round trip for all
+        bool found[Q], proven[Q];
+        unsigned pos[Q];
+        float4 w[Q], c0[Q], c1r[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            found[j] = key[j] != none;
+            pos[j] = found[j] ? min((unsigned)key[j], P.g.n - 1u) : 0u;
+            const float d2 = found[j] ? __uint_as_float((unsigned)(key[j] >> 32)) : bound2;
+            const float cv = fmaxf(cov[j] * P.b.h - P.b.eps, 0.0f);
+            // an idle slot and a non-finite query are "proven": nothing to find (grid_nn1_fast)
+            proven[j] = !act[j] || d2 < cv * cv;
+            w[j] = P.tpts[pos[j]];
+            if (found[j] && proven[j]) { c0[j] = P.tcovp[2 * (size_t)pos[j]]; c1r[j] = P.tcovp[2 * (size_t)pos[j] + 1]; }
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const bool queued = j * kSearchBlock + threadIdx.x < c1;
+            if (!queued) continue;
+            float4* const row = P.ccache + 3 * (size_t)i[j];
+            if (!proven[j]) {
+                // The stages after the first block are a long chain of dependent gathers: a workgroup that walked it for a
+                // handful of points would hold the whole launch for its length. The streaming launch hides such chains behind
+                // its stream, so the point is only marked for it (rho^2 < 0: "search me", kUnresolved).
+                row[0] = make_float4(0.0f, 0.0f, 0.0f, kUnresolved);
+            } else if (found[j]) {
+                row[0] = make_float4(w[j].x, w[j].y, w[j].z, c1r[j].z);
+                row[1] = c0[j];
+                row[2] = make_float4(c1r[j].x, c1r[j].y, w[j].w, __uint_as_float(pos[j]));
+            } else {
+                row[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                row[1] = row[0];
+                row[2] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+            }
+        }
+    }
+    // (sharded: two thousand adds to ONE word would take longer than the searches, ~12 ns apiece)
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(A.search_shards + (blockIdx.x & (kSearchShards - 1)), c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 unsigned reduce_grid(size_t n) {
@@ -1375,6 +1642,9 @@ struct sp_gicp_target {
     float4* covp = nullptr;         // 2 x float4 per target point, grid order: (xx,xy,xz,yy | yz,zz,rho^2,0)
     float* rho2 = nullptr;          // per target point (original order): squared safe radius of the reuse test
     float4* nb = nullptr;           // per target point (grid order): second certificate (nearest neighbour, second radius)
+    float4* bpts = nullptr;         // block rows (grid_device.h): 4 entries per target point, nullptr for small targets
+    unsigned* bstart = nullptr;
+    sp::BlockDesc bdesc{};
     unsigned long long version = 0; // bumped by every sp_gicp_target_update (cached copies of rows become stale)
     int reg_type = SP_REG_GICP;     // what the rows hold: plane(Ct) for GICP, inverse(Ct) for POINT_TO_DISTRIBUTION
     size_t n = 0;
@@ -1395,6 +1665,8 @@ struct sp_gicp_source {
     int opt_stage_mask = 3;  // bit 0 = per-iteration kernel, bit 1 = final reduce (+ solve) / finish kernel
     int opt_reuse = 2;       // 0 always search, 1 reuse on the first certificate, 2 also the second
     int opt_fast_nn = -1;    // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
+    int opt_launch_select = 3;  // bit 0 = the search launch of an iteration, bit 1 = its streaming launch (per-kernel timing)
+    int search_launches = 6;    // sp_gicp_source_set_search_launches: iterations that get a dedicated search launch
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -1406,6 +1678,8 @@ extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
     sp::pooled_free_after(t->covp, t->streams);
     sp::pooled_free_after(t->rho2, t->streams);
     sp::pooled_free_after(t->nb, t->streams);
+    sp::pooled_free_after(t->bpts, t->streams);
+    sp::pooled_free_after(t->bstart, t->streams);
     delete t;
 }
 extern "C" int sp_gicp_target_prepare(sp_gicp_target* t, const float* tgt_covs, int reg_type, void* stream) {
@@ -1481,6 +1755,53 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
             inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
             certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb);
             rc2 = launch_status();
+        }
+        // block rows for the search launches of the device-resident loop (large targets only: they cost four sort keys per
+        // point to build and 64 bytes per point to keep)
+        ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp;
+        if (rc2 == SP_OK && n >= kBlockRowsMinPoints && 4 * n < (1ull << 31)) {
+            const sp_grid* g = grid;
+            BlockDesc bd;
+            const double cells = (double)g->dims[0] * g->dims[1] * g->dims[2];
+            float hb = g->h * (float)std::cbrt(kBlockRowsPointsPerCell * cells / (double)n);
+            if (!(hb > 0.0f) || !std::isfinite(hb)) hb = g->h;
+            size_t table = 0;
+            for (;;) {  // the lattice-row table is bounded like the grid's cell table
+                bd.nx = (int)std::floor((double)g->dims[0] * g->h / hb) + 1;
+                bd.ny = (int)std::floor((double)g->dims[1] * g->h / hb) + 1;
+                bd.nz = (int)std::floor((double)g->dims[2] * g->h / hb) + 1;
+                table = (size_t)bd.nx * (size_t)(bd.ny + 1) * (size_t)(bd.nz + 1);
+                if (table <= (1ull << 25)) break;
+                hb *= 1.26f;
+            }
+            bd.h = hb; bd.inv_h = 1.0f / hb; bd.eps = g->eps * (1.0f + hb / g->h);
+            bd.ox = g->org[0]; bd.oy = g->org[1]; bd.oz = g->org[2];
+            const size_t m = 4 * n;
+            const size_t tmp_bytes = radix_sort_u32_workspace_bytes(m);
+            e = b_kin.get(m * 4);
+            if (e == hipSuccess) e = b_kout.get(m * 4);
+            if (e == hipSuccess) e = b_vin.get(m * 4);
+            if (e == hipSuccess) e = b_vout.get(m * 4);
+            if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(tmp_bytes, 16));
+            if (e == hipSuccess) e = pooled_alloc(&t->bpts, m * sizeof(float4));
+            if (e == hipSuccess) e = pooled_alloc(&t->bstart, (table + 1) * sizeof(unsigned));
+            if (e != hipSuccess) rc2 = SP_ERR_HIP;
+            if (rc2 == SP_OK) {
+                unsigned *kin = b_kin.as<unsigned>(), *kout = b_kout.as<unsigned>(), *vin = b_vin.as<unsigned>(),
+                         *vout = b_vout.as<unsigned>();
+                block_key_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(g->d_pts, (unsigned)n, bd, kin, vin);
+                unsigned end_bit = 1;
+                while ((1ull << end_bit) <= table && end_bit < 32) ++end_bit;
+                bool in_b = false;
+                rc2 = radix_sort_pairs_u32(kin, kout, vin, vout, m, end_bit, b_tmp.p, tmp_bytes, &in_b, st);
+                if (!in_b) { kout = kin; vout = vin; }
+                if (rc2 == SP_OK) {
+                    block_gather_kernel<<<div_up(m, kBlock), kBlock, 0, st>>>(g->d_pts, vout, (unsigned)m, t->bpts);
+                    cell_start_kernel<<<div_up(m + 1, kBlock), kBlock, 0, st>>>(kout, (unsigned)m, (unsigned)table, t->bstart);
+                    rc2 = launch_status();
+                    t->bdesc = bd;
+                }
+            }
         }
         if (hipStreamSynchronize(st) != hipSuccess && rc2 == SP_OK) rc2 = SP_ERR_HIP;
         if (rc2 != SP_OK) {
@@ -1593,6 +1914,9 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
     P.tstart = target->grid->d_start;
     P.tcovp = target->covp;
     P.tnb = source->opt_reuse > 1 ? target->nb : nullptr;
+    P.bpts = target->bpts;
+    P.bstart = target->bstart;
+    P.b = target->bdesc;
     P.g = grid_desc(target->grid);
     P.n = (unsigned)n;
     P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
@@ -1656,7 +1980,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     }
     target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT, transT_on_device, nn_idx_out, nn_d2_out);
-    const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1) && !(source->opt_stage_mask & 28);
+    const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1);
     const unsigned grid = reduce_grid(n);
     float* partials = static_cast<float*>(workspace);
     // Unsorted lanes touch unrelated cells: the ring walk (fewest cache lines per query) wins. Cell-sorted lanes share
@@ -1665,12 +1989,9 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_FUSED(L)                                                              \
     if (!(source->opt_stage_mask & 1)) {}                                                   \
-    else if (source->opt_stage_mask & 4) gicp_fused_kernel<LOSS_NONE, true, 1><<<grid, kBlock, 0, st>>>(P, partials);   \
-    else if (source->opt_stage_mask & 8) gicp_fused_kernel<LOSS_NONE, true, 2><<<grid, kBlock, 0, st>>>(P, partials);   \
-    else if (source->opt_stage_mask & 16) gicp_fused_kernel<LOSS_NONE, true, 3><<<grid, kBlock, 0, st>>>(P, partials);   \
-    else if (fast && p2d) gicp_fused_kernel<L, true, 0, true><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (fast && p2d) gicp_fused_kernel<L, true, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else if (fast) gicp_fused_kernel<L, true><<<grid, kBlock, 0, st>>>(P, partials);   \
-    else if (p2d) gicp_fused_kernel<L, false, 0, true><<<grid, kBlock, 0, st>>>(P, partials);   \
+    else if (p2d) gicp_fused_kernel<L, false, true><<<grid, kBlock, 0, st>>>(P, partials);   \
     else gicp_fused_kernel<L, false><<<grid, kBlock, 0, st>>>(P, partials)
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_FUSED(LOSS_NONE); break;
@@ -1687,27 +2008,30 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
     if (source->opt_stage_mask & 2) final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
     return launch_status();
 }
-// Measurement hook (not part of the stable surface): which of the two launches sp_gicp_iteration_fused issues.
+
 namespace sp {
 namespace {
-struct AlignWs {  // workspace: partial rows A | partial rows B | state A | state B | (timing stamps) | searched log
+struct AlignWs {  // workspace: partial rows A | partial rows B | state A | state B | searched log | fan-in rows | tickets
     float* part[2];
-    AlignState* state;
+    AlignState* state;       // [j & 1]: the state after iteration j
     unsigned* searched_log;  // kSearchedLog entries
     float* fan_row[2];       // fan-in rows (kFanRow floats each), ping-pong like the partial rows
-    unsigned* fan_counter;   // arrival tickets of the fan-in
+    unsigned* fan_counter;   // arrival tickets of the last-arriver logic
+    unsigned* search_shards; // kSearchShards counters of the search launch
 };
 AlignWs align_ws(void* workspace) {
     AlignWs w;
     w.part[0] = static_cast<float*>(workspace);
     w.part[1] = w.part[0] + (size_t)kAlignMaxBlocks * kPartial;
     w.state = reinterpret_cast<AlignState*>(w.part[1] + (size_t)kAlignMaxBlocks * kPartial);
-    w.searched_log = reinterpret_cast<unsigned*>(w.state + 8);  // (state + 2 .. : stamps of the SP_KERNEL_TIMING build)
+    w.searched_log = reinterpret_cast<unsigned*>(w.state + 2);
     w.fan_row[0] = reinterpret_cast<float*>(w.searched_log + kSearchedLog);
     w.fan_row[1] = w.fan_row[0] + kFanRow;
     w.fan_counter = reinterpret_cast<unsigned*>(w.fan_row[1] + kFanRow);
+    w.search_shards = w.fan_counter + 4;
     return w;
 }
+constexpr size_t kAlignResetBytes = (kSearchedLog + 2 * kFanRow + 4 + kSearchShards) * sizeof(float);  // log | rows | tickets | shards: zero at k = 0
 unsigned align_grid(size_t n) {
     unsigned grid = div_up(n, kAlignBlock);
     return grid > (unsigned)kAlignMaxBlocks ? (unsigned)kAlignMaxBlocks : (grid ? grid : 1u);
@@ -1722,6 +2046,33 @@ int align_check(const char* who, const sp_gicp_target* target, const sp_gicp_sou
     }
     (void)who;
     return SP_OK;
+}
+AlignArgs align_args(const AlignWs& w, float* transT_device, const sp_gn_params* gn, int j, int mode, sp_linearized* lin_out) {
+    AlignArgs A;
+    A.T_init = transT_device;
+    A.state_in = &w.state[(j + 1) & 1];
+    A.state_out = &w.state[j & 1];
+    A.has_prev = j > 0;
+    A.lambda = gn->lambda;
+    A.crit_rot = gn->crit_rotation;
+    A.crit_trans = gn->crit_translation;
+    A.lin_out = lin_out;
+    A.mode = mode;
+    A.searched_log = w.searched_log;
+    A.k = j;
+    A.search_launch = 0;
+    A.min_defer = 0;
+    A.fan_row_out = w.fan_row[j & 1];
+    A.fan_row_in = w.fan_row[j & 1];
+    A.fan_counter = w.fan_counter;
+    A.search_shards = w.search_shards;
+    return A;
+}
+// Sharded modes: finish iteration j from the all-reduced row(s) (enqueued behind the caller's collective).
+void launch_solve(const AlignWs& w, float* transT_device, const sp_gn_params* gn, int j, int mode, sp_linearized* lin_out,
+                  hipStream_t st) {
+    const AlignArgs A = align_args(w, transT_device, gn, j, mode, lin_out);
+    align_solve_kernel<<<1, kFinalThreads, 0, st>>>(A, w.part[j & 1], (unsigned)kAlignMaxBlocks);
 }
 }  // namespace
 }  // namespace sp
@@ -1752,8 +2103,8 @@ extern "C" int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gic
     float* partials = static_cast<float*>(workspace);
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_ERR(L)                                                                       \
-    if (p2d) error_prepared_kernel<L, true><<<grid, kBlock, 0, st>>>(P, TL, partials);        \
-    else error_prepared_kernel<L, false><<<grid, kBlock, 0, st>>>(P, TL, partials)
+    if (p2d) error_prepared_kernel<L, true><<<grid, kBlock, 0, st>>>(P, TL, nullptr, partials);        \
+    else error_prepared_kernel<L, false><<<grid, kBlock, 0, st>>>(P, TL, nullptr, partials)
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_ERR(LOSS_NONE); break;
         case SP_LOSS_HUBER: SP_LAUNCH_ERR(LOSS_HUBER); break;
@@ -1767,6 +2118,12 @@ extern "C" int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gic
     return launch_status();
 }
 
+extern "C" int sp_gicp_source_set_search_launches(sp_gicp_source* source, int launches) {
+    if (!source || launches < 0) return SP_ERR_INVALID_ARGUMENT;
+    source->search_launches = launches > sp::kSearchedLog ? sp::kSearchedLog : launches;
+    return SP_OK;
+}
+
 extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                                  const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
                                  int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
@@ -1775,43 +2132,42 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     hipStream_t st = as_stream(stream);
     const int rc = align_check("step", target, source, params, gn, transT_device, workspace, workspace_bytes);
     if (rc != SP_OK) return rc;
-    if (k < 0) return SP_ERR_INVALID_ARGUMENT;
+    if (k < 0 || rows_all_reduced < 0 || rows_all_reduced > 2) return SP_ERR_INVALID_ARGUMENT;
     const size_t n = source->n;
     const AlignWs w = align_ws(workspace);
-    if (k == 0 && rows_all_reduced == 1) {
-        // every rank all-reduces all kAlignMaxBlocks rows whatever its own tile size: rows a rank does not write stay zero
-        if (zero_async(w.part[0], 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != SP_OK) return SP_ERR_HIP;
-    }
-    if (k == 0 && rows_all_reduced == 2) {  // fan-in: ticket counter (and the rows, for a launch that returns at once)
-        if (zero_async(w.fan_row[0], (2 * kFanRow + 4) * sizeof(float), st) != SP_OK) return SP_ERR_HIP;
+    const int mode = rows_all_reduced;
+    if (!(source->opt_launch_select & 1)) {
+        // (per-kernel timing, sp_internal.h: the first half of this iteration was enqueued by the previous call)
+    } else if (k == 0) {
+        // searched-point log, fan-in rows, arrival tickets (the caller's workspace comes as it is); ALIGN_ROWS: every rank
+        // all-reduces all kAlignMaxBlocks rows whatever its own tile size, rows a rank does not write stay zero
+        if (zero_async(w.searched_log, kAlignResetBytes, st) != SP_OK) return SP_ERR_HIP;
+        if (mode == ALIGN_ROWS &&
+            zero_async(w.part[0], 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != SP_OK)
+            return SP_ERR_HIP;
+    } else if (mode != ALIGN_TAIL_SOLVE) {
+        launch_solve(w, transT_device, gn, k - 1, mode, lin_out, st);  // the caller has all-reduced iteration k - 1's row(s)
     }
     target->note(st);
-    const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
+    FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
     const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1);
     const unsigned grid = align_grid(n);
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
-    AlignArgs A;
-    A.T_init = transT_device;
-    A.state_in = &w.state[(k + 1) & 1];
-    A.state_out = &w.state[k & 1];
-    A.prev_partials = w.part[(k + 1) & 1];
-    A.prev_rows = rows_all_reduced == 1 ? (unsigned)kAlignMaxBlocks : grid;
-    A.has_prev = k > 0;
-    A.lambda = gn->lambda;
-    A.crit_rot = gn->crit_rotation;
-    A.crit_trans = gn->crit_translation;
-    A.lin_out = lin_out;
-    A.count_is_float = rows_all_reduced == 1 ? 1 : 0;
-    A.searched_log = w.searched_log;
-    A.k = k;
-    A.fanin = rows_all_reduced == 2 ? 1 : 0;
-    A.fan_row_out = w.fan_row[k & 1];
-    A.fan_row_in = w.fan_row[(k + 1) & 1];
-    A.fan_counter = w.fan_counter;
+    AlignArgs A = align_args(w, transT_device, gn, k, mode, lin_out);
+    // The dedicated search launch: for the first iterations of an alignment, on a cell-ordered source large enough that a
+    // second launch is cheaper than searching inside half-empty streaming waves (below ~100 k points an iteration is
+    // launch-bound either way). ALIGN_ROWS keeps round 1's single-launch form.
+    A.search_launch = (fast && P.ccache != nullptr && P.bpts != nullptr && mode != ALIGN_ROWS && k < source->search_launches &&
+                       n >= 100000) ? 1 : 0;
+    A.min_defer = (unsigned)(n / 128 > 0 ? n / 128 : 1);
+    if (A.search_launch && (source->opt_stage_mask & 1) && (source->opt_launch_select & 1)) {
+        SearchArgs S{transT_device, A.state_in, A.has_prev, w.searched_log, w.search_shards, k, A.min_defer};
+        gicp_search_kernel<<<div_up(n, kSearchChunk), kSearchBlock, 0, st>>>(P, S);
+    }
     float* out = w.part[k & 1];
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_ALIGN(L)                                                                            \
-    if (!(source->opt_stage_mask & 1)) {}                                                                 \
+    if (!(source->opt_stage_mask & 1) || !(source->opt_launch_select & 2)) {}                             \
     else if (fast && p2d) gicp_align_kernel<L, true, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);     \
     else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);              \
     else if (p2d) gicp_align_kernel<L, false, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);         \
@@ -1825,7 +2181,7 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
 #undef SP_LAUNCH_ALIGN
-    if (fills_cache) source->cache_valid = true;
+    if (fills_cache && (source->opt_launch_select & 2)) source->cache_valid = true;
     return launch_status();
 }
 
@@ -1845,20 +2201,25 @@ extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_
                                    uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace sp;
     hipStream_t st = as_stream(stream);
-    if (!source || !transT_device || !gn || last_k < 0) return SP_ERR_INVALID_ARGUMENT;
+    if (!source || !transT_device || !gn || last_k < 0 || rows_all_reduced < 0 || rows_all_reduced > 2)
+        return SP_ERR_INVALID_ARGUMENT;
     if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(source->n)) {
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
     }
     const AlignWs w = align_ws(workspace);
-    const unsigned rows = rows_all_reduced == 1 ? (unsigned)kAlignMaxBlocks : align_grid(source->n);
-    if (source->opt_stage_mask & 2)
-        align_finish_kernel<<<1, kFinalThreads, 0, st>>>(w.part[last_k & 1], rows, &w.state[last_k & 1], gn->lambda,
-                                                         gn->crit_rotation, gn->crit_translation, transT_device, lin_out,
-                                                         delta_out8, iterations_out, rows_all_reduced == 1 ? 1 : 0,
-                                                         w.searched_log, last_k,
-                                                         rows_all_reduced == 2 ? w.fan_row[last_k & 1] : nullptr);
+    if (source->opt_stage_mask & 2) {
+        if (rows_all_reduced != ALIGN_TAIL_SOLVE) launch_solve(w, transT_device, gn, last_k, rows_all_reduced, lin_out, st);
+        align_publish_kernel<<<1, kWave, 0, st>>>(&w.state[last_k & 1], transT_device, delta_out8, iterations_out);
+    }
     return launch_status();
+}
+
+extern "C" int sp_gicp_align_linearization_pose(const void* workspace, int last_k, float* transT_lin_out, void* stream) {
+    if (!workspace || last_k < 0 || !transT_lin_out) return SP_ERR_INVALID_ARGUMENT;
+    const sp::AlignWs w = sp::align_ws(const_cast<void*>(workspace));
+    return sp::hip_status(hipMemcpyAsync(transT_lin_out, w.state[last_k & 1].T_lin, 16 * sizeof(float), hipMemcpyDefault,
+                                         sp::as_stream(stream)));
 }
 
 extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
@@ -1883,8 +2244,8 @@ extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_s
                                 workspace, workspace_bytes, stream);
 }
 
-// Measurement (sp_internal.h): entry k = source points launch k of the last alignment searched for (the rest reused their
-// correspondence); entries of launches that did not run (converged earlier) keep their previous value.
+// Measurement (sp_internal.h): entry k = source points iteration k of the last alignment searched for (the rest reused their
+// correspondence); 0 for iterations that did not run (converged earlier).
 extern "C" const uint32_t* sp_internal_align_searched_log(void* workspace, size_t* n_entries_out) {
     if (n_entries_out) *n_entries_out = sp::kSearchedLog;
     return workspace ? sp::align_ws(workspace).searched_log : nullptr;
@@ -1896,6 +2257,7 @@ extern "C" int sp_internal_source_option(sp_gicp_source* s, int option, int valu
         case SP_INTERNAL_FUSED_STAGE_MASK: s->opt_stage_mask = value; return SP_OK;
         case SP_INTERNAL_FUSED_REUSE: s->opt_reuse = value; s->cache_valid = false; return SP_OK;
         case SP_INTERNAL_FUSED_FAST_NN: s->opt_fast_nn = value; return SP_OK;
+        case SP_INTERNAL_FUSED_LAUNCH_SELECT: s->opt_launch_select = value; return SP_OK;
     }
     return SP_ERR_INVALID_ARGUMENT;
 }

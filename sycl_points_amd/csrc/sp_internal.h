@@ -17,7 +17,7 @@ extern "C" {
 
 enum {
     /* sp_gicp_source: launches issued by sp_gicp_iteration_fused / sp_gicp_align_* for this source
-     * (bit 0 = per-iteration kernel, bit 1 = final reduce + solve / finish kernel; bits 2..4 timing experiments). Default 3. */
+     * (bit 0 = per-iteration kernels, bit 1 = final reduce + solve / finish kernel). Default 3. */
     SP_INTERNAL_FUSED_STAGE_MASK = 0,
     /* sp_gicp_source: 2 (default) carry a correspondence to the next iteration when either certificate proves it unchanged,
      * 1 first certificate only, 0 always search. Takes effect at once (the cache is dropped). */
@@ -26,7 +26,10 @@ enum {
      * 0 ring walk, 1 fast path. */
     SP_INTERNAL_FUSED_FAST_NN = 2,
     /* sp_grid: self-kNN kernel: 0 (default) chosen by k, 1 LDS-tile kernel (k <= 10), 2 wave-cooperative kernel. */
-    SP_INTERNAL_SELF_KNN_MODE = 3
+    SP_INTERNAL_SELF_KNN_MODE = 3,
+    /* sp_gicp_source: which launches of an iteration sp_gicp_align_step enqueues: bit 0 the search launch, bit 1 the
+     * streaming launch. Default 3. bench.py calls a step twice (1, then 2) with an event in between to time each kernel. */
+    SP_INTERNAL_FUSED_LAUNCH_SELECT = 4
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);
