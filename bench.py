@@ -82,9 +82,6 @@ def parse():
     ap.add_argument("--internal", action="append", default=[], metavar="NAME=VALUE",
                     help="measurement only: a per-handle switch of csrc/sp_internal.h on the prepared source, e.g. reuse=0 "
                          "(every launch searches every point); such a line is not a benchmark result")
-    ap.add_argument("--search-launches", type=int, default=6,
-                    help="iterations at the start of an alignment that get a dedicated search launch "
-                         "(sp_gicp_source_set_search_launches; the library's default is 6; results do not depend on it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline workload")
     return ap.parse_args()
@@ -163,7 +160,6 @@ def main():
     params = sp.RegistrationParams(reg_type=REG_TYPE, optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
                                    criteria_translation=0.0, criteria_rotation=0.0)
     reg = sp.Registration(params)
-    reg.set_search_launches(args.search_launches)
     for kv in args.internal:
         name, value = kv.split("=")
         reg._set_source_option(name, int(value))
@@ -277,25 +273,12 @@ def main():
     kern = kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n_local, SORT_MODE)
     launches = classes = converged = None
     if args.path == "fused" and group is None:
-        launches, classes, per_kernel = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
-        # the streaming launch and the search launch, each by its own events (what rocprofv3 reports per kernel)
-        ms_a = 1e-3 * per_kernel["gicp_align_kernel_us"]
-        kern["gicp_align_kernel"].update({"ms": ms_a, "bytes": BYTES_K11 * n_local, "GBps": BYTES_K11 * n_local / (ms_a * 1e-3) / 1e9})
-        if per_kernel["gicp_search_kernel_us"]:
-            ms_s = 1e-3 * per_kernel["gicp_search_kernel_us"]
-            pts = float(np.mean([l["searched_points"] for l in launches if l["search_launch_ran"]]))
-            kern["gicp_search_kernel"] = {
-                "ms": ms_s, "bytes": BYTES_NN * pts, "GBps": BYTES_NN * pts / (ms_s * 1e-3) / 1e9,
-                "launches_per_alignment": per_kernel["gicp_search_kernel_launches"],
-                "note": "first iterations of an alignment only: the points whose cached correspondence is not certified "
-                        "for the new pose, compacted and searched on dense waves (exact 2x2x2 block, then the later stages); "
-                        "refreshes cache rows, computes no sums; bytes = 24 B x the points it searched (mean)"}
+        launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
         converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE)
 
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
-        dom = max((k for k in kern if kern[k].get("per_iteration", True) and not kern[k].get("aggregate")),
-                  key=lambda k: kern[k]["ms"])
+        dom = max((k for k in kern if kern[k].get("per_iteration", True)), key=lambda k: kern[k]["ms"])
         out = {
             "metric": "gicp_correspondences_per_sec",
             "value": (n_gpu if shards != world else n_total) * args.steps / elapsed,  # (rehearsal: one tile only)
@@ -316,7 +299,6 @@ def main():
                                    f"{'4' if world == 1 else '5 generalised'}), k=20 covariances, GN lambda=1, "
                                    f"max_corr 2.0, robust NONE, {ITERS_PER_ALIGN} iterations per alignment",
                        "source_points_per_gpu": n_gpu, "target_points": n_total, "path": args.path, "reg_type": REG_TYPE,
-                       "search_launches": args.search_launches,
                        "nn": "grid(k=1)" if (args.path == "fused" or args.nn == "grid") else "kdtree(k=1)",
                        "target_preparation": "once, in set-up with its NN structure (grid build, plane-regularised covariances, "
                                              "safe radii); per alignment only the source is prepared",
@@ -346,8 +328,7 @@ def main():
                          "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom), "algorithmic_bytes_per_launch": kern[dom]["bytes"],
                          "hbm_frac_measured_traffic": ((measured_traffic(dom) / (kern[dom]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                                                       if measured_traffic(dom) else None),
-                         "iteration_frac": (kern["iteration"]["GBps"] / HBM_PEAK_GBS) if "iteration" in kern else None},
+                                                       if measured_traffic(dom) else None)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, REG_TYPE)
@@ -415,13 +396,11 @@ def class_traffic(cls):
 
 
 def launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n, reps=7):
-    """Duration of EACH launch of one alignment (identity guess, criteria 0) — per iteration the search launch
-    (gicp_search_kernel, first iterations only) and the streaming launch (gicp_align_kernel) — by HIP events recorded between
-    the launches on the launch stream (csrc/sp_internal.h: sp_gicp_align_step enqueues one half of an iteration per call),
-    and how many source points each iteration had to search for (device-side log). An iteration is 'searching' when more
-    than 1 % of its points were searched — the first poses of an alignment — and 'steady' otherwise (correspondences carried
-    over by certificate: a pure stream). The device queue is pre-filled behind a spin kernel so that the host's launch rate
-    does not show up as gaps between the events."""
+    """Duration of EACH of the 20 launches of one alignment (identity guess, criteria 0), by HIP events recorded between
+    the launches on the launch stream, and how many source points each launch had to search for (device-side log,
+    csrc/sp_internal.h). A launch is 'searching' when more than 1 % of its points were searched — the first poses of an
+    alignment — and 'steady' otherwise (correspondences carried over by certificate: a pure stream). The device queue is
+    pre-filled behind a spin kernel so that the host's launch rate does not show up as gaps between the events."""
     L = _lib.lib()
     ws, lin = reg._buffers(T_dev.device)
     fp = reg._factor_params(reg.params.robust_default_scale)
@@ -429,52 +408,64 @@ def launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n, reps=7)
     nlog = C.c_size_t(0)
     log_ptr = L.sp_internal_align_searched_log(sp._ptr(ws), C.byref(nlog))
     log_off = log_ptr - ws.data_ptr()
-    us = np.zeros((reps, ITERS_PER_ALIGN, 2))
+    us = np.zeros((reps, ITERS_PER_ALIGN))
     for r in range(reps):
         T_dev.copy_(T_ident)
         reg._psrc.prepare(prep, reg._bench_source, T_dev, reg._bench_sort_mode)
         torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ITERS_PER_ALIGN + 1)]
-        torch.cuda._sleep(6_000_000)  # ~3 ms: the launches + events are all enqueued before the first one starts
-        ev[0].record()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(ITERS_PER_ALIGN + 1)]
+        torch.cuda._sleep(3_000_000)  # ~1.5 ms: the 20 launches + 21 events are all enqueued before the first one starts
         for k in range(ITERS_PER_ALIGN):
-            for half in (1, 2):  # search launch (and the k = 0 reset), then the streaming launch
-                reg._psrc._set_option("launch_select", half)
-                _lib.check(L.sp_gicp_align_step(prep._h, reg._psrc._h, sp._ptr(T_dev), C.byref(fp), C.byref(gn), k, 0, None,
-                                                None, sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
-                ev[2 * k + half].record()
-        reg._psrc._set_option("launch_select", 3)
+            if k == 1:
+                ev[0].record()  # (launch 0 is preceded by the reset of the log / ticket words: its event starts behind it)
+            _lib.check(L.sp_gicp_align_step(prep._h, reg._psrc._h, sp._ptr(T_dev), C.byref(fp), C.byref(gn), k, 0, None,
+                                            None, sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+            ev[k + 1].record()
         _lib.check(L.sp_gicp_align_finish(reg._psrc._h, sp._ptr(T_dev), C.byref(gn), ITERS_PER_ALIGN - 1, 0, sp._ptr(lin),
                                           sp._ptr(delta), None, sp._ptr(ws), ws.numel(), sp._stream()))
         torch.cuda.synchronize()
-        us[r] = [[1e3 * ev[2 * k + h].elapsed_time(ev[2 * k + h + 1]) for h in (0, 1)] for k in range(ITERS_PER_ALIGN)]
+        us[r, 1:] = [1e3 * ev[k].elapsed_time(ev[k + 1]) for k in range(1, ITERS_PER_ALIGN)]
+    # launch 0 on its own (an event cannot be recorded between the reset kernel and the launch inside one C call): the whole
+    # call between two events, minus the same pair around the reset alone
+    t0 = []
+    for r in range(reps):
+        T_dev.copy_(T_ident)
+        reg._psrc.prepare(prep, reg._bench_source, T_dev, reg._bench_sort_mode)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(500_000)
+        e0.record()
+        _lib.check(L.sp_gicp_align_step(prep._h, reg._psrc._h, sp._ptr(T_dev), C.byref(fp), C.byref(gn), 0, 0, None, None,
+                                        sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        t0.append(1e3 * e0.elapsed_time(e1))
+    # restore the log of a full alignment for the searched counts
+    T_dev.copy_(T_ident)
+    reg._psrc.prepare(prep, reg._bench_source, T_dev, reg._bench_sort_mode)
+    for k in range(ITERS_PER_ALIGN):
+        _lib.check(L.sp_gicp_align_step(prep._h, reg._psrc._h, sp._ptr(T_dev), C.byref(fp), C.byref(gn), k, 0, None, None,
+                                        sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+    _lib.check(L.sp_gicp_align_finish(reg._psrc._h, sp._ptr(T_dev), C.byref(gn), ITERS_PER_ALIGN - 1, 0, sp._ptr(lin),
+                                      sp._ptr(delta), None, sp._ptr(ws), ws.numel(), sp._stream()))
+    torch.cuda.synchronize()
     searched = ws[log_off:log_off + 4 * ITERS_PER_ALIGN].view(torch.int32).cpu().numpy().astype(np.int64)
     med = np.median(us, axis=0)
-    tot = med.sum(axis=1)
-    launches = [{"k": k, "us": round(float(tot[k]), 2), "search_launch_us": round(float(med[k, 0]), 2),
-                 "streaming_launch_us": round(float(med[k, 1]), 2), "searched_points": int(searched[k])}
-                for k in range(ITERS_PER_ALIGN)]
-    K = reg._search_launches if reg._search_launches is not None else 6
-    for k, l in enumerate(launches):
-        l["search_launch_ran"] = bool(k < K and n >= 100000 and (k == 0 or searched[k - 1] >= max(n // 128, 1)))
+    med[0] = float(np.median(t0))
+    launches = [{"k": k, "us": round(float(med[k]), 2), "searched_points": int(searched[k])} for k in range(ITERS_PER_ALIGN)]
+    launches[0]["note"] = "includes the one-off reset kernel of an alignment (~2 us)"
     classes = {}
     for name, sel in (("searching", searched > 0.01 * n), ("steady", searched <= 0.01 * n)):
         if not sel.any():
             continue
-        t = float(tot[sel].mean()) * 1e-6
+        t = float(med[sel].mean()) * 1e-6
         traffic = class_traffic(name)
-        classes[name] = {"iterations": int(sel.sum()), "mean_us": round(t * 1e6, 2),
-                         "algorithmic_bytes_per_iteration": BYTES_ITER * n,
+        classes[name] = {"launches": int(sel.sum()), "mean_us": round(t * 1e6, 2),
+                         "algorithmic_bytes_per_launch": BYTES_ITER * n,
                          "frac_of_hbm_peak_algorithmic": BYTES_ITER * n / t / 1e9 / HBM_PEAK_GBS,
-                         "measured_hbm_bytes_per_iteration": traffic,
+                         "measured_hbm_bytes_per_launch": traffic,
                          "frac_of_hbm_peak_measured_traffic": (traffic / t / 1e9 / HBM_PEAK_GBS) if traffic else None}
-    # (a search launch does work at k = 0 and while the previous iteration searched >= 1/128 of the points; it returns at once
-    # otherwise, or is not enqueued at all: the event pair then shows only the gap)
-    ran = np.array([l["search_launch_ran"] for l in launches])
-    per_kernel = {"gicp_align_kernel_us": float(med[:, 1].mean()),
-                  "gicp_search_kernel_us": float(med[ran, 0].mean()) if ran.any() else None,
-                  "gicp_search_kernel_launches": int(ran.sum())}
-    return launches, classes, per_kernel
+    return launches, classes
 
 
 def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reg_type="GICP", reps=31):
@@ -554,16 +545,11 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
             torch.cuda.synchronize()
             tot += e0.elapsed_time(e1)
         ms = tot / reps_a / ITERS_PER_ALIGN
-        res["iteration"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9, "aggregate": True,
-                            "note": "all launches of one iteration (search launch in the first iterations + streaming launch), "
-                                    "mean over the 20 iterations of an alignment started at the identity, gaps included; "
-                                    "192 B per correspondence = NN 24 B + K11 168 B at the API layouts"}
-        res["gicp_align_kernel"] = {"ms": ms, "bytes": BYTES_K11 * n, "GBps": BYTES_K11 * n / (ms * 1e-3) / 1e9,
-                                    "note": "streaming launch, once per iteration: per point the cached correspondence (certified, "
-                                            "or on trust behind a search launch; stragglers searched inline), linearise, "
-                                            "workgroup reduction; the last-arriving workgroup sums the 256 partial rows, solves "
-                                            "the 6x6 system and updates the pose; mean over the 20 launches of an alignment; "
-                                            "bytes = K11's 168 B per source point at the API layouts (SURVEY 8d)"}
+        res["gicp_align_kernel"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9,
+                                    "note": "per-iteration launch: per point certified reuse of the previous correspondence or "
+                                            "NN(k=1) search, linearise, workgroup reduction; the last-arriving workgroup sums the "
+                                            "256 partial rows, solves the 6x6 system and updates the pose; mean over the 20 "
+                                            "launches of an alignment started at the identity"}
         # (b) the finish kernel alone
         reg._set_source_option("stage_mask", 2)
         align_launches()

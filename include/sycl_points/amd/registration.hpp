@@ -314,7 +314,13 @@ public:
         const float s = options.robust_scale > 0.0f ? options.robust_scale : params_.robust.default_scale;
         rotation_robust_scale_ = options.rotation_robust_scale > 0.0f ? options.rotation_robust_scale
                                                                       : params_.rotation_constraint.robust.default_scale;
-        fused_loop_active_ = false;  // the public entry evaluates the neighbours of the last search, not the cache
+        // The reference evaluates the neighbours the last linearisation left in neighbors_ (registration.hpp:350-359). When
+        // that linearisation ran on the prepared path (align() on a GridKNN / accelerated KDTree) they live in the
+        // correspondence cache of the prepared source, frozen at lin_T_, not in neighbors_.
+        fused_loop_active_ = last_lin_fused_;
+        if (!last_lin_fused_ && (neighbors_.indices == nullptr || neighbors_.indices->size() != source.size()))
+            throw std::runtime_error("[Registration::compute_error_frozen] no correspondences for this source: call align() or "
+                                     "compute_linearized_result() first");
         return compute_error(source, target, pose, s);
     }
     /// registration.hpp:279-294
@@ -325,6 +331,7 @@ public:
         out.assign(N, 0.0f);
         if (N == 0) return;
         target_knn.nearest_neighbor_search_async(source, neighbors_, {}, pose);
+        last_lin_fused_ = false;
         const sp_factor_params fp = factor_params(robust_scale);
         throw_on_error(sp_icp_robust_weights(source.points_device(), source.covs_device(), N, target.points_device(),
                                              target.covs_device(), target.normals_device(), neighbors_.indices->device_data(),
@@ -405,6 +412,7 @@ private:
     LinearizedResult linearize_generic(const PointCloudShared& source, const PointCloudShared& target,
                                        const knn::KNNBase& target_knn, const TransformMatrix& T, float robust_scale) {
         target_knn.nearest_neighbor_search_async(source, neighbors_, {}, T);
+        last_lin_fused_ = false;
         if (params_.reg_type == RegType::GENZ) genz_alpha_ = compute_genz_alpha(target, source.size());
         const sp_factor_params fp = factor_params(robust_scale);
         throw_on_error(sp_gicp_linearize(source.points_device(), source.covs_device(), source.size(), target.points_device(),
@@ -456,13 +464,17 @@ private:
             // neighbour beyond max_correspondence_distance — with partial overlap that search was most of an iteration)
             throw_on_error(sp_gicp_align_fused(ptgt_, psrc_, T_dev_, &fp, &gn, (int)params_.max_iterations, nullptr, nullptr,
                                                lin_dev_, delta_dev, iters_dev, ws_, ws_bytes_, queue_.stream()));
-        float* const host = reinterpret_cast<float*>(static_cast<char*>(pin_) + 256);  // pose | delta[8] | iterations
+        float* const host = reinterpret_cast<float*>(static_cast<char*>(pin_) + 256);  // pose | delta[8] | iterations | T_lin
         hip_check(hipMemcpyAsync(host, T_dev_, 28 * sizeof(float), hipMemcpyDeviceToHost, queue_.stream()), "D2H");
+        // the pose the correspondence cache is frozen at (compute_error_frozen after align(), registration.hpp:350-359)
+        throw_on_error(sp_gicp_align_linearization_pose(ws_, (int)params_.max_iterations - 1, host + 28, queue_.stream()));
         const sp_linearized h = read_lin();  // synchronises the stream
         const LinearizedResult lin = to_result(h);
         RegistrationResult result;
         TransformMatrix T;
         for (int i = 0; i < 16; ++i) T.data()[i] = host[i];
+        for (int i = 0; i < 16; ++i) lin_T_.data()[i] = host[28 + i];
+        last_lin_fused_ = true;
         result.T.matrix() = T;
         uint32_t iters;
         std::memcpy(&iters, &host[24], sizeof iters);
@@ -476,6 +488,7 @@ private:
         const sp_factor_params fp = factor_params(robust_scale);
         TransformMatrix Tc = T;
         lin_T_ = T;  // the pose the correspondences are frozen at (compute_error on the prepared path)
+        last_lin_fused_ = true;
         throw_on_error(sp_gicp_iteration_fused(ptgt_, psrc_, Tc.data(), 0, &fp, nullptr, nullptr, nullptr, lin_dev_, nullptr, ws_,
                                                ws_bytes_, queue_.stream()));
         return to_result(read_lin());
@@ -600,7 +613,7 @@ private:
     void* ws_ = nullptr;
     size_t ws_bytes_ = 0;
     float* T_dev_ = nullptr;
-    void* pin_ = nullptr;  // 512 bytes of pinned host memory: [0, 256) linear system, [256, 368) pose | delta | iterations
+    void* pin_ = nullptr;  // 512 bytes of pinned host memory: [0, 256) linear system, [256, 432) pose | delta | iterations | T_lin
     float genz_alpha_ = 1.0f;
     mutable float rotation_robust_scale_ = 10.0f;  // resolved per call from ExecutionOptions (registration.hpp:219-221)
     sp_map_prior_state map_prior_{};               // MapPrior state (map_prior.hpp:203-210)
@@ -612,6 +625,7 @@ private:
     sp_comm* comm_ = nullptr;  // borrowed (set_communicator)
     bool accelerate_kdtree_ = true;
     mutable bool fused_loop_active_ = false;  // align() is running its optimiser loop on the prepared path
+    mutable bool last_lin_fused_ = false;     // the last linearisation left its correspondences in the prepared source's cache
     TransformMatrix lin_T_ = TransformMatrix::Identity();  // pose of the last fused linearisation
     knn::GridKNN::Ptr kd_grid_;        // GridKNN standing in for the caller's KDTree (grid_for)
     uint64_t kd_grid_tree_id_ = 0;

@@ -332,14 +332,9 @@ int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gicp_source* s
                            sp_linearized* out, void* workspace, size_t workspace_bytes, void* stream);
 /* Registration::align's whole Gauss-Newton loop (registration.hpp:229-276) enqueued by ONE call; pose, convergence flag and
  * iteration count stay in a state block of the workspace, nothing is read back by the host. Per iteration:
- *   [search launch]  the first sp_gicp_source_set_search_launches iterations of an alignment (default 6; cell-ordered sources
- *                    of >= 100 000 points): the source points whose cached correspondence is not certified for this pose are
- *                    compacted and searched on dense waves (exact 2x2x2 block, then the later stages for the unproven), the
- *                    cache rows refreshed. It returns at once when the previous iteration searched < 1/128 of the points.
- *   streaming launch every point: cached correspondence (certified, or on trust behind a search launch; stragglers are
- *                    searched inline) -> linearise -> one partial row per workgroup; the last-arriving workgroup sums the
- *                    rows in a fixed order, solves (H + lambda I) delta = -b, T <- T * se3_exp(delta) and publishes the
- *                    next state. Sums and poses are bit-identical with and without search launches.
+ *   streaming launch every point: cached correspondence when its reuse certificate holds, else exact NN on the grid ->
+ *                    linearise -> one partial row per workgroup; the last-arriving workgroup sums the rows in a fixed
+ *                    order, solves (H + lambda I) delta = -b, T <- T * se3_exp(delta) and publishes the next state.
  * Once is_converged() (registration.hpp:407-410) holds, the remaining launches return at once, as the reference breaks out
  * of its loop. All pointers are device memory:
  *   transT_device  in: initial guess, out: final pose (column-major 4x4)
@@ -377,9 +372,6 @@ float* sp_gicp_align_row(void* workspace, int k, size_t* n_floats_out);
 int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn, int last_k,
                          int rows_all_reduced, sp_linearized* lin_out, float* delta_out8, uint32_t* iterations_out,
                          void* workspace, size_t workspace_bytes, void* stream);
-/* How many iterations at the start of an alignment get a dedicated search launch (see sp_gicp_align_fused; default 6, 0: the
- * single-launch form of every iteration). A tuning knob: results do not depend on it. */
-int sp_gicp_source_set_search_launches(sp_gicp_source* source, int launches);
 /* Pose of the LAST LINEARISATION of an alignment enqueued through sp_gicp_align_* with last iteration index last_k (the
  * pose before the final update; the pose at which convergence was detected when the loop stopped early): what the
  * reference's neighbors_ are frozen at after align() (registration.hpp:229-234), i.e. the transT_lin of a following

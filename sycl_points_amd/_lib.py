@@ -115,7 +115,6 @@ SIGNATURES = {
     "sp_gicp_iteration_fused": (_i, [_vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_fused": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "sp_gicp_source_set_search_launches": (_i, [_vp, _i]),
     "sp_gicp_align_linearization_pose": (_i, [_vp, _i, _vp, _vp]),
     "sp_gicp_align_rows": (_vp, [_vp, _i, _vp]),
     "sp_gicp_align_row": (_vp, [_vp, _i, _vp]),
@@ -161,7 +160,7 @@ INTERNAL_SIGNATURES = {
     "sp_internal_radix_sort_workspace_bytes": (_sz, [_sz]),
     "sp_internal_radix_sort_u32": (_i, [_vp, _vp, _vp, _vp, _sz, C.c_uint, _vp, _sz, _vp, _vp]),
 }
-INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3, "launch_select": 4}
+INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3}
 
 
 def build(force=False):

@@ -742,10 +742,6 @@ class PreparedSource:
         """csrc/sp_internal.h measurement / tuning switch of this prepared source (tests / bench / scratch only)."""
         check(_lib.lib().sp_internal_source_option(self._h, _lib.INTERNAL_OPTION[name], int(value)))
 
-    def set_search_launches(self, launches):
-        """sp_gicp_source_set_search_launches: iterations at the start of an alignment that get a dedicated search launch."""
-        check(_lib.lib().sp_gicp_source_set_search_launches(self._h, int(launches)))
-
     def prepare(self, prepared_target, source, transT=None, sort_by_cell=True):
         p2d = getattr(prepared_target, "reg_type", "GICP") == "POINT_TO_DISTRIBUTION"  # no source covariance in that factor
         if not source.has_cov() and not p2d:
@@ -842,13 +838,6 @@ class Registration:
         self._map_prior = MapPriorState()
         self._psrc = None
         self._source_options = {}  # csrc/sp_internal.h switches applied to the prepared source (tests / bench only)
-        self._search_launches = None  # library default
-
-    def set_search_launches(self, launches):
-        """Tuning knob of the device-resident loop (sp_gicp_source_set_search_launches); results do not depend on it."""
-        self._search_launches = int(launches)
-        if self._psrc is not None:
-            self._psrc.set_search_launches(launches)
 
     def _set_source_option(self, name, value):
         self._source_options[name] = int(value)
@@ -860,8 +849,6 @@ class Registration:
             self._psrc = PreparedSource(n)
             for k, v in self._source_options.items():
                 self._psrc._set_option(k, v)
-            if self._search_launches is not None:
-                self._psrc.set_search_launches(self._search_launches)
             return self._psrc, True
         return self._psrc, False
 

@@ -38,34 +38,6 @@ __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim
     return (int)fminf(fmaxf(t, 0.0f), (float)(dim - 1));
 }
 
-// start[c] = first sorted position whose key >= c  (c in [0, ncells]); keys ascending.
-// One lane per sorted position i in [0, n]: the cells in (key[i-1], key[i]] all start at i (position n closes the table up to
-// ncells). Gaps of a few cells — the usual case — are written by the lane itself; a long gap (empty space between surfaces)
-// is written by its whole wave, 64 cells per step. Coalesced key reads, near-coalesced table writes: 8 us per 1M points at
-// 0.5 points per cell, against 28 us for a binary search per cell.
-static __global__ __launch_bounds__(kBlock) void cell_start_kernel(const unsigned* __restrict__ keys, unsigned n,
-                                                            unsigned ncells, unsigned* __restrict__ start) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    const unsigned lane = threadIdx.x & (kWave - 1);
-    unsigned lo = 0, hi = 0;  // cells [lo, hi) start at position i
-    if (i <= n) {
-        lo = i == 0 ? 0u : min(keys[i - 1], ncells) + 1u;
-        hi = (i == n ? ncells : min(keys[i], ncells)) + 1u;
-        if (lo > hi) lo = hi;
-    }
-    const unsigned len = hi - lo;
-    if (len <= 8u)
-        for (unsigned c = lo; c < hi; ++c) start[c] = i;
-    unsigned long long m = __ballot(len > 8u);
-    while (m) {
-        const int L = __builtin_ctzll(m);
-        m &= m - 1;
-        const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)lo, L), bhi = (unsigned)__builtin_amdgcn_readlane((int)hi, L);
-        const unsigned bi = (unsigned)__builtin_amdgcn_readlane((int)i, L);
-        for (unsigned c = blo + lane; c < bhi; c += kWave) start[c] = bi;
-    }
-}
-
 // (distance, index) lexicographic sorted insertion into the first k slots.
 template <int KCAP>
 __device__ __forceinline__ void lex_insert(float (&bd)[KCAP], int (&bi)[KCAP], int k, float d, int idx, float& kth,
@@ -271,7 +243,6 @@ __device__ __forceinline__ void fast_eval(const FastFlat& f, unsigned base, cons
 // FLT_MAX: a query with nothing that near is "proven" (no point, idx = -1, d2 = bound2) as soon as the scanned block covers
 // the bound's ball, instead of walking rings of cells out to a neighbour it would discard. With partial overlap (the
 // reference's example: 84 % of the source points have no correspondence) that walk was most of an iteration.
-template <int B = 8>
 __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                               const GridDesc& g, float qx, float qy, float qz, Nearest& best,
                                               float bound2 = FLT_MAX) {
@@ -285,10 +256,10 @@ __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, co
     const unsigned long long none = nn_key(bound2, -1);  // nothing found (below the bound): {bound2, -1}
     unsigned long long key = none;
     unsigned bj = 0;
-    for (unsigned base = 0; base < f.total; base += B) {  // B candidates in flight per round trip
-        float4 cand[B];
-        fast_load<B>(pts, f, base, cand);
-        fast_eval<B>(f, base, cand, qx, qy, qz, key, bj);
+    for (unsigned base = 0; base < f.total; base += 8) {
+        float4 cand[8];
+        fast_load<8>(pts, f, base, cand);
+        fast_eval<8>(f, base, cand, qx, qy, qz, key, bj);
     }
     if (key != none) {
         best.pos = fast_pos(f, bj);
@@ -299,35 +270,6 @@ __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, co
     }
     const float cov = fmaxf(cov_cells * g.h - g.eps, 0.0f);
     return best.d2 < cov * cov;  // strict: an unseen point at exactly this distance could win a tie
-}
-
-// Block rows: the first stage above with its candidates CONTIGUOUS. The 2x2x2 block of a query is four x-row ranges in four
-// different places of the cell-ordered array (eight extent words, a four-way position select per candidate). Here every
-// point is stored four times, once in each "lattice row" (j, k) that covers its cell row — lattice row j holds the cell rows
-// j - 1 and j merged, likewise k in z — sorted by x-cell inside the row. The block of a query is then ONE contiguous run of
-// the lattice row nearest to it: two extent words, candidates at consecutive addresses, no position arithmetic.
-// Entry: (x, y, z, position in the cell-ordered primary array), ordered by position inside a cell. 64 bytes per target point;
-// its own cell size (about 2 points per cell: 16 candidates per query, 7 of 8 winners proven).
-struct BlockDesc {
-    float inv_h, h, eps;
-    float ox, oy, oz;
-    int nx, ny, nz;  // cells per axis; lattice rows: (ny + 1) x (nz + 1)
-};
-__device__ __forceinline__ void block_extent(const unsigned* __restrict__ bstart, const BlockDesc& b, float qx, float qy,
-                                             float qz, unsigned& s, unsigned& e, float& cov_cells) {
-    const float fx = (qx - b.ox) * b.inv_h, fy = (qy - b.oy) * b.inv_h, fz = (qz - b.oz) * b.inv_h;
-    const float cxf = fminf(fmaxf(floorf(fx), 0.0f), (float)(b.nx - 1));
-    const float jf = fminf(fmaxf(floorf(fy + 0.5f), 0.0f), (float)b.ny);
-    const float kf = fminf(fmaxf(floorf(fz + 0.5f), 0.0f), (float)b.nz);
-    const float tx = fx - cxf;
-    const bool lx = tx < 0.5f;
-    const int cx = (int)cxf;
-    const int xa = max(cx - (lx ? 1 : 0), 0), xb = min(cx + (lx ? 0 : 1), b.nx - 1);
-    // nearest face of the block that the run covers: x as in fast_extents; lattice row j spans [j - 1, j + 1] cells
-    cov_cells = fminf(fminf(lx ? 1.0f - tx : tx, 1.0f - fabsf(fy - jf)), 1.0f - fabsf(fz - kf));
-    const unsigned row = ((unsigned)kf * (unsigned)(b.ny + 1) + (unsigned)jf) * (unsigned)b.nx;
-    s = bstart[row + xa];
-    e = bstart[row + xb + 1];
 }
 
 // Second stage for k = 1: a block of 4 cells per axis around the query (own cell, one more on the farther side, two
@@ -452,11 +394,10 @@ __device__ __forceinline__ void grid_nn1_later_stages(const float4* __restrict__
     best = grid_nn1(pts, start, g, qx, qy, qz, &seed, 2);
 }
 
-template <int B = 8>
 __device__ __forceinline__ Nearest grid_nn1_auto(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                  const GridDesc& g, float qx, float qy, float qz, float bound2 = FLT_MAX) {
     Nearest best;
-    if (!grid_nn1_fast<B>(pts, start, g, qx, qy, qz, best, bound2)) grid_nn1_later_stages(pts, start, g, qx, qy, qz, best);
+    if (!grid_nn1_fast(pts, start, g, qx, qy, qz, best, bound2)) grid_nn1_later_stages(pts, start, g, qx, qy, qz, best);
     return best;
 }
 

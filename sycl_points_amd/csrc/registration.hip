@@ -614,36 +614,6 @@ __global__ __launch_bounds__(kBlock) void prepare_cov_kernel(const float4* __res
     out[2 * (size_t)i + 1] = make_float4((P.m[1][2] + P.m[2][1]) * 0.5f, P.m[2][2], rho2 ? rho2[src] : 0.0f, 0.0f);
 }
 
-// Block rows of a target (grid_device.h): four (lattice row key, position) pairs per cell-ordered point ...
-__global__ __launch_bounds__(kBlock) void block_key_kernel(const float4* __restrict__ gpts, unsigned n, BlockDesc b,
-                                                           unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = gpts[i];
-    const unsigned rows_y = (unsigned)b.ny + 1u;
-    const unsigned trash = (unsigned)b.nx * rows_y * ((unsigned)b.nz + 1u);  // non-finite points: past the table, never read
-    const bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
-    const int cx = ok ? cell_coord(p.x, b.ox, b.inv_h, b.nx) : 0, cy = ok ? cell_coord(p.y, b.oy, b.inv_h, b.ny) : 0,
-              cz = ok ? cell_coord(p.z, b.oz, b.inv_h, b.nz) : 0;
-#pragma unroll
-    for (unsigned c = 0; c < 4; ++c) {
-        const unsigned j = (unsigned)cy + (c & 1u), k = (unsigned)cz + (c >> 1);
-        keys[4 * (size_t)i + c] = ok ? (k * rows_y + j) * (unsigned)b.nx + (unsigned)cx : trash;
-        vals[4 * (size_t)i + c] = i;
-    }
-}
-// ... and, after the (stable) sort by key, the entries themselves
-__global__ __launch_bounds__(kBlock) void block_gather_kernel(const float4* __restrict__ gpts,
-                                                              const unsigned* __restrict__ order, unsigned m,
-                                                              float4* __restrict__ out) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= m) return;
-    const unsigned pos = order[i];
-    float4 p = gpts[pos];
-    p.w = __uint_as_float(pos);
-    out[i] = p;
-}
-
 // Certificates of the correspondence reuse (fused_point), from one k = 3 self-search on the target grid (row i, original
 // order: the point itself at 0, its nearest other point u1, its second-nearest u2; -1 / FLT_MAX when missing):
 //   rho2[i]  = (d(t, u1) / 2)^2            first test:  |q - t|^2 < rho2            (stored in t's covariance row)
@@ -730,9 +700,6 @@ struct FusedParams {
     const unsigned* tstart;
     const float4* tcovp;   // grid-ordered prepared target covariances
     const float4* tnb;     // grid order: second certificate of the reuse test (certificate_kernel), may be null
-    const float4* bpts;    // block rows of the target (grid_device.h), may be null
-    const unsigned* bstart;
-    BlockDesc b;
     GridDesc g;
     unsigned n;
     float max_d2, scale;
@@ -868,12 +835,12 @@ __device__ __forceinline__ float search_bound2(const FusedParams& P) {
     return (P.nn_idx == nullptr && P.max_d2 < FLT_MAX) ? __uint_as_float(__float_as_uint(P.max_d2) + 1u) : FLT_MAX;
 }
 
-// One source point of the fused iteration: q = T p -> correspondence (cache row by certificate or on trust, else exact NN
-// on the target grid) -> linearise -> accumulate.
-// P.cache_valid: 0 the cache holds nothing (every point is searched), 1 a row is used when its certificate holds, 2 every row
-// is exact for THIS pose already (gicp_search_kernel ran before this launch): a pure coalesced stream of 84 bytes per point
-// (12 p + 24 Cs' as planes + 48 cache row), no search, no gather.
-template <int LOSS, bool FAST_NN, bool P2D = false, bool COMPACT_NN = false>
+// One source point of the fused iteration: q = T p -> correspondence (cache row by certificate, else exact NN on the target
+// grid) -> linearise -> accumulate.
+// P.cache_valid: 0 the cache holds nothing (every point is searched), 1 a row is used when its certificate holds: while
+// correspondences hold, an iteration is a pure coalesced stream of 84 bytes per point (12 p + 24 Cs' as planes + 48 cache
+// row) with no search and no gather, and a wave whose lanes all pass never enters the search code.
+template <int LOSS, bool FAST_NN, bool P2D = false>
 __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
                                             unsigned& cnt, unsigned& searched) {
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
@@ -887,7 +854,7 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         const float4 r0 = row[0], r1 = row[1], r2 = row[2];
         const float d = dist2(qx, qy, qz, r0.x, r0.y, r0.z);
         const unsigned pos = __float_as_uint(r2.w);
-        if (P.cache_valid == 2 ? r0.w >= 0.0f : certified(P, d, r0.w, qx, qy, qz, pos)) {
+        if (certified(P, d, r0.w, qx, qy, qz, pos)) {
             hit = true;
             nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
             nn.d2 = nn.idx >= 0 ? d : FLT_MAX;
@@ -898,18 +865,7 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         ++searched;
         const float bound2 = search_bound2(P);
         if (FAST_NN) {
-            if (COMPACT_NN) {
-                // the streaming launch of the device-resident loop: its searches are stragglers (the search launch takes the
-                // bulk), so the stages after the exact 2x2x2 block are the plain ring walk seeded with that block's winner —
-                // the same answer as the batched stages (exact, ties to the lowest index), in far fewer registers, which
-                // this kernel needs for its 28 accumulators
-                if (!grid_nn1_fast<4>(P.tpts, P.tstart, P.g, qx, qy, qz, nn, bound2)) {
-                    const Nearest seed = nn;
-                    nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 0);
-                }
-            } else {
-                nn = grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz, bound2);
-            }
+            nn = grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz, bound2);
         } else {
             Nearest seed;
             seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f;
@@ -983,33 +939,23 @@ __global__ __launch_bounds__(kBlock) void error_prepared_kernel(FusedParams P, M
 // Whole alignment on the device (Registration::align's Gauss-Newton loop, registration.hpp:229-276), no host round trip:
 // pose, convergence flag and iteration count live in a small state block in HBM that ping-pongs between iterations.
 //
-//   iteration k = [ gicp_search_kernel ]  ->  gicp_align_kernel   (-> all-reduce -> align_solve_kernel, sharded runs)
+//   iteration k = gicp_align_kernel   (-> all-reduce -> align_solve_kernel, sharded runs)
 //
-// gicp_align_kernel streams the source once: per point the cached correspondence (certified, or on trust when the search
-// launch ran before it; stragglers are searched inline), linearisation, 28 sums in registers, one 32-float partial row per
-// workgroup. On one GPU the workgroup whose arrival ticket is the last one then finishes the iteration by itself: it sums the
-// launch's <= 256 rows in a fixed order, solves (H + lambda I) delta = -b, updates the pose and publishes the next state —
-// so the next launch starts from 18 words instead of summing 32 KB and solving a 6x6 system in every one of its workgroups.
-// Once is_converged() holds, the remaining launches return immediately (the reference breaks out of its loop).
+// gicp_align_kernel streams the source once: per point the cached correspondence when its certificate holds, else a search
+// (fused_point), linearisation, 28 sums in registers, one 32-float partial row per workgroup. On one GPU the workgroup whose
+// arrival ticket is the last one then finishes the iteration by itself: it sums the launch's <= 256 rows in a fixed order,
+// solves (H + lambda I) delta = -b, updates the pose and publishes the next state — so the next launch starts from 18 words
+// instead of summing 32 KB and solving a 6x6 system in every one of its workgroups (round 2's prologue, 5.6 us of a 25 us
+// launch). Once is_converged() holds, the remaining launches return immediately (the reference breaks out of its loop).
 //
-// gicp_search_kernel (the first launches of an alignment, sp_gicp_source_set_search_launches): the points whose cached
-// correspondence is NOT certified for this iteration's pose are the expensive ones — a search is a chain of dependent
-// gathers, and inside the streaming kernel it runs in waves where only the uncertified lanes work, under a register
-// budget sized for 28 accumulators. Here they are compacted (per workgroup, through LDS) and the exact first block of each
-// is scanned on dense waves, two queries per lane in lockstep, from the target's block rows (grid_device.h: the block is ONE
-// contiguous run there). A winner that the block proves goes to the cache with its prepared rows; the rest (about one in
-// eight) is only marked, and the streaming launch walks the later stages for them beside its stream. The kernel refreshes
-// cache rows and nothing else; the streaming launch that follows linearises EVERY point in its usual order, so sums and
-// poses are bit-identical with and without it.
+// Measured and NOT kept (profiles/r03_search_launch_experiments_not_kept.txt, profiles/README.md): moving the searches of the
+// first iterations into a launch of their own (uncertified points compacted per workgroup, two queries per lane in
+// lockstep, first block from a 4x duplicated "block row" copy of the target where it is one contiguous run). Standing
+// alone, the exact first block of 1M queries takes 71 us (TA 67 % busy: ~44 TA cycles per scattered 16-byte wave load, 39 of
+// them per 64 queries) against the 22 us it adds inside this kernel, where it overlaps the linearisation of other waves.
 constexpr int kAlignBlock = 1024;      // 16 waves: one workgroup per CU at 4 waves/SIMD -> 256 partial rows
 constexpr int kAlignMaxBlocks = 256;
 constexpr int kSearchedLog = 64;       // launches of an alignment whose searched-point counts are kept
-constexpr int kSearchBlock = 256;
-constexpr int kSearchChunk = 512;      // source points per workgroup of the search launch (two per lane)
-constexpr int kSearchShards = 32;
-constexpr float kUnresolved = -1.0f;   // rho^2 of a cache row the search launch left to the streaming launch
-constexpr size_t kBlockRowsMinPoints = 65536;       // targets below this get no block rows (and no search launches)
-constexpr double kBlockRowsPointsPerCell = 2.0;
 
 struct AlignState {
     float T[16];          // pose after the iterations finished so far
@@ -1039,23 +985,13 @@ struct AlignArgs {
     int mode;
     unsigned* searched_log;      // [iteration] -> source points searched for
     int k;                       // index of this iteration in its alignment
-    int search_launch;           // a gicp_search_kernel was enqueued for this iteration
-    unsigned min_defer;          // ... and it runs (and this launch trusts it) iff iteration k - 1 searched at least this many
     float* fan_row_out;          // this iteration's row (kFanRow floats)
     const float* fan_row_in;     // align_solve_kernel: the same row, all-reduced over the ranks
     unsigned* fan_counter;       // arrival tickets; 0 when a launch starts, reset by the last arriver
-    unsigned* search_shards;     // the search launch's counters (SearchArgs)
 };
 // Row of the fan-in: 0..27 the sums, 28 / 29 the inlier count as two floats that stay exact under a float sum over ranks
 // (count = hi * 4096 + lo, as sp_linearized carries it), 30 the searched-point count (a float value), 31 unused.
 constexpr int kFanRow = 32;
-
-// Does the search launch of iteration k run? Uniform over both grids (the search kernel and the streaming kernel evaluate it
-// on the same data): always for k = 0; later only while the previous iteration still searched a noticeable share of its
-// points — afterwards the few stragglers are cheaper inline than two more launches.
-__device__ __forceinline__ bool search_launch_runs(const unsigned* searched_log, int k, unsigned min_defer) {
-    return k == 0 || (k <= kSearchedLog && searched_log[k - 1] >= min_defer);
-}
 
 // Pose (-> sT) and flags (-> sflag: converged, iterations) of this iteration. Returns false when an earlier iteration
 // converged: workgroup 0 then carries the state forward and the launch has nothing to do.
@@ -1116,7 +1052,7 @@ __device__ __forceinline__ void align_finish_iteration(const AlignArgs& A, const
 // The sum is reduce_rows_1024's fixed order over the launch's `grid` rows: bit-reproducible, and the same bits in both modes.
 // The last arriver resets the ticket counter for the next launch.
 __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __restrict__ partials, const float* sT,
-                                           const unsigned* sflag, bool trusted) {
+                                           const unsigned* sflag) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ unsigned s_last;
     __shared__ sp_linearized slin;
@@ -1133,22 +1069,7 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
     __syncthreads();
     if (!s_last) return;  // uniform per workgroup
     reduce_rows_1024<true>(partials, gridDim.x, kAcc - 1, red, false);
-    // points this iteration searched for: counted by the search launch when it ran (its shards are summed and cleared here),
-    // by this launch's lanes otherwise
     const bool log_k = A.searched_log && A.k < kSearchedLog;
-    if (trusted) {
-        unsigned v = threadIdx.x < kSearchShards ? __hip_atomic_load(A.search_shards + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        if (threadIdx.x < kWave) {
-            v = wave_sum_u32(v);
-            if (threadIdx.x < kSearchShards) A.search_shards[threadIdx.x] = 0u;
-            if (threadIdx.x == 0) {
-                red[1][0] = __uint_as_float(v);
-                if (log_k) A.searched_log[A.k] = v;
-            }
-        }
-        __syncthreads();
-    }
-    const unsigned searched_by_launch = trusted ? __float_as_uint(red[1][0]) : 0u;
     if (A.mode == ALIGN_FANIN) {
         if (threadIdx.x < kFanRow) {
             const unsigned cnt = __float_as_uint(red[0][kAcc - 1]);
@@ -1156,14 +1077,13 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
             if (threadIdx.x < kAcc - 1) v = red[0][threadIdx.x];
             else if (threadIdx.x == kAcc - 1) v = (float)(cnt & 4095u);
             else if (threadIdx.x == kAcc) v = (float)(cnt >> 12);
-            else if (threadIdx.x == kAcc + 1) v = trusted ? (float)searched_by_launch : red[0][kAcc];
+            else if (threadIdx.x == kAcc + 1) v = red[0][kAcc];
             A.fan_row_out[threadIdx.x] = v;
         }
-        if (threadIdx.x == 0 && !trusted && log_k) A.searched_log[A.k] = (unsigned)red[0][kAcc];
+        if (threadIdx.x == 0 && log_k) A.searched_log[A.k] = (unsigned)red[0][kAcc];
     } else if (threadIdx.x == 0) {
-        unsigned searched = (unsigned)red[0][kAcc];
-        if (trusted) searched = searched_by_launch;
-        else if (log_k) A.searched_log[A.k] = searched;
+        const unsigned searched = (unsigned)red[0][kAcc];
+        if (log_k) A.searched_log[A.k] = searched;
         align_finish_iteration(A, red[0], sT, sflag[1], searched, slin, sTn, sdelta, ldlt_ws);
     }
     if (threadIdx.x == 0) __hip_atomic_store(A.fan_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1177,9 +1097,6 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag,
                      A.mode == ALIGN_FANIN ? A.fan_row_out : nullptr))
         return;
-    // the search launch ran for this pose: every cache row is exact, nothing to certify or search
-    const bool trusted = A.search_launch && search_launch_runs(A.searched_log, A.k, A.min_defer);
-    if (trusted) P.cache_valid = 2;
     // the pose is uniform: move it to scalar registers (it would otherwise occupy 12 VGPRs for the whole loop)
     Rigid T = load_rigid_colmajor(sT);
     auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -1199,12 +1116,12 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     unsigned tile = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-        fused_point<LOSS, FAST_NN, P2D, true>(P, T, i, acc, cnt, searched);
+        fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
     if (A.mode == ALIGN_ROWS) {
         block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, true, searched);
     } else {
         block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
-        align_tail(A, partials, sT, sflag, trusted);
+        align_tail(A, partials, sT, sflag);
     }
 }
 
@@ -1244,210 +1161,6 @@ __global__ void align_publish_kernel(const AlignState* __restrict__ state, float
     if (threadIdx.x < 16) T_out[threadIdx.x] = state->T[threadIdx.x];
     else if (threadIdx.x < 24 && delta_out8) delta_out8[threadIdx.x - 16] = state->delta[threadIdx.x - 16];
     else if (threadIdx.x == 24 && iterations_out) *iterations_out = state->iterations;
-}
-
-struct SearchArgs {
-    const float* T_init;
-    const AlignState* state_in;
-    int has_prev;
-    const unsigned* searched_log;
-    unsigned* search_shards;  // kSearchShards counters: points this launch searched for (summed and cleared by the streaming launch)
-    int k;
-    unsigned min_defer;
-};
-
-// One workgroup = kSearchChunk consecutive source points, two per lane. A search is a chain of dependent gathers (point ->
-// run extent -> candidates -> winner's rows), and a workgroup is as many memory round trips deep as its longest lane
-// whatever its size: the kernel then takes that long however few points need a search. So every stage is run for BOTH of a
-// lane's queries before the next one starts — their loads are in flight together and a stage costs one round trip per
-// workgroup, not one per query — and nothing deeper than the first block is walked here.
-__global__ __launch_bounds__(kSearchBlock) void gicp_search_kernel(FusedParams P, SearchArgs A) {
-    constexpr int Q = kSearchChunk / kSearchBlock;  // queries per lane and stage
-    __shared__ float sT[16];
-    __shared__ unsigned sflag[2];
-    __shared__ unsigned q1[kSearchChunk];  // uncertified points of this chunk
-    __shared__ unsigned n1;
-    if (threadIdx.x == 32) n1 = 0;
-    if (!align_begin(A.T_init, A.state_in, nullptr, A.has_prev, sT, sflag)) return;
-    if (!search_launch_runs(A.searched_log, A.k, A.min_defer)) return;  // uniform: the streaming launch searches inline
-    Rigid T = load_rigid_colmajor(sT);
-    auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) T.R[r][c] = uniform(T.R[r][c]);
-        T.t[r] = uniform(T.t[r]);
-    }
-    const unsigned base = blockIdx.x * kSearchChunk;
-    const unsigned lane = threadIdx.x & (kWave - 1);
-    const unsigned last = P.n - 1;  // P.n >= 1 (the launch has a workgroup)
-    // wave-aggregated append to a queue in LDS: one LDS atomic per wave, lanes take consecutive slots
-    auto append = [&](bool want, unsigned* counter) -> unsigned {
-        const unsigned long long mask = __ballot(want);
-        const int leader = mask ? __builtin_ctzll(mask) : 0;
-        unsigned b = 0;
-        if (mask != 0ull && lane == (unsigned)leader) b = atomicAdd(counter, (unsigned)__popcll(mask));
-        b = (unsigned)__shfl((int)b, leader, kWave);
-        return b + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-    };
-    // ---- 1. which points need a search: all of them while the cache is empty, else those whose certificate fails at this pose
-    {
-        unsigned i[Q];
-        bool fail[Q];
-        float4 r0[Q];
-        float sx[Q], sy[Q], sz[Q];
-        unsigned pos[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            i[j] = base + j * kSearchBlock + threadIdx.x;
-            fail[j] = i[j] < P.n;
-            pos[j] = 0;
-            if (P.cache_valid) {
-                const unsigned ic = min(i[j], last);
-                r0[j] = P.ccache[3 * (size_t)ic];
-                sx[j] = P.src[ic]; sy[j] = P.src[P.sstride + ic]; sz[j] = P.src[2 * (size_t)P.sstride + ic];
-                if (P.tnb) pos[j] = __float_as_uint(reinterpret_cast<const float*>(P.ccache + 3 * (size_t)ic + 2)[3]);
-            }
-        }
-        if (P.cache_valid) {
-            float qx[Q], qy[Q], qz[Q], d[Q];
-            bool second[Q];
-            float4 nb[Q];
-#pragma unroll
-            for (int j = 0; j < Q; ++j) {
-                transform_point(T, sx[j], sy[j], sz[j], qx[j], qy[j], qz[j]);
-                d[j] = dist2(qx[j], qy[j], qz[j], r0[j].x, r0[j].y, r0[j].z);
-                const bool pass = d[j] < r0[j].w;
-                second[j] = fail[j] && !pass && P.tnb && r0[j].w > 0.0f;  // the second certificate: one more gather
-                fail[j] = fail[j] && !pass;
-                if (second[j]) nb[j] = P.tnb[pos[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < Q; ++j)
-                if (second[j] && d[j] < nb[j].w && d[j] < dist2(qx[j], qy[j], qz[j], nb[j].x, nb[j].y, nb[j].z)) fail[j] = false;
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            const unsigned slot = append(fail[j], &n1);
-            if (fail[j]) q1[slot] = i[j];
-        }
-    }
-    __syncthreads();
-    const unsigned c1 = n1;
-    if (c1 == 0u) return;  // uniform per workgroup: every point of this chunk is certified
-    const float bound2 = search_bound2(P);
-    const unsigned long long none = nn_key(bound2, -1);
-    // ---- 2. the exact 2x2x2 block of every queued point as ONE contiguous run of the target's block rows, Q queries per
-    //         lane in lockstep: proven winners go to the cache with their prepared rows, the others are queued with their bound
-    {
-        unsigned i[Q];
-        bool act[Q];
-        float qx[Q], qy[Q], qz[Q], cov[Q];
-        unsigned rs[Q], re[Q];
-        {
-            float sx[Q], sy[Q], sz[Q];
-#pragma unroll
-            for (int j = 0; j < Q; ++j) {
-                const unsigned e = j * kSearchBlock + threadIdx.x;
-                act[j] = e < c1;
-                i[j] = act[j] ? q1[e] : 0u;
-                sx[j] = P.src[i[j]]; sy[j] = P.src[P.sstride + i[j]]; sz[j] = P.src[2 * (size_t)P.sstride + i[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < Q; ++j) {
-                transform_point(T, sx[j], sy[j], sz[j], qx[j], qy[j], qz[j]);
-                const bool usable = act[j] && isfinite(qx[j]) && isfinite(qy[j]) && isfinite(qz[j]);
-                // (a non-finite or idle query reads the first run and is given an empty one)
-                block_extent(P.bstart, P.b, usable ? qx[j] : P.b.ox, usable ? qy[j] : P.b.oy, usable ? qz[j] : P.b.oz, rs[j], re[j],
-                             cov[j]);
-                act[j] = usable;
-            }
-#pragma unroll
-            for (int j = 0; j < Q; ++j)
-                if (!act[j]) re[j] = rs[j];
-        }
-        // (squared distance, position) as one 64-bit key: its minimum is the nearest candidate. Exactly equidistant candidates
-        // must resolve to the lowest ORIGINAL index like every other search here; the key would pick the lowest position, so a
-        // tie at the running minimum is flagged and settled below (it takes duplicate target points to get there).
-        unsigned long long key[Q];
-        bool tie[Q];
-        unsigned most = 0;
-#pragma unroll
-        for (int j = 0; j < Q; ++j) { key[j] = none; tie[j] = false; most = max(most, re[j] - rs[j]); }
-        constexpr int B = 8;  // candidates per query and round trip
-        const unsigned bend = 4u * P.g.n - 1u;
-        for (unsigned b0 = 0; b0 < most; b0 += B) {
-            float4 cand[Q][B];
-#pragma unroll
-            for (int j = 0; j < Q; ++j)
-#pragma unroll
-                for (int c = 0; c < B; ++c) cand[j][c] = P.bpts[min(rs[j] + b0 + c, bend)];
-#pragma unroll
-            for (int j = 0; j < Q; ++j)
-#pragma unroll
-                for (int c = 0; c < B; ++c) {
-                    const float d = dist2(qx[j], qy[j], qz[j], cand[j][c].x, cand[j][c].y, cand[j][c].z);
-                    unsigned long long k2 = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cand[j][c].w);
-                    k2 = (rs[j] + b0 + c < re[j]) ? k2 : ~0ull;
-                    const unsigned hi_new = (unsigned)(k2 >> 32), hi_old = (unsigned)(key[j] >> 32);
-                    tie[j] = hi_new < hi_old ? false : (tie[j] || (hi_new == hi_old && k2 != ~0ull && key[j] != none));
-                    key[j] = k2 < key[j] ? k2 : key[j];
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            if (tie[j]) {  // rare: among the candidates at the winning distance take the lowest original index
-                const unsigned dbits = (unsigned)(key[j] >> 32);
-                int best_idx = 0x7fffffff;
-                unsigned best_pos = (unsigned)key[j];
-                for (unsigned b = rs[j]; b < re[j]; ++b) {
-                    const float4 c = P.bpts[b];
-                    if (__float_as_uint(dist2(qx[j], qy[j], qz[j], c.x, c.y, c.z)) != dbits) continue;
-                    const int idx = __float_as_int(P.tpts[__float_as_uint(c.w)].w);
-                    if (idx < best_idx) { best_idx = idx; best_pos = __float_as_uint(c.w); }
-                }
-                key[j] = ((unsigned long long)dbits << 32) | best_pos;
-            }
-        }
-        // winners: the point (x, y, z, index) and, when it is proven, its prepared rows — one round trip for all
-        bool found[Q], proven[Q];
-        unsigned pos[Q];
-        float4 w[Q], c0[Q], c1r[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            found[j] = key[j] != none;
-            pos[j] = found[j] ? min((unsigned)key[j], P.g.n - 1u) : 0u;
-            const float d2 = found[j] ? __uint_as_float((unsigned)(key[j] >> 32)) : bound2;
-            const float cv = fmaxf(cov[j] * P.b.h - P.b.eps, 0.0f);
-            // an idle slot and a non-finite query are "proven": nothing to find (grid_nn1_fast)
-            proven[j] = !act[j] || d2 < cv * cv;
-            w[j] = P.tpts[pos[j]];
-            if (found[j] && proven[j]) { c0[j] = P.tcovp[2 * (size_t)pos[j]]; c1r[j] = P.tcovp[2 * (size_t)pos[j] + 1]; }
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            const bool queued = j * kSearchBlock + threadIdx.x < c1;
-            if (!queued) continue;
-            float4* const row = P.ccache + 3 * (size_t)i[j];
-            if (!proven[j]) {
-                // The stages after the first block are a long chain of dependent gathers: a workgroup that walked it for a
-                // handful of points would hold the whole launch for its length. The streaming launch hides such chains behind
-                // its stream, so the point is only marked for it (rho^2 < 0: "search me", kUnresolved).
-                row[0] = make_float4(0.0f, 0.0f, 0.0f, kUnresolved);
-            } else if (found[j]) {
-                row[0] = make_float4(w[j].x, w[j].y, w[j].z, c1r[j].z);
-                row[1] = c0[j];
-                row[2] = make_float4(c1r[j].x, c1r[j].y, w[j].w, __uint_as_float(pos[j]));
-            } else {
-                row[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                row[1] = row[0];
-                row[2] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
-            }
-        }
-    }
-    // (sharded: two thousand adds to ONE word would take longer than the searches, ~12 ns apiece)
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(A.search_shards + (blockIdx.x & (kSearchShards - 1)), c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 unsigned reduce_grid(size_t n) {
@@ -1642,9 +1355,6 @@ struct sp_gicp_target {
     float4* covp = nullptr;         // 2 x float4 per target point, grid order: (xx,xy,xz,yy | yz,zz,rho^2,0)
     float* rho2 = nullptr;          // per target point (original order): squared safe radius of the reuse test
     float4* nb = nullptr;           // per target point (grid order): second certificate (nearest neighbour, second radius)
-    float4* bpts = nullptr;         // block rows (grid_device.h): 4 entries per target point, nullptr for small targets
-    unsigned* bstart = nullptr;
-    sp::BlockDesc bdesc{};
     unsigned long long version = 0; // bumped by every sp_gicp_target_update (cached copies of rows become stale)
     int reg_type = SP_REG_GICP;     // what the rows hold: plane(Ct) for GICP, inverse(Ct) for POINT_TO_DISTRIBUTION
     size_t n = 0;
@@ -1665,8 +1375,6 @@ struct sp_gicp_source {
     int opt_stage_mask = 3;  // bit 0 = per-iteration kernel, bit 1 = final reduce (+ solve) / finish kernel
     int opt_reuse = 2;       // 0 always search, 1 reuse on the first certificate, 2 also the second
     int opt_fast_nn = -1;    // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
-    int opt_launch_select = 3;  // bit 0 = the search launch of an iteration, bit 1 = its streaming launch (per-kernel timing)
-    int search_launches = 6;    // sp_gicp_source_set_search_launches: iterations that get a dedicated search launch
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -1678,8 +1386,6 @@ extern "C" void sp_gicp_target_destroy(sp_gicp_target* t) {
     sp::pooled_free_after(t->covp, t->streams);
     sp::pooled_free_after(t->rho2, t->streams);
     sp::pooled_free_after(t->nb, t->streams);
-    sp::pooled_free_after(t->bpts, t->streams);
-    sp::pooled_free_after(t->bstart, t->streams);
     delete t;
 }
 extern "C" int sp_gicp_target_prepare(sp_gicp_target* t, const float* tgt_covs, int reg_type, void* stream) {
@@ -1755,53 +1461,6 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
             inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
             certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb);
             rc2 = launch_status();
-        }
-        // block rows for the search launches of the device-resident loop (large targets only: they cost four sort keys per
-        // point to build and 64 bytes per point to keep)
-        ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp;
-        if (rc2 == SP_OK && n >= kBlockRowsMinPoints && 4 * n < (1ull << 31)) {
-            const sp_grid* g = grid;
-            BlockDesc bd;
-            const double cells = (double)g->dims[0] * g->dims[1] * g->dims[2];
-            float hb = g->h * (float)std::cbrt(kBlockRowsPointsPerCell * cells / (double)n);
-            if (!(hb > 0.0f) || !std::isfinite(hb)) hb = g->h;
-            size_t table = 0;
-            for (;;) {  // the lattice-row table is bounded like the grid's cell table
-                bd.nx = (int)std::floor((double)g->dims[0] * g->h / hb) + 1;
-                bd.ny = (int)std::floor((double)g->dims[1] * g->h / hb) + 1;
-                bd.nz = (int)std::floor((double)g->dims[2] * g->h / hb) + 1;
-                table = (size_t)bd.nx * (size_t)(bd.ny + 1) * (size_t)(bd.nz + 1);
-                if (table <= (1ull << 25)) break;
-                hb *= 1.26f;
-            }
-            bd.h = hb; bd.inv_h = 1.0f / hb; bd.eps = g->eps * (1.0f + hb / g->h);
-            bd.ox = g->org[0]; bd.oy = g->org[1]; bd.oz = g->org[2];
-            const size_t m = 4 * n;
-            const size_t tmp_bytes = radix_sort_u32_workspace_bytes(m);
-            e = b_kin.get(m * 4);
-            if (e == hipSuccess) e = b_kout.get(m * 4);
-            if (e == hipSuccess) e = b_vin.get(m * 4);
-            if (e == hipSuccess) e = b_vout.get(m * 4);
-            if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(tmp_bytes, 16));
-            if (e == hipSuccess) e = pooled_alloc(&t->bpts, m * sizeof(float4));
-            if (e == hipSuccess) e = pooled_alloc(&t->bstart, (table + 1) * sizeof(unsigned));
-            if (e != hipSuccess) rc2 = SP_ERR_HIP;
-            if (rc2 == SP_OK) {
-                unsigned *kin = b_kin.as<unsigned>(), *kout = b_kout.as<unsigned>(), *vin = b_vin.as<unsigned>(),
-                         *vout = b_vout.as<unsigned>();
-                block_key_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(g->d_pts, (unsigned)n, bd, kin, vin);
-                unsigned end_bit = 1;
-                while ((1ull << end_bit) <= table && end_bit < 32) ++end_bit;
-                bool in_b = false;
-                rc2 = radix_sort_pairs_u32(kin, kout, vin, vout, m, end_bit, b_tmp.p, tmp_bytes, &in_b, st);
-                if (!in_b) { kout = kin; vout = vin; }
-                if (rc2 == SP_OK) {
-                    block_gather_kernel<<<div_up(m, kBlock), kBlock, 0, st>>>(g->d_pts, vout, (unsigned)m, t->bpts);
-                    cell_start_kernel<<<div_up(m + 1, kBlock), kBlock, 0, st>>>(kout, (unsigned)m, (unsigned)table, t->bstart);
-                    rc2 = launch_status();
-                    t->bdesc = bd;
-                }
-            }
         }
         if (hipStreamSynchronize(st) != hipSuccess && rc2 == SP_OK) rc2 = SP_ERR_HIP;
         if (rc2 != SP_OK) {
@@ -1914,9 +1573,6 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
     P.tstart = target->grid->d_start;
     P.tcovp = target->covp;
     P.tnb = source->opt_reuse > 1 ? target->nb : nullptr;
-    P.bpts = target->bpts;
-    P.bstart = target->bstart;
-    P.b = target->bdesc;
     P.g = grid_desc(target->grid);
     P.n = (unsigned)n;
     P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
@@ -2017,7 +1673,6 @@ struct AlignWs {  // workspace: partial rows A | partial rows B | state A | stat
     unsigned* searched_log;  // kSearchedLog entries
     float* fan_row[2];       // fan-in rows (kFanRow floats each), ping-pong like the partial rows
     unsigned* fan_counter;   // arrival tickets of the last-arriver logic
-    unsigned* search_shards; // kSearchShards counters of the search launch
 };
 AlignWs align_ws(void* workspace) {
     AlignWs w;
@@ -2028,10 +1683,9 @@ AlignWs align_ws(void* workspace) {
     w.fan_row[0] = reinterpret_cast<float*>(w.searched_log + kSearchedLog);
     w.fan_row[1] = w.fan_row[0] + kFanRow;
     w.fan_counter = reinterpret_cast<unsigned*>(w.fan_row[1] + kFanRow);
-    w.search_shards = w.fan_counter + 4;
     return w;
 }
-constexpr size_t kAlignResetBytes = (kSearchedLog + 2 * kFanRow + 4 + kSearchShards) * sizeof(float);  // log | rows | tickets | shards: zero at k = 0
+constexpr size_t kAlignResetBytes = (kSearchedLog + 2 * kFanRow + 4) * sizeof(float);  // log | rows | tickets: zero at k = 0
 unsigned align_grid(size_t n) {
     unsigned grid = div_up(n, kAlignBlock);
     return grid > (unsigned)kAlignMaxBlocks ? (unsigned)kAlignMaxBlocks : (grid ? grid : 1u);
@@ -2060,12 +1714,9 @@ AlignArgs align_args(const AlignWs& w, float* transT_device, const sp_gn_params*
     A.mode = mode;
     A.searched_log = w.searched_log;
     A.k = j;
-    A.search_launch = 0;
-    A.min_defer = 0;
     A.fan_row_out = w.fan_row[j & 1];
     A.fan_row_in = w.fan_row[j & 1];
     A.fan_counter = w.fan_counter;
-    A.search_shards = w.search_shards;
     return A;
 }
 // Sharded modes: finish iteration j from the all-reduced row(s) (enqueued behind the caller's collective).
@@ -2118,12 +1769,6 @@ extern "C" int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gic
     return launch_status();
 }
 
-extern "C" int sp_gicp_source_set_search_launches(sp_gicp_source* source, int launches) {
-    if (!source || launches < 0) return SP_ERR_INVALID_ARGUMENT;
-    source->search_launches = launches > sp::kSearchedLog ? sp::kSearchedLog : launches;
-    return SP_OK;
-}
-
 extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                                  const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
                                  int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
@@ -2136,9 +1781,7 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     const size_t n = source->n;
     const AlignWs w = align_ws(workspace);
     const int mode = rows_all_reduced;
-    if (!(source->opt_launch_select & 1)) {
-        // (per-kernel timing, sp_internal.h: the first half of this iteration was enqueued by the previous call)
-    } else if (k == 0) {
+    if (k == 0) {
         // searched-point log, fan-in rows, arrival tickets (the caller's workspace comes as it is); ALIGN_ROWS: every rank
         // all-reduces all kAlignMaxBlocks rows whatever its own tile size, rows a rank does not write stay zero
         if (zero_async(w.searched_log, kAlignResetBytes, st) != SP_OK) return SP_ERR_HIP;
@@ -2149,25 +1792,15 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
         launch_solve(w, transT_device, gn, k - 1, mode, lin_out, st);  // the caller has all-reduced iteration k - 1's row(s)
     }
     target->note(st);
-    FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
+    const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
     const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1);
     const unsigned grid = align_grid(n);
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
     AlignArgs A = align_args(w, transT_device, gn, k, mode, lin_out);
-    // The dedicated search launch: for the first iterations of an alignment, on a cell-ordered source large enough that a
-    // second launch is cheaper than searching inside half-empty streaming waves (below ~100 k points an iteration is
-    // launch-bound either way). ALIGN_ROWS keeps round 1's single-launch form.
-    A.search_launch = (fast && P.ccache != nullptr && P.bpts != nullptr && mode != ALIGN_ROWS && k < source->search_launches &&
-                       n >= 100000) ? 1 : 0;
-    A.min_defer = (unsigned)(n / 128 > 0 ? n / 128 : 1);
-    if (A.search_launch && (source->opt_stage_mask & 1) && (source->opt_launch_select & 1)) {
-        SearchArgs S{transT_device, A.state_in, A.has_prev, w.searched_log, w.search_shards, k, A.min_defer};
-        gicp_search_kernel<<<div_up(n, kSearchChunk), kSearchBlock, 0, st>>>(P, S);
-    }
     float* out = w.part[k & 1];
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_ALIGN(L)                                                                            \
-    if (!(source->opt_stage_mask & 1) || !(source->opt_launch_select & 2)) {}                             \
+    if (!(source->opt_stage_mask & 1)) {}                                                                 \
     else if (fast && p2d) gicp_align_kernel<L, true, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);     \
     else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);              \
     else if (p2d) gicp_align_kernel<L, false, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);         \
@@ -2181,7 +1814,7 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
 #undef SP_LAUNCH_ALIGN
-    if (fills_cache && (source->opt_launch_select & 2)) source->cache_valid = true;
+    if (fills_cache) source->cache_valid = true;
     return launch_status();
 }
 
@@ -2257,7 +1890,6 @@ extern "C" int sp_internal_source_option(sp_gicp_source* s, int option, int valu
         case SP_INTERNAL_FUSED_STAGE_MASK: s->opt_stage_mask = value; return SP_OK;
         case SP_INTERNAL_FUSED_REUSE: s->opt_reuse = value; s->cache_valid = false; return SP_OK;
         case SP_INTERNAL_FUSED_FAST_NN: s->opt_fast_nn = value; return SP_OK;
-        case SP_INTERNAL_FUSED_LAUNCH_SELECT: s->opt_launch_select = value; return SP_OK;
     }
     return SP_ERR_INVALID_ARGUMENT;
 }

@@ -26,10 +26,7 @@ enum {
      * 0 ring walk, 1 fast path. */
     SP_INTERNAL_FUSED_FAST_NN = 2,
     /* sp_grid: self-kNN kernel: 0 (default) chosen by k, 1 LDS-tile kernel (k <= 10), 2 wave-cooperative kernel. */
-    SP_INTERNAL_SELF_KNN_MODE = 3,
-    /* sp_gicp_source: which launches of an iteration sp_gicp_align_step enqueues: bit 0 the search launch, bit 1 the
-     * streaming launch. Default 3. bench.py calls a step twice (1, then 2) with an event in between to time each kernel. */
-    SP_INTERNAL_FUSED_LAUNCH_SELECT = 4
+    SP_INTERNAL_SELF_KNN_MODE = 3
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);

@@ -347,6 +347,28 @@ static void registration_matches_oracle() {
         std::cout.rdbuf(old);
         CHECK(max_abs_diff(rv.T.matrix(), rc.T.matrix().data()) < 2e-6f && rv.iterations == rc.iterations);
     }
+    // compute_error_frozen after align() (registration.hpp:350-359): the reference evaluates the neighbours its last
+    // linearisation left behind. After the device-resident loop they live in the prepared source's correspondence cache,
+    // frozen at the pose before the last update; the generic path keeps them in neighbors_. Both must give the same error
+    // at the same trial pose (to the rounding of the two factor formulations) and the same inlier count.
+    {
+        alg::registration::Registration rf(*Q, p), rg(*Q, p);
+        rg.set_accelerate_kdtree(false);
+        const auto af = rf.align(source, target, *grid);   // device loop, prepared path
+        const auto ag = rg.align(source, target, *tree);   // host loop, KNNBase + K11
+        CHECK(max_abs_diff(af.T.matrix(), ag.T.matrix().data()) < 2e-6f);
+        TransformMatrix trial = af.T.matrix();
+        trial(0, 3) += 0.01f;
+        const auto [ef, nf] = rf.compute_error_frozen(source, target, trial);
+        const auto [eg, ng] = rg.compute_error_frozen(source, target, trial);
+        CHECK(nf == ng && nf == af.inlier);
+        CHECK(std::fabs(ef - eg) <= 2e-5f * std::fabs(eg));
+        CHECK(ef > af.error);  // off the optimum
+        alg::registration::Registration fresh(*Q, p);
+        bool threw = false;
+        try { (void)fresh.compute_error_frozen(source, target, trial); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);  // nothing linearised yet: a clear error, not a read of stale neighbours
+    }
     // Powell dogleg (registration.hpp:897-965) against the oracle's restatement
     {
         alg::registration::RegistrationParams pd = p;

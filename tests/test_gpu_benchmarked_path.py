@@ -237,12 +237,10 @@ def test_full_oracle_alignment_config4_1m(sp, orc, config4, reg_type):
 
 
 @pytest.mark.parametrize("reg_type", ["GICP", "POINT_TO_DISTRIBUTION"])
-def test_search_launches_change_no_bit(sp, config4, reg_type):
-    """The dedicated search launches of the device-resident loop (gicp_search_kernel: uncertified points compacted and searched
-    on dense waves before the streaming launch, sp_gicp_source_set_search_launches) only refresh cache rows; the streaming
-    launch linearises every point in its usual order. So pose, system, delta, iteration count, neighbours and distances are
-    bit-identical with 0 (every search inline), 2, 6 (default) and 20 search launches, with reuse on and off, at config-4
-    size; and the searched-point log tells the same story either way."""
+def test_linearization_pose_and_searched_log(sp, config4, reg_type):
+    """sp_gicp_align_linearization_pose: the pose the correspondence cache is exact for after an alignment — the pose before
+    the last update (T = T_lin * exp(delta)); and the device-side log of searched points: everything in launch 0, stragglers
+    once the correspondences hold (GICP), at config-4 size. A second run reproduces every bit (fixed summation tree)."""
     import ctypes as C
 
     n, src, tgt, T_gt, Tg, grid, prep_gicp = config4
@@ -253,11 +251,9 @@ def test_search_launches_change_no_bit(sp, config4, reg_type):
     S = sp.PointCloudShared(S_all, covs=covs)
     L = sp._lib.lib()
 
-    def run(launches, reuse, crit):
+    def run(crit):
         p = sp.RegistrationParams(reg_type=reg_type, criteria_translation=crit, criteria_rotation=crit, max_iterations=20)
         reg = sp.Registration(p)
-        reg.set_search_launches(launches)
-        reg._set_source_option("reuse", reuse)
         T_dev, lin, delta = reg.align_fused_loop(S, prep, sort_by_cell="presorted", write_neighbors=True)
         torch.cuda.synchronize()
         ws, _ = reg._buffers(T_dev.device)
@@ -272,16 +268,15 @@ def test_search_launches_change_no_bit(sp, config4, reg_type):
                 reg.neighbors.distances.cpu().numpy().ravel().copy(), T_lin.cpu().numpy().copy(), log]
 
     for crit in (0.0, 1e-3):
-        ref = run(0, 2, crit)
-        assert ref[7][0] == n and (reg_type != "GICP" or (ref[7][3:] < n // 100).all())  # all searched at first, stragglers later
-        for launches, reuse in ((2, 2), (6, 2), (20, 2), (6, 0)):
-            got = run(launches, reuse, crit)
-            for a, b in zip(ref[:7], got[:7]):
-                assert np.array_equal(a, b), (reg_type, crit, launches, reuse)
-            if reuse == 2:
-                assert np.array_equal(ref[7], got[7]), (ref[7], got[7])
-        # the pose of the last linearisation: T = T_lin * exp(delta) was the last update
+        ref, again = run(crit), run(crit)
+        for a, b in zip(ref, again):
+            assert np.array_equal(a, b), (reg_type, crit)
+        assert ref[7][0] == n and (reg_type != "GICP" or (ref[7][3:] < n // 100).all())
         iters = int(ref[3][0])
-        assert iters == (20 if crit == 0.0 else iters) and iters >= 1
-        T, T_lin = ref[0].reshape(4, 4).T, ref[6].reshape(4, 4).T
-        assert np.abs(T - T_lin).max() < (1e-5 if crit == 0.0 else 2e-3) and np.abs(T_lin - T_gt).max() < 1e-2
+        assert iters == 20 if crit == 0.0 else 1 <= iters < 20
+        assert (ref[7][iters:] == 0).all()  # launches after convergence search nothing
+        T, T_lin, delta = ref[0].reshape(4, 4).T, ref[6].reshape(4, 4).T, ref[2]
+        from oracle.pyoracle import Oracle  # T = T_lin * se3_exp(delta): the last Gauss-Newton update
+        step = Oracle().se3_exp(delta[:6])
+        assert np.abs(T_lin @ step - T).max() < 1e-5
+        assert np.abs(T_lin - T_gt).max() < 1e-2
