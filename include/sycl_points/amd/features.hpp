@@ -255,12 +255,16 @@ private:
              const TimestampContainerShared* ts, PointContainerShared& out_pts, RGBContainerShared* out_rgb,
              IntensityContainerShared* out_inten, TimestampContainerShared* out_ts) {
         const size_t ws_bytes = sp_voxel_downsample_workspace_bytes(N);
-        detail::DeviceScratch ws(ws_bytes), info(32);  // voxel count | boxed-path status | this cloud's key box (6 ints)
+        // voxel count | boxed-path status | key box of sp_voxel_key_box (6 ints) | this cloud's key box, sharded
+        constexpr int kInfoInts = 32 + SP_VOXEL_BOX_SHARD_STRIDE * SP_VOXEL_BOX_SHARDS;
+        detail::DeviceScratch ws(ws_bytes), info(kInfoInts * 4);
         hipStream_t st = queue_.stream();
         uint32_t* info_dev = static_cast<uint32_t*>(info.p);
+        int32_t h[kInfoInts];
         // The sort runs on keys compressed to the (widened) key box of the PREVIOUS cloud — scans of one sensor have similar
-        // extents; the device verifies that this cloud fits, otherwise the 64-bit sort is used: same results either way.
-        throw_on_error(sp_voxel_key_box(pts, N, voxel_size_inv_, reinterpret_cast<int32_t*>(info_dev + 2), st));
+        // extents; the device verifies that this cloud fits, and the key kernel finds this cloud's own box on the way (next
+        // call's guess; the exact box of the redo when the cloud did not fit). The first call has no guess and computes the
+        // box first: every call sorts compressed keys (the 64-bit sort is left for boxes of >= 2^32 cells).
         auto launch = [&](const int32_t* box) {
             throw_on_error(sp_voxel_downsample_boxed(
                 pts, N, voxel_size_inv_, min_voxel_count_, rgb ? reinterpret_cast<const float*>(rgb->device_data()) : nullptr,
@@ -268,16 +272,28 @@ private:
                 reinterpret_cast<float*>(out_pts.device_data_for_write(N)),
                 rgb ? reinterpret_cast<float*>(out_rgb->device_data_for_write(N)) : nullptr,
                 inten ? out_inten->device_data_for_write(N) : nullptr, ts ? out_ts->device_data_for_write(N) : nullptr, nullptr,
-                info_dev, box, info_dev + 1, ws.p, ws_bytes, st));
-        };
-        launch(have_key_box_ ? key_box_ : nullptr);
-        int32_t h[8];
-        hip_check(hipMemcpyAsync(h, info.p, sizeof h, hipMemcpyDeviceToHost, st), "D2H");
-        hip_check(hipStreamSynchronize(st), "sync");
-        if (h[1] != 0) {  // the cloud left the remembered box
-            launch(nullptr);
-            hip_check(hipMemcpyAsync(h, info.p, 4, hipMemcpyDeviceToHost, st), "D2H");
+                info_dev, box, info_dev + 1, reinterpret_cast<int32_t*>(info_dev + 32), ws.p, ws_bytes, st));
+            hip_check(hipMemcpyAsync(h, info.p, sizeof h, hipMemcpyDeviceToHost, st), "D2H");
             hip_check(hipStreamSynchronize(st), "sync");
+            for (int a = 0; a < 3; ++a) {  // fold the shards into h[2..7]
+                h[2 + a] = INT32_MAX; h[5 + a] = INT32_MIN;
+                for (int s = 0; s < SP_VOXEL_BOX_SHARDS; ++s) {
+                    h[2 + a] = std::min(h[2 + a], h[32 + SP_VOXEL_BOX_SHARD_STRIDE * s + a]);
+                    h[5 + a] = std::max(h[5 + a], h[32 + SP_VOXEL_BOX_SHARD_STRIDE * s + 3 + a]);
+                }
+            }
+        };
+        if (!have_key_box_) {
+            throw_on_error(sp_voxel_key_box(pts, N, voxel_size_inv_, reinterpret_cast<int32_t*>(info_dev + 2), st));
+            hip_check(hipMemcpyAsync(h, info.p, 32, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipStreamSynchronize(st), "sync");
+            have_key_box_ = h[2] <= h[5] && h[3] <= h[6] && h[4] <= h[7];
+            for (int a = 0; a < 6; ++a) key_box_[a] = h[2 + a];
+        }
+        launch(have_key_box_ ? key_box_ : nullptr);
+        if (h[1] != 0) {  // the cloud left the remembered box: again, with its own
+            int32_t exact[6] = {h[2], h[3], h[4], h[5], h[6], h[7]};
+            launch(exact);
         }
         have_key_box_ = h[2] <= h[5] && h[3] <= h[6] && h[4] <= h[7];
         for (int a = 0; a < 3 && have_key_box_; ++a) {

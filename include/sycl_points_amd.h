@@ -159,9 +159,11 @@ int sp_voxel_keys(const float* points, size_t n, float inv_voxel_size, uint64_t*
 /* VoxelGrid::downsampling (filter/voxel_downsampling.hpp:50-79, 146-288): per-voxel mean of the points (and of rgb
  * and timestamps, median of intensities, when those attribute pointers are non-NULL), voxels with
  * point_sum.w < min_voxel_count dropped, output in ascending key order. The host std::sort + sequential
- * run-length mean of the reference is replaced by a device radix sort of (key, index) and a segmented reduction;
+ * run-length mean of the reference is replaced by a device radix sort of (key, index) (64-bit keys here: 8 passes; see the
+ * boxed form below for the fast path) and a segmented reduction;
  * within a voxel points are summed in ascending index order (the reference's order is unspecified: its sort is
- * unstable). *n_out_dev (a device uint32) receives the voxel count; out arrays must hold n entries.
+ * unstable). *n_out_dev (a device uint32) receives the voxel count; out arrays must hold n entries and must not overlap
+ * the inputs.
  * workspace: sp_voxel_downsample_workspace_bytes(n) bytes. */
 size_t sp_voxel_downsample_workspace_bytes(size_t n);
 int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
@@ -172,16 +174,23 @@ int sp_voxel_downsample(const float* points, size_t n, float inv_voxel_size, siz
 /* The same operation with the bounding box of the cloud's voxel coordinates known to the HOST (box6 = min x,y,z, max x,y,z
  * of the 21-bit key fields; sp_voxel_key_box computes it on the device: read it back, or keep the previous scan's box and
  * check *status_dev_opt). The keys are then compressed to the voxel's position in the box — same order — and sorted by
- * exactly the bits the box needs (3 passes of the hand-written radix sort for a 200^3 box instead of a 64-bit sort: the sort is most of the
- * run time). Results are identical to sp_voxel_downsample. *status_dev_opt receives the number of valid points whose voxel
- * lies outside the box: non-zero means the box did not cover the cloud and the outputs must be discarded. A NULL, empty or
- * too large box (>= 2^32 - 1 cells) falls back to the 64-bit path. */
+ * exactly the bits the box needs (3 passes of the hand-written radix sort for a 200^3 box; the unboxed call sorts the 64-bit
+ * keys in 8 passes of the same sort: the sort is most of the run time). Results are identical to sp_voxel_downsample.
+ * *status_dev_opt receives the number of valid points whose voxel lies outside the box: non-zero means the box did not
+ * cover the cloud and the outputs must be discarded. A NULL, empty or too large box (>= 2^32 - 1 cells) falls back to the
+ * 64-bit path.
+ * box_shards_dev_opt (SP_VOXEL_BOX_SHARDS shards of SP_VOXEL_BOX_SHARD_STRIDE ints — one 128-byte line each — of which the
+ * first 6 are used): the key kernel also records THIS cloud's coordinate box on the way — fold the shards (min of
+ * [s][0..2], max of [s][3..5]; an empty cloud leaves INT32_MAX / INT32_MIN) for the next call's guess, or for the exact box
+ * of a redo when *status_dev_opt != 0. No separate pass over the points. */
+#define SP_VOXEL_BOX_SHARDS 16
+#define SP_VOXEL_BOX_SHARD_STRIDE 32
 int sp_voxel_key_box(const float* points, size_t n, float inv_voxel_size, int32_t* box6_dev, void* stream);
 int sp_voxel_downsample_boxed(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
                               const float* rgb, const float* intensities, const float* timestamps, float* points_out,
                               float* rgb_out, float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt,
-                              uint32_t* n_out_dev, const int32_t* box6_host, uint32_t* status_dev_opt, void* workspace,
-                              size_t workspace_bytes, void* stream);
+                              uint32_t* n_out_dev, const int32_t* box6_host, uint32_t* status_dev_opt,
+                              int32_t* box_shards_dev_opt, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------- transform */
 

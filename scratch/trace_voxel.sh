@@ -9,7 +9,7 @@ rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # last call: find the last key_box / key32 kernel and print from there
 names=[r["Kernel_Name"] for r in rows]
-last=max(i for i,n in enumerate(names) if "key_box_kernel" in n)
+last=max(i for i,n in enumerate(names) if "voxel_init_kernel" in n)
 t0=int(rows[last]["Start_Timestamp"])
 for r in rows[last:]:
     print("%8.1f us  +%7.1f  %s"%((int(r["Start_Timestamp"])-t0)/1e3,(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3,r["Kernel_Name"][:90]))

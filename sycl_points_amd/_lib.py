@@ -94,7 +94,7 @@ SIGNATURES = {
     "sp_voxel_downsample_workspace_bytes": (_sz, [_sz]),
     "sp_voxel_downsample": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_voxel_key_box": (_i, [_vp, _sz, _f, _vp, _vp]),
-    "sp_voxel_downsample_boxed": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_voxel_downsample_boxed": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_transform": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sp_box_filter_flags": (_i, [_vp, _sz, _f, _f, _vp, _vp]),
     "sp_compact_workspace_bytes": (_sz, [_sz]),
@@ -160,6 +160,7 @@ INTERNAL_SIGNATURES = {
     "sp_internal_radix_sort_workspace_bytes": (_sz, [_sz]),
     "sp_internal_radix_sort_u32": (_i, [_vp, _vp, _vp, _vp, _sz, C.c_uint, _vp, _sz, _vp, _vp]),
 }
+VOXEL_BOX_SHARDS, VOXEL_BOX_SHARD_STRIDE = 16, 32  # SP_VOXEL_BOX_SHARDS, SP_VOXEL_BOX_SHARD_STRIDE
 INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3}
 
 

@@ -487,25 +487,32 @@ class VoxelGrid:
         o_i = torch.empty(n, dtype=torch.float32, device=p.device) if inten is not None else None
         o_t = torch.empty(n, dtype=torch.float32, device=p.device) if ts is not None else None
         o_k = torch.empty(n, dtype=torch.int64, device=p.device) if return_keys else None
-        # One read-back at the end: voxel count, boxed-path status, and this cloud's key box (6 ints), which the NEXT call
-        # uses, widened by a margin, to sort keys compressed to that box. A cloud that leaves the remembered box is
-        # detected (status != 0) and redone on the 64-bit path, so results never depend on the guess.
-        info = torch.zeros(8, dtype=torch.int32, device=p.device)
+        # One read-back at the end: voxel count, boxed-path status, and this cloud's key box (sharded, found by the key
+        # kernel on the way), which the NEXT call uses, widened by a margin, to sort keys compressed to that box. A cloud that
+        # leaves the remembered box is detected (status != 0) and redone with its own exact box, so results never depend on
+        # the guess. The first call of a VoxelGrid has no guess: it computes the box first (sp_voxel_key_box, one small
+        # read-back) — every call sorts compressed keys; the 64-bit sort is left for boxes of >= 2^32 cells.
+        S, ST = _lib.VOXEL_BOX_SHARDS, _lib.VOXEL_BOX_SHARD_STRIDE
+        info = torch.zeros(32 + ST * S, dtype=torch.int32, device=p.device)
         base = info.data_ptr()
-        check(L.sp_voxel_key_box(_ptr(p), n, self.voxel_size_inv, C.c_void_p(base + 8), _stream()))
-        guess = getattr(self, "_key_box", None) if boxed else None
         args = (_ptr(p), n, self.voxel_size_inv, self.min_voxel_count, _ptr(rgb), _ptr(inten), _ptr(ts), _ptr(o_p), _ptr(o_c),
                 _ptr(o_i), _ptr(o_t), _ptr(o_k), C.c_void_p(base))
-        if guess is not None:
-            check(L.sp_voxel_downsample_boxed(*args, guess.ctypes.data_as(C.c_void_p), C.c_void_p(base + 4), _ptr(ws), nbytes,
-                                              _stream()))
-        else:
-            check(L.sp_voxel_downsample(*args, _ptr(ws), nbytes, _stream()))
-        counts = info.cpu().numpy()
-        if counts[1] != 0:  # the cloud left the remembered box
-            check(L.sp_voxel_downsample(*args, _ptr(ws), nbytes, _stream()))
-            counts[0] = info[:1].cpu().numpy()[0]
-        box = counts[2:8].astype(np.int64)
+
+        def run(box):
+            check(L.sp_voxel_downsample_boxed(*args, None if box is None else box.ctypes.data_as(C.c_void_p),
+                                              C.c_void_p(base + 4), C.c_void_p(base + 128), _ptr(ws), nbytes, _stream()))
+            c = info.cpu().numpy()
+            sh = c[32:].reshape(S, ST)[:, :6].astype(np.int64)
+            return c, np.concatenate([sh[:, :3].min(0), sh[:, 3:].max(0)])
+
+        guess = getattr(self, "_key_box", None) if boxed else None
+        if guess is None and boxed:
+            check(L.sp_voxel_key_box(_ptr(p), n, self.voxel_size_inv, C.c_void_p(base + 8), _stream()))
+            b0 = info[2:8].cpu().numpy().astype(np.int64)
+            guess = np.ascontiguousarray(b0.astype(np.int32)) if (b0[:3] <= b0[3:]).all() else None
+        counts, box = run(guess)
+        if counts[1] != 0:  # the cloud left the remembered box: again, with its own
+            counts, box = run(np.ascontiguousarray(box.astype(np.int32)))
         if boxed and (box[:3] <= box[3:]).all():
             margin = np.maximum(2, (box[3:] - box[:3] + 1) // 8)
             lo = np.maximum(box[:3] - margin, 0)

@@ -19,7 +19,6 @@
 // neighbour.
 #include <cstring>
 
-#include <rocprim/device/device_scan.hpp>
 
 #include "grid_device.h"
 #include "radix_sort.h"
@@ -1149,7 +1148,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     size_t stmp_bytes = 0;
     ScratchBuf b_units, b_stmp;
     if (e == hipSuccess) {
-        (void)rocprim::exclusive_scan(nullptr, stmp_bytes, units, units, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+        stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
         e = b_units.get((rows + 1) * 4);
         if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4);
         if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
@@ -1171,7 +1170,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
                                                                           g->d_start);
         // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed (same stream: no sync between)
         row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
-        e = rocprim::exclusive_scan(stmp, stmp_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+        if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, stmp, stmp_bytes, st) != SP_OK) e = hipErrorUnknown;
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // the temporaries are idle from here on
@@ -1230,9 +1229,8 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     float4* new_pts = nullptr;
     size_t tmp_bytes = 0, tmp2_bytes = 0;
     const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
-    unsigned* null_u = nullptr;
-    (void)rocprim::exclusive_scan(nullptr, tmp_bytes, null_u, null_u, 0u, n + 1, rocprim::plus<unsigned>(), st);
-    (void)rocprim::exclusive_scan(nullptr, tmp2_bytes, null_u, null_u, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+    tmp_bytes = exclusive_scan_u32_workspace_bytes(n + 1);
+    tmp2_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
     hipError_t e = b_keep.get((n + 1) * 4);
     if (e == hipSuccess) e = b_scan.get((n + 1) * 4);
     if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(std::max(tmp_bytes, tmp2_bytes), 16));
@@ -1251,8 +1249,7 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     unsigned* const units = b_units.as<unsigned>();
     unsigned* const new_start = b_start.as<unsigned>();
     grid_keep_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(g->d_pts, (unsigned)n, flags, (unsigned)n_flags, keep);
-    e = rocprim::exclusive_scan(b_tmp.p, tmp_bytes, keep, scan, 0u, n + 1, rocprim::plus<unsigned>(), st);
-    if (e != hipSuccess) return fail(e);
+    if (exclusive_scan_u32(keep, scan, n + 1, nullptr, b_tmp.p, tmp_bytes, st) != SP_OK) return fail(hipErrorUnknown);
     grid_compact_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(g->d_pts, (unsigned)n, flags, new_indices, (unsigned)n_flags,
                                                               scan, new_pts);
     grid_restart_kernel<<<div_up(g->ncells + 1, kBlock), kBlock, 0, st>>>(g->d_start, g->ncells, scan, new_start);
@@ -1261,7 +1258,7 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     if (e == hipSuccess) e = hipMemcpyAsync(g->d_start, new_start, (g->ncells + 1) * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(e);
     row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
-    e = rocprim::exclusive_scan(b_tmp.p, tmp2_bytes, units, g->d_unit_off, 0u, rows + 1, rocprim::plus<unsigned>(), st);
+    if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, b_tmp.p, tmp2_bytes, st) != SP_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(e);

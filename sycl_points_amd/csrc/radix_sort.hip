@@ -10,10 +10,19 @@
 //                      eight ballots, per-wave counters in LDS, wave order = memory order), the tile is reordered by digit in
 //                      LDS, and runs of equal digit leave as contiguous, coalesced stores
 // No spinning, no cross-workgroup ordering inside a launch (nothing can hang), deterministic, stable.
+//
+// Round 3, measured and not kept (profiles/r03_stage_timings_lookback_sort_not_kept.json): one launch per pass with the tile
+// offsets by decoupled look-back (Onesweep's scheme: ticketed tiles, one AGGREGATE / PREFIX word per tile and digit, each
+// digit's lane walking back over its predecessors). At these sizes every tile of a pass is resident at once, all of them
+// publish their counts at the same moment and the walk of tile t is ~t/2 dependent L2 round trips long: a pass took ~35 us
+// against 21 us for the three launches (voxel downsampling 0.202 ms against 0.161, grid build 0.38 against 0.31).
+// The same kernels are templated on the key type: 64-bit keys (the uncompressed voxel keys) sort in ceil(bits / 8) passes of
+// the same three launches, which replaced the library's merge sort on that path (21 launches, 200 us per 1M keys).
 #include "radix_sort.h"
 
 #include "sp_common.h"
 #include "sp_internal.h"
+#include "sp_lookback.h"
 
 namespace sp {
 namespace {
@@ -26,23 +35,24 @@ constexpr int kRsBins = 256;                // 8-bit digits
 constexpr int kRsScanThreads = 256;
 
 // tile_hist is stored [digit][tile]: the scan over the tiles of a digit reads one contiguous row.
-__global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const uint32_t* __restrict__ keys, unsigned n, unsigned shift,
+template <typename KEY>
+__global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const KEY* __restrict__ keys, unsigned n, unsigned shift,
                                                               unsigned mask, unsigned tiles, unsigned* __restrict__ tile_hist) {
     __shared__ unsigned h[kRsWaves][kRsBins];  // one histogram per wave: eight times less contention on a popular digit
     for (unsigned i = threadIdx.x; i < kRsWaves * kRsBins; i += kRsThreads) (&h[0][0])[i] = 0u;
     __syncthreads();
     const unsigned base = blockIdx.x * kRsTile, w = threadIdx.x >> 6;
-    uint32_t k[kRsItems];
+    KEY k[kRsItems];
 #pragma unroll
     for (int c = 0; c < kRsItems; ++c) {
         const unsigned e = base + c * kRsThreads + threadIdx.x;
-        k[c] = e < n ? keys[e] : 0u;
+        k[c] = e < n ? keys[e] : (KEY)0;
     }
 #pragma unroll
     for (int c = 0; c < kRsItems; ++c) {
         const unsigned e = base + c * kRsThreads + threadIdx.x;
         const bool valid = e < n;
-        const unsigned d = (k[c] >> shift) & mask;
+        const unsigned d = (unsigned)(k[c] >> shift) & mask;
         const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
         const unsigned long long vm = __ballot(valid);
         if (__ballot(valid && d != d0) == 0ull) {  // the high digits of a compact key range: the whole wave agrees
@@ -104,9 +114,10 @@ __global__ __launch_bounds__(kRsScanThreads) void rs_scan_kernel(unsigned* __res
     if (threadIdx.x == 0) digit_total[d] = carry;
 }
 
-__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
+template <typename KEY>
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const KEY* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
-                                                                uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                                KEY* __restrict__ kout, uint32_t* __restrict__ vout,
                                                                 unsigned n, unsigned shift, unsigned mask, unsigned tiles,
                                                                 const unsigned* __restrict__ tile_off,
                                                                 const unsigned* __restrict__ digit_total) {
@@ -114,7 +125,8 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     __shared__ unsigned tstart[kRsBins];         // tile-local position of the digit's first key
     __shared__ unsigned dbase[kRsBins];          // global position of the digit's first key of this tile
     __shared__ unsigned wave_tot[kRsWaves];
-    __shared__ uint32_t lk[kRsTile], lv[kRsTile];
+    __shared__ KEY lk[kRsTile];
+    __shared__ uint32_t lv[kRsTile];
     const unsigned tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const unsigned base = blockIdx.x * kRsTile;
     const unsigned m = min((unsigned)kRsTile, n - base);
@@ -125,21 +137,22 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     }
     __syncthreads();
     // wave w owns the keys [w * 512, (w + 1) * 512) of the tile, 64 at a time: memory order = (wave, chunk, lane)
-    uint32_t k[kRsItems], v[kRsItems];
+    KEY k[kRsItems];
+    uint32_t v[kRsItems];
     unsigned rank[kRsItems];
     const unsigned long long lt = (1ull << lane) - 1ull;
     volatile unsigned* const my_cnt = cnt[w];
 #pragma unroll
     for (int c = 0; c < kRsItems; ++c) {
         const unsigned e = w * (kRsTile / kRsWaves) + c * 64 + lane;
-        k[c] = e < m ? kin[base + e] : 0u;
+        k[c] = e < m ? kin[base + e] : (KEY)0;
         v[c] = e < m ? vin[base + e] : 0u;
     }
 #pragma unroll
     for (int c = 0; c < kRsItems; ++c) {
         const unsigned e = w * (kRsTile / kRsWaves) + c * 64 + lane;
         const bool valid = e < m;
-        const unsigned d = (k[c] >> shift) & mask;
+        const unsigned d = (unsigned)(k[c] >> shift) & mask;
         unsigned long long peers = __ballot(valid);  // lanes of this chunk holding the same digit
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     for (int c = 0; c < kRsItems; ++c) {
         const unsigned e = w * (kRsTile / kRsWaves) + c * 64 + lane;
         if (e < m) {
-            const unsigned d = (k[c] >> shift) & mask;
+            const unsigned d = (unsigned)(k[c] >> shift) & mask;
             const unsigned pos = tstart[d] + cnt[w][d] + rank[c];
             lk[pos] = k[c];
             lv[pos] = v[c];
@@ -176,13 +189,14 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     }
     __syncthreads();
     for (unsigned j = tid; j < m; j += kRsThreads) {
-        const uint32_t kk = lk[j];
-        const unsigned d = (kk >> shift) & mask;
+        const KEY kk = lk[j];
+        const unsigned d = (unsigned)(kk >> shift) & mask;
         const unsigned dst = dbase[d] + (j - tstart[d]);
         kout[dst] = kk;
         vout[dst] = lv[j];
     }
 }
+
 
 }  // namespace
 
@@ -190,6 +204,33 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
 size_t radix_sort_u32_workspace_bytes(size_t n) {
     return ((size_t)div_up(n ? n : 1, (size_t)kRsTile) * kRsBins + kRsBins) * sizeof(unsigned);
 }
+size_t radix_sort_u64_workspace_bytes(size_t n) { return radix_sort_u32_workspace_bytes(n); }
+
+namespace {
+template <typename KEY>
+int radix_sort_pairs(KEY* keys_a, KEY* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits, void* workspace,
+                     bool* result_in_b, hipStream_t st, unsigned first_bit) {
+    const unsigned tiles = div_up(n, (size_t)kRsTile);
+    unsigned* const tile_hist = static_cast<unsigned*>(workspace);
+    unsigned* const digit_total = tile_hist + (size_t)tiles * kRsBins;
+    KEY *kin = keys_a, *kout = keys_b;
+    uint32_t *vin = vals_a, *vout = vals_b;
+    bool in_b = false;
+    for (unsigned shift = first_bit; shift < bits; shift += 8) {
+        const unsigned width = bits - shift < 8 ? bits - shift : 8;
+        const unsigned mask = (1u << width) - 1u;
+        rs_count_kernel<KEY><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+        rs_scan_kernel<<<kRsBins, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
+        rs_scatter_kernel<KEY><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
+                                                             digit_total);
+        KEY* t = kin; kin = kout; kout = t;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+        in_b = !in_b;
+    }
+    *result_in_b = in_b;
+    return launch_status();
+}
+}  // namespace
 
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
                          void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st, unsigned first_bit) {
@@ -197,23 +238,71 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
     if (n == 0 || bits <= first_bit) return SP_OK;
     if (n >= (1ull << 32) - kRsTile || bits > 32 || !workspace || workspace_bytes < radix_sort_u32_workspace_bytes(n))
         return SP_ERR_INVALID_ARGUMENT;
-    const unsigned tiles = div_up(n, (size_t)kRsTile);
-    unsigned* const tile_hist = static_cast<unsigned*>(workspace);
-    unsigned* const digit_total = tile_hist + (size_t)tiles * kRsBins;
-    uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
-    bool in_b = false;
-    for (unsigned shift = first_bit; shift < bits; shift += 8) {
-        const unsigned width = bits - shift < 8 ? bits - shift : 8;
-        const unsigned mask = (1u << width) - 1u;
-        rs_count_kernel<<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
-        rs_scan_kernel<<<kRsBins, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
-        rs_scatter_kernel<<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
-                                                        digit_total);
-        uint32_t* t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
-        in_b = !in_b;
+    return radix_sort_pairs<uint32_t>(keys_a, keys_b, vals_a, vals_b, n, bits, workspace, result_in_b, st, first_bit);
+}
+
+// 64-bit keys (the uncompressed voxel keys, voxel_constants.hpp:36-62): the same passes over the low `bits` <= 64 key bits.
+int radix_sort_pairs_u64(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
+                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st) {
+    *result_in_b = false;
+    if (n == 0 || bits == 0) return SP_OK;
+    if (n >= (1ull << 32) - kRsTile || bits > 64 || !workspace || workspace_bytes < radix_sort_u64_workspace_bytes(n))
+        return SP_ERR_INVALID_ARGUMENT;
+    return radix_sort_pairs<uint64_t>(keys_a, keys_b, vals_a, vals_b, n, bits, workspace, result_in_b, st, 0);
+}
+
+// ------------------------------------------------------------------ exclusive scan (u32), one launch
+// Tiles of 2048 values, tile prefixes by decoupled look-back with a wave-wide window (sp_lookback.h): even with every tile
+// resident at once the walk is a handful of steps (it is the per-digit, one-lane walk of a radix pass that does not pay,
+// see above).
+namespace {
+__global__ __launch_bounds__(kRsThreads) void scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, unsigned n,
+                                                          unsigned* __restrict__ state, unsigned* __restrict__ ticket,
+                                                          unsigned* __restrict__ error, uint32_t* __restrict__ total_out) {
+    __shared__ unsigned wave_tot[kRsWaves];
+    __shared__ unsigned s_tile, s_excl;
+    const unsigned tid = threadIdx.x, w = tid >> 6;
+    if (tid == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned tile = s_tile;
+    const unsigned base = tile * kRsTile + tid * kRsItems;  // blocked: a lane owns kRsItems consecutive values
+    uint32_t v[kRsItems];
+    unsigned sum = 0;
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        v[c] = base + c < n ? in[base + c] : 0u;
+        sum += v[c];
     }
-    *result_in_b = in_b;
+    unsigned tile_total;
+    const unsigned before = block_excl_scan<kRsWaves>(sum, wave_tot, &tile_total);
+    if (w == 0) {
+        const unsigned excl = lookback_exclusive(state, tile, tile_total, error);
+        if (tid == 0) {
+            s_excl = excl;
+            if (total_out && (size_t)(tile + 1) * kRsTile >= n) *total_out = excl + tile_total;  // the last tile
+        }
+    }
+    __syncthreads();
+    unsigned run = s_excl + before;
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        if (base + c < n) out[base + c] = run;
+        run += v[c];
+    }
+}
+}  // namespace
+
+size_t exclusive_scan_u32_workspace_bytes(size_t n) { return ((size_t)div_up(n ? n : 1, (size_t)kRsTile) + 64) * sizeof(unsigned); }
+
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, void* workspace, size_t workspace_bytes,
+                       hipStream_t st) {
+    if (n == 0) return total_out ? zero_async(total_out, sizeof(uint32_t), st) : SP_OK;
+    if (n >= (1ull << 32) - kRsTile || !workspace || workspace_bytes < exclusive_scan_u32_workspace_bytes(n))
+        return SP_ERR_INVALID_ARGUMENT;
+    const unsigned tiles = div_up(n, (size_t)kRsTile);
+    unsigned* const ws = static_cast<unsigned*>(workspace);  // [0] ticket, [1] error, [64 ...] one state word per tile
+    if (zero_async(ws, (tiles + 64) * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
+    scan_kernel<<<tiles, kRsThreads, 0, st>>>(in, out, (unsigned)n, ws + 64, ws, ws + 1, total_out);
     return launch_status();
 }
 

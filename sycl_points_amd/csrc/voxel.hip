@@ -4,15 +4,13 @@
 //
 // The reference computes keys on the device, then copies them to the host, std::sort's an index array and walks
 // the runs sequentially. Here everything stays in HBM:
-//   keys (24 B/pt) -> device LSD radix sort of (key u64, index u32) -> one pass that finds run heads and lets the
-//   head lane sum its run in ascending point-index order (the sort is stable) -> exclusive scan of keep flags ->
-//   scatter in ascending key order.
-// Sort and scan use rocPRIM's device primitives (radix_sort_pairs / exclusive_scan); the key, aggregation and
-// scatter kernels are written here. Headline algorithmic bytes: 40 B/pt (key kernel + one aggregation pass).
+//   keys (24 B/pt) -> device LSD radix sort of (key, index u32) -> one pass that finds run heads and lets the
+//   head lane sum its run in ascending point-index order (the sort is stable) -> exclusive scan of the workgroups' kept
+//   counts -> scatter in ascending key order.
+// Sort and scan are this library's own (radix_sort.hip: stable LSD radix sort of 32- or 64-bit keys, look-back scan); the
+// key, aggregation and scatter kernels are written here. Headline algorithmic bytes: 40 B/pt (key kernel + one
+// aggregation pass).
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "radix_sort.h"
 #include "sp_common.h"
@@ -109,19 +107,62 @@ struct KeyBox {
     unsigned nx, ny, nz;
     unsigned invalid;
 };
+constexpr int kBoxShards = SP_VOXEL_BOX_SHARDS, kBoxStride = SP_VOXEL_BOX_SHARD_STRIDE;
+__global__ __launch_bounds__(kBlock) void voxel_init_kernel(uint32_t* status, int32_t* box_shards) {  // one launch for both
+    if (threadIdx.x == 0 && status) *status = 0u;
+    if (box_shards && threadIdx.x < kBoxShards * 6)
+        box_shards[(threadIdx.x / 6) * kBoxStride + threadIdx.x % 6] = (threadIdx.x % 6) < 3 ? INT32_MAX : INT32_MIN;
+}
+// box_shards (optional, initialised by voxel_init_kernel): the bounding box of THIS cloud's voxel coordinates, found on the
+// way (the next call's guess; the exact box for a redo when the cloud left the one it was given) — a separate pass over the
+// points cost 13.8 us per 1M. Sharded, every shard on a 128-byte line of its own: atomics on one LINE queue up at the L2
+// (two thousand workgroups on sixteen shards packed into six lines took 12 us); the caller folds the shards.
 __global__ __launch_bounds__(kBlock) void key32_kernel(const float4* __restrict__ pts, unsigned n, float inv, KeyBox b,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                       uint32_t* __restrict__ status) {
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        int c0, c1, c2;
-        uint32_t key = b.invalid;
-        if (voxel_coords(pts[i], inv, c0, c1, c2)) {
-            const unsigned x = (unsigned)(c0 - b.x0), y = (unsigned)(c1 - b.y0), z = (unsigned)(c2 - b.z0);
-            if (x < b.nx && y < b.ny && z < b.nz) key = (z * b.ny + y) * b.nx + x;
-            else if (status) atomicAdd(status, 1u);
+                                                       uint32_t* __restrict__ status, int32_t* __restrict__ box_shards) {
+    int lo0 = INT32_MAX, lo1 = INT32_MAX, lo2 = INT32_MAX, hi0 = INT32_MIN, hi1 = INT32_MIN, hi2 = INT32_MIN;
+    // four independent loads per trip (a latency chain otherwise)
+    const unsigned stride = gridDim.x * kBlock;
+    for (unsigned i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[min(i0 + u * stride, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * stride;
+            if (i >= n) continue;
+            int c0, c1, c2;
+            uint32_t key = b.invalid;
+            if (voxel_coords(p[u], inv, c0, c1, c2)) {
+                lo0 = min(lo0, c0); lo1 = min(lo1, c1); lo2 = min(lo2, c2);
+                hi0 = max(hi0, c0); hi1 = max(hi1, c1); hi2 = max(hi2, c2);
+                const unsigned x = (unsigned)(c0 - b.x0), y = (unsigned)(c1 - b.y0), z = (unsigned)(c2 - b.z0);
+                if (x < b.nx && y < b.ny && z < b.nz) key = (z * b.ny + y) * b.nx + x;
+                else if (status) atomicAdd(status, 1u);
+            }
+            keys[i] = key;
+            vals[i] = i;
         }
-        keys[i] = key;
-        vals[i] = i;
+    }
+    if (!box_shards) return;  // uniform
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        lo0 = min(lo0, __shfl_xor(lo0, off)); lo1 = min(lo1, __shfl_xor(lo1, off)); lo2 = min(lo2, __shfl_xor(lo2, off));
+        hi0 = max(hi0, __shfl_xor(hi0, off)); hi1 = max(hi1, __shfl_xor(hi1, off)); hi2 = max(hi2, __shfl_xor(hi2, off));
+    }
+    __shared__ int red[kBlock / kWave][6];
+    const unsigned wave = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red[wave][0] = lo0; red[wave][1] = lo1; red[wave][2] = lo2;
+        red[wave][3] = hi0; red[wave][4] = hi1; red[wave][5] = hi2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = red[0][threadIdx.x];
+        for (unsigned w = 1; w < kBlock / kWave; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        int32_t* const dst = box_shards + kBoxStride * (blockIdx.x & (kBoxShards - 1)) + threadIdx.x;
+        if (threadIdx.x < 3) { if (v != INT32_MAX) atomicMin(dst, v); }
+        else if (v != INT32_MIN) atomicMax(dst, v);
     }
 }
 __device__ __forceinline__ uint64_t expand_key(uint32_t k, const KeyBox& b) {
@@ -155,6 +196,10 @@ struct AggPtrs {
     float* t_ts;
 };
 
+// (Round 3, measured and not kept: aggregation, offsets and scatter as ONE launch with the workgroups' output offsets by
+// decoupled look-back over one word per workgroup (sp_lookback.h). With 3907 tiles of 256 positions, two thousand of them
+// resident at once and all publishing their counts at the same moment, the window walks are long: 79 us against the
+// 22.7 + 5.1 + 8.1 us of the three launches below, gpurun_out -> profiles/r03_voxel_trace_fused_aggregate_not_kept.txt.)
 // One lane per sorted position; the head lane of a run owns the whole run (voxel_downsampling.hpp:194-208,243-268).
 template <typename KEY>
 __global__ __launch_bounds__(kBlock) void aggregate_kernel(const KEY* __restrict__ sk, KEY invalid,
@@ -283,19 +328,9 @@ VoxelWs voxel_ws(size_t n) {
     w.vals_in = take(n * 4); w.vals_out = take(n * 4);
     w.flag = take(n * 4); w.pos = take(n * 4);
     w.t_pts = take(n * 16); w.t_rgb = take(n * 16); w.t_inten = take(n * 4); w.t_ts = take(n * 4);
-    size_t sort_bytes = 0, scan_bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                    (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
-    size_t sort32_bytes = 0;
-    (void)rocprim::radix_sort_pairs<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                               rocprim::default_config, 0>>(
-        nullptr, sort32_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
-        (hipStream_t)0);
-    if (sort32_bytes > sort_bytes) sort_bytes = sort32_bytes;
-    (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n,
-                                  rocprim::plus<uint32_t>(), (hipStream_t)0);
-    w.prim_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    w.prim_bytes = radix_sort_u64_workspace_bytes(n);
     if (radix_sort_u32_workspace_bytes(n) > w.prim_bytes) w.prim_bytes = radix_sort_u32_workspace_bytes(n);
+    if (exclusive_scan_u32_workspace_bytes(n) > w.prim_bytes) w.prim_bytes = exclusive_scan_u32_workspace_bytes(n);
     w.prim = take(w.prim_bytes);
     w.total = o;
     return w;
@@ -335,13 +370,6 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restr
     if (i == n - 1) *n_out = p + f;
 }
 
-size_t scan_bytes_for(size_t n) {
-    size_t b = 0;
-    (void)rocprim::exclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(),
-                                  (hipStream_t)0);
-    return b;
-}
-
 }  // namespace
 }  // namespace sp
 
@@ -357,20 +385,16 @@ extern "C" size_t sp_voxel_downsample_workspace_bytes(size_t n) { return n ? sp:
 
 namespace sp {
 namespace {
-// rocPRIM picks a merge sort (block sort + 20 merge launches, 200 us per 1M 64-bit keys) up to 1M items; with the keys
-// compressed to the bits the cloud's bounding box needs, Onesweep does ceil(bits / 8) passes instead.
-using OnesweepSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-
 int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count, const float* rgb,
                           const float* intensities, const float* timestamps, float* points_out, float* rgb_out,
                           float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt, uint32_t* n_out_dev,
-                          const int32_t* box6_host, uint32_t* status_dev, void* workspace, size_t workspace_bytes,
-                          hipStream_t st) {
+                          const int32_t* box6_host, uint32_t* status_dev, int32_t* box_shards_dev, void* workspace,
+                          size_t workspace_bytes, hipStream_t st) {
     if (!(inv_voxel_size > 0.0f)) {
         sp_set_error("voxel_size must be positive");  // voxel_downsampling.hpp:23-25
         return SP_ERR_INVALID_ARGUMENT;
     }
-    if (zero_async(status_dev, 4, st) != SP_OK) return SP_ERR_HIP;
+    if (status_dev || box_shards_dev) voxel_init_kernel<<<1, kBlock, 0, st>>>(status_dev, box_shards_dev);
     if (n == 0) return zero_async(n_out_dev, 4, st);
     if (n >= (1ull << 32)) {
         sp_set_error("[VoxelGrid::downsampling] more than 2^32 points");
@@ -409,12 +433,11 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
             boxed = true;
         }
     }
-    size_t prim_bytes = w.prim_bytes;
-    hipError_t e;
     if (boxed) {
         uint32_t* k_in = (uint32_t*)(base + w.keys_in);
         uint32_t* k_sorted = (uint32_t*)(base + w.keys_out);
-        key32_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, status_dev);
+        key32_kernel<<<std::min(stream_grid(n, kBlock, 4), 1024u), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in,
+                                                                                    vals_in, status_dev, box_shards_dev);
         unsigned end_bit = 1;
         while ((1ull << end_bit) <= (uint64_t)kb.invalid && end_bit < 32) ++end_bit;  // `invalid` itself must be representable
         bool in_b = false;  // the hand-written sort (radix_sort.hip) ping-pongs between the two buffer pairs
@@ -433,9 +456,19 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
     }
     uint64_t* keys_in = (uint64_t*)(base + w.keys_in);
     uint64_t* keys_sorted = (uint64_t*)(base + w.keys_out);
+    // no usable box (none given, or one of >= 2^32 cells): the 63-bit keys themselves, eight passes of the same sort
     key_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, keys_in, vals_in);
-    e = rocprim::radix_sort_pairs(base + w.prim, prim_bytes, keys_in, keys_sorted, vals_in, vals_sorted, n, 0, 64, st);
-    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    if (box_shards_dev) {  // this cloud's box for the caller, as on the boxed path
+        unsigned grid = div_up(n, kBlock * 16);
+        if (grid > 256u) grid = 256u;
+        key_box_kernel<<<grid ? grid : 1u, kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, box_shards_dev);
+    }
+    bool in_b64 = false;
+    if (radix_sort_pairs_u64(keys_in, keys_sorted, vals_in, vals_sorted, n, 64, base + w.prim, w.prim_bytes, &in_b64, st) != SP_OK) {
+        sp_set_error("[VoxelGrid::downsampling] radix sort failed");
+        return SP_ERR_HIP;
+    }
+    if (!in_b64) { uint64_t* t = keys_in; keys_in = keys_sorted; keys_sorted = t; uint32_t* tv = vals_in; vals_in = vals_sorted; vals_sorted = tv; }
     aggregate_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(keys_sorted, kInvalidKey, vals_sorted, (unsigned)n, pts,
                                                                      (float)min_voxel_count, a, t_pts, flag, pos);
     block_offsets_kernel<<<1, 1024, 0, st>>>(pos, div_up(n, kBlock), n_out_dev);
@@ -453,7 +486,7 @@ extern "C" int sp_voxel_downsample(const float* points, size_t n, float inv_voxe
                                    uint64_t* keys_out_opt, uint32_t* n_out_dev, void* workspace,
                                    size_t workspace_bytes, void* stream) {
     return sp::voxel_downsample_impl(points, n, inv_voxel_size, min_voxel_count, rgb, intensities, timestamps, points_out,
-                                     rgb_out, intensities_out, timestamps_out, keys_out_opt, n_out_dev, nullptr, nullptr,
+                                     rgb_out, intensities_out, timestamps_out, keys_out_opt, n_out_dev, nullptr, nullptr, nullptr,
                                      workspace, workspace_bytes, sp::as_stream(stream));
 }
 
@@ -475,11 +508,11 @@ extern "C" int sp_voxel_downsample_boxed(const float* points, size_t n, float in
                                          const float* rgb, const float* intensities, const float* timestamps,
                                          float* points_out, float* rgb_out, float* intensities_out,
                                          float* timestamps_out, uint64_t* keys_out_opt, uint32_t* n_out_dev,
-                                         const int32_t* box6_host, uint32_t* status_dev_opt, void* workspace,
-                                         size_t workspace_bytes, void* stream) {
+                                         const int32_t* box6_host, uint32_t* status_dev_opt, int32_t* box_shards_dev_opt,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
     return sp::voxel_downsample_impl(points, n, inv_voxel_size, min_voxel_count, rgb, intensities, timestamps, points_out,
                                      rgb_out, intensities_out, timestamps_out, keys_out_opt, n_out_dev, box6_host,
-                                     status_dev_opt, workspace, workspace_bytes, sp::as_stream(stream));
+                                     status_dev_opt, box_shards_dev_opt, workspace, workspace_bytes, sp::as_stream(stream));
 }
 
 extern "C" int sp_box_filter_flags(const float* points, size_t n, float min_distance, float max_distance,
@@ -494,7 +527,7 @@ extern "C" int sp_box_filter_flags(const float* points, size_t n, float min_dist
 
 extern "C" size_t sp_compact_workspace_bytes(size_t n) {
     if (n == 0) return 0;
-    return sp::align_up(n * 4) * 2 + sp::align_up(sp::scan_bytes_for(n));
+    return sp::align_up(n * 4) * 2 + sp::align_up(sp::exclusive_scan_u32_workspace_bytes(n));
 }
 
 extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes, const uint8_t* flags, void* rows_out,
@@ -503,8 +536,8 @@ extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes,
     using namespace sp;
     hipStream_t st = as_stream(stream);
     if (n == 0) return zero_async(n_out_dev, 4, st);
-    if (row_bytes % 4 != 0 || n >= (1ull << 31)) {
-        sp_set_error("[FilterByFlags] row_bytes must be a multiple of 4 and n < 2^31");
+    if (row_bytes % 4 != 0 || n >= (1ull << 30)) {
+        sp_set_error("[FilterByFlags] row_bytes must be a multiple of 4 and n < 2^30");
         return SP_ERR_INVALID_ARGUMENT;
     }
     if (!workspace || workspace_bytes < sp_compact_workspace_bytes(n)) {
@@ -515,10 +548,11 @@ extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes,
     uint32_t* wide = (uint32_t*)base;
     uint32_t* pos = (uint32_t*)(base + align_up(n * 4));
     void* prim = base + 2 * align_up(n * 4);
-    size_t prim_bytes = scan_bytes_for(n);
     widen_flags_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(flags, (unsigned)n, wide);
-    const hipError_t e = rocprim::exclusive_scan(prim, prim_bytes, wide, pos, 0u, n, rocprim::plus<uint32_t>(), st);
-    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    if (exclusive_scan_u32(wide, pos, n, nullptr, prim, exclusive_scan_u32_workspace_bytes(n), st) != SP_OK) {
+        sp_set_error("[FilterByFlags] scan failed");
+        return SP_ERR_HIP;
+    }
     compact_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(wide, pos, (unsigned)n, static_cast<const uint32_t*>(rows),
                                                          (unsigned)(row_bytes / 4), static_cast<uint32_t*>(rows_out),
                                                          new_indices_out_opt, n_out_dev);

@@ -12,8 +12,8 @@
 // Export (downsampling) is deterministic: slot order via flags + exclusive scan (the reference's NVIDIA path, :947-985).
 // Host-side control flow (rehash schedule, staleness counter, has_* flags) follows :117-141 line by line; like the
 // reference, add_point_cloud waits for its kernel and reads the voxel count back.
-#include <rocprim/device/device_scan.hpp>
 
+#include "radix_sort.h"
 #include "sp_common.h"
 #include "sp_math.h"
 
@@ -516,8 +516,7 @@ extern "C" int sp_vhm_downsampling(sp_voxel_hash_map* m, const float* center_hos
     if (m->scratch_cap < cap) {
         (void)hipFree(m->flags); (void)hipFree(m->pos); (void)hipFree(m->scan_tmp);
         m->flags = m->pos = nullptr; m->scan_tmp = nullptr; m->scratch_cap = 0;
-        size_t tmp = 0;
-        (void)rocprim::exclusive_scan(nullptr, tmp, (unsigned*)nullptr, (unsigned*)nullptr, 0u, cap, rocprim::plus<unsigned>(), st);
+        const size_t tmp = exclusive_scan_u32_workspace_bytes(cap + 1);
         hipError_t e = hipMalloc(&m->flags, (cap + 1) * sizeof(unsigned));
         if (e == hipSuccess) e = hipMalloc(&m->pos, (cap + 1) * sizeof(unsigned));
         if (e == hipSuccess) e = hipMalloc(&m->scan_tmp, tmp ? tmp : 16);
@@ -530,8 +529,7 @@ extern "C" int sp_vhm_downsampling(sp_voxel_hash_map* m, const float* center_hos
                                                            center_host3[0] + distance, center_host3[1] + distance,
                                                            center_host3[2] + distance, m->flags);
     if (hipMemsetAsync(m->flags + cap, 0, sizeof(unsigned), st) != hipSuccess) return SP_ERR_HIP;
-    size_t tmp = m->scan_tmp_bytes;
-    if (rocprim::exclusive_scan(m->scan_tmp, tmp, m->flags, m->pos, 0u, cap + 1, rocprim::plus<unsigned>(), st) != hipSuccess) {
+    if (exclusive_scan_u32(m->flags, m->pos, cap + 1, nullptr, m->scan_tmp, m->scan_tmp_bytes, st) != SP_OK) {
         sp_set_error("[VoxelHashMap::downsampling] scan failed");
         return SP_ERR_HIP;
     }

@@ -414,10 +414,10 @@ def test_voxel_boxed_path_equals_64bit_path(sp, orc):
         pc = sp.PointCloudShared(dev(pts), intensities=dev(inten))
         vg = sp.VoxelGrid(vs)
         b, kb = vg.downsampling(pc, return_keys=True, boxed=False)
-        for _ in range(2):  # first call: no remembered box yet (64-bit sort); second call: compressed keys
+        for _ in range(2):  # first call: the box is computed first; second call: the remembered (widened) box
             a, ka = vg.downsampling(pc, return_keys=True, boxed=True)
             assert torch.equal(ka, kb) and torch.equal(a.points, b.points) and torch.equal(a.intensities, b.intensities)
-        # a cloud that leaves the remembered box is redone on the 64-bit path
+        # a cloud that leaves the remembered box is redone with its own box
         far = sp.PointCloudShared(dev(pts + np.float32([500.0, 0, 0, 0])), intensities=dev(inten))
         c, kc = vg.downsampling(far, return_keys=True, boxed=True)
         d, kd = sp.VoxelGrid(vs).downsampling(far, return_keys=True, boxed=False)
@@ -431,15 +431,20 @@ def test_voxel_boxed_path_equals_64bit_path(sp, orc):
     o = torch.empty((5000, 4), dtype=torch.float32, device="cuda")
     cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
     box = np.array([1 << 20, 1 << 20, 1 << 20, (1 << 20) + 3, (1 << 20) + 3, (1 << 20) + 3], np.int32)  # positive octant only
+    shards = torch.zeros((sp._lib.VOXEL_BOX_SHARDS, sp._lib.VOXEL_BOX_SHARD_STRIDE), dtype=torch.int32, device="cuda")
     sp._lib.check(L.sp_voxel_downsample_boxed(sp._ptr(P), 5000, 1.0, 1, None, None, None, sp._ptr(o), None, None, None, None,
                                               sp._ptr(cnt), box.ctypes.data_as(C.c_void_p), C.c_void_p(cnt.data_ptr() + 4),
-                                              sp._ptr(ws), nb, sp._stream()))
+                                              sp._ptr(shards), sp._ptr(ws), nb, sp._stream()))
     assert int(cnt[1]) > 0
     boxd = torch.empty(6, dtype=torch.int32, device="cuda")
     sp._lib.check(L.sp_voxel_key_box(sp._ptr(P), 5000, 1.0, sp._ptr(boxd), sp._stream()))
     keys = sp.VoxelGrid(1.0).compute_voxel_bit(P).cpu().numpy().view(np.uint64)
     f = [(keys >> s) & ((1 << 21) - 1) for s in (0, 21, 42)]
-    assert boxd.cpu().numpy().tolist() == [int(x.min()) for x in f] + [int(x.max()) for x in f]
+    true_box = [int(x.min()) for x in f] + [int(x.max()) for x in f]
+    assert boxd.cpu().numpy().tolist() == true_box
+    # ... and the key kernel of the boxed call found the same box on the way (sharded), although the box it was given was wrong
+    sh = shards.cpu().numpy().astype(np.int64)
+    assert sh[:, :3].min(0).tolist() + sh[:, 3:6].max(0).tolist() == true_box
 
 
 def test_voxel_config3_1m(sp, orc):
