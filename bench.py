@@ -83,6 +83,9 @@ def parse():
                     help="measurement only: a per-handle switch of csrc/sp_internal.h on the prepared source, e.g. reuse=0 "
                          "(every launch searches every point); such a line is not a benchmark result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true",
+                    help="skip the `stages` block (BASELINE configs 2 and 3 and the pre-loop of config 4, timed after the GICP "
+                         "region) and the reuse-off comparison")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline workload")
     return ap.parse_args()
 
@@ -276,6 +279,11 @@ def main():
         launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
         converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE)
 
+    stages = reuse0 = None
+    if world == 1 and shards == 1 and not args.no_stages:
+        if args.path == "fused":
+            reuse0 = reuse_off_comparison(sp, torch, args, S, prep, T_dev, T_ident, delta, SORT_MODE, REG_TYPE, n_local)
+        stages = stage_block(sp, _lib, torch)
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
         dom = max((k for k in kern if kern[k].get("per_iteration", True)), key=lambda k: kern[k]["ms"])
@@ -324,6 +332,8 @@ def main():
             "launches_of_one_alignment": launches,
             "launch_classes": classes,
             "until_converged": converged,
+            "reuse_off_comparison": reuse0,
+            "stages": stages,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom), "algorithmic_bytes_per_launch": kern[dom]["bytes"],
@@ -490,6 +500,102 @@ def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reg
             "iterations_executed": iters, "converged": bool(float(delta[6]) > 0.5), "ms_per_alignment": ms,
             "correspondences_per_s": n * iters / (ms * 1e-3), "alignments_timed": reps,
             "note": "includes the per-alignment source preparation and the launches after convergence (they return at once)"}
+
+
+def median_ms(torch, fn, runs=11):
+    """Median over `runs` single launches of fn (HIP events on the launch stream, one warm-up)."""
+    fn()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(runs):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return float(np.median(ms)), len(ms)
+
+
+def reuse_off_comparison(sp, torch, args, S, prep, T_dev, T_ident, delta, sort_mode, reg_type, n):
+    """A stated comparison, not the benchmark: the same 20-iteration alignment with the correspondence reuse switched off
+    (csrc/sp_internal.h, reuse=0: every launch searches every point) — what the certificates buy. Same outputs, bit for bit
+    (tests/test_gpu_benchmarked_path.py)."""
+    p = sp.RegistrationParams(reg_type=reg_type, optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
+                              criteria_translation=0.0, criteria_rotation=0.0)
+    reg = sp.Registration(p)
+    reg._set_source_option("reuse", 0)
+
+    def one():
+        T_dev.copy_(T_ident)
+        reg.align_fused_loop(S, prep, T_dev=T_dev, delta_dev=delta, prepare=True, sort_by_cell=sort_mode)
+
+    ms, runs = median_ms(torch, one, 7)
+    return {"ms_per_alignment": ms, "ms_per_step": ms / ITERS_PER_ALIGN, "correspondences_per_s": n * ITERS_PER_ALIGN / (ms * 1e-3),
+            "alignments_timed": runs, "note": "reuse=0: every iteration searches all points; includes the source preparation"}
+
+
+def stage_block(sp, _lib, torch):
+    """BASELINE configs 2 and 3 and the pre-loop of config 4 in the driver's line (outside the timed GICP region): each
+    stage with inputs resident in HBM, the median of 11 single runs by HIP events, its rate and the fraction of the roofline
+    that bounds it (fp32 VALU for brute force at 9 operations per pair; HBM at the API-layout bytes otherwise).
+    Outputs are preallocated; the voxel stage is the C-ABI call alone (key box of the previous cloud known, as from the
+    second frame of a sensor on) without the host's read-back of the voxel count."""
+    from sycl_points_amd.synthetic import Mt19937Cloud
+
+    FP32 = 157.3e12
+    L = _lib.lib()
+    out = {}
+    g = Mt19937Cloud(1234)
+    tgt = torch.from_numpy(g.uniform_points(100000, 10.0)).cuda()
+    qry = torch.from_numpy(g.uniform_points(100000, 10.0)).cuda()
+    for k in (1, 20):
+        ms, runs = median_ms(torch, lambda: sp.knn_search_bruteforce(qry, tgt, k))
+        out[f"bruteforce_100k_x_100k_k{k}"] = {
+            "ms": ms, "runs": runs, "pairs_per_s": 1e10 / (ms * 1e-3), "bound": "fp32 VALU (9 operations per pair, LDS-tiled)",
+            "frac_of_bound": 9 * 1e10 / (ms * 1e-3) / FP32, "hbm_GBps_algorithmic": (16 * 2e5 + 8 * 1e5 * k) / (ms * 1e-3) / 1e9}
+    del tgt, qry
+    for name, R in (("sparse_R10", 10.0), ("dense_R2.5", 2.5)):
+        n = 1_000_000
+        P = torch.from_numpy(Mt19937Cloud(1234).uniform_points(n, R)).cuda()
+        vg = sp.VoxelGrid(0.1)
+        nvox = vg.downsampling(P).size()  # (remembers the key box)
+        box = vg._key_box
+        nbytes = L.sp_voxel_downsample_workspace_bytes(n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=P.device)
+        o_p = torch.empty((n, 4), dtype=torch.float32, device=P.device)
+        info = torch.zeros(32 + _lib.VOXEL_BOX_SHARDS * _lib.VOXEL_BOX_SHARD_STRIDE, dtype=torch.int32, device=P.device)
+        b = info.data_ptr()
+
+        def run():
+            _lib.check(L.sp_voxel_downsample_boxed(sp._ptr(P), n, vg.voxel_size_inv, 1, None, None, None, sp._ptr(o_p), None,
+                                                   None, None, None, C.c_void_p(b), box.ctypes.data_as(C.c_void_p),
+                                                   C.c_void_p(b + 4), C.c_void_p(b + 128), sp._ptr(ws), nbytes, sp._stream()))
+
+        ms, runs = median_ms(torch, run)
+        assert int(info[0]) == nvox and int(info[1]) == 0
+        ms_api, _ = median_ms(torch, lambda: vg.downsampling(P), 5)
+        out[f"voxel_downsample_1M_{name}"] = {
+            "ms": ms, "runs": runs, "voxels": nvox, "points_per_s": n / (ms * 1e-3), "bound": "HBM at 40 B per point",
+            "GBps": 40 * n / (ms * 1e-3) / 1e9, "frac_of_bound": 40 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ms_whole_api_call_with_count_read_back": ms_api}
+        del P, ws, o_p
+    n = 1_000_000
+    P = torch.from_numpy(Mt19937Cloud(1234).uniform_points(n, 10.0)).cuda()
+    grid = sp.GridKNN.build(P, points_per_cell=6.0)
+    for name, (knn, cov), bytes_pt in (("self_knn_k20_1M", (True, False), 176), ("self_knn_k20_plus_covariance_1M", (False, True), 176 + 464)):
+        ms, runs = median_ms(torch, lambda: grid.self_knn(20, knn, cov, False))
+        out[name] = {"ms": ms, "runs": runs, "points_per_s": n / (ms * 1e-3),
+                     "bound": f"HBM at {bytes_pt} B per point (API layouts" + (": kNN 176 + K5 464)" if cov else ")"),
+                     "GBps": bytes_pt * n / (ms * 1e-3) / 1e9, "frac_of_bound": bytes_pt * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    res = grid.self_knn(20, True, False, False)[0]
+    ms, runs = median_ms(torch, lambda: sp.covariance.estimate(res, P))
+    out["covariance_K5_alone_1M_k20"] = {"ms": ms, "runs": runs, "points_per_s": n / (ms * 1e-3), "bound": "HBM at 464 B per point",
+                                         "GBps": 464 * n / (ms * 1e-3) / 1e9,
+                                         "frac_of_bound": 464 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    ms, runs = median_ms(torch, lambda: sp.GridKNN.build(P, points_per_cell=0.5), 5)
+    out["grid_build_1M"] = {"ms": ms, "runs": runs, "note": "device build of the in-loop NN structure (synchronises once)"}
+    return out
 
 
 def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n, sort_mode, reps=3):
