@@ -23,6 +23,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #if __has_include(<Eigen/Dense>)
@@ -117,24 +118,39 @@ inline void hip_check(hipError_t e, const char* what) {
 }
 
 namespace detail {
-// The HBM mirrors of the containers (shared_vector) come from a small cache of idle device buffers: hipMalloc / hipFree cost
-// 0.1-0.2 ms apiece on this runtime, and a pipeline that builds a few point clouds per frame (the reference's example: twenty
-// attribute vectors per loop) spent more time there than in its kernels. A buffer is cached only after the device has gone
-// idle (what hipFree waits for too), so its next owner can use it at once. At most 48 buffers / 2 GiB are kept idle.
+// The HBM mirrors of the containers (shared_vector) and the per-call scratch of the algorithms come from a small cache of
+// device buffers: hipMalloc / hipFree cost 0.1-0.2 ms apiece on this runtime, and a pipeline that builds a few point clouds
+// per frame (the reference's example: twenty attribute vectors per loop) spent more time there than in its kernels.
+// A released buffer is tagged with an event recorded on the stream its owner used (no device-wide wait in a destructor —
+// round 2 called hipDeviceSynchronize() for every buffer a shared_vector dropped) and is handed out again only once that
+// event has completed; buffers are keyed by the device they were allocated on. At most 48 buffers / 2 GiB are kept.
+// (hipEventQuery is not capture-safe: do not create or destroy containers while a stream of the process is being captured.)
 struct DeviceBufferCache {
+    struct Entry {
+        void* p;
+        size_t bytes;
+        int device;
+        hipEvent_t ready;  // nullptr: idle already
+    };
     static void* acquire(size_t bytes, size_t* got) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
         {
             std::lock_guard<std::mutex> lock(mutex());
-            auto& idle = buffers();
-            size_t best = idle.size();
-            for (size_t i = 0; i < idle.size(); ++i)
-                if (idle[i].second >= bytes && idle[i].second <= 2 * bytes + 4096 && (best == idle.size() || idle[i].second < idle[best].second))
-                    best = i;
-            if (best != idle.size()) {
-                void* p = idle[best].first;
-                *got = idle[best].second;
-                total() -= idle[best].second;
-                idle.erase(idle.begin() + (std::ptrdiff_t)best);
+            auto& pool = buffers();
+            size_t best = pool.size();
+            for (size_t i = 0; i < pool.size(); ++i) {
+                Entry& e = pool[i];
+                if (e.device != dev || e.bytes < bytes || e.bytes > 2 * bytes + 4096) continue;
+                if (best != pool.size() && e.bytes >= pool[best].bytes) continue;
+                if (!settle(e)) continue;  // its last user is still running
+                best = i;
+            }
+            if (best != pool.size()) {
+                void* p = pool[best].p;
+                *got = pool[best].bytes;
+                total() -= pool[best].bytes;
+                pool.erase(pool.begin() + (std::ptrdiff_t)best);
                 return p;
             }
         }
@@ -143,29 +159,50 @@ struct DeviceBufferCache {
         *got = bytes;
         return p;
     }
-    static void release(void* p, size_t bytes) {
+    /// `stream`: every kernel / copy that touched the buffer was enqueued on it (or has completed). idle = true: the caller
+    /// knows the device is done with the buffer (it synchronised).
+    static void release(void* p, size_t bytes, hipStream_t stream, bool idle = false) {
         if (!p) return;
-        (void)hipDeviceSynchronize();  // nothing in flight may still use it (hipFree would wait as well)
+        Entry e{p, bytes, 0, nullptr};
+        (void)hipGetDevice(&e.device);
+        if (!idle) {
+            if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(e.ready, stream) != hipSuccess) {
+                if (e.ready) (void)hipEventDestroy(e.ready);
+                e.ready = nullptr;
+                (void)hipDeviceSynchronize();  // no event to be had: wait, as hipFree would
+            }
+        }
         std::vector<void*> drop;
         {
             std::lock_guard<std::mutex> lock(mutex());
-            auto& idle = buffers();
-            idle.emplace_back(p, bytes);
+            auto& pool = buffers();
+            pool.push_back(e);
             total() += bytes;
-            while (idle.size() > 48 || total() > (size_t(2) << 30)) {  // oldest first
-                drop.push_back(idle.front().first);
-                total() -= idle.front().second;
-                idle.erase(idle.begin());
+            for (size_t i = 0; i < pool.size() && (pool.size() > 48 || total() > (size_t(2) << 30));) {  // oldest settled first
+                if (pool[i].device == e.device && settle(pool[i])) {
+                    drop.push_back(pool[i].p);
+                    total() -= pool[i].bytes;
+                    pool.erase(pool.begin() + (std::ptrdiff_t)i);
+                } else {
+                    ++i;
+                }
             }
         }
         for (void* d : drop) (void)hipFree(d);
     }
 
 private:
+    static bool settle(Entry& e) {  // true once nothing on the device uses the buffer any more
+        if (e.ready == nullptr) return true;
+        if (hipEventQuery(e.ready) != hipSuccess) return false;
+        (void)hipEventDestroy(e.ready);
+        e.ready = nullptr;
+        return true;
+    }
     static std::mutex& mutex() { static std::mutex m; return m; }
     static size_t& total() { static size_t t = 0; return t; }
-    static std::vector<std::pair<void*, size_t>>& buffers() {
-        static auto* c = new std::vector<std::pair<void*, size_t>>();  // never destroyed: the HIP runtime may be gone by then
+    static std::vector<Entry>& buffers() {
+        static auto* c = new std::vector<Entry>();  // never destroyed: the HIP runtime may be gone by then
         return *c;
     }
 };
@@ -250,6 +287,12 @@ struct events {
 
 // ---------------------------------------------------------------------------------------------- shared_vector
 /// utils/sycl_utils.hpp:630-635. std::vector semantics on the host + an HBM mirror.
+///
+/// Which copy is current is tracked per container, not per element: every NON-CONST accessor (operator[], at, data, begin /
+/// end) must assume the caller writes and marks the host copy newer, so the next device use uploads the whole vector again.
+/// Read through a const reference, `host()` or `std::as_const(v)` when only reading — nothing is marked then — and write
+/// in bulk where possible. (The reference's USM-shared vector pays per page instead; with XNACK off on this part managed
+/// memory would be served over PCIe)
 template <typename T>
 class shared_vector {
 public:
@@ -269,7 +312,7 @@ public:
         if (this != &o) { host_ = o.host(); host_dirty_ = true; dev_dirty_ = false; }
         return *this;
     }
-    ~shared_vector() { if (dev_) detail::DeviceBufferCache::release(dev_, dev_bytes_); }
+    ~shared_vector() { if (dev_) detail::DeviceBufferCache::release(dev_, dev_bytes_, stream()); }
 
     // ---- host side (std::vector surface)
     size_t size() const { return size_override_ ? dev_size_ : host_.size(); }
@@ -292,6 +335,25 @@ public:
     const_iterator begin() const { sync_host(); return host_.begin(); }
     const_iterator end() const { sync_host(); return host_.end(); }
     const std::vector<T>& host() const { sync_host(); return host_; }
+    /// std::vector::insert / erase on the host copy (PointCloudShared::extend / erase, points/point_cloud.hpp:319-368)
+    template <class It>
+    iterator insert(const_iterator pos, It first, It last) {
+        sync_host();
+        host_dirty_ = true;
+        return host_.insert(pos, first, last);
+    }
+    iterator erase(const_iterator first, const_iterator last) {
+        sync_host();
+        host_dirty_ = true;
+        return host_.erase(first, last);
+    }
+    /// the elements of `o` appended (its host copy is brought up to date first)
+    void append(const shared_vector& o) {
+        const std::vector<T>& src = o.host();
+        sync_host();
+        host_.insert(host_.end(), src.begin(), src.end());
+        host_dirty_ = true;
+    }
 
     // ---- device side (what the kernels get)
     /// Read-only device pointer; uploads first if the host copy is newer.
@@ -315,8 +377,9 @@ private:
         size_t got = 0;
         T* nd = static_cast<T*>(detail::DeviceBufferCache::acquire(std::max<size_t>(n, 1) * sizeof(T), &got));
         if (dev_) {
-            if (dev_dirty_ && dev_size_) hip_check(hipMemcpy(nd, dev_, std::min(dev_size_, n) * sizeof(T), hipMemcpyDeviceToDevice), "hipMemcpy");
-            detail::DeviceBufferCache::release(dev_, dev_bytes_);
+            if (dev_dirty_ && dev_size_)  // (in stream order behind the kernels that wrote the old buffer)
+                hip_check(hipMemcpyAsync(nd, dev_, std::min(dev_size_, n) * sizeof(T), hipMemcpyDeviceToDevice, stream()), "hipMemcpy");
+            detail::DeviceBufferCache::release(dev_, dev_bytes_, stream());
         }
         dev_ = nd;
         dev_bytes_ = got;
@@ -448,7 +511,107 @@ struct PointCloudShared {
     void reserve_rgb(size_t n) const { rgb->reserve(n); }
     void reserve_intensities(size_t n) const { intensities->reserve(n); }
     void reserve_timestamps(size_t n) const { timestamp_offsets->reserve(n); }
-    void clear() const { points->clear(); covs->clear(); normals->clear(); rgb->clear(); intensities->clear(); timestamp_offsets->clear(); }
+    /// points/point_cloud.hpp:307-317 (the timestamp base goes with the offsets)
+    void clear() {
+        points->clear(); covs->clear(); normals->clear(); rgb->clear(); intensities->clear(); timestamp_offsets->clear();
+        start_time_ms = 0.0; end_time_ms = 0.0;
+    }
+    /// points/point_cloud.hpp:319-338: the points of `other` appended; an attribute survives when both clouds have it
+    void extend(const PointCloudShared& other) {
+        const size_t org_size = size();
+        const bool cov = has_cov() && other.has_cov(), nrm = has_normal() && other.has_normal(), col = has_rgb() && other.has_rgb(),
+                   inten = has_intensity() && other.has_intensity();
+        if (cov) covs->append(*other.covs);
+        if (nrm) normals->append(*other.normals);
+        if (col) rgb->append(*other.rgb);
+        if (inten) intensities->append(*other.intensities);
+        points->append(*other.points);
+        merge_timestamp_offsets(other, org_size);
+    }
+    /// points/point_cloud.hpp:340-366: the points [start_idx, end_idx) and their attributes removed
+    void erase(size_t start_idx, size_t end_idx) {
+        auto cut = [&](auto& v) { v->erase(std::as_const(*v).begin() + (std::ptrdiff_t)start_idx, std::as_const(*v).begin() + (std::ptrdiff_t)end_idx); };
+        const bool cov = has_cov(), nrm = has_normal(), col = has_rgb(), inten = has_intensity(), ts = has_timestamps();
+        if (cov) cut(covs);
+        if (nrm) cut(normals);
+        if (col) cut(rgb);
+        if (inten) cut(intensities);
+        if (ts) {
+            cut(timestamp_offsets);
+            if (timestamp_offsets->empty()) {
+                start_time_ms = 0.0;
+                end_time_ms = 0.0;
+            } else {
+                const auto& h = timestamp_offsets->host();
+                end_time_ms = start_time_ms + static_cast<double>(*std::max_element(h.begin(), h.end()));
+            }
+        }
+        cut(points);
+    }
+    void operator+=(const PointCloudShared& pc) { extend(pc); }
+
+private:
+    /// points/point_cloud.hpp:393-397
+    void invalidate_timestamps() {
+        timestamp_offsets->clear();
+        start_time_ms = 0.0;
+        end_time_ms = 0.0;
+    }
+    /// points/point_cloud.hpp:399-423: move the timestamp base to an earlier time (later: offsets would go negative)
+    void shift_timestamp_base(double new_start_time_ms) {
+        if (!has_timestamps() || new_start_time_ms >= start_time_ms) {
+            if (new_start_time_ms > start_time_ms) invalidate_timestamps();
+            return;
+        }
+        const double delta_ms = start_time_ms - new_start_time_ms;
+        const double max_value = static_cast<double>(std::numeric_limits<TimestampOffset>::max());
+        for (auto& offset : *timestamp_offsets) {
+            const double adjusted = static_cast<double>(offset) + delta_ms;
+            if (adjusted > max_value)
+                throw std::runtime_error("[PointCloudShared::shift_timestamp_base] Timestamp offset overflow while shifting base");
+            offset = static_cast<TimestampOffset>(adjusted);
+        }
+        start_time_ms = new_start_time_ms;
+    }
+    /// points/point_cloud.hpp:425-474, statement for statement. extend() calls it AFTER the points have been appended, as the
+    /// reference does, so `has_timestamps()` (offsets as many as points) is false for this cloud whenever `other` is not
+    /// empty: the merged cloud keeps timestamps only when this cloud was empty (it adopts the other's); two timestamped
+    /// clouds merge into one without valid timestamps. That is the reference's behaviour and is kept.
+    void merge_timestamp_offsets(const PointCloudShared& other, size_t original_size) {
+        if (other.size() == 0) return;
+        if (!other.has_timestamps()) {
+            if (has_timestamps()) invalidate_timestamps();
+            return;
+        }
+        if (!has_timestamps()) {
+            if (original_size == 0) {  // this cloud was empty: adopt the other cloud's timestamps
+                timestamp_offsets->append(*other.timestamp_offsets);
+                start_time_ms = other.start_time_ms;
+                end_time_ms = other.end_time_ms;
+            }
+            return;  // points without (valid) timestamps: the other cloud's are dropped
+        }
+        const double new_start_ms = std::min(start_time_ms, other.start_time_ms);
+        if (new_start_ms < start_time_ms) shift_timestamp_base(new_start_ms);
+        const double base_delta_ms = other.start_time_ms - new_start_ms;
+        const double max_value = static_cast<double>(std::numeric_limits<TimestampOffset>::max());
+        if (base_delta_ms > max_value)
+            throw std::runtime_error("[PointCloudShared::merge_timestamp_offsets] Timestamp base delta exceeds representable offset range");
+        const auto& src = other.timestamp_offsets->host();
+        std::vector<TimestampOffset> shifted;
+        shifted.reserve(src.size());
+        for (const auto offset : src) {
+            const double adjusted = static_cast<double>(offset) + base_delta_ms;
+            if (adjusted > max_value)
+                throw std::runtime_error("[PointCloudShared::merge_timestamp_offsets] Timestamp offset overflow while merging clouds");
+            shifted.push_back(static_cast<TimestampOffset>(adjusted));
+        }
+        timestamp_offsets->insert(std::as_const(*timestamp_offsets).end(), shifted.begin(), shifted.end());
+        start_time_ms = new_start_ms;
+        end_time_ms = std::max(end_time_ms, other.end_time_ms);
+    }
+
+public:
 
     // device views for the kernels
     const float* points_device() const { return reinterpret_cast<const float*>(points->device_data()); }

@@ -5,6 +5,7 @@
 //   algorithms/common/filter_by_flags.hpp        : filter::FilterByFlags
 //   algorithms/common/transform.hpp              : transform::transform, transform_copy
 #pragma once
+#include <exception>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -20,57 +21,22 @@ namespace algorithms {
 namespace detail {
 /// Scratch device memory that lives for one call (the reference allocates shared_vectors per call the same way,
 /// e.g. registration.hpp:685-686).
-// Device scratch of one call (workspaces, counters). Every user synchronises its stream before the scratch leaves scope, so
-// a released buffer is idle: it is kept for the next call instead of going through hipFree / hipMalloc, which cost 0.1-0.2 ms
-// apiece on this runtime — more than the kernels of a 70 k-point voxel downsampling. At most eight idle buffers are kept.
+// Device scratch of one call (workspaces, counters), from the cache the containers use (core.hpp: keyed by device, no
+// hipMalloc / hipFree per call). Every user synchronises its stream before the scratch leaves scope, so the buffer goes
+// back idle; when the scope is left by an exception that may not have happened yet, and the device is drained first.
 struct DeviceScratch {
     void* p = nullptr;
     size_t bytes = 0;
     explicit DeviceScratch(size_t n) {
-        if (!n) return;
-        {
-            std::lock_guard<std::mutex> lock(mutex());
-            auto& idle = cache();
-            size_t best = idle.size();
-            for (size_t i = 0; i < idle.size(); ++i)
-                if (idle[i].second >= n && idle[i].second <= 4 * n + 4096 && (best == idle.size() || idle[i].second < idle[best].second))
-                    best = i;
-            if (best != idle.size()) {
-                p = idle[best].first;
-                bytes = idle[best].second;
-                idle.erase(idle.begin() + (std::ptrdiff_t)best);
-                return;
-            }
-        }
-        hip_check(hipMalloc(&p, n), "hipMalloc");
-        bytes = n;
+        if (n) p = ::sycl_points::detail::DeviceBufferCache::acquire(n, &bytes);
     }
     ~DeviceScratch() {
         if (!p) return;
-        void* drop = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(mutex());
-            auto& idle = cache();
-            idle.emplace_back(p, bytes);
-            if (idle.size() > 8) {
-                size_t smallest = 0;
-                for (size_t i = 1; i < idle.size(); ++i)
-                    if (idle[i].second < idle[smallest].second) smallest = i;
-                drop = idle[smallest].first;
-                idle.erase(idle.begin() + (std::ptrdiff_t)smallest);
-            }
-        }
-        if (drop) (void)hipFree(drop);
+        if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();
+        ::sycl_points::detail::DeviceBufferCache::release(p, bytes, nullptr, /*idle=*/true);
     }
     DeviceScratch(const DeviceScratch&) = delete;
     DeviceScratch& operator=(const DeviceScratch&) = delete;
-
-private:
-    static std::mutex& mutex() { static std::mutex m; return m; }
-    static std::vector<std::pair<void*, size_t>>& cache() {
-        static auto* c = new std::vector<std::pair<void*, size_t>>();  // never destroyed: the HIP runtime may be gone by then
-        return *c;
-    }
 };
 // One 4-byte read-back through pinned memory (a copy into pageable memory is staged and blocks inside the runtime).
 inline void* pinned_word() {

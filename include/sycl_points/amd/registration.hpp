@@ -705,28 +705,62 @@ private:
 class RegistrationPipeline {
 public:
     using Ptr = std::shared_ptr<RegistrationPipeline>;
+    /// registration_pipeline.hpp:24-43: from an aligner callable, from a Registration backend, or from a queue
+    RegistrationPipeline(pipeline::RegistrationAligner aligner, const RegistrationPipelineParams& p = RegistrationPipelineParams())
+        : params_(p), aligner_(std::move(aligner)) {
+        wrap_aligner();
+    }
+    RegistrationPipeline(const Registration::Ptr& registration, const RegistrationPipelineParams& p = RegistrationPipelineParams())
+        : RegistrationPipeline(pipeline::make_registration_aligner(registration), p) {
+        registration_ = registration;
+    }
     RegistrationPipeline(const sycl_utils::DeviceQueue& queue, const RegistrationPipelineParams& p = RegistrationPipelineParams())
-        : params_(p), registration_(std::make_shared<Registration>(queue, p.registration)) {
-        aligner_ = pipeline::make_registration_aligner(registration_);
+        : RegistrationPipeline(std::make_shared<Registration>(queue, p.registration), p) {}
+
+    RegistrationResult align(const PointCloudShared& source, const PointCloudShared& target, const knn::KNNBase& target_knn,
+                             const TransformMatrix& initial_guess = TransformMatrix::Identity(),
+                             const Registration::ExecutionOptions& options = Registration::ExecutionOptions()) const {
+        update_registration_input(source);
+        return aligner_(*input_, target, target_knn, initial_guess, options);
+    }
+    const Registration::Ptr& registration() const { return registration_; }
+    /// registration_pipeline.hpp:64-77: geometry ICP robust weights of the latest registration input
+    void compute_icp_robust_weights(const PointCloudShared& target, const knn::KNNBase& target_knn, const TransformMatrix& pose,
+                                    float robust_scale, shared_vector<float>& out) const {
+        if (registration_ == nullptr)
+            throw std::runtime_error("[RegistrationPipeline::compute_icp_robust_weights] Registration backend is not available.");
+        const auto source = get_deskewed_point_cloud();
+        if (source == nullptr)
+            throw std::runtime_error("[RegistrationPipeline::compute_icp_robust_weights] Registration input point cloud is not available.");
+        registration_->compute_icp_robust_weights(*source, target, target_knn, pose, robust_scale, out);
+    }
+    const PointCloudShared* get_registration_input_point_cloud() const { return input_.get(); }
+    /// registration_pipeline.hpp:82-89. The velocity-update (deskew) stage is outside this library's scope,
+    /// so this is always the registration input — what the reference returns with velocity_update disabled.
+    const PointCloudShared::Ptr get_deskewed_point_cloud() const { return input_; }
+    /// registration_pipeline.hpp:91-97
+    float get_inlier_ratio(const RegistrationResult& result) const {
+        const auto* in = get_registration_input_point_cloud();
+        if (in && in->size() > 0) return static_cast<float>(result.inlier) / static_cast<float>(in->size());
+        return 0.0f;
+    }
+
+private:
+    void wrap_aligner() {  // registration_pipeline.hpp:100-119 (robust wrapper outermost)
         if (params_.robust.auto_scale) {
             robust_ = std::make_shared<pipeline::RobustAligner>(aligner_, params_);
             aligner_ = robust_->make_aligner();
         }
-        filter_ = std::make_shared<filter::PreprocessFilter>(queue);
-        input_ = std::make_shared<PointCloudShared>(queue);
     }
-    RegistrationResult align(const PointCloudShared& source, const PointCloudShared& target, const knn::KNNBase& target_knn,
-                             const TransformMatrix& initial_guess = TransformMatrix::Identity(),
-                             const Registration::ExecutionOptions& options = Registration::ExecutionOptions()) const {
+    void update_registration_input(const PointCloudShared& source) const {  // registration_pipeline.hpp:121-140
+        if (filter_ == nullptr || input_ == nullptr) {
+            filter_ = std::make_shared<filter::PreprocessFilter>(source.queue);
+            input_ = std::make_shared<PointCloudShared>(source.queue);
+        }
         const auto& rs = params_.random_sampling;
         if (rs.enable && source.size() > rs.num) filter_->random_sampling(source, *input_, rs.num);
         else *input_ = source;  // shallow (registration_pipeline.hpp:138)
-        return aligner_(*input_, target, target_knn, initial_guess, options);
     }
-    const Registration::Ptr& registration() const { return registration_; }
-    const PointCloudShared* get_registration_input_point_cloud() const { return input_.get(); }
-
-private:
     RegistrationPipelineParams params_;
     Registration::Ptr registration_;
     pipeline::RobustAligner::Ptr robust_;

@@ -31,6 +31,7 @@ std::mutex g_pool_mutex;
 std::vector<PoolEntry> g_pool;
 std::vector<void*> g_to_free;  // surplus buffers: freed by the next scratch_acquire (an allocating call), never by a release
 constexpr size_t kKeep = 24;
+constexpr size_t kKeepBytes = size_t(4) << 30;  // idle bytes kept per device
 }  // namespace
 
 namespace {
@@ -69,16 +70,39 @@ hipError_t scratch_acquire(void** ptr, size_t bytes) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         surplus.swap(g_to_free);
     }
-    for (void* q : surplus) (void)hipFree(q);
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
+        // Settle every released buffer of this device whose events have completed (an entry that is never the best fit would
+        // otherwise keep its events, and the pool would grow past kKeep with nothing known to be idle), then trim the idle ones
+        // to kKeep buffers / kKeepBytes: smallest first, freed just below (this call allocates and may synchronise anyway).
+        size_t idle = 0, idle_bytes = 0;
+        for (auto& e : g_pool)
+            if (!e.busy && e.device == dev && entry_idle(e)) { ++idle; idle_bytes += e.bytes; }
+        while (idle > kKeep || idle_bytes > kKeepBytes) {
+            size_t k = g_pool.size();
+            for (size_t i = 0; i < g_pool.size(); ++i) {
+                const PoolEntry& e = g_pool[i];
+                if (e.busy || e.device != dev || !e.pending.empty()) continue;
+                const bool smaller = k == g_pool.size() || e.bytes < g_pool[k].bytes;
+                // over the byte budget only: drop the LARGEST idle buffer (the smallest would not bring the total down)
+                const bool larger = k == g_pool.size() || e.bytes > g_pool[k].bytes;
+                if (idle > kKeep ? smaller : larger) k = i;
+            }
+            if (k == g_pool.size()) break;
+            surplus.push_back(g_pool[k].p);
+            --idle;
+            idle_bytes -= g_pool[k].bytes;
+            g_pool.erase(g_pool.begin() + (long)k);
+        }
         PoolEntry* best = nullptr;
         for (auto& e : g_pool)  // best fit among the idle buffers of this device, not more than 4x oversized
             if (!e.busy && e.device == dev && e.bytes >= bytes && e.bytes <= 4 * bytes && (!best || e.bytes < best->bytes) &&
-                entry_idle(e))
+                e.pending.empty())
                 best = &e;
-        if (best) { best->busy = true; *ptr = best->p; return hipSuccess; }
+        if (best) { best->busy = true; *ptr = best->p; }
     }
+    for (void* q : surplus) (void)hipFree(q);
+    if (*ptr) return hipSuccess;
     void* p = nullptr;
     const hipError_t err = hipMalloc(&p, bytes);
     if (err != hipSuccess) return err;

@@ -330,11 +330,11 @@ int read_counter(sp_voxel_hash_map* m, hipStream_t st, unsigned* out) {
     if (hipMemcpyAsync(out, m->counter, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) return SP_ERR_HIP;
     return hip_status(hipStreamSynchronize(st));  // the reference waits here too (wait_and_throw + shared read)
 }
+__global__ void vhm_seed_counter_kernel(unsigned* counter, unsigned v) { *counter = v; }
 int write_counter(sp_voxel_hash_map* m, hipStream_t st, unsigned v) {
-    // (a kernarg-free way to seed the counter: memset for 0, a 4-byte pageable copy otherwise — the value is consumed by
-    // the copy engine before this returns only for pageable memory, which a stack variable is)
-    if (v == 0) return hip_status(hipMemsetAsync(m->counter, 0, sizeof(unsigned), st));
-    return hip_status(hipMemcpyAsync(m->counter, &v, sizeof(unsigned), hipMemcpyHostToDevice, st));
+    // the value travels in the kernarg segment: nothing is read from a host variable after this returns
+    vhm_seed_counter_kernel<<<1, 1, 0, st>>>(m->counter, v);
+    return launch_status();
 }
 
 int rehash(sp_voxel_hash_map* m, size_t new_cap, hipStream_t st) {

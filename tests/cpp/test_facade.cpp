@@ -210,6 +210,43 @@ public:
     mutable int calls = 0;
 };
 
+static void point_cloud_extend_erase() {  // points/point_cloud.hpp:307-368, 393-474
+    auto make = [&](size_t n, float x0, bool with_ts, double t0) {
+        PointCloudCPU c;
+        for (size_t i = 0; i < n; ++i) {
+            c.points->emplace_back(x0 + float(i), 0.0f, 0.0f, 1.0f);
+            c.covs->push_back(Covariance::Identity() * (x0 + float(i)));
+            c.intensities->push_back(x0 + float(i));
+            if (with_ts) c.timestamp_offsets->push_back(float(i));
+        }
+        c.start_time_ms = with_ts ? t0 : 0.0;
+        c.end_time_ms = with_ts ? t0 + double(n - 1) : 0.0;
+        return c;
+    };
+    PointCloudShared a(*Q, make(5, 0.0f, true, 100.0)), b(*Q, make(3, 10.0f, true, 50.0));
+    (void)a.points_device();  // the mirrors exist: extend / erase must keep host and device views consistent
+    a.extend(b);
+    CHECK(a.size() == 8 && a.has_cov() && a.has_intensity() && !a.has_normal() && !a.has_rgb());
+    CHECK((*a.points)[5].x() == 10.0f && (*a.points)[7].x() == 12.0f && (*a.covs)[6](0, 0) == 11.0f && (*a.intensities)[7] == 12.0f);
+    CHECK(!a.has_timestamps());  // the reference drops the timestamps of two merged, timestamped clouds (see merge_timestamp_offsets)
+    PointCloudShared e(*Q);
+    e += b;                       // an empty cloud adopts them
+    CHECK(e.size() == 3 && e.has_timestamps() && e.start_time_ms == 50.0 && e.end_time_ms == 52.0 && (*e.timestamp_offsets)[2] == 2.0f);
+    CHECK(!e.has_cov());          // attributes survive only when BOTH clouds have them (the empty cloud has none)
+    e.erase(0, 1);
+    CHECK(e.size() == 2 && (*e.points)[0].x() == 11.0f && e.has_timestamps() && e.end_time_ms == 52.0);
+    e.erase(1, 2);
+    CHECK(e.size() == 1 && e.end_time_ms == 51.0);
+    a.erase(2, 6);
+    CHECK(a.size() == 4 && (*a.points)[1].x() == 1.0f && (*a.points)[2].x() == 11.0f && a.has_cov() && (*a.covs)[3](1, 1) == 12.0f);
+    // the device view follows: the L-infinity box filter on the device sees the four remaining points
+    alg::filter::PreprocessFilter pf(*Q);
+    pf.box_filter(a, 0.5f, 11.5f);
+    CHECK(a.size() == 2 && (*a.points)[0].x() == 1.0f && (*a.points)[1].x() == 11.0f);
+    a.clear();
+    CHECK(a.size() == 0 && a.start_time_ms == 0.0 && a.end_time_ms == 0.0);
+}
+
 static void point_cloud_files() {  // io/point_cloud_reader.hpp: PLY (the bundled clouds) and PCD, ascii and binary
     const char* dir = std::getenv("SP_GOLDEN_DIR");
     if (dir) {
@@ -467,8 +504,24 @@ static void registration_matches_oracle() {
     CHECK(thrown);
     // random sampling default (num = 1000, mt19937(1234)) wires through
     alg::registration::RegistrationPipeline sampled(*Q);
-    sampled.align(source, target, *tree);
+    const auto r_sampled = sampled.align(source, target, *tree);
     CHECK(sampled.get_registration_input_point_cloud()->size() == 1000);
+    // the pipeline's accessors (registration_pipeline.hpp:64-97): inlier ratio over the registration input, the deskewed cloud
+    // (= the registration input: no velocity-update stage here), robust weights of that input at a pose
+    CHECK(sampled.get_deskewed_point_cloud().get() == sampled.get_registration_input_point_cloud());
+    CHECK(std::fabs(sampled.get_inlier_ratio(r_sampled) - float(r_sampled.inlier) / 1000.0f) < 1e-7f && r_sampled.inlier > 0);
+    shared_vector<float> wts(*Q);
+    sampled.compute_icp_robust_weights(target, *tree, r_sampled.T.matrix(), 10.0f, wts);
+    CHECK(wts.size() == 1000);
+    size_t ones = 0;
+    for (size_t i = 0; i < wts.size(); ++i) ones += std::as_const(wts)[i] == 1.0f;  // robust NONE: weight 1 per inlier
+    CHECK(ones == r_sampled.inlier);
+    alg::registration::RegistrationPipelineParams pq;
+    pq.registration = p;
+    pq.random_sampling.enable = false;
+    alg::registration::RegistrationPipeline from_backend(std::make_shared<alg::registration::Registration>(*Q, p), pq);
+    const auto r_backend = from_backend.align(source, target, *grid);
+    CHECK(max_abs_diff(r_backend.T.matrix(), r_grid.T.matrix().data()) == 0.0f);  // constructed around a given backend
 }
 
 // algorithms/mapping/voxel_hash_map.hpp through the facade, on the reference's own cases
@@ -615,6 +668,7 @@ int main() {
     RUN(kdtree_grid_vs_bruteforce);
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
+    RUN(point_cloud_extend_erase);
     RUN(point_cloud_files);
     RUN(voxel_hash_map_known_answers);
     RUN(sharded_align_one_rank);
