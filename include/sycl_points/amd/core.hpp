@@ -135,24 +135,39 @@ struct DeviceBufferCache {
     static void* acquire(size_t bytes, size_t* got) {
         int dev = 0;
         (void)hipGetDevice(&dev);
+        hipEvent_t wait_for = nullptr;
+        void* taken = nullptr;
         {
             std::lock_guard<std::mutex> lock(mutex());
             auto& pool = buffers();
-            size_t best = pool.size();
+            size_t best = pool.size(), best_busy = pool.size();
             for (size_t i = 0; i < pool.size(); ++i) {
                 Entry& e = pool[i];
                 if (e.device != dev || e.bytes < bytes || e.bytes > 2 * bytes + 4096) continue;
-                if (best != pool.size() && e.bytes >= pool[best].bytes) continue;
-                if (!settle(e)) continue;  // its last user is still running
-                best = i;
+                if (settle(e)) {
+                    if (best == pool.size() || e.bytes < pool[best].bytes) best = i;
+                } else if (best_busy == pool.size() || e.bytes < pool[best_busy].bytes) {
+                    best_busy = i;  // its last user is still running
+                }
             }
-            if (best != pool.size()) {
-                void* p = pool[best].p;
-                *got = pool[best].bytes;
-                total() -= pool[best].bytes;
-                pool.erase(pool.begin() + (std::ptrdiff_t)best);
-                return p;
+            // A buffer of the right size whose last user has not finished yet is still the better deal: waiting for that event
+            // (a kernel or two of the caller's own stream, usually done by the time we look) costs microseconds, hipMalloc
+            // 0.1-0.2 ms. A frame loop frees and re-creates its containers back to back: without this it allocated every time.
+            const size_t pick = best != pool.size() ? best : best_busy;
+            if (pick != pool.size()) {
+                taken = pool[pick].p;
+                *got = pool[pick].bytes;
+                wait_for = pool[pick].ready;
+                total() -= pool[pick].bytes;
+                pool.erase(pool.begin() + (std::ptrdiff_t)pick);
             }
+        }
+        if (taken) {
+            if (wait_for) {
+                (void)hipEventSynchronize(wait_for);
+                (void)hipEventDestroy(wait_for);
+            }
+            return taken;
         }
         void* p = nullptr;
         hip_check(hipMalloc(&p, bytes), "hipMalloc");
@@ -309,7 +324,7 @@ public:
     shared_vector(size_t n, const T& v, const sycl_utils::DeviceQueue::StreamHolder& h) : host_(n, v) { bind(h); }
     shared_vector(const shared_vector& o) : host_(o.host()), queue_(o.queue_), stream_(o.stream_) {}
     shared_vector& operator=(const shared_vector& o) {
-        if (this != &o) { host_ = o.host(); host_dirty_ = true; dev_dirty_ = false; }
+        if (this != &o) { host_ = o.host(); host_dirty_ = true; dev_dirty_ = false; ++generation_; }
         return *this;
     }
     ~shared_vector() { if (dev_) detail::DeviceBufferCache::release(dev_, dev_bytes_, stream()); }
@@ -317,21 +332,21 @@ public:
     // ---- host side (std::vector surface)
     size_t size() const { return size_override_ ? dev_size_ : host_.size(); }
     bool empty() const { return size() == 0; }
-    void resize(size_t n) { sync_host(); host_.resize(n); host_dirty_ = true; }
-    void resize(size_t n, const T& v) { sync_host(); host_.resize(n, v); host_dirty_ = true; }
+    void resize(size_t n) { sync_host(); host_.resize(n); touch(); }
+    void resize(size_t n, const T& v) { sync_host(); host_.resize(n, v); touch(); }
     void reserve(size_t n) { host_.reserve(n); }
-    void clear() { size_override_ = false; dev_dirty_ = false; host_.clear(); host_dirty_ = true; }
-    void assign(size_t n, const T& v) { size_override_ = false; dev_dirty_ = false; host_.assign(n, v); host_dirty_ = true; }
-    void push_back(const T& v) { sync_host(); host_.push_back(v); host_dirty_ = true; }
-    template <class... A> void emplace_back(A&&... a) { sync_host(); host_.emplace_back(std::forward<A>(a)...); host_dirty_ = true; }
-    T& operator[](size_t i) { sync_host(); host_dirty_ = true; return host_[i]; }
+    void clear() { size_override_ = false; dev_dirty_ = false; host_.clear(); touch(); }
+    void assign(size_t n, const T& v) { size_override_ = false; dev_dirty_ = false; host_.assign(n, v); touch(); }
+    void push_back(const T& v) { sync_host(); host_.push_back(v); touch(); }
+    template <class... A> void emplace_back(A&&... a) { sync_host(); host_.emplace_back(std::forward<A>(a)...); touch(); }
+    T& operator[](size_t i) { sync_host(); touch(); return host_[i]; }
     const T& operator[](size_t i) const { sync_host(); return host_[i]; }
-    T& at(size_t i) { sync_host(); host_dirty_ = true; return host_.at(i); }
+    T& at(size_t i) { sync_host(); touch(); return host_.at(i); }
     const T& at(size_t i) const { sync_host(); return host_.at(i); }
-    T* data() { sync_host(); host_dirty_ = true; return host_.data(); }
+    T* data() { sync_host(); touch(); return host_.data(); }
     const T* data() const { sync_host(); return host_.data(); }
-    iterator begin() { sync_host(); host_dirty_ = true; return host_.begin(); }
-    iterator end() { sync_host(); host_dirty_ = true; return host_.end(); }
+    iterator begin() { sync_host(); touch(); return host_.begin(); }
+    iterator end() { sync_host(); touch(); return host_.end(); }
     const_iterator begin() const { sync_host(); return host_.begin(); }
     const_iterator end() const { sync_host(); return host_.end(); }
     const std::vector<T>& host() const { sync_host(); return host_; }
@@ -339,12 +354,12 @@ public:
     template <class It>
     iterator insert(const_iterator pos, It first, It last) {
         sync_host();
-        host_dirty_ = true;
+        touch();
         return host_.insert(pos, first, last);
     }
     iterator erase(const_iterator first, const_iterator last) {
         sync_host();
-        host_dirty_ = true;
+        touch();
         return host_.erase(first, last);
     }
     /// the elements of `o` appended (its host copy is brought up to date first)
@@ -352,7 +367,7 @@ public:
         const std::vector<T>& src = o.host();
         sync_host();
         host_.insert(host_.end(), src.begin(), src.end());
-        host_dirty_ = true;
+        touch();
     }
 
     // ---- device side (what the kernels get)
@@ -362,15 +377,20 @@ public:
     T* device_data_for_write(size_t n) {
         ensure_capacity(n);
         dev_size_ = n; size_override_ = true; dev_dirty_ = true; host_dirty_ = false;
+        ++generation_;
         return dev_;
     }
     /// Read-write device pointer (in-place kernels).
-    T* device_data_rw() { sync_device(); dev_dirty_ = true; dev_size_ = host_.size(); size_override_ = true; return dev_; }
+    T* device_data_rw() { sync_device(); dev_dirty_ = true; dev_size_ = host_.size(); size_override_ = true; ++generation_; return dev_; }
     /// After a kernel produced fewer rows than reserved (compaction, downsampling).
-    void set_device_size(size_t n) { dev_size_ = n; size_override_ = true; dev_dirty_ = true; }
+    void set_device_size(size_t n) { dev_size_ = n; size_override_ = true; dev_dirty_ = true; ++generation_; }
+    /// Changes whenever the contents may have changed (any non-const access counts): a structure built on the container can
+    /// tell whether it still describes it.
+    uint64_t generation() const { return generation_; }
     hipStream_t stream() const { return queue_ ? queue_->stream : stream_; }
 
 private:
+    void touch() { host_dirty_ = true; ++generation_; }
     void bind(const sycl_utils::DeviceQueue::StreamHolder& h) { stream_ = h.stream; }
     void ensure_capacity(size_t n) const {
         if (n <= dev_cap_) return;
@@ -410,6 +430,7 @@ private:
     mutable T* dev_ = nullptr;
     mutable size_t dev_cap_ = 0, dev_size_ = 0, dev_bytes_ = 0;
     mutable bool host_dirty_ = true, dev_dirty_ = false, size_override_ = false;
+    uint64_t generation_ = 0;
     std::shared_ptr<sycl_utils::DeviceQueue::StreamHolder> queue_;
     hipStream_t stream_ = nullptr;
 };

@@ -261,11 +261,28 @@ private:
             int32_t exact[6] = {h[2], h[3], h[4], h[5], h[6], h[7]};
             launch(exact);
         }
+        const bool had_box = have_key_box_;
         have_key_box_ = h[2] <= h[5] && h[3] <= h[6] && h[4] <= h[7];
-        for (int a = 0; a < 3 && have_key_box_; ++a) {
-            const int32_t margin = std::max<int32_t>(2, (h[5 + a] - h[2 + a] + 1) / 8);
-            key_box_[a] = std::max<int32_t>(h[2 + a] - margin, 0);
-            key_box_[3 + a] = std::min<int32_t>(h[5 + a] + margin, (1 << 21) - 1);
+        if (have_key_box_) {
+            // Keep what earlier clouds needed as well (one VoxelGrid usually serves several scans in turn — source and target of
+            // a registration —, and a guess that forgets the other scan is redone every call), unless that has grown to more
+            // than 8x the cells this cloud needs.
+            int32_t lo[3], hi[3], ulo[3], uhi[3];
+            double cells = 1.0, ucells = 1.0;
+            for (int a = 0; a < 3; ++a) {
+                const int32_t margin = std::max<int32_t>(2, (h[5 + a] - h[2 + a] + 1) / 8);
+                lo[a] = std::max<int32_t>(h[2 + a] - margin, 0);
+                hi[a] = std::min<int32_t>(h[5 + a] + margin, (1 << 21) - 1);
+                ulo[a] = had_box ? std::min(lo[a], key_box_[a]) : lo[a];
+                uhi[a] = had_box ? std::max(hi[a], key_box_[3 + a]) : hi[a];
+                cells *= double(hi[a] - lo[a] + 1);
+                ucells *= double(uhi[a] - ulo[a] + 1);
+            }
+            const bool keep = ucells <= 8.0 * cells;
+            for (int a = 0; a < 3; ++a) {
+                key_box_[a] = keep ? ulo[a] : lo[a];
+                key_box_[3 + a] = keep ? uhi[a] : hi[a];
+            }
         }
         const size_t V = static_cast<uint32_t>(h[0]);
         out_pts.set_device_size(V);

@@ -93,29 +93,105 @@ inline KNNResult knn_search_bruteforce(const sycl_utils::DeviceQueue& queue, con
     return result;
 }
 
-/// algorithms/knn/kdtree.hpp:142-766
+/// MI355X-native KNNBase for clouds of any density profile: a bounding-volume hierarchy over the Morton-sorted points, built
+/// entirely on the device (sp_bvh_*, csrc/bvh.hip). Exact kNN, k <= 32, bit-identical to knn_search_bruteforce.
+class BVH : public KNNBase {
+public:
+    using Ptr = std::shared_ptr<BVH>;
+    sycl_utils::DeviceQueue queue;
+
+    explicit BVH(const sycl_utils::DeviceQueue& q) : queue(q) {}
+    ~BVH() override { if (bvh_) sp_bvh_destroy(bvh_); }
+    BVH(const BVH&) = delete;
+    BVH& operator=(const BVH&) = delete;
+
+    static Ptr build(const sycl_utils::DeviceQueue& q, const PointContainerShared& points) {
+        auto t = std::make_shared<BVH>(q);
+        throw_on_error(sp_bvh_create(reinterpret_cast<const float*>(points.device_data()), points.size(), q.stream(), &t->bvh_));
+        return t;
+    }
+    static Ptr build(const sycl_utils::DeviceQueue& q, const PointCloudShared& cloud) { return build(q, *cloud.points); }
+    const sp_bvh* handle() const { return bvh_; }
+    size_t size() const { return sp_bvh_size(bvh_); }
+
+    sycl_utils::events knn_search_async(const PointCloudShared& queries, const size_t k, KNNResult& result,
+                                        const std::vector<sycl_utils::event>& = {},
+                                        const TransformMatrix& transT = TransformMatrix::Identity()) const override {
+        const size_t nq = queries.size();
+        if (k > 32) throw std::runtime_error("[BVH::knn_search_async] `k` is too large (max 32).");
+        detail::prepare_result(queue, result, nq, nq ? k : 0);
+        if (nq == 0) return sycl_utils::events();
+        throw_on_error(sp_bvh_search(bvh_, queries.points_device(), nq, k, transT.data(), 0,
+                                     result.indices->device_data_for_write(nq * k),
+                                     result.distances->device_data_for_write(nq * k), queue.stream()));
+        return sycl_utils::events(queue.stream());
+    }
+    /// The cloud's own points as queries, walked in tree order (row i = neighbours of point i, itself first).
+    KNNResult self_knn(const size_t k) const {
+        const size_t n = size();
+        if (k > 32) throw std::runtime_error("[BVH::self_knn] `k` is too large (max 32).");
+        KNNResult result;
+        result.allocate(queue, n, n ? k : 0);
+        if (n == 0) return result;
+        throw_on_error(sp_bvh_self_knn(bvh_, k, result.indices->device_data_for_write(n * k),
+                                       result.distances->device_data_for_write(n * k), queue.stream()));
+        queue.wait();
+        return result;
+    }
+
+private:
+    sp_bvh* bvh_ = nullptr;
+};
+
+/// algorithms/knn/kdtree.hpp:142-766.
+///
+/// The reference builds its tree on the host (recursive nth_element: 30 ms per 1M points here, on 16 threads) and its callers
+/// rebuild it every frame (pipeline/submapping.hpp:197, pipeline/pointcloud_processing.hpp:64). build() here builds the
+/// device's own hierarchy instead (BVH above: 0.2-0.5 ms) and knn_search answers from it — the same exact neighbours; only
+/// the order inside a group of exactly equal distances differs (lowest index first, the brute-force rule, instead of the
+/// first visited). The reference-topology tree is built the first time something needs it: radius search, lazy delete, k > 32,
+/// or set_reference_tie_order(true).
 class KDTree : public KNNBase {
 public:
     using Ptr = std::shared_ptr<KDTree>;
     sycl_utils::DeviceQueue queue;
 
     explicit KDTree(const sycl_utils::DeviceQueue& q) : queue(q) {}
-    ~KDTree() override { if (tree_) sp_kdtree_destroy(tree_); }
+    ~KDTree() override {
+        if (tree_) sp_kdtree_destroy(tree_);
+        if (bvh_) sp_bvh_destroy(bvh_);
+        if (dev_points_) {
+            (void)hipStreamSynchronize(queue.stream());
+            (void)hipFree(dev_points_);
+        }
+    }
     KDTree(const KDTree&) = delete;
     KDTree& operator=(const KDTree&) = delete;
 
     static Ptr build(const sycl_utils::DeviceQueue& q, const PointContainerShared& points, size_t leaf_threshold = 16) {
         auto t = std::make_shared<KDTree>(q);
-        throw_on_error(sp_kdtree_create(reinterpret_cast<const float*>(points.data()), points.size(), leaf_threshold,
-                                        q.stream(), &t->tree_));
+        // (a cloud of a few hundred points: the host build is microseconds and the reference's balanced tree is the shallower one.
+        // From a few thousand points on the device build wins even where the search is a little slower — the reference's
+        // example on its 6 k-point downsampled scans, same box: build 1.40 -> 0.33 ms, search 0.51 -> 0.78 ms per loop.)
+        if (points.size() < kDeviceBuildMinPoints)
+            throw_on_error(sp_kdtree_create(reinterpret_cast<const float*>(points.data()), points.size(), leaf_threshold, q.stream(),
+                                            &t->tree_));
+        else
+            throw_on_error(sp_bvh_create(reinterpret_cast<const float*>(points.device_data()), points.size(), q.stream(), &t->bvh_));
         static std::atomic<uint64_t> next_id{1};
         t->id_ = next_id.fetch_add(1);
         t->size_ = points.size();
+        t->leaf_threshold_ = leaf_threshold;
         return t;
     }
     static Ptr build(const sycl_utils::DeviceQueue& q, const PointCloudShared& cloud, size_t leaf_threshold = 16) {
-        return build(q, *cloud.points, leaf_threshold);
+        auto t = build(q, *cloud.points, leaf_threshold);
+        t->built_on_ = cloud.points;  // (shared ownership: the address cannot be handed to another container meanwhile)
+        t->built_generation_ = cloud.points->generation();
+        return t;
     }
+    /// MI355X extension: answer knn_search from the reference-topology tree (first-visited tie order, host build) always.
+    void set_reference_tie_order(bool v) { reference_order_ = v; }
 
     sycl_utils::events knn_search_async(const PointCloudShared& queries, const size_t k, KNNResult& result,
                                         const std::vector<sycl_utils::event>& = {},
@@ -124,7 +200,21 @@ public:
         if (k > 100) throw std::runtime_error("[KDTree::knn_search_async] `k` is too large. not support.");
         detail::prepare_result(queue, result, nq, nq ? k : 0);
         if (nq == 0) return sycl_utils::events();
-        throw_on_error(sp_kdtree_search(tree_, queries.points_device(), nq, k, transT.data(), 0,
+        if (bvh_ != nullptr && pristine_ && !reference_order_ && k <= 32) {
+            // the tree's own cloud, untouched since build() and searched in place (the covariance pre-step of every pipeline):
+            // its points are walked in tree order, neighbouring lanes share their path (1.5x faster than in query order)
+            if (built_on_ != nullptr && queries.points == built_on_ && queries.points->generation() == built_generation_ && nq == size_ &&
+                transT == TransformMatrix::Identity()) {
+                throw_on_error(sp_bvh_self_knn(bvh_, k, result.indices->device_data_for_write(nq * k),
+                                               result.distances->device_data_for_write(nq * k), queue.stream()));
+                return sycl_utils::events(queue.stream());
+            }
+            throw_on_error(sp_bvh_search(bvh_, queries.points_device(), nq, k, transT.data(), 0,
+                                         result.indices->device_data_for_write(nq * k),
+                                         result.distances->device_data_for_write(nq * k), queue.stream()));
+            return sycl_utils::events(queue.stream());
+        }
+        throw_on_error(sp_kdtree_search(host_tree(), queries.points_device(), nq, k, transT.data(), 0,
                                         result.indices->device_data_for_write(nq * k),
                                         result.distances->device_data_for_write(nq * k), queue.stream()));
         return sycl_utils::events(queue.stream());
@@ -139,7 +229,7 @@ public:
             return sycl_utils::events();
         }
         detail::prepare_result(queue, result, nq, max_k);
-        throw_on_error(sp_kdtree_radius_search(tree_, queries.points_device(), nq, max_k, radius, transT.data(), 0,
+        throw_on_error(sp_kdtree_radius_search(host_tree(), queries.points_device(), nq, max_k, radius, transT.data(), 0,
                                                result.indices->device_data_for_write(nq * max_k),
                                                result.distances->device_data_for_write(nq * max_k), queue.stream()));
         return sycl_utils::events(queue.stream());
@@ -147,9 +237,9 @@ public:
     void remove_nodes_by_flags(const shared_vector<uint8_t>& flags, const shared_vector<int32_t>& indices) {
         if (flags.size() != indices.size())
             throw std::runtime_error("[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.");
-        throw_on_error(sp_kdtree_remove_by_flags(tree_, flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
+        throw_on_error(sp_kdtree_remove_by_flags(host_tree(), flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
         queue.wait();
-        pristine_ = false;
+        pristine_ = false;  // the device hierarchy still holds the removed points: the tree answers from here on
     }
     /// Identity of the built tree (unique per build), its point count, and whether no node was ever removed — what
     /// Registration::align needs to decide that a GridKNN on the same cloud answers the same nearest-neighbour queries.
@@ -158,10 +248,36 @@ public:
     bool pristine() const { return pristine_; }
 
 private:
-    sp_kdtree* tree_ = nullptr;
+    static constexpr size_t kDeviceBuildMinPoints = 1024;
+    /// The points the tree was built on, in their original order, on the device (the hierarchy keeps its own copy, like the
+    /// nodes of the reference's tree: the source cloud may be gone or changed by now).
+    const float* device_points() const {
+        if (dev_points_ == nullptr && size_) {
+            hip_check(hipMalloc(&dev_points_, size_ * 16), "hipMalloc");
+            throw_on_error(sp_bvh_export_points(bvh_, static_cast<float*>(dev_points_), queue.stream()));
+        }
+        return static_cast<const float*>(dev_points_);
+    }
+    /// The reference's tree (host build with its rule, kdtree.hpp:292-413).
+    sp_kdtree* host_tree() const {
+        if (tree_ == nullptr) {
+            std::vector<float> host(4 * std::max<size_t>(size_, 1));
+            if (size_) {
+                hip_check(hipMemcpyAsync(host.data(), device_points(), size_ * 16, hipMemcpyDeviceToHost, queue.stream()), "D2H");
+                hip_check(hipStreamSynchronize(queue.stream()), "sync");
+            }
+            throw_on_error(sp_kdtree_create(host.data(), size_, leaf_threshold_, queue.stream(), &tree_));
+        }
+        return tree_;
+    }
+    mutable sp_kdtree* tree_ = nullptr;
+    sp_bvh* bvh_ = nullptr;
+    mutable void* dev_points_ = nullptr;
     uint64_t id_ = 0;
-    size_t size_ = 0;
-    bool pristine_ = true;
+    size_t size_ = 0, leaf_threshold_ = 16;
+    bool pristine_ = true, reference_order_ = false;
+    std::shared_ptr<PointContainerShared> built_on_;  // the cloud's point container at build(), and its generation then
+    uint64_t built_generation_ = 0;
 };
 
 /// MI355X-native KNNBase: exact kNN on a device-built uniform grid (sp_grid_*). Bit-identical to

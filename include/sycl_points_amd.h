@@ -150,6 +150,30 @@ int sp_normals_from_cov(const float* points, const float* covs, size_t n, float*
 /* covariance::kernel::update_covariance_plane applied to a whole array (covariance.hpp:67-74); in place allowed. */
 int sp_cov_update_plane(const float* covs, size_t n, float* covs_out, void* stream);
 
+/* ------------------------------------------------------------------- device-built tree (any density profile) */
+
+/* KDTree::build + knn_search_async (algorithms/knn/kdtree.hpp:292-413, 424-562) for callers that rebuild the structure every
+ * frame (pipeline/submapping.hpp:197, pipeline/pointcloud_processing.hpp:64) on clouds whose density varies by orders of
+ * magnitude (raw LiDAR scans): a bounding-volume hierarchy over the Morton-sorted points, leaves of 16 points, built ENTIRELY on
+ * the device (bounding box, 30-bit Morton keys, radix sort, boxes level by level: a fraction of a millisecond per 1M points
+ * against 30 ms for the host's recursive nth_element) and balanced by count, so it is indifferent to where the points are
+ * (GridKNN is the faster structure on near-uniform clouds, sp_grid_*). sp_bvh_create allocates and synchronises.
+ *   sp_bvh_search    exact kNN, 1 <= k <= 32, queries searched at transT * q (NULL: identity; host or device matrix as for
+ *                    sp_kdtree_search); rows as KNNResult (knn/result.hpp:12-34): ascending, -1 / FLT_MAX padded; ties to the
+ *                    lowest index — bit-identical to sp_knn_bruteforce.
+ *   sp_bvh_self_knn  the cloud's own points as queries (row i = neighbours of point i, itself first), walked in tree order. */
+typedef struct sp_bvh sp_bvh;
+int sp_bvh_create(const float* points, size_t n, void* stream, sp_bvh** out);
+void sp_bvh_destroy(sp_bvh* bvh);
+size_t sp_bvh_size(const sp_bvh* bvh);
+int sp_bvh_search(const sp_bvh* bvh, const float* queries, size_t nq, size_t k, const float* transT, int transT_on_device,
+                  int32_t* idx_out, float* d2_out, void* stream);
+int sp_bvh_self_knn(const sp_bvh* bvh, size_t k, int32_t* idx_out, float* d2_out, void* stream);
+/* The points the tree was built on, back in their original order (x, y, z, 1): the tree keeps its own copy, like the nodes of
+ * the reference's KDTree, so a caller that needs them again later (the facade builds the reference-topology KD-tree lazily,
+ * for radius search / lazy delete) does not depend on the source cloud still being there. */
+int sp_bvh_export_points(const sp_bvh* bvh, float* points_out, void* stream);
+
 /* --------------------------------------------------------------------------------------- voxel grid */
 
 /* filter::kernel::compute_voxel_bit (algorithms/common/voxel_constants.hpp:36-62, kernel K9).

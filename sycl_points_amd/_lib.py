@@ -90,6 +90,12 @@ SIGNATURES = {
     "sp_normals_from_knn": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "sp_normals_from_cov": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "sp_cov_update_plane": (_i, [_vp, _sz, _vp, _vp]),
+    "sp_bvh_create": (_i, [_vp, _sz, _vp, C.POINTER(_vp)]),
+    "sp_bvh_destroy": (None, [_vp]),
+    "sp_bvh_size": (_sz, [_vp]),
+    "sp_bvh_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
+    "sp_bvh_self_knn": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "sp_bvh_export_points": (_i, [_vp, _vp, _vp]),
     "sp_voxel_keys": (_i, [_vp, _sz, _f, _vp, _vp]),
     "sp_voxel_downsample_workspace_bytes": (_sz, [_sz]),
     "sp_voxel_downsample": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -228,6 +228,51 @@ class KDTree(KNNBase):
         torch.cuda.current_stream().synchronize()
 
 
+class BVH(KNNBase):
+    """MI355X-native KNNBase for clouds of any density profile (csrc/bvh.hip): a bounding-volume hierarchy over the
+    Morton-sorted points, built entirely on the device (the job of KDTree::build, kdtree.hpp:292-413, without its host
+    build); exact kNN, k <= 32, bit-identical to knn_search_bruteforce."""
+
+    def __init__(self, handle, n, device):
+        self._h = handle
+        self.n = n
+        self.device = device
+
+    @staticmethod
+    def build(points):
+        p = _dev_f32(_points_of(points), 4)
+        h = C.c_void_p()
+        check(_lib.lib().sp_bvh_create(_ptr(p), p.shape[0], _stream(), C.byref(h)))
+        return BVH(h, p.shape[0], p.device)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_bvh_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def knn_search_async(self, queries, k, result, transT=None):
+        q = _dev_f32(_points_of(queries), 4)
+        if k > 32:
+            raise SpError(2, "[BVH::knn_search_async] `k` is too large. not support.")
+        result.resize(q.shape[0], k, q.device)
+        if q.shape[0] == 0:
+            return
+        tp, on_dev, keep = _trans_arg(transT)
+        check(_lib.lib().sp_bvh_search(self._h, _ptr(q), q.shape[0], k, tp, on_dev, _ptr(result.indices),
+                                       _ptr(result.distances), _stream()))
+
+    def self_knn(self, k):
+        """The cloud's own points as queries, in tree order (row i = neighbours of point i)."""
+        res = KNNResult()
+        res.resize(self.n, k, self.device)
+        if self.n:
+            check(_lib.lib().sp_bvh_self_knn(self._h, k, _ptr(res.indices), _ptr(res.distances), _stream()))
+        return res
+
+
 class GridKNN(KNNBase):
     """MI355X-native KNNBase: exact kNN on a device-built uniform grid (csrc/grid.hip); bit-identical to
     knn_search_bruteforce. `points_per_cell` tunes the cell size (about 2 for k = 1, about 6-8 for k = 20)."""
@@ -517,6 +562,14 @@ class VoxelGrid:
             margin = np.maximum(2, (box[3:] - box[:3] + 1) // 8)
             lo = np.maximum(box[:3] - margin, 0)
             hi = np.minimum(box[3:] + margin, (1 << 21) - 1)
+            # Keep what earlier clouds needed as well (one VoxelGrid usually serves several scans in turn — source and target
+            # of a registration —, and a guess that forgets the other scan is redone every call), unless that has grown to
+            # more than 8x the cells this cloud needs.
+            prev = getattr(self, "_key_box", None)
+            if prev is not None:
+                ulo, uhi = np.minimum(lo, prev[:3]), np.maximum(hi, prev[3:])
+                if np.prod((uhi - ulo + 1).astype(np.float64)) <= 8.0 * np.prod((hi - lo + 1).astype(np.float64)):
+                    lo, hi = ulo, uhi
             self._key_box = np.ascontiguousarray(np.concatenate([lo, hi]).astype(np.int32))
         v = int(counts[0])
         out.points = o_p[:v]

@@ -1,0 +1,472 @@
+// Device-built bounding-volume hierarchy for exact kNN on clouds of ANY density profile
+// (the job of KDTree::build + knn_search_async, algorithms/knn/kdtree.hpp:292-413, 424-562, without the host build).
+//
+// Why a second structure: GridKNN (grid.hip) sizes its cells for the cloud's AVERAGE density. On the reference's bundled
+// LiDAR scan (points on surfaces, density 5000 : 1 between cells) a query near the sensor scans thousands of candidates and
+// the KD-tree is 3-10x faster (profiles/r02_h_real_cloud_grid_vs_kdtree.txt) — but the reference's KD-tree is built on the
+// host by recursive nth_element: 30 ms per 1M points on 16 threads, every frame (pipeline/submapping.hpp:197). This tree
+// follows the points wherever they are and is built by the device in a fraction of a millisecond (Karras 2012, "Maximizing
+// parallelism in the construction of BVHs, octrees and k-d trees"):
+//   build   bounding box (integer atomics) -> 48-bit Morton key of every point (box read from device memory: no host round
+//           trip) -> the library's radix sort -> points gathered in Morton order -> one lane per internal node finds its key
+//           range and split from the longest common prefixes of neighbouring keys (equal keys: the index breaks the tie), so a
+//           node is an octree cell and siblings are DISJOINT -> boxes bottom-up, one lane per point walking towards the root;
+//           the second child to arrive at a node carries on (write-through stores + an agent-scope ticket, no fence).
+//           A node keeps BOTH children's boxes (64 bytes: one line per visit).
+//   search  one lane per query, depth-first, per-lane stack in LDS. A subtree of <= 16 points is a leaf: its points are
+//           consecutive and come as batches of independent loads. Exact: a subtree is skipped only when its box lies strictly
+//           beyond the current k-th distance, and lists are (distance, index)-lexicographic like brute force, so results are
+//           bit-identical to knn_search_bruteforce, ties included. (A query that would overflow the stack scans all points.)
+//   self    the cloud's own points are the queries, taken in Morton order (neighbouring lanes walk the same subtrees:
+//           their node and leaf loads share cache lines) and written back by original index.
+#include "grid_device.h"
+#include "radix_sort.h"
+
+void sp_set_error(const char* msg);
+
+struct sp_bvh {
+    size_t n = 0;
+    float4* pts = nullptr;    // n points in Morton order, w = original index bits
+    float4* node = nullptr;   // 4 x float4 per internal node (n - 1): (Llo, first) (Lhi, split) (Rlo, last) (Rhi, -)
+    float4* obox = nullptr;   // 2 x float4 per internal node: its own box (re-tested when a stacked node is taken up again);
+                              // lo.w = the lowest original index below the node (ties, see bvh_search_kernel)
+    mutable sp::StreamSet streams;
+};
+
+namespace sp {
+namespace {
+
+constexpr int kBvhLeaf = 16;
+constexpr int kBvhStack = 48;
+constexpr uint64_t kBvhInvalidKey = (1ull << 48) - 1ull;  // cell (65535, 65535, 65535): no valid point gets it
+
+__device__ __forceinline__ unsigned enc_f(float f) {  // order-preserving float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__global__ void bvh_bbox_init_kernel(unsigned* bbox) {
+    if (threadIdx.x < 3) bbox[threadIdx.x] = 0xffffffffu;
+    else if (threadIdx.x < 6) bbox[threadIdx.x] = 0u;
+}
+// bbox[0..2] = min xyz, bbox[3..5] = max xyz (encoded), over the finite points; four loads in flight per lane.
+__global__ __launch_bounds__(kBlock) void bvh_bbox_kernel(const float4* __restrict__ pts, unsigned n, unsigned* bbox) {
+    __shared__ unsigned red[kBlock / kWave][6];
+    unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    const unsigned stride = gridDim.x * kBlock;
+    for (unsigned i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[min(i0 + u * stride, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * stride < n && isfinite(p[u].x) && isfinite(p[u].y) && isfinite(p[u].z)) {
+                const unsigned e[3] = {enc_f(p[u].x), enc_f(p[u].y), enc_f(p[u].z)};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], e[a]); mx[a] = max(mx[a], e[a]); }
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = min(mn[a], (unsigned)__shfl_xor((int)mn[a], o, 64));
+            mx[a] = max(mx[a], (unsigned)__shfl_xor((int)mx[a], o, 64));
+        }
+    const unsigned wave = threadIdx.x / kWave;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[wave][a] = mn[a]; red[wave][3 + a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned v = red[0][threadIdx.x];
+        for (int w = 1; w < kBlock / kWave; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bbox[threadIdx.x], v);
+        else atomicMax(&bbox[threadIdx.x], v);
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint64_t x) {  // up to 21 bits -> every third bit
+    x = (x | (x << 32)) & 0x001f00000000ffffull;
+    x = (x | (x << 16)) & 0x001f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ __launch_bounds__(kBlock) void bvh_key_kernel(const float4* __restrict__ pts, unsigned n,
+                                                         const unsigned* __restrict__ bbox, uint64_t* __restrict__ keys,
+                                                         unsigned* __restrict__ vals) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    uint64_t key = kBvhInvalidKey;  // non-finite points: behind all others, in no box, never a neighbour (their distance is NaN)
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+        const float v[3] = {p.x, p.y, p.z};
+        uint64_t c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = dec_f(bbox[a]), hi = dec_f(bbox[3 + a]);
+            const float ext = hi - lo;
+            const float t = ext > 0.0f ? (v[a] - lo) / ext * 65535.0f : 0.0f;
+            c[a] = (uint64_t)fminf(fmaxf(t, 0.0f), 65534.0f);
+        }
+        key = spread21(c[0]) | (spread21(c[1]) << 1) | (spread21(c[2]) << 2);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+__global__ __launch_bounds__(kBlock) void bvh_gather_kernel(const float4* __restrict__ pts, const unsigned* __restrict__ order,
+                                                            unsigned n, float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned src = order[i];
+    float4 p = pts[src];
+    p.w = __uint_as_float(src);
+    out[i] = p;
+}
+
+// Length of the common prefix of the (key, position) pairs i and j; -1 outside the array.
+__device__ __forceinline__ int bvh_delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    return a == b ? 64 + __clz((unsigned)(i ^ j)) : __clzll((long long)(a ^ b));
+}
+// Karras 2012, section 4: internal node i covers the keys [first, last] and splits them behind `split`; its children are
+// node `split` (a point when first == split) and node `split + 1` (a point when split + 1 == last).
+__global__ __launch_bounds__(kBlock) void bvh_hierarchy_kernel(const uint64_t* __restrict__ keys, int n, float4* __restrict__ node,
+                                                               int* __restrict__ parent, int* __restrict__ leaf_parent,
+                                                               unsigned* __restrict__ tickets) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (bvh_delta(keys, n, i, i + 1) - bvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = bvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (bvh_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (bvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = bvh_delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (bvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int split = i + s * d + min(d, 0);
+    const int first = min(i, j), last = max(i, j);
+    // (the boxes arrive bottom-up; the three integers ride in the w slots)
+    node[4 * (size_t)i] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(first));
+    node[4 * (size_t)i + 1] = make_float4(-INFINITY, -INFINITY, -INFINITY, __int_as_float(split));
+    node[4 * (size_t)i + 2] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(last));
+    node[4 * (size_t)i + 3] = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+    tickets[i] = 0u;
+    if (first == split) leaf_parent[split] = i; else parent[split] = i;
+    if (split + 1 == last) leaf_parent[last] = i; else parent[split + 1] = i;
+    if (i == 0) parent[0] = -1;
+}
+// One lane per point, walking towards the root: it writes the box of the subtree it has finished into its parent's slot for
+// that child and takes the parent's ticket; the first to arrive leaves, the second reads its sibling's box and carries the
+// union on. Cross-workgroup hand-off without a fence (MI355X_MICROARCH.md, the counter form: every handed-off word is stored
+// write-through (sc1) by ONE lane, that lane drains its stores before it adds to the agent-scope counter, and the lane whose
+// add came second reads them with sc1 loads).
+__global__ __launch_bounds__(kBlock) void bvh_box_kernel(const float4* __restrict__ spts, int n, float4* __restrict__ node,
+                                                         float4* __restrict__ obox, const int* __restrict__ parent,
+                                                         const int* __restrict__ leaf_parent, unsigned* __restrict__ tickets,
+                                                         int* __restrict__ child_min) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = spts[i];
+    int min_idx = __float_as_int(p.w);  // lowest original index of the finished subtree
+    const bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    float lo[3] = {ok ? p.x : INFINITY, ok ? p.y : INFINITY, ok ? p.z : INFINITY};
+    float hi[3] = {ok ? p.x : -INFINITY, ok ? p.y : -INFINITY, ok ? p.z : -INFINITY};
+    int child = i;
+    bool child_is_point = true;
+    int cur = leaf_parent[i];
+    while (cur >= 0) {
+        float* const rec = reinterpret_cast<float*>(node + 4 * (size_t)cur);
+        // (first and split were written by the hierarchy launch: plain loads)
+        const int first = __float_as_int(rec[3]), split = __float_as_int(rec[7]);
+        // the left child of `cur` is number `split` — the POINT `split` when the left range is that single point
+        const bool left = child_is_point ? (child == split && first == split) : (child == split && first != split);
+        float* const mine = rec + (left ? 0 : 8);
+        float* const other = rec + (left ? 8 : 0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            __hip_atomic_store(mine + a, lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 4 + a, hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(child_min + 2 * (size_t)cur + (left ? 0 : 1), min_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_fetch_add(tickets + cur, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // first to arrive
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], __hip_atomic_load(other + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            hi[a] = fmaxf(hi[a], __hip_atomic_load(other + 4 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        min_idx = min(min_idx, __hip_atomic_load(child_min + 2 * (size_t)cur + (left ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        obox[2 * (size_t)cur] = make_float4(lo[0], lo[1], lo[2], __int_as_float(min_idx));
+        obox[2 * (size_t)cur + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        child = cur;
+        child_is_point = false;
+        cur = parent[cur];
+    }
+}
+
+__device__ __forceinline__ float box_d2(float lx, float ly, float lz, float hx, float hy, float hz, float qx, float qy, float qz) {
+    const float dx = fmaxf(fmaxf(lx - qx, qx - hx), 0.0f), dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.0f),
+                dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.0f);
+    // never above the true squared distance to any point inside (per axis the box's gap is below the point's; the factor
+    // covers the different rounding of the two sums): a box is skipped only when it lies strictly beyond the k-th distance
+    return fmaf(dx, dx, fmaf(dy, dy, dz * dz)) * 0.999999f;
+}
+
+template <int KCAP>
+__global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __restrict__ node, const float4* __restrict__ obox,
+                                                            const float4* __restrict__ spts, unsigned n,
+                                                            const float4* __restrict__ queries, unsigned nq, int k, Mat4Arg T_val,
+                                                            const float* __restrict__ T_dev, int32_t* __restrict__ idx_out,
+                                                            float* __restrict__ d2_out) {
+    __shared__ unsigned st_node[kBvhStack][kBlock];
+    const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
+    if (qi >= nq) return;  // no barrier below
+    const unsigned lane = threadIdx.x;
+    float qx, qy, qz;
+    size_t row;
+    if (queries) {
+        const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+        const float4 q4 = queries[qi];
+        transform_point(T, q4.x, q4.y, q4.z, qx, qy, qz);
+        row = qi;
+    } else {  // self-kNN: the cloud's own points in Morton order, results by original index
+        const float4 q4 = spts[qi];
+        qx = q4.x; qy = q4.y; qz = q4.z;
+        row = __float_as_uint(q4.w);
+    }
+    float bd[KCAP];
+    int bi[KCAP];
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
+    float kth = FLT_MAX;
+    int kth_idx = -1;
+    // the points [first, last], batches of eight independent loads
+    auto scan = [&](unsigned first, unsigned last) {
+#pragma unroll 1
+        for (unsigned b = first; b <= last; b += 8) {
+            float4 slot[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) slot[s] = spts[min(b + s, last)];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float d = dist2(qx, qy, qz, slot[s].x, slot[s].y, slot[s].z);
+                const int pi = __float_as_int(slot[s].w);
+                // (a non-finite point gives a NaN distance: every comparison fails, it is never taken)
+                if (b + s <= last && (d < kth || (d == kth && pi < kth_idx))) lex_insert<KCAP>(bd, bi, k, d, pi, kth, kth_idx);
+            }
+        }
+    };
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz) && n != 0u) {
+        if (n <= (unsigned)kBvhLeaf) {
+            scan(0u, n - 1u);
+        } else {
+            int sp_top = 0;
+            bool overflow = false;
+            unsigned cur = 0;  // the root is always entered
+            for (;;) {
+                const float4 r0 = node[4 * (size_t)cur], r1 = node[4 * (size_t)cur + 1], r2 = node[4 * (size_t)cur + 2],
+                             r3 = node[4 * (size_t)cur + 3];
+                const unsigned first = __float_as_uint(r0.w), split = __float_as_uint(r1.w), last = __float_as_uint(r2.w);
+                const float dl = box_d2(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, qx, qy, qz);
+                const float dr = box_d2(r2.x, r2.y, r2.z, r3.x, r3.y, r3.z, qx, qy, qz);
+                const bool l_near = !(dr < dl);
+                // nearer child first; a child of <= kBvhLeaf points is scanned on the spot, a larger one is entered / stacked
+                unsigned next = ~0u;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const bool take_left = (pass == 0) == l_near;
+                    const float dc = take_left ? dl : dr;
+                    const unsigned cf = take_left ? first : split + 1u, cl = take_left ? split : last;
+                    if (dc > kth) continue;  // (an empty box is +inf away)
+                    // A box exactly AT the k-th distance can only matter through a point at that very distance with a lower
+                    // index than the k-th neighbour's (lists are (distance, index)-lexicographic). Clouds with thousands of
+                    // copies of one point (invalid returns of a scan) would otherwise visit every copy from every copy.
+                    if (dc == kth && cl > cf && __float_as_int(obox[2 * (size_t)(take_left ? split : split + 1u)].w) > kth_idx) continue;
+                    if (cl - cf < (unsigned)kBvhLeaf) {
+                        scan(cf, cl);
+                    } else {
+                        const unsigned child = take_left ? split : split + 1u;
+                        if (next == ~0u) {
+                            next = child;  // entered next (pass 1: the nearer child was a leaf or out of reach)
+                        } else if (sp_top < kBvhStack) {
+                            st_node[sp_top][lane] = child;
+                            ++sp_top;
+                        } else {
+                            overflow = true;
+                        }
+                    }
+                }
+                if (overflow) break;
+                if (next != ~0u) { cur = next; continue; }
+                // take up the most recent stacked node that is still within reach
+                bool found = false;
+                while (sp_top > 0) {
+                    --sp_top;
+                    const unsigned c = st_node[sp_top][lane];
+                    const float4 o0 = obox[2 * (size_t)c], o1 = obox[2 * (size_t)c + 1];
+                    const float dc = box_d2(o0.x, o0.y, o0.z, o1.x, o1.y, o1.z, qx, qy, qz);
+                    if (dc > kth || (dc == kth && __float_as_int(o0.w) > kth_idx)) continue;
+                    cur = c;
+                    found = true;
+                    break;
+                }
+                if (!found) break;
+            }
+            if (overflow) {  // a tree deeper than the stack (degenerate clouds): start over and look at every point
+#pragma unroll
+                for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
+                kth = FLT_MAX; kth_idx = -1;
+                scan(0u, n - 1u);
+            }
+        }
+    }
+    const size_t o = row * (size_t)k;
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i)
+        if (i < k) { d2_out[o + i] = bd[i]; idx_out[o + i] = bi[i]; }
+}
+
+__global__ __launch_bounds__(kBlock) void bvh_export_kernel(const float4* __restrict__ spts, unsigned n, float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 p = spts[i];
+    const unsigned o = __float_as_uint(p.w);
+    p.w = 1.0f;
+    out[o] = p;
+}
+
+template <int KCAP>
+void launch_bvh(const sp_bvh* b, const float4* q, unsigned nq, int k, const Mat4Arg& Tv, const float* T_dev, int32_t* idx, float* d2,
+                hipStream_t st) {
+    bvh_search_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(b->node, b->obox, b->pts, (unsigned)b->n, q, nq, k, Tv, T_dev, idx,
+                                                                 d2);
+}
+
+int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const float* transT, int transT_on_device,
+                 int32_t* idx_out, float* d2_out, hipStream_t st) {
+    if (k == 0 || k > 32) {
+        sp_set_error("[BVH] k must be in 1..32");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    b->streams.note(st);
+    Mat4Arg Tv;
+    for (int i = 0; i < 16; ++i) Tv.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    if (transT && !transT_on_device)
+        for (int i = 0; i < 16; ++i) Tv.m[i] = transT[i];
+    const float* T_dev = transT_on_device ? transT : nullptr;
+    const int kk = (int)k;
+    if (k == 1) launch_bvh<1>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
+    else if (k <= 10) launch_bvh<10>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
+    else if (k <= 20) launch_bvh<20>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
+    else launch_bvh<32>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
+    return launch_status();
+}
+
+}  // namespace
+}  // namespace sp
+
+extern "C" void sp_bvh_destroy(sp_bvh* b) {
+    if (!b) return;
+    sp::pooled_free_after(b->pts, b->streams);
+    sp::pooled_free_after(b->node, b->streams);
+    sp::pooled_free_after(b->obox, b->streams);
+    delete b;
+}
+
+extern "C" int sp_bvh_create(const float* points, size_t n, void* stream, sp_bvh** out) {
+    using namespace sp;
+    if (!out || (n && !points)) return SP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (n >= (1ull << 30)) {
+        sp_set_error("[BVH] more than 2^30 points");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t st = as_stream(stream);
+    sp_bvh* b = new sp_bvh();
+    b->n = n;
+    b->streams.note(st);
+    const size_t ni = n > 1 ? n - 1 : 1;  // internal nodes
+    ScratchBuf b_bbox, b_kin, b_kout, b_vin, b_vout, b_tmp, b_parent, b_lparent, b_tickets, b_cmin;
+    const size_t tmp_bytes = radix_sort_u64_workspace_bytes(n ? n : 1);
+    hipError_t e = pooled_alloc(&b->pts, (n ? n : 1) * sizeof(float4));
+    if (e == hipSuccess) e = pooled_alloc(&b->node, 4 * ni * sizeof(float4));
+    if (e == hipSuccess) e = pooled_alloc(&b->obox, 2 * ni * sizeof(float4));
+    if (e == hipSuccess) e = b_bbox.get(8 * sizeof(unsigned));
+    if (e == hipSuccess && n) e = b_kin.get(n * 8);
+    if (e == hipSuccess && n) e = b_kout.get(n * 8);
+    if (e == hipSuccess && n) e = b_vin.get(n * 4);
+    if (e == hipSuccess && n) e = b_vout.get(n * 4);
+    if (e == hipSuccess && n) e = b_tmp.get(tmp_bytes);
+    if (e == hipSuccess && n) e = b_parent.get(ni * 4);
+    if (e == hipSuccess && n) e = b_lparent.get(n * 4);
+    if (e == hipSuccess && n) e = b_tickets.get(ni * 4);
+    if (e == hipSuccess && n) e = b_cmin.get(2 * ni * 4);
+    auto fail = [&](const char* msg) {
+        sp_set_error(msg);
+        (void)hipStreamSynchronize(st);
+        sp_bvh_destroy(b);
+        return SP_ERR_HIP;
+    };
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    const float4* pts = reinterpret_cast<const float4*>(points);
+    if (n) {
+        unsigned* const bbox = b_bbox.as<unsigned>();
+        uint64_t *kin = b_kin.as<uint64_t>(), *kout = b_kout.as<uint64_t>();
+        unsigned *vin = b_vin.as<unsigned>(), *vout = b_vout.as<unsigned>();
+        bvh_bbox_init_kernel<<<1, 64, 0, st>>>(bbox);
+        unsigned g = div_up(n, (size_t)kBlock * 16);
+        bvh_bbox_kernel<<<g > 256u ? 256u : (g ? g : 1u), kBlock, 0, st>>>(pts, (unsigned)n, bbox);
+        bvh_key_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, (unsigned)n, bbox, kin, vin);
+        bool in_b = false;
+        if (radix_sort_pairs_u64(kin, kout, vin, vout, n, 48, b_tmp.p, tmp_bytes, &in_b, st) != SP_OK) return fail("[BVH] sort failed");
+        if (!in_b) { kout = kin; vout = vin; }
+        bvh_gather_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vout, (unsigned)n, b->pts);
+        if (n > 1) {
+            bvh_hierarchy_kernel<<<div_up(n - 1, kBlock), kBlock, 0, st>>>(kout, (int)n, b->node, b_parent.as<int>(),
+                                                                          b_lparent.as<int>(), b_tickets.as<unsigned>());
+            bvh_box_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(b->pts, (int)n, b->node, b->obox, b_parent.as<int>(),
+                                                                b_lparent.as<int>(), b_tickets.as<unsigned>(), b_cmin.as<int>());
+        }
+    }
+    if (launch_status() != SP_OK || hipStreamSynchronize(st) != hipSuccess) return fail("[BVH] build failed");  // scratch idle from here
+    *out = b;
+    return SP_OK;
+}
+
+extern "C" size_t sp_bvh_size(const sp_bvh* b) { return b ? b->n : 0; }
+
+extern "C" int sp_bvh_search(const sp_bvh* bvh, const float* queries, size_t nq, size_t k, const float* transT,
+                             int transT_on_device, int32_t* idx_out, float* d2_out, void* stream) {
+    if (!bvh || !idx_out || !d2_out || (!queries && nq)) return SP_ERR_INVALID_ARGUMENT;
+    if (nq == 0) return SP_OK;
+    if (nq >= (1ull << 32)) return SP_ERR_INVALID_ARGUMENT;
+    return sp::bvh_dispatch(bvh, reinterpret_cast<const float4*>(queries), (unsigned)nq, k, transT, transT_on_device, idx_out, d2_out,
+                            sp::as_stream(stream));
+}
+
+extern "C" int sp_bvh_self_knn(const sp_bvh* bvh, size_t k, int32_t* idx_out, float* d2_out, void* stream) {
+    if (!bvh || !idx_out || !d2_out) return SP_ERR_INVALID_ARGUMENT;
+    if (bvh->n == 0) return SP_OK;
+    return sp::bvh_dispatch(bvh, nullptr, (unsigned)bvh->n, k, nullptr, 0, idx_out, d2_out, sp::as_stream(stream));
+}
+
+extern "C" int sp_bvh_export_points(const sp_bvh* bvh, float* points_out, void* stream) {
+    if (!bvh || (!points_out && bvh->n)) return SP_ERR_INVALID_ARGUMENT;
+    if (bvh->n == 0) return SP_OK;
+    hipStream_t st = sp::as_stream(stream);
+    bvh->streams.note(st);
+    sp::bvh_export_kernel<<<sp::div_up(bvh->n, sp::kBlock), sp::kBlock, 0, st>>>(bvh->pts, (unsigned)bvh->n,
+                                                                               reinterpret_cast<float4*>(points_out));
+    return sp::launch_status();
+}

@@ -76,8 +76,9 @@ hipError_t scratch_acquire(void** ptr, size_t bytes) {
         // otherwise keep its events, and the pool would grow past kKeep with nothing known to be idle), then trim the idle ones
         // to kKeep buffers / kKeepBytes: smallest first, freed just below (this call allocates and may synchronise anyway).
         size_t idle = 0, idle_bytes = 0;
-        for (auto& e : g_pool)
-            if (!e.busy && e.device == dev && entry_idle(e)) { ++idle; idle_bytes += e.bytes; }
+        if (g_pool.size() > kKeep / 2)  // (a handful of entries: nothing to trim, and the best-fit scan below settles what it looks at)
+            for (auto& e : g_pool)
+                if (!e.busy && e.device == dev && entry_idle(e)) { ++idle; idle_bytes += e.bytes; }
         while (idle > kKeep || idle_bytes > kKeepBytes) {
             size_t k = g_pool.size();
             for (size_t i = 0; i < g_pool.size(); ++i) {
@@ -97,7 +98,7 @@ hipError_t scratch_acquire(void** ptr, size_t bytes) {
         PoolEntry* best = nullptr;
         for (auto& e : g_pool)  // best fit among the idle buffers of this device, not more than 4x oversized
             if (!e.busy && e.device == dev && e.bytes >= bytes && e.bytes <= 4 * bytes && (!best || e.bytes < best->bytes) &&
-                e.pending.empty())
+                entry_idle(e))
                 best = &e;
         if (best) { best->busy = true; *ptr = best->p; }
     }
