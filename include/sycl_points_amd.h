@@ -501,6 +501,35 @@ int sp_gicp_align_sharded(const sp_gicp_target* target, const sp_gicp_source* so
                           int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
                           uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same sharded loop WITHOUT a collective per iteration (direct exchange). An all-reduce of 128 bytes is pure latency — a
+ * library launch between two kernels, 15-30 us on an 8-GPU node against ~30 us of compute per iteration. Here every rank owns
+ * a small slot buffer in uncached device memory and maps its peers' (hipIpc handles, exchanged ONCE through the caller's own
+ * channel); the streaming launch's last-arriving workgroup stores the rank's 128-byte row, tagged with the iteration's
+ * sequence number, straight into every rank's buffer over xGMI, and the one-workgroup solve launch that follows waits until
+ * all `world` rows carry the tag, adds them in rank order (identical sums, identical pose on every rank) and solves.
+ *   sp_xchg_create / sp_xchg_handle / sp_xchg_connect   every rank creates, all ranks gather the SP_XCHG_HANDLE_BYTES-byte
+ *                       handles in rank order (MPI_Allgather, torch.distributed, a file ...) and connect; world <= 8
+ *   sp_gicp_align_direct   arguments as sp_gicp_align_sharded; only enqueues; every rank must call it the same number of
+ *                       times (the sequence numbers are counted per alignment); max_iterations <= 255
+ *   sp_gicp_align_status   the wait is BOUNDED (sp_xchg_set_timeout_ms, default 2000): a row that does not arrive stops the
+ *                       alignment and raises a flag in its state block instead of hanging the queue; this call reads the
+ *                       flag back (it synchronises the stream) -> SP_OK, or SP_ERR_RUNTIME when a peer was missing.
+ * Summation order differs from one GPU (per-rank sums first), so poses agree to rounding, as with sp_gicp_align_sharded. */
+#define SP_XCHG_HANDLE_BYTES 64
+typedef struct sp_xchg sp_xchg;
+int sp_xchg_create(int rank, int world, sp_xchg** out);
+int sp_xchg_handle(const sp_xchg* xchg, void* handle_out);
+int sp_xchg_connect(sp_xchg* xchg, const void* handles_of_all_ranks);
+int sp_xchg_set_timeout_ms(sp_xchg* xchg, unsigned milliseconds);
+int sp_xchg_rank(const sp_xchg* xchg);
+int sp_xchg_world(const sp_xchg* xchg);
+void sp_xchg_destroy(sp_xchg* xchg);
+int sp_gicp_align_direct(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                         const sp_factor_params* params, const sp_gn_params* gn, int max_iterations, sp_xchg* xchg,
+                         int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
+                         uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream);
+int sp_gicp_align_status(const void* workspace, int last_k, void* stream);
+
 /* ------------------------------------------------------------------------------------- voxel hash map */
 
 /* VoxelHashMap (algorithms/mapping/voxel_hash_map.hpp:22-1072): submap accumulation keyed by compute_voxel_bit

@@ -122,6 +122,15 @@ SIGNATURES = {
     "sp_gicp_align_fused": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_linearization_pose": (_i, [_vp, _i, _vp, _vp]),
+    "sp_xchg_create": (_i, [_i, _i, C.POINTER(_vp)]),
+    "sp_xchg_handle": (_i, [_vp, _vp]),
+    "sp_xchg_connect": (_i, [_vp, _vp]),
+    "sp_xchg_set_timeout_ms": (_i, [_vp, C.c_uint]),
+    "sp_xchg_rank": (_i, [_vp]),
+    "sp_xchg_world": (_i, [_vp]),
+    "sp_xchg_destroy": (None, [_vp]),
+    "sp_gicp_align_direct": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_gicp_align_status": (_i, [_vp, _i, _vp]),
     "sp_gicp_align_rows": (_vp, [_vp, _i, _vp]),
     "sp_gicp_align_row": (_vp, [_vp, _i, _vp]),
     "sp_comm_unique_id": (_i, [_vp]),

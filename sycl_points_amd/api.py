@@ -676,6 +676,47 @@ class Communicator:
             pass
 
 
+class Exchange:
+    """Direct exchange of the per-iteration row between the ranks of a sharded alignment (sp_xchg_*, csrc/sp_xchg.h): no
+    collective per iteration. `all_gather(bytes) -> list of bytes in rank order` is the caller's own channel, used once."""
+
+    def __init__(self, rank, world, all_gather, timeout_ms=None):
+        L = _lib.lib()
+        h = C.c_void_p()
+        check(L.sp_xchg_create(int(rank), int(world), C.byref(h)))
+        self._h = h
+        self.rank, self.world = int(rank), int(world)
+        mine = (C.c_char * 64)()
+        check(L.sp_xchg_handle(self._h, mine))
+        handles = all_gather(bytes(mine))
+        blob = b"".join(handles)
+        assert len(blob) == 64 * self.world
+        check(L.sp_xchg_connect(self._h, C.c_char_p(blob)))
+        if timeout_ms is not None:
+            check(L.sp_xchg_set_timeout_ms(self._h, int(timeout_ms)))
+
+    @staticmethod
+    def from_process_group(group=None, timeout_ms=None):
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def gather(b):
+            out = [None] * world
+            dist.all_gather_object(out, b, group=group)
+            return out
+
+        return Exchange(rank, world, gather, timeout_ms)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().sp_xchg_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class VoxelHashMap:
     """algorithms/mapping/voxel_hash_map.hpp:22-250 over the sp_vhm_* entry points: submap accumulation in HBM.
     add_point_cloud takes a PointCloudShared in the sensor frame and the sensor pose (4x4, map frame); downsampling
@@ -1247,7 +1288,7 @@ class Registration:
     def align_fused_loop(self, source, prepared_target, initial_guess=None, iterations=None, robust_scale=-1.0,
                          group=None, T_dev=None, delta_dev=None, prepare=True, sort_by_cell=True,
                          write_neighbors=False, per_iteration_launches=False, update_target=False, graph=False,
-                         comm=None, exchange="row"):
+                         comm=None, exchange="row", xchg=None):
         """The same fixed-length Gauss-Newton loop as align_device_loop on the prepared / fused path
         (sp_gicp_iteration_fused): one launch per iteration does NN + linearise + reduce, and, on a single GPU, the
         second (one-workgroup) launch also solves and updates the pose. On one GPU the default is
@@ -1284,6 +1325,16 @@ class Registration:
                    (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1))
         fp = self._factor_params(scale)
         gn = GnParams(p.gn_lambda, p.criteria_rotation, p.criteria_translation)
+        if xchg is not None:
+            # rows exchanged directly between the ranks' buffers (sp_gicp_align_direct): one C call, no collective
+            if getattr(self, "_iters_dev", None) is None or self._iters_dev.device != dev:
+                self._iters_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            check(L.sp_gicp_align_direct(prepared_target._h, self._psrc._h, _ptr(T_dev), C.byref(fp),
+                                         C.byref(gn), iters,
+                                         xchg._h, None, None, _ptr(lin), _ptr(delta_dev), _ptr(self._iters_dev), _ptr(ws),
+                                         ws.numel(), _stream()))
+            self._direct_last_k = iters - 1
+            return T_dev, lin, delta_dev
         if write_neighbors:
             self.neighbors.resize(n, 1, dev)
         ni = _ptr(self.neighbors.indices) if write_neighbors else None
@@ -1372,6 +1423,11 @@ class Registration:
                 check(L.sp_gn_update(_ptr(lin), _ptr(T_dev), p.gn_lambda, p.criteria_rotation, p.criteria_translation,
                                      _ptr(delta_dev), _stream()))
         return T_dev, lin, delta_dev
+
+    def direct_status(self):
+        """sp_gicp_align_status after align_fused_loop(..., xchg=...): raises SpError when a peer's row did not arrive."""
+        ws, _ = self._buffers(torch.device("cuda", torch.cuda.current_device()))
+        check(_lib.lib().sp_gicp_align_status(_ptr(ws), int(self._direct_last_k), _stream()))
 
     @staticmethod
     def T_from_device(T_dev):

@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "sp_common.h"
+#include "sp_xchg.h"
 
 void sp_set_error(const char* msg);
 
@@ -145,3 +146,76 @@ extern "C" int sp_gicp_align_sharded(const sp_gicp_target* target, const sp_gicp
     return sp_gicp_align_finish(source, transT_device, gn, max_iterations - 1, 2, lin_out, delta_out8, iterations_out,
                                 workspace, workspace_bytes, stream);
 }
+
+// ------------------------------------------------------------------ direct exchange (sp_xchg.h)
+extern "C" void sp_xchg_destroy(sp_xchg* x) {
+    if (!x) return;
+    (void)hipDeviceSynchronize();  // no kernel of this process may still be storing into a peer's buffer
+    for (int r = 0; r < x->world && r < kXchgMaxWorld; ++r)
+        if (x->connected && r != x->rank && x->peers_host[r]) (void)hipIpcCloseMemHandle(x->peers_host[r]);
+    if (x->peers_dev) (void)hipFree(x->peers_dev);
+    if (x->local) (void)hipFree(x->local);
+    delete x;
+}
+
+extern "C" int sp_xchg_create(int rank, int world, sp_xchg** out) {
+    if (!out || world < 1 || world > kXchgMaxWorld || rank < 0 || rank >= world) return SP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    sp_xchg* x = new sp_xchg();
+    x->rank = rank;
+    x->world = world;
+    const size_t bytes = (size_t)2 * world * kXchgRow * sizeof(unsigned long long);
+    // uncached: written by other agents (and other processes), polled here — nothing of it may sit in this GPU's L2
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&x->local), bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(reinterpret_cast<void**>(&x->local), bytes);
+    }
+    if (e == hipSuccess) e = hipMemset(x->local, 0, bytes);  // tag 0 is never a sequence number
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x->peers_dev), kXchgMaxWorld * sizeof(void*));
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&x->handle, x->local);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        sp_set_error(hipGetErrorString(e));
+        sp_xchg_destroy(x);
+        return SP_ERR_HIP;
+    }
+    *out = x;
+    return SP_OK;
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) == SP_XCHG_HANDLE_BYTES, "sp_xchg handle is a hipIpcMemHandle_t");
+
+extern "C" int sp_xchg_handle(const sp_xchg* x, void* handle_out) {
+    if (!x || !handle_out) return SP_ERR_INVALID_ARGUMENT;
+    std::memcpy(handle_out, &x->handle, SP_XCHG_HANDLE_BYTES);
+    return SP_OK;
+}
+
+extern "C" int sp_xchg_connect(sp_xchg* x, const void* handles_all) {
+    if (!x || !handles_all || x->connected) return SP_ERR_INVALID_ARGUMENT;
+    const char* h = static_cast<const char*>(handles_all);
+    for (int r = 0; r < x->world; ++r) {
+        if (r == x->rank) { x->peers_host[r] = x->local; continue; }
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, h + (size_t)r * SP_XCHG_HANDLE_BYTES, SP_XCHG_HANDLE_BYTES);
+        const hipError_t e = hipIpcOpenMemHandle(&x->peers_host[r], hd, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            sp_set_error(hipGetErrorString(e));
+            for (int q = 0; q < r; ++q)
+                if (q != x->rank && x->peers_host[q]) { (void)hipIpcCloseMemHandle(x->peers_host[q]); x->peers_host[q] = nullptr; }
+            return SP_ERR_HIP;
+        }
+    }
+    if (hipMemcpy(x->peers_dev, x->peers_host, x->world * sizeof(void*), hipMemcpyHostToDevice) != hipSuccess) return SP_ERR_HIP;
+    x->connected = true;
+    return SP_OK;
+}
+
+extern "C" int sp_xchg_set_timeout_ms(sp_xchg* x, unsigned ms) {
+    if (!x || ms == 0) return SP_ERR_INVALID_ARGUMENT;
+    x->timeout_ms = ms;
+    return SP_OK;
+}
+extern "C" int sp_xchg_rank(const sp_xchg* x) { return x ? x->rank : 0; }
+extern "C" int sp_xchg_world(const sp_xchg* x) { return x ? x->world : 1; }

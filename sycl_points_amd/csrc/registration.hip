@@ -12,6 +12,7 @@
 // are skipped, which leaves every finite result bit-identical.
 #include "grid_device.h"
 #include "radix_sort.h"
+#include "sp_xchg.h"
 
 void sp_set_error(const char* msg);
 
@@ -970,7 +971,7 @@ constexpr int kStateWords = sizeof(AlignState) / 4;
 constexpr int kStateFlagWord = 40;     // word index of AlignState::converged (iterations follows)
 static_assert(offsetof(AlignState, converged) == 4 * kStateFlagWord, "AlignState layout");
 
-enum { ALIGN_TAIL_SOLVE = 0, ALIGN_ROWS = 1, ALIGN_FANIN = 2 };
+enum { ALIGN_TAIL_SOLVE = 0, ALIGN_ROWS = 1, ALIGN_FANIN = 2, ALIGN_DIRECT = 3 };
 
 struct AlignArgs {
     const float* T_init;         // iteration 0
@@ -981,13 +982,15 @@ struct AlignArgs {
     sp_linearized* lin_out;      // system of the last finished iteration (may be null)
     // How iteration k is finished: ALIGN_TAIL_SOLVE the launch's last-arriving workgroup sums its rows and solves (one GPU);
     // ALIGN_FANIN that workgroup writes ONE 128-byte row, the caller all-reduces it over the ranks and align_solve_kernel
-    // finishes; ALIGN_ROWS the caller all-reduces all partial rows (counts travel as floats), then align_solve_kernel.
+    // finishes; ALIGN_ROWS the caller all-reduces all partial rows (counts travel as floats), then align_solve_kernel;
+    // ALIGN_DIRECT that workgroup stores the row into every rank's slot buffer and align_solve_kernel waits for all rows.
     int mode;
     unsigned* searched_log;      // [iteration] -> source points searched for
     int k;                       // index of this iteration in its alignment
     float* fan_row_out;          // this iteration's row (kFanRow floats)
     const float* fan_row_in;     // align_solve_kernel: the same row, all-reduced over the ranks
     unsigned* fan_counter;       // arrival tickets; 0 when a launch starts, reset by the last arriver
+    XchgArgs x;                  // ALIGN_DIRECT: where the row goes instead of a collective (sp_xchg.h)
 };
 // Row of the fan-in: 0..27 the sums, 28 / 29 the inlier count as two floats that stay exact under a float sum over ranks
 // (count = hi * 4096 + lo, as sp_linearized carries it), 30 the searched-point count (a float value), 31 unused.
@@ -1070,7 +1073,7 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
     if (!s_last) return;  // uniform per workgroup
     reduce_rows_1024<true>(partials, gridDim.x, kAcc - 1, red, false);
     const bool log_k = A.searched_log && A.k < kSearchedLog;
-    if (A.mode == ALIGN_FANIN) {
+    if (A.mode == ALIGN_FANIN || A.mode == ALIGN_DIRECT) {
         if (threadIdx.x < kFanRow) {
             const unsigned cnt = __float_as_uint(red[0][kAcc - 1]);
             float v = 0.0f;
@@ -1079,6 +1082,12 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
             else if (threadIdx.x == kAcc) v = (float)(cnt >> 12);
             else if (threadIdx.x == kAcc + 1) v = red[0][kAcc];
             A.fan_row_out[threadIdx.x] = v;
+            if (A.mode == ALIGN_DIRECT) {  // the row, tagged, into slot [k & 1][rank] of every rank's buffer (sp_xchg.h)
+                const unsigned long long granule = ((unsigned long long)A.x.seq << 32) | __float_as_uint(v);
+                const size_t slot = ((size_t)(A.k & 1) * A.x.world + A.x.rank) * kFanRow + threadIdx.x;
+                for (int r = 0; r < A.x.world; ++r)
+                    __hip_atomic_store(A.x.peers[r] + slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         if (threadIdx.x == 0 && log_k) A.searched_log[A.k] = (unsigned)red[0][kAcc];
     } else if (threadIdx.x == 0) {
@@ -1095,8 +1104,8 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     __shared__ float sT[16];
     __shared__ unsigned sflag[2];
     if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag,
-                     A.mode == ALIGN_FANIN ? A.fan_row_out : nullptr))
-        return;
+                     (A.mode == ALIGN_FANIN || A.mode == ALIGN_DIRECT) ? A.fan_row_out : nullptr))
+        return;  // (converged: every rank holds the same state and stops at the same launch — nobody waits for a row)
     // the pose is uniform: move it to scalar registers (it would otherwise occupy 12 VGPRs for the whole loop)
     Rigid T = load_rigid_colmajor(sT);
     auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -1137,7 +1146,50 @@ __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A,
     __shared__ float sdelta[8];
     __shared__ LdltScratch ldlt_ws;
     if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag)) return;
-    if (A.mode == ALIGN_FANIN) {
+    if (A.mode == ALIGN_DIRECT) {
+        // wait for the row of every rank (bounded), then add them in rank order: the same sum on every rank
+        __shared__ float xrow[kXchgMaxWorld][kFanRow];
+        __shared__ unsigned s_late;
+        if (threadIdx.x == 0) s_late = 0u;
+        __syncthreads();
+        if (threadIdx.x < (unsigned)A.x.world * kFanRow) {
+            const unsigned r = threadIdx.x / kFanRow, e = threadIdx.x % kFanRow;
+            const unsigned long long* const g = A.x.local + ((size_t)(A.k & 1) * A.x.world + r) * kFanRow + e;
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long v = 0;
+            bool ok = false;
+            for (;;) {
+                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)(v >> 32) == A.x.seq) { ok = true; break; }
+                if (wall_clock64() - t0 > A.x.budget) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok) s_late = 1u;
+            xrow[r][e] = ok ? __uint_as_float((unsigned)v) : 0.0f;
+        }
+        __syncthreads();
+        if (s_late) {  // a peer's row did not arrive: stop the alignment here and say so (sp_gicp_align_status)
+            if (threadIdx.x < kStateWords) {
+                unsigned w = A.has_prev ? reinterpret_cast<const unsigned*>(A.state_in)[threadIdx.x] : 0u;
+                if (!A.has_prev && threadIdx.x < 16) w = __float_as_uint(A.T_init[threadIdx.x]);
+                if (threadIdx.x == kStateFlagWord) w = 1u;      // converged: the remaining launches return at once
+                if (threadIdx.x == kStateFlagWord + 3) w = 1u;  // pad = error
+                reinterpret_cast<unsigned*>(A.state_out)[threadIdx.x] = w;
+            }
+            return;
+        }
+        if (threadIdx.x < kFanRow) {
+            float sum = 0.0f;
+            for (int r = 0; r < A.x.world; ++r) sum += xrow[r][threadIdx.x];
+            red[1][threadIdx.x] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
+        else if (threadIdx.x == kAcc - 1)  // the count, folded as integers: exact
+            red[0][kAcc - 1] = __uint_as_float((unsigned)red[1][kAcc] * 4096u + (unsigned)red[1][kAcc - 1]);
+        else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points, all ranks (a float value)
+        __syncthreads();
+    } else if (A.mode == ALIGN_FANIN) {
         if (threadIdx.x < kFanRow) red[1][threadIdx.x] = A.fan_row_in[threadIdx.x];
         __syncthreads();
         if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
@@ -1717,12 +1769,19 @@ AlignArgs align_args(const AlignWs& w, float* transT_device, const sp_gn_params*
     A.fan_row_out = w.fan_row[j & 1];
     A.fan_row_in = w.fan_row[j & 1];
     A.fan_counter = w.fan_counter;
+    A.x = XchgArgs{nullptr, nullptr, 0, 1, 0u, 0ull};
     return A;
 }
 // Sharded modes: finish iteration j from the all-reduced row(s) (enqueued behind the caller's collective).
+XchgArgs xchg_args(const sp_xchg* x, int j) {
+    if (!x) return XchgArgs{nullptr, nullptr, 0, 1, 0u, 0ull};
+    return XchgArgs{x->peers_dev, x->local, x->rank, x->world, x->epoch * 256u + (unsigned)j + 1u,
+                    (unsigned long long)x->timeout_ms * 100000ull};  // wall_clock64: 100 MHz
+}
 void launch_solve(const AlignWs& w, float* transT_device, const sp_gn_params* gn, int j, int mode, sp_linearized* lin_out,
-                  hipStream_t st) {
-    const AlignArgs A = align_args(w, transT_device, gn, j, mode, lin_out);
+                  hipStream_t st, const sp_xchg* x = nullptr) {
+    AlignArgs A = align_args(w, transT_device, gn, j, mode, lin_out);
+    A.x = xchg_args(x, j);
     align_solve_kernel<<<1, kFinalThreads, 0, st>>>(A, w.part[j & 1], (unsigned)kAlignMaxBlocks);
 }
 }  // namespace
@@ -1769,15 +1828,17 @@ extern "C" int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gic
     return launch_status();
 }
 
-extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
-                                 const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
-                                 int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-    using namespace sp;
+namespace sp {
+namespace {
+int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                    const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced, int32_t* nn_idx_out,
+                    float* nn_d2_out, sp_linearized* lin_out, void* workspace, size_t workspace_bytes, void* stream,
+                    const sp_xchg* xchg) {
     hipStream_t st = as_stream(stream);
     const int rc = align_check("step", target, source, params, gn, transT_device, workspace, workspace_bytes);
     if (rc != SP_OK) return rc;
-    if (k < 0 || rows_all_reduced < 0 || rows_all_reduced > 2) return SP_ERR_INVALID_ARGUMENT;
+    if (k < 0 || rows_all_reduced < 0 || rows_all_reduced > 3 || ((rows_all_reduced == ALIGN_DIRECT) != (xchg != nullptr)))
+        return SP_ERR_INVALID_ARGUMENT;
     const size_t n = source->n;
     const AlignWs w = align_ws(workspace);
     const int mode = rows_all_reduced;
@@ -1789,7 +1850,8 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
             zero_async(w.part[0], 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != SP_OK)
             return SP_ERR_HIP;
     } else if (mode != ALIGN_TAIL_SOLVE) {
-        launch_solve(w, transT_device, gn, k - 1, mode, lin_out, st);  // the caller has all-reduced iteration k - 1's row(s)
+        // the caller has all-reduced iteration k - 1's row(s) / the peers are storing theirs into this rank's slots
+        launch_solve(w, transT_device, gn, k - 1, mode, lin_out, st, xchg);
     }
     target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
@@ -1797,6 +1859,7 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     const unsigned grid = align_grid(n);
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
     AlignArgs A = align_args(w, transT_device, gn, k, mode, lin_out);
+    A.x = xchg_args(xchg, k);
     float* out = w.part[k & 1];
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_ALIGN(L)                                                                            \
@@ -1817,6 +1880,17 @@ extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_so
     if (fills_cache) source->cache_valid = true;
     return launch_status();
 }
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_gicp_align_step(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                                 const sp_factor_params* params, const sp_gn_params* gn, int k, int rows_all_reduced,
+                                 int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (rows_all_reduced == sp::ALIGN_DIRECT) return SP_ERR_INVALID_ARGUMENT;  // (sp_gicp_align_direct)
+    return sp::align_step_impl(target, source, transT_device, params, gn, k, rows_all_reduced, nn_idx_out, nn_d2_out, lin_out,
+                               workspace, workspace_bytes, stream, nullptr);
+}
 
 extern "C" float* sp_gicp_align_rows(void* workspace, int k, size_t* n_floats_out) {
     if (n_floats_out) *n_floats_out = (size_t)sp::kAlignMaxBlocks * sp::kPartial;
@@ -1829,12 +1903,13 @@ extern "C" float* sp_gicp_align_row(void* workspace, int k, size_t* n_floats_out
     return sp::align_ws(workspace).fan_row[k & 1];
 }
 
-extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn,
-                                   int last_k, int rows_all_reduced, sp_linearized* lin_out, float* delta_out8,
-                                   uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream) {
-    using namespace sp;
+namespace sp {
+namespace {
+int align_finish_impl(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn, int last_k,
+                      int rows_all_reduced, sp_linearized* lin_out, float* delta_out8, uint32_t* iterations_out,
+                      void* workspace, size_t workspace_bytes, void* stream, const sp_xchg* xchg) {
     hipStream_t st = as_stream(stream);
-    if (!source || !transT_device || !gn || last_k < 0 || rows_all_reduced < 0 || rows_all_reduced > 2)
+    if (!source || !transT_device || !gn || last_k < 0 || rows_all_reduced < 0 || rows_all_reduced > 3)
         return SP_ERR_INVALID_ARGUMENT;
     if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(source->n)) {
         sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
@@ -1842,10 +1917,63 @@ extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_
     }
     const AlignWs w = align_ws(workspace);
     if (source->opt_stage_mask & 2) {
-        if (rows_all_reduced != ALIGN_TAIL_SOLVE) launch_solve(w, transT_device, gn, last_k, rows_all_reduced, lin_out, st);
+        if (rows_all_reduced != ALIGN_TAIL_SOLVE) launch_solve(w, transT_device, gn, last_k, rows_all_reduced, lin_out, st, xchg);
         align_publish_kernel<<<1, kWave, 0, st>>>(&w.state[last_k & 1], transT_device, delta_out8, iterations_out);
     }
     return launch_status();
+}
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, const sp_gn_params* gn,
+                                   int last_k, int rows_all_reduced, sp_linearized* lin_out, float* delta_out8,
+                                   uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (rows_all_reduced == sp::ALIGN_DIRECT) return SP_ERR_INVALID_ARGUMENT;
+    return sp::align_finish_impl(source, transT_device, gn, last_k, rows_all_reduced, lin_out, delta_out8, iterations_out,
+                                 workspace, workspace_bytes, stream, nullptr);
+}
+
+// The sharded loop with the rows exchanged DIRECTLY between the ranks' buffers (sp_xchg.h): per iteration the streaming
+// launch (its last-arriving workgroup stores the rank's row into every rank's slot buffer) and the one-workgroup solve launch
+// that waits for all rows — no collective, no host involvement; the latency-bound 128-byte all-reduce of
+// sp_gicp_align_sharded (a library launch of its own between the two kernels) is gone.
+extern "C" int sp_gicp_align_direct(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                                   const sp_factor_params* params, const sp_gn_params* gn, int max_iterations, sp_xchg* xchg,
+                                   int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
+                                   uint32_t* iterations_out, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    if (!xchg || !xchg->connected) {
+        sp_set_error("[sp_gicp_align_direct] the exchange is not connected (sp_xchg_connect)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (max_iterations <= 0 || max_iterations > 255) {
+        sp_set_error("[sp_gicp_align_direct] max_iterations must be in 1..255");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    ++xchg->epoch;  // every rank calls this the same number of times: the tags agree
+    // (a rank whose shard is empty still takes part: its launch writes a zero row)
+    for (int k = 0; k < max_iterations; ++k) {
+        const int rc = align_step_impl(target, source, transT_device, params, gn, k, ALIGN_DIRECT, nn_idx_out, nn_d2_out, lin_out,
+                                       workspace, workspace_bytes, stream, xchg);
+        if (rc != SP_OK) return rc;
+    }
+    return align_finish_impl(source, transT_device, gn, max_iterations - 1, ALIGN_DIRECT, lin_out, delta_out8, iterations_out,
+                             workspace, workspace_bytes, stream, xchg);
+}
+
+extern "C" int sp_gicp_align_status(const void* workspace, int last_k, void* stream) {
+    if (!workspace || last_k < 0) return SP_ERR_INVALID_ARGUMENT;
+    const sp::AlignWs w = sp::align_ws(const_cast<void*>(workspace));
+    unsigned err = 0;
+    hipStream_t st = sp::as_stream(stream);
+    if (hipMemcpyAsync(&err, &w.state[last_k & 1].pad, sizeof err, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return SP_ERR_HIP;
+    if (err) {
+        sp_set_error("[sp_gicp_align_direct] the row of another rank did not arrive within the time limit: the alignment was stopped");
+        return SP_ERR_RUNTIME;
+    }
+    return SP_OK;
 }
 
 extern "C" int sp_gicp_align_linearization_pose(const void* workspace, int last_k, float* transT_lin_out, void* stream) {

@@ -210,3 +210,84 @@ def test_fanin_row_equals_the_256_row_sum_bit_for_bit(tmp_path):
         assert int(ref[-1]) == 12 and int(np.frombuffer(ref[16 + 43:16 + 44].tobytes(), np.uint32)[0]) == n
         for run in r[si][1:]:
             assert np.array_equal(run, ref), f"n = {n}: sharded fan-in differs from the single-GPU loop"
+
+
+def _direct_worker(rank, world, port, n, iters, out_path, absent):
+    """Two processes on the one GPU exchange their rows DIRECTLY (sp_xchg: hipIpc-mapped slot buffers, tagged granules, bounded
+    wait) instead of through a collective; gloo only carries the 64-byte handles once. `absent`: rank 1 connects and then never
+    runs the loop — rank 0's wait must end in an error code, not in a hang."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sycl_points_amd.sharding import shard_range
+
+    sp, S, Tg, _ = _make(n)
+    lo, hi = shard_range(n, rank, world)
+    Sh = sp.PointCloudShared(S.points[lo:hi].contiguous(), covs=S.covs[lo:hi].contiguous())
+    grid = sp.GridKNN.build(Tg.points)
+    prep = sp.PreparedTarget(grid, Tg.covs)
+    p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters)
+    x = sp.Exchange.from_process_group(dist.group.WORLD, timeout_ms=300 if absent else 20000)
+    res = {}
+    if not absent:
+        for rep in range(2):  # twice: the sequence numbers move on, the slots are reused
+            reg = sp.Registration(p)
+            T, lin, _ = reg.align_fused_loop(Sh, prep, iterations=iters, xchg=x)
+            torch.cuda.synchronize()
+            reg.direct_status()
+            res[f"T{rep}"] = T.cpu().numpy()
+            res[f"inl{rep}"] = np.float32(reg._read_lin(lin).inlier)
+            res[f"it{rep}"] = np.float32(int(reg._iters_dev[0]))
+        regc = sp.Registration(sp.RegistrationParams(max_iterations=iters))  # default criteria: every rank stops at the same launch
+        Tc, _, dc = regc.align_fused_loop(Sh, prep, xchg=x)
+        torch.cuda.synchronize()
+        regc.direct_status()
+        res["Tc"] = Tc.cpu().numpy()
+        res["itc"] = np.float32(int(regc._iters_dev[0]))
+        regg = sp.Registration(p)
+        Tg_, _, _ = regg.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD)  # the gloo row exchange
+        torch.cuda.synchronize()
+        res["Tgloo"] = Tg_.cpu().numpy()
+    elif rank == 0:
+        reg = sp.Registration(p)
+        reg.align_fused_loop(Sh, prep, iterations=iters, xchg=x)
+        torch.cuda.synchronize()  # returns: the wait is bounded
+        try:
+            reg.direct_status()
+            res["err"] = np.float32(0)
+        except sp.SpError as e:
+            res["err"] = np.float32(1)
+            assert "did not arrive" in str(e)
+    dist.barrier()
+    np.savez(out_path % rank, **res)
+    del x
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_direct_exchange_two_processes_one_gpu(tmp_path):
+    n, iters, world = 60000, 8, 2
+    out = str(tmp_path / "direct%d.npz")
+    mp.spawn(_direct_worker, args=(world, _free_port(), n, iters, out, False), nprocs=world, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    for key in r0.files:
+        assert np.array_equal(r0[key], r1[key]), key  # every rank holds the identical pose, count and iteration number
+    assert np.array_equal(r0["T0"], r0["T1"])  # a second alignment over the same slots reproduces the first, bit for bit
+    assert np.abs(r0["T0"] - r0["Tgloo"]).max() < 2e-6  # = the collective exchange's pose (the summation order differs)
+    assert int(r0["inl0"]) == n and int(r0["it0"]) == iters
+    assert 1 <= int(r0["itc"]) < iters and np.abs(r0["Tc"] - r0["T0"]).max() < 2e-3
+    sp, S, Tg, T_gt = _make(n)
+    prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
+    reg = sp.Registration(sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters))
+    T_single, _, _ = reg.align_fused_loop(S, prep, iterations=iters)
+    assert np.abs(r0["T0"] - T_single.cpu().numpy()).max() < 2e-6
+
+
+@pytest.mark.timeout(600)
+def test_direct_exchange_missing_peer_is_an_error_not_a_hang(tmp_path):
+    n, iters, world = 60000, 4, 2
+    out = str(tmp_path / "absent%d.npz")
+    mp.spawn(_direct_worker, args=(world, _free_port(), n, iters, out, True), nprocs=world, join=True)
+    assert int(np.load(out % 0)["err"]) == 1
