@@ -64,8 +64,11 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: run the multi-GPU code path (RCCL all-reduce of the 192-byte system every iteration) "
                          "with a world of one rank")
-    ap.add_argument("--exchange", choices=["rccl-row", "torch-row", "torch-rows"], default="rccl-row",
-                    help="sharded runs: what moves the linear system between the ranks every iteration. rccl-row: the 128-byte "
+    ap.add_argument("--exchange", choices=["auto", "direct", "rccl-row", "torch-row", "torch-rows"], default="auto",
+                    help="sharded runs: what moves the linear system between the ranks every iteration. direct: every rank "
+                         "stores its 128-byte row straight into the peers' IPC-mapped slot buffers, no collective launch "
+                         "(sp_gicp_align_direct); auto: direct when it maps and reproduces the ground truth on an eager "
+                         "alignment, else rccl-row, else torch-row. rccl-row: the 128-byte "
                          "fan-in row through the library's own RCCL communicator (sp_gicp_align_sharded, the C ABI path); "
                          "torch-row: the same row through torch.distributed; torch-rows: round 1's 32 KB of partial rows")
     ap.add_argument("--no-graph", action="store_true",
@@ -172,7 +175,21 @@ def main():
     group = dist.group.WORLD if (world > 1 or args.force_sharded) else None
     use_graph = group is not None and not args.no_graph and os.environ.get("SP_BENCH_GRAPH", "1") == "1"
     comm = None
-    if group is not None and args.exchange == "rccl-row" and args.path == "fused":
+    xchg = None
+    if group is not None and args.exchange in ("auto", "direct") and args.path == "fused":
+        try:
+            xchg = sp.Exchange.from_process_group(group)
+        except Exception as e:  # the peers' buffers could not be mapped here
+            if rank == 0:
+                print(f"bench: direct exchange unavailable ({e!r})", file=sys.stderr)
+        if world > 1:  # all ranks or none
+            flag = torch.tensor([1.0 if xchg is not None else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() < 0.5:
+                xchg = None
+        if xchg is None and args.exchange == "direct":
+            raise RuntimeError("--exchange direct: the peers' slot buffers could not be mapped")
+    if group is not None and args.exchange in ("auto", "rccl-row") and args.path == "fused":
         try:
             comm = sp.Communicator.from_process_group(group)
         except Exception as e:  # no RCCL behind the C ABI on this machine: torch.distributed moves the row instead
@@ -183,7 +200,8 @@ def main():
     def align_chunk(iters, first):
         if args.path == "fused":
             reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta, prepare=first,
-                                 sort_by_cell=SORT_MODE, graph=use_graph, comm=comm, exchange=exchange)
+                                 sort_by_cell=SORT_MODE, graph=use_graph and xchg is None, comm=comm, exchange=exchange,
+                                 xchg=xchg)
         else:
             reg.align_device_loop(S, Tg, knn, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta)
 
@@ -210,13 +228,24 @@ def main():
         def exchange_ok():
             T_dev.copy_(T_ident)
             reg.align_fused_loop(S, prep, iterations=ITERS_PER_ALIGN, group=group, T_dev=T_dev, delta_dev=delta, prepare=True,
-                                 sort_by_cell=SORT_MODE, graph=False, comm=comm, exchange=exchange)
+                                 sort_by_cell=SORT_MODE, graph=False, comm=comm, exchange=exchange, xchg=xchg)
             torch.cuda.synchronize()
             err = np.abs(reg.T_from_device(T_dev) - T_gt).max()
+            if xchg is not None:
+                try:
+                    reg.direct_status()
+                except sp.SpError:
+                    err = float("inf")  # a peer's row did not arrive within the bound
             ok = torch.tensor([1.0 if (np.isfinite(err) and err < 1e-3) else 0.0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             return ok.item() > 0.5, float(err)
         good, err = exchange_ok()
+        if not good and xchg is not None:
+            if args.exchange == "direct":
+                raise RuntimeError(f"--exchange direct: pose error {err:.3g} on an eager alignment")
+            exchange_fallback = f"direct exchange gave pose error {err:.3g} on an eager alignment; using the RCCL row"
+            xchg = None
+            good, err = exchange_ok()
         if not good and comm is not None:
             exchange_fallback = f"sp_comm exchange gave pose error {err:.3g} on an eager alignment; using torch.distributed"
             comm = None
@@ -316,11 +345,15 @@ def main():
                                      if args.shard_chunk > 0 else "source in contiguous tiles") +
                                     ", target replicated" if shards > 1 else "none"),
                        "exchange": (None if group is None else
+                                    "128-byte row per iteration stored directly into the peers' IPC-mapped slot buffers "
+                                    "(sp_gicp_align_direct): no collective launch" if xchg is not None else
                                     ("128-byte fan-in row per iteration, " if exchange == "row" else "32 KB of partial rows per iteration, ") +
                                     ("sp_gicp_align_sharded over the library's RCCL communicator" if comm is not None
                                      else "torch.distributed all-reduce")),
                        "exchange_fallback": exchange_fallback,
-                       "launch": ("one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
+                       "launch": ("one C call per alignment: two launches per iteration (linearise; wait for the peers' rows + "
+                                  "solve), nothing from the host in between" if xchg is not None else
+                                  "one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
                                   else ("per-iteration launches + all-reduce from the host" if group is not None
                                         else "one C call per alignment"))},
             "iterations_per_sec": args.steps / elapsed,

@@ -154,6 +154,7 @@ extern "C" void sp_xchg_destroy(sp_xchg* x) {
     for (int r = 0; r < x->world && r < kXchgMaxWorld; ++r)
         if (x->connected && r != x->rank && x->peers_host[r]) (void)hipIpcCloseMemHandle(x->peers_host[r]);
     if (x->peers_dev) (void)hipFree(x->peers_dev);
+    if (x->epoch_dev) (void)hipFree(x->epoch_dev);
     if (x->local) (void)hipFree(x->local);
     delete x;
 }
@@ -173,6 +174,9 @@ extern "C" int sp_xchg_create(int rank, int world, sp_xchg** out) {
     }
     if (e == hipSuccess) e = hipMemset(x->local, 0, bytes);  // tag 0 is never a sequence number
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x->peers_dev), kXchgMaxWorld * sizeof(void*));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x->epoch_dev), sizeof(unsigned));
+    const unsigned one = 1u;
+    if (e == hipSuccess) e = hipMemcpy(x->epoch_dev, &one, sizeof one, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipIpcGetMemHandle(&x->handle, x->local);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {

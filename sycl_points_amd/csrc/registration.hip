@@ -1083,7 +1083,8 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
             else if (threadIdx.x == kAcc + 1) v = red[0][kAcc];
             A.fan_row_out[threadIdx.x] = v;
             if (A.mode == ALIGN_DIRECT) {  // the row, tagged, into slot [k & 1][rank] of every rank's buffer (sp_xchg.h)
-                const unsigned long long granule = ((unsigned long long)A.x.seq << 32) | __float_as_uint(v);
+                const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k + 1u;
+                const unsigned long long granule = ((unsigned long long)seq << 32) | __float_as_uint(v);
                 const size_t slot = ((size_t)(A.k & 1) * A.x.world + A.x.rank) * kFanRow + threadIdx.x;
                 for (int r = 0; r < A.x.world; ++r)
                     __hip_atomic_store(A.x.peers[r] + slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1155,12 +1156,13 @@ __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A,
         if (threadIdx.x < (unsigned)A.x.world * kFanRow) {
             const unsigned r = threadIdx.x / kFanRow, e = threadIdx.x % kFanRow;
             const unsigned long long* const g = A.x.local + ((size_t)(A.k & 1) * A.x.world + r) * kFanRow + e;
+            const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k + 1u;
             const unsigned long long t0 = wall_clock64();
             unsigned long long v = 0;
             bool ok = false;
             for (;;) {
                 v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned)(v >> 32) == A.x.seq) { ok = true; break; }
+                if ((unsigned)(v >> 32) == seq) { ok = true; break; }
                 if (wall_clock64() - t0 > A.x.budget) break;
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -1209,7 +1211,9 @@ __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A,
 
 // After the last iteration: the results out of the state block.
 __global__ void align_publish_kernel(const AlignState* __restrict__ state, float* __restrict__ T_out,
-                                     float* __restrict__ delta_out8, uint32_t* __restrict__ iterations_out) {
+                                     float* __restrict__ delta_out8, uint32_t* __restrict__ iterations_out,
+                                     unsigned* __restrict__ xchg_epoch) {
+    if (threadIdx.x == 32 && xchg_epoch) *xchg_epoch += 1u;  // direct exchange: the next alignment's tags (sp_xchg.h)
     if (threadIdx.x < 16) T_out[threadIdx.x] = state->T[threadIdx.x];
     else if (threadIdx.x < 24 && delta_out8) delta_out8[threadIdx.x - 16] = state->delta[threadIdx.x - 16];
     else if (threadIdx.x == 24 && iterations_out) *iterations_out = state->iterations;
@@ -1769,13 +1773,14 @@ AlignArgs align_args(const AlignWs& w, float* transT_device, const sp_gn_params*
     A.fan_row_out = w.fan_row[j & 1];
     A.fan_row_in = w.fan_row[j & 1];
     A.fan_counter = w.fan_counter;
-    A.x = XchgArgs{nullptr, nullptr, 0, 1, 0u, 0ull};
+    A.x = XchgArgs{nullptr, nullptr, 0, 1, nullptr, 0ull};
     return A;
 }
 // Sharded modes: finish iteration j from the all-reduced row(s) (enqueued behind the caller's collective).
 XchgArgs xchg_args(const sp_xchg* x, int j) {
-    if (!x) return XchgArgs{nullptr, nullptr, 0, 1, 0u, 0ull};
-    return XchgArgs{x->peers_dev, x->local, x->rank, x->world, x->epoch * 256u + (unsigned)j + 1u,
+    if (!x) return XchgArgs{nullptr, nullptr, 0, 1, nullptr, 0ull};
+    (void)j;
+    return XchgArgs{x->peers_dev, x->local, x->rank, x->world, x->epoch_dev,
                     (unsigned long long)x->timeout_ms * 100000ull};  // wall_clock64: 100 MHz
 }
 void launch_solve(const AlignWs& w, float* transT_device, const sp_gn_params* gn, int j, int mode, sp_linearized* lin_out,
@@ -1918,7 +1923,8 @@ int align_finish_impl(const sp_gicp_source* source, float* transT_device, const 
     const AlignWs w = align_ws(workspace);
     if (source->opt_stage_mask & 2) {
         if (rows_all_reduced != ALIGN_TAIL_SOLVE) launch_solve(w, transT_device, gn, last_k, rows_all_reduced, lin_out, st, xchg);
-        align_publish_kernel<<<1, kWave, 0, st>>>(&w.state[last_k & 1], transT_device, delta_out8, iterations_out);
+        align_publish_kernel<<<1, kWave, 0, st>>>(&w.state[last_k & 1], transT_device, delta_out8, iterations_out,
+                                                  xchg ? xchg->epoch_dev : nullptr);
     }
     return launch_status();
 }
@@ -1950,7 +1956,7 @@ extern "C" int sp_gicp_align_direct(const sp_gicp_target* target, const sp_gicp_
         sp_set_error("[sp_gicp_align_direct] max_iterations must be in 1..255");
         return SP_ERR_INVALID_ARGUMENT;
     }
-    ++xchg->epoch;  // every rank calls this the same number of times: the tags agree
+    // (the tags count alignments in a device word that the last launch bumps: every rank must enqueue the same alignments)
     // (a rank whose shard is empty still takes part: its launch writes a zero row)
     for (int k = 0; k < max_iterations; ++k) {
         const int rc = align_step_impl(target, source, transT_device, params, gn, k, ALIGN_DIRECT, nn_idx_out, nn_d2_out, lin_out,

@@ -25,7 +25,9 @@ struct sp_xchg {
     unsigned long long** peers_dev = nullptr;     // device array [world]: every rank's slot buffer as mapped here
     void* peers_host[kXchgMaxWorld] = {};         // the same pointers (for hipIpcCloseMemHandle)
     bool connected = false;
-    unsigned epoch = 0;                           // alignments run so far (the tag's high part)
+    unsigned* epoch_dev = nullptr;                // device word: alignments run so far + 1 (the tag's high part). On the device
+                                                  // so that a captured hipGraph of an alignment stays valid when replayed: the
+                                                  // last launch of every alignment increments it
     unsigned timeout_ms = 2000;
     hipIpcMemHandle_t handle;
 };
@@ -35,6 +37,6 @@ struct XchgArgs {
     unsigned long long* const* peers;  // nullptr: no direct exchange
     unsigned long long* local;
     int rank, world;
-    unsigned seq;                      // tag of this iteration's rows
+    const unsigned* epoch;             // tag of iteration k's rows = *epoch * 256 + k + 1
     unsigned long long budget;         // wall_clock64 ticks (100 MHz) a poll may take
 };
