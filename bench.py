@@ -621,11 +621,15 @@ def stage_block(sp, _lib, torch):
         out[name] = {"ms": ms, "runs": runs, "points_per_s": n / (ms * 1e-3),
                      "bound": f"HBM at {bytes_pt} B per point (API layouts" + (": kNN 176 + K5 464)" if cov else ")"),
                      "GBps": bytes_pt * n / (ms * 1e-3) / 1e9, "frac_of_bound": bytes_pt * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    res = grid.self_knn(20, True, False, False)[0]
-    ms, runs = median_ms(torch, lambda: sp.covariance.estimate(res, P))
-    out["covariance_K5_alone_1M_k20"] = {"ms": ms, "runs": runs, "points_per_s": n / (ms * 1e-3), "bound": "HBM at 464 B per point",
-                                         "GBps": 464 * n / (ms * 1e-3) / 1e9,
-                                         "frac_of_bound": 464 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    for label, cloud in (("", P), ("_cell_ordered", P[sp.GridKNN.build(P, points_per_cell=1.0).order()].contiguous())):
+        g = grid if cloud is P else sp.GridKNN.build(cloud, points_per_cell=6.0)
+        res = g.self_knn(20, True, False, False)[0]
+        ms, runs = median_ms(torch, lambda: sp.covariance.estimate(res, cloud))
+        out["covariance_K5_alone_1M_k20" + label] = {
+            "ms": ms, "runs": runs, "points_per_s": n / (ms * 1e-3), "bound": "HBM at 464 B per point",
+            "cloud_order": "cell order (voxel-downsampled / GridKNN.order())" if label else "as generated (random): every gather misses L2",
+            "GBps": 464 * n / (ms * 1e-3) / 1e9, "frac_of_bound": 464 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del res
     ms, runs = median_ms(torch, lambda: sp.GridKNN.build(P, points_per_cell=0.5), 5)
     out["grid_build_1M"] = {"ms": ms, "runs": runs, "note": "device build of the in-loop NN structure (synchronises once)"}
     return out

@@ -283,6 +283,36 @@ private:
     sp_comm* h_ = nullptr;
 };
 
+/// MI355X extension: RAII handle of the direct exchange (sp_xchg): every rank owns a small slot buffer the
+/// other ranks map through hipIpc and store their per-iteration 128-byte row into — no collective launch per iteration.
+/// Construct on every rank, pass `handle_bytes()` to all ranks through the application's own channel, then `connect()` with
+/// the world's handles concatenated in rank order. A peer's row that does not arrive within `set_timeout_ms` (2 s) ends the
+/// alignment with SP_ERR_RUNTIME instead of hanging.
+class Exchange {
+public:
+    Exchange(int rank, int world) { throw_on_error(sp_xchg_create(rank, world, &h_)); }
+    ~Exchange() { sp_xchg_destroy(h_); }
+    Exchange(const Exchange&) = delete;
+    Exchange& operator=(const Exchange&) = delete;
+    std::vector<unsigned char> handle_bytes() const {
+        std::vector<unsigned char> b(SP_XCHG_HANDLE_BYTES);
+        throw_on_error(sp_xchg_handle(h_, b.data()));
+        return b;
+    }
+    void connect(const std::vector<unsigned char>& all_handles_in_rank_order) {
+        if (all_handles_in_rank_order.size() != size_t(SP_XCHG_HANDLE_BYTES) * size_t(world()))
+            throw std::invalid_argument("[Exchange] connect needs world x SP_XCHG_HANDLE_BYTES bytes");
+        throw_on_error(sp_xchg_connect(h_, all_handles_in_rank_order.data()));
+    }
+    void set_timeout_ms(unsigned ms) { throw_on_error(sp_xchg_set_timeout_ms(h_, ms)); }
+    sp_xchg* handle() const { return h_; }
+    int rank() const { return sp_xchg_rank(h_); }
+    int world() const { return sp_xchg_world(h_); }
+
+private:
+    sp_xchg* h_ = nullptr;
+};
+
 /// The reference's `sycl::event`: here the stream the work was enqueued on (all work of a cloud shares one in-order
 /// stream, so "depends on these events" is already implied by enqueue order; the type exists for source compatibility).
 struct event {

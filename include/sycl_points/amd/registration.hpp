@@ -247,7 +247,7 @@ public:
         if (fused && params_.optimization_method == OptimizationMethod::GAUSS_NEWTON && !params_.verbose &&
             params_.max_iterations > 0 && !pose_terms)
             return align_on_device(source.size(), initial_guess, robust_scale);
-        if (comm_ != nullptr)
+        if (comm_ != nullptr || xchg_ != nullptr)
             throw std::runtime_error("[Registration::align] a communicator is set: only the device-resident Gauss-Newton loop "
                                      "(GICP / POINT_TO_DISTRIBUTION on a GridKNN, no host-side pose terms) is sharded");
 
@@ -279,6 +279,10 @@ public:
     /// Gauss-Newton, no host-side pose terms); every other configuration throws, since a rank-local result would silently
     /// differ between ranks. nullptr (default): single GPU.
     void set_communicator(sp_comm* comm) { comm_ = comm; }
+    /// The same sharded alignment with the rows exchanged directly between the ranks' slot buffers (Exchange, sp_xchg):
+    /// sp_gicp_align_direct, no collective launch per iteration. Takes precedence over a communicator. A peer that does
+    /// not deliver within the exchange's timeout makes align() throw (SP_ERR_RUNTIME) on every waiting rank.
+    void set_exchange(sp_xchg* xchg) { xchg_ = xchg; }
 
     /// MI355X extension: when align() is given a KDTree (no nodes removed) and the factor is GICP, search on a GridKNN
     /// built from the target instead (default on; results agree to rounding with the KD-tree path).
@@ -456,7 +460,10 @@ private:
         float* delta_dev = T_dev_ + 16;
         uint32_t* iters_dev = reinterpret_cast<uint32_t*>(T_dev_ + 24);
         hip_check(hipMemcpyAsync(T_dev_, initial_guess.data(), 16 * sizeof(float), hipMemcpyHostToDevice, queue_.stream()), "H2D");
-        if (comm_ != nullptr)  // source sharded over the ranks: one 128-byte all-reduce per iteration
+        if (xchg_ != nullptr)  // source sharded over the ranks: rows stored into the peers' slot buffers
+            throw_on_error(sp_gicp_align_direct(ptgt_, psrc_, T_dev_, &fp, &gn, (int)params_.max_iterations, xchg_, nullptr,
+                                                nullptr, lin_dev_, delta_dev, iters_dev, ws_, ws_bytes_, queue_.stream()));
+        else if (comm_ != nullptr)  // one 128-byte all-reduce per iteration
             throw_on_error(sp_gicp_align_sharded(ptgt_, psrc_, T_dev_, &fp, &gn, (int)params_.max_iterations, comm_, nullptr,
                                                  nullptr, lin_dev_, delta_dev, iters_dev, ws_, ws_bytes_, queue_.stream()));
         else
@@ -469,6 +476,8 @@ private:
         // the pose the correspondence cache is frozen at (compute_error_frozen after align(), registration.hpp:350-359)
         throw_on_error(sp_gicp_align_linearization_pose(ws_, (int)params_.max_iterations - 1, host + 28, queue_.stream()));
         const sp_linearized h = read_lin();  // synchronises the stream
+        if (xchg_ != nullptr)  // a row that did not arrive: the loop stopped, the pose is not the alignment's
+            throw_on_error(sp_gicp_align_status(ws_, (int)params_.max_iterations - 1, queue_.stream()));
         const LinearizedResult lin = to_result(h);
         RegistrationResult result;
         TransformMatrix T;
@@ -623,6 +632,7 @@ private:
     uint64_t ptgt_grid_id_ = 0;  // GridKNN::id() the prepared target was built on
     bool source_presorted_ = false;
     sp_comm* comm_ = nullptr;  // borrowed (set_communicator)
+    sp_xchg* xchg_ = nullptr;  // borrowed (set_exchange)
     bool accelerate_kdtree_ = true;
     mutable bool fused_loop_active_ = false;  // align() is running its optimiser loop on the prepared path
     mutable bool last_lin_fused_ = false;     // the last linearisation left its correspondences in the prepared source's cache

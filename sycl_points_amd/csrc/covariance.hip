@@ -75,14 +75,46 @@ __device__ __forceinline__ float4 normal_of(const Mat3& C, const float4 p) {
     return make_float4(-nx, -ny, -nz, 0.0f);
 }
 
-__global__ __launch_bounds__(kBlock) void cov_kernel(const float4* __restrict__ pts, unsigned n,
-                                                     const int32_t* __restrict__ knn, int k,
-                                                     float4* __restrict__ covs) {
+__global__ __launch_bounds__(kBlock) void cov_direct_kernel(const float4* __restrict__ pts, unsigned n,
+                                                            const int32_t* __restrict__ knn, int k,
+                                                            float4* __restrict__ covs) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Mat3 C;
     estimate_cov(pts, knn + (size_t)i * k, k, C);
     store_cov(covs + 4 * (size_t)i, C);
+}
+// K5 with the two streamed arrays moved in whole lines: a workgroup's 256 index lists are one contiguous k KB block, copied
+// into LDS with 16-byte loads (a lane reading its own list from global memory strides k*4 bytes: every one of its k loads
+// touches 40 lines per wave); the 256 covariances (64 B each) go back through the same LDS region and leave as 16 KB of
+// consecutive 16-byte stores. What remains scattered is what the algorithm scatters: the k gathered points per lane.
+// Same arithmetic, same order as cov_direct_kernel. `knn` 16-byte aligned, LDS = max(k, 16) KB.
+__global__ __launch_bounds__(kBlock) void cov_kernel(const float4* __restrict__ pts, unsigned n,
+                                                     const int32_t* __restrict__ knn, int k,
+                                                     float4* __restrict__ covs) {
+    extern __shared__ int4 s_stage[];
+    int32_t* s_idx = reinterpret_cast<int32_t*>(s_stage);
+    const unsigned t = threadIdx.x;
+    const unsigned base = blockIdx.x * kBlock;
+    const unsigned cnt = min((unsigned)kBlock, n - base);
+    const unsigned total = cnt * (unsigned)k;
+    const int32_t* g = knn + (size_t)base * k;  // (base * k * 4 bytes: a multiple of 1 KB)
+    const int4* g4 = reinterpret_cast<const int4*>(g);
+    for (unsigned e = t; e < total / 4; e += kBlock) s_stage[e] = g4[e];
+    for (unsigned e = (total & ~3u) + t; e < total; e += kBlock) s_idx[e] = g[e];
+    __syncthreads();
+    Mat3 C;
+    if (t < cnt) estimate_cov(pts, s_idx + t * k, k, C);
+    __syncthreads();  // every list has been read: the region now carries the covariances
+    float4* s_cov = reinterpret_cast<float4*>(s_stage);
+    if (t < cnt) store_cov(s_cov + 4 * t, C);
+    __syncthreads();
+    float4* out = covs + 4 * (size_t)base;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned e = t + r * kBlock;
+        if (e < 4 * cnt) out[e] = s_cov[e];
+    }
 }
 __global__ __launch_bounds__(kBlock) void normal_knn_kernel(const float4* __restrict__ pts, unsigned n,
                                                             const int32_t* __restrict__ knn, int k,
@@ -217,8 +249,14 @@ extern "C" int sp_cov_estimate(const float* points, size_t n, const int32_t* knn
                                void* stream) {
     using namespace sp;
     if (n == 0) return SP_OK;
-    cov_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(points), (unsigned)n,
-                                                                    knn_idx, (int)k, reinterpret_cast<float4*>(covs_out));
+    const float4* p = reinterpret_cast<const float4*>(points);
+    float4* c = reinterpret_cast<float4*>(covs_out);
+    if (k >= 1 && k <= 64 && (reinterpret_cast<uintptr_t>(knn_idx) & 15) == 0) {
+        const size_t lds = (size_t)kBlock * 4 * (k < 16 ? 16 : k);
+        cov_kernel<<<div_up(n, kBlock), kBlock, lds, as_stream(stream)>>>(p, (unsigned)n, knn_idx, (int)k, c);
+    } else {
+        cov_direct_kernel<<<div_up(n, kBlock), kBlock, 0, as_stream(stream)>>>(p, (unsigned)n, knn_idx, (int)k, c);
+    }
     return launch_status();
 }
 extern "C" int sp_normals_from_knn(const float* points, size_t n, const int32_t* knn_idx, size_t k, float* normals_out,

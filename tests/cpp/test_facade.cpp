@@ -652,6 +652,20 @@ static void sharded_align_one_rank() {
     for (int i = 0; i < 16; ++i) same = same && a.T.matrix().data()[i] == b.T.matrix().data()[i];
     CHECK(same);
     CHECK(max_abs_diff(a.T.matrix(), Tgt) < 2e-3f);
+    {   // the direct exchange with a world of one rank: the same loop, rows through the (own) slot buffer
+        sycl_utils::Exchange x(0, 1);
+        x.connect(x.handle_bytes());
+        CHECK(x.rank() == 0 && x.world() == 1);
+        alg::registration::Registration direct(*Q, params);
+        direct.set_exchange(x.handle());
+        const auto c = direct.align(source, target, *tgrid);
+        CHECK(c.converged && c.iterations == a.iterations && c.inlier == a.inlier);
+        CHECK(max_abs_diff(a.T.matrix(), c.T.matrix().data()) < 2e-6f);
+        const auto c2 = direct.align(source, target, *tgrid);  // a second alignment: the tags advance
+        bool same2 = true;
+        for (int i = 0; i < 16; ++i) same2 = same2 && c.T.matrix().data()[i] == c2.T.matrix().data()[i];
+        CHECK(same2);
+    }
     // a configuration that would leave the ranks with different results is refused, not run rank-locally
     params.optimization_method = alg::registration::OptimizationMethod::LEVENBERG_MARQUARDT;
     alg::registration::Registration lm(*Q, params);
