@@ -7,9 +7,12 @@
 // the reference's tie rule (strict '<': the lowest target index wins) exactly.
 // The bound is fp32 VALU, not HBM: 9 VALU ops per (query, target) pair, HBM traffic is O(nq + nt).
 // k = 1 has its own packed-fp32 kernel (3.5 instructions per pair); k > 1 on >= 16 tiles of targets runs it as pass A of a
-// bound-then-collect scheme (8.5 -> 4.0 ms at 100k x 100k, k = 20; see knn_bf_bounded_kernel).
+// bound-then-collect scheme: chunk minima -> a bound per query -> only the (query, chunk) pairs that can hold a neighbour
+// are scanned again (a fifth of them at k = 20), every target within the bound becomes a candidate, a wave sorts each
+// query's candidates (8.5 ms single pass -> 3.6 ms bounded lists in round 2 -> see knn_bf_collect_kernel).
 #include "sp_common.h"
 #include "sp_math.h"
+#include "sp_wave_select.h"
 
 namespace sp {
 namespace {
@@ -228,56 +231,143 @@ __global__ __launch_bounds__(kBlock) void knn_bf_merge_kernel(const int32_t* __r
 // ---- k > 1 on large problems: bound first, then collect ------------------------------------------------------------
 // The sorted insertion costs ~5 instructions per list slot and, in a stream of n targets, a query inserts about
 // k ln(n / k) times (170 at k = 20, n = 100 k): with 64 lanes x 2 queries per wave almost a quarter of the targets send the
-// wave through the insertion code. So the scan is done twice, both times at packed-fp32 rate:
-//   pass A  the k = 1 kernel over G >= k chunks of the targets: G chunk minima per query. Their k-th smallest, tau, is the
-//           distance of a real target and at least k targets are within it (one per chunk), so the k-th neighbour is too.
-//   pass B  distances again, two queries per lane (one packed pair); four targets are folded with v_pk_min and tested
-//           against the bound once: only a group holding a target with d <= tau (about k + G/k of the n) enters the
-//           exact per-target compare and the sorted insertion. Same strict '<' in ascending target order, same chunk-order
-//           merge: lists are bit-identical to the single-pass kernel's.
+// wave through the insertion code. So nothing is inserted while scanning:
+//   pass A   the k = 1 kernel over G >= k chunks of the targets: G chunk minima per query. Their k-th smallest, tau, is the
+//            distance of a real target and at least k targets are within it (one per chunk), so the k-th neighbour is too.
+//   lists    a query needs chunk c again only if that chunk's minimum is within tau — k of the G chunks unless minima tie
+//            (20 of 98 at 100 k targets). Every chunk gets the list of the queries that need it (one atomic per wave and
+//            chunk reserves the wave's slots; the order inside a list does not reach the results).
+//   pass B   one workgroup per (chunk, 512 queries of its list): distances again at packed-fp32 rate, four targets folded
+//            with v_pk_min and tested against the bound once; a target within the bound is appended to its query's
+//            candidate array as the 64-bit key (distance bits : index). About k + G/k candidates per query.
+//   select   one wave per query sorts the candidates (64-lane bitonic network) and writes the first k: ordered by
+//            (distance, index) — the reference's strict '<' in ascending target order. A query with more than kCandCap
+//            candidates (many targets at the same distance, or fewer than k finite chunk minima) is rescanned over all
+//            targets by its wave with the sorted-insertion form. Lists are bit-identical to the single-pass kernel's.
+constexpr int kCandCap = 64;
+
+constexpr int kMaxChunks = 256;     // G: the targets are cut into at most this many chunks of whole LDS tiles
+constexpr int kMaxNeeded = 32;      // chunks one query may be listed for; beyond that (tied minima) its wave rescans everything
+
+// tau per query, and wave_cnt[c][wave] = how many of the wave's 64 queries need chunk c. (No atomics: a counter per chunk,
+// bumped by every wave, put 150 k atomics on four cache lines — 1.3 ms at 100 k queries; counts + scans are 20 us.)
 __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __restrict__ chunk_min, unsigned nq, int k,
-                                                              unsigned nchunks, float* __restrict__ bound) {
+                                                              unsigned nchunks, float* __restrict__ bound,
+                                                              unsigned* __restrict__ wave_cnt, unsigned nwaves,
+                                                              unsigned* __restrict__ cand_cnt) {
     const unsigned q = blockIdx.x * kBlock + threadIdx.x;
-    if (q >= nq) return;
+    const bool live = q < nq;
+    const unsigned qc = live ? q : nq - 1;
     float bd[20];
     int bi[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
     float kth = FLT_MAX;
     for (unsigned c = 0; c < nchunks; ++c) {
-        const float d = chunk_min[(size_t)c * nq + q];
+        const float d = chunk_min[(size_t)c * nq + qc];
         if (d < kth) topk_insert<20>(bd, bi, k, d, 0, kth);
     }
     // `d < bound` must admit d == tau; a query without k finite chunk minima (NaN / overflowing coordinates) is not bounded
-    bound[q] = kth < FLT_MAX ? fminf(nextafterf(kth, FLT_MAX), FLT_MAX) : FLT_MAX;
+    float b = kth < FLT_MAX ? fminf(nextafterf(kth, FLT_MAX), FLT_MAX) : FLT_MAX;
+    unsigned needed = 0;
+    for (unsigned c = 0; c < nchunks; ++c) needed += chunk_min[(size_t)c * nq + qc] < b ? 1u : 0u;
+    if (needed > (unsigned)kMaxNeeded) b = -1.0f;  // listed nowhere: the select kernel scans all targets for it
+    if (live) {
+        bound[q] = b;
+        cand_cnt[q] = needed > (unsigned)kMaxNeeded ? (unsigned)kCandCap + 1u : 0u;
+    }
+    const unsigned wave = q >> 6, lane = threadIdx.x & 63;
+    for (unsigned c = 0; c < nchunks; ++c) {
+        const unsigned long long m = __ballot(live && chunk_min[(size_t)c * nq + qc] < b);
+        if (lane == 0 && wave < nwaves) wave_cnt[(size_t)c * nwaves + wave] = (unsigned)__builtin_popcountll(m);  // (the last workgroup may hold an idle wave)
+    }
+}
+// One workgroup per chunk: wave_cnt[c][.] becomes its exclusive scan, chunk_cnt[c] the total.
+__global__ __launch_bounds__(kBlock) void knn_bf_wave_offsets_kernel(unsigned* __restrict__ wave_cnt, unsigned nwaves,
+                                                                     unsigned* __restrict__ chunk_cnt) {
+    __shared__ unsigned s[kBlock];
+    unsigned* row = wave_cnt + (size_t)blockIdx.x * nwaves;
+    const unsigned t = threadIdx.x;
+    unsigned carry = 0;
+    for (unsigned base = 0; base < nwaves; base += kBlock) {
+        const unsigned v = base + t < nwaves ? row[base + t] : 0u;
+        s[t] = v;
+        __syncthreads();
+        for (unsigned d = 1; d < (unsigned)kBlock; d <<= 1) {
+            const unsigned o = t >= d ? s[t - d] : 0u;
+            __syncthreads();
+            s[t] += o;
+            __syncthreads();
+        }
+        if (base + t < nwaves) row[base + t] = carry + s[t] - v;
+        carry += s[kBlock - 1];
+        __syncthreads();
+    }
+    if (t == 0) chunk_cnt[blockIdx.x] = carry;
+}
+// chunk_off = exclusive scan of chunk_cnt (<= 256 values)
+__global__ __launch_bounds__(kMaxChunks) void knn_bf_offsets_kernel(const unsigned* __restrict__ chunk_cnt, unsigned nchunks,
+                                                                    unsigned* __restrict__ chunk_off) {
+    __shared__ unsigned s[kMaxChunks];
+    const unsigned t = threadIdx.x;
+    s[t] = t < nchunks ? chunk_cnt[t] : 0u;
+    __syncthreads();
+    for (unsigned d = 1; d < (unsigned)kMaxChunks; d <<= 1) {
+        const unsigned v = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    if (t < nchunks) chunk_off[t] = s[t] - chunk_cnt[t];
+}
+// The lists themselves: chunk c's queries, ascending, at chunk_list[chunk_off[c] ...].
+__global__ __launch_bounds__(kBlock) void knn_bf_lists_kernel(const float* __restrict__ chunk_min, unsigned nq, unsigned nchunks,
+                                                              const float* __restrict__ bound,
+                                                              const unsigned* __restrict__ chunk_off,
+                                                              const unsigned* __restrict__ wave_off, unsigned nwaves,
+                                                              unsigned* __restrict__ chunk_list) {
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = q < nq;
+    const unsigned qc = live ? q : nq - 1;
+    const float b = bound[qc];
+    const unsigned wave = q >> 6, lane = threadIdx.x & 63;
+    for (unsigned c = 0; c < nchunks; ++c) {
+        const bool need = live && chunk_min[(size_t)c * nq + qc] < b;
+        const unsigned long long m = __ballot(need);
+        if (need)
+            chunk_list[chunk_off[c] + wave_off[(size_t)c * nwaves + wave] +
+                       (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = q;
+    }
 }
 
 constexpr int kGroup = 4;  // targets folded per bound test (kTile % kGroup == 0)
 
-template <int KCAP>
-__global__ __launch_bounds__(kBlock) void knn_bf_bounded_kernel(const float4* __restrict__ queries, unsigned nq,
-                                                                const float4* __restrict__ targets, unsigned nt, int k,
+__global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                                const float4* __restrict__ targets, unsigned nt,
                                                                 unsigned chunk, const float* __restrict__ bound,
-                                                                int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+                                                                const unsigned* __restrict__ chunk_cnt,
+                                                                const unsigned* __restrict__ chunk_off,
+                                                                const unsigned* __restrict__ chunk_list,
+                                                                unsigned* __restrict__ cand_cnt,
+                                                                unsigned long long* __restrict__ cand) {
     __shared__ float4 tile[kTile];
-    const unsigned split = blockIdx.y;
-    const unsigned t_begin = split * chunk;
+    const unsigned c = blockIdx.y;
+    const unsigned listed = chunk_cnt[c];
+    const unsigned first = blockIdx.x * 2 * kBlock;
+    if (first >= listed) return;  // (workgroup-uniform)
+    const unsigned* const list = chunk_list + chunk_off[c];
+    const unsigned t_begin = c * chunk;
     const unsigned t_end = min(nt, t_begin + chunk);
     unsigned qid[2];
     v2f qx, qy, qz;
-    float cap[2], kth[2];
-    float bd[2][KCAP];
-    int bi[2][KCAP];
+    float cap[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        qid[u] = (blockIdx.x * 2 + u) * kBlock + threadIdx.x;
-        const unsigned qc = min(qid[u], nq - 1);
-        const float4 q = queries[qc];
+        const unsigned slot = first + u * kBlock + threadIdx.x;
+        qid[u] = list[min(slot, listed - 1)];
+        const float4 q = queries[qid[u]];
         qx[u] = q.x; qy[u] = q.y; qz[u] = q.z;
-        cap[u] = bound[qc];
-        kth[u] = cap[u];
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) { bd[u][i] = FLT_MAX; bi[u][i] = -1; }
+        cap[u] = slot < listed ? bound[qid[u]] : -1.0f;  // (no distance is below -1: an idle slot collects nothing)
     }
     for (unsigned base = t_begin; base < t_end; base += kTile) {
         const unsigned cnt = min((unsigned)kTile, t_end - base);
@@ -298,30 +388,64 @@ __global__ __launch_bounds__(kBlock) void knn_bf_bounded_kernel(const float4* __
             }
             const v2f m = __builtin_elementwise_min(__builtin_elementwise_min(d[0], d[1]),
                                                     __builtin_elementwise_min(d[2], d[3]));
-            if (m[0] < kth[0] || m[1] < kth[1]) {
+            if (m[0] < cap[0] || m[1] < cap[1]) {
 #pragma unroll
                 for (int t = 0; t < kGroup; ++t) {
                     const unsigned j = g * kGroup + t;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        if (j < cnt && d[t][u] < kth[u]) {
-                            float list_kth;
-                            topk_insert<KCAP>(bd[u], bi[u], k, d[t][u], (int)(base + j), list_kth);
-                            kth[u] = fminf(list_kth, cap[u]);
+                        if (j < cnt && d[t][u] < cap[u]) {
+                            const unsigned s = atomicAdd(&cand_cnt[qid[u]], 1u);
+                            if (s < (unsigned)kCandCap) cand[(size_t)qid[u] * kCandCap + s] = cand_key(d[t][u], (int)(base + j));
                         }
                     }
                 }
             }
         }
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (qid[u] < nq) {
-            const size_t o = ((size_t)split * nq + qid[u]) * (size_t)k;
-#pragma unroll
-            for (int i = 0; i < KCAP; ++i)
-                if (i < k) { d2_out[o + i] = bd[u][i]; idx_out[o + i] = bi[u][i]; }
+}
+
+// One wave per query: sort its candidates, or (overflow) scan every target with the sorted top-k across the lanes.
+__global__ __launch_bounds__(kBlock) void knn_bf_select_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                               const float4* __restrict__ targets, unsigned nt, int k,
+                                                               const unsigned* __restrict__ cand_cnt,
+                                                               const unsigned long long* __restrict__ cand,
+                                                               int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    const unsigned q = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (q >= nq) return;  // (wave-uniform)
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned cnt = cand_cnt[q];
+    Cand best;
+    best.pos = 0;
+    if (cnt <= (unsigned)kCandCap) {
+        Cand c;
+        c.key = lane < cnt ? cand[(size_t)q * kCandCap + lane] : kNoCand;
+        c.pos = 0;
+        best = bitonic_sort64(c, lane);
+    } else {
+        const float4 qq = queries[q];
+        const unsigned long long kmask = (1ull << k) - 1ull;  // k <= 20
+        best.key = kNoCand;
+        unsigned long long kth = kNoCand;
+        for (unsigned base = 0; base < nt; base += 64) {
+            const unsigned j = base + lane;
+            const float4 p = targets[min(j, nt - 1)];
+            Cand c;
+            c.key = j < nt ? cand_key(dist2(qq.x, qq.y, qq.z, p.x, p.y, p.z), (int)j) : kNoCand;
+            c.pos = 0;
+            if (base == 0) {
+                best = bitonic_sort64(c, lane);
+                kth = bcast_k(best.key, k - 1);
+            } else {
+                insert_candidates(c, best, kth, k, kmask, lane);
+            }
         }
+    }
+    if (lane < (unsigned)k) {
+        // an empty slot, or a distance that `d < FLT_MAX` would not have admitted (inf / NaN bit patterns order above it)
+        const bool none = best.key >= kNoCand;
+        idx_out[(size_t)q * k + lane] = none ? -1 : key_idx(best.key);
+        d2_out[(size_t)q * k + lane] = none ? FLT_MAX : key_d2(best.key);
     }
 }
 
@@ -386,7 +510,7 @@ int run_k1(const float* q, size_t nq, const float* t, size_t nt, int32_t* idx, f
 struct BoundedPlan {
     bool use;
     BfPlan a, b;                                       // pass A = the k = 1 kernel over G chunks; pass B = two queries per lane
-    size_t off_min, off_bound, off_lists, bytes;  // workspace layout
+    size_t off_min, off_bound, off_counts, off_chunk_list, off_cand, bytes;  // workspace layout
 };
 
 BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
@@ -394,45 +518,47 @@ BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
     if (k < 2 || nt < (size_t)16 * kTile) return P;
     P.a.qpt = kQ1;
     P.a.qblocks = div_up(nq, (size_t)kBlock * kQ1);
-    P.a.chunk = div_up(div_up(nt, (size_t)64), kTile) * kTile;
+    P.a.chunk = div_up(div_up(nt, (size_t)kMaxChunks), kTile) * kTile;  // 1024 targets per chunk up to 256 K targets
     P.a.nsplit = div_up(nt, P.a.chunk);
     if (P.a.nsplit < k) return P;
     P.b.qpt = 2;
-    P.b.qblocks = div_up(nq, (size_t)kBlock * 2);
-    unsigned want = div_up((size_t)kNumCU * 4, P.b.qblocks);
-    const unsigned max_split = div_up(nt, kTile);
-    if (want < 1) want = 1;
-    if (want > max_split) want = max_split;
-    P.b.chunk = div_up(div_up(nt, want), kTile) * kTile;
-    P.b.nsplit = div_up(nt, P.b.chunk);
+    P.b.qblocks = div_up(nq, (size_t)kBlock * 2);  // (upper bound: workgroups beyond a chunk's list return at once)
+    P.b.chunk = P.a.chunk;
+    P.b.nsplit = P.a.nsplit;
     P.use = true;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     P.off_min = 0;
-    P.off_bound = P.off_min + (size_t)P.a.nsplit * nq * 4;
-    P.off_lists = (P.off_bound + nq * 4 + 15) & ~(size_t)15;
-    P.bytes = P.off_lists + (P.b.nsplit > 1 ? (size_t)P.b.nsplit * nq * k * 8 : 0);
+    P.off_bound = up(P.off_min + (size_t)P.a.nsplit * nq * 4);
+    // chunk list lengths | offsets (kMaxChunks each) | candidates per query | per-wave counts, chunk-major
+    P.off_counts = up(P.off_bound + nq * 4);
+    P.off_chunk_list = up(P.off_counts + (2 * (size_t)kMaxChunks + nq + (size_t)P.a.nsplit * div_up(nq, (size_t)64)) * 4);
+    P.off_cand = up(P.off_chunk_list + nq * (size_t)kMaxNeeded * 4);
+    P.bytes = P.off_cand + nq * (size_t)kCandCap * 8;
     return P;
 }
 
-template <int KCAP>
 int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, int32_t* idx, float* d2, void* ws,
                 const BoundedPlan& P, hipStream_t st) {
     char* w = static_cast<char*>(ws);
     float* amin = reinterpret_cast<float*>(w + P.off_min);
     float* bound = reinterpret_cast<float*>(w + P.off_bound);
+    unsigned* chunk_cnt = reinterpret_cast<unsigned*>(w + P.off_counts);
+    unsigned* chunk_off = chunk_cnt + kMaxChunks;
+    unsigned* cand_cnt = chunk_cnt + 2 * kMaxChunks;
+    unsigned* wave_cnt = cand_cnt + nq;
+    unsigned* chunk_list = reinterpret_cast<unsigned*>(w + P.off_chunk_list);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(w + P.off_cand);
     const float4* q4 = reinterpret_cast<const float4*>(q);
     const float4* t4 = reinterpret_cast<const float4*>(t);
-    knn_bf_k1_kernel<true><<<dim3(P.a.qblocks, P.a.nsplit), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, nullptr, amin);
-    knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, P.a.nsplit, bound);
-    int32_t* pidx = idx;
-    float* pd2 = d2;
-    if (P.b.nsplit > 1) {
-        pidx = reinterpret_cast<int32_t*>(w + P.off_lists);
-        pd2 = reinterpret_cast<float*>(pidx + (size_t)P.b.nsplit * nq * k);
-    }
-    knn_bf_bounded_kernel<KCAP><<<dim3(P.b.qblocks, P.b.nsplit), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, (int)k,
-                                                                                  P.b.chunk, bound, pidx, pd2);
-    if (P.b.nsplit > 1)
-        knn_bf_merge_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(pidx, pd2, (unsigned)nq, (int)k, P.b.nsplit, idx, d2);
+    const unsigned G = P.a.nsplit, nwaves = div_up(nq, (size_t)64);
+    knn_bf_k1_kernel<true><<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, nullptr, amin);
+    knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, G, bound, wave_cnt, nwaves, cand_cnt);
+    knn_bf_wave_offsets_kernel<<<G, kBlock, 0, st>>>(wave_cnt, nwaves, chunk_cnt);
+    knn_bf_offsets_kernel<<<1, kMaxChunks, 0, st>>>(chunk_cnt, G, chunk_off);
+    knn_bf_lists_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, G, bound, chunk_off, wave_cnt, nwaves, chunk_list);
+    knn_bf_collect_kernel<<<dim3(P.b.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.b.chunk, bound,
+                                                                   chunk_cnt, chunk_off, chunk_list, cand_cnt, cand);
+    knn_bf_select_kernel<<<div_up(nq * 64, kBlock), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, (int)k, cand_cnt, cand, idx, d2);
     return launch_status();
 }
 
@@ -478,9 +604,7 @@ extern "C" int sp_knn_bruteforce(const float* queries, size_t nq, const float* t
             sp_set_error("[knn_search_bruteforce] workspace too small (sp_knn_bruteforce_workspace_bytes)");
             return SP_ERR_INVALID_ARGUMENT;
         }
-        if (k <= 5) return run_bounded<5>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, bp, st);
-        if (k <= 10) return run_bounded<10>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, bp, st);
-        return run_bounded<20>(queries, nq, targets, nt, k, idx_out, d2_out, workspace, bp, st);
+        return run_bounded(queries, nq, targets, nt, k, idx_out, d2_out, workspace, bp, st);
     }
     const BfPlan p = plan(nq, nt, k);
     if (p.nsplit > 1 && (workspace == nullptr || workspace_bytes < (size_t)p.nsplit * nq * k * 8)) {

@@ -107,6 +107,31 @@ def test_bruteforce_two_pass_path_matches_oracle_bitwise(sp, orc, k):
     assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("k", [2, 20])
+def test_bruteforce_two_pass_overflow_paths(sp, orc, k):
+    # the collect path keeps at most 64 candidates per query and lists a query for at most 32 chunks; beyond either, the
+    # query's wave rescans all targets. One point repeated 600 times all over the target array (ties in > 32 chunks), another
+    # 150 times inside two chunks (> 64 candidates from few chunks), queries on and near both, and targets with inf / NaN.
+    g = orc.rng(77)
+    tgt = g.uniform_points(40000, 10.0)
+    a, b = np.float32([1.25, -2.5, 3.0, 1.0]), np.float32([-4.0, 0.5, 0.25, 1.0])
+    tgt[np.arange(600) * 61 + 7] = a
+    tgt[2048 + np.arange(150) * 9] = b
+    tgt[5] = [np.inf, 0.0, 0.0, 1.0]
+    tgt[3000] = [np.nan, 1.0, 1.0, 1.0]
+    qry = np.concatenate([g.uniform_points(300, 10.0), a[None], b[None], (a + np.float32([0.01, 0, 0, 0]))[None],
+                          (b + np.float32([0, 0.02, 0, 0]))[None]])
+    r = sp.knn_search_bruteforce(dev(qry), dev(tgt), k)
+    oi, od = orc.knn_bruteforce(qry, tgt, k)
+    assert np.array_equal(r.indices.cpu().numpy(), oi)
+    assert np.array_equal(r.distances.cpu().numpy(), od)
+    # every target the same point: all distances tie, the first k indices win
+    same = np.tile(a, (20000, 1))
+    r = sp.knn_search_bruteforce(dev(qry[:70]), dev(same), k)
+    oi, od = orc.knn_bruteforce(qry[:70], same, k)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+
+
 def test_bruteforce_config2_size_k20(sp, orc):
     # 100k x 100k at k = 20 (the reference's MAX_K): oracle on a 500-query sample, size-independent properties on all
     # (ascending distances, distance == distance to the reported index, no index twice).
