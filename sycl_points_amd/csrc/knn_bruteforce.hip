@@ -249,10 +249,146 @@ constexpr int kCandCap = 64;
 constexpr int kMaxChunks = 256;     // G: the targets are cut into at most this many chunks of whole LDS tiles
 constexpr int kMaxNeeded = 32;      // chunks one query may be listed for; beyond that (tied minima) its wave rescans everything
 
+// ---- pass A in 2 instructions per pair: chunk minima of an APPROXIMATE distance with a proven error bound -----------------
+// Pass A only has to bound the k-th neighbour's distance, so it need not evaluate the reference's expression. With both
+// clouds centred on the targets' bounding box (q^ = q - c, p^ = p - c) the tile holds (-2p^x, -2p^y, -2p^z, |p^|^2) and
+//     d~ = fma(q^x, -2p^x, fma(q^y, -2p^y, fma(q^z, -2p^z, |p^|^2))) + |q^|^2
+// costs 3 packed FMAs + 1 packed min per two pairs (the |q^|^2 is added to the minimum afterwards) against 7 for the exact
+// form. Error against the reference's fp32 value d_ref (u = 2^-24, Q = |q^|, P = |p^| <= pmax):
+//     |d~ - |q^-p^|^2|        <= 7 u (Q+P)^2     (3 roundings in |p^|^2, 3 in the chain, 3 in |q^|^2, 1 in the final add)
+//     ||q^-p^|^2 - |q-p|^2|   <= 2.1 u (Q+P)^2   (the two centring subtractions round)
+//     |d_ref - |q-p|^2|       <= 5.1 u (Q+P)^2   (5 roundings, relative)
+// so |d~ - d_ref| <= E = 20 u (Q + pmax)^2 with room to spare. The bound kernel turns the k-th smallest approximate chunk
+// minimum m_k into tau = m_k + E (at least k targets have d_ref <= tau) and lists a query for every chunk whose
+// approximate minimum is <= tau + E (no chunk holding a target with d_ref <= tau is missed). Candidates and results come
+// from the exact expression in the collect kernel, as before: lists stay bit-identical. Centred coordinates make E / spacing^2
+// a function of the target COUNT alone for a roughly uniform cloud (0.008 at 10^5 targets, 0.04 at 10^6): the host uses this
+// pass up to kApproxMaxTargets and the exact k = 1 kernel beyond. A cloud with overflowing or non-finite extents makes E
+// non-finite; such queries go to the select kernel's full rescan.
+constexpr size_t kApproxMaxTargets = 2u << 20;
+
+struct BfFrame {
+    float cx, cy, cz;  // centre of the finite targets' bounding box
+    float pmax;        // >= |p - c| for every finite target
+};
+__device__ __forceinline__ unsigned enc_ordered(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(unsigned e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+__global__ void knn_bf_box_init_kernel(unsigned* box) {
+    if (threadIdx.x < 6) box[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+}
+__global__ __launch_bounds__(kBlock) void knn_bf_box_kernel(const float4* __restrict__ targets, unsigned nt, unsigned* box) {
+    unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nt; i += gridDim.x * kBlock) {
+        const float4 p = targets[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            const unsigned e[3] = {enc_ordered(p.x), enc_ordered(p.y), enc_ordered(p.z)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], e[a]); mx[a] = max(mx[a], e[a]); }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = min(mn[a], (unsigned)__shfl_xor((int)mn[a], o, 64));
+            mx[a] = max(mx[a], (unsigned)__shfl_xor((int)mx[a], o, 64));
+        }
+    }
+    __shared__ unsigned red[kBlock / kWave][6];
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = mn[a]; red[threadIdx.x >> 6][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {  // one atomic per workgroup and bound (64 workgroups: the six words share a cache line)
+        unsigned v = red[0][threadIdx.x];
+        for (int w = 1; w < kBlock / kWave; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&box[threadIdx.x], v);
+        else atomicMax(&box[threadIdx.x], v);
+    }
+}
+__global__ void knn_bf_frame_kernel(const unsigned* __restrict__ box, BfFrame* __restrict__ frame) {
+    if (threadIdx.x != 0) return;
+    BfFrame f{0.0f, 0.0f, 0.0f, 0.0f};
+    if (box[0] != 0xffffffffu) {  // (no finite target: every distance is non-finite, nothing is ever a candidate)
+        float h2 = 0.0f;
+        float c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = dec_ordered(box[a]), hi = dec_ordered(box[3 + a]);
+            c[a] = 0.5f * lo + 0.5f * hi;
+            const float h = fmaxf(hi - c[a], c[a] - lo);
+            h2 += h * h;
+        }
+        f.cx = c[0]; f.cy = c[1]; f.cz = c[2];
+        f.pmax = sqrtf(h2) * 1.0001f;  // (the roundings above are parts in 10^7)
+    }
+    *frame = f;
+}
+
+__global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                                 const float4* __restrict__ targets, unsigned nt,
+                                                                 unsigned chunk, const BfFrame* __restrict__ frame,
+                                                                 float* __restrict__ amin) {
+    __shared__ float4 tile[kTile];
+    const unsigned split = blockIdx.y;
+    const unsigned t_begin = split * chunk;
+    const unsigned t_end = min(nt, t_begin + chunk);
+    const float cx = frame->cx, cy = frame->cy, cz = frame->cz;
+    unsigned qid[kQ1];
+    v2f qx[kQ1 / 2], qy[kQ1 / 2], qz[kQ1 / 2], m[kQ1 / 2];
+    float qq[kQ1];
+#pragma unroll
+    for (int u = 0; u < kQ1; ++u) {
+        qid[u] = (blockIdx.x * kQ1 + u) * kBlock + threadIdx.x;
+        const float4 q = queries[min(qid[u], nq - 1)];
+        const float x = q.x - cx, y = q.y - cy, z = q.z - cz;
+        qx[u >> 1][u & 1] = x; qy[u >> 1][u & 1] = y; qz[u >> 1][u & 1] = z;
+        qq[u] = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        m[u >> 1][u & 1] = FLT_MAX;
+    }
+    for (unsigned base = t_begin; base < t_end; base += kTile) {
+        const unsigned cnt = min((unsigned)kTile, t_end - base);
+        __syncthreads();
+        // (the tail of the last tile repeats its first point: a duplicate cannot change the minimum)
+        for (unsigned i = threadIdx.x; i < kTile; i += kBlock) {
+            const float4 p = targets[base + (i < cnt ? i : 0u)];
+            const float x = p.x - cx, y = p.y - cy, z = p.z - cz;
+            tile[i] = make_float4(-2.0f * x, -2.0f * y, -2.0f * z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < kTile; ++j) {
+            const float4 t = tile[j];  // same address in every lane: one broadcast LDS read
+            const v2f axy = {t.x, t.y}, czw = {t.z, t.w};
+#pragma unroll
+            for (int h = 0; h < kQ1 / 2; ++h) {
+                v2f s = __builtin_elementwise_fma(qz[h], __builtin_shufflevector(czw, czw, 0, 0), __builtin_shufflevector(czw, czw, 1, 1));
+                s = __builtin_elementwise_fma(qy[h], __builtin_shufflevector(axy, axy, 1, 1), s);
+                s = __builtin_elementwise_fma(qx[h], __builtin_shufflevector(axy, axy, 0, 0), s);
+                m[h] = __builtin_elementwise_min(m[h], s);  // (minNum: a NaN from a non-finite target never wins)
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kQ1; ++u)
+        if (qid[u] < nq) {
+            const float mu = m[u >> 1][u & 1];
+            amin[(size_t)split * nq + qid[u]] = mu < FLT_MAX ? mu + qq[u] : FLT_MAX;
+        }
+}
+
 // tau per query, and wave_cnt[c][wave] = how many of the wave's 64 queries need chunk c. (No atomics: a counter per chunk,
 // bumped by every wave, put 150 k atomics on four cache lines — 1.3 ms at 100 k queries; counts + scans are 20 us.)
 __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __restrict__ chunk_min, unsigned nq, int k,
-                                                              unsigned nchunks, float* __restrict__ bound,
+                                                              unsigned nchunks, const float4* __restrict__ queries,
+                                                              const BfFrame* __restrict__ frame /* nullptr: exact minima */,
+                                                              float* __restrict__ bound, float* __restrict__ bound_need,
                                                               unsigned* __restrict__ wave_cnt, unsigned nwaves,
                                                               unsigned* __restrict__ cand_cnt) {
     const unsigned q = blockIdx.x * kBlock + threadIdx.x;
@@ -263,22 +399,44 @@ __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 20; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
     float kth = FLT_MAX;
-    for (unsigned c = 0; c < nchunks; ++c) {
-        const float d = chunk_min[(size_t)c * nq + qc];
-        if (d < kth) topk_insert<20>(bd, bi, k, d, 0, kth);
+    // (a hundred thousand queries are 1.5 waves per SIMD: nothing hides a load's latency, so they go out eight at a time)
+    for (unsigned c0 = 0; c0 < nchunks; c0 += 8) {
+        float d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = c0 + j < nchunks ? chunk_min[(size_t)(c0 + j) * nq + qc] : FLT_MAX;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (d[j] < kth) topk_insert<20>(bd, bi, k, d[j], 0, kth);
+    }
+    float E = 0.0f;  // |approximate - reference| distance, see knn_bf_chunkmin_kernel
+    if (frame) {
+        const float4 qq = queries[qc];
+        const float x = qq.x - frame->cx, y = qq.y - frame->cy, z = qq.z - frame->cz;
+        const float r = sqrtf(x * x + y * y + z * z) * 1.0001f + frame->pmax;
+        E = 20.0f * 5.9604645e-8f * 1.0001f * r * r;
     }
     // `d < bound` must admit d == tau; a query without k finite chunk minima (NaN / overflowing coordinates) is not bounded
-    float b = kth < FLT_MAX ? fminf(nextafterf(kth, FLT_MAX), FLT_MAX) : FLT_MAX;
+    float b = FLT_MAX, bn = FLT_MAX;
+    bool rescan = !(E < FLT_MAX);  // non-finite frame or query: no usable bound (and the minima may be meaningless)
+    if (!rescan && kth < FLT_MAX) {
+        const float tau = E > 0.0f ? nextafterf(kth + E, FLT_MAX) : kth;
+        b = fminf(nextafterf(tau, FLT_MAX), FLT_MAX);
+        bn = E > 0.0f ? fminf(nextafterf(nextafterf(tau + E, FLT_MAX), FLT_MAX), FLT_MAX) : b;
+    }
     unsigned needed = 0;
-    for (unsigned c = 0; c < nchunks; ++c) needed += chunk_min[(size_t)c * nq + qc] < b ? 1u : 0u;
-    if (needed > (unsigned)kMaxNeeded) b = -1.0f;  // listed nowhere: the select kernel scans all targets for it
+#pragma unroll 8
+    for (unsigned c = 0; c < nchunks; ++c) needed += chunk_min[(size_t)c * nq + qc] < bn ? 1u : 0u;
+    rescan = rescan || needed > (unsigned)kMaxNeeded;
+    if (rescan) { b = -1.0f; bn = -INFINITY; }  // listed nowhere: the select kernel scans all targets for it
     if (live) {
         bound[q] = b;
-        cand_cnt[q] = needed > (unsigned)kMaxNeeded ? (unsigned)kCandCap + 1u : 0u;
+        bound_need[q] = bn;
+        cand_cnt[q] = rescan ? (unsigned)kCandCap + 1u : 0u;
     }
     const unsigned wave = q >> 6, lane = threadIdx.x & 63;
+#pragma unroll 8
     for (unsigned c = 0; c < nchunks; ++c) {
-        const unsigned long long m = __ballot(live && chunk_min[(size_t)c * nq + qc] < b);
+        const unsigned long long m = __ballot(live && chunk_min[(size_t)c * nq + qc] < bn);
         if (lane == 0 && wave < nwaves) wave_cnt[(size_t)c * nwaves + wave] = (unsigned)__builtin_popcountll(m);  // (the last workgroup may hold an idle wave)
     }
 }
@@ -331,6 +489,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_lists_kernel(const float* __res
     const unsigned qc = live ? q : nq - 1;
     const float b = bound[qc];
     const unsigned wave = q >> 6, lane = threadIdx.x & 63;
+#pragma unroll 8
     for (unsigned c = 0; c < nchunks; ++c) {
         const bool need = live && chunk_min[(size_t)c * nq + qc] < b;
         const unsigned long long m = __ballot(need);
@@ -515,7 +674,8 @@ struct BoundedPlan {
 
 BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
     BoundedPlan P{};
-    if (k < 2 || nt < (size_t)16 * kTile) return P;
+    if (k < 1 || nt < (size_t)16 * kTile) return P;
+    if (k == 1 && nt > kApproxMaxTargets) return P;  // (exact minima only: the k = 1 kernel finishes the job itself)
     P.a.qpt = kQ1;
     P.a.qblocks = div_up(nq, (size_t)kBlock * kQ1);
     P.a.chunk = div_up(div_up(nt, (size_t)kMaxChunks), kTile) * kTile;  // 1024 targets per chunk up to 256 K targets
@@ -530,7 +690,7 @@ BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
     P.off_min = 0;
     P.off_bound = up(P.off_min + (size_t)P.a.nsplit * nq * 4);
     // chunk list lengths | offsets (kMaxChunks each) | candidates per query | per-wave counts, chunk-major
-    P.off_counts = up(P.off_bound + nq * 4);
+    P.off_counts = up(P.off_bound + 2 * nq * 4 + 64);  // (bound | bound for the chunk lists | box + frame)
     P.off_chunk_list = up(P.off_counts + (2 * (size_t)kMaxChunks + nq + (size_t)P.a.nsplit * div_up(nq, (size_t)64)) * 4);
     P.off_cand = up(P.off_chunk_list + nq * (size_t)kMaxNeeded * 4);
     P.bytes = P.off_cand + nq * (size_t)kCandCap * 8;
@@ -542,6 +702,9 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
     char* w = static_cast<char*>(ws);
     float* amin = reinterpret_cast<float*>(w + P.off_min);
     float* bound = reinterpret_cast<float*>(w + P.off_bound);
+    float* bound_need = bound + nq;
+    unsigned* box = reinterpret_cast<unsigned*>(bound_need + nq);
+    BfFrame* frame = reinterpret_cast<BfFrame*>(box + 8);
     unsigned* chunk_cnt = reinterpret_cast<unsigned*>(w + P.off_counts);
     unsigned* chunk_off = chunk_cnt + kMaxChunks;
     unsigned* cand_cnt = chunk_cnt + 2 * kMaxChunks;
@@ -551,11 +714,20 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
     const float4* q4 = reinterpret_cast<const float4*>(q);
     const float4* t4 = reinterpret_cast<const float4*>(t);
     const unsigned G = P.a.nsplit, nwaves = div_up(nq, (size_t)64);
-    knn_bf_k1_kernel<true><<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, nullptr, amin);
-    knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, G, bound, wave_cnt, nwaves, cand_cnt);
+    const bool approx = nt <= kApproxMaxTargets;
+    if (approx) {
+        knn_bf_box_init_kernel<<<1, 64, 0, st>>>(box);
+        knn_bf_box_kernel<<<std::min(div_up(nt, kBlock), 64u), kBlock, 0, st>>>(t4, (unsigned)nt, box);
+        knn_bf_frame_kernel<<<1, 64, 0, st>>>(box, frame);
+        knn_bf_chunkmin_kernel<<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, frame, amin);
+    } else {
+        knn_bf_k1_kernel<true><<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, nullptr, amin);
+    }
+    knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, G, q4, approx ? frame : nullptr, bound,
+                                                               bound_need, wave_cnt, nwaves, cand_cnt);
     knn_bf_wave_offsets_kernel<<<G, kBlock, 0, st>>>(wave_cnt, nwaves, chunk_cnt);
     knn_bf_offsets_kernel<<<1, kMaxChunks, 0, st>>>(chunk_cnt, G, chunk_off);
-    knn_bf_lists_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, G, bound, chunk_off, wave_cnt, nwaves, chunk_list);
+    knn_bf_lists_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, G, bound_need, chunk_off, wave_cnt, nwaves, chunk_list);
     knn_bf_collect_kernel<<<dim3(P.b.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.b.chunk, bound,
                                                                    chunk_cnt, chunk_off, chunk_list, cand_cnt, cand);
     knn_bf_select_kernel<<<div_up(nq * 64, kBlock), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, (int)k, cand_cnt, cand, idx, d2);

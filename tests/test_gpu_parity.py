@@ -132,6 +132,29 @@ def test_bruteforce_two_pass_overflow_paths(sp, orc, k):
     assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("k", [1, 3, 20])
+def test_bruteforce_approximate_bound_is_safe(sp, orc, k):
+    # pass A of the large-problem path bounds the k-th distance with an approximate expression and a proven error term
+    # (knn_bf_chunkmin_kernel): clouds far from the origin (the term is relative to the CENTRED extent), a thin slab, targets
+    # on a lattice (many exactly equal distances), one target 10^30 away (the bound is useless: every query is rescanned).
+    g = orc.rng(2024)
+    off = np.float32([1000.0, -2000.0, 50.0, 0.0])
+    tgt = g.uniform_points(20000, 10.0) + off
+    qry = np.concatenate([g.uniform_points(700, 10.0) + off, np.float32([[0.0, 0.0, 0.0, 1.0]]), tgt[:50]])
+    for T, Q in ((tgt, qry),
+                 (tgt * np.float32([1, 1, 1e-3, 1]), qry * np.float32([1, 1, 1e-3, 1])),
+                 (np.round(tgt), np.round(qry[:300]) + np.float32([0.5, 0, 0, 0]))):
+        r = sp.knn_search_bruteforce(dev(Q), dev(T), k)
+        oi, od = orc.knn_bruteforce(Q, T, k)
+        assert np.array_equal(r.indices.cpu().numpy(), oi)
+        assert np.array_equal(r.distances.cpu().numpy(), od)
+    far = tgt.copy()
+    far[77] = [1e30, 0.0, 0.0, 1.0]
+    r = sp.knn_search_bruteforce(dev(qry[:40]), dev(far), k)
+    oi, od = orc.knn_bruteforce(qry[:40], far, k)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+
+
 def test_bruteforce_config2_size_k20(sp, orc):
     # 100k x 100k at k = 20 (the reference's MAX_K): oracle on a 500-query sample, size-independent properties on all
     # (ascending distances, distance == distance to the reported index, no index twice).
