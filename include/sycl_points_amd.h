@@ -49,6 +49,11 @@ int sp_set_device(int device);
 size_t sp_knn_bruteforce_workspace_bytes(size_t nq, size_t nt, size_t k);
 int sp_knn_bruteforce(const float* queries, size_t nq, const float* targets, size_t nt, size_t k, int32_t* idx_out,
                       float* d2_out, void* workspace, size_t workspace_bytes, void* stream);
+/* From 16 K targets on, the search bounds every query's k-th distance first (chunk minima of an approximate distance with a
+ * proven error term) and evaluates the reference's expression only where a neighbour can be. That first pass runs on the
+ * matrix cores (bf16-split operands, v_mfma_f32_32x32x16_bf16); valu != 0 selects its packed-fp32 VALU form instead, for
+ * measurement (process-wide; the results do not depend on it). */
+int sp_knn_bruteforce_set_pass_a(int valu);
 
 /* KD-tree (algorithms/knn/kdtree.hpp:142-766).
  * sp_kdtree_create: KDTree::build (kdtree.hpp:165-178, 292-413) — host median-split build from HOST points

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sp_device_count": (_i, []),
     "sp_set_device": (_i, [_i]),
     "sp_knn_bruteforce_workspace_bytes": (_sz, [_sz, _sz, _sz]),
+    "sp_knn_bruteforce_set_pass_a": (_i, [_i]),
     "sp_knn_bruteforce": (_i, [_vp, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp]),
     "sp_kdtree_create": (_i, [_vp, _sz, _sz, _vp, C.POINTER(_vp)]),
     "sp_kdtree_destroy": (None, [_vp]),

@@ -383,12 +383,148 @@ __global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_kernel(const float4* _
         }
 }
 
+// ---- pass A on the matrix cores ---------------------------------------------------------------------------------------
+// |p^|^2 - 2 q^.p^ over (chunk of targets) x (queries) is a GEMM with K = 4; in bf16 pieces it is one
+// v_mfma_f32_32x32x16_bf16 per 32 targets x 32 queries: 1024 pairs in 32 cycles of a SIMD, against 2 packed VALU
+// instructions per pair (8 pairs per cycle). Every centred coordinate is split exactly, x = x1 + x2 + x3 with bf16 pieces
+// (|x - x1 - x2| <= 2^-16 |x|), and the 16 k-slots carry, per coordinate, the four products of the two leading pieces
+//     A (target row)   -2p1  -2p1  -2p2  -2p2          B (query column)   q1  q2  q1  q2
+// then |p^|^2 in three pieces against 1, 1, 1, and one empty slot. Products of bf16 pieces are exact in fp32; what is lost:
+//     the dropped piece products                     <= 2^-14 |q_x p_x| per coordinate, <= 2^-16 (Q+P)^2 in total
+//     the matrix core's 16 accumulations             <= 2u each of the running magnitude (taken as truncating): 33 u (Q+P)^2
+//     |p^|^2, |q^|^2, the final add, centring, d_ref  <= 14.2 u (Q+P)^2 as in the VALU form above
+// = 1.81e-5 (Q+P)^2; the bound kernel uses kMfmaErr = 2.0e-5. At 10^5 uniform targets that is a quarter of the nearest
+// neighbour's squared distance (a few per cent of the 20th's): some more (query, chunk) pairs for the exact collect pass,
+// which stays a small part. D[target][query] has the query on the lane and 16 targets in the registers, so the running
+// minimum is 8 v_min3_f32 per MFMA on the lane's own registers — no cross-lane work until the chunk ends.
+// Rows of non-finite targets and the padding up to whole chunks are (0, ..., |p|^2 = 3.4e38): never a minimum.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float kValuErr = 20.0f * 5.9604645e-8f;
+constexpr float kMfmaErr = 2.0e-5f;
+constexpr int kQTiles = 4;                          // 32-query tiles per wave: their B fragments stay in registers
+constexpr unsigned kMfmaQueries = 4 * kQTiles * 32;  // queries per workgroup of 4 waves
+
+__device__ __forceinline__ unsigned bf16_rne(float f) {  // bits of the nearest bf16 (finite f)
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
+// x = v(a) + v(b) + v(c) exactly (each remainder is exactly representable in fp32)
+__device__ __forceinline__ void bf16_split3(float x, unsigned& a, unsigned& b, unsigned& c) {
+    a = bf16_rne(x);
+    const float r1 = x - bf16_val(a);
+    b = bf16_rne(r1);
+    c = bf16_rne(r1 - bf16_val(b));
+}
+__device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) { return (lo & 0xffffu) | (hi << 16); }
+
+__global__ __launch_bounds__(kBlock) void knn_bf_prep_targets_kernel(const float4* __restrict__ targets, unsigned nt,
+                                                                     unsigned rows, const BfFrame* __restrict__ frame,
+                                                                     uint4* __restrict__ tA) {
+    const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= rows) return;
+    uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0x7f7fu, 0u);  // (k12 = 3.39e38, everything else 0)
+    if (t < nt) {
+        const float4 p = targets[t];
+        const float x = p.x - frame->cx, y = p.y - frame->cy, z = p.z - frame->cz;
+        const float w = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        if (isfinite(w)) {
+            unsigned x1, x2, x3, y1, y2, y3, z1, z2, z3, w1, w2, w3;
+            bf16_split3(-2.0f * x, x1, x2, x3);  // (the factor is a power of two: the pieces of -2x are -2 times those of x)
+            bf16_split3(-2.0f * y, y1, y2, y3);
+            bf16_split3(-2.0f * z, z1, z2, z3);
+            bf16_split3(w, w1, w2, w3);
+            lo = make_uint4(pack2(x1, x1), pack2(x2, x2), pack2(y1, y1), pack2(y2, y2));
+            hi = make_uint4(pack2(z1, z1), pack2(z2, z2), pack2(w1, w2), pack2(w3, 0u));
+        }
+    }
+    tA[2 * (size_t)t] = lo;
+    tA[2 * (size_t)t + 1] = hi;
+}
+__global__ __launch_bounds__(kBlock) void knn_bf_prep_queries_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                                     unsigned cols, const BfFrame* __restrict__ frame,
+                                                                     uint4* __restrict__ qB, float* __restrict__ qq) {
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= cols) return;
+    uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = lo;
+    float n2 = 0.0f;
+    if (q < nq) {
+        const float4 p = queries[q];
+        const float x = p.x - frame->cx, y = p.y - frame->cy, z = p.z - frame->cz;
+        n2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        unsigned x1, x2, x3, y1, y2, y3, z1, z2, z3;
+        bf16_split3(x, x1, x2, x3);
+        bf16_split3(y, y1, y2, y3);
+        bf16_split3(z, z1, z2, z3);
+        lo = make_uint4(pack2(x1, x2), pack2(x1, x2), pack2(y1, y2), pack2(y1, y2));
+        hi = make_uint4(pack2(z1, z2), pack2(z1, z2), pack2(0x3f80u, 0x3f80u), pack2(0x3f80u, 0u));
+    }
+    qB[2 * (size_t)q] = lo;
+    qB[2 * (size_t)q + 1] = hi;
+    qq[q] = n2;
+}
+
+__device__ __forceinline__ float min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
+// grid: x = groups of kMfmaQueries queries, y = groups of `chunks_per_wg` chunks. `chunk` is a multiple of 32; tA holds
+// nchunks * chunk rows, qB / qq a multiple of kMfmaQueries columns.
+__global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_mfma_kernel(const uint4* __restrict__ tA, const uint4* __restrict__ qB,
+                                                                      const float* __restrict__ qq, unsigned nq, unsigned chunk,
+                                                                      unsigned nchunks, unsigned chunks_per_wg,
+                                                                      float* __restrict__ amin) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned r = lane & 31, h = lane >> 5;
+    const unsigned q0 = (blockIdx.x * 4 + wave) * (kQTiles * 32);
+    bf16x8 b[kQTiles];
+    float myqq[kQTiles];
+#pragma unroll
+    for (int t = 0; t < kQTiles; ++t) {
+        const unsigned qi = q0 + t * 32 + r;
+        const uint4 v = qB[2 * (size_t)qi + h];
+        b[t] = __builtin_bit_cast(bf16x8, v);
+        myqq[t] = qq[qi];
+    }
+    const f32x16 zero = {};
+    const unsigned steps = chunk / 32;
+    const unsigned c_end = min(nchunks, (blockIdx.y + 1) * chunks_per_wg);
+    for (unsigned c = blockIdx.y * chunks_per_wg; c < c_end; ++c) {
+        float m[kQTiles];
+#pragma unroll
+        for (int t = 0; t < kQTiles; ++t) m[t] = FLT_MAX;
+        const uint4* a_ptr = tA + 2 * ((size_t)c * chunk + r) + h;  // lane (r, h): k = 8h .. 8h+7 of target row r
+        uint4 a_next = a_ptr[0];
+        for (unsigned s = 0; s < steps; ++s) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, a_next);
+            if (s + 1 < steps) a_next = a_ptr[(size_t)(s + 1) * 64];  // (in flight while this step's MFMAs run)
+#pragma unroll
+            for (int t = 0; t < kQTiles; ++t) {
+                const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[t], zero, 0, 0, 0);
+                float v = min3(m[t], d[0], d[1]);
+                v = min3(v, d[2], d[3]);
+                v = min3(v, d[4], d[5]);
+                v = min3(v, d[6], d[7]);
+                v = min3(v, d[8], d[9]);
+                v = min3(v, d[10], d[11]);
+                v = min3(v, d[12], d[13]);
+                m[t] = min3(v, d[14], d[15]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kQTiles; ++t) {
+            const float v = fminf(m[t], __shfl_xor(m[t], 32, 64));  // the two lane halves hold different targets of one query
+            const unsigned qi = q0 + t * 32 + r;
+            if (h == 0 && qi < nq) amin[(size_t)c * nq + qi] = v < 1e37f ? v + myqq[t] : FLT_MAX;
+        }
+    }
+}
+
 // tau per query, and wave_cnt[c][wave] = how many of the wave's 64 queries need chunk c. (No atomics: a counter per chunk,
 // bumped by every wave, put 150 k atomics on four cache lines — 1.3 ms at 100 k queries; counts + scans are 20 us.)
 __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __restrict__ chunk_min, unsigned nq, int k,
                                                               unsigned nchunks, const float4* __restrict__ queries,
                                                               const BfFrame* __restrict__ frame /* nullptr: exact minima */,
-                                                              float* __restrict__ bound, float* __restrict__ bound_need,
+                                                              float err_coeff, float* __restrict__ bound, float* __restrict__ bound_need,
                                                               unsigned* __restrict__ wave_cnt, unsigned nwaves,
                                                               unsigned* __restrict__ cand_cnt) {
     const unsigned q = blockIdx.x * kBlock + threadIdx.x;
@@ -413,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __res
         const float4 qq = queries[qc];
         const float x = qq.x - frame->cx, y = qq.y - frame->cy, z = qq.z - frame->cz;
         const float r = sqrtf(x * x + y * y + z * z) * 1.0001f + frame->pmax;
-        E = 20.0f * 5.9604645e-8f * 1.0001f * r * r;
+        E = err_coeff * 1.0001f * r * r;
     }
     // `d < bound` must admit d == tau; a query without k finite chunk minima (NaN / overflowing coordinates) is not bounded
     float b = FLT_MAX, bn = FLT_MAX;
@@ -434,7 +570,6 @@ __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __res
         cand_cnt[q] = rescan ? (unsigned)kCandCap + 1u : 0u;
     }
     const unsigned wave = q >> 6, lane = threadIdx.x & 63;
-#pragma unroll 8
     for (unsigned c = 0; c < nchunks; ++c) {
         const unsigned long long m = __ballot(live && chunk_min[(size_t)c * nq + qc] < bn);
         if (lane == 0 && wave < nwaves) wave_cnt[(size_t)c * nwaves + wave] = (unsigned)__builtin_popcountll(m);  // (the last workgroup may hold an idle wave)
@@ -489,7 +624,6 @@ __global__ __launch_bounds__(kBlock) void knn_bf_lists_kernel(const float* __res
     const unsigned qc = live ? q : nq - 1;
     const float b = bound[qc];
     const unsigned wave = q >> 6, lane = threadIdx.x & 63;
-#pragma unroll 8
     for (unsigned c = 0; c < nchunks; ++c) {
         const bool need = live && chunk_min[(size_t)c * nq + qc] < b;
         const unsigned long long m = __ballot(need);
@@ -608,6 +742,10 @@ __global__ __launch_bounds__(kBlock) void knn_bf_select_kernel(const float4* __r
     }
 }
 
+// Which approximate pass A runs (sp_knn_bruteforce_set_pass_a: 0 = matrix cores (default), 1 = packed VALU): both are kept
+// because both are measured in bench.py's stages block; the lists do not depend on the choice.
+int g_pass_a_valu = 0;
+
 struct BfPlan {
     unsigned qblocks, nsplit, chunk;
     int qpt;
@@ -669,7 +807,7 @@ int run_k1(const float* q, size_t nq, const float* t, size_t nt, int32_t* idx, f
 struct BoundedPlan {
     bool use;
     BfPlan a, b;                                       // pass A = the k = 1 kernel over G chunks; pass B = two queries per lane
-    size_t off_min, off_bound, off_counts, off_chunk_list, off_cand, bytes;  // workspace layout
+    size_t off_min, off_bound, off_counts, off_chunk_list, off_cand, off_operands, bytes;  // workspace layout
 };
 
 BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
@@ -693,7 +831,9 @@ BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
     P.off_counts = up(P.off_bound + 2 * nq * 4 + 64);  // (bound | bound for the chunk lists | box + frame)
     P.off_chunk_list = up(P.off_counts + (2 * (size_t)kMaxChunks + nq + (size_t)P.a.nsplit * div_up(nq, (size_t)64)) * 4);
     P.off_cand = up(P.off_chunk_list + nq * (size_t)kMaxNeeded * 4);
-    P.bytes = P.off_cand + nq * (size_t)kCandCap * 8;
+    P.off_operands = up(P.off_cand + nq * (size_t)kCandCap * 8);  // bf16 rows of the targets | columns of the queries | |q^|^2
+    const size_t rows = (size_t)P.a.nsplit * P.a.chunk, cols = div_up(nq, (size_t)kMfmaQueries) * (size_t)kMfmaQueries;
+    P.bytes = P.off_operands + rows * 32 + cols * 36;
     return P;
 }
 
@@ -716,15 +856,28 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
     const unsigned G = P.a.nsplit, nwaves = div_up(nq, (size_t)64);
     const bool approx = nt <= kApproxMaxTargets;
     if (approx) {
+        const unsigned rows = G * P.a.chunk, cols = div_up(nq, (size_t)kMfmaQueries) * kMfmaQueries;
+        uint4* tA = reinterpret_cast<uint4*>(w + P.off_operands);
+        uint4* qB = tA + 2 * (size_t)rows;
+        float* qq = reinterpret_cast<float*>(qB + 2 * (size_t)cols);
         knn_bf_box_init_kernel<<<1, 64, 0, st>>>(box);
         knn_bf_box_kernel<<<std::min(div_up(nt, kBlock), 64u), kBlock, 0, st>>>(t4, (unsigned)nt, box);
         knn_bf_frame_kernel<<<1, 64, 0, st>>>(box, frame);
-        knn_bf_chunkmin_kernel<<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, frame, amin);
+        if (g_pass_a_valu) {
+            knn_bf_chunkmin_kernel<<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, frame, amin);
+        } else {
+            knn_bf_prep_targets_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(t4, (unsigned)nt, rows, frame, tA);
+            knn_bf_prep_queries_kernel<<<div_up(cols, kBlock), kBlock, 0, st>>>(q4, (unsigned)nq, cols, frame, qB, qq);
+            const unsigned cpw = 2;
+            knn_bf_chunkmin_mfma_kernel<<<dim3(cols / kMfmaQueries, div_up(G, cpw)), kBlock, 0, st>>>(tA, qB, qq, (unsigned)nq, P.a.chunk,
+                                                                                                      G, cpw, amin);
+        }
     } else {
         knn_bf_k1_kernel<true><<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, nullptr, amin);
     }
-    knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, G, q4, approx ? frame : nullptr, bound,
-                                                               bound_need, wave_cnt, nwaves, cand_cnt);
+    knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, G, q4, approx ? frame : nullptr,
+                                                               g_pass_a_valu ? kValuErr : kMfmaErr, bound, bound_need, wave_cnt, nwaves,
+                                                               cand_cnt);
     knn_bf_wave_offsets_kernel<<<G, kBlock, 0, st>>>(wave_cnt, nwaves, chunk_cnt);
     knn_bf_offsets_kernel<<<1, kMaxChunks, 0, st>>>(chunk_cnt, G, chunk_off);
     knn_bf_lists_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, G, bound_need, chunk_off, wave_cnt, nwaves, chunk_list);
@@ -741,6 +894,11 @@ __global__ void fill_empty_kernel(int32_t* idx, float* d2, size_t n) {
 
 }  // namespace
 }  // namespace sp
+
+extern "C" int sp_knn_bruteforce_set_pass_a(int valu) {
+    sp::g_pass_a_valu = valu ? 1 : 0;
+    return SP_OK;
+}
 
 extern "C" size_t sp_knn_bruteforce_workspace_bytes(size_t nq, size_t nt, size_t k) {
     if (nq == 0 || nt == 0 || k == 0) return 0;

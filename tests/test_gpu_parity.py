@@ -155,6 +155,49 @@ def test_bruteforce_approximate_bound_is_safe(sp, orc, k):
     assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("valu", [0, 1])
+def test_bruteforce_pass_a_error_stays_inside_its_bound(sp, orc, valu):
+    # The chunk minima of pass A (matrix cores: bf16-split operands; or packed VALU) are approximate by construction; the
+    # bound kernel adds E = c (|q - centre| + pmax)^2 with c = 2.0e-5 / 20 * 2^-24 (knn_bruteforce.hip). Read the minima back
+    # from the workspace (first G x nq floats, G chunks of `chunk` targets) and compare with float64 chunk minima: the error
+    # must stay inside E — with margin, or the constant is not conservative — and the lists must not depend on the form.
+    import ctypes as C
+    from sycl_points_amd import _lib
+    L = _lib.lib()
+    g = orc.rng(5)
+    nt, nq, k = 40000, 3000, 5
+    tgt = g.uniform_points(nt, 10.0) + np.float32([300.0, -100.0, 20.0, 0.0])
+    qry = g.uniform_points(nq, 12.0) + np.float32([300.0, -100.0, 20.0, 0.0])
+    T, Q = dev(tgt), dev(qry)
+    nbytes = L.sp_knn_bruteforce_workspace_bytes(nq, nt, k)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    idx = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    d2 = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    _lib.check(L.sp_knn_bruteforce_set_pass_a(valu))
+    try:
+        _lib.check(L.sp_knn_bruteforce(sp._ptr(Q), nq, sp._ptr(T), nt, k, sp._ptr(idx), sp._ptr(d2), sp._ptr(ws), nbytes, sp._stream()))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(L.sp_knn_bruteforce_set_pass_a(0))
+    oi, od = orc.knn_bruteforce(qry, tgt, k)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d2.cpu().numpy(), od)
+    chunk = -(-(-(-nt // 256)) // 1024) * 1024
+    G = -(-nt // chunk)
+    amin = ws[: G * nq * 4].view(torch.float32).reshape(G, nq).cpu().numpy().astype(np.float64)
+    t64, q64 = tgt[:, :3].astype(np.float64), qry[:, :3].astype(np.float64)
+    lo, hi = tgt[:, :3].min(0).astype(np.float64), tgt[:, :3].max(0).astype(np.float64)
+    centre = 0.5 * (lo + hi)
+    pmax = np.linalg.norm(np.maximum(hi - centre, centre - lo))
+    coeff = 20.0 * 2.0**-24 if valu else 2.0e-5
+    E = coeff * (np.linalg.norm(q64 - centre, axis=1) + pmax) ** 2
+    worst = 0.0
+    for c in range(G):
+        blk = t64[c * chunk:(c + 1) * chunk]
+        ref = ((q64[:, None, :] - blk[None, :, :]) ** 2).sum(2).min(1)
+        worst = max(worst, float((np.abs(amin[c] - ref) / E).max()))
+    assert worst < 0.6, worst
+
+
 def test_bruteforce_config2_size_k20(sp, orc):
     # 100k x 100k at k = 20 (the reference's MAX_K): oracle on a 500-query sample, size-independent properties on all
     # (ascending distances, distance == distance to the reported index, no index twice).
