@@ -1,5 +1,5 @@
 import torch, numpy as np, sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sycl_points_amd.api as sp
 from sycl_points_amd.synthetic import Mt19937Cloud
 g = Mt19937Cloud(1234)

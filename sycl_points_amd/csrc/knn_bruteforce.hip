@@ -402,7 +402,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float kValuErr = 20.0f * 5.9604645e-8f;
 constexpr float kMfmaErr = 2.0e-5f;
-constexpr int kQTiles = 4;                          // 32-query tiles per wave: their B fragments stay in registers
+constexpr int kQTiles = 8;                          // 32-query tiles per wave: their B fragments stay in registers
 constexpr unsigned kMfmaQueries = 4 * kQTiles * 32;  // queries per workgroup of 4 waves
 
 __device__ __forceinline__ unsigned bf16_rne(float f) {  // bits of the nearest bf16 (finite f)
@@ -497,6 +497,8 @@ __global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_mfma_kernel(const uint
         for (unsigned s = 0; s < steps; ++s) {
             const bf16x8 a = __builtin_bit_cast(bf16x8, a_next);
             if (s + 1 < steps) a_next = a_ptr[(size_t)(s + 1) * 64];  // (in flight while this step's MFMAs run)
+            // (measured: the SIMD is vector-issue-bound here — 8 v_min3 + the MFMA's own 8 issue cycles per 32-cycle product —
+            // and reaches 82 % of that bound whichever way the products and minima are ordered in the source)
 #pragma unroll
             for (int t = 0; t < kQTiles; ++t) {
                 const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[t], zero, 0, 0, 0);
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_mfma_kernel(const uint
 __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __restrict__ chunk_min, unsigned nq, int k,
                                                               unsigned nchunks, const float4* __restrict__ queries,
                                                               const BfFrame* __restrict__ frame /* nullptr: exact minima */,
-                                                              float err_coeff, float* __restrict__ bound, float* __restrict__ bound_need,
+                                                              float err_coeff, float* __restrict__ bound, uint4* __restrict__ need_mask,
                                                               unsigned* __restrict__ wave_cnt, unsigned nwaves,
                                                               unsigned* __restrict__ cand_cnt) {
     const unsigned q = blockIdx.x * kBlock + threadIdx.x;
@@ -552,6 +554,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __res
         E = err_coeff * 1.0001f * r * r;
     }
     // `d < bound` must admit d == tau; a query without k finite chunk minima (NaN / overflowing coordinates) is not bounded
+    static_assert(kMaxChunks == 256, "the need mask is 8 words");
     float b = FLT_MAX, bn = FLT_MAX;
     bool rescan = !(E < FLT_MAX);  // non-finite frame or query: no usable bound (and the minima may be meaningless)
     if (!rescan && kth < FLT_MAX) {
@@ -559,20 +562,51 @@ __global__ __launch_bounds__(kBlock) void knn_bf_bound_kernel(const float* __res
         b = fminf(nextafterf(tau, FLT_MAX), FLT_MAX);
         bn = E > 0.0f ? fminf(nextafterf(nextafterf(tau + E, FLT_MAX), FLT_MAX), FLT_MAX) : b;
     }
+    // which chunks can hold a candidate: one bit per chunk (G <= 256), kept in registers for the counts below and stored for
+    // the list kernel, so the minima are read twice, not four times
+    unsigned mask[kMaxChunks / 32];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 32; ++i) mask[i] = 0u;
     unsigned needed = 0;
-#pragma unroll 8
-    for (unsigned c = 0; c < nchunks; ++c) needed += chunk_min[(size_t)c * nq + qc] < bn ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 32; ++i) {
+        if ((unsigned)i * 32u < nchunks) {  // (uniform)
+#pragma unroll
+            for (int c0 = 0; c0 < 32; c0 += 8) {
+                float d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned c = i * 32 + c0 + j;
+                    d[j] = c < nchunks ? chunk_min[(size_t)c * nq + qc] : FLT_MAX;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mask[i] |= (d[j] < bn ? 1u : 0u) << (c0 + j);
+            }
+            needed += __builtin_popcount(mask[i]);
+        }
+    }
     rescan = rescan || needed > (unsigned)kMaxNeeded;
-    if (rescan) { b = -1.0f; bn = -INFINITY; }  // listed nowhere: the select kernel scans all targets for it
+    if (rescan) {  // listed nowhere: the select kernel scans all targets for it
+        b = -1.0f;
+#pragma unroll
+        for (int i = 0; i < kMaxChunks / 32; ++i) mask[i] = 0u;
+    }
     if (live) {
         bound[q] = b;
-        bound_need[q] = bn;
+        need_mask[2 * (size_t)q] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+        need_mask[2 * (size_t)q + 1] = make_uint4(mask[4], mask[5], mask[6], mask[7]);
         cand_cnt[q] = rescan ? (unsigned)kCandCap + 1u : 0u;
     }
     const unsigned wave = q >> 6, lane = threadIdx.x & 63;
-    for (unsigned c = 0; c < nchunks; ++c) {
-        const unsigned long long m = __ballot(live && chunk_min[(size_t)c * nq + qc] < bn);
-        if (lane == 0 && wave < nwaves) wave_cnt[(size_t)c * nwaves + wave] = (unsigned)__builtin_popcountll(m);  // (the last workgroup may hold an idle wave)
+    if (wave >= nwaves) return;  // (the last workgroup may hold an idle wave)
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 32; ++i) {
+        if ((unsigned)i * 32u >= nchunks) break;  // (uniform)
+        const unsigned mi = live ? mask[i] : 0u;
+        for (unsigned c0 = 0; c0 < 32 && i * 32 + c0 < nchunks; ++c0) {
+            const unsigned long long m = __ballot((mi >> c0) & 1u);
+            if (lane == 0) wave_cnt[(size_t)(i * 32 + c0) * nwaves + wave] = (unsigned)__builtin_popcountll(m);
+        }
     }
 }
 // One workgroup per chunk: wave_cnt[c][.] becomes its exclusive scan, chunk_cnt[c] the total.
@@ -598,38 +632,56 @@ __global__ __launch_bounds__(kBlock) void knn_bf_wave_offsets_kernel(unsigned* _
     }
     if (t == 0) chunk_cnt[blockIdx.x] = carry;
 }
-// chunk_off = exclusive scan of chunk_cnt (<= 256 values)
+// chunk_off = exclusive scan of chunk_cnt (<= 256 values); blk_off = exclusive scan of the collect kernel's work items per
+// chunk (blocks of 2 * kBlock listed queries, times `subs` sub-ranges of the chunk's targets), blk_off[nchunks] = their number.
 __global__ __launch_bounds__(kMaxChunks) void knn_bf_offsets_kernel(const unsigned* __restrict__ chunk_cnt, unsigned nchunks,
-                                                                    unsigned* __restrict__ chunk_off) {
-    __shared__ unsigned s[kMaxChunks];
+                                                                    unsigned subs, unsigned* __restrict__ chunk_off,
+                                                                    unsigned* __restrict__ blk_off) {
+    __shared__ unsigned s[kMaxChunks], sb[kMaxChunks];
     const unsigned t = threadIdx.x;
-    s[t] = t < nchunks ? chunk_cnt[t] : 0u;
+    const unsigned cnt = t < nchunks ? chunk_cnt[t] : 0u;
+    const unsigned blocks = (cnt + 2 * kBlock - 1) / (2 * kBlock) * subs;
+    s[t] = cnt;
+    sb[t] = blocks;
     __syncthreads();
     for (unsigned d = 1; d < (unsigned)kMaxChunks; d <<= 1) {
-        const unsigned v = t >= d ? s[t - d] : 0u;
+        const unsigned v = t >= d ? s[t - d] : 0u, vb = t >= d ? sb[t - d] : 0u;
         __syncthreads();
         s[t] += v;
+        sb[t] += vb;
         __syncthreads();
     }
-    if (t < nchunks) chunk_off[t] = s[t] - chunk_cnt[t];
+    if (t < nchunks) {
+        chunk_off[t] = s[t] - cnt;
+        blk_off[t] = sb[t] - blocks;
+    }
+    if (t == nchunks - 1) blk_off[nchunks] = sb[t];
 }
 // The lists themselves: chunk c's queries, ascending, at chunk_list[chunk_off[c] ...].
-__global__ __launch_bounds__(kBlock) void knn_bf_lists_kernel(const float* __restrict__ chunk_min, unsigned nq, unsigned nchunks,
-                                                              const float* __restrict__ bound,
+__global__ __launch_bounds__(kBlock) void knn_bf_lists_kernel(const uint4* __restrict__ need_mask, unsigned nq, unsigned nchunks,
                                                               const unsigned* __restrict__ chunk_off,
                                                               const unsigned* __restrict__ wave_off, unsigned nwaves,
                                                               unsigned* __restrict__ chunk_list) {
     const unsigned q = blockIdx.x * kBlock + threadIdx.x;
     const bool live = q < nq;
-    const unsigned qc = live ? q : nq - 1;
-    const float b = bound[qc];
     const unsigned wave = q >> 6, lane = threadIdx.x & 63;
-    for (unsigned c = 0; c < nchunks; ++c) {
-        const bool need = live && chunk_min[(size_t)c * nq + qc] < b;
-        const unsigned long long m = __ballot(need);
-        if (need)
-            chunk_list[chunk_off[c] + wave_off[(size_t)c * nwaves + wave] +
-                       (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = q;
+    unsigned mask[kMaxChunks / 32] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (live) {
+        const uint4 a = need_mask[2 * (size_t)q], b = need_mask[2 * (size_t)q + 1];
+        mask[0] = a.x; mask[1] = a.y; mask[2] = a.z; mask[3] = a.w;
+        mask[4] = b.x; mask[5] = b.y; mask[6] = b.z; mask[7] = b.w;
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 32; ++i) {
+        if ((unsigned)i * 32u >= nchunks) break;  // (uniform)
+        for (unsigned c0 = 0; c0 < 32 && i * 32 + c0 < nchunks; ++c0) {
+            const bool need = (mask[i] >> c0) & 1u;
+            const unsigned long long m = __ballot(need);
+            const unsigned c = i * 32 + c0;
+            if (need)
+                chunk_list[chunk_off[c] + wave_off[(size_t)c * nwaves + wave] +
+                           (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = q;
+        }
     }
 }
 
@@ -640,17 +692,28 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
                                                                 unsigned chunk, const float* __restrict__ bound,
                                                                 const unsigned* __restrict__ chunk_cnt,
                                                                 const unsigned* __restrict__ chunk_off,
-                                                                const unsigned* __restrict__ chunk_list,
+                                                                const unsigned* __restrict__ blk_off, unsigned nchunks,
+                                                                unsigned subs, const unsigned* __restrict__ chunk_list,
                                                                 unsigned* __restrict__ cand_cnt,
                                                                 unsigned long long* __restrict__ cand) {
     __shared__ float4 tile[kTile];
-    const unsigned c = blockIdx.y;
+    const unsigned items = blk_off[nchunks];
+    for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {  // (workgroup-uniform)
+    unsigned lo = 0, hi = nchunks;  // the chunk of this work item: last c with blk_off[c] <= item
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (blk_off[mid] <= item) lo = mid;
+        else hi = mid;
+    }
+    const unsigned c = lo;
+    const unsigned local = item - blk_off[c];
     const unsigned listed = chunk_cnt[c];
-    const unsigned first = blockIdx.x * 2 * kBlock;
-    if (first >= listed) return;  // (workgroup-uniform)
+    const unsigned first = (local / subs) * 2 * kBlock;
+    const unsigned sub = local % subs;
     const unsigned* const list = chunk_list + chunk_off[c];
-    const unsigned t_begin = c * chunk;
-    const unsigned t_end = min(nt, t_begin + chunk);
+    const unsigned sub_len = chunk / subs;  // (a multiple of kGroup: chunks are whole LDS tiles, subs is 1, 2 or 4)
+    const unsigned t_begin = min(nt, c * chunk + sub * sub_len);
+    const unsigned t_end = min(nt, t_begin + sub_len);
     unsigned qid[2];
     v2f qx, qy, qz;
     float cap[2];
@@ -667,10 +730,10 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
         __syncthreads();
         // the tail of the last tile is padded with a point 1e18 away (finite distance, beyond every real bound; the
         // exact path below checks the index as well)
-        for (unsigned i = threadIdx.x; i < kTile; i += kBlock)
+        const unsigned ngroups = (cnt + kGroup - 1) / kGroup;
+        for (unsigned i = threadIdx.x; i < ngroups * kGroup; i += kBlock)
             tile[i] = i < cnt ? targets[base + i] : make_float4(1e18f, 1e18f, 1e18f, 0.0f);
         __syncthreads();
-        const unsigned ngroups = (cnt + kGroup - 1) / kGroup;
 #pragma unroll 2
         for (unsigned g = 0; g < ngroups; ++g) {
             v2f d[kGroup];
@@ -695,6 +758,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
                 }
             }
         }
+    }
     }
 }
 
@@ -827,9 +891,9 @@ BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     P.off_min = 0;
     P.off_bound = up(P.off_min + (size_t)P.a.nsplit * nq * 4);
-    // chunk list lengths | offsets (kMaxChunks each) | candidates per query | per-wave counts, chunk-major
-    P.off_counts = up(P.off_bound + 2 * nq * 4 + 64);  // (bound | bound for the chunk lists | box + frame)
-    P.off_chunk_list = up(P.off_counts + (2 * (size_t)kMaxChunks + nq + (size_t)P.a.nsplit * div_up(nq, (size_t)64)) * 4);
+    // chunk list lengths | offsets | work-item offsets (kMaxChunks (+1) each) | candidates per query | per-wave counts, chunk-major
+    P.off_counts = up(P.off_bound + nq * 4 + 64 + nq * 32);  // (bound | box + frame | need mask, 8 words per query)
+    P.off_chunk_list = up(P.off_counts + (3 * (size_t)kMaxChunks + 64 + nq + (size_t)P.a.nsplit * div_up(nq, (size_t)64)) * 4);
     P.off_cand = up(P.off_chunk_list + nq * (size_t)kMaxNeeded * 4);
     P.off_operands = up(P.off_cand + nq * (size_t)kCandCap * 8);  // bf16 rows of the targets | columns of the queries | |q^|^2
     const size_t rows = (size_t)P.a.nsplit * P.a.chunk, cols = div_up(nq, (size_t)kMfmaQueries) * (size_t)kMfmaQueries;
@@ -842,12 +906,13 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
     char* w = static_cast<char*>(ws);
     float* amin = reinterpret_cast<float*>(w + P.off_min);
     float* bound = reinterpret_cast<float*>(w + P.off_bound);
-    float* bound_need = bound + nq;
-    unsigned* box = reinterpret_cast<unsigned*>(bound_need + nq);
+    unsigned* box = reinterpret_cast<unsigned*>(bound + nq);
     BfFrame* frame = reinterpret_cast<BfFrame*>(box + 8);
+    uint4* need_mask = reinterpret_cast<uint4*>(w + ((P.off_bound + nq * 4 + 64 + 15) & ~(size_t)15));
     unsigned* chunk_cnt = reinterpret_cast<unsigned*>(w + P.off_counts);
     unsigned* chunk_off = chunk_cnt + kMaxChunks;
-    unsigned* cand_cnt = chunk_cnt + 2 * kMaxChunks;
+    unsigned* blk_off = chunk_cnt + 2 * kMaxChunks;
+    unsigned* cand_cnt = chunk_cnt + 3 * kMaxChunks + 64;
     unsigned* wave_cnt = cand_cnt + nq;
     unsigned* chunk_list = reinterpret_cast<unsigned*>(w + P.off_chunk_list);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(w + P.off_cand);
@@ -868,7 +933,7 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
         } else {
             knn_bf_prep_targets_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(t4, (unsigned)nt, rows, frame, tA);
             knn_bf_prep_queries_kernel<<<div_up(cols, kBlock), kBlock, 0, st>>>(q4, (unsigned)nq, cols, frame, qB, qq);
-            const unsigned cpw = 2;
+            const unsigned cpw = 2;  // chunks per workgroup (1 .. 14 and 2 / 4 / 8 tiles per wave all within 10 %: scratch/bf_sweep.sh)
             knn_bf_chunkmin_mfma_kernel<<<dim3(cols / kMfmaQueries, div_up(G, cpw)), kBlock, 0, st>>>(tA, qB, qq, (unsigned)nq, P.a.chunk,
                                                                                                       G, cpw, amin);
         }
@@ -876,13 +941,15 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
         knn_bf_k1_kernel<true><<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, nullptr, amin);
     }
     knn_bf_bound_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, (int)k, G, q4, approx ? frame : nullptr,
-                                                               g_pass_a_valu ? kValuErr : kMfmaErr, bound, bound_need, wave_cnt, nwaves,
+                                                               g_pass_a_valu ? kValuErr : kMfmaErr, bound, need_mask, wave_cnt, nwaves,
                                                                cand_cnt);
     knn_bf_wave_offsets_kernel<<<G, kBlock, 0, st>>>(wave_cnt, nwaves, chunk_cnt);
-    knn_bf_offsets_kernel<<<1, kMaxChunks, 0, st>>>(chunk_cnt, G, chunk_off);
-    knn_bf_lists_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(amin, (unsigned)nq, G, bound_need, chunk_off, wave_cnt, nwaves, chunk_list);
-    knn_bf_collect_kernel<<<dim3(P.b.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.b.chunk, bound,
-                                                                   chunk_cnt, chunk_off, chunk_list, cand_cnt, cand);
+    // few (query, chunk) pairs at small k: more, shorter work items (sub-ranges of a chunk's targets) keep every CU busy
+    const unsigned subs = k <= 4 ? 4u : (k <= 10 ? 2u : 1u);
+    knn_bf_offsets_kernel<<<1, kMaxChunks, 0, st>>>(chunk_cnt, G, subs, chunk_off, blk_off);
+    knn_bf_lists_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(need_mask, (unsigned)nq, G, chunk_off, wave_cnt, nwaves, chunk_list);
+    knn_bf_collect_kernel<<<kNumCU * 8, kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.b.chunk, bound, chunk_cnt, chunk_off,
+                                                         blk_off, G, subs, chunk_list, cand_cnt, cand);
     knn_bf_select_kernel<<<div_up(nq * 64, kBlock), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, (int)k, cand_cnt, cand, idx, d2);
     return launch_status();
 }
