@@ -671,16 +671,22 @@ __global__ __launch_bounds__(kBlock) void knn_bf_lists_kernel(const uint4* __res
         mask[0] = a.x; mask[1] = a.y; mask[2] = a.z; mask[3] = a.w;
         mask[4] = b.x; mask[5] = b.y; mask[6] = b.z; mask[7] = b.w;
     }
+    // where this wave's entries start in every chunk's list: fetched by all lanes at once (chunk c in lane c % 64), then
+    // broadcast per chunk — 196 dependent scalar loads in a row were most of this kernel at 1.5 waves per SIMD
+    unsigned start[kMaxChunks / 64];
+#pragma unroll
+    for (int j = 0; j < kMaxChunks / 64; ++j) {
+        const unsigned c = j * 64 + lane;
+        start[j] = (c < nchunks && wave < nwaves) ? chunk_off[c] + wave_off[(size_t)c * nwaves + wave] : 0u;
+    }
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 32; ++i) {
         if ((unsigned)i * 32u >= nchunks) break;  // (uniform)
         for (unsigned c0 = 0; c0 < 32 && i * 32 + c0 < nchunks; ++c0) {
             const bool need = (mask[i] >> c0) & 1u;
             const unsigned long long m = __ballot(need);
-            const unsigned c = i * 32 + c0;
-            if (need)
-                chunk_list[chunk_off[c] + wave_off[(size_t)c * nwaves + wave] +
-                           (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = q;
+            const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)start[i / 2], (i & 1) * 32 + c0);
+            if (need) chunk_list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = q;
         }
     }
 }
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
     const unsigned first = (local / subs) * 2 * kBlock;
     const unsigned sub = local % subs;
     const unsigned* const list = chunk_list + chunk_off[c];
-    const unsigned sub_len = chunk / subs;  // (a multiple of kGroup: chunks are whole LDS tiles, subs is 1, 2 or 4)
+    const unsigned sub_len = chunk / subs;  // (a multiple of kGroup: chunks are multiples of 256, subs is 1, 2 or 4)
     const unsigned t_begin = min(nt, c * chunk + sub * sub_len);
     const unsigned t_end = min(nt, t_begin + sub_len);
     unsigned qid[2];
@@ -880,7 +886,7 @@ BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
     if (k == 1 && nt > kApproxMaxTargets) return P;  // (exact minima only: the k = 1 kernel finishes the job itself)
     P.a.qpt = kQ1;
     P.a.qblocks = div_up(nq, (size_t)kBlock * kQ1);
-    P.a.chunk = div_up(div_up(nt, (size_t)kMaxChunks), kTile) * kTile;  // 1024 targets per chunk up to 256 K targets
+    P.a.chunk = div_up(div_up(nt, (size_t)kMaxChunks), (size_t)256) * 256;  // as many chunks as the need mask has bits
     P.a.nsplit = div_up(nt, P.a.chunk);
     if (P.a.nsplit < k) return P;
     P.b.qpt = 2;

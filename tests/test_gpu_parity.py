@@ -181,7 +181,7 @@ def test_bruteforce_pass_a_error_stays_inside_its_bound(sp, orc, valu):
         _lib.check(L.sp_knn_bruteforce_set_pass_a(0))
     oi, od = orc.knn_bruteforce(qry, tgt, k)
     assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d2.cpu().numpy(), od)
-    chunk = -(-(-(-nt // 256)) // 1024) * 1024
+    chunk = -(-(-(-nt // 256)) // 256) * 256  # (plan_bounded: at most 256 chunks, whole multiples of 256 targets)
     G = -(-nt // chunk)
     amin = ws[: G * nq * 4].view(torch.float32).reshape(G, nq).cpu().numpy().astype(np.float64)
     t64, q64 = tgt[:, :3].astype(np.float64), qry[:, :3].astype(np.float64)
