@@ -571,7 +571,8 @@ def reuse_off_comparison(sp, torch, args, S, prep, T_dev, T_ident, delta, sort_m
 def stage_block(sp, _lib, torch):
     """BASELINE configs 2 and 3 and the pre-loop of config 4 in the driver's line (outside the timed GICP region): each
     stage with inputs resident in HBM, the median of 11 single runs by HIP events, its rate and the fraction of the roofline
-    that bounds it (fp32 VALU for brute force at 9 operations per pair; HBM at the API-layout bytes otherwise).
+    that bounds it (brute force against the bf16 MFMA peak of its bounding pass, with the fp32 VALU roofline of
+    the reference's 9-operation expression beside it; HBM at the API-layout bytes otherwise).
     Outputs are preallocated; the voxel stage is the C-ABI call alone (key box of the previous cloud known, as from the
     second frame of a sensor on) without the host's read-back of the voxel count."""
     from sycl_points_amd.synthetic import Mt19937Cloud
@@ -582,11 +583,23 @@ def stage_block(sp, _lib, torch):
     g = Mt19937Cloud(1234)
     tgt = torch.from_numpy(g.uniform_points(100000, 10.0)).cuda()
     qry = torch.from_numpy(g.uniform_points(100000, 10.0)).cuda()
+    BF16 = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
     for k in (1, 20):
         ms, runs = median_ms(torch, lambda: sp.knn_search_bruteforce(qry, tgt, k))
+        _lib.check(L.sp_knn_bruteforce_set_pass_a(1))
+        try:
+            ms_valu, _ = median_ms(torch, lambda: sp.knn_search_bruteforce(qry, tgt, k), 5)
+        finally:
+            _lib.check(L.sp_knn_bruteforce_set_pass_a(0))
+        floor_ms = 1e10 * 2 * 16 / BF16 * 1e3  # pass A alone at the bf16 peak: one 32x32x16 MFMA (32 flop per pair) per 1024 pairs
         out[f"bruteforce_100k_x_100k_k{k}"] = {
-            "ms": ms, "runs": runs, "pairs_per_s": 1e10 / (ms * 1e-3), "bound": "fp32 VALU (9 operations per pair, LDS-tiled)",
-            "frac_of_bound": 9 * 1e10 / (ms * 1e-3) / FP32, "hbm_GBps_algorithmic": (16 * 2e5 + 8 * 1e5 * k) / (ms * 1e-3) / 1e9}
+            "ms": ms, "runs": runs, "pairs_per_s": 1e10 / (ms * 1e-3),
+            "bound": "bf16 MFMA: every pair goes through pass A (|p|^2 - 2 q.p on bf16-split operands, 32 flop per pair); the "
+                     "reference's fp32 expression is evaluated only for the (query, chunk) pairs that can hold a neighbour",
+            "frac_of_bound": floor_ms / ms,
+            "rate_vs_fp32_valu_roofline_of_the_reference_expression": 9 * 1e10 / (ms * 1e-3) / FP32,
+            "ms_with_pass_a_on_packed_fp32_valu": ms_valu,
+            "hbm_GBps_algorithmic": (16 * 2e5 + 8 * 1e5 * k) / (ms * 1e-3) / 1e9}
     del tgt, qry
     for name, R in (("sparse_R10", 10.0), ("dense_R2.5", 2.5)):
         n = 1_000_000

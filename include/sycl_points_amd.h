@@ -370,9 +370,11 @@ int sp_gicp_error_prepared(const sp_gicp_target* target, const sp_gicp_source* s
                            sp_linearized* out, void* workspace, size_t workspace_bytes, void* stream);
 /* Registration::align's whole Gauss-Newton loop (registration.hpp:229-276) enqueued by ONE call; pose, convergence flag and
  * iteration count stay in a state block of the workspace, nothing is read back by the host. Per iteration:
- *   streaming launch every point: cached correspondence when its reuse certificate holds, else exact NN on the grid ->
- *                    linearise -> one partial row per workgroup; the last-arriving workgroup sums the rows in a fixed
- *                    order, solves (H + lambda I) delta = -b, T <- T * se3_exp(delta) and publishes the next state.
+ *   streaming launch its first act finishes the PREVIOUS iteration, in every workgroup for itself: the previous launch's
+ *                    partial rows summed in a fixed order, (H + lambda I) delta = -b solved, T <- T * se3_exp(delta)
+ *                    (workgroup 0 publishes the state); then every point: cached correspondence when its reuse certificate
+ *                    holds, else exact NN on the grid -> linearise -> one partial row per workgroup.
+ *   after the last   a one-workgroup launch finishes the last iteration the same way and writes the outputs.
  * Once is_converged() (registration.hpp:407-410) holds, the remaining launches return at once, as the reference breaks out
  * of its loop. All pointers are device memory:
  *   transT_device  in: initial guess, out: final pose (column-major 4x4)
@@ -390,7 +392,8 @@ int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* sour
  *   for k in 0 .. max_iterations-1:  sp_gicp_align_step(k)                       (enqueue iteration k)
  *                                    all-reduce(sum) sp_gicp_align_rows(ws, k)   (32 KB of float32, in place, same stream order)
  *   sp_gicp_align_finish(last_k = max_iterations-1)
- * rows_all_reduced == 0: one GPU, the loop of sp_gicp_align_fused. With rows_all_reduced != 0 the streaming launch leaves
+ * rows_all_reduced == 0: one GPU, the loop of sp_gicp_align_fused (iteration k is finished by step k + 1, or by finish:
+ * lin_out and the state block describe iteration k only from then on). With rows_all_reduced != 0 the streaming launch leaves
  * its sums for the collective, and step k + 1 (and finish) first enqueue a one-workgroup kernel that finishes iteration k
  * from the all-reduced sums — the same sums and the same solve on every rank, hence the identical pose without a broadcast.
  * rows_all_reduced == 1: all partial rows travel (inlier counts as float VALUES, exact: < 2^24 per row); every rank must

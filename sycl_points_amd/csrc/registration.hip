@@ -943,11 +943,14 @@ __global__ __launch_bounds__(kBlock) void error_prepared_kernel(FusedParams P, M
 //   iteration k = gicp_align_kernel   (-> all-reduce -> align_solve_kernel, sharded runs)
 //
 // gicp_align_kernel streams the source once: per point the cached correspondence when its certificate holds, else a search
-// (fused_point), linearisation, 28 sums in registers, one 32-float partial row per workgroup. On one GPU the workgroup whose
-// arrival ticket is the last one then finishes the iteration by itself: it sums the launch's <= 256 rows in a fixed order,
-// solves (H + lambda I) delta = -b, updates the pose and publishes the next state — so the next launch starts from 18 words
-// instead of summing 32 KB and solving a 6x6 system in every one of its workgroups (round 2's prologue, 5.6 us of a 25 us
-// launch). Once is_converged() holds, the remaining launches return immediately (the reference breaks out of its loop).
+// (fused_point), linearisation, 28 sums in registers, one 32-float partial row per workgroup. On one GPU (ALIGN_PROLOGUE)
+// iteration k - 1 is finished at the START of launch k, by every workgroup for itself: sum the previous launch's <= 256
+// rows in a fixed order, solve (H + lambda I) delta = -b, update the pose (workgroup 0 also publishes the state).
+// Letting the workgroup with the last arrival ticket finish its own launch instead (18 words for the next launch to read
+// rather than 32 KB to sum in every workgroup) was built in round 3, measured on the same box and removed: the ticket round
+// trip, the sum and the solve then all sit behind the slowest workgroup while 255 CUs idle, and the next launch still starts
+// with a dependent read — 30.6 against 28.9 us per steady-state launch (profiles/r03_tail_solve_vs_prologue_same_box.txt).
+// Once is_converged() holds, the remaining launches return immediately (the reference breaks out of its loop).
 //
 // Measured and NOT kept (profiles/r03_search_launch_experiments_not_kept.txt, profiles/README.md): moving the searches of the
 // first iterations into a launch of their own (uncertified points compacted per workgroup, two queries per lane in
@@ -971,17 +974,22 @@ constexpr int kStateWords = sizeof(AlignState) / 4;
 constexpr int kStateFlagWord = 40;     // word index of AlignState::converged (iterations follows)
 static_assert(offsetof(AlignState, converged) == 4 * kStateFlagWord, "AlignState layout");
 
-enum { ALIGN_TAIL_SOLVE = 0, ALIGN_ROWS = 1, ALIGN_FANIN = 2, ALIGN_DIRECT = 3 };
+enum { ALIGN_PROLOGUE = 0, ALIGN_ROWS = 1, ALIGN_FANIN = 2, ALIGN_DIRECT = 3 };
 
 struct AlignArgs {
+    // ALIGN_PROLOGUE: the fields below describe the iteration the launch FINISHES first (k = its index, launch index - 1;
+    // `first`: launch 0, nothing to finish); every other mode: the iteration the launch (or align_solve_kernel) works on.
     const float* T_init;         // iteration 0
     const AlignState* state_in;  // state after iteration k - 1 (k > 0)
     AlignState* state_out;       // state after iteration k
     int has_prev;
+    int first;
+    const float* prev_rows;      // ALIGN_PROLOGUE: the partial rows of iteration k (written by the previous launch)
     float lambda, crit_rot, crit_trans;
     sp_linearized* lin_out;      // system of the last finished iteration (may be null)
-    // How iteration k is finished: ALIGN_TAIL_SOLVE the launch's last-arriving workgroup sums its rows and solves (one GPU);
-    // ALIGN_FANIN that workgroup writes ONE 128-byte row, the caller all-reduces it over the ranks and align_solve_kernel
+    // How iteration k is finished: ALIGN_PROLOGUE by the next launch (or align_solve_kernel after the last one) from the
+    // partial rows (one GPU); ALIGN_FANIN the launch's last-arriving workgroup sums the rows into ONE 128-byte row, the
+    // caller all-reduces it over the ranks and align_solve_kernel
     // finishes; ALIGN_ROWS the caller all-reduces all partial rows (counts travel as floats), then align_solve_kernel;
     // ALIGN_DIRECT that workgroup stores the row into every rank's slot buffer and align_solve_kernel waits for all rows.
     int mode;
@@ -1044,7 +1052,7 @@ __device__ __forceinline__ void align_finish_iteration(const AlignArgs& A, const
     if (A.lin_out) *A.lin_out = slin;
 }
 
-// End of a streaming launch in the ALIGN_TAIL_SOLVE / ALIGN_FANIN modes (MI355X_MICROARCH.md "fanin",
+// End of a streaming launch in the ALIGN_FANIN / ALIGN_DIRECT modes (MI355X_MICROARCH.md "fanin",
 // cdna_hip_programming.md Guideline 16, the counter form with sc1 loads in place of an acquire; every condition of its table
 // row holds):
 //   * every word of the rows was stored write-through (store_row_word<true>: global_store ... sc1) by lanes of wave 0,
@@ -1052,16 +1060,11 @@ __device__ __forceinline__ void align_finish_iteration(const AlignArgs& A, const
 //   * the workgroup whose ticket is the last one learns it from the value its add returned, tells its other waves through
 //     LDS + barrier, and reads every row with sc1 loads (never a plain load of another workgroup's bytes),
 //   * no fence, no spin: a workgroup either leaves or sums — nothing waits for a workgroup that has not been dispatched.
-// The sum is reduce_rows_1024's fixed order over the launch's `grid` rows: bit-reproducible, and the same bits in both modes.
+// The sum is reduce_rows_1024's fixed order over the launch's `grid` rows: bit-reproducible, the same bits as ALIGN_PROLOGUE's.
 // The last arriver resets the ticket counter for the next launch.
-__device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __restrict__ partials, const float* sT,
-                                           const unsigned* sflag) {
+__device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __restrict__ partials) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ unsigned s_last;
-    __shared__ sp_linearized slin;
-    __shared__ float sTn[16];
-    __shared__ float sdelta[8];
-    __shared__ LdltScratch ldlt_ws;
     if (threadIdx.x < kWave) {  // the storing lanes (0 .. kAcc) all sit in wave 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
@@ -1073,7 +1076,7 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
     if (!s_last) return;  // uniform per workgroup
     reduce_rows_1024<true>(partials, gridDim.x, kAcc - 1, red, false);
     const bool log_k = A.searched_log && A.k < kSearchedLog;
-    if (A.mode == ALIGN_FANIN || A.mode == ALIGN_DIRECT) {
+    {
         if (threadIdx.x < kFanRow) {
             const unsigned cnt = __float_as_uint(red[0][kAcc - 1]);
             float v = 0.0f;
@@ -1091,22 +1094,94 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
             }
         }
         if (threadIdx.x == 0 && log_k) A.searched_log[A.k] = (unsigned)red[0][kAcc];
-    } else if (threadIdx.x == 0) {
-        const unsigned searched = (unsigned)red[0][kAcc];
-        if (log_k) A.searched_log[A.k] = searched;
-        align_finish_iteration(A, red[0], sT, sflag[1], searched, slin, sTn, sdelta, ldlt_ws);
     }
     if (threadIdx.x == 0) __hip_atomic_store(A.fan_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int LOSS, bool FAST_NN, bool P2D = false>
+// ALIGN_PROLOGUE, start of launch k + 1: finish iteration k (A describes it) in every workgroup — the previous launch's rows
+// summed in reduce_rows_1024's fixed order, solve, pose update — and leave the new pose in sT. Workgroup 0 publishes the
+// state. Returns false when the alignment had converged before, or converges with this step: nothing left to do.
+// (Tried: this step, or the whole prologue, as a noinline function to keep its registers apart from the point loop's. The
+// step alone changes nothing; the whole prologue brings the POINT_TO_DISTRIBUTION instantiations from 1-5 spilled registers to
+// 1-2 but gives every instantiation a 184-byte stack frame per lane. Inlined, the GICP instantiations have no spill except
+// Tukey's one register.)
+__device__ __forceinline__ void prologue_step(const float* red0, sp_linearized* slin, float* sT, float lambda,
+                                                         float crit_rot, float crit_trans, float* sdelta, LdltScratch* ws) {
+    unpack_totals(red0, kAcc - 1, slin);
+    gn_update_impl(slin, sT, lambda, crit_rot, crit_trans, sdelta, false, *ws);
+}
+__device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT, unsigned* sflag) {
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ sp_linearized slin;
+    __shared__ float sdelta[8];
+    __shared__ LdltScratch ldlt_ws;
+    if (A.first) {
+        if (threadIdx.x < 16) sT[threadIdx.x] = A.T_init[threadIdx.x];
+        else if (threadIdx.x < 18) sflag[threadIdx.x - 16] = 0u;
+        // (a new alignment: the searched-point log starts empty — entry j is written when iteration j is finished)
+        if (blockIdx.x == 0 && A.searched_log && threadIdx.x >= 64 && threadIdx.x < 64 + kSearchedLog) A.searched_log[threadIdx.x - 64] = 0u;
+        __syncthreads();
+        return true;
+    }
+    // the previous state (18 words) is requested before the rows and stored after their loads have been issued: one
+    // memory round trip for both
+    unsigned sv = 0;
+    if (threadIdx.x < 18) {
+        if (A.has_prev)
+            sv = reinterpret_cast<const unsigned*>(A.state_in)[threadIdx.x < 16 ? threadIdx.x : kStateFlagWord + threadIdx.x - 16];
+        else
+            sv = threadIdx.x < 16 ? __float_as_uint(A.T_init[threadIdx.x]) : 0u;
+    }
+    reduce_rows_1024(A.prev_rows, gridDim.x, kAcc - 1, red, false, [=] {
+        if (threadIdx.x < 16) sT[threadIdx.x] = __uint_as_float(sv);
+        else if (threadIdx.x < 18) sflag[threadIdx.x - 16] = sv;
+    });
+    if (sflag[0]) {  // converged earlier (uniform over the grid): carry the state forward
+        if (blockIdx.x == 0 && threadIdx.x < kStateWords)
+            reinterpret_cast<unsigned*>(A.state_out)[threadIdx.x] = reinterpret_cast<const unsigned*>(A.state_in)[threadIdx.x];
+        return false;
+    }
+    if (threadIdx.x == 0) {
+        // (the step is applied to sT in place: no copy, no second barrier on the path every workgroup waits on)
+        AlignState* const so = A.state_out;
+        const bool publish = blockIdx.x == 0;
+        if (publish) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) so->T_lin[i] = sT[i];
+        }
+        prologue_step(red[0], &slin, sT, A.lambda, A.crit_rot, A.crit_trans, sdelta, &ldlt_ws);
+        if (publish) {
+            const unsigned searched = (unsigned)red[0][kAcc];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) so->T[i] = sT[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) so->delta[i] = sdelta[i];
+            so->converged = sdelta[6] > 0.5f ? 1u : 0u;
+            so->iterations = sflag[1] + 1;
+            so->searched = searched;
+            so->pad = 0;
+            if (A.searched_log && A.k < kSearchedLog) A.searched_log[A.k] = searched;
+            if (A.lin_out) *A.lin_out = slin;
+        }
+    }
+    __syncthreads();
+    return !(sdelta[6] > 0.5f);  // converged with this step: no further linearisation (registration.hpp:266-268)
+}
+
+// SHARDED = false: the single-GPU form (ALIGN_PROLOGUE) with nothing of the other modes compiled in — the exchange code
+// in the same kernel cost 0.4 us per launch (scalar register pressure at the kernel's start), measured on the same box.
+template <int LOSS, bool FAST_NN, bool P2D = false, bool SHARDED = false>
 __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, AlignArgs A,
                                                                  float* __restrict__ partials) {
     __shared__ float sT[16];
     __shared__ unsigned sflag[2];
-    if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag,
-                     (A.mode == ALIGN_FANIN || A.mode == ALIGN_DIRECT) ? A.fan_row_out : nullptr))
-        return;  // (converged: every rank holds the same state and stops at the same launch — nobody waits for a row)
+    if constexpr (!SHARDED) {
+        if (!align_prologue(A, sT, sflag)) return;
+    } else {
+        if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag,
+                         (A.mode == ALIGN_FANIN || A.mode == ALIGN_DIRECT) ? A.fan_row_out : nullptr))
+            return;  // (converged: every rank holds the same state and stops at the same launch — nobody waits for a row)
+    }
     // the pose is uniform: move it to scalar registers (it would otherwise occupy 12 VGPRs for the whole loop)
     Rigid T = load_rigid_colmajor(sT);
     auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -1127,18 +1202,44 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
         fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
-    if (A.mode == ALIGN_ROWS) {
+    if constexpr (!SHARDED) {
+        block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
+    } else if (A.mode == ALIGN_ROWS) {
         block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, true, searched);
     } else {
         block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
-        align_tail(A, partials, sT, sflag);
+        align_tail(A, partials);
     }
 }
 
 // Sharded runs: finishes iteration k on every rank from the all-reduced row (ALIGN_FANIN) or rows (ALIGN_ROWS) — the same
 // sums, the same solve, hence the identical pose on every rank without a broadcast. One workgroup.
+struct AlignPublish {  // after the LAST iteration: the results out of the state block (all null: nothing to publish)
+    float* T_out;
+    float* delta_out8;
+    uint32_t* iterations_out;
+    unsigned* xchg_epoch;
+};
+__device__ __forceinline__ void align_publish(const AlignState* state, const AlignPublish& Pb) {
+    // (the state was stored by a thread of this workgroup: fence + barrier, then read past the L1)
+    __threadfence();
+    __syncthreads();
+    if (!Pb.T_out) return;
+    const unsigned* const w = reinterpret_cast<const unsigned*>(state);
+    if (threadIdx.x < 16)
+        reinterpret_cast<unsigned*>(Pb.T_out)[threadIdx.x] = __hip_atomic_load(w + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (threadIdx.x < 24 && Pb.delta_out8)
+        reinterpret_cast<unsigned*>(Pb.delta_out8)[threadIdx.x - 16] =
+            __hip_atomic_load(w + 32 + (threadIdx.x - 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (threadIdx.x == 24 && Pb.iterations_out)
+        *Pb.iterations_out = __hip_atomic_load(w + kStateFlagWord + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (threadIdx.x == 32 && Pb.xchg_epoch)
+        *Pb.xchg_epoch += 1u;  // direct exchange: the next alignment's tags (sp_xchg.h)
+}
+static_assert(offsetof(AlignState, delta) == 4 * 32, "AlignState layout");
+
 __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A, const float* __restrict__ rows,
-                                                                    unsigned nrows) {
+                                                                    unsigned nrows, AlignPublish Pb) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ float sT[16];
     __shared__ unsigned sflag[2];
@@ -1146,7 +1247,10 @@ __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A,
     __shared__ float sTn[16];
     __shared__ float sdelta[8];
     __shared__ LdltScratch ldlt_ws;
-    if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag)) return;
+    if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag)) {
+        align_publish(A.state_out, Pb);
+        return;
+    }
     if (A.mode == ALIGN_DIRECT) {
         // wait for the row of every rank (bounded), then add them in rank order: the same sum on every rank
         __shared__ float xrow[kXchgMaxWorld][kFanRow];
@@ -1178,6 +1282,7 @@ __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A,
                 if (threadIdx.x == kStateFlagWord + 3) w = 1u;  // pad = error
                 reinterpret_cast<unsigned*>(A.state_out)[threadIdx.x] = w;
             }
+            align_publish(A.state_out, Pb);
             return;
         }
         if (threadIdx.x < kFanRow) {
@@ -1200,23 +1305,14 @@ __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A,
         else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points, all ranks (a float value)
         __syncthreads();
     } else {
-        reduce_rows_1024(rows, nrows, kAcc - 1, red, true);
+        reduce_rows_1024(rows, nrows, kAcc - 1, red, A.mode == ALIGN_ROWS);
     }
     if (threadIdx.x == 0) {
         const unsigned searched = (unsigned)red[0][kAcc];
-        if (A.mode == ALIGN_ROWS && A.searched_log && A.k < kSearchedLog) A.searched_log[A.k] = searched;
+        if ((A.mode == ALIGN_ROWS || A.mode == ALIGN_PROLOGUE) && A.searched_log && A.k < kSearchedLog) A.searched_log[A.k] = searched;
         align_finish_iteration(A, red[0], sT, sflag[1], searched, slin, sTn, sdelta, ldlt_ws);
     }
-}
-
-// After the last iteration: the results out of the state block.
-__global__ void align_publish_kernel(const AlignState* __restrict__ state, float* __restrict__ T_out,
-                                     float* __restrict__ delta_out8, uint32_t* __restrict__ iterations_out,
-                                     unsigned* __restrict__ xchg_epoch) {
-    if (threadIdx.x == 32 && xchg_epoch) *xchg_epoch += 1u;  // direct exchange: the next alignment's tags (sp_xchg.h)
-    if (threadIdx.x < 16) T_out[threadIdx.x] = state->T[threadIdx.x];
-    else if (threadIdx.x < 24 && delta_out8) delta_out8[threadIdx.x - 16] = state->delta[threadIdx.x - 16];
-    else if (threadIdx.x == 24 && iterations_out) *iterations_out = state->iterations;
+    align_publish(A.state_out, Pb);
 }
 
 unsigned reduce_grid(size_t n) {
@@ -1763,6 +1859,8 @@ AlignArgs align_args(const AlignWs& w, float* transT_device, const sp_gn_params*
     A.state_in = &w.state[(j + 1) & 1];
     A.state_out = &w.state[j & 1];
     A.has_prev = j > 0;
+    A.first = 0;
+    A.prev_rows = nullptr;
     A.lambda = gn->lambda;
     A.crit_rot = gn->crit_rotation;
     A.crit_trans = gn->crit_translation;
@@ -1783,11 +1881,13 @@ XchgArgs xchg_args(const sp_xchg* x, int j) {
     return XchgArgs{x->peers_dev, x->local, x->rank, x->world, x->epoch_dev,
                     (unsigned long long)x->timeout_ms * 100000ull};  // wall_clock64: 100 MHz
 }
+// (ALIGN_PROLOGUE: the rows of the last launch, `rows` = its grid; ALIGN_ROWS: all kAlignMaxBlocks all-reduced rows)
 void launch_solve(const AlignWs& w, float* transT_device, const sp_gn_params* gn, int j, int mode, sp_linearized* lin_out,
-                  hipStream_t st, const sp_xchg* x = nullptr) {
+                  hipStream_t st, const sp_xchg* x = nullptr, unsigned rows = kAlignMaxBlocks,
+                  AlignPublish Pb = AlignPublish{nullptr, nullptr, nullptr, nullptr}) {
     AlignArgs A = align_args(w, transT_device, gn, j, mode, lin_out);
     A.x = xchg_args(x, j);
-    align_solve_kernel<<<1, kFinalThreads, 0, st>>>(A, w.part[j & 1], (unsigned)kAlignMaxBlocks);
+    align_solve_kernel<<<1, kFinalThreads, 0, st>>>(A, w.part[j & 1], rows, Pb);
 }
 }  // namespace
 }  // namespace sp
@@ -1850,11 +1950,11 @@ int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, 
     if (k == 0) {
         // searched-point log, fan-in rows, arrival tickets (the caller's workspace comes as it is); ALIGN_ROWS: every rank
         // all-reduces all kAlignMaxBlocks rows whatever its own tile size, rows a rank does not write stay zero
-        if (zero_async(w.searched_log, kAlignResetBytes, st) != SP_OK) return SP_ERR_HIP;
+        if (mode != ALIGN_PROLOGUE && zero_async(w.searched_log, kAlignResetBytes, st) != SP_OK) return SP_ERR_HIP;
         if (mode == ALIGN_ROWS &&
             zero_async(w.part[0], 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != SP_OK)
             return SP_ERR_HIP;
-    } else if (mode != ALIGN_TAIL_SOLVE) {
+    } else if (mode != ALIGN_PROLOGUE) {
         // the caller has all-reduced iteration k - 1's row(s) / the peers are storing theirs into this rank's slots
         launch_solve(w, transT_device, gn, k - 1, mode, lin_out, st, xchg);
     }
@@ -1864,15 +1964,23 @@ int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, 
     const unsigned grid = align_grid(n);
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
     AlignArgs A = align_args(w, transT_device, gn, k, mode, lin_out);
+    if (mode == ALIGN_PROLOGUE) {  // the launch first finishes iteration k - 1 from the previous launch's rows
+        A = align_args(w, transT_device, gn, k > 0 ? k - 1 : 0, mode, lin_out);
+        A.first = k == 0;
+        A.prev_rows = w.part[(k + 1) & 1];
+    }
     A.x = xchg_args(xchg, k);
     float* out = w.part[k & 1];
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
-#define SP_LAUNCH_ALIGN(L)                                                                            \
-    if (!(source->opt_stage_mask & 1)) {}                                                                 \
-    else if (fast && p2d) gicp_align_kernel<L, true, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);     \
-    else if (fast) gicp_align_kernel<L, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);              \
-    else if (p2d) gicp_align_kernel<L, false, true><<<grid, kAlignBlock, 0, st>>>(P, A, out);         \
-    else gicp_align_kernel<L, false><<<grid, kAlignBlock, 0, st>>>(P, A, out)
+#define SP_LAUNCH_ALIGN2(L, S)                                                                          \
+    if (fast && p2d) gicp_align_kernel<L, true, true, S><<<grid, kAlignBlock, 0, st>>>(P, A, out);         \
+    else if (fast) gicp_align_kernel<L, true, false, S><<<grid, kAlignBlock, 0, st>>>(P, A, out);          \
+    else if (p2d) gicp_align_kernel<L, false, true, S><<<grid, kAlignBlock, 0, st>>>(P, A, out);           \
+    else gicp_align_kernel<L, false, false, S><<<grid, kAlignBlock, 0, st>>>(P, A, out)
+#define SP_LAUNCH_ALIGN(L)                                                                             \
+    if (!(source->opt_stage_mask & 1)) {}                                                                  \
+    else if (mode == ALIGN_PROLOGUE) { SP_LAUNCH_ALIGN2(L, false); }                                      \
+    else { SP_LAUNCH_ALIGN2(L, true); }
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_ALIGN(LOSS_NONE); break;
         case SP_LOSS_HUBER: SP_LAUNCH_ALIGN(LOSS_HUBER); break;
@@ -1882,6 +1990,7 @@ int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, 
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
 #undef SP_LAUNCH_ALIGN
+#undef SP_LAUNCH_ALIGN2
     if (fills_cache) source->cache_valid = true;
     return launch_status();
 }
@@ -1922,9 +2031,9 @@ int align_finish_impl(const sp_gicp_source* source, float* transT_device, const 
     }
     const AlignWs w = align_ws(workspace);
     if (source->opt_stage_mask & 2) {
-        if (rows_all_reduced != ALIGN_TAIL_SOLVE) launch_solve(w, transT_device, gn, last_k, rows_all_reduced, lin_out, st, xchg);
-        align_publish_kernel<<<1, kWave, 0, st>>>(&w.state[last_k & 1], transT_device, delta_out8, iterations_out,
-                                                  xchg ? xchg->epoch_dev : nullptr);
+        launch_solve(w, transT_device, gn, last_k, rows_all_reduced, lin_out, st, xchg,
+                     rows_all_reduced == ALIGN_PROLOGUE ? align_grid(source->n) : (unsigned)kAlignMaxBlocks,
+                     AlignPublish{transT_device, delta_out8, iterations_out, xchg ? xchg->epoch_dev : nullptr});
     }
     return launch_status();
 }
