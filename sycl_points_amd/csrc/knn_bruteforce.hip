@@ -355,15 +355,16 @@ __global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_kernel(const float4* _
     for (unsigned base = t_begin; base < t_end; base += kTile) {
         const unsigned cnt = min((unsigned)kTile, t_end - base);
         __syncthreads();
-        // (the tail of the last tile repeats its first point: a duplicate cannot change the minimum)
-        for (unsigned i = threadIdx.x; i < kTile; i += kBlock) {
+        // (the tile is padded to a multiple of 4 with copies of its first point: a duplicate cannot change the minimum)
+        const unsigned padded = (cnt + 3u) & ~3u;
+        for (unsigned i = threadIdx.x; i < padded; i += kBlock) {
             const float4 p = targets[base + (i < cnt ? i : 0u)];
             const float x = p.x - cx, y = p.y - cy, z = p.z - cz;
             tile[i] = make_float4(-2.0f * x, -2.0f * y, -2.0f * z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
         }
         __syncthreads();
 #pragma unroll 4
-        for (int j = 0; j < kTile; ++j) {
+        for (unsigned j = 0; j < padded; ++j) {
             const float4 t = tile[j];  // same address in every lane: one broadcast LDS read
             const v2f axy = {t.x, t.y}, czw = {t.z, t.w};
 #pragma unroll
