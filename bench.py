@@ -351,8 +351,8 @@ def main():
                                     ("sp_gicp_align_sharded over the library's RCCL communicator" if comm is not None
                                      else "torch.distributed all-reduce")),
                        "exchange_fallback": exchange_fallback,
-                       "launch": ("one C call per alignment: two launches per iteration (linearise; wait for the peers' rows + "
-                                  "solve), nothing from the host in between" if xchg is not None else
+                       "launch": ("one C call per alignment: one launch per iteration (its prologue waits for the peers' rows of the "
+                                  "previous iteration and solves), nothing from the host in between" if xchg is not None else
                                   "one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
                                   else ("per-iteration launches + all-reduce from the host" if group is not None
                                         else "one C call per alignment"))},

@@ -394,8 +394,8 @@ int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* sour
  *   sp_gicp_align_finish(last_k = max_iterations-1)
  * rows_all_reduced == 0: one GPU, the loop of sp_gicp_align_fused (iteration k is finished by step k + 1, or by finish:
  * lin_out and the state block describe iteration k only from then on). With rows_all_reduced != 0 the streaming launch leaves
- * its sums for the collective, and step k + 1 (and finish) first enqueue a one-workgroup kernel that finishes iteration k
- * from the all-reduced sums — the same sums and the same solve on every rank, hence the identical pose without a broadcast.
+ * its sums for the collective, and launch k + 1 (after the last one: finish) finishes iteration k from the all-reduced sums
+ * in its prologue — the same sums and the same solve on every rank, hence the identical pose without a broadcast.
  * rows_all_reduced == 1: all partial rows travel (inlier counts as float VALUES, exact: < 2^24 per row); every rank must
  * all-reduce all of sp_gicp_align_rows' floats (rows a rank does not use are zeroed by step 0). All ranks must pass the same
  * rows_all_reduced. transT_device must not be written between step 0 and finish. */
@@ -513,8 +513,9 @@ int sp_gicp_align_sharded(const sp_gicp_target* target, const sp_gicp_source* so
  * library launch between two kernels, 15-30 us on an 8-GPU node against ~30 us of compute per iteration. Here every rank owns
  * a small slot buffer in uncached device memory and maps its peers' (hipIpc handles, exchanged ONCE through the caller's own
  * channel); the streaming launch's last-arriving workgroup stores the rank's 128-byte row, tagged with the iteration's
- * sequence number, straight into every rank's buffer over xGMI, and the one-workgroup solve launch that follows waits until
- * all `world` rows carry the tag, adds them in rank order (identical sums, identical pose on every rank) and solves.
+ * sequence number, straight into every rank's buffer over xGMI, and the NEXT streaming launch's prologue (every workgroup
+ * for itself) waits until all `world` rows carry the tag, adds them in rank order (identical sums, identical pose on every
+ * rank) and solves: one launch per iteration, nothing in between.
  *   sp_xchg_create / sp_xchg_handle / sp_xchg_connect   every rank creates, all ranks gather the SP_XCHG_HANDLE_BYTES-byte
  *                       handles in rank order (MPI_Allgather, torch.distributed, a file ...) and connect; world <= 8
  *   sp_gicp_align_direct   arguments as sp_gicp_align_sharded; only enqueues; every rank must call it the same number of

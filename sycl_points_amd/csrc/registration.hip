@@ -994,7 +994,8 @@ struct AlignArgs {
     // ALIGN_DIRECT that workgroup stores the row into every rank's slot buffer and align_solve_kernel waits for all rows.
     int mode;
     unsigned* searched_log;      // [iteration] -> source points searched for
-    int k;                       // index of this iteration in its alignment
+    int k;                       // index of the iteration that is being FINISHED (prologue / align_solve_kernel)
+    int k_launch;                // index of the iteration the streaming launch itself works on (its row, its tag)
     float* fan_row_out;          // this iteration's row (kFanRow floats)
     const float* fan_row_in;     // align_solve_kernel: the same row, all-reduced over the ranks
     unsigned* fan_counter;       // arrival tickets; 0 when a launch starts, reset by the last arriver
@@ -1075,7 +1076,7 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
     __syncthreads();
     if (!s_last) return;  // uniform per workgroup
     reduce_rows_1024<true>(partials, gridDim.x, kAcc - 1, red, false);
-    const bool log_k = A.searched_log && A.k < kSearchedLog;
+    const bool log_k = A.searched_log && A.k_launch < kSearchedLog;
     {
         if (threadIdx.x < kFanRow) {
             const unsigned cnt = __float_as_uint(red[0][kAcc - 1]);
@@ -1086,14 +1087,14 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
             else if (threadIdx.x == kAcc + 1) v = red[0][kAcc];
             A.fan_row_out[threadIdx.x] = v;
             if (A.mode == ALIGN_DIRECT) {  // the row, tagged, into slot [k & 1][rank] of every rank's buffer (sp_xchg.h)
-                const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k + 1u;
+                const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k_launch + 1u;
                 const unsigned long long granule = ((unsigned long long)seq << 32) | __float_as_uint(v);
-                const size_t slot = ((size_t)(A.k & 1) * A.x.world + A.x.rank) * kFanRow + threadIdx.x;
+                const size_t slot = ((size_t)(A.k_launch & 1) * A.x.world + A.x.rank) * kFanRow + threadIdx.x;
                 for (int r = 0; r < A.x.world; ++r)
                     __hip_atomic_store(A.x.peers[r] + slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        if (threadIdx.x == 0 && log_k) A.searched_log[A.k] = (unsigned)red[0][kAcc];
+        if (threadIdx.x == 0 && log_k) A.searched_log[A.k_launch] = (unsigned)red[0][kAcc];
     }
     if (threadIdx.x == 0) __hip_atomic_store(A.fan_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1101,6 +1102,78 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
 // ALIGN_PROLOGUE, start of launch k + 1: finish iteration k (A describes it) in every workgroup — the previous launch's rows
 // summed in reduce_rows_1024's fixed order, solve, pose update — and leave the new pose in sT. Workgroup 0 publishes the
 // state. Returns false when the alignment had converged before, or converges with this step: nothing left to do.
+// Totals of iteration A.k -> red[0] (28 sums, the uint32 count, the searched count as a float value), by mode: the partial
+// rows of one launch (ALIGN_PROLOGUE) or the all-reduced ones (ALIGN_ROWS: counts as float values), the all-reduced fan-in
+// row (ALIGN_FANIN), or the rows the ranks stored into this rank's slot buffer (ALIGN_DIRECT: bounded wait, rows added in
+// rank order — the same sum on every rank). `after_loads` runs once the loads are issued. Returns false when a peer's row
+// did not arrive in time. Ends with a barrier.
+template <bool SHARDED, typename Hook>
+__device__ __forceinline__ bool align_totals(const AlignArgs& A, const float* __restrict__ rows, unsigned nrows,
+                                             float (*red)[kPartial], Hook after_loads, const unsigned* converged = nullptr) {
+    if constexpr (!SHARDED) {
+        reduce_rows_1024(rows, nrows, kAcc - 1, red, false, after_loads);
+        return true;
+    } else {
+        if (A.mode == ALIGN_ROWS || A.mode == ALIGN_PROLOGUE) {
+            reduce_rows_1024(rows, nrows, kAcc - 1, red, A.mode == ALIGN_ROWS, after_loads);
+            return true;
+        }
+        if (A.mode == ALIGN_DIRECT) {
+            __shared__ float xrow[kXchgMaxWorld][kFanRow];
+            __shared__ unsigned s_late;
+            after_loads();
+            if (threadIdx.x == 0) s_late = 0u;
+            __syncthreads();
+            if (converged && *converged) return true;  // (set by `after_loads`: nobody has stored a row, do not wait for one)
+            if (threadIdx.x < (unsigned)A.x.world * kFanRow) {
+                const unsigned r = threadIdx.x / kFanRow, e = threadIdx.x % kFanRow;
+                const unsigned long long* const g = A.x.local + ((size_t)(A.k & 1) * A.x.world + r) * kFanRow + e;
+                const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k + 1u;
+                const unsigned long long t0 = wall_clock64();
+                unsigned long long v = 0;
+                bool ok = false;
+                for (;;) {
+                    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((unsigned)(v >> 32) == seq) { ok = true; break; }
+                    if (wall_clock64() - t0 > A.x.budget) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (!ok) s_late = 1u;
+                xrow[r][e] = ok ? __uint_as_float((unsigned)v) : 0.0f;
+            }
+            __syncthreads();
+            if (s_late) return false;
+            if (threadIdx.x < kFanRow) {
+                float sum = 0.0f;
+                for (int r = 0; r < A.x.world; ++r) sum += xrow[r][threadIdx.x];
+                red[1][threadIdx.x] = sum;
+            }
+        } else {  // ALIGN_FANIN
+            const float rv = threadIdx.x < kFanRow ? A.fan_row_in[threadIdx.x] : 0.0f;
+            after_loads();
+            if (threadIdx.x < kFanRow) red[1][threadIdx.x] = rv;
+        }
+        __syncthreads();
+        if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
+        else if (threadIdx.x == kAcc - 1)  // the count, folded as integers: exact
+            red[0][kAcc - 1] = __uint_as_float((unsigned)red[1][kAcc] * 4096u + (unsigned)red[1][kAcc - 1]);
+        else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points, all ranks (a float value)
+        __syncthreads();
+        return true;
+    }
+}
+// A peer's row did not arrive (ALIGN_DIRECT): the state says converged + error, so the remaining launches return at once and
+// sp_gicp_align_status reports it.
+__device__ __forceinline__ void align_store_late_state(const AlignArgs& A) {
+    if (threadIdx.x < kStateWords) {
+        unsigned w = A.has_prev ? reinterpret_cast<const unsigned*>(A.state_in)[threadIdx.x] : 0u;
+        if (!A.has_prev && threadIdx.x < 16) w = __float_as_uint(A.T_init[threadIdx.x]);
+        if (threadIdx.x == kStateFlagWord) w = 1u;      // converged
+        if (threadIdx.x == kStateFlagWord + 3) w = 1u;  // pad = error
+        reinterpret_cast<unsigned*>(A.state_out)[threadIdx.x] = w;
+    }
+}
+
 // (Tried: this step, or the whole prologue, as a noinline function to keep its registers apart from the point loop's. The
 // step alone changes nothing; the whole prologue brings the POINT_TO_DISTRIBUTION instantiations from 1-5 spilled registers to
 // 1-2 but gives every instantiation a 184-byte stack frame per lane. Inlined, the GICP instantiations have no spill except
@@ -1110,6 +1183,7 @@ __device__ __forceinline__ void prologue_step(const float* red0, sp_linearized* 
     unpack_totals(red0, kAcc - 1, slin);
     gn_update_impl(slin, sT, lambda, crit_rot, crit_trans, sdelta, false, *ws);
 }
+template <bool SHARDED>
 __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT, unsigned* sflag) {
     __shared__ float red[kFinalThreads / 32][kPartial];
     __shared__ sp_linearized slin;
@@ -1118,8 +1192,10 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT, un
     if (A.first) {
         if (threadIdx.x < 16) sT[threadIdx.x] = A.T_init[threadIdx.x];
         else if (threadIdx.x < 18) sflag[threadIdx.x - 16] = 0u;
-        // (a new alignment: the searched-point log starts empty — entry j is written when iteration j is finished)
-        if (blockIdx.x == 0 && A.searched_log && threadIdx.x >= 64 && threadIdx.x < 64 + kSearchedLog) A.searched_log[threadIdx.x - 64] = 0u;
+        // (a new alignment: the searched-point log starts empty — entry j is written when iteration j is finished; the sharded
+        // modes clear it with their tickets and rows before launch 0)
+        if (!SHARDED && blockIdx.x == 0 && A.searched_log && threadIdx.x >= 64 && threadIdx.x < 64 + kSearchedLog)
+            A.searched_log[threadIdx.x - 64] = 0u;
         __syncthreads();
         return true;
     }
@@ -1132,10 +1208,15 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT, un
         else
             sv = threadIdx.x < 16 ? __float_as_uint(A.T_init[threadIdx.x]) : 0u;
     }
-    reduce_rows_1024(A.prev_rows, gridDim.x, kAcc - 1, red, false, [=] {
+    const unsigned nrows = (SHARDED && A.mode == ALIGN_ROWS) ? (unsigned)kAlignMaxBlocks : gridDim.x;
+    const bool arrived = align_totals<SHARDED>(A, A.prev_rows, nrows, red, [=] {
         if (threadIdx.x < 16) sT[threadIdx.x] = __uint_as_float(sv);
         else if (threadIdx.x < 18) sflag[threadIdx.x - 16] = sv;
-    });
+    }, sflag);
+    if (!arrived) {  // (uniform per workgroup; every workgroup of every rank runs into the same bound)
+        if (blockIdx.x == 0) align_store_late_state(A);
+        return false;
+    }
     if (sflag[0]) {  // converged earlier (uniform over the grid): carry the state forward
         if (blockIdx.x == 0 && threadIdx.x < kStateWords)
             reinterpret_cast<unsigned*>(A.state_out)[threadIdx.x] = reinterpret_cast<const unsigned*>(A.state_in)[threadIdx.x];
@@ -1175,13 +1256,8 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
                                                                  float* __restrict__ partials) {
     __shared__ float sT[16];
     __shared__ unsigned sflag[2];
-    if constexpr (!SHARDED) {
-        if (!align_prologue(A, sT, sflag)) return;
-    } else {
-        if (!align_begin(A.T_init, A.state_in, A.state_out, A.has_prev, sT, sflag,
-                         (A.mode == ALIGN_FANIN || A.mode == ALIGN_DIRECT) ? A.fan_row_out : nullptr))
-            return;  // (converged: every rank holds the same state and stops at the same launch — nobody waits for a row)
-    }
+    // (converged: every rank holds the same state and stops at the same launch — nobody waits for a row)
+    if (!align_prologue<SHARDED>(A, sT, sflag)) return;
     // the pose is uniform: move it to scalar registers (it would otherwise occupy 12 VGPRs for the whole loop)
     Rigid T = load_rigid_colmajor(sT);
     auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -1251,61 +1327,10 @@ __global__ __launch_bounds__(kFinalThreads) void align_solve_kernel(AlignArgs A,
         align_publish(A.state_out, Pb);
         return;
     }
-    if (A.mode == ALIGN_DIRECT) {
-        // wait for the row of every rank (bounded), then add them in rank order: the same sum on every rank
-        __shared__ float xrow[kXchgMaxWorld][kFanRow];
-        __shared__ unsigned s_late;
-        if (threadIdx.x == 0) s_late = 0u;
-        __syncthreads();
-        if (threadIdx.x < (unsigned)A.x.world * kFanRow) {
-            const unsigned r = threadIdx.x / kFanRow, e = threadIdx.x % kFanRow;
-            const unsigned long long* const g = A.x.local + ((size_t)(A.k & 1) * A.x.world + r) * kFanRow + e;
-            const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k + 1u;
-            const unsigned long long t0 = wall_clock64();
-            unsigned long long v = 0;
-            bool ok = false;
-            for (;;) {
-                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned)(v >> 32) == seq) { ok = true; break; }
-                if (wall_clock64() - t0 > A.x.budget) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (!ok) s_late = 1u;
-            xrow[r][e] = ok ? __uint_as_float((unsigned)v) : 0.0f;
-        }
-        __syncthreads();
-        if (s_late) {  // a peer's row did not arrive: stop the alignment here and say so (sp_gicp_align_status)
-            if (threadIdx.x < kStateWords) {
-                unsigned w = A.has_prev ? reinterpret_cast<const unsigned*>(A.state_in)[threadIdx.x] : 0u;
-                if (!A.has_prev && threadIdx.x < 16) w = __float_as_uint(A.T_init[threadIdx.x]);
-                if (threadIdx.x == kStateFlagWord) w = 1u;      // converged: the remaining launches return at once
-                if (threadIdx.x == kStateFlagWord + 3) w = 1u;  // pad = error
-                reinterpret_cast<unsigned*>(A.state_out)[threadIdx.x] = w;
-            }
-            align_publish(A.state_out, Pb);
-            return;
-        }
-        if (threadIdx.x < kFanRow) {
-            float sum = 0.0f;
-            for (int r = 0; r < A.x.world; ++r) sum += xrow[r][threadIdx.x];
-            red[1][threadIdx.x] = sum;
-        }
-        __syncthreads();
-        if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
-        else if (threadIdx.x == kAcc - 1)  // the count, folded as integers: exact
-            red[0][kAcc - 1] = __uint_as_float((unsigned)red[1][kAcc] * 4096u + (unsigned)red[1][kAcc - 1]);
-        else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points, all ranks (a float value)
-        __syncthreads();
-    } else if (A.mode == ALIGN_FANIN) {
-        if (threadIdx.x < kFanRow) red[1][threadIdx.x] = A.fan_row_in[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x < kAcc - 1) red[0][threadIdx.x] = red[1][threadIdx.x];
-        else if (threadIdx.x == kAcc - 1)  // the count, folded as integers: exact
-            red[0][kAcc - 1] = __uint_as_float((unsigned)red[1][kAcc] * 4096u + (unsigned)red[1][kAcc - 1]);
-        else if (threadIdx.x == kAcc) red[0][kAcc] = red[1][kAcc + 1];  // searched points, all ranks (a float value)
-        __syncthreads();
-    } else {
-        reduce_rows_1024(rows, nrows, kAcc - 1, red, A.mode == ALIGN_ROWS);
+    if (!align_totals<true>(A, rows, nrows, red, [] {})) {
+        align_store_late_state(A);
+        align_publish(A.state_out, Pb);
+        return;
     }
     if (threadIdx.x == 0) {
         const unsigned searched = (unsigned)red[0][kAcc];
@@ -1868,6 +1893,7 @@ AlignArgs align_args(const AlignWs& w, float* transT_device, const sp_gn_params*
     A.mode = mode;
     A.searched_log = w.searched_log;
     A.k = j;
+    A.k_launch = j;
     A.fan_row_out = w.fan_row[j & 1];
     A.fan_row_in = w.fan_row[j & 1];
     A.fan_counter = w.fan_counter;
@@ -1954,21 +1980,19 @@ int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, 
         if (mode == ALIGN_ROWS &&
             zero_async(w.part[0], 2 * (size_t)kAlignMaxBlocks * kPartial * sizeof(float), st) != SP_OK)
             return SP_ERR_HIP;
-    } else if (mode != ALIGN_PROLOGUE) {
-        // the caller has all-reduced iteration k - 1's row(s) / the peers are storing theirs into this rank's slots
-        launch_solve(w, transT_device, gn, k - 1, mode, lin_out, st, xchg);
     }
     target->note(st);
     const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
     const bool fills_cache = P.ccache != nullptr && (source->opt_stage_mask & 1);
     const unsigned grid = align_grid(n);
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
-    AlignArgs A = align_args(w, transT_device, gn, k, mode, lin_out);
-    if (mode == ALIGN_PROLOGUE) {  // the launch first finishes iteration k - 1 from the previous launch's rows
-        A = align_args(w, transT_device, gn, k > 0 ? k - 1 : 0, mode, lin_out);
-        A.first = k == 0;
-        A.prev_rows = w.part[(k + 1) & 1];
-    }
+    // the launch first finishes iteration k - 1: from the previous launch's rows (one GPU), from the all-reduced row(s), or
+    // from the rows the peers are storing into this rank's slots
+    AlignArgs A = align_args(w, transT_device, gn, k > 0 ? k - 1 : 0, mode, lin_out);
+    A.first = k == 0;
+    A.prev_rows = w.part[(k + 1) & 1];
+    A.k_launch = k;
+    A.fan_row_out = w.fan_row[k & 1];
     A.x = xchg_args(xchg, k);
     float* out = w.part[k & 1];
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
@@ -2048,10 +2072,10 @@ extern "C" int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_
                                  workspace, workspace_bytes, stream, nullptr);
 }
 
-// The sharded loop with the rows exchanged DIRECTLY between the ranks' buffers (sp_xchg.h): per iteration the streaming
-// launch (its last-arriving workgroup stores the rank's row into every rank's slot buffer) and the one-workgroup solve launch
-// that waits for all rows — no collective, no host involvement; the latency-bound 128-byte all-reduce of
-// sp_gicp_align_sharded (a library launch of its own between the two kernels) is gone.
+// The sharded loop with the rows exchanged DIRECTLY between the ranks' buffers (sp_xchg.h): per iteration ONE launch — its
+// last-arriving workgroup stores the rank's row into every rank's slot buffer, the next launch's prologue waits for all rows —
+// no collective, no host involvement; the latency-bound 128-byte all-reduce of sp_gicp_align_sharded (a library launch of its
+// own between two kernels) is gone.
 extern "C" int sp_gicp_align_direct(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                                    const sp_factor_params* params, const sp_gn_params* gn, int max_iterations, sp_xchg* xchg,
                                    int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,

@@ -65,9 +65,9 @@ def test_per_iteration_kernels_do_not_spill():
         single_gpu = re.search(r"gicp_align_kernelILi\dELb[01]ELb[01]ELb0E", row) is not None
         if "gicp_align_kernelILi0ELb1ELb0ELb0E" in row:  # the benchmarked instantiation
             assert spills == 0, row
-        # GICP: none (Tukey's weight keeps one more value alive: one register); POINT_TO_DISTRIBUTION: a few registers in the
-        # single-GPU form, whose launch also carries the solve of the previous iteration
-        assert spills <= ((5 if single_gpu else 2) if p2d else (1 if tukey else 0)), row
+        # GICP: none (Tukey's weight keeps one more value alive: one register); POINT_TO_DISTRIBUTION: up to five registers
+        # (its own point loop is still open)
+        assert spills <= (5 if p2d else (1 if tukey else 0)), (single_gpu, row)
 
 
 def test_sp_linearized_is_192_bytes():
