@@ -415,6 +415,270 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_tile_kernel(const float4*
     self_knn_outputs<KCAP>(pts, q, bd, bi, bp, k, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lane per query for LONG lists (7 <= k <= 24): bound, collect, sort — no insertion anywhere.
+// The wave-cooperative kernel below spends ~630 vector instructions on ONE query (a 64-lane sorting network and ballot-ranked
+// insertions); a lane-per-query kernel does 64 queries per instruction but could not keep a sorted 20-entry list cheaply
+// (every insertion is a 20-step select chain that the whole wave walks). Here nothing is kept sorted while scanning:
+//   1. the lane's candidates — its 3x3x3 cells = nine x-segments of the cell-ordered array, up to kSelCand points — are
+//      fetched once; their squared distances stay in the lane's LDS column as 7-bit keys (192 bytes per lane; a register
+//      array, fully unrolled, made the compiler spill 700-900 registers; 16-bit keys allowed one wave per SIMD only and the
+//      kernel was latency-bound at 1.45 ms per 1 M points);
+//   2. a threshold t with k <= #{key <= t} <= 32 is found on those keys by the t^1.5 law of points in a ball, two or three
+//      counting passes (the key scale comes from the lane's own candidate count);
+//   3. the <= 32 candidates within t go to a per-lane list in LDS, come back as exact 64-bit (distance, index) keys and each
+//      is RANKED among the lane's keys (a branch-free count): lexicographic order = brute force's tie rule; ranks < k are
+//      the list, written straight to their places;
+//   4. exactness as in the tile kernel: the k-th distance must be inside the block's coverage, otherwise (or when a segment
+//      is longer than its slots, or no threshold is found) the query goes to the to-do list of the ring-walk kernel.
+// Same lists, distances and covariances as the other kernels, bit for bit.
+constexpr int kSelCand = 192;  // candidates of one query (27 cells: 162 at the default density, sigma 13)
+constexpr int kSelList = 32;   // entries that may pass the threshold
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float4* __restrict__ pts,
+                                                                     const unsigned* __restrict__ start,
+                                                                     const unsigned* __restrict__ unit_off, GridDesc g,
+                                                                     int k, TileOut out) {
+    // the lane's keys, one byte each, in groups of eight (one ds_read_b64 per eight candidates), [group][lane]: conflict-free
+    __shared__ unsigned long long l_key8[kSelCand / 8][kWave];  // 12 KB
+    __shared__ int l_pos[kSelList][kWave];                      //  8 KB  (20 KB per wave: eight waves per CU)
+    unsigned char* const l_key = reinterpret_cast<unsigned char*>(&l_key8[0][0]);
+    const unsigned unit = blockIdx.x;
+    const unsigned rows = (unsigned)g.ny * g.nz;
+    unsigned lo = 0, hi = rows;
+    while (hi - lo > 1) {  // row of this unit: last r with unit_off[r] <= unit (wave-uniform)
+        const unsigned mid = (lo + hi) >> 1;
+        if (unit_off[mid] <= unit) lo = mid;
+        else hi = mid;
+    }
+    const unsigned row = lo;
+    const int ry = (int)(row % g.ny), rz = (int)(row / g.ny);
+    const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
+    const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
+    const unsigned qe = min(qs + 64u, row_e);
+    if (qe <= out.pos_lo || qs >= out.pos_hi) return;  // wave-uniform: the unit lies outside the requested range
+    const unsigned lane = threadIdx.x;
+    const unsigned qpos = min(qs + lane, qe - 1);
+    const bool active = qs + lane < qe && qs + lane >= out.pos_lo && qs + lane < out.pos_hi;
+    const float4 q = pts[qpos];
+    const int cx = cell_coord(q.x, g.ox, g.inv_h, g.nx);
+    const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+    const int ya = max(ry - 1, 0), yb = min(ry + 1, g.ny - 1), za = max(rz - 1, 0), zb = min(rz + 1, g.nz - 1);
+    auto key_slot = [&](unsigned j) -> unsigned char& { return l_key[((j >> 3) * kWave + lane) * 8 + (j & 7u)]; };
+
+    // 1. the nine segments; the distance of every point in them as a 7-BIT key in the lane's LDS column:
+    //        key = floor(d * 64 / t0), saturating at 127,   t0 = the squared radius of the ball that holds 26 points at the
+    //        density of the lane's own 27 cells (so the threshold sought below sits near key 64, one key step = 1.6 %).
+    // A monotone key is all the threshold needs: if a point outside the collected set {key <= t} were among the k nearest,
+    // the >= k collected points, whose keys are smaller, would all be strictly nearer.
+    unsigned sbeg[9], slen[9], cbase[9];
+    unsigned total = 0, maxlen = 0;
+#pragma unroll
+    for (int s9 = 0; s9 < 9; ++s9) {
+        const int y = ry + (s9 % 3) - 1, z = rz + (s9 / 3) - 1;
+        unsigned b = 0, e = 0;
+        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {  // (wave-uniform)
+            const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
+            b = start[rr + xa];
+            e = start[rr + xb + 1];
+        }
+        sbeg[s9] = b;
+        slen[s9] = e - b;
+        total += e - b;
+    }
+    bool fallback = !active || total > (unsigned)kSelCand;
+    if (fallback) total = 0;
+    {
+        unsigned acc = 0;
+#pragma unroll
+        for (int s9 = 0; s9 < 9; ++s9) {
+            if (fallback) slen[s9] = 0u;
+            cbase[s9] = acc;
+            acc += slen[s9];
+            maxlen = max(maxlen, slen[s9]);
+        }
+    }
+    const float cells = (float)((xb - xa + 1) * (yb - ya + 1) * (zb - za + 1));
+    const float t0 = g.h * g.h * __powf(26.0f * cells / (4.18879f * fmaxf((float)total, 1.0f)), 0.6666667f);
+    const float key_scale = 64.0f / fmaxf(t0, FLT_MIN);
+    // All nine segments advance together, four points each per trip: 36 independent loads in flight and ~8 trips, where a
+    // loop per segment made 27 dependent round trips.
+    const unsigned trips = wave_max_u32(maxlen);
+    for (unsigned o = 0; o < trips; o += 4) {
+        float4 p[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9) p[u][s9] = pts[(o + u < slen[s9]) ? sbeg[s9] + o + u : qpos];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9)
+                if (o + u < slen[s9]) {
+                    const float kd = dist2(q.x, q.y, q.z, p[u][s9].x, p[u][s9].y, p[u][s9].z) * key_scale;
+                    key_slot(cbase[s9] + o + u) = (unsigned char)(kd < 127.0f ? (unsigned)kd : 127u);  // (NaN -> 127)
+                }
+    }
+    const unsigned groups = (wave_max_u32(total) + 7u) >> 3;  // the counting loops run to the longest list of the wave
+    for (unsigned j = total; j < 8u * groups; ++j) key_slot(j) = 0xffu;  // (high bit set: never counted)
+    // 2. a threshold key t < 127 with k .. kSelList candidates at or below it. The count grows like t^1.5 (points in a ball),
+    // so a miss is corrected by that law — two or three counting passes for the whole wave — inside a bracket that falls back
+    // to bisection. Four keys are counted at once (the classic "bytes less than n" mask + a population count).
+    unsigned t = 64u;
+    unsigned t_lo = 0u, t_hi = 127u;  // keys below t_lo are known to count < k, keys from t_hi on > kSelList (127 = saturated)
+    bool found = false;
+    for (int it = 0; it < 10; ++it) {
+        const unsigned cmpc = 0x01010101u * (127u + t + 1u);  // (t + 1 <= 127)
+        unsigned cnt = 0;
+#pragma unroll 4
+        for (unsigned gq = 0; gq < groups; ++gq) {
+            const unsigned long long w = l_key8[gq][lane];
+            const unsigned w0 = (unsigned)w, w1 = (unsigned)(w >> 32);
+            cnt += __builtin_popcount((cmpc - (w0 & 0x7f7f7f7fu)) & ~w0 & 0x80808080u);
+            cnt += __builtin_popcount((cmpc - (w1 & 0x7f7f7f7fu)) & ~w1 & 0x80808080u);
+        }
+        if (!found && !fallback) {
+            if (cnt >= (unsigned)k && cnt <= (unsigned)kSelList) {
+                found = true;
+            } else {
+                if (cnt < (unsigned)k) t_lo = t + 1u;
+                else t_hi = t;
+                if (t_lo >= t_hi) {
+                    fallback = true;  // the keys cannot separate k .. kSelList points (ties, or sparser than the estimate)
+                } else {
+                    const float aim = 0.5f * (float)(k + kSelList);
+                    const float r = __powf(aim / fmaxf((float)cnt, 0.5f), 0.6666667f);
+                    unsigned tn = (unsigned)(((float)t + 0.5f) * fminf(fmaxf(r, 0.3f), 3.0f));
+                    if (tn < t_lo || tn >= t_hi) tn = (t_lo + t_hi) >> 1;  // outside the bracket: bisect
+                    t = tn;
+                }
+            }
+        }
+        if (__ballot(!found && !fallback) == 0ull) break;
+    }
+    fallback = fallback || !found;
+    // 3. the candidates at or below the threshold: their numbers in the lane's column, to the lane's list ...
+    unsigned c = 0;
+#pragma unroll 2
+    for (unsigned gq = 0; gq < groups; ++gq) {
+        const unsigned long long w = l_key8[gq][lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned kk = (unsigned)(w >> (8 * u)) & 0xffu;
+            if (kk <= t && !fallback) {
+                l_pos[c][lane] = (int)(8u * gq + u);
+                ++c;
+            }
+        }
+    }
+    // ... each number back to its position (which segment it falls in), exact distance and original index as a 64-bit key,
+    // on registers
+    const unsigned cmax = wave_max_u32(c);
+    unsigned long long key[kSelList];
+    int pos[kSelList];
+#pragma unroll
+    for (int i = 0; i < kSelList; ++i) {
+        key[i] = kNoCand;
+        pos[i] = -1;
+        if ((unsigned)i < cmax) {  // (wave-uniform)
+            const bool have = (unsigned)i < c;
+            const unsigned j = have ? (unsigned)l_pos[i][lane] : 0u;
+            unsigned off = sbeg[0];  // position = number + (start of its segment - numbers before the segment)
+#pragma unroll
+            for (int s9 = 1; s9 < 9; ++s9) off = j >= cbase[s9] ? sbeg[s9] - cbase[s9] : off;
+            const int pp = have ? (int)(j + off) : (int)qpos;
+            const float4 p = pts[pp];
+            if (have) {
+                key[i] = cand_key(dist2(q.x, q.y, q.z, p.x, p.y, p.z), __float_as_int(p.w));
+                pos[i] = pp;
+            }
+        }
+    }
+    // rank of every entry among the lane's entries (keys are distinct: the index is part of them) = its place in the list,
+    // counted on registers. (A 32-input sorting network on registers was the first form: 240 compare-exchanges of three
+    // registers each, which the register allocator answered with 560 spills; counting only reads the keys.)
+    int (*l_spos)[kWave] = l_pos;  // the list region, rewritten in sorted order (every position is on registers by now)
+    const unsigned orig = __float_as_uint(q.w);
+    const size_t lo_out = (size_t)orig * (size_t)k;
+    const bool write_lists = out.knn_idx != nullptr && active && !fallback;
+    float kth = FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < kSelList; ++i) {
+        unsigned rank = 0;
+#pragma unroll
+        for (int j = 0; j < kSelList; ++j) rank += key[j] < key[i] ? 1u : 0u;
+        if ((unsigned)i < c) {
+            l_spos[rank][lane] = pos[i];
+            if (rank == (unsigned)k - 1u) kth = key_d2(key[i]);
+            // (written before exactness is known: a query that turns out unproven is rewritten by the to-do kernel, which
+            // runs after this one)
+            if (write_lists && rank < (unsigned)k) {
+                out.knn_idx[lo_out + rank] = key_idx(key[i]);
+                out.knn_d2[lo_out + rank] = key_d2(key[i]);
+            }
+        }
+    }
+    if (!active) return;
+    // 4. is the k-th neighbour provably inside the scanned block?
+    if (!fallback) {
+        float cov = FLT_MAX;
+        if (xa > 0) cov = fminf(cov, q.x - (g.ox + xa * g.h));
+        if (xb < g.nx - 1) cov = fminf(cov, (g.ox + (xb + 1) * g.h) - q.x);
+        if (ya > 0) cov = fminf(cov, q.y - (g.oy + ya * g.h));
+        if (yb < g.ny - 1) cov = fminf(cov, (g.oy + (yb + 1) * g.h) - q.y);
+        if (za > 0) cov = fminf(cov, q.z - (g.oz + za * g.h));
+        if (zb < g.nz - 1) cov = fminf(cov, (g.oz + (zb + 1) * g.h) - q.z);
+        if (cov != FLT_MAX) {
+            cov = fmaxf(cov - g.eps, 0.0f);
+            fallback = !(kth < cov * cov);
+        }
+    }
+    if (fallback) {
+        const unsigned slot = atomicAdd(out.todo_count, 1u);
+        out.todo[slot] = qs + lane;
+        return;
+    }
+    if (out.covs || out.normals) {
+        // covariance::kernel::estimate over the list in ascending order (covariance.hpp:16-47), k >= 7 valid neighbours here
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, oxx = 0.0f, oxy = 0.0f, oxz = 0.0f, oyy = 0.0f, oyz = 0.0f, ozz = 0.0f;
+#pragma unroll 12
+        for (int j = 0; j < k; ++j) {
+            const float4 p = pts[l_spos[j][lane]];
+            sx += p.x; sy += p.y; sz += p.z;
+            oxx += p.x * p.x; oxy += p.x * p.y; oxz += p.x * p.z;
+            oyy += p.y * p.y; oyz += p.y * p.z; ozz += p.z * p.z;
+        }
+        const float inv = 1.0f / (float)k;
+        const float mx = sx * inv, my = sy * inv, mz = sz * inv;
+        const float cxy = oxy * inv - mx * my, cxz = oxz * inv - mx * mz, cyz = oyz * inv - my * mz;
+        Mat3 C;
+        C.m[0][0] = oxx * inv - mx * mx; C.m[0][1] = (cxy + cxy) * 0.5f; C.m[0][2] = (cxz + cxz) * 0.5f;
+        C.m[1][1] = oyy * inv - my * my; C.m[1][2] = (cyz + cyz) * 0.5f; C.m[2][2] = ozz * inv - mz * mz;
+        C.m[1][0] = C.m[0][1]; C.m[2][0] = C.m[0][2]; C.m[2][1] = C.m[1][2];
+        if (out.covs) {
+            float4* o4 = out.covs + 4 * (size_t)orig;
+            o4[0] = make_float4(C.m[0][0], C.m[1][0], C.m[2][0], 0.0f);
+            o4[1] = make_float4(C.m[0][1], C.m[1][1], C.m[2][1], 0.0f);
+            o4[2] = make_float4(C.m[0][2], C.m[1][2], C.m[2][2], 0.0f);
+            o4[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        if (out.normals) {  // covariance::kernel::extract_normal (covariance.hpp:49-65)
+            float ev[3];
+            Mat3 V;
+            symmetric_eigen3(C, ev, V);
+            const float nx_ = V.m[0][0], ny_ = V.m[1][0], nz_ = V.m[2][0];
+            const float dd = chain3(nx_, q.x, ny_, q.y, nz_, q.z);
+            out.normals[orig] = (dd <= 1.0f) ? make_float4(nx_, ny_, nz_, 0.0f) : make_float4(-nx_, -ny_, -nz_, 0.0f);
+        }
+    }
+}
+
 // Lane per point, for short lists (k <= 10): the ring walk of grid_search_kernel over the grid's own cell-ordered points
 // (neighbouring lanes walk neighbouring cells), positions carried along for the fused covariance / normal. Exact by
 // construction (the walk ends when the k-th neighbour is proven), so there is no to-do list. On 1M points: k = 10 in
@@ -519,25 +783,11 @@ __global__ __launch_bounds__(kBlock) void grid_self_knn_lane_kernel(const float4
 // A candidate is ordered by (squared distance, index): for non-negative floats the bit pattern orders like the value, so
 // the pair packs into one 64-bit key and "nearer, ties to the lower index" is a single unsigned compare.
 
-__global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4* __restrict__ pts,
-                                                                   const unsigned* __restrict__ start,
-                                                                   const unsigned* __restrict__ unit_off, GridDesc g,
-                                                                   int k, TileOut out) {
-    __shared__ float sm_terms[9][33];  // covariance terms of the k <= 20 neighbours (row stride 33: conflict-free columns)
-    const unsigned unit = blockIdx.x;
-    const unsigned rows = (unsigned)g.ny * g.nz;
-    unsigned lo = 0, hi = rows;
-    while (hi - lo > 1) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (unit_off[mid] <= unit) lo = mid;
-        else hi = mid;
-    }
-    const unsigned row = lo;
-    const int ry = (int)(row % g.ny), rz = (int)(row / g.ny);
-    const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
-    const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
-    const unsigned nq = min(64u, row_e - qs);
-    if (qs + nq <= out.pos_lo || qs >= out.pos_hi) return;  // the unit lies outside the requested range
+// The queries at grid positions [qs, qs + nq) of x-row (ry, rz), nq <= 64 (`last`: the last valid position to read from).
+__device__ __forceinline__ void self_knn_wave_queries(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                      const GridDesc& g, int k, const TileOut& out, float (*sm_terms)[33],
+                                                      unsigned qs, unsigned nq, int ry, int rz, unsigned last) {
+    const unsigned row_e = last + 1u;
     const unsigned lane = threadIdx.x;
     const float4 myq = pts[min(qs + lane, row_e - 1)];
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -753,6 +1003,43 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
     }
 }
 
+__global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4* __restrict__ pts,
+                                                                   const unsigned* __restrict__ start,
+                                                                   const unsigned* __restrict__ unit_off, GridDesc g,
+                                                                   int k, TileOut out) {
+    __shared__ float sm_terms[9][33];  // covariance terms of the k <= 20 neighbours (row stride 33: conflict-free columns)
+    const unsigned unit = blockIdx.x;
+    const unsigned rows = (unsigned)g.ny * g.nz;
+    unsigned lo = 0, hi = rows;
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (unit_off[mid] <= unit) lo = mid;
+        else hi = mid;
+    }
+    const unsigned row = lo;
+    const int ry = (int)(row % g.ny), rz = (int)(row / g.ny);
+    const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
+    const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
+    const unsigned nq = min(64u, row_e - qs);
+    if (qs + nq <= out.pos_lo || qs >= out.pos_hi) return;  // the unit lies outside the requested range
+    self_knn_wave_queries(pts, start, g, k, out, sm_terms, qs, nq, ry, rz, row_e - 1u);
+}
+// The same search for a LIST of queries (the to-do list of the lane-per-query kernels): a fixed grid of waves takes them one
+// at a time. The ring walk that used to finish them kept 27 k of 1 M queries busy for 1.5 ms (a lane each, a 20-step
+// insertion per candidate); a wave each, they take a few tens of microseconds.
+__global__ __launch_bounds__(kWave) void grid_self_knn_wave_list_kernel(const float4* __restrict__ pts,
+                                                                        const unsigned* __restrict__ start, GridDesc g, int k,
+                                                                        TileOut out) {
+    __shared__ float sm_terms[9][33];
+    const unsigned n_items = *out.todo_count;
+    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {  // (wave-uniform)
+        const unsigned pos = out.todo[item];
+        const float4 q = pts[pos];
+        const int ry = cell_coord(q.y, g.oy, g.inv_h, g.ny), rz = cell_coord(q.z, g.oz, g.inv_h, g.nz);
+        self_knn_wave_queries(pts, start, g, k, out, sm_terms, pos, 1u, ry, rz, pos);
+    }
+}
+
 // Ring walk for the queries the tile kernel could not prove exact (their positions are listed in `todo`).
 template <int KCAP>
 __global__ __launch_bounds__(kBlock) void grid_self_knn_todo_kernel(const float4* __restrict__ pts,
@@ -876,7 +1163,7 @@ template <int KCAP>
 int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
     const GridDesc g = grid_desc(gr);
     if (zero_async(out.todo_count, 4, st) != SP_OK) return SP_ERR_HIP;
-    if (KCAP <= 10 && gr->self_knn_mode == 0) {  // short lists: lane per point, exact without a to-do pass
+    if (KCAP <= 10 && gr->self_knn_mode == 0 && k <= 7) {  // short lists: lane per point, exact without a to-do pass
         grid_self_knn_lane_kernel<KCAP><<<div_up(out.pos_hi - out.pos_lo, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
         return launch_status();
     }
@@ -884,7 +1171,14 @@ int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
         // lane-per-query tile kernel for short lists (k = 3 on 1M points: 0.70 ms against 1.94 ms; it loses from k = 7 up: scratch/selfknn_modes.py)
         if (KCAP <= 10 && (gr->self_knn_mode == 1 || (gr->self_knn_mode == 0 && k <= 6)))
             grid_self_knn_tile_kernel<KCAP><<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
-        else
+        else if (k >= 7 && k <= 24 && (gr->self_knn_mode == 0 || gr->self_knn_mode == 3)) {
+            // (1 M points: k = 8 / 10 / 12 / 16 / 20 in 0.48 / 0.49 / 0.49 / 0.52 / 0.60 ms against 0.54 / 0.68 for the lane kernel
+            // and 0.84 ... 0.95 for the wave-cooperative one; with covariances 0.47 ... 0.57 against 1.0 ... 1.15)
+            grid_self_knn_select_kernel<<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
+            // its unproven queries (a few per cent: the k-th neighbour not provably inside the 27 cells), a wave each
+            grid_self_knn_wave_list_kernel<<<kNumCU * 32, kWave, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
+            return launch_status();
+        } else
             grid_self_knn_wave_kernel<<<gr->n_units, kWave, 0, st>>>(gr->d_pts, gr->d_start, gr->d_unit_off, g, k, out);
     }
     grid_self_knn_todo_kernel<KCAP><<<div_up(gr->n, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g, k, out);
