@@ -251,8 +251,12 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
     for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
     float kth = FLT_MAX;
     int kth_idx = -1;
+    // Self-kNN: the query's neighbours in Morton order are mostly its neighbours in space, so they go into the list BEFORE the
+    // descent — the k-th of them bounds the search from the first node on, instead of the bound staying infinite until k
+    // points have been met on the way down. The descent then skips those positions [w0, w1] (a point must not enter twice).
+    unsigned w0 = 1u, w1 = 0u;  // (empty)
     // the points [first, last], batches of eight independent loads
-    auto scan = [&](unsigned first, unsigned last) {
+    auto scan = [&](unsigned first, unsigned last, bool skip_window) {
 #pragma unroll 1
         for (unsigned b = first; b <= last; b += 8) {
             float4 slot[8];
@@ -262,14 +266,21 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
             for (int s = 0; s < 8; ++s) {
                 const float d = dist2(qx, qy, qz, slot[s].x, slot[s].y, slot[s].z);
                 const int pi = __float_as_int(slot[s].w);
+                const bool seen = skip_window && b + s >= w0 && b + s <= w1;
                 // (a non-finite point gives a NaN distance: every comparison fails, it is never taken)
-                if (b + s <= last && (d < kth || (d == kth && pi < kth_idx))) lex_insert<KCAP>(bd, bi, k, d, pi, kth, kth_idx);
+                if (b + s <= last && !seen && (d < kth || (d == kth && pi < kth_idx))) lex_insert<KCAP>(bd, bi, k, d, pi, kth, kth_idx);
             }
         }
     };
+    if (!queries && KCAP > 1 && n > (unsigned)kBvhLeaf && isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+        const unsigned half = (unsigned)(KCAP <= 10 ? 8 : 16);
+        w0 = qi >= half ? qi - half : 0u;
+        w1 = min(qi + half, n - 1u);
+        scan(w0, w1, false);
+    }
     if (isfinite(qx) && isfinite(qy) && isfinite(qz) && n != 0u) {
         if (n <= (unsigned)kBvhLeaf) {
-            scan(0u, n - 1u);
+            scan(0u, n - 1u, false);
         } else {
             int sp_top = 0;
             bool overflow = false;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
                     // copies of one point (invalid returns of a scan) would otherwise visit every copy from every copy.
                     if (dc == kth && cl > cf && __float_as_int(obox[2 * (size_t)(take_left ? split : split + 1u)].w) > kth_idx) continue;
                     if (cl - cf < (unsigned)kBvhLeaf) {
-                        scan(cf, cl);
+                        scan(cf, cl, true);
                     } else {
                         const unsigned child = take_left ? split : split + 1u;
                         if (next == ~0u) {
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
 #pragma unroll
                 for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
                 kth = FLT_MAX; kth_idx = -1;
-                scan(0u, n - 1u);
+                scan(0u, n - 1u, false);
             }
         }
     }
