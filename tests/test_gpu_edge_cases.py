@@ -1,6 +1,8 @@
 """Edge cases of the structure builds rewritten in round 2 (hand-written radix sort, gap-fill cell table, block-offset voxel
 compaction): tiny clouds, exactly one tile, clustered clouds with huge runs of empty cells, non-finite points, 8 M points.
 GridKNN must stay bit-identical to brute force; voxel downsampling to the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -102,6 +104,40 @@ def test_self_knn_lists_with_duplicates_and_sparse_clouds(sp, orc, k):
             oi, od = orc.knn_bruteforce(cloud, cloud, k)
             assert np.array_equal(res.indices.cpu().numpy(), oi) and np.array_equal(res.distances.cpu().numpy(), od)
             assert np.array_equal(covs.cpu().numpy().reshape(-1, 16), np.asarray(orc.cov_estimate(cloud, oi), np.float32).reshape(-1, 16))
+
+
+@pytest.mark.parametrize("k", [8, 9, 13, 20])
+def test_self_knn_select_kernel_equals_the_wave_kernel_bit_for_bit(sp, orc, k):
+    # grid_self_knn_select_kernel (lane per query: 7-bit keys, threshold, rank; its unproven queries go to the wave-per-query
+    # list kernel) against the wave-cooperative kernel (internal switch self_knn_mode = 2): lists, distances, covariances and
+    # normals, on a uniform cloud, on a cloud whose density varies by four orders of magnitude (most cells overflow the
+    # candidate cap: everything goes through the list kernel), on a tiny cloud, on one point repeated (all distances tie: no
+    # threshold separates k .. 32 of them), with non-finite points, and over a range of positions.
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_bvh import nonuniform_cloud
+
+    g = orc.rng(77 + k)
+    same = np.tile(np.float32([[1.0, 2.0, 3.0, 1.0]]), (300, 1))
+    holes = g.uniform_points(5000, 6.0)
+    holes[::13, 1] = np.nan
+    holes[7::31, 0] = np.inf
+    for cloud, ppc in ((g.uniform_points(30000, 6.0), 6.0), (nonuniform_cloud(20000), 6.0), (g.uniform_points(37, 2.0), 6.0),
+                       (np.concatenate([same, g.uniform_points(2000, 4.0)]), 6.0), (holes, 6.0), (g.uniform_points(30000, 6.0), 2.0)):
+        outs = []
+        for mode in (0, 2):
+            grid = sp.GridKNN.build(dev(cloud), points_per_cell=ppc)
+            grid._set_option("self_knn_mode", mode)
+            res, covs, nrm = grid.self_knn(k, want_knn=True, want_covs=True, want_normals=True)
+            outs.append((res.indices.cpu().numpy(), res.distances.cpu().numpy(), covs.cpu().numpy(), nrm.cpu().numpy()))
+        finite = np.isfinite(cloud[:, :3]).all(1)  # (rows of non-finite points are not defined)
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a[finite], b[finite], equal_nan=True)
+    cloud = g.uniform_points(20000, 6.0)
+    grid = sp.GridKNN.build(dev(cloud), points_per_cell=6.0)
+    whole = grid.self_knn(k, want_knn=False, want_covs=True)[1].cpu().numpy()
+    oi, _ = orc.knn_bruteforce(cloud, cloud, k)
+    assert np.array_equal(whole.reshape(-1, 16), np.asarray(orc.cov_estimate(cloud, oi), np.float32).reshape(-1, 16))
 
 
 def test_grid_with_non_finite_points(sp, orc):
