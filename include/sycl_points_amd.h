@@ -493,7 +493,10 @@ float sp_map_prior_apply_host(const sp_map_prior_state* state, const float* T_es
  *   sp_gicp_align_sharded  sp_gicp_align_fused with the source sharded over `comm`: per iteration one launch
  *                       (sp_gicp_align_step, rows_all_reduced = 2) + one sp_allreduce_rows, then sp_gicp_align_finish; every
  *                       rank ends with the identical pose. Only enqueues (hipGraph-capturable). All ranks must pass the same
- *                       params, gn and max_iterations; a rank with an empty shard still calls it. */
+ *                       params, gn and max_iterations; a rank with an empty shard still calls it.
+ * An error return on one rank (bad arguments, a HIP error) leaves the other ranks inside that iteration's collective: the
+ * communicator cannot be used again — destroy it (sp_comm_destroy) on every rank and create a new one. Launches after
+ * convergence contribute a zero row. */
 #define SP_COMM_ID_BYTES 128
 typedef struct sp_comm sp_comm;
 int sp_comm_unique_id(void* id_out);

@@ -1217,9 +1217,15 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT, un
         if (blockIdx.x == 0) align_store_late_state(A);
         return false;
     }
+    // (a launch that has nothing to do still leaves a defined row for the caller's all-reduce: zeros)
+    auto zero_row = [&] {
+        if (SHARDED && A.mode == ALIGN_FANIN && blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + kFanRow)
+            A.fan_row_out[threadIdx.x - 64] = 0.0f;
+    };
     if (sflag[0]) {  // converged earlier (uniform over the grid): carry the state forward
         if (blockIdx.x == 0 && threadIdx.x < kStateWords)
             reinterpret_cast<unsigned*>(A.state_out)[threadIdx.x] = reinterpret_cast<const unsigned*>(A.state_in)[threadIdx.x];
+        zero_row();
         return false;
     }
     if (threadIdx.x == 0) {
@@ -1246,7 +1252,11 @@ __device__ __forceinline__ bool align_prologue(const AlignArgs& A, float* sT, un
         }
     }
     __syncthreads();
-    return !(sdelta[6] > 0.5f);  // converged with this step: no further linearisation (registration.hpp:266-268)
+    if (sdelta[6] > 0.5f) {  // converged with this step: no further linearisation (registration.hpp:266-268)
+        zero_row();
+        return false;
+    }
+    return true;
 }
 
 // SHARDED = false: the single-GPU form (ALIGN_PROLOGUE) with nothing of the other modes compiled in — the exchange code
