@@ -139,9 +139,13 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
                                                              const float4* __restrict__ queries, unsigned nq, int k,
                                                              Mat4Arg T_val, const float* __restrict__ T_dev,
                                                              int32_t* __restrict__ idx_out,
-                                                             float* __restrict__ d2_out) {
-    const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
-    if (qi >= nq) return;
+                                                             float* __restrict__ d2_out,
+                                                             const unsigned* __restrict__ todo = nullptr,
+                                                             const unsigned* __restrict__ todo_count = nullptr) {
+    // (todo: only the listed queries — what grid_search_select_kernel could not prove)
+    const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (todo ? *todo_count : nq)) return;
+    const unsigned qi = todo ? todo[t] : t;
     const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
     const float4 q4 = queries[qi];
     float qx, qy, qz;
@@ -441,35 +445,18 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return v;
 }
 
-__global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float4* __restrict__ pts,
-                                                                     const unsigned* __restrict__ start,
-                                                                     const unsigned* __restrict__ unit_off, GridDesc g,
-                                                                     int k, TileOut out) {
-    // the lane's keys, one byte each, in groups of eight (one ds_read_b64 per eight candidates), [group][lane]: conflict-free
-    __shared__ unsigned long long l_key8[kSelCand / 8][kWave];  // 12 KB
-    __shared__ int l_pos[kSelList][kWave];                      //  8 KB  (20 KB per wave: eight waves per CU)
+// Phases 1 - 3 and the exactness test of the lane-per-query selection (see above) for the query q in cell (cx, ry, rz):
+// its k nearest of the 27 cells go to list_idx / list_d2[0 .. k) (when not null), their grid positions in ascending order to
+// the lane's column of l_pos. Returns true when the lists are proven exact, false when the query has to be searched again by
+// a kernel without the 27-cell limit. `qpos`: any valid position (idle slots read it).
+__device__ __forceinline__ bool self_knn_select_core(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                     const GridDesc& g, int k, const float4 q, int cx, int ry, int rz,
+                                                     bool active, unsigned qpos, unsigned long long (*l_key8)[kWave],
+                                                     int (*l_pos)[kWave], int32_t* list_idx, float* list_d2) {
     unsigned char* const l_key = reinterpret_cast<unsigned char*>(&l_key8[0][0]);
-    const unsigned unit = blockIdx.x;
-    const unsigned rows = (unsigned)g.ny * g.nz;
-    unsigned lo = 0, hi = rows;
-    while (hi - lo > 1) {  // row of this unit: last r with unit_off[r] <= unit (wave-uniform)
-        const unsigned mid = (lo + hi) >> 1;
-        if (unit_off[mid] <= unit) lo = mid;
-        else hi = mid;
-    }
-    const unsigned row = lo;
-    const int ry = (int)(row % g.ny), rz = (int)(row / g.ny);
-    const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
-    const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
-    const unsigned qe = min(qs + 64u, row_e);
-    if (qe <= out.pos_lo || qs >= out.pos_hi) return;  // wave-uniform: the unit lies outside the requested range
-    const unsigned lane = threadIdx.x;
-    const unsigned qpos = min(qs + lane, qe - 1);
-    const bool active = qs + lane < qe && qs + lane >= out.pos_lo && qs + lane < out.pos_hi;
-    const float4 q = pts[qpos];
-    const int cx = cell_coord(q.x, g.ox, g.inv_h, g.nx);
     const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
     const int ya = max(ry - 1, 0), yb = min(ry + 1, g.ny - 1), za = max(rz - 1, 0), zb = min(rz + 1, g.nz - 1);
+    const unsigned lane = threadIdx.x;
     auto key_slot = [&](unsigned j) -> unsigned char& { return l_key[((j >> 3) * kWave + lane) * 8 + (j & 7u)]; };
 
     // 1. the nine segments; the distance of every point in them as a 7-BIT key in the lane's LDS column:
@@ -483,7 +470,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float
     for (int s9 = 0; s9 < 9; ++s9) {
         const int y = ry + (s9 % 3) - 1, z = rz + (s9 / 3) - 1;
         unsigned b = 0, e = 0;
-        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {  // (wave-uniform)
+        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {  // (wave-uniform for the self-kNN, per lane for external queries)
             const unsigned rr = ((unsigned)z * g.ny + y) * g.nx;
             b = start[rr + xa];
             e = start[rr + xb + 1];
@@ -604,9 +591,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float
     // counted on registers. (A 32-input sorting network on registers was the first form: 240 compare-exchanges of three
     // registers each, which the register allocator answered with 560 spills; counting only reads the keys.)
     int (*l_spos)[kWave] = l_pos;  // the list region, rewritten in sorted order (every position is on registers by now)
-    const unsigned orig = __float_as_uint(q.w);
-    const size_t lo_out = (size_t)orig * (size_t)k;
-    const bool write_lists = out.knn_idx != nullptr && active && !fallback;
+    const bool write_lists = list_idx != nullptr && active && !fallback;
     float kth = FLT_MAX;
 #pragma unroll
     for (int i = 0; i < kSelList; ++i) {
@@ -619,12 +604,12 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float
             // (written before exactness is known: a query that turns out unproven is rewritten by the to-do kernel, which
             // runs after this one)
             if (write_lists && rank < (unsigned)k) {
-                out.knn_idx[lo_out + rank] = key_idx(key[i]);
-                out.knn_d2[lo_out + rank] = key_d2(key[i]);
+                list_idx[rank] = key_idx(key[i]);
+                list_d2[rank] = key_d2(key[i]);
             }
         }
     }
-    if (!active) return;
+    if (!active) return true;
     // 4. is the k-th neighbour provably inside the scanned block?
     if (!fallback) {
         float cov = FLT_MAX;
@@ -639,6 +624,44 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float
             fallback = !(kth < cov * cov);
         }
     }
+    return !fallback;
+}
+
+__global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float4* __restrict__ pts,
+                                                                     const unsigned* __restrict__ start,
+                                                                     const unsigned* __restrict__ unit_off, GridDesc g,
+                                                                     int k, TileOut out) {
+    // the lane's keys, one byte each, in groups of eight (one ds_read_b64 per eight candidates), [group][lane]: conflict-free
+    __shared__ unsigned long long l_key8[kSelCand / 8][kWave];  // 12 KB
+    __shared__ int l_pos[kSelList][kWave];                      //  8 KB  (20 KB per wave: eight waves per CU)
+    const unsigned unit = blockIdx.x;
+    const unsigned rows = (unsigned)g.ny * g.nz;
+    unsigned lo = 0, hi = rows;
+    while (hi - lo > 1) {  // row of this unit: last r with unit_off[r] <= unit (wave-uniform)
+        const unsigned mid = (lo + hi) >> 1;
+        if (unit_off[mid] <= unit) lo = mid;
+        else hi = mid;
+    }
+    const unsigned row = lo;
+    const int ry = (int)(row % g.ny), rz = (int)(row / g.ny);
+    const unsigned row_s = start[(size_t)row * g.nx], row_e = start[(size_t)(row + 1) * g.nx];
+    const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
+    const unsigned qe = min(qs + 64u, row_e);
+    if (qe <= out.pos_lo || qs >= out.pos_hi) return;  // wave-uniform: the unit lies outside the requested range
+    const unsigned lane = threadIdx.x;
+    const unsigned qpos = min(qs + lane, qe - 1);
+    const bool active = qs + lane < qe && qs + lane >= out.pos_lo && qs + lane < out.pos_hi;
+    const float4 q = pts[qpos];
+    const int cx = cell_coord(q.x, g.ox, g.inv_h, g.nx);
+    const unsigned orig = __float_as_uint(q.w);
+    // (the lists are written before exactness is known: a query that turns out unproven is rewritten by the list kernel,
+    // which runs after this one)
+    const bool proven = self_knn_select_core(pts, start, g, k, q, cx, ry, rz, active, qpos, l_key8, l_pos,
+                                             out.knn_idx ? out.knn_idx + (size_t)orig * (size_t)k : nullptr,
+                                             out.knn_idx ? out.knn_d2 + (size_t)orig * (size_t)k : nullptr);
+    if (!active) return;
+    int (*l_spos)[kWave] = l_pos;
+    const bool fallback = !proven;
     if (fallback) {
         const unsigned slot = atomicAdd(out.todo_count, 1u);
         out.todo[slot] = qs + lane;
@@ -676,6 +699,38 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_select_kernel(const float
             const float dd = chain3(nx_, q.x, ny_, q.y, nz_, q.z);
             out.normals[orig] = (dd <= 1.0f) ? make_float4(nx_, ny_, nz_, 0.0f) : make_float4(-nx_, -ny_, -nz_, 0.0f);
         }
+    }
+}
+
+// The same selection for EXTERNAL queries (KNNBase::knn_search_async on a GridKNN, 8 <= k <= 24): a lane per query in the
+// caller's order, its cell from its (transformed) coordinates; what cannot be proven inside the 27 cells (and non-finite
+// queries) goes to the ring-walk kernel through a list. 1 M queries against 1 M points, k = 20: 7.4 ms with the ring walk
+// alone (a 20-step insertion per candidate in every lane).
+__global__ __launch_bounds__(kWave) void grid_search_select_kernel(const float4* __restrict__ pts,
+                                                                   const unsigned* __restrict__ start, GridDesc g,
+                                                                   const float4* __restrict__ queries, unsigned nq, int k,
+                                                                   Mat4Arg T_val, const float* __restrict__ T_dev,
+                                                                   int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                                   unsigned* __restrict__ todo, unsigned* __restrict__ todo_count) {
+    __shared__ unsigned long long l_key8[kSelCand / 8][kWave];
+    __shared__ int l_pos[kSelList][kWave];
+    const unsigned qi = blockIdx.x * kWave + threadIdx.x;
+    const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+    const float4 q4 = queries[min(qi, nq - 1u)];
+    float4 q;
+    transform_point(T, q4.x, q4.y, q4.z, q.x, q.y, q.z);
+    q.w = 0.0f;
+    const bool finite_q = isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
+    const bool active = qi < nq && finite_q && g.n > 0;
+    const int cx = cell_coord(q.x, g.ox, g.inv_h, g.nx), cy = cell_coord(q.y, g.oy, g.inv_h, g.ny),
+              cz = cell_coord(q.z, g.oz, g.inv_h, g.nz);
+    const bool proven = self_knn_select_core(pts, start, g, k, q, cx, cy, cz, active, 0u, l_key8, l_pos,
+                                             idx_out + (size_t)min(qi, nq - 1u) * (size_t)k,
+                                             d2_out + (size_t)min(qi, nq - 1u) * (size_t)k);
+    if (qi < nq && !active) {  // a non-finite query (or an empty grid): the empty list (knn/result.hpp:21-27)
+        for (int i = 0; i < k; ++i) { idx_out[(size_t)qi * k + i] = -1; d2_out[(size_t)qi * k + i] = FLT_MAX; }
+    } else if (qi < nq && !proven) {
+        todo[atomicAdd(todo_count, 1u)] = qi;
     }
 }
 
@@ -783,13 +838,12 @@ __global__ __launch_bounds__(kBlock) void grid_self_knn_lane_kernel(const float4
 // A candidate is ordered by (squared distance, index): for non-negative floats the bit pattern orders like the value, so
 // the pair packs into one 64-bit key and "nearer, ties to the lower index" is a single unsigned compare.
 
-// The queries at grid positions [qs, qs + nq) of x-row (ry, rz), nq <= 64 (`last`: the last valid position to read from).
+// nq <= 64 queries of x-row (ry, rz): lane j holds query j in `myq` (coordinates + the bits of its output row); `qs`: the grid
+// position of query 0 (self-kNN: tested against the requested range).
 __device__ __forceinline__ void self_knn_wave_queries(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                       const GridDesc& g, int k, const TileOut& out, float (*sm_terms)[33],
-                                                      unsigned qs, unsigned nq, int ry, int rz, unsigned last) {
-    const unsigned row_e = last + 1u;
+                                                      unsigned qs, unsigned nq, int ry, int rz, const float4 myq) {
     const unsigned lane = threadIdx.x;
-    const float4 myq = pts[min(qs + lane, row_e - 1)];
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
 
     int cur_cx = -1, cur_variant = -1;
@@ -879,7 +933,12 @@ __device__ __forceinline__ void self_knn_wave_queries(const float4* __restrict__
         float4 p_next;
         unsigned pos_next;
         bool valid_next;
-        if (!selected) fetch(0, p_next, pos_next, valid_next);
+        // (total == 0 cannot happen for the cloud's own points — a query is in its own cell — but an external query can sit in an
+        // empty neighbourhood: nothing to fetch, the rings below find its neighbours)
+        p_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        pos_next = 0u;
+        valid_next = false;
+        if (!selected && total > 0u) fetch(0, p_next, pos_next, valid_next);
         for (unsigned base = 0; !selected && base < total; base += 64) {
             const float4 p = p_next;
             const unsigned pos = pos_next;
@@ -1022,7 +1081,7 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_kernel(const float4*
     const unsigned qs = row_s + (unit - unit_off[row]) * 64u;
     const unsigned nq = min(64u, row_e - qs);
     if (qs + nq <= out.pos_lo || qs >= out.pos_hi) return;  // the unit lies outside the requested range
-    self_knn_wave_queries(pts, start, g, k, out, sm_terms, qs, nq, ry, rz, row_e - 1u);
+    self_knn_wave_queries(pts, start, g, k, out, sm_terms, qs, nq, ry, rz, pts[min(qs + threadIdx.x, row_e - 1u)]);
 }
 // The same search for a LIST of queries (the to-do list of the lane-per-query kernels): a fixed grid of waves takes them one
 // at a time. The ring walk that used to finish them kept 27 k of 1 M queries busy for 1.5 ms (a lane each, a 20-step
@@ -1036,7 +1095,25 @@ __global__ __launch_bounds__(kWave) void grid_self_knn_wave_list_kernel(const fl
         const unsigned pos = out.todo[item];
         const float4 q = pts[pos];
         const int ry = cell_coord(q.y, g.oy, g.inv_h, g.ny), rz = cell_coord(q.z, g.oz, g.inv_h, g.nz);
-        self_knn_wave_queries(pts, start, g, k, out, sm_terms, pos, 1u, ry, rz, pos);
+        self_knn_wave_queries(pts, start, g, k, out, sm_terms, pos, 1u, ry, rz, q);
+    }
+}
+// ... and for a list of EXTERNAL queries (what grid_search_select_kernel could not prove): rows by query number.
+__global__ __launch_bounds__(kWave) void grid_search_wave_list_kernel(const float4* __restrict__ pts,
+                                                                      const unsigned* __restrict__ start, GridDesc g,
+                                                                      const float4* __restrict__ queries, int k, Mat4Arg T_val,
+                                                                      const float* __restrict__ T_dev, TileOut out) {
+    __shared__ float sm_terms[9][33];
+    const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+    const unsigned n_items = *out.todo_count;
+    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {  // (wave-uniform)
+        const unsigned qi = out.todo[item];
+        const float4 q4 = queries[qi];
+        float4 q;
+        transform_point(T, q4.x, q4.y, q4.z, q.x, q.y, q.z);
+        q.w = __uint_as_float(qi);
+        const int ry = cell_coord(q.y, g.oy, g.inv_h, g.ny), rz = cell_coord(q.z, g.oz, g.inv_h, g.nz);
+        self_knn_wave_queries(pts, start, g, k, out, sm_terms, 0u, 1u, ry, rz, q);
     }
 }
 
@@ -1224,6 +1301,31 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
                                                                       reinterpret_cast<const float4*>(q), (unsigned)nq,
                                                                       tv, T_dev ? T : nullptr, idx, d2);
         return launch_status();
+    }
+    if (k > 10 && k <= 24 && gr->n != 0 && (gr->self_knn_mode == 0 || gr->self_knn_mode == 3)) {
+        // lane-per-query selection inside the 27 cells; the queries it cannot prove (a few per cent at the densities the grid
+        // is built for) are listed and finished a wave each. (k <= 10 stays on the ring walk: its row pruning scans fewer
+        // candidates than all 27 cells, which decides for queries in random order — 0.8 against 2.2 ms at k = 10.) The list lives in the library's buffer pool for the
+        // duration of the call (handed back tagged with an event on this stream).
+        unsigned* todo = nullptr;
+        if (pooled_alloc(&todo, (nq + 1) * sizeof(unsigned)) != hipSuccess) return SP_ERR_HIP;
+        unsigned* const todo_count = todo + nq;
+        int rc = zero_async(todo_count, 4, st);
+        if (rc == SP_OK) {
+            grid_search_select_kernel<<<div_up(nq, kWave), kWave, 0, st>>>(gr->d_pts, gr->d_start, g,
+                                                                        reinterpret_cast<const float4*>(q), (unsigned)nq, (int)k, tv,
+                                                                        T_dev ? T : nullptr, idx, d2, todo, todo_count);
+            TileOut lo;
+            lo.knn_idx = idx; lo.knn_d2 = d2; lo.covs = nullptr; lo.normals = nullptr;
+            lo.todo = todo; lo.todo_count = todo_count; lo.pos_lo = 0u; lo.pos_hi = 0xffffffffu;
+            grid_search_wave_list_kernel<<<kNumCU * 32, kWave, 0, st>>>(gr->d_pts, gr->d_start, g, reinterpret_cast<const float4*>(q),
+                                                                      (int)k, tv, T_dev ? T : nullptr, lo);
+            rc = launch_status();
+        }
+        StreamSet used;
+        used.note(st);
+        pooled_free_after(todo, used);
+        return rc;
     }
     grid_search_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g,
                                                                   reinterpret_cast<const float4*>(q), (unsigned)nq,

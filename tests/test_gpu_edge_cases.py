@@ -140,6 +140,27 @@ def test_self_knn_select_kernel_equals_the_wave_kernel_bit_for_bit(sp, orc, k):
     assert np.array_equal(whole.reshape(-1, 16), np.asarray(orc.cov_estimate(cloud, oi), np.float32).reshape(-1, 16))
 
 
+@pytest.mark.parametrize("k", [11, 20])
+def test_grid_external_queries_select_path(sp, orc, k):
+    # KNNBase::knn_search_async on a GridKNN with k > 10 runs grid_search_select_kernel (lane per query inside the 27 cells)
+    # and finishes the unproven queries a wave each: queries far outside the cloud and in empty neighbourhoods (no candidate
+    # at all in their 27 cells), non-finite queries, a sparse grid (nearly everything unproven), dense cells (candidate cap),
+    # duplicated targets (ties), a transform, fewer targets than k.
+    g = orc.rng(900 + k)
+    tgt = g.uniform_points(15000, 5.0)
+    tgt_dup = np.concatenate([tgt, tgt[:300]])
+    qry = np.concatenate([g.uniform_points(3000, 5.0), g.uniform_points(500, 30.0), np.float32([[1e4, -1e4, 0.0, 1.0]])])
+    qry[7, 0] = np.nan
+    qry[11, 2] = np.inf
+    T = orc.se3_exp([0.01, 0.02, -0.03, 0.3, -0.2, 0.1])
+    for cloud, ppc in ((tgt, 6.0), (tgt, 0.3), (tgt, 40.0), (tgt_dup, 6.0), (tgt[:k - 3], 6.0)):
+        grid = sp.GridKNN.build(dev(cloud), points_per_cell=ppc)
+        r = grid.knn_search(dev(qry), k, T)
+        oi, od = orc.knn_bruteforce(orc.transform_points(qry, T), cloud, k)
+        assert np.array_equal(r.indices.cpu().numpy(), oi)
+        assert np.array_equal(r.distances.cpu().numpy(), od)
+
+
 def test_grid_with_non_finite_points(sp, orc):
     # non-finite points go to a trash cell past the grid (never searched): the gap-fill cell table must close exactly there
     g = orc.rng(404)
