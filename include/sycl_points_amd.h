@@ -93,6 +93,10 @@ float sp_grid_cell_size(const sp_grid* grid);
  * sorted by voxel key) keeps neighbouring lanes on neighbouring cells of ANY grid it is later searched against, so
  * sp_gicp_source_prepare can skip its per-alignment sort (SP_SOURCE_PRESORTED). */
 int sp_grid_order(const sp_grid* grid, uint32_t* idx_out, void* stream);
+/* KNNBase::knn_search_async on the grid (k <= 20). For k > 10 the call takes nq + 1 words of scratch from the library's
+ * buffer pool for its duration (the list of queries a first, 27-cell pass could not prove): inside a stream capture that
+ * works once the pool holds such a buffer, i.e. after one eager call of the same size. Queries in the cell order of any grid
+ * (sp_grid_order) are served three times faster than in random order (their candidates share cache lines). */
 int sp_grid_search(const sp_grid* grid, const float* queries, size_t nq, size_t k, const float* transT,
                    int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
 /* The grid's counterpart of KDTree::radius_search_async (knn/kdtree.hpp:251-280, 574-719): the max_k nearest target
