@@ -160,6 +160,11 @@ public:
     ~KDTree() override {
         if (tree_) sp_kdtree_destroy(tree_);
         if (bvh_) sp_bvh_destroy(bvh_);
+        if (self_grid_) sp_grid_destroy(self_grid_);
+        if (self_grid_ws_) {
+            (void)hipStreamSynchronize(queue.stream());
+            (void)hipFree(self_grid_ws_);
+        }
         if (dev_points_) {
             (void)hipStreamSynchronize(queue.stream());
             (void)hipFree(dev_points_);
@@ -205,6 +210,15 @@ public:
             // its points are walked in tree order, neighbouring lanes share their path (1.5x faster than in query order)
             if (built_on_ != nullptr && queries.points == built_on_ && queries.points->generation() == built_generation_ && nq == size_ &&
                 transT == TransformMatrix::Identity()) {
+                // A large cloud of near-uniform density (a voxel-downsampled scan, a submap): the uniform grid's lane-per-query
+                // selection answers 8 <= k <= 20 five to nine times faster than the hierarchy (1 M points, k = 20: 0.6 against
+                // 5.5 ms) with the same lists. Built once per tree (0.2 ms), kept only if no cell is overfull.
+                if (k >= 8 && k <= 20 && uniform_grid() != nullptr) {
+                    throw_on_error(sp_grid_self_knn(self_grid_, k, result.indices->device_data_for_write(nq * k),
+                                                    result.distances->device_data_for_write(nq * k), nullptr, nullptr, self_grid_ws_,
+                                                    sp_grid_self_workspace_bytes(self_grid_), queue.stream()));
+                    return sycl_utils::events(queue.stream());
+                }
                 throw_on_error(sp_bvh_self_knn(bvh_, k, result.indices->device_data_for_write(nq * k),
                                                result.distances->device_data_for_write(nq * k), queue.stream()));
                 return sycl_utils::events(queue.stream());
@@ -270,6 +284,28 @@ private:
         }
         return tree_;
     }
+    /// A grid on the tree's own cloud for the self-kNN of large clouds, when its density allows (see knn_search_async).
+    sp_grid* uniform_grid() const {
+        if (!self_grid_tried_) {
+            self_grid_tried_ = true;
+            if (size_ >= kGridSelfMinPoints) {
+                constexpr float kPointsPerCell = 6.0f;
+                throw_on_error(sp_grid_create(device_points(), size_, 0.0f, kPointsPerCell, queue.stream(), &self_grid_));
+                if (sp_grid_max_cell_points(self_grid_) > kGridSelfMaxCell) {  // surfaces, clusters: the hierarchy's case
+                    sp_grid_destroy(self_grid_);
+                    self_grid_ = nullptr;
+                } else {
+                    hip_check(hipMalloc(&self_grid_ws_, sp_grid_self_workspace_bytes(self_grid_)), "hipMalloc");
+                }
+            }
+        }
+        return self_grid_;
+    }
+    static constexpr size_t kGridSelfMinPoints = 32768;
+    static constexpr uint32_t kGridSelfMaxCell = 48;
+    mutable sp_grid* self_grid_ = nullptr;
+    mutable void* self_grid_ws_ = nullptr;
+    mutable bool self_grid_tried_ = false;
     mutable sp_kdtree* tree_ = nullptr;
     sp_bvh* bvh_ = nullptr;
     mutable void* dev_points_ = nullptr;

@@ -77,6 +77,7 @@ SIGNATURES = {
     "sp_grid_size": (_sz, [_vp]),
     "sp_grid_order": (_i, [_vp, _vp, _vp]),
     "sp_grid_cell_size": (_f, [_vp]),
+    "sp_grid_max_cell_points": (C.c_uint32, [_vp]),
     "sp_grid_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
     "sp_grid_radius_search": (_i, [_vp, _vp, _sz, _sz, _f, _vp, _i, _vp, _vp, _vp]),
     "sp_grid_remove_by_flags": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -238,6 +238,15 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
 // outside the scanned block (sparse regions) is appended to a to-do list and finished by the ring walk.
 // The work units of every x-row (ceil(points in the row / 64); entry `rows` = 0, so the scan that follows needs no memset).
 // (A hand-written single-workgroup scan of these ~16 k values took 16-45 us in three forms against 7.6 us for the library's.)
+// The fullest cell (a statistic of the build: callers choose between the grid and the hierarchy by it, sp_grid_max_cell_points).
+__global__ __launch_bounds__(kBlock) void cell_max_kernel(const unsigned* __restrict__ start, unsigned ncells,
+                                                          unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (unsigned c = blockIdx.x * kBlock + threadIdx.x; c < ncells; c += gridDim.x * kBlock) m = max(m, start[c + 1] - start[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 __global__ void row_units_kernel(const unsigned* __restrict__ start, unsigned nx, unsigned rows,
                                  unsigned* __restrict__ units) {
     const unsigned r = blockIdx.x * kBlock + threadIdx.x;
@@ -1471,6 +1480,11 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
         row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
         if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, stmp, stmp_bytes, st) != SP_OK) e = hipErrorUnknown;
     }
+    if (e == hipSuccess) {  // the fullest cell, through the first word of the (now idle) row-unit scratch
+        if (zero_async(units, 4, st) != SP_OK) e = hipErrorUnknown;
+        cell_max_kernel<<<std::min(div_up(g->ncells, kBlock), 256u), kBlock, 0, st>>>(g->d_start, (unsigned)g->ncells, units);
+        if (e == hipSuccess) e = hipMemcpyAsync(&g->max_cell, units, 4, hipMemcpyDeviceToHost, st);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // the temporaries are idle from here on
     if (e != hipSuccess) return fail(e);
@@ -1607,6 +1621,8 @@ extern "C" int sp_grid_search(const sp_grid* grid, const float* queries, size_t 
     if (k <= 10) return launch<10>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     return launch<20>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
 }
+
+extern "C" uint32_t sp_grid_max_cell_points(const sp_grid* grid) { return grid ? grid->max_cell : 0u; }
 
 extern "C" size_t sp_grid_self_workspace_bytes(const sp_grid* grid) { return grid ? (grid->n + 2) * 4 : 0; }
 

@@ -675,11 +675,37 @@ static void sharded_align_one_rank() {
     CHECK(threw);
 }
 
+static void kdtree_self_knn_large_clouds() {
+    // KDTree::knn_search on the tree's own cloud: from 32 k points on, a cloud of near-uniform density is answered by the grid's
+    // lane-per-query selection, a clustered one (fullest cell over the limit) by the device-built hierarchy; both must give
+    // brute force's lists.
+    std::mt19937 gen(99);
+    for (int clustered = 0; clustered < 2; ++clustered) {
+        PointCloudCPU c;
+        random_points(gen, c, clustered ? 20000 : 40000, 10.0f);
+        if (clustered) {
+            std::uniform_real_distribution<float> U(-0.05f, 0.05f);
+            for (int i = 0; i < 20000; ++i) c.points->emplace_back(1.0f + U(gen), 2.0f + U(gen), -3.0f + U(gen), 1.0f);
+        }
+        PointCloudShared cloud(*Q, c);
+        auto tree = alg::knn::KDTree::build(*Q, cloud);
+        for (size_t k : {10, 20}) {
+            auto kd = tree->knn_search(cloud, k);
+            auto bf = alg::knn::knn_search_bruteforce(*Q, cloud, cloud, k);
+            bool same = kd.query_size == cloud.size() && kd.k == k;
+            for (size_t i = 0; same && i < cloud.size() * k; ++i)
+                same = (*kd.indices)[i] == (*bf.indices)[i] && (*kd.distances)[i] == (*bf.distances)[i];
+            CHECK(same);
+        }
+    }
+}
+
 int main() {
     sycl_utils::DeviceQueue queue(0);
     Q = &queue;
     queue.print_device_info();
     RUN(kdtree_grid_vs_bruteforce);
+    RUN(kdtree_self_knn_large_clouds);
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
     RUN(point_cloud_extend_erase);
