@@ -296,6 +296,11 @@ class GridKNN(KNNBase):
     def cell_size(self):
         return float(_lib.lib().sp_grid_cell_size(self._h))
 
+    def max_cell_points(self):
+        """Points in the fullest cell at build time (sp_grid_max_cell_points): far above the points-per-cell target means the
+        cloud is not of near-uniform density and a BVH serves it better."""
+        return int(_lib.lib().sp_grid_max_cell_points(self._h))
+
     def order(self):
         """Original indices of the points in this grid's cell order (int64 tensor, usable for tensor indexing). A source
         cloud stored in this order needs no per-alignment sort (align_fused_loop(sort_by_cell="presorted"))."""
