@@ -88,7 +88,7 @@ int sp_grid_create(const float* points, size_t n, float cell_size, float points_
 void sp_grid_destroy(sp_grid* grid);
 size_t sp_grid_size(const sp_grid* grid);
 float sp_grid_cell_size(const sp_grid* grid);
-/* Points in the fullest cell when the grid was built. The grid's searches assume near-uniform density (a query scans its 27
+/* Points in the fullest cell (measured on the first call: one small kernel and a blocking read-back; cached). The grid's searches assume near-uniform density (a query scans its 27
  * cells): a value far above the points-per-cell target says that a hierarchy (sp_bvh_*) serves this cloud better. */
 uint32_t sp_grid_max_cell_points(const sp_grid* grid);
 /* idx_out[i] = original index of the i-th point in the grid's cell order (z-major, then y, then x; stable inside a cell).

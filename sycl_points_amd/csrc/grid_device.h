@@ -13,7 +13,8 @@ struct sp_grid {
     uint32_t* d_start = nullptr;  // ncells + 1
     uint32_t* d_unit_off = nullptr;  // rows + 1: first 64-query work unit of every x-row (self-kNN tiling)
     uint32_t n_units = 0;
-    uint32_t max_cell = 0;            // points in the fullest cell at build time (0: not measured)
+    mutable uint32_t max_cell = 0;    // points in the fullest cell, measured on first request (sp_grid_max_cell_points)
+    mutable bool max_cell_known = false;
     // tuning switch (sp_internal.h): self-kNN kernel — 0 chosen by k (lane per point for k <= 10, wave-cooperative above),
     // 1 LDS-tile kernel (k <= 10), 2 wave-cooperative kernel. Results are identical.
     int self_knn_mode = 0;
