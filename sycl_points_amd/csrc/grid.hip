@@ -51,13 +51,19 @@ __host__ __device__ inline float dec(unsigned u) {
 __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__ pts, unsigned n, unsigned* bbox) {
     __shared__ unsigned red[kBlock / kWave][6];
     unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float4 p = pts[i];
-        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-            const unsigned e[3] = {enc(p.x), enc(p.y), enc(p.z)};
+    // (four loads in flight per lane: one at a time, 16 dependent trips made this the longest kernel of the build, 18 us)
+    const unsigned stride = gridDim.x * kBlock;
+    for (unsigned i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float4 p[4];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], e[a]); mx[a] = max(mx[a], e[a]); }
-        }
+        for (int u = 0; u < 4; ++u) p[u] = pts[min(i0 + u * stride, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * stride < n && isfinite(p[u].x) && isfinite(p[u].y) && isfinite(p[u].z)) {
+                const unsigned e[3] = {enc(p[u].x), enc(p[u].y), enc(p[u].z)};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], e[a]); mx[a] = max(mx[a], e[a]); }
+            }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -1389,7 +1395,7 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     unsigned h_bbox[6];
     e = hipMemcpyAsync(d_bbox, init, sizeof init, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        bbox_kernel<<<std::min(stream_grid(n), 256u), kBlock, 0, st>>>(pts, (unsigned)n, d_bbox);
+        bbox_kernel<<<std::min(stream_grid(n, kBlock, 4), 256u), kBlock, 0, st>>>(pts, (unsigned)n, d_bbox);  // (1024 workgroups: 26 us — their 6 atomics each share one cache line)
         e = hipMemcpyAsync(h_bbox, d_bbox, sizeof h_bbox, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
