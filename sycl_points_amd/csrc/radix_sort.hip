@@ -31,11 +31,11 @@ constexpr int kRsThreads = 512;             // 8 waves
 constexpr int kRsWaves = kRsThreads / 64;
 constexpr int kRsItems = 4;                 // keys per lane (tile = 2048 keys: two workgroups per CU at 1 M keys)
 constexpr int kRsTile = kRsThreads * kRsItems;
-constexpr int kRsBins = 256;                // 8-bit digits
+constexpr int kRsMaxBins = 512;             // digits of 8 bits, or of 9 where that saves a pass (18 key bits: 2 passes, not 3)
 constexpr int kRsScanThreads = 256;
 
 // tile_hist is stored [digit][tile]: the scan over the tiles of a digit reads one contiguous row.
-template <typename KEY>
+template <typename KEY, int kRsBins>
 __global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const KEY* __restrict__ keys, unsigned n, unsigned shift,
                                                               unsigned mask, unsigned tiles, unsigned* __restrict__ tile_hist) {
     __shared__ unsigned h[kRsWaves][kRsBins];  // one histogram per wave: eight times less contention on a popular digit
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kRsScanThreads) void rs_scan_kernel(unsigned* __res
     if (threadIdx.x == 0) digit_total[d] = carry;
 }
 
-template <typename KEY>
+template <typename KEY, int kRsBins>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const KEY* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 KEY* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -154,8 +154,11 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const KEY* __res
         const bool valid = e < m;
         const unsigned d = (unsigned)(k[c] >> shift) & mask;
         unsigned long long peers = __ballot(valid);  // lanes of this chunk holding the same digit
+        constexpr int kDigitBits = kRsBins == 512 ? 9 : 8;
+        static_assert(kRsBins == 256 || kRsBins == 512, "digits of 8 or 9 bits");
+        static_assert(kRsBins <= kRsThreads, "one lane per digit in the offset steps");
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < kDigitBits; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long mm = __ballot(bit);
             peers &= bit ? mm : ~mm;
@@ -200,9 +203,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const KEY* __res
 
 }  // namespace
 
-// tile histograms [256][tiles] + the 256 digit totals
+// tile histograms [digits][tiles] + the digit totals, for the wider (9-bit) digit
 size_t radix_sort_u32_workspace_bytes(size_t n) {
-    return ((size_t)div_up(n ? n : 1, (size_t)kRsTile) * kRsBins + kRsBins) * sizeof(unsigned);
+    return ((size_t)div_up(n ? n : 1, (size_t)kRsTile) * kRsMaxBins + kRsMaxBins) * sizeof(unsigned);
 }
 size_t radix_sort_u64_workspace_bytes(size_t n) { return radix_sort_u32_workspace_bytes(n); }
 
@@ -211,18 +214,30 @@ template <typename KEY>
 int radix_sort_pairs(KEY* keys_a, KEY* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits, void* workspace,
                      bool* result_in_b, hipStream_t st, unsigned first_bit) {
     const unsigned tiles = div_up(n, (size_t)kRsTile);
+    // 9-bit digits where they save a pass (18 key bits — the cell ids of a 6-points-per-cell grid on 1 M points, a dense voxel
+    // box — sort in 2 passes instead of 3; 24 bits stay at 3 passes of 8)
+    const unsigned span = bits - first_bit;
+    const unsigned digit = (span + 8u) / 9u < (span + 7u) / 8u ? 9u : 8u;
+    const unsigned bins = 1u << digit;
     unsigned* const tile_hist = static_cast<unsigned*>(workspace);
-    unsigned* const digit_total = tile_hist + (size_t)tiles * kRsBins;
+    unsigned* const digit_total = tile_hist + (size_t)tiles * bins;
     KEY *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
     bool in_b = false;
-    for (unsigned shift = first_bit; shift < bits; shift += 8) {
-        const unsigned width = bits - shift < 8 ? bits - shift : 8;
+    for (unsigned shift = first_bit; shift < bits; shift += digit) {
+        const unsigned width = bits - shift < digit ? bits - shift : digit;
         const unsigned mask = (1u << width) - 1u;
-        rs_count_kernel<KEY><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
-        rs_scan_kernel<<<kRsBins, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
-        rs_scatter_kernel<KEY><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
-                                                             digit_total);
+        if (digit == 9u) {
+            rs_count_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            rs_scan_kernel<<<512, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
+            rs_scatter_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
+                                                                      digit_total);
+        } else {
+            rs_count_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            rs_scan_kernel<<<256, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
+            rs_scatter_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
+                                                                      digit_total);
+        }
         KEY* t = kin; kin = kout; kout = t;
         uint32_t* tv = vin; vin = vout; vout = tv;
         in_b = !in_b;
