@@ -86,6 +86,10 @@ def parse():
                     help="measurement only: a per-handle switch of csrc/sp_internal.h on the prepared source, e.g. reuse=0 "
                          "(every launch searches every point); such a line is not a benchmark result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only what the timed region launches (alignments of 20 iterations, criteria 0): no per-launch profile, "
+                         "no until-converged / reuse-off / stage legs — the run profiles/collect_traffic.py wraps, so that every "
+                         "dispatch of the dominant kernel it sees belongs to the timed mix of launches")
     ap.add_argument("--no-stages", action="store_true",
                     help="skip the `stages` block (BASELINE configs 2 and 3 and the pre-loop of config 4, timed after the GICP "
                          "region) and the reuse-off comparison")
@@ -304,12 +308,12 @@ def main():
     # ---- per-kernel durations over one alignment, by HIP events on the launch stream (rank 0's numbers are reported)
     kern = kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n_local, SORT_MODE)
     launches = classes = converged = None
-    if args.path == "fused" and group is None:
+    if args.path == "fused" and group is None and not args.timed_only:
         launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
         converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE)
 
     stages = reuse0 = None
-    if world == 1 and shards == 1 and not args.no_stages:
+    if world == 1 and shards == 1 and not args.no_stages and not args.timed_only:
         if args.path == "fused":
             reuse0 = reuse_off_comparison(sp, torch, args, S, prep, T_dev, T_ident, delta, SORT_MODE, REG_TYPE, n_local)
         stages = stage_block(sp, _lib, torch)
@@ -367,12 +371,14 @@ def main():
             "until_converged": converged,
             "reuse_off_comparison": reuse0,
             "stages": stages,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(dom), "algorithmic_bytes_per_launch": kern[dom]["bytes"],
-                         "hbm_frac_measured_traffic": ((measured_traffic(dom) / (kern[dom]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                                                       if measured_traffic(dom) else None)},
+            "roofline": roofline_block(dom, kern[dom]),
         }
+        # beside `value` (which counts every source point of every iteration, as BASELINE.md 4 defines the metric): the same
+        # alignment when every iteration searches every point, and what a caller of align() gets with the default criteria
+        if reuse0:
+            out["correspondences_per_s_every_iteration_searches"] = reuse0["correspondences_per_s"]
+        if converged:
+            out["correspondences_per_s_until_converged"] = converged["correspondences_per_s"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, REG_TYPE)
         sys.stdout.flush()
@@ -382,16 +388,34 @@ def main():
         dist.destroy_process_group()
 
 
+HBM_COPY_GBS = 6290.0  # measured float4 streaming copy of the part (MI355X_MICROARCH.md chip table)
+
+
 def measured_traffic(kernel):
-    """HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs and
-    corrected as MI355X_MICROARCH.md §HBM prescribes), if a summary for this kernel has been committed under profiles/."""
+    """HBM bytes per launch of the TIMED MIX of launches (one alignment = 20 launches from the identity guess, criteria 0:
+    the first ones search, the rest stream), from the rocprofv3 PMC passes over `bench.py --timed-only` (FETCH_SIZE /
+    WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md §HBM prescribes: profiles/collect_traffic.py), if a
+    summary for this kernel has been committed under profiles/. Returns (bytes or None, how it was obtained)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     try:
-        return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
+        k = json.load(open(path)).get(kernel, {})
+        return k.get("timed_mix_hbm_bytes_per_launch", k.get("hbm_bytes_per_launch")), k.get("correction")
     except Exception:
-        return None
+        return None, None
+
+
+def roofline_block(dom, k):
+    traffic, how = measured_traffic(dom)
+    t = k["ms"] * 1e-3
+    return {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": k["bytes"],
+            "frac_of_measured_copy_peak": k["GBps"] / HBM_COPY_GBS,
+            "hbm_frac_measured_traffic": (traffic / t / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "copy_peak_frac_measured_traffic": (traffic / t / 1e9 / HBM_COPY_GBS) if traffic else None,
+            "traffic_note": ("mean over the launches of the timed mix (profiles/traffic.json, collected by "
+                             "profiles/collect_traffic.py over `bench.py --timed-only`); " + how) if traffic else None}
 
 
 def preloop_times(sp, _lib, torch, g6, covs_full, rank, world):
@@ -702,10 +726,10 @@ def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, d
             tot += e0.elapsed_time(e1)
         ms = tot / reps_a / ITERS_PER_ALIGN
         res["gicp_align_kernel"] = {"ms": ms, "bytes": BYTES_ITER * n, "GBps": BYTES_ITER * n / (ms * 1e-3) / 1e9,
-                                    "note": "per-iteration launch: per point certified reuse of the previous correspondence or "
-                                            "NN(k=1) search, linearise, workgroup reduction; the last-arriving workgroup sums the "
-                                            "256 partial rows, solves the 6x6 system and updates the pose; mean over the 20 "
-                                            "launches of an alignment started at the identity"}
+                                    "note": "per-iteration launch: prologue (every workgroup sums the previous launch's 256 "
+                                            "partial rows, solves the 6x6 system and updates the pose), then per point certified "
+                                            "reuse of the previous correspondence or NN(k=1) search, linearise, workgroup "
+                                            "reduction; mean over the 20 launches of an alignment started at the identity"}
         # (b) the finish kernel alone
         reg._set_source_option("stage_mask", 2)
         align_launches()

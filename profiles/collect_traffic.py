@@ -1,14 +1,28 @@
 #!/usr/bin/env python3
-"""Collect HBM traffic of the hot kernels with rocprofv3 PMC counters and write profiles/traffic.json.
+"""Collect HBM traffic of the hot kernels with rocprofv3 PMC counters and write gpurun_out/traffic.json (copy it to
+profiles/traffic.json: bench.py prints its `timed_mix_hbm_bytes_per_launch` as roofline.traffic).
 
 Run on the GPU box from the repository root:  python3 profiles/collect_traffic.py
-Method (MI355X_MICROARCH.md §HBM / cdna_hip_programming.md §7): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE
-passes (they do not fit one pass on gfx950), with --kernel-trace only; both are in KiB. The guide's gfx950 correction
-(FETCH_SIZE reads exactly half for WIDE COALESCED streaming reads) does not transfer to gather-shaped kernels, so, as the
-guide prescribes for other access shapes, the read side is CALIBRATED on a known byte count in the same access pattern:
-prepare_cov_kernel gathers one 64-byte covariance row per lane through an index (the shape of the fused kernel's loads)
-and reads a known n x (64 + 16) bytes. factor = known / FETCH_SIZE; WRITE_SIZE is exact for 16-byte stores (checked:
-prepare_cov writes exactly n x 32 bytes). bytes = factor * FETCH_SIZE * 1024 + WRITE_SIZE * 1024, per launch. This script never touches the GPU itself; rocprofv3 wraps `python3 bench.py` directly.
+Method (MI355X_MICROARCH.md §HBM / cdna_hip_programming.md §7):
+  * FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (they do not fit one pass on gfx950), with --kernel-trace
+    only; both are in KiB. rocprofv3 wraps `python3 bench.py ...` directly (no env / bash hop).
+  * The profiled command is `bench.py --timed-only`: every dispatch of gicp_align_kernel it makes belongs to an alignment of
+    20 launches from the identity guess with criteria 0 — the mix of launches the timed region runs (warm-up, timed blocks,
+    the verification alignment and the HIP-event leg all launch exactly that). Dispatch i of the kernel is therefore launch
+    i % 20 of an alignment; the mean over all dispatches is the mean over the timed mix.
+  * Classes by the same rule bench.py's launch_classes uses: a launch is "searching" when more than 1 % of its points
+    were searched. On the counter side a searched point rewrites its 48-byte cache row: 1 % of 1 M points = 480 KiB of
+    WRITE_SIZE.
+  * Correction, ONE rule for every launch, the guide's and nothing else: on gfx950 FETCH_SIZE reports exactly half of the
+    bytes of a wide coalesced streaming read and WRITE_SIZE reads 16-byte stores exactly; other access shapes (the gathers
+    of a searching launch: 16-byte points, 32-byte prepared rows, 4-byte cell extents, each a 64-byte request of its own)
+    are taken as the counter reports them. The bytes a launch is KNOWN to stream coalesced are the nine source planes
+    (36 B / point) and, from launch 1 on, the 48-byte correspondence-cache row of every point (read to test its
+    certificate): HBM bytes = FETCH_SIZE + streamed / 2 + WRITE_SIZE. For a steady launch (nothing but those streams) this
+    is FETCH_SIZE x 2 when the counter indeed reads streamed / 2 — printed per launch as `fetch_over_half_stream` (1.00 =
+    the rule holds exactly). Round 1-3 multiplied the searching launches' FETCH_SIZE by a factor 1.13 calibrated in round 1
+    on a kernel that has changed since; that constant is gone.
+This script never touches the GPU itself.
 """
 import collections
 import csv
@@ -21,85 +35,77 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
 KERNELS = {"gicp_align_kernel": "gicp_align_kernel", "align_finish_kernel": "align_finish_kernel",
-           "gicp_fused_kernel": "gicp_fused_kernel", "final_reduce_kernel": "final_reduce_kernel",
-           "prepare_cov_kernel": "prepare_cov_kernel"}
+           "align_solve_kernel": "align_solve_kernel", "prepare_source_kernel": "prepare_source_kernel"}
+ITERS = 20
+N_POINTS = 1_000_000
+SEARCH_WRITE_KIB = 0.01 * N_POINTS * 48 / 1024.0  # 1 % of the points rewrote their cache row
 
 
-def run_pass(counter):
-    d = os.path.join(OUT, counter)
+def run_pass(counter, cmd_tail, sub):
+    d = os.path.join(OUT, sub, counter)
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "40", "--warmup", "20", "--repeats", "3"]
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable] + cmd_tail
     subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return read_pass(counter)
 
 
-def read_pass(counter):
-    d = os.path.join(OUT, counter)
-    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
-            continue
-        for key, pat in KERNELS.items():
-            if pat in r["Kernel_Name"]:
-                acc[key].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
-
-
-GATHER_FACTOR = 1.13  # read-side calibration for gather-shaped launches, measured in round 1 (r01_g) on
-                      # prepare_cov_kernel (known n x 80 B gathered -> FETCH_SIZE x 1.13); since the correspondence cache
-                      # was added that kernel's window also sees write-backs of older dirty lines, so the constant is kept
-
-
-def per_launch(counter, pattern):
-    d = os.path.join(OUT, counter)
-    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
+def per_launch(counter, pattern, sub):
+    d = os.path.join(OUT, sub, counter)
+    fs = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    if not fs:
+        return []
+    f = max(fs, key=os.path.getmtime)
     rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(f))
             if r["Counter_Name"] == counter and pattern in r["Kernel_Name"]]
     return [v for _, v in sorted(rows)]
 
 
 def main():
+    bench = [os.path.join(ROOT, "bench.py"), "--timed-only", "--no-cpu-baseline", "--steps", "40", "--warmup", "20", "--repeats", "3"]
     if "--reuse" not in sys.argv:  # otherwise recompute from CSVs already under gpurun_out/pmc_traffic (no GPU needed)
-        run_pass("FETCH_SIZE")
-        run_pass("WRITE_SIZE")
+        run_pass("FETCH_SIZE", bench, "bench")
+        run_pass("WRITE_SIZE", bench, "bench")
     out = {}
     for key, pat in KERNELS.items():
-        f, w = per_launch("FETCH_SIZE", pat), per_launch("WRITE_SIZE", pat)
+        f, w = per_launch("FETCH_SIZE", pat, "bench"), per_launch("WRITE_SIZE", pat, "bench")
         if not f or len(f) != len(w):
             continue
         if key == "gicp_align_kernel":
-            # Steady-state launches (every correspondence certified from the source-ordered cache, nothing written back
-            # to it) are wide coalesced streams: the guide's gfx950 rule applies, FETCH_SIZE reads half the bytes (check:
-            # 2 x 47.4 MiB = 99.4 MB against the 96 B/point the kernel is known to stream). Launches that search (the first
-            # poses of an alignment: cache rows rewritten, WRITE_SIZE in the tens of MiB) are gather-shaped: calibrated
-            # factor. Both in KiB as the counters report.
-            # (a searched point rewrites its 48-byte cache row: 480 KiB of writes = 1 % of 1M points searched, the same
-            # threshold bench.py's launch_classes uses on the device-side searched-point count)
-            # launches that return at once (an earlier iteration converged: bench.py's until_converged leg) fetch < 1 MiB
-            # and belong to neither class
-            steady = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w) if b < 480.0 and a >= 1024.0]
-            search = [(GATHER_FACTOR * a + b) * 1024.0 for a, b in zip(f, w) if b >= 480.0]
-            allb = steady + search
-            out[key] = {"launches": len(allb), "hbm_bytes_per_launch": sum(allb) / len(allb),
-                        "steady_state_launches": len(steady),
-                        "steady_state_hbm_bytes_per_launch": sum(steady) / max(len(steady), 1),
-                        "searching_launches": len(search),
-                        "searching_hbm_bytes_per_launch": sum(search) / max(len(search), 1),
-                        "classes": {"steady": {"launches": len(steady),
-                                               "hbm_bytes_per_launch": sum(steady) / max(len(steady), 1)},
-                                    "searching": {"launches": len(search),
-                                                  "hbm_bytes_per_launch": sum(search) / max(len(search), 1)}},
-                        "FETCH_SIZE_KiB_per_launch": sum(f) / len(f), "WRITE_SIZE_KiB_per_launch": sum(w) / len(w),
-                        "correction": "steady-state launches: FETCH_SIZE x 2 (wide coalesced stream, guide's gfx950 rule); "
-                                      "searching launches: FETCH_SIZE x 1.13 (gather-shaped, calibrated); WRITE_SIZE exact"}
+            n_al = len(f) // ITERS
+            f, w = f[:n_al * ITERS], w[:n_al * ITERS]
+            streamed = [N_POINTS * 36 + (N_POINTS * 48 if (i % ITERS) >= 1 else 0) for i in range(len(f))]
+            corrected = [a * 1024.0 + s2 / 2.0 + b * 1024.0 for a, b, s2 in zip(f, w, streamed)]
+            searching = [b >= SEARCH_WRITE_KIB for b in w]
+            by_pos = []
+            for k in range(ITERS):
+                v = corrected[k::ITERS]
+                fk, wk = sum(f[k::ITERS]) / n_al, sum(w[k::ITERS]) / n_al
+                by_pos.append({"k": k, "class": "searching" if searching[k] else "steady", "hbm_bytes": sum(v) / len(v),
+                               "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "streamed_bytes_known": streamed[k],
+                               "fetch_over_half_stream": fk * 1024.0 / (streamed[k] / 2.0),
+                               "points_searched_from_WRITE_SIZE": int(wk * 1024.0 / 48.0)})
+            st = [c for c, s2 in zip(corrected, searching) if not s2]
+            se = [c for c, s2 in zip(corrected, searching) if s2]
+            n_se = sum(1 for p in by_pos if p["class"] == "searching")
+            mix = sum(corrected) / len(corrected)
+            out[key] = {
+                "launches": len(corrected), "alignments": n_al,
+                "timed_mix_hbm_bytes_per_launch": mix,
+                "timed_mix": f"({ITERS - n_se} x steady + {n_se} x searching) / {ITERS}: every dispatch of the profiled run is "
+                             f"launch i % {ITERS} of an alignment of the timed workload",
+                "hbm_bytes_per_launch": mix,
+                "classes": {"steady": {"launches": len(st), "hbm_bytes_per_launch": sum(st) / max(len(st), 1)},
+                            "searching": {"launches": len(se), "hbm_bytes_per_launch": sum(se) / max(len(se), 1)}},
+                "by_launch_in_alignment": by_pos,
+                "FETCH_SIZE_KiB_per_launch": sum(f) / len(f), "WRITE_SIZE_KiB_per_launch": sum(w) / len(w),
+                "correction": "HBM bytes = FETCH_SIZE + (bytes known to be streamed coalesced: 36 B / point of source planes, "
+                              "+ 48 B / point of cache rows from launch 1 on) / 2 + WRITE_SIZE — the guide's gfx950 rule (FETCH_SIZE "
+                              "reads half of a wide coalesced stream) applied to the streams only; gathers as the counter reports "
+                              f"them; classes: searching = WRITE_SIZE >= {SEARCH_WRITE_KIB:.0f} KiB (1 % of the points searched)"}
         else:
             fm, wm = sum(f) / len(f), sum(w) / len(w)
             out[key] = {"launches": len(f), "FETCH_SIZE_KiB_per_launch": fm, "WRITE_SIZE_KiB_per_launch": wm,
-                        "hbm_bytes_per_launch": (GATHER_FACTOR * fm + wm) * 1024.0,
-                        "correction": "FETCH_SIZE x 1.13 (gather-shaped, calibrated); WRITE_SIZE exact"}
+                        "correction": "raw counters (KiB): no correction applied"}
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

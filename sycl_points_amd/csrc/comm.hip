@@ -165,12 +165,14 @@ extern "C" int sp_xchg_create(int rank, int world, sp_xchg** out) {
     sp_xchg* x = new sp_xchg();
     x->rank = rank;
     x->world = world;
-    const size_t bytes = (size_t)2 * world * kXchgRow * sizeof(unsigned long long);
-    // uncached: written by other agents (and other processes), polled here — nothing of it may sit in this GPU's L2
+    const size_t bytes = (size_t)kXchgSlots * world * kXchgRow * sizeof(unsigned long long);
+    // uncached (or at least fine-grained): written by other agents (and other processes), polled here — nothing of it may sit
+    // in this GPU's L2. No silent fall-back to ordinary memory: polls could then be served stale lines and every alignment would
+    // run into its time limit; the caller falls back to the collective instead (bench.py --exchange auto).
     hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&x->local), bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        e = hipMalloc(reinterpret_cast<void**>(&x->local), bytes);
+        e = hipExtMallocWithFlags(reinterpret_cast<void**>(&x->local), bytes, hipDeviceMallocFinegrained);
     }
     if (e == hipSuccess) e = hipMemset(x->local, 0, bytes);  // tag 0 is never a sequence number
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x->peers_dev), kXchgMaxWorld * sizeof(void*));

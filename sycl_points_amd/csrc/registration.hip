@@ -1086,10 +1086,10 @@ __device__ __forceinline__ void align_tail(const AlignArgs& A, const float* __re
             else if (threadIdx.x == kAcc) v = (float)(cnt >> 12);
             else if (threadIdx.x == kAcc + 1) v = red[0][kAcc];
             A.fan_row_out[threadIdx.x] = v;
-            if (A.mode == ALIGN_DIRECT) {  // the row, tagged, into slot [k & 1][rank] of every rank's buffer (sp_xchg.h)
+            if (A.mode == ALIGN_DIRECT) {  // the row, tagged, into slot [epoch & 1][k & 1][rank] of every rank's buffer (sp_xchg.h)
                 const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k_launch + 1u;
                 const unsigned long long granule = ((unsigned long long)seq << 32) | __float_as_uint(v);
-                const size_t slot = ((size_t)(A.k_launch & 1) * A.x.world + A.x.rank) * kFanRow + threadIdx.x;
+                const size_t slot = ((size_t)xchg_slot(*A.x.epoch, A.k_launch) * A.x.world + A.x.rank) * kFanRow + threadIdx.x;
                 for (int r = 0; r < A.x.world; ++r)
                     __hip_atomic_store(A.x.peers[r] + slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -1127,8 +1127,9 @@ __device__ __forceinline__ bool align_totals(const AlignArgs& A, const float* __
             if (converged && *converged) return true;  // (set by `after_loads`: nobody has stored a row, do not wait for one)
             if (threadIdx.x < (unsigned)A.x.world * kFanRow) {
                 const unsigned r = threadIdx.x / kFanRow, e = threadIdx.x % kFanRow;
-                const unsigned long long* const g = A.x.local + ((size_t)(A.k & 1) * A.x.world + r) * kFanRow + e;
-                const unsigned seq = *A.x.epoch * 256u + (unsigned)A.k + 1u;
+                const unsigned epoch = *A.x.epoch;
+                const unsigned long long* const g = A.x.local + ((size_t)xchg_slot(epoch, A.k) * A.x.world + r) * kFanRow + e;
+                const unsigned seq = epoch * 256u + (unsigned)A.k + 1u;
                 const unsigned long long t0 = wall_clock64();
                 unsigned long long v = 0;
                 bool ok = false;
@@ -2015,6 +2016,13 @@ int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, 
     if (!(source->opt_stage_mask & 1)) {}                                                                  \
     else if (mode == ALIGN_PROLOGUE) { SP_LAUNCH_ALIGN2(L, false); }                                      \
     else { SP_LAUNCH_ALIGN2(L, true); }
+#ifdef SP_DEV_MIN  // development builds only (scratch/devbuild.sh): one instantiation of the kernel, a fraction of the compile time
+    if (params->robust_type != SP_LOSS_NONE || !fast || p2d || mode != ALIGN_PROLOGUE) {
+        sp_set_error("SP_DEV_MIN build: only GICP / NONE / sorted source / one GPU");
+        return SP_ERR_RUNTIME;
+    }
+    if (source->opt_stage_mask & 1) gicp_align_kernel<LOSS_NONE, true, false, false><<<grid, kAlignBlock, 0, st>>>(P, A, out);
+#else
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_ALIGN(LOSS_NONE); break;
         case SP_LOSS_HUBER: SP_LAUNCH_ALIGN(LOSS_HUBER); break;
@@ -2023,6 +2031,7 @@ int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, 
         case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_ALIGN(LOSS_GEMAN_MCCLURE); break;
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
+#endif
 #undef SP_LAUNCH_ALIGN
 #undef SP_LAUNCH_ALIGN2
     if (fills_cache) source->cache_valid = true;
@@ -2104,7 +2113,14 @@ extern "C" int sp_gicp_align_direct(const sp_gicp_target* target, const sp_gicp_
     for (int k = 0; k < max_iterations; ++k) {
         const int rc = align_step_impl(target, source, transT_device, params, gn, k, ALIGN_DIRECT, nn_idx_out, nn_d2_out, lin_out,
                                        workspace, workspace_bytes, stream, xchg);
-        if (rc != SP_OK) return rc;
+        if (rc != SP_OK) {
+            // launches of this alignment may be in the queue already: still enqueue the finish launch, which bumps the epoch
+            // word — the peers bump theirs, and a rank that fell behind would mismatch every tag from then on
+            if (k > 0)
+                (void)align_finish_impl(source, transT_device, gn, k - 1, ALIGN_DIRECT, lin_out, delta_out8, iterations_out, workspace,
+                                        workspace_bytes, stream, xchg);
+            return rc;
+        }
     }
     return align_finish_impl(source, transT_device, gn, max_iterations - 1, ALIGN_DIRECT, lin_out, delta_out8, iterations_out,
                              workspace, workspace_bytes, stream, xchg);

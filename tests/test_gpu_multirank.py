@@ -246,6 +246,24 @@ def _direct_worker(rank, world, port, n, iters, out_path, absent):
         regc.direct_status()
         res["Tc"] = Tc.cpu().numpy()
         res["itc"] = np.float32(int(regc._iters_dev[0]))
+        # Back to back, nothing synchronised in between, odd iteration counts and early convergence, one rank enqueueing late:
+        # the slot an alignment's LAST row sits in must not be the one the next alignment's FIRST row goes to (round 3 indexed
+        # the slots by the parity of the iteration alone: a late peer then missed a row and ran into its time limit).
+        regs = []
+        for rep, it in enumerate((7, 5, 7, 3, 0, 0)):
+            if rank == rep % 2:
+                torch.cuda._sleep(4_000_000)  # this rank's launches of the alignment start ~2 ms after the peer's
+            pk = (sp.RegistrationParams(max_iterations=iters) if it == 0 else  # 0: default criteria, stops early
+                  sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=it))
+            regk = sp.Registration(pk)
+            Tk, _, _ = regk.align_fused_loop(Sh, prep, iterations=None if it == 0 else it, xchg=x)
+            regs.append((regk, Tk.clone()))
+        torch.cuda.synchronize()
+        for rep, (regk, Tk) in enumerate(regs):
+            res[f"Ts{rep}"] = Tk.cpu().numpy()
+        for regk, _ in regs:
+            regk.direct_status()  # raises when a row did not arrive in time
+        res["stress_ok"] = np.float32(1)
         regg = sp.Registration(p)
         Tg_, _, _ = regg.align_fused_loop(Sh, prep, iterations=iters, group=dist.group.WORLD)  # the gloo row exchange
         torch.cuda.synchronize()
@@ -278,6 +296,11 @@ def test_direct_exchange_two_processes_one_gpu(tmp_path):
     assert np.abs(r0["T0"] - r0["Tgloo"]).max() < 2e-6  # = the collective exchange's pose (the summation order differs)
     assert int(r0["inl0"]) == n and int(r0["it0"]) == iters
     assert 1 <= int(r0["itc"]) < iters and np.abs(r0["Tc"] - r0["T0"]).max() < 2e-3
+    # the back-to-back series: same poses on both ranks (checked above for every key), repeats identical, all near the answer
+    assert int(r0["stress_ok"]) == 1
+    assert np.array_equal(r0["Ts0"], r0["Ts2"]) and np.array_equal(r0["Ts4"], r0["Ts5"])
+    for rep in range(6):
+        assert np.isfinite(r0[f"Ts{rep}"]).all() and np.abs(r0[f"Ts{rep}"] - r0["T0"]).max() < 5e-3, rep
     sp, S, Tg, T_gt = _make(n)
     prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
     reg = sp.Registration(sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=iters))
