@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsycl_points_amd.so")
+# SP_AMD_LIB: another build of the same library (A/B measurements on one box, scratch/ab.sh); the tests and bench.py never set it
+LIB_PATH = os.environ.get("SP_AMD_LIB") or os.path.join(_HERE, "lib", "libsycl_points_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SP_OK, SP_ERR_INVALID_ARGUMENT, SP_ERR_RUNTIME, SP_ERR_HIP = 0, 1, 2, 3
