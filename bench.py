@@ -310,7 +310,7 @@ def main():
     launches = classes = converged = None
     if args.path == "fused" and group is None and not args.timed_only:
         launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
-        converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE)
+        converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE, internal=args.internal)
 
     stages = reuse0 = None
     if world == 1 and shards == 1 and not args.no_stages and not args.timed_only:
@@ -535,13 +535,15 @@ def launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n, reps=7)
     return launches, classes
 
 
-def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reg_type="GICP", reps=31):
+def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reg_type="GICP", reps=31, internal=()):
     """What a caller of align() gets: ONE alignment with the reference's default convergence criteria (1e-3 / 1e-3,
     registration_params.hpp:94-96) from the identity guess, timed whole (source preparation + max_iterations launches, the
     ones after convergence returning at once, + finish) with HIP events; correspondences/s = points x executed iterations
     / that time. Median over `reps` alignments."""
     p = sp.RegistrationParams(reg_type=reg_type, optimization_method="GN", max_iterations=ITERS_PER_ALIGN)
     reg = sp.Registration(p)
+    for kv in internal:
+        reg._set_source_option(kv.split("=")[0], int(kv.split("=")[1]))
     ms = []
     for _ in range(reps + 2):
         T_dev.copy_(T_ident)

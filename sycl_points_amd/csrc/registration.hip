@@ -10,6 +10,9 @@
 // bit-reproducible from run to run. HBM-bound: 168 B per source point.
 // The factor arithmetic keeps the reference's fma chains (sp_math.h); structural zeros of the padded 4x4/4x6 types
 // are skipped, which leaves every finite result bit-identical.
+#include <algorithm>
+#include <mutex>
+
 #include "grid_device.h"
 #include "radix_sort.h"
 #include "sp_xchg.h"
@@ -1299,6 +1302,176 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The whole alignment as ONE launch (single GPU; sp_gicp_align_fused takes it when every workgroup is co-resident: one
+// 1024-lane workgroup per CU, at most 256 of them). The iterations are separated by the arrival counter the sharded modes' fan-in
+// already uses, not by kernel boundaries:
+//   iteration k   per-point loop exactly as gicp_align_kernel -> the workgroup's partial row, stored write-through (sc1) ->
+//                 wave 0 drains its stores, lane 0 adds 1 to the counter shard of its XCD (agent scope)
+//   then          every workgroup waits until the shards add up to grid * (k + 1) — one lane polls with sc1 loads and s_sleep,
+//                 bounded by wall_clock64 (a grid that is not fully resident ends with the error word set, never hangs) — and
+//                 runs today's prologue on the rows (sc1 loads, same fixed order: the same bits as the per-launch form)
+// (MI355X_MICROARCH.md, hand-off table, first row: one lane signals for all its workgroup's sc1 stores behind the storing
+// wave's vmcnt(0) wait; the consumer polls with sc1 loads, the polling wave loads after its poll has matched, the others behind
+// a workgroup barrier it joins.) What it removes: the kernel boundary and the launch ramp of every iteration, the launches
+// that only find out that an earlier iteration converged (an alignment that converges after 3 of 20 iterations enqueued 17 of
+// them, 2.5 us each), and the finish launch (workgroup 0 finishes the last iteration itself).
+// Rows ping-pong by the parity of k: a workgroup can only write row k + 1 after every workgroup has stored row k, i.e. after
+// every workgroup has finished reading the rows of k - 1 that it overwrites.
+// The pose of a launch into scalar registers (it is uniform; it would otherwise occupy 12 VGPRs for the whole loop).
+__device__ __forceinline__ Rigid uniform_pose(const float* sT) {
+    Rigid T = load_rigid_colmajor(sT);
+    auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T.R[r][c] = uniform(T.R[r][c]);
+        T.t[r] = uniform(T.t[r]);
+    }
+    return T;
+}
+constexpr int kTicketShards = 8;
+constexpr int kTicketStride = 32;  // uint32 words between two shards (128 bytes: a line each)
+struct PersistArgs {
+    float* part[2];              // partial rows, ping-pong
+    AlignState* state;           // [2]
+    unsigned* searched_log;
+    unsigned* tickets;           // kTicketShards counters, kTicketStride words apart, zero when the launch starts
+    const float* T_init;         // device: initial guess (read before T_out is written)
+    float lambda, crit_rot, crit_trans;
+    sp_linearized* lin_out;
+    float* T_out;                // device: final pose (may be T_init)
+    float* delta_out8;
+    uint32_t* iterations_out;
+    int max_iterations;
+    int k_begin;                 // first iteration this launch runs; iterations 0 .. k_begin - 1 were launched one by one, the
+                                 // rows of k_begin - 1 are in part[(k_begin - 1) & 1], the state after k_begin - 2 in state[k_begin & 1]
+    int cache_valid_later;       // launches after the first may trust the cache (reuse switched on)
+    unsigned long long budget;   // wall_clock64 ticks a wait may take
+};
+template <int LOSS, bool FAST_NN, bool P2D = false>
+__global__ __launch_bounds__(kAlignBlock) void gicp_align_persistent_kernel(FusedParams P, PersistArgs A) {
+    __shared__ float sT[16];
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ sp_linearized slin;
+    __shared__ float sdelta[8];
+    __shared__ LdltScratch ldlt_ws;
+    __shared__ unsigned s_flag;  // 0 go on, 1 converged / done, 2 a wait ran out
+    const unsigned stride = gridDim.x * kAlignBlock;
+    unsigned tile = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    __shared__ unsigned s_prev[2];  // converged, iterations of the state this launch starts from
+    if (A.k_begin >= 2) {  // the state after iteration k_begin - 2: the pose launch k_begin - 1 ran at, the flags
+        if (threadIdx.x < 18) {
+            const unsigned v = reinterpret_cast<const unsigned*>(&A.state[A.k_begin & 1])[threadIdx.x < 16 ? threadIdx.x : kStateFlagWord + threadIdx.x - 16];
+            if (threadIdx.x < 16) sT[threadIdx.x] = __uint_as_float(v);
+            else s_prev[threadIdx.x - 16] = v;
+        }
+    } else {
+        if (threadIdx.x < 16) sT[threadIdx.x] = A.T_init[threadIdx.x];
+        else if (threadIdx.x < 18) s_prev[threadIdx.x - 16] = 0u;
+    }
+    if (A.k_begin == 0 && blockIdx.x == 0 && A.searched_log && threadIdx.x >= 64 && threadIdx.x < 64 + kSearchedLog)
+        A.searched_log[threadIdx.x - 64] = 0u;
+    __syncthreads();
+    if (s_prev[0]) {  // converged before this launch (uniform): workgroup 0 hands out the results of that state
+        if (blockIdx.x == 0) {
+            const AlignState* const sp_ = &A.state[A.k_begin & 1];
+            if (threadIdx.x < kStateWords)
+                reinterpret_cast<unsigned*>(&A.state[(A.k_begin + 1) & 1])[threadIdx.x] = reinterpret_cast<const unsigned*>(sp_)[threadIdx.x];
+            if (threadIdx.x < 16) A.T_out[threadIdx.x] = sp_->T[threadIdx.x];
+            else if (threadIdx.x < 24 && A.delta_out8) A.delta_out8[threadIdx.x - 16] = sp_->delta[threadIdx.x - 16];
+            else if (threadIdx.x == 24 && A.iterations_out) *A.iterations_out = sp_->iterations;
+        }
+        return;
+    }
+    unsigned iterations = s_prev[1];
+    for (int k = A.k_begin;; ++k) {
+        if (k > 0) {
+            // ---- wait for the rows of iteration k - 1 (a kernel boundary did, for the first one), then finish it: the prologue
+            // of gicp_align_kernel
+            if (threadIdx.x == 0) {
+                const unsigned want = gridDim.x * (unsigned)(k - A.k_begin);
+                const unsigned long long t0 = wall_clock64();
+                unsigned flag = 0;
+                for (;;) {
+                    unsigned have = 0;
+#pragma unroll
+                    for (int sh = 0; sh < kTicketShards; ++sh)
+                        have += __hip_atomic_load(A.tickets + sh * kTicketStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (have >= want) break;
+                    if (wall_clock64() - t0 > A.budget) { flag = 2; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                s_flag = flag;
+            }
+            __syncthreads();
+            if (s_flag == 2) {  // (uniform per workgroup; every workgroup runs into the same bound)
+                if (blockIdx.x == 0 && threadIdx.x < 16) A.T_out[threadIdx.x] = __int_as_float(0x7fc00000);  // loud: NaN pose
+                if (blockIdx.x == 0 && threadIdx.x == 16 && A.iterations_out) *A.iterations_out = 0xffffffffu;
+                if (blockIdx.x == 0 && threadIdx.x == 17) { A.state[0].pad = 2u; A.state[1].pad = 2u; }
+                return;
+            }
+            reduce_rows_1024<true>(A.part[(k - 1) & 1], gridDim.x, kAcc - 1, red, false, [] {});
+            if (threadIdx.x == 0) {
+                const bool publish = blockIdx.x == 0;
+                AlignState* const so = &A.state[(k - 1) & 1];
+                if (publish) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) so->T_lin[i] = sT[i];
+                }
+                prologue_step(red[0], &slin, sT, A.lambda, A.crit_rot, A.crit_trans, sdelta, &ldlt_ws);
+                const bool conv = sdelta[6] > 0.5f;
+                const bool last = conv || k == A.max_iterations;
+                if (publish) {
+                    const unsigned searched = (unsigned)red[0][kAcc];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) so->T[i] = sT[i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) so->delta[i] = sdelta[i];
+                    so->converged = conv ? 1u : 0u;
+                    so->iterations = iterations + 1;
+                    so->searched = searched;
+                    so->pad = 0;
+                    if (A.searched_log && k - 1 < kSearchedLog) A.searched_log[k - 1] = searched;
+                    if (A.lin_out) *A.lin_out = slin;
+                    if (last) {  // the outputs, and the same state in the other slot (whoever reads state[last & 1] finds it)
+                        A.state[k & 1] = *so;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) A.T_out[i] = sT[i];
+                        if (A.delta_out8)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) A.delta_out8[i] = sdelta[i];
+                        if (A.iterations_out) *A.iterations_out = iterations + 1;
+                    }
+                }
+                s_flag = last ? 1u : 0u;
+            }
+            __syncthreads();
+            ++iterations;
+            if (s_flag) return;  // converged with this step, or the last iteration is finished (uniform over the grid)
+        }
+        const Rigid T = uniform_pose(sT);
+        float acc[kAcc - 1];
+        unsigned cnt = 0, searched = 0;
+#pragma unroll
+        for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
+        if (k == 1) P.cache_valid = A.cache_valid_later;  // (P is this kernel's own copy of the parameters; a launch that
+                                                           //  begins later was handed the right value)
+        for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
+            fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
+        block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, A.part[k & 1] + (size_t)blockIdx.x * kPartial, false, searched);
+        if (threadIdx.x < kWave) {  // the storing lanes all sit in wave 0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0)
+                __hip_atomic_fetch_add(A.tickets + (blockIdx.x & (kTicketShards - 1)) * kTicketStride, 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (after the last iteration's rows only workgroup 0 is needed: it finishes the iteration and writes the outputs)
+        if (k == A.max_iterations - 1 && blockIdx.x != 0) return;
+    }
+}
+
 // Sharded runs: finishes iteration k on every rank from the all-reduced row (ALIGN_FANIN) or rows (ALIGN_ROWS) — the same
 // sums, the same solve, hence the identical pose on every rank without a broadcast. One workgroup.
 struct AlignPublish {  // after the LAST iteration: the results out of the state block (all null: nothing to publish)
@@ -1563,6 +1736,8 @@ struct sp_gicp_source {
     int opt_stage_mask = 3;  // bit 0 = per-iteration kernel, bit 1 = final reduce (+ solve) / finish kernel
     int opt_reuse = 2;       // 0 always search, 1 reuse on the first certificate, 2 also the second
     int opt_fast_nn = -1;    // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
+    int opt_persistent = 1;  // sp_gicp_align_fused: 1 the tail of an alignment as one launch when the grid is resident, 0 a launch per iteration
+    int opt_persistent_from = 4;  // first iteration of that tail
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -2148,6 +2323,99 @@ extern "C" int sp_gicp_align_linearization_pose(const void* workspace, int last_
                                          sp::as_stream(stream)));
 }
 
+namespace sp {
+namespace {
+// ---- the one-launch form of sp_gicp_align_fused (gicp_align_persistent_kernel)
+constexpr size_t kTicketOffsetBytes = 96 * 1024;  // in the workspace, behind everything align_ws() lays out (< 66 KB)
+static_assert(kTicketOffsetBytes + kTicketShards * kTicketStride * 4 <= (size_t)kMaxBlocks * kPartial * sizeof(float), "workspace");
+struct PersistGuard {  // one persistent alignment at a time per process: two in flight on different streams would each hold
+    std::mutex m;      // CUs the other one is waiting for (both would run into their time limit)
+    hipStream_t last = nullptr;
+    hipEvent_t done = nullptr;
+    bool used = false;
+};
+PersistGuard& persist_guard() { static PersistGuard g; return g; }
+int device_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+    }();
+    return cus;
+}
+bool persistent_ok(const sp_gicp_target* target, const sp_gicp_source* source, const sp_factor_params* params,
+                   const sp_gn_params* gn, const float* T, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (source->opt_persistent == 0 || source->opt_stage_mask != 3) return false;
+    if (align_check("fused", target, source, params, gn, T, workspace, workspace_bytes) != SP_OK) return false;  // (reported by the step)
+    if ((int)align_grid(source->n) > device_cus()) return false;  // every workgroup needs a CU of its own
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;  // (no event query in a capture)
+    PersistGuard& g = persist_guard();
+    std::lock_guard<std::mutex> lock(g.m);
+    if (g.used && g.last != st && hipEventQuery(g.done) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;  // another stream's alignment may still be running: take the per-launch form
+    }
+    return true;
+}
+int launch_persistent(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                      const sp_factor_params* params, const sp_gn_params* gn, int k_begin, int max_iterations, int32_t* nn_idx_out,
+                      float* nn_d2_out, sp_linearized* lin_out, float* delta_out8, uint32_t* iterations_out, void* workspace,
+                      hipStream_t st) {
+    const AlignWs w = align_ws(workspace);
+    unsigned* const tickets = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kTicketOffsetBytes);
+    if (zero_async(tickets, kTicketShards * kTicketStride * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
+    target->note(st);
+    const FusedParams P = make_fused_params(target, source, params, transT_device, 1, nn_idx_out, nn_d2_out);
+    PersistArgs A;
+    A.part[0] = w.part[0]; A.part[1] = w.part[1];
+    A.state = w.state;
+    A.searched_log = w.searched_log;
+    A.tickets = tickets;
+    A.T_init = transT_device;
+    A.lambda = gn->lambda; A.crit_rot = gn->crit_rotation; A.crit_trans = gn->crit_translation;
+    A.lin_out = lin_out;
+    A.T_out = transT_device;
+    A.delta_out8 = delta_out8;
+    A.iterations_out = iterations_out;
+    A.max_iterations = max_iterations;
+    A.k_begin = k_begin;
+    A.cache_valid_later = (source->opt_reuse && P.ccache != nullptr) ? 1 : 0;
+    A.budget = 50ull * 100000ull;  // 50 ms of wall_clock64 (100 MHz)
+    const unsigned grid = align_grid(source->n);
+    const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
+    const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
+#define SP_LAUNCH_PERSIST(L)                                                                              \
+    if (fast && p2d) gicp_align_persistent_kernel<L, true, true><<<grid, kAlignBlock, 0, st>>>(P, A);      \
+    else if (fast) gicp_align_persistent_kernel<L, true, false><<<grid, kAlignBlock, 0, st>>>(P, A);       \
+    else if (p2d) gicp_align_persistent_kernel<L, false, true><<<grid, kAlignBlock, 0, st>>>(P, A);        \
+    else gicp_align_persistent_kernel<L, false, false><<<grid, kAlignBlock, 0, st>>>(P, A)
+#ifdef SP_DEV_MIN
+    if (params->robust_type != SP_LOSS_NONE || !fast || p2d) { sp_set_error("SP_DEV_MIN build"); return SP_ERR_RUNTIME; }
+    gicp_align_persistent_kernel<LOSS_NONE, true, false><<<grid, kAlignBlock, 0, st>>>(P, A);
+#else
+    switch (params->robust_type) {
+        case SP_LOSS_NONE: SP_LAUNCH_PERSIST(LOSS_NONE); break;
+        case SP_LOSS_HUBER: SP_LAUNCH_PERSIST(LOSS_HUBER); break;
+        case SP_LOSS_TUKEY: SP_LAUNCH_PERSIST(LOSS_TUKEY); break;
+        case SP_LOSS_CAUCHY: SP_LAUNCH_PERSIST(LOSS_CAUCHY); break;
+        case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_PERSIST(LOSS_GEMAN_MCCLURE); break;
+        default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
+    }
+#endif
+#undef SP_LAUNCH_PERSIST
+    if (P.ccache != nullptr) source->cache_valid = true;
+    PersistGuard& g = persist_guard();
+    {
+        std::lock_guard<std::mutex> lock(g.m);
+        if (!g.done && hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) g.done = nullptr;
+        if (g.done && hipEventRecord(g.done, st) == hipSuccess) { g.last = st; g.used = true; }
+    }
+    return launch_status();
+}
+}  // namespace
+}  // namespace sp
+
 extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                                   const sp_factor_params* params, const sp_gn_params* gn, int max_iterations,
                                   int32_t* nn_idx_out, float* nn_d2_out, sp_linearized* lin_out, float* delta_out8,
@@ -2160,6 +2428,25 @@ extern "C" int sp_gicp_align_fused(const sp_gicp_target* target, const sp_gicp_s
         if (zero_async(delta_out8, 8 * sizeof(float), st) != SP_OK) return SP_ERR_HIP;
         if (zero_async(iterations_out, sizeof(uint32_t), st) != SP_OK) return SP_ERR_HIP;
         return SP_OK;
+    }
+    // The form. A launch per iteration is the fastest way through an iteration (a grid-wide wait inside one launch costs more
+    // than a kernel boundary on this part: 40 against 33.5 us per iteration, same box, profiles/r04_c_*), but an alignment with
+    // convergence criteria rarely runs all its iterations, and every launch enqueued after the converged one still costs
+    // 2.5 us to find that out (17 of 20 in the benchmark's cloud). So: the first iterations one launch each, the REST as one
+    // launch that loops on the device (gicp_align_persistent_kernel) — it returns at once when the alignment has converged,
+    // and also writes the results, so there is no finish launch. With criteria that cannot be met (<= 0: a fixed number of
+    // iterations) every iteration gets its own launch.
+    const int k_tail = (gn->crit_rotation > 0.0f && gn->crit_translation > 0.0f) ? std::min(max_iterations, source->opt_persistent_from)
+                                                                                : max_iterations;
+    if (k_tail < max_iterations &&
+        persistent_ok(target, source, params, gn, transT_device, workspace, workspace_bytes, st)) {
+        for (int k = 0; k < k_tail; ++k) {
+            const int rc = sp_gicp_align_step(target, source, transT_device, params, gn, k, 0, nn_idx_out, nn_d2_out, lin_out,
+                                              workspace, workspace_bytes, stream);
+            if (rc != SP_OK) return rc;
+        }
+        return launch_persistent(target, source, transT_device, params, gn, k_tail, max_iterations, nn_idx_out, nn_d2_out, lin_out,
+                                 delta_out8, iterations_out, workspace, st);
     }
     for (int k = 0; k < max_iterations; ++k) {
         const int rc = sp_gicp_align_step(target, source, transT_device, params, gn, k, 0, nn_idx_out, nn_d2_out, lin_out,
@@ -2183,6 +2470,8 @@ extern "C" int sp_internal_source_option(sp_gicp_source* s, int option, int valu
         case SP_INTERNAL_FUSED_STAGE_MASK: s->opt_stage_mask = value; return SP_OK;
         case SP_INTERNAL_FUSED_REUSE: s->opt_reuse = value; s->cache_valid = false; return SP_OK;
         case SP_INTERNAL_FUSED_FAST_NN: s->opt_fast_nn = value; return SP_OK;
+        case SP_INTERNAL_FUSED_PERSISTENT: s->opt_persistent = value; return SP_OK;
+        case SP_INTERNAL_FUSED_PERSISTENT_FROM: s->opt_persistent_from = value < 0 ? 0 : value; return SP_OK;
     }
     return SP_ERR_INVALID_ARGUMENT;
 }

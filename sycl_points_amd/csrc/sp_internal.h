@@ -26,7 +26,13 @@ enum {
      * 0 ring walk, 1 fast path. */
     SP_INTERNAL_FUSED_FAST_NN = 2,
     /* sp_grid: self-kNN kernel: 0 (default) chosen by k, 1 LDS-tile kernel (k <= 10), 2 wave-cooperative kernel. */
-    SP_INTERNAL_SELF_KNN_MODE = 3
+    SP_INTERNAL_SELF_KNN_MODE = 3,
+    /* sp_gicp_source: sp_gicp_align_fused, when the convergence criteria can be met, runs the TAIL of the alignment as one
+     * launch that loops on the device (1, default; taken when every workgroup of the grid is resident) or every iteration
+     * as a launch of its own (0). Same bits either way. */
+    SP_INTERNAL_FUSED_PERSISTENT = 4,
+    /* sp_gicp_source: first iteration of that tail (default 4; 0: the whole alignment as one launch). */
+    SP_INTERNAL_FUSED_PERSISTENT_FROM = 5
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);
