@@ -312,10 +312,12 @@ def main():
         launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
         converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE, internal=args.internal)
 
-    stages = reuse0 = None
+    stages = reuse0 = p2d = None
     if world == 1 and shards == 1 and not args.no_stages and not args.timed_only:
         if args.path == "fused":
             reuse0 = reuse_off_comparison(sp, torch, args, S, prep, T_dev, T_ident, delta, SORT_MODE, REG_TYPE, n_local)
+            if args.reg == "gicp":
+                p2d = p2d_block(sp, torch, S, Tg, grid, T_dev, T_ident, delta, n_local, SORT_MODE, T_gt)
         stages = stage_block(sp, _lib, torch)
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
@@ -370,6 +372,7 @@ def main():
             "launch_classes": classes,
             "until_converged": converged,
             "reuse_off_comparison": reuse0,
+            "point_to_distribution": p2d,
             "stages": stages,
             "roofline": roofline_block(dom, kern[dom]),
         }
@@ -559,6 +562,28 @@ def until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, reg
             "iterations_executed": iters, "converged": bool(float(delta[6]) > 0.5), "ms_per_alignment": ms,
             "correspondences_per_s": n * iters / (ms * 1e-3), "alignments_timed": reps,
             "note": "includes the per-alignment source preparation and the launches after convergence (they return at once)"}
+
+
+def p2d_block(sp, torch, S, Tg, grid, T_dev, T_ident, delta, n, sort_mode, T_gt):
+    """BASELINE config 4 read literally ("GICP (point-to-distribution)"): the same clouds with RegType::POINT_TO_DISTRIBUTION
+    (factor.hpp:311-373: M = inverse(Ct), no source covariance) through the same one-call loop. Its Gauss-Newton iteration
+    converges more slowly than GICP's, so more of its 20 launches search. Median of 7 alignments each."""
+    prep = sp.PreparedTarget(grid, Tg.covs, reg_type="POINT_TO_DISTRIBUTION")
+    p = sp.RegistrationParams(reg_type="POINT_TO_DISTRIBUTION", optimization_method="GN", max_iterations=ITERS_PER_ALIGN,
+                              criteria_translation=0.0, criteria_rotation=0.0)
+    reg = sp.Registration(p)
+
+    def one():
+        T_dev.copy_(T_ident)
+        reg.align_fused_loop(S, prep, T_dev=T_dev, delta_dev=delta, prepare=True, sort_by_cell=sort_mode)
+
+    ms, runs = median_ms(torch, one, 7)
+    err = float(np.abs(reg.T_from_device(T_dev) - T_gt).max())
+    conv = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n, sort_mode, "POINT_TO_DISTRIBUTION", reps=7)
+    return {"reg_type": "POINT_TO_DISTRIBUTION", "ms_per_step": ms / ITERS_PER_ALIGN, "ms_per_alignment_20_iterations": ms,
+            "correspondences_per_s": n * ITERS_PER_ALIGN / (ms * 1e-3), "alignments_timed": runs,
+            "pose_max_abs_err_vs_ground_truth": err, "until_converged": conv,
+            "note": "includes the per-alignment source preparation; the target's rows (inverse covariances) are set-up"}
 
 
 def median_ms(torch, fn, runs=11):
