@@ -197,6 +197,16 @@ public:
     }
     /// MI355X extension: answer knn_search from the reference-topology tree (first-visited tie order, host build) always.
     void set_reference_tie_order(bool v) { reference_order_ = v; }
+    /// MI355X extension: which structure knn_search_async(queries, k, ..., transT) answers from — the decision itself, without
+    /// searching (the Python mirror sycl_points_amd.api.KDTree takes the same one; tests hold the two to each other).
+    enum class Backend { HostTree, Hierarchy, Grid };
+    Backend backend_for(const PointCloudShared& queries, size_t k, const TransformMatrix& transT = TransformMatrix::Identity()) const {
+        if (!(bvh_ != nullptr && pristine_ && !reference_order_ && k <= 32)) return Backend::HostTree;
+        const bool own_cloud = built_on_ != nullptr && queries.points == built_on_ && queries.points->generation() == built_generation_ &&
+                               queries.size() == size_ && transT == TransformMatrix::Identity();
+        if (own_cloud && k >= 8 && k <= 20 && uniform_grid() != nullptr) return Backend::Grid;
+        return Backend::Hierarchy;
+    }
 
     sycl_utils::events knn_search_async(const PointCloudShared& queries, const size_t k, KNNResult& result,
                                         const std::vector<sycl_utils::event>& = {},

@@ -686,16 +686,25 @@ public:
         const bool fixed = options.robust_scale > 0.0f || options.rotation_robust_scale > 0.0f;
         bool autos = !fixed && params_.robust.type != robust::RobustLossType::NONE && sched_.auto_scale;
         if (autos && (sched_.min_scale <= 0.0f || sched_.min_scale >= sched_.init_scale)) autos = false;
+        if (autos && (sched_.rotation_min_scale <= 0.0f || sched_.rotation_min_scale >= sched_.rotation_init_scale)) autos = false;
         if (autos && sched_.auto_scaling_iter == 0) autos = false;
         const size_t levels = autos ? std::max<size_t>(1, sched_.auto_scaling_iter) : 1;
+        // pipeline/robust.hpp:83-98: both scales shrink geometrically from init to min over the levels
         float scale = options.robust_scale > 0.0f ? options.robust_scale
                                                   : (autos ? sched_.init_scale : params_.robust.default_scale);
         const float factor = levels > 1 ? std::pow(sched_.min_scale / sched_.init_scale, 1.0f / static_cast<float>(levels - 1)) : 1.0f;
+        float rot_scale = options.rotation_robust_scale > 0.0f
+                              ? options.rotation_robust_scale
+                              : (autos ? sched_.rotation_init_scale : params_.rotation_constraint.robust.default_scale);
+        const float rot_factor =
+            levels > 1 ? std::pow(sched_.rotation_min_scale / sched_.rotation_init_scale, 1.0f / static_cast<float>(levels - 1)) : 1.0f;
         for (size_t level = 0; level < levels; ++level) {
             auto o = options;
             o.robust_scale = scale;
+            o.rotation_robust_scale = rot_scale;
             result = aligner_(source, target, knn, result.T.matrix(), o);
             scale *= factor;
+            rot_scale *= rot_factor;
         }
         return result;
     }

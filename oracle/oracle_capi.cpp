@@ -92,6 +92,14 @@ void orc_matmul4(const float* A, const float* B, float* out) {
     Mat4 a, b; std::memcpy(a.d, A, 64); std::memcpy(b.d, B, 64);
     const Mat4 r = matmul<4, 4, 4>(a, b); std::memcpy(out, r.d, 64);
 }
+// the annealing wrapper's schedule (oracle_registration.hpp: robust_annealing_scales); returns the number of levels written
+int orc_robust_annealing_scales(int loss_is_none, int auto_scale, float default_scale, float init_scale, float min_scale,
+                                int auto_scaling_iter, float* scales_out, int capacity) {
+    const std::vector<float> s = robust_annealing_scales(loss_is_none != 0, auto_scale != 0, default_scale, init_scale, min_scale,
+                                                         (size_t)std::max(0, auto_scaling_iter));
+    for (int i = 0; i < (int)s.size() && i < capacity; ++i) scales_out[i] = s[i];
+    return (int)s.size();
+}
 void orc_se3_exp(const float* twist6, float* T16) { Vec6 a; std::memcpy(a.d, twist6, 24); const Mat4 T = se3_exp(a); std::memcpy(T16, T.d, 64); }
 void orc_se3_log(const float* T16, float* twist6) { Mat4 T; std::memcpy(T.d, T16, 64); const Vec6 a = se3_log(T); std::memcpy(twist6, a.d, 24); }
 void orc_so3_exp(const float* w3, float* q4) { Vec3 w; std::memcpy(w.d, w3, 12); const Vec4 q = so3_exp(w); std::memcpy(q4, q.d, 16); }

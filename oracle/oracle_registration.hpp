@@ -698,6 +698,23 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
     return result;
 }
 
+// pipeline/robust.hpp:52-98 — the scales the annealing wrapper hands to the aligner, level by level: geometric from init_scale
+// to min_scale over auto_scaling_iter levels; one level at default_scale when the schedule is off or its bounds are invalid.
+inline std::vector<float> robust_annealing_scales(bool loss_is_none, bool auto_scale, float default_scale, float init_scale,
+                                                  float min_scale, size_t auto_scaling_iter) {
+    bool enable = !loss_is_none && auto_scale;
+    if (enable && (min_scale <= 0.0f || min_scale >= init_scale)) enable = false;
+    if (enable && auto_scaling_iter == 0) enable = false;
+    const size_t levels = enable ? std::max<size_t>(1, auto_scaling_iter) : 1;
+    float robust_scale = enable ? init_scale : default_scale;
+    const float factor = levels > 1 ? std::pow(min_scale / init_scale, 1.0f / (float)(levels - 1)) : 1.0f;
+    std::vector<float> scales;
+    for (size_t level = 0; level < levels; ++level) {
+        scales.push_back(robust_scale);
+        robust_scale *= factor;
+    }
+    return scales;
+}
 // pipeline/robust.hpp:42-114 — geometric robust-scale annealing around align().
 inline RegResult align_robust_annealing(const RegParams& params, const Cloud& source, const Cloud& target,
                                         const NearestFn& nearest, const float* init_T_colmajor, bool auto_scale,
@@ -705,16 +722,9 @@ inline RegResult align_robust_annealing(const RegParams& params, const Cloud& so
     RegResult result;
     result.T = to_mat4(init_T_colmajor);
     if (source.n == 0) return result;
-    bool enable = params.robust_type != LOSS_NONE && auto_scale;
-    if (enable && (min_scale <= 0.0f || min_scale >= init_scale)) enable = false;
-    if (enable && auto_scaling_iter == 0) enable = false;
-    const size_t levels = enable ? std::max<size_t>(1, auto_scaling_iter) : 1;
-    float robust_scale = enable ? init_scale : params.robust_default_scale;
-    const float factor = levels > 1 ? std::pow(min_scale / init_scale, 1.0f / (float)(levels - 1)) : 1.0f;
-    for (size_t level = 0; level < levels; ++level) {
+    for (const float robust_scale : robust_annealing_scales(params.robust_type == LOSS_NONE, auto_scale, params.robust_default_scale,
+                                                            init_scale, min_scale, auto_scaling_iter))
         result = align(params, source, target, nearest, result.T.d, robust_scale);
-        robust_scale *= factor;
-    }
     return result;
 }
 

@@ -155,6 +155,16 @@ class Oracle:
         self.lib.orc_matmul4(_p(A), _p(B), _p(out))
         return out.T.copy()
 
+    def robust_annealing_scales(self, loss, auto_scale, default_scale, init_scale, min_scale, auto_scaling_iter):
+        """Scales the annealing wrapper (pipeline/robust.hpp:42-114) hands to the aligner, level by level."""
+        out = np.zeros(64, np.float32)
+        f = self.lib.orc_robust_annealing_scales
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int]
+        n = f(1 if loss == "NONE" else 0, 1 if auto_scale else 0, default_scale, init_scale, min_scale, int(auto_scaling_iter),
+              _p(out), 64)
+        return out[:n].copy()
+
     def se3_exp(self, twist):
         t = _f(twist)
         out = np.zeros((4, 4), np.float32)

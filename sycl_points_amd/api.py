@@ -173,22 +173,76 @@ def _trans_arg(transT):
 
 
 class KDTree(KNNBase):
-    """algorithms/knn/kdtree.hpp:142-766."""
+    """algorithms/knn/kdtree.hpp:142-766.
+
+    build(points) is the reference's tree (host build with its rule, device search). build(points, accelerate=True) mirrors the
+    C++ facade's KDTree (include/sycl_points/amd/knn.hpp): from 1024 points on the hierarchy is built on the device (BVH) and
+    knn_search answers from it for k <= 32; a search of the tree's OWN cloud with 8 <= k <= 20 on at least 32768 points of
+    near-uniform density (fullest cell of a 6-points-per-cell grid <= 48 points) is answered by that grid; radius search, lazy
+    delete, k > 32 use the reference's tree, built the first time it is needed. `backend_for` is the decision itself
+    (tests/test_gpu_facade.py holds it to the facade's on the same clouds)."""
+
+    DEVICE_BUILD_MIN_POINTS = 1024   # knn.hpp: KDTree::kDeviceBuildMinPoints
+    GRID_SELF_MIN_POINTS = 32768     # knn.hpp: KDTree::kGridSelfMinPoints
+    GRID_SELF_MAX_CELL = 48          # knn.hpp: KDTree::kGridSelfMaxCell
+    GRID_SELF_POINTS_PER_CELL = 6.0
 
     def __init__(self, handle, n, device):
         self._h = handle
         self.n = n
         self.device = device
+        self._bvh = None          # accelerate=True: the device-built hierarchy
+        self._points = None       # ... the points it was built on (device tensor), for the lazily built reference tree / the grid
+        self._self_grid = None
+        self._self_grid_tried = False
+        self._pristine = True
+        self._leaf_threshold = 16
 
     @staticmethod
-    def build(points, leaf_threshold=16):
+    def build(points, leaf_threshold=16, accelerate=False):
         p = _points_of(points)
+        if accelerate and p.shape[0] >= KDTree.DEVICE_BUILD_MIN_POINTS:
+            pd = _dev_f32(p, 4)
+            t = KDTree(None, pd.shape[0], pd.device)
+            t._bvh = BVH.build(pd)
+            t._points = pd
+            t._leaf_threshold = leaf_threshold
+            return t
         host = np.ascontiguousarray(p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else p, np.float32)
         dev = p.device if isinstance(p, torch.Tensor) and p.is_cuda else torch.device("cuda")
         h = C.c_void_p()
         check(_lib.lib().sp_kdtree_create(host.ctypes.data_as(C.c_void_p), host.shape[0], leaf_threshold, _stream(),
                                           C.byref(h)))
         return KDTree(h, host.shape[0], dev)
+
+    def _host_tree(self):
+        if not self._h:
+            host = np.ascontiguousarray(self._points.detach().cpu().numpy(), np.float32)
+            h = C.c_void_p()
+            check(_lib.lib().sp_kdtree_create(host.ctypes.data_as(C.c_void_p), host.shape[0], self._leaf_threshold, _stream(),
+                                              C.byref(h)))
+            self._h = h
+        return self._h
+
+    def _uniform_grid(self):
+        if not self._self_grid_tried:
+            self._self_grid_tried = True
+            if self.n >= KDTree.GRID_SELF_MIN_POINTS:
+                g = GridKNN.build(self._points, points_per_cell=KDTree.GRID_SELF_POINTS_PER_CELL)
+                if g.max_cell_points() <= KDTree.GRID_SELF_MAX_CELL:
+                    self._self_grid = g
+        return self._self_grid
+
+    def backend_for(self, queries, k, transT=None):
+        """'kdtree' | 'bvh' | 'grid': what knn_search_async(queries, k, ..., transT) answers from (KDTree::backend_for)."""
+        if self._bvh is None or not self._pristine or k > 32:
+            return "kdtree"
+        q = _points_of(queries)
+        own = (transT is None and isinstance(q, torch.Tensor) and q.is_cuda and q.shape[0] == self.n and
+               q.data_ptr() == self._points.data_ptr())
+        if own and 8 <= k <= 20 and self._uniform_grid() is not None:
+            return "grid"
+        return "bvh"
 
     def __del__(self):
         try:
@@ -202,11 +256,24 @@ class KDTree(KNNBase):
         q = _dev_f32(_points_of(queries), 4)
         if k > 100:
             raise SpError(2, "[KDTree::knn_search_async] `k` is too large. not support.")
+        backend = self.backend_for(queries, k, transT) if self._bvh is not None else "kdtree"
+        if backend == "grid":
+            res = self._uniform_grid().self_knn(k)[0]
+            result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k
+            return
+        if backend == "bvh":
+            own = transT is None and q.shape[0] == self.n and q.data_ptr() == self._points.data_ptr()
+            if own:
+                res = self._bvh.self_knn(k)
+                result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k
+            else:
+                self._bvh.knn_search_async(queries, k, result, transT)
+            return
         result.resize(q.shape[0], k, q.device)
         if q.shape[0] == 0:
             return
         tp, on_dev, keep = _trans_arg(transT)
-        check(_lib.lib().sp_kdtree_search(self._h, _ptr(q), q.shape[0], k, tp, on_dev, _ptr(result.indices),
+        check(_lib.lib().sp_kdtree_search(self._host_tree(), _ptr(q), q.shape[0], k, tp, on_dev, _ptr(result.indices),
                                           _ptr(result.distances), _stream()))
 
     def radius_search_async(self, queries, max_k, radius, result, transT=None):
@@ -218,14 +285,15 @@ class KDTree(KNNBase):
             return
         result.resize(q.shape[0], max_k, q.device)
         tp, on_dev, keep = _trans_arg(transT)
-        check(_lib.lib().sp_kdtree_radius_search(self._h, _ptr(q), q.shape[0], max_k, radius, tp, on_dev,
+        check(_lib.lib().sp_kdtree_radius_search(self._host_tree(), _ptr(q), q.shape[0], max_k, radius, tp, on_dev,
                                                  _ptr(result.indices), _ptr(result.distances), _stream()))
 
     def remove_nodes_by_flags(self, flags, indices):
         if flags.shape[0] != indices.shape[0]:
             raise SpError(2, "[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.")
-        check(_lib.lib().sp_kdtree_remove_by_flags(self._h, _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
+        check(_lib.lib().sp_kdtree_remove_by_flags(self._host_tree(), _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
         torch.cuda.current_stream().synchronize()
+        self._pristine = False  # the device hierarchy still holds the removed points: the tree answers from here on
 
 
 class BVH(KNNBase):

@@ -675,6 +675,138 @@ static void sharded_align_one_rank() {
     CHECK(threw);
 }
 
+// ---- the reference's pipeline seam tests, restated on the facade (cpp/tests/test_registration_pipeline.cpp): an injected
+// RegistrationAligner lambda records what RegistrationPipeline / RobustAligner hand it.
+namespace {
+class DummyKNN : public alg::knn::KNNBase {  // test_registration_pipeline.cpp:16-23
+public:
+    sycl_utils::events knn_search_async(const PointCloudShared&, const size_t, alg::knn::KNNResult&,
+                                        const std::vector<sycl_utils::event>& = std::vector<sycl_utils::event>(),
+                                        const TransformMatrix& = TransformMatrix::Identity()) const override {
+        return sycl_utils::events();
+    }
+};
+PointCloudShared make_cloud(size_t size) {  // test_registration_pipeline.cpp:63-78
+    PointCloudShared cloud(*Q);
+    cloud.points->resize(size);
+    cloud.intensities->resize(size);
+    cloud.timestamp_offsets->resize(size);
+    for (size_t i = 0; i < size; ++i) {
+        cloud.points->data()[i] = PointType(static_cast<float>(i), static_cast<float>(i + 1), static_cast<float>(i + 2), 1.0f);
+        cloud.intensities->data()[i] = static_cast<float>(i);
+        cloud.timestamp_offsets->data()[i] = static_cast<float>(i) * 0.1f;
+    }
+    cloud.start_time_ms = 1.0;
+    cloud.end_time_ms = 2.0;
+    return cloud;
+}
+}  // namespace
+
+static void pipeline_random_sampling_seam() {  // test_registration_pipeline.cpp:106-193, 195-...
+    namespace reg = alg::registration;
+    for (const auto& c : {std::array<size_t, 4>{1, 3, 6, 3}, std::array<size_t, 4>{0, 2, 5, 5}, std::array<size_t, 4>{1, 8, 5, 5}}) {
+        // {enable, num, source size, expected registration input size}: limits / can be disabled / does not shrink a small cloud
+        reg::RegistrationPipelineParams params;
+        params.random_sampling.enable = c[0] != 0;
+        params.random_sampling.num = c[1];
+        size_t aligned = 0;
+        bool has_i = false, has_t = false;
+        auto aligner = [&](const PointCloudShared& source, const PointCloudShared&, const alg::knn::KNNBase&, const TransformMatrix&,
+                           const reg::Registration::ExecutionOptions&) {
+            aligned = source.size();
+            has_i = source.has_intensity();
+            has_t = source.has_timestamps();
+            reg::RegistrationResult result;
+            result.inlier = static_cast<uint32_t>(source.size());
+            return result;
+        };
+        reg::RegistrationPipeline pipeline(aligner, params);
+        const auto source = make_cloud(c[2]);
+        const auto target = make_cloud(4);
+        DummyKNN knn;
+        const auto result = pipeline.align(source, target, knn);
+        CHECK(result.inlier == c[3]);
+        CHECK(aligned == c[3]);
+        CHECK(pipeline.get_registration_input_point_cloud() != nullptr);
+        CHECK(pipeline.get_registration_input_point_cloud()->size() == c[3]);
+        CHECK(has_i && has_t);  // the sampled cloud keeps its attributes (:131-137)
+        CHECK(pipeline.get_registration_input_point_cloud()->has_intensity());
+        CHECK(pipeline.get_registration_input_point_cloud()->has_timestamps());
+        CHECK(pipeline.get_deskewed_point_cloud().get() == pipeline.get_registration_input_point_cloud());  // :195-210
+        CHECK(std::fabs(pipeline.get_inlier_ratio(result) - 1.0f) < 1e-6f);
+    }
+}
+
+static void pipeline_robust_annealing_seam() {  // test_registration_pipeline.cpp:360-409
+    namespace reg = alg::registration;
+    reg::RegistrationPipelineParams params;
+    params.registration.robust.type = alg::robust::RobustLossType::HUBER;
+    params.registration.robust.default_scale = 8.0f;
+    std::vector<float> fixed_scales;
+    auto fixed_aligner = [&](const PointCloudShared&, const PointCloudShared&, const alg::knn::KNNBase&, const TransformMatrix&,
+                             const reg::Registration::ExecutionOptions& options) {
+        fixed_scales.push_back(options.robust_scale);
+        return reg::RegistrationResult{};
+    };
+    reg::RegistrationPipeline fixed_pipeline(fixed_aligner, params);
+    DummyKNN knn;
+    fixed_pipeline.align(make_cloud(3), make_cloud(3), knn);
+    CHECK(fixed_scales.size() == 1);
+    CHECK(fixed_scales.size() == 1 && fixed_scales.front() == -1.0f);  // auto scaling off: the scale stays unset
+
+    params.robust.auto_scale = true;
+    params.robust.init_scale = 6.0f;
+    params.robust.min_scale = 2.0f;
+    params.robust.rotation_init_scale = 9.0f;
+    params.robust.rotation_min_scale = 3.0f;
+    params.robust.auto_scaling_iter = 3;
+    std::vector<float> scales, rot_scales;
+    auto annealed_aligner = [&](const PointCloudShared&, const PointCloudShared&, const alg::knn::KNNBase&, const TransformMatrix&,
+                                const reg::Registration::ExecutionOptions& options) {
+        scales.push_back(options.robust_scale);
+        rot_scales.push_back(options.rotation_robust_scale);
+        return reg::RegistrationResult{};
+    };
+    reg::RegistrationPipeline annealed_pipeline(annealed_aligner, params);
+    annealed_pipeline.align(make_cloud(3), make_cloud(3), knn);
+    CHECK(scales.size() == 3 && rot_scales.size() == 3);
+    if (scales.size() == 3 && rot_scales.size() == 3) {
+        CHECK(scales[0] == 6.0f);
+        CHECK(std::fabs(scales[1] - std::sqrt(12.0f)) < 1e-5f);
+        CHECK(std::fabs(scales[2] - 2.0f) < 1e-5f);
+        CHECK(rot_scales[0] == 9.0f);
+        CHECK(std::fabs(rot_scales[1] - std::sqrt(27.0f)) < 1e-5f);
+        CHECK(std::fabs(rot_scales[2] - 3.0f) < 1e-5f);
+    }
+    // the same schedule through RobustAligner directly, and a fixed scale from the caller switches the annealing off (:52-55)
+    reg::pipeline::RobustAligner ra(annealed_aligner, params);
+    scales.clear();
+    rot_scales.clear();
+    reg::Registration::ExecutionOptions fixed;
+    fixed.robust_scale = 4.0f;
+    ra.align(make_cloud(3), make_cloud(3), knn, TransformMatrix::Identity(), fixed);
+    CHECK(scales.size() == 1 && scales[0] == 4.0f);
+}
+
+static void kdtree_backend_on_the_bundled_scan() {
+    // The reference's raw LiDAR scan (cpp/data/target.ply, 69 088 points on surfaces): its density varies by orders of magnitude,
+    // the fullest cell of a 6-points-per-cell grid holds far more than 48 points, so KDTree answers from the device-built hierarchy
+    // for every k <= 32 — the decision tests/test_gpu_facade.py holds the Python mirror to. A few hundred points: the host tree.
+    const char* dir = std::getenv("SP_GOLDEN_DIR");
+    if (!dir) { std::printf("  (SP_GOLDEN_DIR not set: skipped)\n"); return; }
+    const auto scan = PointCloudReader::readFile(std::string(dir) + "/target.ply", *Q);
+    CHECK(scan.size() == 69088);
+    auto tree = alg::knn::KDTree::build(*Q, scan);
+    using Backend = alg::knn::KDTree::Backend;
+    for (size_t k : {1, 10, 20, 32}) CHECK(tree->backend_for(scan, k) == Backend::Hierarchy);
+    CHECK(tree->backend_for(scan, 33) == Backend::HostTree);
+    std::mt19937 gen(5);
+    PointCloudCPU c;
+    random_points(gen, c, 800, 10.0f);
+    PointCloudShared small(*Q, c);
+    CHECK(alg::knn::KDTree::build(*Q, small)->backend_for(small, 10) == Backend::HostTree);
+}
+
 static void kdtree_self_knn_large_clouds() {
     // KDTree::knn_search on the tree's own cloud: from 32 k points on, a cloud of near-uniform density is answered by the grid's
     // lane-per-query selection, a clustered one (fullest cell over the limit) by the device-built hierarchy; both must give
@@ -689,6 +821,11 @@ static void kdtree_self_knn_large_clouds() {
         }
         PointCloudShared cloud(*Q, c);
         auto tree = alg::knn::KDTree::build(*Q, cloud);
+        using Backend = alg::knn::KDTree::Backend;
+        CHECK(tree->backend_for(cloud, 20) == (clustered ? Backend::Hierarchy : Backend::Grid));
+        CHECK(tree->backend_for(cloud, 8) == (clustered ? Backend::Hierarchy : Backend::Grid));
+        CHECK(tree->backend_for(cloud, 5) == Backend::Hierarchy);   // below the selection kernel's range
+        CHECK(tree->backend_for(cloud, 40) == Backend::HostTree);   // beyond the hierarchy's k
         for (size_t k : {10, 20}) {
             auto kd = tree->knn_search(cloud, k);
             auto bf = alg::knn::knn_search_bruteforce(*Q, cloud, cloud, k);
@@ -706,9 +843,12 @@ int main() {
     queue.print_device_info();
     RUN(kdtree_grid_vs_bruteforce);
     RUN(kdtree_self_knn_large_clouds);
+    RUN(kdtree_backend_on_the_bundled_scan);
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
     RUN(point_cloud_extend_erase);
+    RUN(pipeline_random_sampling_seam);
+    RUN(pipeline_robust_annealing_seam);
     RUN(point_cloud_files);
     RUN(voxel_hash_map_known_answers);
     RUN(sharded_align_one_rank);

@@ -76,3 +76,42 @@ def test_example_registration_config1(orc, knn):
     # sanity against the bundled ground truth (cpp/data/T_target_source.txt; not a 1e-5 pin)
     T_gt = np.loadtxt(os.path.join(GOLD, "T_target_source.txt")).astype(np.float32)
     assert np.abs(T[:3, 3] - T_gt[:3, 3]).max() < 0.05 and np.abs(T[:3, :3] - T_gt[:3, :3]).max() < 0.01
+
+
+def test_python_kdtree_takes_the_facades_decisions(orc):
+    """sycl_points_amd.api.KDTree.build(points, accelerate=True) mirrors the facade's KDTree (knn.hpp): the same structure
+    answers the same query on the same cloud as in tests/cpp/test_facade.cpp (kdtree_backend_on_the_bundled_scan,
+    kdtree_self_knn_large_clouds) — the raw scan of surfaces goes to the device-built hierarchy, a large cloud of uniform
+    density to the grid for 8 <= k <= 20, small clouds / k > 32 / a tree with removed nodes to the reference's tree — and the
+    lists are the exact ones (oracle brute force) whichever structure answers."""
+    import torch
+
+    import sycl_points_amd.api as sp
+
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    scan = dev(read_ply_xyz(os.path.join(GOLD, "target.ply")))
+    tree = sp.KDTree.build(scan, accelerate=True)
+    for k in (1, 10, 20, 32):
+        assert tree.backend_for(scan, k) == "bvh"
+    assert tree.backend_for(scan, 33) == "kdtree"
+    sub = scan[:3000].contiguous()
+    oi, od = orc.knn_bruteforce(sub.cpu().numpy(), scan.cpu().numpy(), 10)
+    r = tree.knn_search(sub, 10)
+    assert np.array_equal(r.distances.cpu().numpy(), od)  # (indices may differ inside groups of exactly equal distances)
+    uni = dev(orc.rng(99).uniform_points(40000, 10.0))
+    t2 = sp.KDTree.build(uni, accelerate=True)
+    assert t2.backend_for(uni, 20) == "grid" and t2.backend_for(uni, 8) == "grid"
+    assert t2.backend_for(uni, 5) == "bvh" and t2.backend_for(uni, 40) == "kdtree"
+    assert t2.backend_for(uni[:100].contiguous(), 20) == "bvh"  # other queries than the tree's own cloud
+    oi, od = orc.knn_bruteforce(uni.cpu().numpy()[:2000], uni.cpu().numpy(), 20)
+    for k, q in ((20, uni), (5, uni)):
+        r = t2.knn_search(q, k)
+        assert np.array_equal(r.indices.cpu().numpy()[:2000], oi[:, :k]) and np.array_equal(r.distances.cpu().numpy()[:2000], od[:, :k])
+    small = dev(orc.rng(5).uniform_points(800, 10.0))
+    assert sp.KDTree.build(small, accelerate=True).backend_for(small, 10) == "kdtree"
+    # a removal hands the tree to the reference's structure (the hierarchy would still hold the removed points)
+    flags = np.ones(40000, np.uint8)
+    flags[::10] = 0  # (1 = keep, with the kept points' new indices: test_kdtree.cpp:459-512)
+    new_idx = np.where(flags == 1, np.cumsum(flags) - 1, -1).astype(np.int32)
+    t2.remove_nodes_by_flags(dev(flags), dev(new_idx))
+    assert t2.backend_for(uni, 20) == "kdtree"

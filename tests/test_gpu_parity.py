@@ -551,6 +551,33 @@ def test_voxel_config3_1m(sp, orc):
     assert np.mean(k2 == k) > 0.999  # means of one-point voxels are the points themselves
 
 
+def test_voxel_config3_dense_1m_boxed(sp, orc):
+    """BASELINE config 3's dense variant at full size (R = 2.5, voxel 0.1, 1 M points, about 8 points per voxel)
+    through the path bench.py times for it: keys compressed to the cloud's key box (18 key bits: the sort takes two passes of
+    9-bit digits, radix_sort.hip) — keys, means and counts against the oracle, and against the 64-bit path."""
+    pts = cloud(orc, 1234, 1000000, 2.5)
+    rs = np.random.RandomState(11)
+    inten = rs.uniform(0, 255, len(pts)).astype(np.float32)
+    pc = sp.PointCloudShared(dev(pts), intensities=dev(inten))
+    vg = sp.VoxelGrid(0.1)
+    o = orc.voxel_downsample(pts, 0.1, 1, intensity=inten, stable=True)
+    assert 100_000 < len(o["keys"]) < 160_000  # ~8 points per voxel: the segmented reduce does real work
+    for _ in range(2):  # the box is computed by the first call and remembered (widened) for the second
+        out, keys = vg.downsampling(pc, return_keys=True, boxed=True)
+        k = keys.cpu().numpy().view(np.uint64)
+        assert np.array_equal(k, o["keys"])
+        assert np.array_equal(out.points.cpu().numpy(), o["points"])
+        assert np.array_equal(out.intensities.cpu().numpy(), o["intensities"])  # medians
+    b, kb = sp.VoxelGrid(0.1).downsampling(pc, return_keys=True, boxed=False)
+    assert torch.equal(kb, keys) and torch.equal(b.points, out.points)
+    # min_voxel_count drops sparse voxels identically
+    vg6 = sp.VoxelGrid(0.1)
+    vg6.set_min_voxel_count(6)
+    out3, k3 = vg6.downsampling(pc, return_keys=True, boxed=True)
+    o3 = orc.voxel_downsample(pts, 0.1, 6, intensity=inten, stable=True)
+    assert np.array_equal(k3.cpu().numpy().view(np.uint64), o3["keys"]) and np.array_equal(out3.points.cpu().numpy(), o3["points"])
+
+
 # ------------------------------------------------------------------ K10 / K14
 def test_box_filter_transform_compaction(sp, orc):
     pts = cloud(orc, 8, 50000, 60.0)

@@ -297,16 +297,18 @@ def test_p2p_weights_max_corr(orc):
     assert w.tolist() == [1.0, 1.0, 0.0]
 
 
-def test_annealing_schedule():
-    # test_registration_pipeline.cpp:360-409: 3 levels from 6 -> 2 gives 6, sqrt(12), 2; 9 -> 3 gives 9, sqrt(27), 3
+def test_annealing_schedule(orc):
+    # test_registration_pipeline.cpp:360-409, on the oracle's restatement of pipeline/robust.hpp:52-98 (the facade's RobustAligner
+    # is held to the same answers with the reference's injected-lambda test in tests/cpp/test_facade.cpp): HUBER, 3 levels from
+    # 6 -> 2 gives 6, sqrt(12), 2; 9 -> 3 gives 9, sqrt(27), 3; auto scaling off or NONE: one level at the default scale
     for init, mn in ((6.0, 2.0), (9.0, 3.0)):
-        f = np.float32(np.power(np.float32(mn / init), np.float32(1.0 / 2.0)))
-        s = np.float32(init)
-        seq = []
-        for _ in range(3):
-            seq.append(float(s))
-            s = np.float32(s * f)
-        assert np.allclose(seq, [init, np.sqrt(init * mn), mn], rtol=1e-5)
+        seq = orc.robust_annealing_scales("HUBER", True, 8.0, init, mn, 3)
+        assert len(seq) == 3 and seq[0] == np.float32(init)
+        assert abs(seq[1] - np.sqrt(init * mn)) < 1e-5 and abs(seq[2] - mn) < 1e-5
+    assert orc.robust_annealing_scales("HUBER", False, 8.0, 6.0, 2.0, 3).tolist() == [8.0]
+    assert orc.robust_annealing_scales("NONE", True, 8.0, 6.0, 2.0, 3).tolist() == [8.0]
+    assert orc.robust_annealing_scales("HUBER", True, 8.0, 6.0, 7.0, 3).tolist() == [8.0]  # min >= init: schedule refused
+    assert orc.robust_annealing_scales("HUBER", True, 8.0, 6.0, 2.0, 0).tolist() == [8.0]  # zero levels: refused
 
 
 # ---------------------------------------------------------------- test_preprocess_filter.cpp
