@@ -410,6 +410,18 @@ public:
         ++generation_;
         return dev_;
     }
+    /// `n` elements that live on the device only for now — a kernel is about to write all of them (device_data_for_write(n)),
+    /// or `fill_bits` (a 32-bit pattern, for 4-byte T) is put there by a device fill. No host storage is touched until the host
+    /// reads the vector: a 20 M-entry neighbour list is 80 MB that std::vector would allocate and initialise for nothing
+    /// (25 ms per list on the host clock of the config-4 harness, examples/bench_registration.cpp).
+    void resize_on_device(size_t n, const uint32_t* fill_bits = nullptr) {
+        static_assert(sizeof(T) % 4 == 0, "device fill works on 32-bit words");
+        std::vector<T>().swap(host_);
+        ensure_capacity(n);
+        if (fill_bits && n) hip_check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dev_), (int)*fill_bits, n * (sizeof(T) / 4), stream()), "fill");
+        dev_size_ = n; size_override_ = true; dev_dirty_ = true; host_dirty_ = false;
+        ++generation_;
+    }
     /// Read-write device pointer (in-place kernels).
     T* device_data_rw() { sync_device(); dev_dirty_ = true; dev_size_ = host_.size(); size_override_ = true; ++generation_; return dev_; }
     /// After a kernel produced fewer rows than reserved (compaction, downsampling).

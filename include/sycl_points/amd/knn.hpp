@@ -26,11 +26,16 @@ struct KNNResult {
     size_t query_size = 0;
     size_t k = 0;
 
-    void allocate(const sycl_utils::DeviceQueue& queue, size_t query_size_ = 0, size_t k_ = 0) {
+    /// result.hpp:20-27: query_size x k entries of -1 / FLT_MAX. They are put there by a device fill, not by a host vector
+    /// (shared_vector::resize_on_device); `fill = false` when a search that writes every entry follows at once.
+    void allocate(const sycl_utils::DeviceQueue& queue, size_t query_size_ = 0, size_t k_ = 0, bool fill = true) {
         query_size = query_size_;
         k = k_;
-        indices = std::make_shared<shared_vector<int32_t>>(query_size * k, -1, queue);
-        distances = std::make_shared<shared_vector<float>>(query_size * k, std::numeric_limits<float>::max(), queue);
+        indices = std::make_shared<shared_vector<int32_t>>(queue);
+        distances = std::make_shared<shared_vector<float>>(queue);
+        const uint32_t minus_one = 0xffffffffu, flt_max = 0x7f7fffffu;
+        indices->resize_on_device(query_size * k, fill ? &minus_one : nullptr);
+        distances->resize_on_device(query_size * k, fill ? &flt_max : nullptr);
     }
     void resize(size_t query_size_ = 0, size_t k_ = 0) {
         query_size = query_size_;
@@ -69,8 +74,15 @@ public:
 
 namespace detail {
 inline void prepare_result(const sycl_utils::DeviceQueue& q, KNNResult& r, size_t nq, size_t k) {
-    if (r.indices == nullptr || r.distances == nullptr) r.allocate(q, nq, k);  // kdtree.hpp:446-450
-    else r.resize(nq, k);
+    // kdtree.hpp:446-450; every search kernel writes all nq x k entries (padding included): no fill, no host storage
+    if (r.indices == nullptr || r.distances == nullptr) {
+        r.allocate(q, nq, k, false);
+    } else {
+        r.query_size = nq;
+        r.k = k;
+        r.indices->resize_on_device(nq * k);
+        r.distances->resize_on_device(nq * k);
+    }
 }
 }  // namespace detail
 

@@ -432,9 +432,20 @@ private:
             ptgt_ = nullptr;
             throw_on_error(sp_gicp_target_create(grid.handle(), target.covs_device(), target.size(), queue_.stream(), &ptgt_));
             ptgt_grid_id_ = grid.id();
+            ptgt_covs_ = target.covs.get();  // (created with the GICP rows of these covariances)
+            ptgt_covs_gen_ = target.covs->generation();
+            ptgt_reg_ = int(RegType::GICP);
         }
-        // rows of the factor asked for: plane(Ct) for GICP, inverse(Ct) for point-to-distribution (factor.hpp:311-317)
-        throw_on_error(sp_gicp_target_prepare(ptgt_, target.covs_device(), int(params_.reg_type), queue_.stream()));
+        // rows of the factor asked for: plane(Ct) for GICP, inverse(Ct) for point-to-distribution (factor.hpp:311-317) —
+        // once per (target covariances, factor): a caller that aligns frame after frame against the same target does not pay
+        // the 30 us per million points again (the container's generation moves whenever somebody may have written to it)
+        if (ptgt_covs_ != target.covs.get() || ptgt_covs_gen_ != target.covs->generation() ||
+            ptgt_reg_ != int(params_.reg_type)) {
+            throw_on_error(sp_gicp_target_prepare(ptgt_, target.covs_device(), int(params_.reg_type), queue_.stream()));
+            ptgt_covs_ = target.covs.get();
+            ptgt_covs_gen_ = target.covs->generation();
+            ptgt_reg_ = int(params_.reg_type);
+        }
         if (psrc_ == nullptr || psrc_cap_ < source.size()) {
             if (psrc_) sp_gicp_source_destroy(psrc_);
             psrc_ = nullptr;
@@ -630,6 +641,9 @@ private:
     size_t psrc_cap_ = 0;
     sp_gicp_target* ptgt_ = nullptr;
     uint64_t ptgt_grid_id_ = 0;  // GridKNN::id() the prepared target was built on
+    const void* ptgt_covs_ = nullptr;  // the covariance container the prepared rows were computed from, ...
+    uint64_t ptgt_covs_gen_ = 0;       // ... its generation then, ...
+    int ptgt_reg_ = -1;                // ... and the factor they are the rows of
     bool source_presorted_ = false;
     sp_comm* comm_ = nullptr;  // borrowed (set_communicator)
     sp_xchg* xchg_ = nullptr;  // borrowed (set_exchange)

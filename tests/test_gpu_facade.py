@@ -115,3 +115,62 @@ def test_python_kdtree_takes_the_facades_decisions(orc):
     new_idx = np.where(flags == 1, np.cumsum(flags) - 1, -1).astype(np.int32)
     t2.remove_nodes_by_flags(dev(flags), dev(new_idx))
     assert t2.backend_for(uni, 20) == "kdtree"
+
+
+def test_cpp_harness_config4_matches_the_python_path(tmp_path):
+    """examples/bench_registration.cpp: BASELINE config 4 (1 M vs 1 M, GICP, Gauss-Newton, 20 iterations, criteria 0) driven
+    entirely through the header facade — VoxelGrid -> KDTree::build -> knn_search -> covariance::estimate_async ->
+    Registration::align — with the reference harness's per-stage microseconds (cpp/examples/example_registration.cpp:126-161).
+    The same clouds through the Python mirror give the same pose to 1e-5 (the two host layers drive the same kernels), and
+    the facade's loop costs at most 10 % (+ the read-back of the result) more per iteration than the C ABI loop timed with
+    HIP events: what a drop-in C++ caller pays at 1 M points."""
+    import torch
+
+    import sycl_points_amd.api as sp
+    from sycl_points_amd.synthetic import gicp_pair
+
+    _build()
+    n = 1_000_000
+    src, tgt, T_gt = gicp_pair(n, 10.0)
+    sp_path, tp_path = str(tmp_path / "src.bin"), str(tmp_path / "tgt.bin")
+    np.ascontiguousarray(src, np.float32).tofile(sp_path)
+    np.ascontiguousarray(tgt, np.float32).tofile(tp_path)
+    r = subprocess.run([os.path.join(CPP, "bench_registration"), "--points", sp_path, tp_path, "--loops", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-1500:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "first and second alignment give the same pose: yes" in r.stdout
+    T_cpp = np.array([float(x) for x in [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:]],
+                     np.float32).reshape(4, 4).T
+    us_cpp = float([l for l in r.stdout.splitlines() if l.startswith("US_PER_ITERATION ")][0].split()[1])
+
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    vg = sp.VoxelGrid(0.02)
+    S = vg.downsampling(sp.PointCloudShared(dev(src)))
+    Tg = vg.downsampling(sp.PointCloudShared(dev(tgt)))
+    assert f"downsampled: source {S.size()}, target {Tg.size()}" in r.stdout
+    for c in (S, Tg):
+        c.covs = sp.GridKNN.build(c.points, points_per_cell=6.0).self_knn(20, want_knn=False, want_covs=True)[1]
+    prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points, points_per_cell=0.5), Tg.covs)
+    p = sp.RegistrationParams(criteria_translation=0.0, criteria_rotation=0.0, max_iterations=20)
+    reg = sp.Registration(p)
+    T_dev = torch.zeros(16, dtype=torch.float32, device="cuda")
+    T_ident = torch.eye(4, dtype=torch.float32, device="cuda").reshape(-1).contiguous()
+    delta = torch.zeros(8, dtype=torch.float32, device="cuda")
+    ms = []
+    for _ in range(8):
+        T_dev.copy_(T_ident)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reg.align_fused_loop(S, prep, T_dev=T_dev, delta_dev=delta, prepare=True, sort_by_cell="presorted")
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    us_py = 1e3 * float(np.median(ms[2:])) / 20
+    T_py = reg.T_from_device(T_dev)
+    assert np.abs(T_cpp - T_py).max() < 1e-5, np.abs(T_cpp - T_py).max()
+    assert np.abs(T_cpp - T_gt).max() < 2e-4
+    print(f"us per iteration: facade {us_cpp:.2f} (host clock, incl. uploads of the pose and the read-back), C ABI {us_py:.2f} (HIP events)")
+    # one alignment = 20 iterations; the facade adds a 64-byte upload, a 112 + 192-byte read-back and a stream synchronisation
+    # per ALIGNMENT (measured 20-40 us on the host clock): allow 10 % + 2 us per iteration
+    assert us_cpp <= 1.10 * us_py + 2.0, (us_cpp, us_py)
