@@ -180,25 +180,12 @@ def main():
     use_graph = group is not None and not args.no_graph and os.environ.get("SP_BENCH_GRAPH", "1") == "1"
     comm = None
     xchg = None
-    if group is not None and args.exchange in ("auto", "direct") and args.path == "fused":
-        try:
-            xchg = sp.Exchange.from_process_group(group)
-        except Exception as e:  # the peers' buffers could not be mapped here
-            if rank == 0:
-                print(f"bench: direct exchange unavailable ({e!r})", file=sys.stderr)
-        if world > 1:  # all ranks or none
-            flag = torch.tensor([1.0 if xchg is not None else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if flag.item() < 0.5:
-                xchg = None
-        if xchg is None and args.exchange == "direct":
-            raise RuntimeError("--exchange direct: the peers' slot buffers could not be mapped")
-    if group is not None and args.exchange in ("auto", "rccl-row") and args.path == "fused":
-        try:
-            comm = sp.Communicator.from_process_group(group)
-        except Exception as e:  # no RCCL behind the C ABI on this machine: torch.distributed moves the row instead
-            if rank == 0:
-                print(f"bench: sp_comm unavailable ({e!r}); exchanging the row through torch.distributed", file=sys.stderr)
+    elog = lambda m: print(m, file=sys.stderr, flush=True)  # noqa: E731
+    if group is not None and args.path == "fused":
+        from sycl_points_amd.exchange_select import open_carriers
+        xchg, comm = open_carriers(dist, torch, dev, rank, world, args.exchange,
+                                   lambda: sp.Exchange.from_process_group(group),
+                                   lambda: sp.Communicator.from_process_group(group), elog)
     exchange = "rows" if args.exchange == "torch-rows" else "row"
 
     def align_chunk(iters, first):
@@ -228,36 +215,25 @@ def main():
     # rank; if the library's own RCCL communicator does not deliver that (it cannot be rehearsed with more than one rank on
     # the one-GPU test box), the row travels through torch.distributed instead and the line says so.
     exchange_fallback = None
+    exchange_legs = None
     if group is not None and world > 1 and args.path == "fused":
-        def exchange_ok():
+        from sycl_points_amd.exchange_select import verify_and_fall_back
+
+        def try_alignment(x, c):
             T_dev.copy_(T_ident)
             reg.align_fused_loop(S, prep, iterations=ITERS_PER_ALIGN, group=group, T_dev=T_dev, delta_dev=delta, prepare=True,
-                                 sort_by_cell=SORT_MODE, graph=False, comm=comm, exchange=exchange, xchg=xchg)
+                                 sort_by_cell=SORT_MODE, graph=False, comm=c, exchange=exchange, xchg=x)
             torch.cuda.synchronize()
             err = np.abs(reg.T_from_device(T_dev) - T_gt).max()
-            if xchg is not None:
+            if x is not None:
                 try:
                     reg.direct_status()
                 except sp.SpError:
                     err = float("inf")  # a peer's row did not arrive within the bound
-            ok = torch.tensor([1.0 if (np.isfinite(err) and err < 1e-3) else 0.0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            return ok.item() > 0.5, float(err)
-        good, err = exchange_ok()
-        if not good and xchg is not None:
-            if args.exchange == "direct":
-                raise RuntimeError(f"--exchange direct: pose error {err:.3g} on an eager alignment")
-            exchange_fallback = f"direct exchange gave pose error {err:.3g} on an eager alignment; using the RCCL row"
-            xchg = None
-            good, err = exchange_ok()
-        if not good and comm is not None:
-            exchange_fallback = f"sp_comm exchange gave pose error {err:.3g} on an eager alignment; using torch.distributed"
-            comm = None
-            good, err = exchange_ok()
-        if not good:
-            raise RuntimeError(f"sharded alignment does not reach the ground truth (max abs pose error {err:.3g})")
-        if rank == 0 and exchange_fallback:
-            print("bench: " + exchange_fallback, file=sys.stderr, flush=True)
+            return err
+
+        xchg, comm, exchange_fallback, exchange_legs = verify_and_fall_back(dist, torch, dev, rank, world, args.exchange, xchg,
+                                                                            comm, try_alignment, elog)
 
     if use_graph:
         # set-up, like building the grid: capture the hipGraph of every chunk length the warm-up and the timed region
@@ -357,6 +333,7 @@ def main():
                                     ("sp_gicp_align_sharded over the library's RCCL communicator" if comm is not None
                                      else "torch.distributed all-reduce")),
                        "exchange_fallback": exchange_fallback,
+                       "exchange_verification_legs": exchange_legs,
                        "launch": ("one C call per alignment: one launch per iteration (its prologue waits for the peers' rows of the "
                                   "previous iteration and solves), nothing from the host in between" if xchg is not None else
                                   "one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live

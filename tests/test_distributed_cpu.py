@@ -118,3 +118,90 @@ def test_two_rank_sharded_gicp_matches_single_process(tmp_path, orc):
     assert np.abs(T2 - ref["T"]).max() < 1e-5                # sharded == unsharded to rounding
     assert int(r0[16]) == ref["inlier"] == n
     assert np.abs(T2 - T_gt).max() < 2e-3
+
+
+# ------------------------------------------------------------------ the exchange ladder of bench.py --exchange auto
+def _ladder_worker(rank, world, port, scenario, out_path):
+    """Two gloo ranks walk sycl_points_amd.exchange_select with the device calls stubbed: which carrier every rank ends on,
+    that both ranks take every decision together, and that a carrier failing on ONE rank only is dropped on both."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sycl_points_amd.exchange_select import carrier_name, open_carriers, verify_and_fall_back
+
+    log = []
+    sc = scenario
+
+    def make_direct():
+        if sc.get("direct_unavailable_on") == rank or sc.get("direct_unavailable_on") == "all":
+            raise RuntimeError("hipIpcOpenMemHandle failed")
+        return "XCHG"
+
+    def make_comm():
+        if sc.get("comm_unavailable_on") == rank or sc.get("comm_unavailable_on") == "all":
+            raise RuntimeError("librccl.so.1 not found")
+        return "COMM"
+
+    calls = []
+
+    def try_alignment(x, c):
+        name = carrier_name(x, c)
+        calls.append(name)
+        bad = sc.get("bad", {})  # carrier -> rank (or "all") on which the alignment misses the ground truth / raises
+        where = bad.get(name)
+        if where == "all" or where == rank:
+            if sc.get("raises"):
+                raise RuntimeError("row did not arrive")
+            return float("inf") if name == "direct" else 0.5
+        return 3e-6
+
+    res = {"error": ""}
+    try:
+        xchg, comm = open_carriers(dist, torch, "cpu", rank, world, sc.get("want", "auto"), make_direct, make_comm, log.append)
+        xchg, comm, note, legs = verify_and_fall_back(dist, torch, "cpu", rank, world, sc.get("want", "auto"), xchg, comm,
+                                                      try_alignment, log.append)
+        res.update(final=carrier_name(xchg, comm), note=note or "", legs=[(l["carrier"], bool(l["ok"])) for l in legs],
+                   timed=all(l["seconds"] >= 0.0 for l in legs))
+    except RuntimeError as e:
+        res["error"] = str(e)
+    res["calls"] = calls
+    dist.barrier()
+    np.save(out_path % rank, np.array([res], dtype=object), allow_pickle=True)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario, final, tried", [
+    ({}, "direct", ["direct"]),                                                          # everything works: no fall-back
+    ({"direct_unavailable_on": 1}, "rccl-row", ["rccl-row"]),                            # one rank cannot map: nobody uses it
+    ({"direct_unavailable_on": "all", "comm_unavailable_on": 0}, "torch.distributed", ["torch.distributed"]),
+    ({"bad": {"direct": 1}}, "rccl-row", ["direct", "rccl-row"]),                        # wrong pose on one rank only
+    ({"bad": {"direct": "all", "rccl-row": 0}}, "torch.distributed", ["direct", "rccl-row", "torch.distributed"]),
+    ({"bad": {"direct": 0}, "raises": True}, "rccl-row", ["direct", "rccl-row"]),        # a carrier that throws on one rank
+    ({"want": "rccl-row"}, "rccl-row", ["rccl-row"]),
+    ({"want": "torch-row"}, "torch.distributed", ["torch.distributed"]),
+])
+def test_exchange_ladder_two_gloo_ranks(tmp_path, scenario, final, tried):
+    out = str(tmp_path / "ladder%d.npy")
+    mp.spawn(_ladder_worker, args=(2, _free_port(), scenario, out), nprocs=2, join=True)
+    r = [np.load(out % k, allow_pickle=True)[0] for k in range(2)]
+    for k in range(2):
+        assert r[k]["error"] == "", r[k]["error"]
+        assert r[k]["final"] == final and r[k]["calls"] == tried and r[k]["timed"]
+        assert [c for c, _ in r[k]["legs"]] == tried and r[k]["legs"][-1][1] and not any(ok for _, ok in r[k]["legs"][:-1])
+    assert (r[0]["note"] != "") == (len(tried) > 1)
+
+
+def test_exchange_ladder_gives_up_loudly(tmp_path):
+    """Nothing reaches the ground truth: every rank raises (no rank is left waiting in a collective); --exchange direct never
+    falls back silently."""
+    out = str(tmp_path / "ladderx%d.npy")
+    mp.spawn(_ladder_worker, args=(2, _free_port(), {"bad": {"direct": "all", "rccl-row": "all", "torch.distributed": 1}}, out),
+             nprocs=2, join=True)
+    for k in range(2):
+        assert "does not reach the ground truth" in np.load(out % k, allow_pickle=True)[0]["error"]
+    mp.spawn(_ladder_worker, args=(2, _free_port(), {"want": "direct", "bad": {"direct": 1}}, out), nprocs=2, join=True)
+    for k in range(2):
+        assert "--exchange direct" in np.load(out % k, allow_pickle=True)[0]["error"]
+    mp.spawn(_ladder_worker, args=(2, _free_port(), {"want": "direct", "direct_unavailable_on": 0}, out), nprocs=2, join=True)
+    for k in range(2):
+        assert "could not be mapped" in np.load(out % k, allow_pickle=True)[0]["error"]
