@@ -213,7 +213,7 @@ public:
     /// searching (the Python mirror sycl_points_amd.api.KDTree takes the same one; tests hold the two to each other).
     enum class Backend { HostTree, Hierarchy, Grid };
     Backend backend_for(const PointCloudShared& queries, size_t k, const TransformMatrix& transT = TransformMatrix::Identity()) const {
-        if (!(bvh_ != nullptr && pristine_ && !reference_order_ && k <= 32)) return Backend::HostTree;
+        if (!(on_hierarchy() && k <= 32)) return Backend::HostTree;
         const bool own_cloud = built_on_ != nullptr && queries.points == built_on_ && queries.points->generation() == built_generation_ &&
                                queries.size() == size_ && transT == TransformMatrix::Identity();
         if (own_cloud && k >= 8 && k <= 20 && uniform_grid() != nullptr) return Backend::Grid;
@@ -227,7 +227,7 @@ public:
         if (k > 100) throw std::runtime_error("[KDTree::knn_search_async] `k` is too large. not support.");
         detail::prepare_result(queue, result, nq, nq ? k : 0);
         if (nq == 0) return sycl_utils::events();
-        if (bvh_ != nullptr && pristine_ && !reference_order_ && k <= 32) {
+        if (on_hierarchy() && k <= 32) {
             // the tree's own cloud, untouched since build() and searched in place (the covariance pre-step of every pipeline):
             // its points are walked in tree order, neighbouring lanes share their path (1.5x faster than in query order)
             if (built_on_ != nullptr && queries.points == built_on_ && queries.points->generation() == built_generation_ && nq == size_ &&
@@ -265,6 +265,12 @@ public:
             return sycl_utils::events();
         }
         detail::prepare_result(queue, result, nq, max_k);
+        if (on_hierarchy() && max_k <= 32) {
+            throw_on_error(sp_bvh_radius_search(bvh_, queries.points_device(), nq, max_k, radius, transT.data(), 0,
+                                                result.indices->device_data_for_write(nq * max_k),
+                                                result.distances->device_data_for_write(nq * max_k), queue.stream()));
+            return sycl_utils::events(queue.stream());
+        }
         throw_on_error(sp_kdtree_radius_search(host_tree(), queries.points_device(), nq, max_k, radius, transT.data(), 0,
                                                result.indices->device_data_for_write(nq * max_k),
                                                result.distances->device_data_for_write(nq * max_k), queue.stream()));
@@ -273,9 +279,18 @@ public:
     void remove_nodes_by_flags(const shared_vector<uint8_t>& flags, const shared_vector<int32_t>& indices) {
         if (flags.size() != indices.size())
             throw std::runtime_error("[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.");
-        throw_on_error(sp_kdtree_remove_by_flags(host_tree(), flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
+        // lazy delete in whichever structures exist (both must agree from now on); the grid on the tree's own cloud is dropped,
+        // and so is the shortcut for searches of that cloud (its points carry other indices now)
+        if (bvh_ != nullptr)
+            throw_on_error(sp_bvh_remove_by_flags(bvh_, flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
+        if (tree_ != nullptr || bvh_ == nullptr)
+            throw_on_error(sp_kdtree_remove_by_flags(host_tree(), flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
         queue.wait();
-        pristine_ = false;  // the device hierarchy still holds the removed points: the tree answers from here on
+        pristine_ = false;
+        removed_after_host_tree_ = tree_ == nullptr;  // a host tree built later would come from export_points: see host_tree()
+        if (self_grid_) { sp_grid_destroy(self_grid_); self_grid_ = nullptr; }
+        self_grid_tried_ = true;
+        built_on_ = nullptr;
     }
     /// Identity of the built tree (unique per build), its point count, and whether no node was ever removed — what
     /// Registration::align needs to decide that a GridKNN on the same cloud answers the same nearest-neighbour queries.
@@ -285,6 +300,9 @@ public:
 
 private:
     static constexpr size_t kDeviceBuildMinPoints = 1024;
+    /// The device-built hierarchy answers: kNN (k <= 32), radius search and — since round 4 — after a lazy delete too
+    /// (sp_bvh_radius_search / sp_bvh_remove_by_flags); the reference's tree only for its own tie order and k > 32.
+    bool on_hierarchy() const { return bvh_ != nullptr && !reference_order_; }
     /// The points the tree was built on, in their original order, on the device (the hierarchy keeps its own copy, like the
     /// nodes of the reference's tree: the source cloud may be gone or changed by now).
     const float* device_points() const {
@@ -296,6 +314,10 @@ private:
     }
     /// The reference's tree (host build with its rule, kdtree.hpp:292-413).
     sp_kdtree* host_tree() const {
+        if (tree_ == nullptr && removed_after_host_tree_)
+            throw std::runtime_error("[KDTree] the reference-topology tree is needed (k > 32 or set_reference_tie_order) after nodes "
+                                     "were removed from a tree that had not built it: call set_reference_tie_order(true) before "
+                                     "remove_nodes_by_flags");
         if (tree_ == nullptr) {
             std::vector<float> host(4 * std::max<size_t>(size_, 1));
             if (size_) {
@@ -334,6 +356,7 @@ private:
     uint64_t id_ = 0;
     size_t size_ = 0, leaf_threshold_ = 16;
     bool pristine_ = true, reference_order_ = false;
+    bool removed_after_host_tree_ = false;  // nodes were removed while only the hierarchy existed
     std::shared_ptr<PointContainerShared> built_on_;  // the cloud's point container at build(), and its generation then
     uint64_t built_generation_ = 0;
 };

@@ -181,6 +181,17 @@ size_t sp_bvh_size(const sp_bvh* bvh);
 int sp_bvh_search(const sp_bvh* bvh, const float* queries, size_t nq, size_t k, const float* transT, int transT_on_device,
                   int32_t* idx_out, float* d2_out, void* stream);
 int sp_bvh_self_knn(const sp_bvh* bvh, size_t k, int32_t* idx_out, float* d2_out, void* stream);
+/* KDTree::radius_search_async (knn/kdtree.hpp:574-719) on the device-built hierarchy: per query the max_k (<= 32) nearest of the
+ * points within `radius` (squared distance <= radius^2, inclusive as in the reference), ascending, -1 / FLT_MAX padded; ties to
+ * the lowest index. Same arguments as sp_kdtree_radius_search. */
+int sp_bvh_radius_search(const sp_bvh* bvh, const float* queries, size_t nq, size_t max_k, float radius, const float* transT,
+                         int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
+/* KDTree::remove_nodes_by_flags (knn/kdtree.hpp:282-284, 721-765), same arguments as sp_kdtree_remove_by_flags: flags 1 = keep,
+ * 0 = remove; a kept point p is relabelled new_indices[p] (an order-preserving relabelling, as FilterByFlags::calculate_indices
+ * gives, common/filter_by_flags.hpp:30-57); points whose index is >= n_flags are left alone. Lazy, as in the reference: the
+ * removed points stay in their leaves but can no longer be found (no rebuild, no compaction; sp_bvh_size does not change);
+ * sp_bvh_self_knn afterwards writes the rows of the kept points at their new indices. Allocates scratch and synchronises. */
+int sp_bvh_remove_by_flags(sp_bvh* bvh, const uint8_t* flags, const int32_t* new_indices, size_t n_flags, void* stream);
 /* The points the tree was built on, back in their original order (x, y, z, 1): the tree keeps its own copy, like the nodes of
  * the reference's KDTree, so a caller that needs them again later (the facade builds the reference-topology KD-tree lazily,
  * for radius search / lazy delete) does not depend on the source cloud still being there. */

@@ -98,6 +98,8 @@ SIGNATURES = {
     "sp_bvh_size": (_sz, [_vp]),
     "sp_bvh_search": (_i, [_vp, _vp, _sz, _sz, _vp, _i, _vp, _vp, _vp]),
     "sp_bvh_self_knn": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "sp_bvh_radius_search": (_i, [_vp, _vp, _sz, _sz, _f, _vp, _i, _vp, _vp, _vp]),
+    "sp_bvh_remove_by_flags": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "sp_bvh_export_points": (_i, [_vp, _vp, _vp]),
     "sp_voxel_keys": (_i, [_vp, _sz, _f, _vp, _vp]),
     "sp_voxel_downsample_workspace_bytes": (_sz, [_sz]),

@@ -216,6 +216,8 @@ class KDTree(KNNBase):
         return KDTree(h, host.shape[0], dev)
 
     def _host_tree(self):
+        if not self._h and self._points is None:
+            raise SpError(2, "[KDTree] the reference tree is needed (k > 32) after nodes were removed from the device hierarchy")
         if not self._h:
             host = np.ascontiguousarray(self._points.detach().cpu().numpy(), np.float32)
             h = C.c_void_p()
@@ -235,10 +237,10 @@ class KDTree(KNNBase):
 
     def backend_for(self, queries, k, transT=None):
         """'kdtree' | 'bvh' | 'grid': what knn_search_async(queries, k, ..., transT) answers from (KDTree::backend_for)."""
-        if self._bvh is None or not self._pristine or k > 32:
+        if self._bvh is None or k > 32:
             return "kdtree"
         q = _points_of(queries)
-        own = (transT is None and isinstance(q, torch.Tensor) and q.is_cuda and q.shape[0] == self.n and
+        own = (self._pristine and transT is None and isinstance(q, torch.Tensor) and q.is_cuda and q.shape[0] == self.n and
                q.data_ptr() == self._points.data_ptr())
         if own and 8 <= k <= 20 and self._uniform_grid() is not None:
             return "grid"
@@ -262,7 +264,7 @@ class KDTree(KNNBase):
             result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k
             return
         if backend == "bvh":
-            own = transT is None and q.shape[0] == self.n and q.data_ptr() == self._points.data_ptr()
+            own = self._pristine and transT is None and q.shape[0] == self.n and q.data_ptr() == self._points.data_ptr()
             if own:
                 res = self._bvh.self_knn(k)
                 result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k
@@ -283,6 +285,9 @@ class KDTree(KNNBase):
         if q.shape[0] == 0 or max_k == 0:
             result.resize(0, 0, q.device)
             return
+        if self._bvh is not None and max_k <= 32:
+            self._bvh.radius_search_async(queries, max_k, radius, result, transT)
+            return
         result.resize(q.shape[0], max_k, q.device)
         tp, on_dev, keep = _trans_arg(transT)
         check(_lib.lib().sp_kdtree_radius_search(self._host_tree(), _ptr(q), q.shape[0], max_k, radius, tp, on_dev,
@@ -291,9 +296,16 @@ class KDTree(KNNBase):
     def remove_nodes_by_flags(self, flags, indices):
         if flags.shape[0] != indices.shape[0]:
             raise SpError(2, "[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.")
-        check(_lib.lib().sp_kdtree_remove_by_flags(self._host_tree(), _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
+        if self._bvh is not None:
+            self._bvh.remove_nodes_by_flags(flags, indices)
+        if self._h or self._bvh is None:
+            check(_lib.lib().sp_kdtree_remove_by_flags(self._host_tree(), _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
+        elif self._points is not None:
+            self._points = None  # (a reference tree built from here on would not be of the cloud the flags refer to)
         torch.cuda.current_stream().synchronize()
-        self._pristine = False  # the device hierarchy still holds the removed points: the tree answers from here on
+        self._pristine = False  # no own-cloud shortcut / grid any more: the points carry other indices now
+        self._self_grid = None
+        self._self_grid_tried = True
 
 
 class BVH(KNNBase):
@@ -339,6 +351,31 @@ class BVH(KNNBase):
         if self.n:
             check(_lib.lib().sp_bvh_self_knn(self._h, k, _ptr(res.indices), _ptr(res.distances), _stream()))
         return res
+
+    def radius_search_async(self, queries, max_k, radius, result, transT=None):
+        """KDTree::radius_search_async (kdtree.hpp:574-719) on the device-built hierarchy (sp_bvh_radius_search), max_k <= 32."""
+        q = _dev_f32(_points_of(queries), 4)
+        if max_k > 32:
+            raise SpError(2, "[BVH::radius_search_async] `max_k` is too large (max 32).")
+        if q.shape[0] == 0 or max_k == 0:
+            result.resize(0, 0, q.device)
+            return
+        result.resize(q.shape[0], max_k, q.device)
+        tp, on_dev, keep = _trans_arg(transT)
+        check(_lib.lib().sp_bvh_radius_search(self._h, _ptr(q), q.shape[0], max_k, radius, tp, on_dev, _ptr(result.indices),
+                                              _ptr(result.distances), _stream()))
+
+    def radius_search(self, queries, max_k, radius, transT=None):
+        r = KNNResult()
+        self.radius_search_async(queries, max_k, radius, r, transT)
+        torch.cuda.current_stream().synchronize()
+        return r
+
+    def remove_nodes_by_flags(self, flags, indices):
+        """KDTree::remove_nodes_by_flags (kdtree.hpp:721-765), lazily: sp_bvh_remove_by_flags."""
+        if flags.shape[0] != indices.shape[0]:
+            raise SpError(2, "[BVH::remove_nodes_by_flags] flags and indices must have the same size.")
+        check(_lib.lib().sp_bvh_remove_by_flags(self._h, _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
 
 
 class GridKNN(KNNBase):

@@ -223,12 +223,15 @@ __device__ __forceinline__ float box_d2(float lx, float ly, float lz, float hx, 
     return fmaf(dx, dx, fmaf(dy, dy, dz * dz)) * 0.999999f;
 }
 
-template <int KCAP>
+// RADIUS (KDTree::radius_search_async, kdtree.hpp:574-719): the `k` nearest among the points within radius_sq (inclusive) —
+// a candidate must lie inside the ball AND beat the current k-th; a subtree is skipped when its box lies beyond the smaller
+// of the two bounds.
+template <int KCAP, bool RADIUS = false>
 __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __restrict__ node, const float4* __restrict__ obox,
                                                             const float4* __restrict__ spts, unsigned n,
                                                             const float4* __restrict__ queries, unsigned nq, int k, Mat4Arg T_val,
                                                             const float* __restrict__ T_dev, int32_t* __restrict__ idx_out,
-                                                            float* __restrict__ d2_out) {
+                                                            float* __restrict__ d2_out, float radius_sq = 0.0f) {
     __shared__ unsigned st_node[kBvhStack][kBlock];
     const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
     if (qi >= nq) return;  // no barrier below
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
         const float4 q4 = spts[qi];
         qx = q4.x; qy = q4.y; qz = q4.z;
         row = __float_as_uint(q4.w);
+        if (__float_as_int(q4.w) < 0) return;  // a removed point (sp_bvh_remove_by_flags): no row of its own any more
     }
     float bd[KCAP];
     int bi[KCAP];
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
                 const int pi = __float_as_int(slot[s].w);
                 const bool seen = skip_window && b + s >= w0 && b + s <= w1;
                 // (a non-finite point gives a NaN distance: every comparison fails, it is never taken)
-                if (b + s <= last && !seen && (d < kth || (d == kth && pi < kth_idx))) lex_insert<KCAP>(bd, bi, k, d, pi, kth, kth_idx);
+                if (b + s <= last && !seen && (!RADIUS || d <= radius_sq) && (d < kth || (d == kth && pi < kth_idx)))
+                    lex_insert<KCAP>(bd, bi, k, d, pi, kth, kth_idx);
             }
         }
     };
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
                     const bool take_left = (pass == 0) == l_near;
                     const float dc = take_left ? dl : dr;
                     const unsigned cf = take_left ? first : split + 1u, cl = take_left ? split : last;
-                    if (dc > kth) continue;  // (an empty box is +inf away)
+                    if (dc > kth || (RADIUS && dc > radius_sq)) continue;  // (an empty box is +inf away)
                     // A box exactly AT the k-th distance can only matter through a point at that very distance with a lower
                     // index than the k-th neighbour's (lists are (distance, index)-lexicographic). Clouds with thousands of
                     // copies of one point (invalid returns of a scan) would otherwise visit every copy from every copy.
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
                     const unsigned c = st_node[sp_top][lane];
                     const float4 o0 = obox[2 * (size_t)c], o1 = obox[2 * (size_t)c + 1];
                     const float dc = box_d2(o0.x, o0.y, o0.z, o1.x, o1.y, o1.z, qx, qy, qz);
-                    if (dc > kth || (dc == kth && __float_as_int(o0.w) > kth_idx)) continue;
+                    if (dc > kth || (RADIUS && dc > radius_sq) || (dc == kth && __float_as_int(o0.w) > kth_idx)) continue;
                     cur = c;
                     found = true;
                     break;
@@ -357,15 +362,56 @@ __global__ __launch_bounds__(kBlock) void bvh_export_kernel(const float4* __rest
     out[o] = p;
 }
 
-template <int KCAP>
-void launch_bvh(const sp_bvh* b, const float4* q, unsigned nq, int k, const Mat4Arg& Tv, const float* T_dev, int32_t* idx, float* d2,
-                hipStream_t st) {
-    bvh_search_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(b->node, b->obox, b->pts, (unsigned)b->n, q, nq, k, Tv, T_dev, idx,
-                                                                 d2);
+// Lazy delete (KDTree::remove_nodes_by_flags, kdtree.hpp:282-284, 721-765): a removed point stays in its leaf with NaN
+// coordinates (its distance is NaN, no comparison takes it) and index -1; a kept one is relabelled. The boxes stay as they are
+// (conservative). `kept_before` = exclusive prefix sum of the flags.
+__global__ __launch_bounds__(kBlock) void bvh_remove_points_kernel(float4* __restrict__ spts, unsigned n,
+                                                                   const uint8_t* __restrict__ flags,
+                                                                   const int32_t* __restrict__ new_indices, unsigned n_flags) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 p = spts[i];
+    const int o = __float_as_int(p.w);
+    if (o < 0 || (unsigned)o >= n_flags) return;  // removed earlier / outside the flag array: left alone
+    if (flags[o]) {
+        p.w = __int_as_float(new_indices[o]);
+    } else {
+        const float nan = __int_as_float(0x7fc00000);
+        p = make_float4(nan, nan, nan, __int_as_float(-1));
+    }
+    spts[i] = p;
+}
+// The lowest index below a node (obox lo.w: what lets a box exactly at the k-th distance be skipped when it cannot hold a
+// lower index) becomes a LOWER BOUND of the lowest NEW index below it: the number of kept points before the old lowest index.
+// Exact for an order-preserving relabelling (the reference's: FilterByFlags::calculate_indices, a running count); any bound
+// from below keeps the search exact.
+__global__ __launch_bounds__(kBlock) void bvh_remove_minidx_kernel(float4* __restrict__ obox, unsigned n_internal,
+                                                                   const uint32_t* __restrict__ kept_before, unsigned n_flags) {
+    const unsigned c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= n_internal) return;
+    const int old_min = __float_as_int(obox[2 * (size_t)c].w);
+    if (old_min >= 0 && (unsigned)old_min < n_flags) obox[2 * (size_t)c].w = __int_as_float((int)kept_before[old_min]);
+}
+__global__ __launch_bounds__(kBlock) void bvh_flags_to_u32_kernel(const uint8_t* __restrict__ flags, unsigned n,
+                                                                  uint32_t* __restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = flags[i] ? 1u : 0u;
 }
 
+template <int KCAP>
+void launch_bvh(const sp_bvh* b, const float4* q, unsigned nq, int k, const Mat4Arg& Tv, const float* T_dev, int32_t* idx, float* d2,
+                hipStream_t st, float radius_sq) {
+    if (radius_sq >= 0.0f)
+        bvh_search_kernel<KCAP, true><<<div_up(nq, kBlock), kBlock, 0, st>>>(b->node, b->obox, b->pts, (unsigned)b->n, q, nq, k, Tv,
+                                                                           T_dev, idx, d2, radius_sq);
+    else
+        bvh_search_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(b->node, b->obox, b->pts, (unsigned)b->n, q, nq, k, Tv, T_dev,
+                                                                     idx, d2);
+}
+
+// radius_sq < 0: plain kNN
 int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const float* transT, int transT_on_device,
-                 int32_t* idx_out, float* d2_out, hipStream_t st) {
+                 int32_t* idx_out, float* d2_out, hipStream_t st, float radius_sq = -1.0f) {
     if (k == 0 || k > 32) {
         sp_set_error("[BVH] k must be in 1..32");
         return SP_ERR_INVALID_ARGUMENT;
@@ -377,10 +423,10 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         for (int i = 0; i < 16; ++i) Tv.m[i] = transT[i];
     const float* T_dev = transT_on_device ? transT : nullptr;
     const int kk = (int)k;
-    if (k == 1) launch_bvh<1>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
-    else if (k <= 10) launch_bvh<10>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
-    else if (k <= 20) launch_bvh<20>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
-    else launch_bvh<32>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st);
+    if (k == 1) launch_bvh<1>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st, radius_sq);
+    else if (k <= 10) launch_bvh<10>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st, radius_sq);
+    else if (k <= 20) launch_bvh<20>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st, radius_sq);
+    else launch_bvh<32>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st, radius_sq);
     return launch_status();
 }
 
@@ -464,6 +510,43 @@ extern "C" int sp_bvh_search(const sp_bvh* bvh, const float* queries, size_t nq,
     if (nq >= (1ull << 32)) return SP_ERR_INVALID_ARGUMENT;
     return sp::bvh_dispatch(bvh, reinterpret_cast<const float4*>(queries), (unsigned)nq, k, transT, transT_on_device, idx_out, d2_out,
                             sp::as_stream(stream));
+}
+
+extern "C" int sp_bvh_radius_search(const sp_bvh* bvh, const float* queries, size_t nq, size_t max_k, float radius,
+                                    const float* transT, int transT_on_device, int32_t* idx_out, float* d2_out, void* stream) {
+    if (!bvh || !idx_out || !d2_out || (!queries && nq)) return SP_ERR_INVALID_ARGUMENT;
+    if (nq == 0) return SP_OK;
+    if (nq >= (1ull << 32) || !(radius >= 0.0f)) return SP_ERR_INVALID_ARGUMENT;
+    return sp::bvh_dispatch(bvh, reinterpret_cast<const float4*>(queries), (unsigned)nq, max_k, transT, transT_on_device, idx_out,
+                            d2_out, sp::as_stream(stream), radius * radius);
+}
+
+extern "C" int sp_bvh_remove_by_flags(sp_bvh* bvh, const uint8_t* flags, const int32_t* new_indices, size_t n_flags, void* stream) {
+    using namespace sp;
+    if (!bvh || (n_flags && (!flags || !new_indices))) return SP_ERR_INVALID_ARGUMENT;
+    if (bvh->n == 0 || n_flags == 0) return SP_OK;
+    if (n_flags >= (1ull << 30)) return SP_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    bvh->streams.note(st);
+    ScratchBuf b_f, b_pre, b_ws;
+    const size_t wsb = exclusive_scan_u32_workspace_bytes(n_flags);
+    hipError_t e = b_f.get(n_flags * 4);
+    if (e == hipSuccess) e = b_pre.get(n_flags * 4);
+    if (e == hipSuccess) e = b_ws.get(wsb ? wsb : 16);
+    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    bvh_flags_to_u32_kernel<<<div_up(n_flags, kBlock), kBlock, 0, st>>>(flags, (unsigned)n_flags, b_f.as<uint32_t>());
+    if (exclusive_scan_u32(b_f.as<uint32_t>(), b_pre.as<uint32_t>(), n_flags, nullptr, b_ws.p, wsb, st) != SP_OK) {
+        sp_set_error("[BVH::remove_nodes_by_flags] scan failed");
+        return SP_ERR_HIP;
+    }
+    if (bvh->n > 1)
+        bvh_remove_minidx_kernel<<<div_up(bvh->n - 1, kBlock), kBlock, 0, st>>>(bvh->obox, (unsigned)(bvh->n - 1), b_pre.as<uint32_t>(),
+                                                                              (unsigned)n_flags);
+    bvh_remove_points_kernel<<<div_up(bvh->n, kBlock), kBlock, 0, st>>>(bvh->pts, (unsigned)bvh->n, flags, new_indices,
+                                                                      (unsigned)n_flags);
+    const int rc = launch_status();
+    if (hipStreamSynchronize(st) != hipSuccess) return SP_ERR_HIP;  // the scratch is idle again
+    return rc;
 }
 
 extern "C" int sp_bvh_self_knn(const sp_bvh* bvh, size_t k, int32_t* idx_out, float* d2_out, void* stream) {

@@ -807,6 +807,51 @@ static void kdtree_backend_on_the_bundled_scan() {
     CHECK(alg::knn::KDTree::build(*Q, small)->backend_for(small, 10) == Backend::HostTree);
 }
 
+static void kdtree_radius_and_lazy_delete_on_the_hierarchy() {
+    // KDTree::radius_search_async / remove_nodes_by_flags (kdtree.hpp:574-765) on a cloud large enough for the device-built
+    // hierarchy (no host tree is ever built): radius search = brute force's list cut at the radius; after a removal the tree
+    // answers like brute force over the kept points under their new indices (test_kdtree.cpp:459-512).
+    std::mt19937 gen(17);
+    PointCloudCPU c, qc;
+    random_points(gen, c, 20000, 5.0f);
+    random_points(gen, qc, 500, 5.0f);
+    PointCloudShared cloud(*Q, c), queries(*Q, qc);
+    auto tree = alg::knn::KDTree::build(*Q, cloud);
+    const size_t max_k = 10;
+    const float radius = 0.4f;
+    alg::knn::KNNResult rr;
+    tree->radius_search_async(queries, max_k, radius, rr).wait_and_throw();
+    auto bf = alg::knn::knn_search_bruteforce(*Q, queries, cloud, max_k);
+    bool same = rr.query_size == queries.size() && rr.k == max_k;
+    for (size_t i = 0; same && i < queries.size() * max_k; ++i) {
+        const bool inside = (*bf.distances)[i] <= radius * radius;
+        same = inside ? ((*rr.indices)[i] == (*bf.indices)[i] && (*rr.distances)[i] == (*bf.distances)[i])
+                      : ((*rr.indices)[i] == -1 && (*rr.distances)[i] == std::numeric_limits<float>::max());
+    }
+    CHECK(same);
+    CHECK(tree->backend_for(queries, 10) == alg::knn::KDTree::Backend::Hierarchy);
+    // lazy delete: every third point goes
+    shared_vector<uint8_t> flags(c.size(), uint8_t(1), *Q);
+    shared_vector<int32_t> new_idx(c.size(), -1, *Q);
+    PointCloudCPU kept;
+    int32_t next = 0;
+    for (size_t i = 0; i < c.size(); ++i) {
+        if (i % 3 == 0) { flags[i] = 0; continue; }
+        new_idx[i] = next++;
+        kept.points->push_back((*c.points)[i]);
+    }
+    tree->remove_nodes_by_flags(flags, new_idx);
+    CHECK(!tree->pristine());
+    CHECK(tree->backend_for(queries, 10) == alg::knn::KDTree::Backend::Hierarchy);  // still the hierarchy: no host build
+    PointCloudShared kept_cloud(*Q, kept);
+    auto kd = tree->knn_search(queries, max_k);
+    auto bf2 = alg::knn::knn_search_bruteforce(*Q, queries, kept_cloud, max_k);
+    same = true;
+    for (size_t i = 0; same && i < queries.size() * max_k; ++i)
+        same = (*kd.indices)[i] == (*bf2.indices)[i] && (*kd.distances)[i] == (*bf2.distances)[i];
+    CHECK(same);
+}
+
 static void kdtree_self_knn_large_clouds() {
     // KDTree::knn_search on the tree's own cloud: from 32 k points on, a cloud of near-uniform density is answered by the grid's
     // lane-per-query selection, a clustered one (fullest cell over the limit) by the device-built hierarchy; both must give
@@ -844,6 +889,7 @@ int main() {
     RUN(kdtree_grid_vs_bruteforce);
     RUN(kdtree_self_knn_large_clouds);
     RUN(kdtree_backend_on_the_bundled_scan);
+    RUN(kdtree_radius_and_lazy_delete_on_the_hierarchy);
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
     RUN(point_cloud_extend_erase);

