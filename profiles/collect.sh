@@ -46,7 +46,7 @@ PY
 python3 $ROOT/profiles/collect_traffic.py > $OUT/collect_traffic.log 2>&1 || echo "collect_traffic failed"
 cp $ROOT/gpurun_out/traffic.json $OUT/traffic.json 2>/dev/null || true
 for c in FETCH_SIZE WRITE_SIZE; do
-  f=$(ls -t $ROOT/gpurun_out/pmc_traffic/$c/*/*counter_collection.csv 2>/dev/null | head -1)
+  f=$(ls -t $ROOT/gpurun_out/pmc_traffic/bench/$c/*/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python3 - "$f" "$c" > $OUT/${TAG}_pmc_${c}_summary.csv <<'PY'
 import collections, csv, sys
 acc = collections.defaultdict(list)
