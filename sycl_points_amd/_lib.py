@@ -176,12 +176,14 @@ SIGNATURES = {
 INTERNAL_SIGNATURES = {
     "sp_internal_source_option": (_i, [_vp, _i, _i]),
     "sp_internal_grid_option": (_i, [_vp, _i, _i]),
+    "sp_internal_bvh_option": (_i, [_vp, _i, _i]),
     "sp_internal_align_searched_log": (_vp, [_vp, _vp]),
     "sp_internal_radix_sort_workspace_bytes": (_sz, [_sz]),
     "sp_internal_radix_sort_u32": (_i, [_vp, _vp, _vp, _vp, _sz, C.c_uint, _vp, _sz, _vp, _vp]),
 }
 VOXEL_BOX_SHARDS, VOXEL_BOX_SHARD_STRIDE = 16, 32  # SP_VOXEL_BOX_SHARDS, SP_VOXEL_BOX_SHARD_STRIDE
-INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3, "persistent": 4, "persistent_from": 5}
+INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3, "persistent": 4, "persistent_from": 5,
+                   "bvh_self_heap": 6}
 
 
 def build(force=False):

@@ -344,6 +344,10 @@ class BVH(KNNBase):
         check(_lib.lib().sp_bvh_search(self._h, _ptr(q), q.shape[0], k, tp, on_dev, _ptr(result.indices),
                                        _ptr(result.distances), _stream()))
 
+    def _set_option(self, name, value):
+        """csrc/sp_internal.h switches of this handle (tests, comparisons)."""
+        check(_lib.lib().sp_internal_bvh_option(self._h, _lib.INTERNAL_OPTION[name], int(value)))
+
     def self_knn(self, k):
         """The cloud's own points as queries, in tree order (row i = neighbours of point i)."""
         res = KNNResult()

@@ -32,11 +32,15 @@ enum {
      * as a launch of its own (0). Same bits either way. */
     SP_INTERNAL_FUSED_PERSISTENT = 4,
     /* sp_gicp_source: first iteration of that tail (default 4; 0: the whole alignment as one launch). */
-    SP_INTERNAL_FUSED_PERSISTENT_FROM = 5
+    SP_INTERNAL_FUSED_PERSISTENT_FROM = 5,
+    /* sp_bvh: sp_bvh_self_knn for 2 <= k <= 21 with the lane's k best in a heap (1, default) or by the sorted-insertion kernel
+     * that serves every other search (0). Same lists either way. */
+    SP_INTERNAL_BVH_SELF_HEAP = 6
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);
 int sp_internal_grid_option(sp_grid* grid, int option, int value);
+int sp_internal_bvh_option(sp_bvh* bvh, int option, int value);
 /* Device pointer to the per-launch log of an sp_gicp_align_* workspace: entry k = number of source points launch k had to
  * search for (the others reused their previous correspondence by certificate). *n_entries_out = entries kept (64). */
 const uint32_t* sp_internal_align_searched_log(void* workspace, size_t* n_entries_out);
