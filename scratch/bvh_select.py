@@ -49,5 +49,19 @@ for name, pts in clouds:
         t_new = med(lambda: b.self_knn(k))
         same = torch.equal(ref.indices, new.indices) and torch.equal(ref.distances, new.distances)
         bad = int((ref.indices != new.indices).any(1).sum())
-        line.append(f" k={k}: sorted-insertion {t_old:.3f} ms, heap {t_new:.3f} ms, identical {same} ({bad} rows differ) |")
+        rq = sp.KNNResult()
+        b._set_option("bvh_self_heap", 0)
+        b.knn_search_async(P, k, rq)
+        qi0, qd0 = rq.indices.clone(), rq.distances.clone()
+        tq_old = med(lambda: b.knn_search_async(P, k, rq))
+        rr0 = b.radius_search(P, k, 0.3)
+        tr_old = med(lambda: b.radius_search_async(P, k, 0.3, rq))
+        b._set_option("bvh_self_heap", 1)
+        b.knn_search_async(P, k, rq)
+        sameq = torch.equal(qi0, rq.indices) and torch.equal(qd0, rq.distances) and torch.equal(qi0, ref.indices)
+        tq_new = med(lambda: b.knn_search_async(P, k, rq))
+        rr1 = b.radius_search(P, k, 0.3)
+        samer = torch.equal(rr0.indices, rr1.indices) and torch.equal(rr0.distances, rr1.distances)
+        tr_new = med(lambda: b.radius_search_async(P, k, 0.3, rq))
+        line.append(f"\n   k={k}: self {t_old:.3f} -> {t_new:.3f} ms identical {same} ({bad} rows differ); query-order {tq_old:.3f} -> {tq_new:.3f} ms identical {sameq}; radius 0.3 {tr_old:.3f} -> {tr_new:.3f} ms identical {samer}")
     print("".join(line), flush=True)

@@ -33,7 +33,7 @@ struct sp_bvh {
     float4* obox = nullptr;   // 2 x float4 per internal node: its own box (re-tested when a stacked node is taken up again);
                               // lo.w = the lowest original index below the node (ties, see bvh_search_kernel)
     mutable sp::StreamSet streams;
-    int self_heap = 1;        // sp_bvh_self_knn, 2 <= k <= 21: bvh_self_heap_kernel (0: the sorted-insertion kernel alone; tests, comparisons)
+    int self_heap = 1;        // searches for 2 <= k <= 21: bvh_heap_kernel (0: the sorted-insertion kernel alone; tests, comparisons)
 };
 
 namespace sp {
@@ -363,15 +363,16 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Self-kNN for lists of 2..21 entries with the running k best of a lane in a 4-ary MAX-HEAP of (distance, index) keys: the
+// Searches for lists of 2..21 entries with the running k best of a lane in a 4-ary MAX-HEAP of (distance, index) keys: the
 // root and its four children on registers, the sixteen grandchildren in the lane's LDS column. Replacing the root costs two
 // sift steps (the largest of four, twice) whatever k is, where the sorted list of bvh_search_kernel is a k-step select chain
 // that the whole wave walks whenever ANY of its 64 lanes accepts a candidate — with lanes in different leaves that is
 // nearly every candidate (107 k vector wave-instructions per 64 queries at k = 20, profiles/r03_bvh_vs_kdtree_vs_grid.txt).
 // The walk is restructured as well: the lanes of a wave first all find a leaf, then all scan one (bvh_walk), instead of
 // scanning inline in the descent with a few lanes active. The bound of the walk starts at the k-th smallest distance to the
-// lane's 33 neighbours in Morton order (bisection on the bit patterns of the 33 distances, which stay on registers; nothing
-// is inserted for it, so no point can enter twice) and follows the root once k candidates are in. At the end the k keys are
+// lane's 33 neighbours in Morton order when the cloud's own points are the queries (bisection on the bit patterns of the 33
+// distances, which stay on registers), at the radius for a radius search, at infinity otherwise, and follows the root once k
+// candidates are in. At the end the k keys are
 // ranked by counting. Exact and bit-identical to the sorted-insertion kernel: keys are (distance, index)-lexicographic, a
 // subtree is skipped only when its box lies strictly beyond the bound or exactly at it without a lower index inside.
 // A non-finite query point or a tree deeper than the stack goes to that kernel through a list.
@@ -444,26 +445,40 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ node, const 
     return ok;
 }
 
-template <int KCAP>  // 5 (root + children only), 10 or 21
-__global__ __launch_bounds__(kBlock) void bvh_self_heap_kernel(const float4* __restrict__ node, const float4* __restrict__ obox,
-                                                               const float4* __restrict__ spts, unsigned n, int k,
-                                                               int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
-                                                               unsigned* __restrict__ todo, unsigned* __restrict__ todo_count) {
+// MODE 0: the cloud's own points in Morton order (rows by original index); 1: external queries searched at T * q;
+// 2: the same within radius_sq (inclusive; KDTree::radius_search_async).
+template <int KCAP, int MODE>  // KCAP 5 (root + children only), 10 or 21
+__global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restrict__ node, const float4* __restrict__ obox,
+                                                          const float4* __restrict__ spts, unsigned n,
+                                                          const float4* __restrict__ queries, unsigned nq, int k, Mat4Arg T_val,
+                                                          const float* __restrict__ T_dev, float radius_sq,
+                                                          int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                          unsigned* __restrict__ todo, unsigned* __restrict__ todo_count) {
     constexpr int kDeep = KCAP > 5 ? KCAP - 5 : 1;  // grandchildren (slots 5 ..)
     __shared__ unsigned st_node[kHeapStack][kBlock];
     __shared__ unsigned long long heap2[kDeep][kBlock];
     const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
-    if (qi >= n) return;  // no barrier below
+    if (qi >= nq) return;  // no barrier below
     const unsigned lane = threadIdx.x;
-    const float4 q4 = spts[qi];
-    const float qx = q4.x, qy = q4.y, qz = q4.z;
-    if (__float_as_int(q4.w) < 0) return;  // a removed point: no row of its own
-    const size_t o = (size_t)__float_as_uint(q4.w) * (size_t)k;
-    bool mine = isfinite(qx) && isfinite(qy) && isfinite(qz);  // false: handed on to bvh_search_kernel
+    float qx, qy, qz;
+    size_t o;
+    if (MODE == 0) {
+        const float4 q4 = spts[qi];
+        qx = q4.x; qy = q4.y; qz = q4.z;
+        if (__float_as_int(q4.w) < 0) return;  // a removed point: no row of its own
+        o = (size_t)__float_as_uint(q4.w) * (size_t)k;
+    } else {
+        const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+        const float4 q4 = queries[qi];
+        transform_point(T, q4.x, q4.y, q4.z, qx, qy, qz);
+        o = (size_t)qi * (size_t)k;
+    }
+    const bool mine = isfinite(qx) && isfinite(qy) && isfinite(qz);  // false: handed on to bvh_search_kernel
 
-    // the k-th smallest distance to the Morton neighbours (FLT_MAX when fewer than k of them are valid)
-    float top = FLT_MAX;
-    {
+    // Where the walk starts to prune. Self-search: the k-th smallest distance to the Morton neighbours (when k of them are
+    // valid). Nothing is inserted for it, so no point can enter twice.
+    float top = MODE == 2 ? radius_sq : FLT_MAX;
+    if (MODE == 0) {
         unsigned wb[2 * kSelHalf + 1];
         unsigned hi = 0u, finite = 0u;
 #pragma unroll
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void bvh_self_heap_kernel(const float4* __r
             bound_idx = key_idx(h0);
         }
     });
-    if (!mine || !ok) {
+    if (!mine || !ok) {  // (a non-finite query gets the empty list from the other kernel)
         todo[atomicAdd(todo_count, 1u)] = qi;
         return;
     }
@@ -648,8 +663,12 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         for (int i = 0; i < 16; ++i) Tv.m[i] = transT[i];
     const float* T_dev = transT_on_device ? transT : nullptr;
     const int kk = (int)k;
-    if (!q && radius_sq < 0.0f && k >= 2 && k <= 21 && b->n > (size_t)kBvhLeaf && b->self_heap) {
-        // heap kernel; what it hands on (non-finite points, a tree deeper than its stack) is finished by the sorted-insertion kernel
+    // (measured, scratch/bvh_select.py: the heap kernel wins wherever the device is full — 1 M queries, every k and mode, 1.2 to 3.5
+    // times — and for radius and self searches of any size; short external lists on a cloud that leaves SIMDs idle are
+    // latency-bound and 20-50 % faster on the other kernel's inline leaf scans)
+    const bool small_external = q && radius_sq < 0.0f && k <= 10 && nq < 256u * 1024u;
+    if (k >= 2 && k <= 21 && b->n > (size_t)kBvhLeaf && b->self_heap && !small_external) {
+        // heap kernel; what it hands on (non-finite queries, a tree deeper than its stack) is finished by the sorted-insertion kernel
         unsigned* todo = nullptr;
         if (pooled_alloc(&todo, ((size_t)nq + 1) * sizeof(unsigned)) != hipSuccess) return SP_ERR_HIP;
         unsigned* const todo_count = todo + nq;
@@ -657,23 +676,31 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         if (rc == SP_OK) {
             const unsigned g = div_up(nq, kBlock);
             const unsigned n32 = (unsigned)b->n;
-            if (k <= 5) {
-                bvh_self_heap_kernel<5><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, kk, idx_out, d2_out, todo, todo_count);
-                bvh_search_kernel<10><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,
-                                                           todo, todo_count);
-            } else if (k <= 10) {
-                bvh_self_heap_kernel<10><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, kk, idx_out, d2_out, todo, todo_count);
-                bvh_search_kernel<10><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,
-                                                           todo, todo_count);
-            } else {
-                bvh_self_heap_kernel<21><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, kk, idx_out, d2_out, todo, todo_count);
-                if (k <= 20)
-                    bvh_search_kernel<20><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out,
-                                                               0.0f, todo, todo_count);
-                else
-                    bvh_search_kernel<32><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out,
-                                                               0.0f, todo, todo_count);
-            }
+            const float r2 = radius_sq;
+#define SP_BVH_HEAP(KC, OLDK)                                                                                                          \
+    do {                                                                                                                                \
+        if (!q) {                                                                                                                       \
+            bvh_heap_kernel<KC, 0><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
+                                                        todo_count);                                                                   \
+            bvh_search_kernel<OLDK><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,    \
+                                                         todo, todo_count);                                                            \
+        } else if (r2 < 0.0f) {                                                                                                         \
+            bvh_heap_kernel<KC, 1><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
+                                                        todo_count);                                                                   \
+            bvh_search_kernel<OLDK><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,    \
+                                                         todo, todo_count);                                                            \
+        } else {                                                                                                                        \
+            bvh_heap_kernel<KC, 2><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
+                                                        todo_count);                                                                   \
+            bvh_search_kernel<OLDK, true><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out,    \
+                                                               r2, todo, todo_count);                                                  \
+        }                                                                                                                               \
+    } while (0)
+            if (k <= 5) SP_BVH_HEAP(5, 10);
+            else if (k <= 10) SP_BVH_HEAP(10, 10);
+            else if (k <= 20) SP_BVH_HEAP(21, 20);
+            else SP_BVH_HEAP(21, 32);
+#undef SP_BVH_HEAP
             rc = launch_status();
         }
         StreamSet used;

@@ -33,7 +33,7 @@ enum {
     SP_INTERNAL_FUSED_PERSISTENT = 4,
     /* sp_gicp_source: first iteration of that tail (default 4; 0: the whole alignment as one launch). */
     SP_INTERNAL_FUSED_PERSISTENT_FROM = 5,
-    /* sp_bvh: sp_bvh_self_knn for 2 <= k <= 21 with the lane's k best in a heap (1, default) or by the sorted-insertion kernel
+    /* sp_bvh: searches for 2 <= k <= 21 with the lane's k best in a heap (1, default) or by the sorted-insertion kernel
      * that serves every other search (0). Same lists either way. */
     SP_INTERNAL_BVH_SELF_HEAP = 6
 };

@@ -132,6 +132,68 @@ def test_bvh_raw_lidar_scan_and_nonuniform_1m(sp, orc):
     assert torch.equal(q.indices, s.indices[dev(sel)]) and torch.equal(q.distances, s.distances[dev(sel)])
 
 
+def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
+    """Lists of 2..21 entries come from bvh_heap_kernel (the lane's k best in a 4-ary heap: root and children on registers,
+    grandchildren in LDS), everything else — and whatever that kernel hands on — from the sorted-insertion kernel. Both must
+    give the lists of knn_search_bruteforce (knn/bruteforce.hpp:46-92: (distance, index)-lexicographic), bit for bit: on a
+    cloud with exact duplicates (more copies than k), non-finite points and queries, in the three modes (own points, external
+    queries with a transform, radius search), for every heap shape (k <= 5: no LDS level; k = 6..10; k = 11..21 with 21 = the
+    full third level), before and after a lazy delete, and with enough queries (300 k) for the heap kernel to be the one that
+    is dispatched for short external lists too."""
+    rs = np.random.RandomState(3)
+    pts = nonuniform_cloud(40_000, seed=11)
+    pts[1000:1030] = pts[1000]       # 30 copies: more than any k here
+    pts[2000:2008] = pts[2000]
+    pts[17, 0] = np.nan
+    pts[23, 2] = np.inf
+    q = pts[rs.permutation(len(pts))[:5000]].copy()
+    q[:, :3] += rs.normal(0, 0.05, (len(q), 3)).astype(np.float32)
+    q[5, 1] = np.nan
+    T = orc.se3_exp(np.array([0.05, -0.1, 0.02, 0.2, -0.1, 0.1], np.float32))
+    qT = orc.transform_points(q, T)
+    P, Q = dev(pts), dev(q)
+    b = sp.BVH.build(P)
+
+    def both(fn, rows=None):
+        b._set_option("bvh_self_heap", 0)
+        a = fn()
+        ai, ad = a.indices[:rows].clone(), a.distances[:rows].clone()
+        b._set_option("bvh_self_heap", 1)
+        c = fn()
+        assert torch.equal(ai, c.indices[:rows]) and torch.equal(ad, c.distances[:rows])
+        return c
+
+    for k in (2, 5, 6, 10, 11, 20, 21):
+        s = both(lambda: b.self_knn(k))
+        r = both(lambda: b.knn_search(Q, k, T))
+        if k in (2, 6, 20):  # brute force on the host is the slow part (and the reference's arrays end at k = 20)
+            bi, bd = orc.knn_bruteforce(pts, pts, k)
+            assert np.array_equal(s.indices.cpu().numpy(), bi) and np.array_equal(s.distances.cpu().numpy(), bd)
+            qi, qd = orc.knn_bruteforce(qT, pts, k)
+            assert np.array_equal(r.indices.cpu().numpy(), qi) and np.array_equal(r.distances.cpu().numpy(), qd)
+        both(lambda: b.radius_search(Q, k, 0.25, T))
+        both(lambda: b.radius_search(P, k, 0.02))  # most balls hold fewer than k points: rows end in (-1, FLT_MAX)
+    # many external queries: the heap kernel serves short lists too
+    big_q = dev(np.tile(q, (60, 1)))
+    for k in (3, 10):
+        r = both(lambda: b.knn_search(big_q, k, T))
+        small = b.knn_search(Q, k, T)
+        assert torch.equal(r.indices[:len(q)], small.indices) and torch.equal(r.distances[-len(q):], small.distances)
+    # after a lazy delete (removed points stay in their leaves with NaN coordinates)
+    keep = rs.rand(len(pts)) > 0.3
+    new_idx = (np.cumsum(keep) - 1).astype(np.int32)
+    b.remove_nodes_by_flags(dev(keep.astype(np.uint8)), dev(new_idx))
+    kept = pts[keep]
+    n_kept = int(keep.sum())
+    for k in (4, 20):
+        s = both(lambda: b.self_knn(k), n_kept)  # (rows behind the kept points are not written)
+        r = both(lambda: b.knn_search(Q, k, T))
+        bi, bd = orc.knn_bruteforce(qT, kept, k)
+        assert np.array_equal(r.indices.cpu().numpy(), bi) and np.array_equal(r.distances.cpu().numpy(), bd)
+        si, sd = orc.knn_bruteforce(kept, kept, k)
+        assert np.array_equal(s.indices.cpu().numpy()[:n_kept], si) and np.array_equal(s.distances.cpu().numpy()[:n_kept], sd)
+
+
 def test_bvh_radius_search_and_lazy_delete_match_the_oracle(sp, orc):
     """KDTree::radius_search_async and remove_nodes_by_flags (kdtree.hpp:574-765) on the device-built hierarchy
     (sp_bvh_radius_search / sp_bvh_remove_by_flags) against the oracle's KD-tree with the shapes of the reference's own tests
