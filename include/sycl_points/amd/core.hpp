@@ -122,20 +122,51 @@ namespace detail {
 // device buffers: hipMalloc / hipFree cost 0.1-0.2 ms apiece on this runtime, and a pipeline that builds a few point clouds
 // per frame (the reference's example: twenty attribute vectors per loop) spent more time there than in its kernels.
 // A released buffer is tagged with an event recorded on the stream its owner used (no device-wide wait in a destructor —
-// round 2 called hipDeviceSynchronize() for every buffer a shared_vector dropped) and is handed out again only once that
-// event has completed; buffers are keyed by the device they were allocated on. At most 48 buffers / 2 GiB are kept.
+// round 2 called hipDeviceSynchronize() for every buffer a shared_vector dropped) AND on every other live DeviceQueue stream
+// of that device: a container is read by kernels of other queues too (a tree's queue searching a query cloud bound to another
+// queue, a registration reading both clouds), and those kernels are not behind the owner's event. Usually there is one queue
+// and one event; a program with q queues pays q events per released buffer, never a device-wide wait. The buffer is handed
+// out again only once all its events have completed; buffers are keyed by the device they were allocated on. At most 48
+// buffers / 2 GiB are kept. Streams the facade did not create (a raw stream handed to the C ABI with a container's pointer)
+// are the caller's to order against the container's lifetime.
 // (hipEventQuery is not capture-safe: do not create or destroy containers while a stream of the process is being captured.)
+struct QueueStreams {  // the live DeviceQueue streams of the process
+    static void add(hipStream_t s, int device) {
+        std::lock_guard<std::mutex> lock(mutex());
+        list().push_back({s, device});
+    }
+    static void remove(hipStream_t s) {
+        std::lock_guard<std::mutex> lock(mutex());
+        auto& l = list();
+        for (size_t i = 0; i < l.size(); ++i)
+            if (l[i].first == s) { l.erase(l.begin() + (std::ptrdiff_t)i); break; }
+    }
+    static std::vector<hipStream_t> others(hipStream_t own, int device) {
+        std::lock_guard<std::mutex> lock(mutex());
+        std::vector<hipStream_t> out;
+        for (const auto& e : list())
+            if (e.second == device && e.first != own) out.push_back(e.first);
+        return out;
+    }
+
+private:
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static std::vector<std::pair<hipStream_t, int>>& list() {
+        static auto* l = new std::vector<std::pair<hipStream_t, int>>();
+        return *l;
+    }
+};
 struct DeviceBufferCache {
     struct Entry {
         void* p;
         size_t bytes;
         int device;
-        hipEvent_t ready;  // nullptr: idle already
+        std::vector<hipEvent_t> ready;  // empty: idle already
     };
     static void* acquire(size_t bytes, size_t* got) {
         int dev = 0;
         (void)hipGetDevice(&dev);
-        hipEvent_t wait_for = nullptr;
+        std::vector<hipEvent_t> wait_for;
         void* taken = nullptr;
         {
             std::lock_guard<std::mutex> lock(mutex());
@@ -157,15 +188,15 @@ struct DeviceBufferCache {
             if (pick != pool.size()) {
                 taken = pool[pick].p;
                 *got = pool[pick].bytes;
-                wait_for = pool[pick].ready;
+                wait_for.swap(pool[pick].ready);
                 total() -= pool[pick].bytes;
                 pool.erase(pool.begin() + (std::ptrdiff_t)pick);
             }
         }
         if (taken) {
-            if (wait_for) {
-                (void)hipEventSynchronize(wait_for);
-                (void)hipEventDestroy(wait_for);
+            for (hipEvent_t ev : wait_for) {
+                (void)hipEventSynchronize(ev);
+                (void)hipEventDestroy(ev);
             }
             return taken;
         }
@@ -178,13 +209,22 @@ struct DeviceBufferCache {
     /// knows the device is done with the buffer (it synchronised).
     static void release(void* p, size_t bytes, hipStream_t stream, bool idle = false) {
         if (!p) return;
-        Entry e{p, bytes, 0, nullptr};
+        Entry e{p, bytes, 0, {}};
         (void)hipGetDevice(&e.device);
         if (!idle) {
-            if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(e.ready, stream) != hipSuccess) {
-                if (e.ready) (void)hipEventDestroy(e.ready);
-                e.ready = nullptr;
-                (void)hipDeviceSynchronize();  // no event to be had: wait, as hipFree would
+            std::vector<hipStream_t> streams = QueueStreams::others(stream, e.device);
+            streams.insert(streams.begin(), stream);
+            for (hipStream_t s : streams) {
+                hipEvent_t ev = nullptr;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
+                    if (ev) (void)hipEventDestroy(ev);
+                    for (hipEvent_t done : e.ready) (void)hipEventDestroy(done);
+                    e.ready.clear();
+                    (void)hipGetLastError();
+                    (void)hipDeviceSynchronize();  // no event to be had: wait, as hipFree would
+                    break;
+                }
+                e.ready.push_back(ev);
             }
         }
         std::vector<void*> drop;
@@ -208,10 +248,11 @@ struct DeviceBufferCache {
 
 private:
     static bool settle(Entry& e) {  // true once nothing on the device uses the buffer any more
-        if (e.ready == nullptr) return true;
-        if (hipEventQuery(e.ready) != hipSuccess) return false;
-        (void)hipEventDestroy(e.ready);
-        e.ready = nullptr;
+        while (!e.ready.empty()) {
+            if (hipEventQuery(e.ready.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
+            (void)hipEventDestroy(e.ready.back());
+            e.ready.pop_back();
+        }
         return true;
     }
     static std::mutex& mutex() { static std::mutex m; return m; }
@@ -231,7 +272,12 @@ struct DeviceQueue {
     struct StreamHolder {
         hipStream_t stream = nullptr;
         int device = 0;
-        ~StreamHolder() { if (stream) (void)hipStreamDestroy(stream); }
+        ~StreamHolder() {
+            if (stream) {
+                detail::QueueStreams::remove(stream);
+                (void)hipStreamDestroy(stream);
+            }
+        }
     };
     std::shared_ptr<StreamHolder> ptr;  // the reference exposes `ptr` (a sycl::queue); kept as the stream holder
 
@@ -241,6 +287,7 @@ struct DeviceQueue {
         ptr->device = device;
         throw_on_error(sp_set_device(device));
         hip_check(hipStreamCreateWithFlags(&ptr->stream, hipStreamNonBlocking), "hipStreamCreate");
+        detail::QueueStreams::add(ptr->stream, device);
     }
     hipStream_t stream() const { return ptr->stream; }
     void wait() const { hip_check(hipStreamSynchronize(ptr->stream), "hipStreamSynchronize"); }

@@ -14,6 +14,41 @@ void sp_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
 
 namespace sp {
 namespace {
+std::once_flag g_err_once;
+unsigned* g_err_host = nullptr;  // pinned, mapped
+unsigned* g_err_dev = nullptr;
+}  // namespace
+unsigned* device_error_word() {
+    std::call_once(g_err_once, [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+        *static_cast<volatile unsigned*>(h) = 0u;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_err_host = static_cast<unsigned*>(h);
+        g_err_dev = static_cast<unsigned*>(d);
+    });
+    return g_err_dev;
+}
+int launch_status() {
+    const int rc = hip_status(hipGetLastError());
+    if (g_err_host) {
+        const unsigned code = *static_cast<volatile unsigned*>(g_err_host);
+        if (code != 0u) {
+            *static_cast<volatile unsigned*>(g_err_host) = 0u;
+            sp_set_error(code == kDevErrLookback
+                             ? "a kernel of an EARLIER call gave up waiting for another workgroup's prefix (exclusive scan look-back): "
+                               "the offsets that call produced (compaction, removal, grid units) are wrong"
+                             : "a kernel of an earlier call reported a device-side failure");
+            return SP_ERR_HIP;
+        }
+    }
+    return rc;
+}
+}  // namespace sp
+
+namespace sp {
+namespace {
 struct PoolEntry {
     void* p; size_t bytes; int device; bool busy;
     std::vector<hipEvent_t> pending;  // work that may still touch p (scratch_release_after); empty: idle

@@ -312,12 +312,13 @@ size_t exclusive_scan_u32_workspace_bytes(size_t n) { return ((size_t)div_up(n ?
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, void* workspace, size_t workspace_bytes,
                        hipStream_t st) {
     if (n == 0) return total_out ? zero_async(total_out, sizeof(uint32_t), st) : SP_OK;
-    if (n >= (1ull << 32) - kRsTile || !workspace || workspace_bytes < exclusive_scan_u32_workspace_bytes(n))
-        return SP_ERR_INVALID_ARGUMENT;
+    // (the state word of a tile packs a 2-bit flag with a 30-bit running sum: the total must stay below 2^30, which n < 2^30
+    // guarantees for the flag arrays this is used on)
+    if (n >= (1ull << 30) || !workspace || workspace_bytes < exclusive_scan_u32_workspace_bytes(n)) return SP_ERR_INVALID_ARGUMENT;
     const unsigned tiles = div_up(n, (size_t)kRsTile);
-    unsigned* const ws = static_cast<unsigned*>(workspace);  // [0] ticket, [1] error, [64 ...] one state word per tile
+    unsigned* const ws = static_cast<unsigned*>(workspace);  // [0] ticket, [64 ...] one state word per tile
     if (zero_async(ws, (tiles + 64) * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
-    scan_kernel<<<tiles, kRsThreads, 0, st>>>(in, out, (unsigned)n, ws + 64, ws, ws + 1, total_out);
+    scan_kernel<<<tiles, kRsThreads, 0, st>>>(in, out, (unsigned)n, ws + 64, ws, device_error_word(), total_out);
     return launch_status();
 }
 

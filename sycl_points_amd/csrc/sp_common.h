@@ -17,8 +17,14 @@ inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? SP_OK : SP_ERR_HIP; }
 
-// Launch-time check: converts a failed launch into SP_ERR_HIP (no sync; graph-capture safe).
-inline int launch_status() { return hip_status(hipGetLastError()); }
+// Launch-time check: converts a failed launch into SP_ERR_HIP (no sync; graph-capture safe). It also reports, once, a
+// failure a KERNEL of an earlier call raised through device_error_word() — by then the call that hit it has returned
+// SP_OK, so the message names the kernel and says so (capi_common.hip).
+int launch_status();
+// One word of pinned host memory per process that kernels can write (system scope) when a "cannot happen" guard trips — a
+// look-back poll that ran out (sp_lookback.h) — so that it is not lost: nullptr when the allocation failed (no device).
+unsigned* device_error_word();
+constexpr unsigned kDevErrLookback = 1u;
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

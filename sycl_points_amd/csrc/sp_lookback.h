@@ -36,7 +36,10 @@ __device__ __forceinline__ unsigned lookback_exclusive(unsigned* __restrict__ st
                 if (word >> 30) break;
                 __builtin_amdgcn_s_sleep(1);
             } while (++spins < kLbSpinLimit);
-            if ((word >> 30) == 0u) { *error = 1u; word = kLbPrefix; }  // (never: the tile holds an earlier ticket)
+            if ((word >> 30) == 0u) {  // (never: the tile holds an earlier ticket) — reported through launch_status()
+                if (error) __hip_atomic_store(error, kDevErrLookback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                word = kLbPrefix;
+            }
         }
         const unsigned long long pm = __ballot((word >> 30) == 2u);  // nearest PREFIX in the window (lane 0 = nearest tile)
         const unsigned first = pm ? (unsigned)__builtin_ctzll(pm) : 63u;

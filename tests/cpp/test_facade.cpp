@@ -852,6 +852,43 @@ static void kdtree_radius_and_lazy_delete_on_the_hierarchy() {
     CHECK(same);
 }
 
+static void containers_read_from_another_queue() {
+    // A container's device buffer goes back to the buffer cache when the container dies, tagged with events on EVERY live queue's
+    // stream (core.hpp DeviceBufferCache): a search enqueued on the tree's queue may still be reading a query cloud that is bound
+    // to another queue. Twenty times over: search asynchronously on queue B, drop the query cloud at once, take a new container
+    // of the same size on queue A (the cache hands out the buffer just released) and overwrite it — the lists must be those of
+    // a search that was waited for.
+    sycl_utils::DeviceQueue qa(0), qb(0);
+    std::mt19937 gen(5);
+    PointCloudCPU tc, qc;
+    random_points(gen, tc, 200000, 10.0f);
+    random_points(gen, qc, 200000, 10.0f);
+    PointCloudShared target(qb, tc);
+    auto tree = alg::knn::KDTree::build(qb, target);
+    alg::knn::KNNResult ref;
+    {
+        PointCloudShared queries(qa, qc);
+        tree->knn_search_async(queries, 10, ref).wait_and_throw();
+    }
+    (void)ref.indices->host();
+    bool same = true;
+    for (int rep = 0; rep < 20 && same; ++rep) {
+        alg::knn::KNNResult r;
+        {
+            PointCloudShared queries(qa, qc);
+            (void)queries.points_device();
+            tree->knn_search_async(queries, 10, r);  // not waited for
+        }  // the query cloud's buffer is released here, the search may still be running on qb
+        shared_vector<PointType> scribble(qc.size(), PointType(1e6f, 1e6f, 1e6f, 1.0f), qa);
+        (void)scribble.device_data();  // same size: the buffer that was just released, overwritten on qa
+        qb.wait();
+        const auto& ri = r.indices->host();
+        const auto& ei = ref.indices->host();
+        for (size_t i = 0; same && i < ei.size(); i += 97) same = ri[i] == ei[i];
+    }
+    CHECK(same);
+}
+
 static void kdtree_self_knn_large_clouds() {
     // KDTree::knn_search on the tree's own cloud: from 32 k points on, a cloud of near-uniform density is answered by the grid's
     // lane-per-query selection, a clustered one (fullest cell over the limit) by the device-built hierarchy; both must give
@@ -888,6 +925,7 @@ int main() {
     queue.print_device_info();
     RUN(kdtree_grid_vs_bruteforce);
     RUN(kdtree_self_knn_large_clouds);
+    RUN(containers_read_from_another_queue);
     RUN(kdtree_backend_on_the_bundled_scan);
     RUN(kdtree_radius_and_lazy_delete_on_the_hierarchy);
     RUN(voxelgrid_known_answer);
