@@ -673,7 +673,39 @@ def stage_block(sp, _lib, torch):
         del res
     ms, runs = median_ms(torch, lambda: sp.GridKNN.build(P, points_per_cell=0.5), 5)
     out["grid_build_1M"] = {"ms": ms, "runs": runs, "note": "device build of the in-loop NN structure (synchronises once)"}
+    del grid
+    # KDTree::build + knn_search on a cloud the uniform grid is bad at (what the facade's KDTree::build answers from the
+    # device-built hierarchy, csrc/bvh.hip): three noisy planes, a slab and a fifth of the points in a 20 cm ball
+    NU = torch.from_numpy(nonuniform_cloud(n)).cuda()
+    ms_b, _ = median_ms(torch, lambda: sp.BVH.build(NU), 5)
+    bvh = sp.BVH.build(NU)
+    res = sp.KNNResult()
+    ms_self, runs = median_ms(torch, lambda: bvh.self_knn(20), 7)
+    ms_q, _ = median_ms(torch, lambda: bvh.knn_search_async(NU, 20, res), 5)
+    ms_u, _ = median_ms(torch, lambda: sp.BVH.build(P).self_knn(20), 3)
+    out["hierarchy_knn_k20_nonuniform_1M"] = {
+        "ms": ms_self, "runs": runs, "points_per_s": n / (ms_self * 1e-3), "bound": "HBM at 176 B per point (API layouts)",
+        "GBps": 176 * n / (ms_self * 1e-3) / 1e9, "frac_of_bound": 176 * n / (ms_self * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "ms_queries_in_cloud_order": ms_q, "ms_build": ms_b, "ms_build_plus_self_knn_uniform_1M": ms_u,
+        "cloud": "three noisy planes + slab + 200 k points in a 20 cm ball (tests/test_gpu_bvh.py::nonuniform_cloud)"}
     return out
+
+
+def nonuniform_cloud(n, seed=7):
+    """The non-uniform cloud of tests/test_gpu_bvh.py (density varies by more than four orders of magnitude)."""
+    rs = np.random.RandomState(seed)
+    m = n // 5
+    parts = []
+    for axis in range(3):
+        p = rs.uniform(-40, 40, (m, 3))
+        p[:, axis] = rs.normal(0.0, 0.01, m)
+        parts.append(p)
+    parts.append(rs.uniform(-40, 40, (n - 4 * m, 3)) * np.array([1.0, 1.0, 0.1]))
+    c = rs.normal(0.0, 1.0, (m, 3))
+    parts.append(np.array([3.0, -2.0, 1.0]) + 0.2 * c / np.maximum(np.linalg.norm(c, axis=1, keepdims=True), 1e-9) * rs.uniform(0, 1, (m, 1)) ** (1 / 3))
+    pts = np.ones((n, 4), np.float32)
+    pts[:, :3] = np.concatenate(parts)[:n].astype(np.float32)
+    return pts
 
 
 def kernel_times(sp, _lib, torch, args, reg, S, Tg, knn, prep, T_dev, T_ident, delta, n, sort_mode, reps=3):
