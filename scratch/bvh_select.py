@@ -60,8 +60,13 @@ for name, pts in clouds:
         b.knn_search_async(P, k, rq)
         sameq = torch.equal(qi0, rq.indices) and torch.equal(qd0, rq.distances) and torch.equal(qi0, ref.indices)
         tq_new = med(lambda: b.knn_search_async(P, k, rq))
+        b._set_option("bvh_sort_queries", 0)
+        b.knn_search_async(P, k, rq)
+        sameq = sameq and torch.equal(qi0, rq.indices) and torch.equal(qd0, rq.distances)
+        tq_unsorted = med(lambda: b.knn_search_async(P, k, rq))
+        b._set_option("bvh_sort_queries", 1)
         rr1 = b.radius_search(P, k, 0.3)
         samer = torch.equal(rr0.indices, rr1.indices) and torch.equal(rr0.distances, rr1.distances)
         tr_new = med(lambda: b.radius_search_async(P, k, 0.3, rq))
-        line.append(f"\n   k={k}: self {t_old:.3f} -> {t_new:.3f} ms identical {same} ({bad} rows differ); query-order {tq_old:.3f} -> {tq_new:.3f} ms identical {sameq}; radius 0.3 {tr_old:.3f} -> {tr_new:.3f} ms identical {samer}")
+        line.append(f"\n   k={k}: self {t_old:.3f} -> {t_new:.3f} ms identical {same} ({bad} rows differ); query-order {tq_old:.3f} -> heap {tq_unsorted:.3f} -> heap + sorted queries {tq_new:.3f} ms identical {sameq}; radius 0.3 {tr_old:.3f} -> {tr_new:.3f} ms identical {samer}")
     print("".join(line), flush=True)

@@ -32,7 +32,10 @@ struct sp_bvh {
     float4* node = nullptr;   // 4 x float4 per internal node (n - 1): (Llo, first) (Lhi, split) (Rlo, last) (Rhi, -)
     float4* obox = nullptr;   // 2 x float4 per internal node: its own box (re-tested when a stacked node is taken up again);
                               // lo.w = the lowest original index below the node (ties, see bvh_search_kernel)
+    unsigned* bbox = nullptr; // the cloud's bounding box as the build found it (6 order-preserving words): external queries are
+                              // sorted along the same curve before a search
     mutable sp::StreamSet streams;
+    int sort_queries = 1;     // external queries (>= 400 k of them) searched in the order of the tree's curve (0: as given)
     int self_heap = 1;        // searches for 2 <= k <= 21: bvh_heap_kernel (0: the sorted-insertion kernel alone; tests, comparisons)
 };
 
@@ -445,6 +448,35 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ node, const 
     return ok;
 }
 
+// External queries in the order of the tree's own curve: neighbouring lanes then walk the same subtrees and their node and
+// leaf loads share cache lines, as they do for the cloud's own points (1 M queries in arbitrary order, k = 20: 5.8 ms on the
+// non-uniform cloud against 3.4 ms for the same points in tree order). Key = the build's 48-bit Morton code of the transformed
+// query in the tree's bounding box (clamped; non-finite queries last), sorted by the library's radix sort.
+__global__ __launch_bounds__(kBlock) void bvh_query_key_kernel(const float4* __restrict__ queries, unsigned nq, Mat4Arg T_val,
+                                                               const float* __restrict__ T_dev, const unsigned* __restrict__ bbox,
+                                                               uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nq) return;
+    const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+    const float4 q4 = queries[i];
+    float v[3];
+    transform_point(T, q4.x, q4.y, q4.z, v[0], v[1], v[2]);
+    uint64_t key = kBvhInvalidKey;
+    if (isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2])) {  // (the key of bvh_key_kernel, clamped to the tree's box)
+        uint64_t c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = dec_f(bbox[a]), hi = dec_f(bbox[3 + a]);
+            const float ext = hi - lo;
+            const float t = ext > 0.0f ? (v[a] - lo) / ext * 65535.0f : 0.0f;
+            c[a] = (uint64_t)fminf(fmaxf(t, 0.0f), 65534.0f);
+        }
+        key = spread21(c[0]) | (spread21(c[1]) << 1) | (spread21(c[2]) << 2);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
 // MODE 0: the cloud's own points in Morton order (rows by original index); 1: external queries searched at T * q;
 // 2: the same within radius_sq (inclusive; KDTree::radius_search_async).
 template <int KCAP, int MODE>  // KCAP 5 (root + children only), 10 or 21
@@ -453,12 +485,14 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
                                                           const float4* __restrict__ queries, unsigned nq, int k, Mat4Arg T_val,
                                                           const float* __restrict__ T_dev, float radius_sq,
                                                           int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
-                                                          unsigned* __restrict__ todo, unsigned* __restrict__ todo_count) {
+                                                          unsigned* __restrict__ todo, unsigned* __restrict__ todo_count,
+                                                          const unsigned* __restrict__ order) {
     constexpr int kDeep = KCAP > 5 ? KCAP - 5 : 1;  // grandchildren (slots 5 ..)
     __shared__ unsigned st_node[kHeapStack][kBlock];
     __shared__ unsigned long long heap2[kDeep][kBlock];
-    const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
-    if (qi >= nq) return;  // no barrier below
+    const unsigned gi = blockIdx.x * kBlock + threadIdx.x;
+    if (gi >= nq) return;  // no barrier below
+    const unsigned qi = (MODE != 0 && order) ? order[gi] : gi;  // (external queries: in the order of the tree's curve)
     const unsigned lane = threadIdx.x;
     float qx, qy, qz;
     size_t o;
@@ -475,17 +509,38 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
     }
     const bool mine = isfinite(qx) && isfinite(qy) && isfinite(qz);  // false: handed on to bvh_search_kernel
 
-    // Where the walk starts to prune. Self-search: the k-th smallest distance to the Morton neighbours (when k of them are
-    // valid). Nothing is inserted for it, so no point can enter twice.
+    // Where the walk starts to prune: the k-th smallest distance to 33 consecutive points of the Morton order around the query
+    // (when k of them are valid) — the query's own neighbours on the curve for a self-search, for an external query those of
+    // the leaf a greedy descent (nearer child, no stack) ends in; a radius search starts from the radius if that is smaller.
+    // Nothing is inserted for it, so no point can enter twice. (Without it an external search ran twice as long as the
+    // self-search of the same points: the bound stays infinite until k candidates have been met.)
     float top = MODE == 2 ? radius_sq : FLT_MAX;
-    if (MODE == 0) {
+    if (mine) {
+        unsigned centre = qi;
+        if (MODE != 0) {
+            unsigned cur = 0;
+            for (;;) {
+                const float4 r0 = node[4 * (size_t)cur], r1 = node[4 * (size_t)cur + 1], r2 = node[4 * (size_t)cur + 2],
+                             r3 = node[4 * (size_t)cur + 3];
+                const unsigned first = __float_as_uint(r0.w), split = __float_as_uint(r1.w), last = __float_as_uint(r2.w);
+                const float dl = box_d2(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, qx, qy, qz);
+                const float dr = box_d2(r2.x, r2.y, r2.z, r3.x, r3.y, r3.z, qx, qy, qz);
+                const bool left = !(dr < dl);
+                const unsigned cf = left ? first : split + 1u, cl = left ? split : last;
+                if (cl - cf < (unsigned)kBvhLeaf) {
+                    centre = cf + ((cl - cf) >> 1);
+                    break;
+                }
+                cur = left ? split : split + 1u;
+            }
+        }
         unsigned wb[2 * kSelHalf + 1];
         unsigned hi = 0u, finite = 0u;
 #pragma unroll
         for (int u = 0; u <= 2 * kSelHalf; ++u) {
-            const long long pos = (long long)qi - kSelHalf + u;
+            const long long pos = (long long)centre - kSelHalf + u;
             const bool inside = pos >= 0 && pos < (long long)n;
-            const float4 p = spts[inside ? (size_t)pos : (size_t)qi];
+            const float4 p = spts[inside ? (size_t)pos : (size_t)centre];
             const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
             const unsigned b = __float_as_uint(d);
             const bool valid = inside && b <= 0x7f7fffffu;  // (d >= 0: the bit pattern orders like the value; NaN and inf are above)
@@ -503,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
             if (c >= (unsigned)k) hi = mid;
             else lo = mid + 1u;
         }
-        if (finite >= (unsigned)k) top = __uint_as_float(hi);
+        if (finite >= (unsigned)k) top = fminf(top, __uint_as_float(hi));
     }
 
     // slots below k start as (FLT_MAX, INT_MAX) — above every candidate, so the first k candidates replace them and the root is
@@ -663,16 +718,30 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         for (int i = 0; i < 16; ++i) Tv.m[i] = transT[i];
     const float* T_dev = transT_on_device ? transT : nullptr;
     const int kk = (int)k;
-    // (measured, scratch/bvh_select.py: the heap kernel wins wherever the device is full — 1 M queries, every k and mode, 1.2 to 3.5
-    // times — and for radius and self searches of any size; short external lists on a cloud that leaves SIMDs idle are
-    // latency-bound and 20-50 % faster on the other kernel's inline leaf scans)
-    const bool small_external = q && radius_sq < 0.0f && k <= 10 && nq < 256u * 1024u;
-    if (k >= 2 && k <= 21 && b->n > (size_t)kBvhLeaf && b->self_heap && !small_external) {
+    if (k >= (q ? 1u : 2u) && k <= 21 && b->n > (size_t)kBvhLeaf && b->self_heap) {
         // heap kernel; what it hands on (non-finite queries, a tree deeper than its stack) is finished by the sorted-insertion kernel
         unsigned* todo = nullptr;
         if (pooled_alloc(&todo, ((size_t)nq + 1) * sizeof(unsigned)) != hipSuccess) return SP_ERR_HIP;
         unsigned* const todo_count = todo + nq;
         int rc = zero_async(todo_count, 4, st);
+        // external queries: sorted along the tree's curve first (0.15 ms per million: 10-20 % off a search of a million queries, a
+        // loss below a few hundred thousand)
+        uint32_t* sortbuf = nullptr;
+        const unsigned* order = nullptr;
+        if (rc == SP_OK && q && nq >= 400000u && b->sort_queries) {
+            const size_t wsb = radix_sort_u64_workspace_bytes(nq);
+            const size_t words = 6 * (size_t)nq + (wsb + 3) / 4 + 2;
+            if (pooled_alloc(&sortbuf, words * sizeof(uint32_t)) != hipSuccess) { rc = SP_ERR_HIP; }
+            else {
+                uint64_t *ka = reinterpret_cast<uint64_t*>(sortbuf), *kb = ka + nq;
+                uint32_t *va = reinterpret_cast<uint32_t*>(kb + nq), *vb = va + nq;
+                void* const tmp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(vb + nq) + 7) & ~uintptr_t(7));
+                bvh_query_key_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(q, nq, Tv, T_dev, b->bbox, ka, va);
+                bool in_b = false;
+                rc = radix_sort_pairs_u64(ka, kb, va, vb, nq, 48, tmp, wsb, &in_b, st);
+                order = in_b ? vb : va;
+            }
+        }
         if (rc == SP_OK) {
             const unsigned g = div_up(nq, kBlock);
             const unsigned n32 = (unsigned)b->n;
@@ -681,17 +750,17 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
     do {                                                                                                                                \
         if (!q) {                                                                                                                       \
             bvh_heap_kernel<KC, 0><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
-                                                        todo_count);                                                                   \
+                                                        todo_count, order);                                                             \
             bvh_search_kernel<OLDK><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,    \
                                                          todo, todo_count);                                                            \
         } else if (r2 < 0.0f) {                                                                                                         \
             bvh_heap_kernel<KC, 1><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
-                                                        todo_count);                                                                   \
+                                                        todo_count, order);                                                             \
             bvh_search_kernel<OLDK><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,    \
                                                          todo, todo_count);                                                            \
         } else {                                                                                                                        \
             bvh_heap_kernel<KC, 2><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
-                                                        todo_count);                                                                   \
+                                                        todo_count, order);                                                             \
             bvh_search_kernel<OLDK, true><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out,    \
                                                                r2, todo, todo_count);                                                  \
         }                                                                                                                               \
@@ -706,6 +775,7 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         StreamSet used;
         used.note(st);
         pooled_free_after(todo, used);
+        if (sortbuf) pooled_free_after(sortbuf, used);
         return rc;
     }
     if (k == 1) launch_bvh<1>(b, q, nq, kk, Tv, T_dev, idx_out, d2_out, st, radius_sq);
@@ -723,6 +793,7 @@ extern "C" void sp_bvh_destroy(sp_bvh* b) {
     sp::pooled_free_after(b->pts, b->streams);
     sp::pooled_free_after(b->node, b->streams);
     sp::pooled_free_after(b->obox, b->streams);
+    sp::pooled_free_after(b->bbox, b->streams);
     delete b;
 }
 
@@ -739,12 +810,12 @@ extern "C" int sp_bvh_create(const float* points, size_t n, void* stream, sp_bvh
     b->n = n;
     b->streams.note(st);
     const size_t ni = n > 1 ? n - 1 : 1;  // internal nodes
-    ScratchBuf b_bbox, b_kin, b_kout, b_vin, b_vout, b_tmp, b_parent, b_lparent, b_tickets, b_cmin;
+    ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp, b_parent, b_lparent, b_tickets, b_cmin;
     const size_t tmp_bytes = radix_sort_u64_workspace_bytes(n ? n : 1);
     hipError_t e = pooled_alloc(&b->pts, (n ? n : 1) * sizeof(float4));
     if (e == hipSuccess) e = pooled_alloc(&b->node, 4 * ni * sizeof(float4));
     if (e == hipSuccess) e = pooled_alloc(&b->obox, 2 * ni * sizeof(float4));
-    if (e == hipSuccess) e = b_bbox.get(8 * sizeof(unsigned));
+    if (e == hipSuccess) e = pooled_alloc(&b->bbox, 8 * sizeof(unsigned));
     if (e == hipSuccess && n) e = b_kin.get(n * 8);
     if (e == hipSuccess && n) e = b_kout.get(n * 8);
     if (e == hipSuccess && n) e = b_vin.get(n * 4);
@@ -763,7 +834,7 @@ extern "C" int sp_bvh_create(const float* points, size_t n, void* stream, sp_bvh
     if (e != hipSuccess) return fail(hipGetErrorString(e));
     const float4* pts = reinterpret_cast<const float4*>(points);
     if (n) {
-        unsigned* const bbox = b_bbox.as<unsigned>();
+        unsigned* const bbox = b->bbox;
         uint64_t *kin = b_kin.as<uint64_t>(), *kout = b_kout.as<uint64_t>();
         unsigned *vin = b_vin.as<unsigned>(), *vout = b_vout.as<unsigned>();
         bvh_bbox_init_kernel<<<1, 64, 0, st>>>(bbox);
@@ -787,8 +858,10 @@ extern "C" int sp_bvh_create(const float* points, size_t n, void* stream, sp_bvh
 }
 
 extern "C" int sp_internal_bvh_option(sp_bvh* b, int option, int value) {
-    if (!b || option != SP_INTERNAL_BVH_SELF_HEAP) return SP_ERR_INVALID_ARGUMENT;
-    b->self_heap = value;
+    if (!b) return SP_ERR_INVALID_ARGUMENT;
+    if (option == SP_INTERNAL_BVH_SELF_HEAP) b->self_heap = value;
+    else if (option == SP_INTERNAL_BVH_SORT_QUERIES) b->sort_queries = value;
+    else return SP_ERR_INVALID_ARGUMENT;
     return SP_OK;
 }
 

@@ -35,7 +35,10 @@ enum {
     SP_INTERNAL_FUSED_PERSISTENT_FROM = 5,
     /* sp_bvh: searches for 2 <= k <= 21 with the lane's k best in a heap (1, default) or by the sorted-insertion kernel
      * that serves every other search (0). Same lists either way. */
-    SP_INTERNAL_BVH_SELF_HEAP = 6
+    SP_INTERNAL_BVH_SELF_HEAP = 6,
+    /* sp_bvh: external queries (16 k or more) are searched in the order of the tree's Morton curve (1, default) or as given (0).
+     * Same lists either way. */
+    SP_INTERNAL_BVH_SORT_QUERIES = 7
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);

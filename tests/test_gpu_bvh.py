@@ -133,7 +133,7 @@ def test_bvh_raw_lidar_scan_and_nonuniform_1m(sp, orc):
 
 
 def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
-    """Lists of 2..21 entries come from bvh_heap_kernel (the lane's k best in a 4-ary heap: root and children on registers,
+    """Lists of 1..21 entries (2..21 for the cloud's own points) come from bvh_heap_kernel (the lane's k best in a 4-ary heap: root and children on registers,
     grandchildren in LDS), everything else — and whatever that kernel hands on — from the sorted-insertion kernel. Both must
     give the lists of knn_search_bruteforce (knn/bruteforce.hpp:46-92: (distance, index)-lexicographic), bit for bit: on a
     cloud with exact duplicates (more copies than k), non-finite points and queries, in the three modes (own points, external
@@ -163,6 +163,9 @@ def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
         assert torch.equal(ai, c.indices[:rows]) and torch.equal(ad, c.distances[:rows])
         return c
 
+    r1 = both(lambda: b.knn_search(Q, 1, T))  # (k = 1: the heap is its root)
+    bi, bd = orc.knn_bruteforce(qT, pts, 1)
+    assert np.array_equal(r1.indices.cpu().numpy(), bi) and np.array_equal(r1.distances.cpu().numpy(), bd)
     for k in (2, 5, 6, 10, 11, 20, 21):
         s = both(lambda: b.self_knn(k))
         r = both(lambda: b.knn_search(Q, k, T))
@@ -173,12 +176,19 @@ def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
             assert np.array_equal(r.indices.cpu().numpy(), qi) and np.array_equal(r.distances.cpu().numpy(), qd)
         both(lambda: b.radius_search(Q, k, 0.25, T))
         both(lambda: b.radius_search(P, k, 0.02))  # most balls hold fewer than k points: rows end in (-1, FLT_MAX)
-    # many external queries: the heap kernel serves short lists too
-    big_q = dev(np.tile(q, (60, 1)))
-    for k in (3, 10):
+    # many external queries (400 k or more) are searched in the order of the tree's curve: rows still by query
+    big_q = dev(np.tile(q, (90, 1)))
+    for k in (1, 3, 10):
         r = both(lambda: b.knn_search(big_q, k, T))
         small = b.knn_search(Q, k, T)
         assert torch.equal(r.indices[:len(q)], small.indices) and torch.equal(r.distances[-len(q):], small.distances)
+        b._set_option("bvh_sort_queries", 0)
+        u = b.knn_search(big_q, k, T)
+        b._set_option("bvh_sort_queries", 1)
+        assert torch.equal(r.indices, u.indices) and torch.equal(r.distances, u.distances)
+    rr = both(lambda: b.radius_search(big_q, 8, 0.25, T))
+    rs_small = b.radius_search(Q, 8, 0.25, T)
+    assert torch.equal(rr.indices[:len(q)], rs_small.indices) and torch.equal(rr.distances[:len(q)], rs_small.distances)
     # after a lazy delete (removed points stay in their leaves with NaN coordinates)
     keep = rs.rand(len(pts)) > 0.3
     new_idx = (np.cumsum(keep) - 1).astype(np.int32)
