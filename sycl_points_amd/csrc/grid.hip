@@ -726,10 +726,13 @@ __global__ __launch_bounds__(kWave) void grid_search_select_kernel(const float4*
                                                                    const float4* __restrict__ queries, unsigned nq, int k,
                                                                    Mat4Arg T_val, const float* __restrict__ T_dev,
                                                                    int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
-                                                                   unsigned* __restrict__ todo, unsigned* __restrict__ todo_count) {
+                                                                   unsigned* __restrict__ todo, unsigned* __restrict__ todo_count,
+                                                                   const unsigned* __restrict__ order = nullptr) {
     __shared__ unsigned long long l_key8[kSelCand / 8][kWave];
     __shared__ int l_pos[kSelList][kWave];
-    const unsigned qi = blockIdx.x * kWave + threadIdx.x;
+    const unsigned gi = blockIdx.x * kWave + threadIdx.x;
+    // (order: the queries sorted by cell, grid_query_cell_kernel — an idle lane of the last wave is number nq, as without it)
+    const unsigned qi = (order && gi < nq) ? order[gi] : gi;
     const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
     const float4 q4 = queries[min(qi, nq - 1u)];
     float4 q;
@@ -1291,9 +1294,11 @@ __global__ __launch_bounds__(kBlock) void grid_search_k1_kernel(const float4* __
                                                                 const float4* __restrict__ queries, unsigned nq,
                                                                 Mat4Arg T_val, const float* __restrict__ T_dev,
                                                                 int32_t* __restrict__ idx_out,
-                                                                float* __restrict__ d2_out) {
-    const unsigned qi = blockIdx.x * kBlock + threadIdx.x;
-    if (qi >= nq) return;
+                                                                float* __restrict__ d2_out,
+                                                                const unsigned* __restrict__ order = nullptr) {
+    const unsigned gi = blockIdx.x * kBlock + threadIdx.x;
+    if (gi >= nq) return;
+    const unsigned qi = order ? order[gi] : gi;
     const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
     const float4 q4 = queries[qi];
     float qx, qy, qz;
@@ -1301,6 +1306,27 @@ __global__ __launch_bounds__(kBlock) void grid_search_k1_kernel(const float4* __
     const Nearest nn = grid_nn1_auto(pts, start, g, qx, qy, qz);
     idx_out[qi] = nn.idx;
     d2_out[qi] = nn.d2;
+}
+
+// External queries in cell order (1 M queries in arbitrary order, k = 20: 2.1 ms against 0.68 ms for the same queries in cell
+// order): key = the cell the transformed query falls into (non-finite queries last), sorted by the library's radix sort.
+__global__ __launch_bounds__(kBlock) void grid_query_cell_kernel(const float4* __restrict__ queries, unsigned nq, GridDesc g,
+                                                                 Mat4Arg T_val, const float* __restrict__ T_dev,
+                                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                                 uint32_t* __restrict__ count) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) *count = nq;
+    if (i >= nq) return;
+    const Rigid T = load_rigid_colmajor(T_dev ? T_dev : T_val.m);
+    const float4 q4 = queries[i];
+    float qx, qy, qz;
+    transform_point(T, q4.x, q4.y, q4.z, qx, qy, qz);
+    unsigned key = (unsigned)g.nx * g.ny * g.nz;
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz))
+        key = ((unsigned)cell_coord(qz, g.oz, g.inv_h, g.nz) * g.ny + cell_coord(qy, g.oy, g.inv_h, g.ny)) * g.nx +
+              cell_coord(qx, g.ox, g.inv_h, g.nx);
+    keys[i] = key;
+    vals[i] = i;
 }
 
 template <int KCAP>
@@ -1311,10 +1337,31 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
     if (T && !T_dev)
         for (int i = 0; i < 16; ++i) tv.m[i] = T[i];
     const GridDesc g = grid_desc(gr);
+    // many queries: in cell order (0.1 ms per million for the sort; a loss below a few hundred thousand)
+    uint32_t* sortbuf = nullptr;
+    const unsigned* order = nullptr;
+    unsigned* order_count = nullptr;
+    struct Release {
+        uint32_t*& p; hipStream_t st;
+        ~Release() { if (p) { StreamSet used; used.note(st); pooled_free_after(p, used); } }
+    } release{sortbuf, st};
+    if (nq >= 400000 && gr->sort_queries && gr->n != 0 && gr->ncells < 0xffffffffull) {
+        const size_t wsb = radix_sort_u32_workspace_bytes(nq);
+        if (pooled_alloc(&sortbuf, (4 * nq + 4) * sizeof(uint32_t) + wsb) != hipSuccess) return SP_ERR_HIP;
+        uint32_t *ka = sortbuf, *kb = ka + nq, *va = kb + nq, *vb = va + nq;
+        order_count = vb + nq;
+        grid_query_cell_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(reinterpret_cast<const float4*>(q), (unsigned)nq, g, tv,
+                                                                     T_dev ? T : nullptr, ka, va, order_count);
+        unsigned bits = 1;
+        while ((1ull << bits) <= (unsigned long long)gr->ncells && bits < 32) ++bits;  // (the key `ncells` itself must fit)
+        bool in_b = false;
+        if (radix_sort_pairs_u32(ka, kb, va, vb, nq, bits, order_count + 4, wsb, &in_b, st) != SP_OK) return SP_ERR_HIP;
+        order = in_b ? vb : va;
+    }
     if (KCAP == 1) {
         grid_search_k1_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g,
                                                                       reinterpret_cast<const float4*>(q), (unsigned)nq,
-                                                                      tv, T_dev ? T : nullptr, idx, d2);
+                                                                      tv, T_dev ? T : nullptr, idx, d2, order);
         return launch_status();
     }
     if (k > 10 && k <= 24 && gr->n != 0 && (gr->self_knn_mode == 0 || gr->self_knn_mode == 3)) {
@@ -1329,7 +1376,7 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
         if (rc == SP_OK) {
             grid_search_select_kernel<<<div_up(nq, kWave), kWave, 0, st>>>(gr->d_pts, gr->d_start, g,
                                                                         reinterpret_cast<const float4*>(q), (unsigned)nq, (int)k, tv,
-                                                                        T_dev ? T : nullptr, idx, d2, todo, todo_count);
+                                                                        T_dev ? T : nullptr, idx, d2, todo, todo_count, order);
             TileOut lo;
             lo.knn_idx = idx; lo.knn_d2 = d2; lo.covs = nullptr; lo.normals = nullptr;
             lo.todo = todo; lo.todo_count = todo_count; lo.pos_lo = 0u; lo.pos_hi = 0xffffffffu;
@@ -1344,7 +1391,7 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
     }
     grid_search_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g,
                                                                   reinterpret_cast<const float4*>(q), (unsigned)nq,
-                                                                  (int)k, tv, T_dev ? T : nullptr, idx, d2);
+                                                                  (int)k, tv, T_dev ? T : nullptr, idx, d2, order, order_count);
     return launch_status();
 }
 
@@ -1705,8 +1752,10 @@ extern "C" int sp_grid_radius_search(const sp_grid* grid, const float* queries, 
 
 // Per-handle tuning switch (sp_internal.h): exported for tests/ and scratch/ only.
 extern "C" int sp_internal_grid_option(sp_grid* grid, int option, int value) {
-    if (!grid || option != SP_INTERNAL_SELF_KNN_MODE) return SP_ERR_INVALID_ARGUMENT;
-    grid->self_knn_mode = value;
+    if (!grid) return SP_ERR_INVALID_ARGUMENT;
+    if (option == SP_INTERNAL_SELF_KNN_MODE) grid->self_knn_mode = value;
+    else if (option == SP_INTERNAL_GRID_SORT_QUERIES) grid->sort_queries = value;
+    else return SP_ERR_INVALID_ARGUMENT;
     return SP_OK;
 }
 

@@ -18,6 +18,7 @@ struct sp_grid {
     // tuning switch (sp_internal.h): self-kNN kernel — 0 chosen by k (lane per point for k <= 10, wave-cooperative above),
     // 1 LDS-tile kernel (k <= 10), 2 wave-cooperative kernel. Results are identical.
     int self_knn_mode = 0;
+    int sort_queries = 1;  // external queries (400 k or more) are searched in cell order (sp_internal.h; 0: as given)
     mutable sp::StreamSet streams;  // every stream the arrays have been handed to (sp_grid_destroy tags the pool entries)
 };
 

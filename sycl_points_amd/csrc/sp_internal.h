@@ -38,7 +38,9 @@ enum {
     SP_INTERNAL_BVH_SELF_HEAP = 6,
     /* sp_bvh: external queries (16 k or more) are searched in the order of the tree's Morton curve (1, default) or as given (0).
      * Same lists either way. */
-    SP_INTERNAL_BVH_SORT_QUERIES = 7
+    SP_INTERNAL_BVH_SORT_QUERIES = 7,
+    /* sp_grid: the same for sp_grid_search / sp_grid_radius_search: in cell order (1, default) or as given (0). */
+    SP_INTERNAL_GRID_SORT_QUERIES = 8
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);

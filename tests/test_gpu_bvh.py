@@ -204,6 +204,37 @@ def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
         assert np.array_equal(s.indices.cpu().numpy()[:n_kept], si) and np.array_equal(s.distances.cpu().numpy()[:n_kept], sd)
 
 
+def test_gridknn_sorts_many_external_queries_by_cell(sp, orc):
+    """sp_grid_search / sp_grid_radius_search with 400 k queries or more search them in cell order (a key per query, the
+    library's radix sort, rows still by query number): the lists must be those of the unsorted search and of brute force —
+    for k = 1 (its own kernel), k <= 10 (ring walk), k = 20 (selection inside 27 cells + list of the unproven), with a query
+    transform, non-finite queries and queries outside the grid."""
+    g0 = orc.rng(77)
+    pts = g0.uniform_points(50_000, 5.0)
+    q = g0.uniform_points(6000, 5.6)  # some outside the cloud's box
+    q[11, 1] = np.nan
+    q[12, 0] = np.inf
+    T = orc.se3_exp(np.array([0.02, -0.03, 0.01, 0.1, -0.05, 0.08], np.float32))
+    qT = orc.transform_points(q, T)
+    Q, big = dev(q), dev(np.tile(q, (70, 1)))
+    for ppc, ks in ((2.0, (1, 5)), (6.0, (10, 20))):
+        grid = sp.GridKNN.build(dev(pts), points_per_cell=ppc)
+        for k in ks:
+            r = grid.knn_search(big, k, T)
+            grid._set_option("grid_sort_queries", 0)
+            u = grid.knn_search(big, k, T)
+            grid._set_option("grid_sort_queries", 1)
+            assert torch.equal(r.indices, u.indices) and torch.equal(r.distances, u.distances)
+            bi, bd = orc.knn_bruteforce(qT, pts, k)
+            for rows in (slice(0, len(q)), slice(-len(q), None)):
+                assert np.array_equal(r.indices[rows].cpu().numpy(), bi) and np.array_equal(r.distances[rows].cpu().numpy(), bd)
+        rr = grid.radius_search(big, 6, 0.2, T)
+        grid._set_option("grid_sort_queries", 0)
+        ru = grid.radius_search(big, 6, 0.2, T)
+        grid._set_option("grid_sort_queries", 1)
+        assert torch.equal(rr.indices, ru.indices) and torch.equal(rr.distances, ru.distances)
+
+
 def test_bvh_radius_search_and_lazy_delete_match_the_oracle(sp, orc):
     """KDTree::radius_search_async and remove_nodes_by_flags (kdtree.hpp:574-765) on the device-built hierarchy
     (sp_bvh_radius_search / sp_bvh_remove_by_flags) against the oracle's KD-tree with the shapes of the reference's own tests
