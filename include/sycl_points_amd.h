@@ -99,7 +99,9 @@ int sp_grid_order(const sp_grid* grid, uint32_t* idx_out, void* stream);
 /* KNNBase::knn_search_async on the grid (k <= 20). For k > 10 the call takes nq + 1 words of scratch from the library's
  * buffer pool for its duration (the list of queries a first, 27-cell pass could not prove): inside a stream capture that
  * works once the pool holds such a buffer, i.e. after one eager call of the same size. Queries in the cell order of any grid
- * (sp_grid_order) are served three times faster than in random order (their candidates share cache lines). */
+ * (sp_grid_order) are served three times faster than in random order (their candidates share cache lines); 400 k queries or
+ * more are therefore sorted by cell first (a key per query and the library's radix sort, scratch from the pool as above; rows
+ * still by query number). */
 int sp_grid_search(const sp_grid* grid, const float* queries, size_t nq, size_t k, const float* transT,
                    int transT_on_device, int32_t* idx_out, float* d2_out, void* stream);
 /* The grid's counterpart of KDTree::radius_search_async (knn/kdtree.hpp:251-280, 574-719): the max_k nearest target
@@ -172,7 +174,8 @@ int sp_cov_update_plane(const float* covs, size_t n, float* covs_out, void* stre
  * (GridKNN is the faster structure on near-uniform clouds, sp_grid_*). sp_bvh_create allocates and synchronises.
  *   sp_bvh_search    exact kNN, 1 <= k <= 32, queries searched at transT * q (NULL: identity; host or device matrix as for
  *                    sp_kdtree_search); rows as KNNResult (knn/result.hpp:12-34): ascending, -1 / FLT_MAX padded; ties to the
- *                    lowest index — bit-identical to sp_knn_bruteforce.
+ *                    lowest index — bit-identical to sp_knn_bruteforce. The queries may come in any order (400 k or more are
+ *                    searched along the tree's own curve, rows still by query number; scratch from the library's pool).
  *   sp_bvh_self_knn  the cloud's own points as queries (row i = neighbours of point i, itself first), walked in tree order. */
 typedef struct sp_bvh sp_bvh;
 int sp_bvh_create(const float* points, size_t n, void* stream, sp_bvh** out);
