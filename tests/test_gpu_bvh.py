@@ -130,6 +130,14 @@ def test_bvh_raw_lidar_scan_and_nonuniform_1m(sp, orc):
     assert same.mean() > 0.99
     q = B.knn_search(dev(big[sel]), 20)  # the query path (arbitrary query order) gives the same rows as the self path
     assert torch.equal(q.indices, s.indices[dev(sel)]) and torch.equal(q.distances, s.distances[dev(sel)])
+    # every row against the sorted-insertion kernel: a dozen of this cloud's queries (Morton neighbourhoods across a jump of the
+    # curve) fill the heap kernel's LDS stack and carry on in its HBM part
+    B._set_option("bvh_self_heap", 0)
+    s0 = B.self_knn(20)
+    B._set_option("bvh_self_heap", 1)
+    assert torch.equal(s0.indices, s.indices) and torch.equal(s0.distances, s.distances)
+    qa = B.knn_search(dev(big), 20)  # 1 M external queries: sorted along the tree's curve, rows by query
+    assert torch.equal(qa.indices, s.indices) and torch.equal(qa.distances, s.distances)
 
 
 def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
