@@ -36,7 +36,7 @@ struct sp_bvh {
                               // sorted along the same curve before a search
     mutable sp::StreamSet streams;
     int sort_queries = 1;     // external queries (>= 400 k of them) searched in the order of the tree's curve (0: as given)
-    int self_heap = 1;        // searches for 2 <= k <= 21: bvh_heap_kernel (0: the sorted-insertion kernel alone; tests, comparisons)
+    int self_heap = 1;        // searches by bvh_heap_kernel (0: the sorted-insertion kernel alone; tests, comparisons)
 };
 
 namespace sp {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Searches for lists of 2..21 entries with the running k best of a lane in a 4-ary MAX-HEAP of (distance, index) keys: the
+// Searches (lists of up to 32 entries) with the running k best of a lane in a 4-ary MAX-HEAP of (distance, index) keys: the
 // root and its four children on registers, the sixteen grandchildren in the lane's LDS column. Replacing the root costs two
 // sift steps (the largest of four, twice) whatever k is, where the sorted list of bvh_search_kernel is a k-step select chain
 // that the whole wave walks whenever ANY of its 64 lanes accepts a candidate — with lanes in different leaves that is
@@ -488,7 +488,10 @@ __global__ __launch_bounds__(kBlock) void bvh_query_key_kernel(const float4* __r
 
 // MODE 0: the cloud's own points in Morton order (rows by original index); 1: external queries searched at T * q;
 // 2: the same within radius_sq (inclusive; KDTree::radius_search_async).
-template <int KCAP, int MODE>  // KCAP 5 (root + children only), 10 or 21
+// KCAP 5 (root + four children, no LDS level), 10, 21 (sixteen grandchildren) or 32 (EIGHT children on registers and up to four
+// grandchildren below each: 23 slots in LDS, two workgroups per CU — still two sift steps; the sorted list at k = 24 runs
+// 12 ms per 1 M queries on 190 registers where this runs 3)
+template <int KCAP, int MODE>
 __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restrict__ node, const float4* __restrict__ obox,
                                                           const float4* __restrict__ spts, unsigned n,
                                                           const float4* __restrict__ queries, unsigned nq, int k, Mat4Arg T_val,
@@ -496,7 +499,8 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
                                                           int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
                                                           unsigned* __restrict__ todo, unsigned* __restrict__ todo_count,
                                                           const unsigned* __restrict__ order, unsigned* __restrict__ deep) {
-    constexpr int kDeep = KCAP > 5 ? KCAP - 5 : 1;  // grandchildren (slots 5 ..)
+    constexpr int F1 = KCAP > 21 ? 8 : 4;                     // children of the root (slots 1 .. F1)
+    constexpr int kDeep = KCAP > 1 + F1 ? KCAP - 1 - F1 : 1;  // grandchildren (slots 1 + F1 ..)
     __shared__ unsigned st_node[kHeapStack][kBlock];
     __shared__ unsigned long long heap2[kDeep][kBlock];
     const unsigned gi = blockIdx.x * kBlock + threadIdx.x;
@@ -572,11 +576,12 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
 
     // slots below k start as (FLT_MAX, INT_MAX) — above every candidate, so the first k candidates replace them and the root is
     // a real key from then on; slots from k on hold 0, which is never the largest child and never moves
-    unsigned long long h0 = kNoCand, h1 = 1 < k ? kNoCand : 0ull, h2 = 2 < k ? kNoCand : 0ull, h3 = 3 < k ? kNoCand : 0ull,
-                       h4 = 4 < k ? kNoCand : 0ull;
-    if (KCAP > 5)
+    unsigned long long h0 = kNoCand, hh[F1];
 #pragma unroll
-        for (int j = 0; j < kDeep; ++j) heap2[j][lane] = 5 + j < k ? kNoCand : 0ull;
+    for (int j = 0; j < F1; ++j) hh[j] = 1 + j < k ? kNoCand : 0ull;
+    if (KCAP > 1 + F1)
+#pragma unroll
+        for (int j = 0; j < kDeep; ++j) heap2[j][lane] = 1 + F1 + j < k ? kNoCand : 0ull;
     float bound = top;
     int bound_idx = 0x7fffffff;
     const bool ok = bvh_walk<kHeapStack>(node, obox, st_node, deep + gi, nq, lane, qx, qy, qz, bound, bound_idx, mine, [&](unsigned first, unsigned last) {
@@ -592,16 +597,16 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
                 // (a removed / non-finite point: NaN, the comparison with `top` fails)
                 if (b + s <= last && d <= top && nk < h0) {
                     // the root leaves; the newcomer sinks from its place past every larger child
-                    unsigned long long m = h1;
-                    int mi = 1;
-                    if (h2 > m) { m = h2; mi = 2; }
-                    if (h3 > m) { m = h3; mi = 3; }
-                    if (h4 > m) { m = h4; mi = 4; }
+                    unsigned long long m = hh[0];
+                    int mi = 0;
+#pragma unroll
+                    for (int j = 1; j < F1; ++j)
+                        if (hh[j] > m) { m = hh[j]; mi = j; }
                     if (m > nk) {
                         h0 = m;
-                        unsigned long long put = nk;  // what slot mi receives
-                        if (KCAP > 5) {
-                            const int base = 4 * (mi - 1);
+                        unsigned long long put = nk;  // what child mi receives
+                        if (KCAP > 1 + F1) {
+                            const int base = 4 * mi;
                             unsigned long long c2[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) c2[j] = base + j < kDeep ? heap2[min(base + j, kDeep - 1)][lane] : 0ull;
@@ -615,10 +620,8 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
                                 put = m2;
                             }
                         }
-                        h1 = mi == 1 ? put : h1;
-                        h2 = mi == 2 ? put : h2;
-                        h3 = mi == 3 ? put : h3;
-                        h4 = mi == 4 ? put : h4;
+#pragma unroll
+                        for (int j = 0; j < F1; ++j) hh[j] = mi == j ? put : hh[j];
                     } else {
                         h0 = nk;
                     }
@@ -638,12 +641,11 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
     // the k keys ranked by counting (equal keys can only be empty slots: they keep their order)
     unsigned long long key[KCAP];
     key[0] = h0;
-    if (KCAP > 1) key[1] = h1;
-    if (KCAP > 2) key[2] = h2;
-    if (KCAP > 3) key[3] = h3;
-    if (KCAP > 4) key[4] = h4;
 #pragma unroll
-    for (int i = 5; i < KCAP; ++i) key[i] = heap2[i - 5][lane];
+    for (int j = 0; j < F1; ++j)
+        if (1 + j < KCAP) key[1 + j] = hh[j];
+#pragma unroll
+    for (int i = 1 + F1; i < KCAP; ++i) key[i] = heap2[i - 1 - F1][lane];
 #pragma unroll
     for (int i = 0; i < KCAP; ++i) {
         if (i < k) {
@@ -727,7 +729,7 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         for (int i = 0; i < 16; ++i) Tv.m[i] = transT[i];
     const float* T_dev = transT_on_device ? transT : nullptr;
     const int kk = (int)k;
-    if (k >= (q ? 1u : 2u) && k <= 21 && b->n > (size_t)kBvhLeaf && b->self_heap) {
+    if (k >= (q ? 1u : 2u) && b->n > (size_t)kBvhLeaf && b->self_heap) {
         // heap kernel; what it hands on (non-finite queries, a tree deeper than its stack) is finished by the sorted-insertion kernel
         unsigned* todo = nullptr;
         // (+ the deep part of the walk's stack: [slot][query], written by the few lanes that get there)
@@ -779,7 +781,8 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
             if (k <= 5) SP_BVH_HEAP(5, 10);
             else if (k <= 10) SP_BVH_HEAP(10, 10);
             else if (k <= 20) SP_BVH_HEAP(21, 20);
-            else SP_BVH_HEAP(21, 32);
+            else if (k == 21) SP_BVH_HEAP(21, 32);
+            else SP_BVH_HEAP(32, 32);
 #undef SP_BVH_HEAP
             rc = launch_status();
         }

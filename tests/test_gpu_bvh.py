@@ -141,12 +141,12 @@ def test_bvh_raw_lidar_scan_and_nonuniform_1m(sp, orc):
 
 
 def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
-    """Lists of 1..21 entries (2..21 for the cloud's own points) come from bvh_heap_kernel (the lane's k best in a 4-ary heap: root and children on registers,
+    """Lists of 1..32 entries (2..32 for the cloud's own points) come from bvh_heap_kernel (the lane's k best in a 4-ary heap: root and children on registers,
     grandchildren in LDS), everything else — and whatever that kernel hands on — from the sorted-insertion kernel. Both must
     give the lists of knn_search_bruteforce (knn/bruteforce.hpp:46-92: (distance, index)-lexicographic), bit for bit: on a
     cloud with exact duplicates (more copies than k), non-finite points and queries, in the three modes (own points, external
-    queries with a transform, radius search), for every heap shape (k <= 5: no LDS level; k = 6..10; k = 11..21 with 21 = the
-    full third level), before and after a lazy delete, and with enough queries (300 k) for the heap kernel to be the one that
+    queries with a transform, radius search), for every heap shape (k <= 5: no LDS level; k = 6..10; k = 11..21 with 21 = every
+    slot of the second level; k = 22..32: eight children on registers), before and after a lazy delete, and with enough queries (300 k) for the heap kernel to be the one that
     is dispatched for short external lists too."""
     rs = np.random.RandomState(3)
     pts = nonuniform_cloud(40_000, seed=11)
@@ -174,7 +174,7 @@ def test_bvh_heap_kernel_equals_the_sorted_insertion_kernel(sp, orc):
     r1 = both(lambda: b.knn_search(Q, 1, T))  # (k = 1: the heap is its root)
     bi, bd = orc.knn_bruteforce(qT, pts, 1)
     assert np.array_equal(r1.indices.cpu().numpy(), bi) and np.array_equal(r1.distances.cpu().numpy(), bd)
-    for k in (2, 5, 6, 10, 11, 20, 21):
+    for k in (2, 5, 6, 10, 11, 20, 21, 22, 27, 32):
         s = both(lambda: b.self_knn(k))
         r = both(lambda: b.knn_search(Q, k, T))
         if k in (2, 6, 20):  # brute force on the host is the slow part (and the reference's arrays end at k = 20)
