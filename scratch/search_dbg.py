@@ -1,5 +1,5 @@
 """where a searching launch spends its time: later search stages inside gicp_align_kernel, launch by launch
-(dev build: bash scratch/devbuild.sh -DSP_SEARCH_DBG). usage: search_dbg.py [world]  (emulated rank 0 of `world` ranks)"""
+(git apply scratch/experiments/r04_search_stage_stamps.patch; bash scratch/devbuild.sh -DSP_SEARCH_DBG). usage: search_dbg.py [world]  (emulated rank 0 of `world` ranks)"""
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
