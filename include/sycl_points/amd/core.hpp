@@ -487,6 +487,8 @@ public:
     void reserve(size_t n) { host_.reserve(n); }
     void clear() { size_override_ = false; dev_dirty_ = false; host_.clear(); touch(); }
     void assign(size_t n, const T& v) { size_override_ = false; dev_dirty_ = false; host_.assign(n, v); touch(); }
+    /// the n elements at p become the contents (one pass over fresh memory; resize + copy would touch every page twice)
+    void assign(const T* p, size_t n) { size_override_ = false; dev_dirty_ = false; host_.assign(p, p + n); touch(); }
     void push_back(const T& v) { sync_host(); host_.push_back(v); touch(); }
     template <class... A> void emplace_back(A&&... a) { sync_host(); host_.emplace_back(std::forward<A>(a)...); touch(); }
     T& operator[](size_t i) { sync_host(); touch(); return host_[i]; }
@@ -812,8 +814,8 @@ private:
     }
     template <class S, class V>
     static void copy_in(S& dst, const V& src) {
-        dst.resize(src.size());
-        if (!src.empty()) std::memcpy(static_cast<void*>(dst.data()), static_cast<const void*>(src.data()), src.size() * sizeof(src[0]));
+        static_assert(sizeof(dst[0]) == sizeof(src[0]), "same element layout");
+        dst.assign(reinterpret_cast<const typename S::value_type*>(src.data()), src.size());
     }
 };
 
