@@ -177,10 +177,7 @@ public:
             (void)hipStreamSynchronize(queue.stream());
             (void)hipFree(self_grid_ws_);
         }
-        if (dev_points_) {
-            (void)hipStreamSynchronize(queue.stream());
-            (void)hipFree(dev_points_);
-        }
+        if (dev_points_) sycl_points::detail::DeviceBufferCache::release(dev_points_, dev_points_bytes_, queue.stream());
     }
     KDTree(const KDTree&) = delete;
     KDTree& operator=(const KDTree&) = delete;
@@ -190,11 +187,21 @@ public:
         // (a cloud of a few hundred points: the host build is microseconds and the reference's balanced tree is the shallower one.
         // From a few thousand points on the device build wins even where the search is a little slower — the reference's
         // example on its 6 k-point downsampled scans, same box: build 1.40 -> 0.33 ms, search 0.51 -> 0.78 ms per loop.)
-        if (points.size() < kDeviceBuildMinPoints)
+        if (points.size() < kDeviceBuildMinPoints) {
             throw_on_error(sp_kdtree_create(reinterpret_cast<const float*>(points.data()), points.size(), leaf_threshold, q.stream(),
                                             &t->tree_));
-        else
-            throw_on_error(sp_bvh_create(reinterpret_cast<const float*>(points.device_data()), points.size(), q.stream(), &t->bvh_));
+        } else {
+            // The tree keeps its own copy of the points (like the nodes of the reference's tree: the source cloud may be gone or
+            // changed by the time it is searched) — 16 MB per million points, a few microseconds on the device — and builds the
+            // hierarchy from it when something first needs it. The commonest life of a tree — searched with its own cloud for the
+            // covariances (a grid answers that on a near-uniform cloud), then handed to Registration::align (which searches on a
+            // grid of its own) — never does: half a millisecond per million points and tree saved.
+            t->hierarchy_ = true;
+            size_t got = 0;
+            t->dev_points_ = sycl_points::detail::DeviceBufferCache::acquire(points.size() * 16, &got);
+            t->dev_points_bytes_ = got;
+            hip_check(hipMemcpyAsync(t->dev_points_, points.device_data(), points.size() * 16, hipMemcpyDeviceToDevice, q.stream()), "D2D");
+        }
         static std::atomic<uint64_t> next_id{1};
         t->id_ = next_id.fetch_add(1);
         t->size_ = points.size();
@@ -241,11 +248,11 @@ public:
                                                     sp_grid_self_workspace_bytes(self_grid_), queue.stream()));
                     return sycl_utils::events(queue.stream());
                 }
-                throw_on_error(sp_bvh_self_knn(bvh_, k, result.indices->device_data_for_write(nq * k),
+                throw_on_error(sp_bvh_self_knn(hierarchy(), k, result.indices->device_data_for_write(nq * k),
                                                result.distances->device_data_for_write(nq * k), queue.stream()));
                 return sycl_utils::events(queue.stream());
             }
-            throw_on_error(sp_bvh_search(bvh_, queries.points_device(), nq, k, transT.data(), 0,
+            throw_on_error(sp_bvh_search(hierarchy(), queries.points_device(), nq, k, transT.data(), 0,
                                          result.indices->device_data_for_write(nq * k),
                                          result.distances->device_data_for_write(nq * k), queue.stream()));
             return sycl_utils::events(queue.stream());
@@ -266,7 +273,7 @@ public:
         }
         detail::prepare_result(queue, result, nq, max_k);
         if (on_hierarchy() && max_k <= 32) {
-            throw_on_error(sp_bvh_radius_search(bvh_, queries.points_device(), nq, max_k, radius, transT.data(), 0,
+            throw_on_error(sp_bvh_radius_search(hierarchy(), queries.points_device(), nq, max_k, radius, transT.data(), 0,
                                                 result.indices->device_data_for_write(nq * max_k),
                                                 result.distances->device_data_for_write(nq * max_k), queue.stream()));
             return sycl_utils::events(queue.stream());
@@ -281,9 +288,9 @@ public:
             throw std::runtime_error("[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.");
         // lazy delete in whichever structures exist (both must agree from now on); the grid on the tree's own cloud is dropped,
         // and so is the shortcut for searches of that cloud (its points carry other indices now)
-        if (bvh_ != nullptr)
-            throw_on_error(sp_bvh_remove_by_flags(bvh_, flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
-        if (tree_ != nullptr || bvh_ == nullptr)
+        if (hierarchy_)
+            throw_on_error(sp_bvh_remove_by_flags(hierarchy(), flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
+        if (tree_ != nullptr || !hierarchy_)
             throw_on_error(sp_kdtree_remove_by_flags(host_tree(), flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
         queue.wait();
         pristine_ = false;
@@ -302,16 +309,14 @@ private:
     static constexpr size_t kDeviceBuildMinPoints = 1024;
     /// The device-built hierarchy answers: kNN (k <= 32), radius search and — since round 4 — after a lazy delete too
     /// (sp_bvh_radius_search / sp_bvh_remove_by_flags); the reference's tree only for its own tie order and k > 32.
-    bool on_hierarchy() const { return bvh_ != nullptr && !reference_order_; }
-    /// The points the tree was built on, in their original order, on the device (the hierarchy keeps its own copy, like the
-    /// nodes of the reference's tree: the source cloud may be gone or changed by now).
-    const float* device_points() const {
-        if (dev_points_ == nullptr && size_) {
-            hip_check(hipMalloc(&dev_points_, size_ * 16), "hipMalloc");
-            throw_on_error(sp_bvh_export_points(bvh_, static_cast<float*>(dev_points_), queue.stream()));
-        }
-        return static_cast<const float*>(dev_points_);
+    bool on_hierarchy() const { return hierarchy_ && !reference_order_; }
+    /// The device-built hierarchy, built on first use from the tree's copy of the points.
+    sp_bvh* hierarchy() const {
+        if (bvh_ == nullptr) throw_on_error(sp_bvh_create(device_points(), size_, queue.stream(), &bvh_));
+        return bvh_;
     }
+    /// The points the tree was built on, in their original order, on the device (the tree's own copy, taken at build()).
+    const float* device_points() const { return static_cast<const float*>(dev_points_); }
     /// The reference's tree (host build with its rule, kdtree.hpp:292-413).
     sp_kdtree* host_tree() const {
         if (tree_ == nullptr && removed_after_host_tree_)
@@ -351,8 +356,10 @@ private:
     mutable void* self_grid_ws_ = nullptr;
     mutable bool self_grid_tried_ = false;
     mutable sp_kdtree* tree_ = nullptr;
-    sp_bvh* bvh_ = nullptr;
-    mutable void* dev_points_ = nullptr;
+    mutable sp_bvh* bvh_ = nullptr;   // built by hierarchy()
+    bool hierarchy_ = false;          // the tree answers from the device-built hierarchy (>= kDeviceBuildMinPoints points)
+    void* dev_points_ = nullptr;      // its copy of the points (hierarchy_ only)
+    size_t dev_points_bytes_ = 0;
     uint64_t id_ = 0;
     size_t size_ = 0, leaf_threshold_ = 16;
     bool pristine_ = true, reference_order_ = false;
