@@ -95,12 +95,13 @@ inline KNNResult knn_search_bruteforce(const sycl_utils::DeviceQueue& queue, con
     if (nq == 0) return result;
     const size_t ws_bytes = sp_knn_bruteforce_workspace_bytes(nq, nt, k);
     void* ws = nullptr;
-    if (ws_bytes) hip_check(hipMalloc(&ws, ws_bytes), "hipMalloc");
+    size_t ws_got = 0;
+    if (ws_bytes) ws = sycl_points::detail::DeviceBufferCache::acquire(ws_bytes, &ws_got);  // (no hipMalloc / hipFree per call)
     const int rc = sp_knn_bruteforce(queries.points_device(), nq, targets.points_device(), nt, k,
                                      result.indices->device_data_for_write(nq * k),
                                      result.distances->device_data_for_write(nq * k), ws, ws_bytes, queue.stream());
     if (rc == SP_OK) queue.wait();
-    if (ws) (void)hipFree(ws);
+    if (ws) sycl_points::detail::DeviceBufferCache::release(ws, ws_got, queue.stream(), rc == SP_OK);
     throw_on_error(rc);
     return result;
 }
@@ -173,10 +174,7 @@ public:
         if (tree_) sp_kdtree_destroy(tree_);
         if (bvh_) sp_bvh_destroy(bvh_);
         if (self_grid_) sp_grid_destroy(self_grid_);
-        if (self_grid_ws_) {
-            (void)hipStreamSynchronize(queue.stream());
-            (void)hipFree(self_grid_ws_);
-        }
+        if (self_grid_ws_) sycl_points::detail::DeviceBufferCache::release(self_grid_ws_, self_grid_ws_bytes_, queue.stream());
         if (dev_points_) sycl_points::detail::DeviceBufferCache::release(dev_points_, dev_points_bytes_, queue.stream());
     }
     KDTree(const KDTree&) = delete;
@@ -344,7 +342,8 @@ private:
                     sp_grid_destroy(self_grid_);
                     self_grid_ = nullptr;
                 } else {
-                    hip_check(hipMalloc(&self_grid_ws_, sp_grid_self_workspace_bytes(self_grid_)), "hipMalloc");
+                    // (from the facade's buffer cache: hipMalloc / hipFree cost 0.1-0.2 ms apiece, per tree and frame)
+                    self_grid_ws_ = sycl_points::detail::DeviceBufferCache::acquire(sp_grid_self_workspace_bytes(self_grid_), &self_grid_ws_bytes_);
                 }
             }
         }
@@ -354,6 +353,7 @@ private:
     static constexpr uint32_t kGridSelfMaxCell = 48;
     mutable sp_grid* self_grid_ = nullptr;
     mutable void* self_grid_ws_ = nullptr;
+    mutable size_t self_grid_ws_bytes_ = 0;
     mutable bool self_grid_tried_ = false;
     mutable sp_kdtree* tree_ = nullptr;
     mutable sp_bvh* bvh_ = nullptr;   // built by hierarchy()
