@@ -889,6 +889,25 @@ static void containers_read_from_another_queue() {
     CHECK(same);
 }
 
+static void large_containers_round_trip() {
+    // Uploads and downloads of a megabyte or more go through two pinned staging buffers of 8 MB (core.hpp StagedCopy): sizes
+    // that are no multiple of the chunk, one chunk exactly, several chunks; device-side modification in between (a transform).
+    for (size_t n : {size_t(70000), size_t(524288), size_t(1300001)}) {  // 1.1 MB, 8 MB = one chunk, 20.8 MB
+        PointCloudCPU c;
+        c.points->resize(n);
+        for (size_t i = 0; i < n; ++i) (*c.points)[i] = PointType((float)(i % 1000) * 0.25f, (float)(i % 777), (float)(i / 1000), 1.0f);
+        PointCloudShared cloud(*Q, c);
+        TransformMatrix T = TransformMatrix::Identity();
+        T(0, 3) = 1.0f; T(1, 3) = -2.0f; T(2, 3) = 0.5f;
+        alg::transform::transform(cloud, T);  // on the device: the host copy becomes stale and is read back below
+        bool ok = cloud.size() == n;
+        const auto& h = cloud.points->host();
+        for (size_t i = 0; ok && i < n; i += (i < 100 || i + 100 >= n) ? 1 : 997)
+            ok = h[i].x() == (float)(i % 1000) * 0.25f + 1.0f && h[i].y() == (float)(i % 777) - 2.0f && h[i].z() == (float)(i / 1000) + 0.5f;
+        CHECK(ok);
+    }
+}
+
 static void kdtree_self_knn_large_clouds() {
     // KDTree::knn_search on the tree's own cloud: from 32 k points on, a cloud of near-uniform density is answered by the grid's
     // lane-per-query selection, a clustered one (fullest cell over the limit) by the device-built hierarchy; both must give
@@ -926,6 +945,7 @@ int main() {
     RUN(kdtree_grid_vs_bruteforce);
     RUN(kdtree_self_knn_large_clouds);
     RUN(containers_read_from_another_queue);
+    RUN(large_containers_round_trip);
     RUN(kdtree_backend_on_the_bundled_scan);
     RUN(kdtree_radius_and_lazy_delete_on_the_hierarchy);
     RUN(voxelgrid_known_answer);
