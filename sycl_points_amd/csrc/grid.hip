@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(kBlock) void grid_query_cell_kernel(const float4* _
 
 template <int KCAP>
 int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* T, int T_dev, int32_t* idx, float* d2,
-           hipStream_t st) {
+           hipStream_t st, bool queries_in_cell_order = false) {
     Mat4Arg tv;
     for (int i = 0; i < 16; ++i) tv.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     if (T && !T_dev)
@@ -1345,7 +1345,7 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
         uint32_t*& p; hipStream_t st;
         ~Release() { if (p) { StreamSet used; used.note(st); pooled_free_after(p, used); } }
     } release{sortbuf, st};
-    if (nq >= 400000 && gr->sort_queries && gr->n != 0 && gr->ncells < 0xffffffffull) {
+    if (nq >= 400000 && gr->sort_queries && !queries_in_cell_order && gr->n != 0 && gr->ncells < 0xffffffffull) {
         const size_t wsb = radix_sort_u32_workspace_bytes(nq);
         if (pooled_alloc(&sortbuf, (4 * nq + 4) * sizeof(uint32_t) + wsb) != hipSuccess) return SP_ERR_HIP;
         uint32_t *ka = sortbuf, *kb = ka + nq, *va = kb + nq, *vb = va + nq;
@@ -1669,6 +1669,19 @@ extern "C" int sp_grid_search(const sp_grid* grid, const float* queries, size_t 
     if (k <= 10) return launch<10>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     return launch<20>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
 }
+
+// The grid's own cell-ordered points as queries (row i = neighbours of the point at grid position i): the caller knows the
+// order, no sort (internal: the certificates of sp_gicp_target_create).
+namespace sp {
+int grid_search_own_points(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, hipStream_t st) {
+    if (!grid || k == 0 || k > 10) return SP_ERR_INVALID_ARGUMENT;
+    if (grid->n == 0) return SP_OK;
+    grid->streams.note(st);
+    const float* q = reinterpret_cast<const float*>(grid->d_pts);
+    if (k == 1) return launch<1>(grid, q, grid->n, k, nullptr, 0, idx_out, d2_out, st, true);
+    return launch<10>(grid, q, grid->n, k, nullptr, 0, idx_out, d2_out, st, true);
+}
+}  // namespace sp
 
 // Measured the first time it is asked for (one small kernel + a blocking read-back on the default stream): the grids of the
 // registration path never ask, and their build stays at its 0.18 ms.

@@ -24,6 +24,9 @@ struct sp_grid {
 
 namespace sp {
 
+// grid.hip: kNN of the grid's own cell-ordered points (k <= 10), rows by grid position; enqueues only
+int grid_search_own_points(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, hipStream_t st);
+
 struct GridDesc {
     float inv_h, h, eps;
     float ox, oy, oz;

@@ -1819,7 +1819,7 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
         unsigned* const inv = b_inv.as<unsigned>();
         int rc2 = e == hipSuccess ? SP_OK : SP_ERR_HIP;
         if (rc2 == SP_OK)
-            rc2 = sp_grid_search(grid, reinterpret_cast<const float*>(grid->d_pts), n, 3, nullptr, 0, idx3, d23, stream);
+            rc2 = grid_search_own_points(grid, 3, idx3, d23, st);  // (in cell order already: no sort of the queries)
         if (rc2 == SP_OK) {
             inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
             certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb);
