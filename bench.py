@@ -97,8 +97,80 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, child_cmd=None, env=None, stdout=None):
+    """`python bench.py --gpus N` without a launcher around it: THIS process — which has made no GPU call and never will —
+    starts N children of the same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what
+    torch.distributed.run would have set; under torchrun WORLD_SIZE is there already and this function is not reached), relays
+    rank 0's stdout (the ONE JSON line) to its own, lets the children's stderr through, and returns 0 only if every child did.
+    A child that dies takes the others with it (they would wait in a collective for ever). Never an exec of a process that has
+    touched the GPU: children are started, this process only waits."""
+    import signal
+    import subprocess
+
+    cmd = list(child_cmd) if child_cmd is not None else [sys.executable, os.path.abspath(__file__)]
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(_free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base["WORLD_SIZE"] = base["LOCAL_WORLD_SIZE"] = str(n)
+    out = sys.stdout if stdout is None else stdout
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd + list(argv), env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      start_new_session=True))
+    rc = 0
+    chunks = []
+    import threading
+
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # rank 0's pipe is drained while waiting (its line is small, but a full pipe must never block it)
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in pending:
+                        try:
+                            os.killpg(procs[q].pid, signal.SIGTERM)  # the exact process groups started above
+                        except ProcessLookupError:
+                            pass
+            if pending:
+                time.sleep(0.05)
+        reader.join(timeout=10.0)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+    line0 = b"".join(c for c in chunks if c)
+    out.write(line0.decode(errors="replace"))
+    out.flush()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     # The contract is ONE JSON line on stdout. Libraries below print there too (RCCL writes a version banner to stdout when a
     # communicator is created): everything written to fd 1 from here on goes to stderr, and the line is written to the real
     # stdout at the end.
@@ -111,8 +183,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_sharded:
@@ -188,11 +260,13 @@ def main():
                                    lambda: sp.Communicator.from_process_group(group), elog)
     exchange = "rows" if args.exchange == "torch-rows" else "row"
 
+    cur = {"xchg": xchg, "comm": comm}  # the carrier the loop below runs on (N > 1: every verified one is timed in turn)
+
     def align_chunk(iters, first):
         if args.path == "fused":
             reg.align_fused_loop(S, prep, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta, prepare=first,
-                                 sort_by_cell=SORT_MODE, graph=use_graph and xchg is None, comm=comm, exchange=exchange,
-                                 xchg=xchg)
+                                 sort_by_cell=SORT_MODE, graph=use_graph and cur["xchg"] is None, comm=cur["comm"],
+                                 exchange=exchange, xchg=cur["xchg"])
         else:
             reg.align_device_loop(S, Tg, knn, iterations=iters, group=group, T_dev=T_dev, delta_dev=delta)
 
@@ -216,8 +290,9 @@ def main():
     # the one-GPU test box), the row travels through torch.distributed instead and the line says so.
     exchange_fallback = None
     exchange_legs = None
+    carriers = [(None, xchg, comm)]
     if group is not None and world > 1 and args.path == "fused":
-        from sycl_points_amd.exchange_select import verify_and_fall_back
+        from sycl_points_amd.exchange_select import verified_carriers
 
         def try_alignment(x, c):
             T_dev.copy_(T_ident)
@@ -232,46 +307,69 @@ def main():
                     err = float("inf")  # a peer's row did not arrive within the bound
             return err
 
-        xchg, comm, exchange_fallback, exchange_legs = verify_and_fall_back(dist, torch, dev, rank, world, args.exchange, xchg,
-                                                                            comm, try_alignment, elog)
+        carriers, exchange_legs = verified_carriers(dist, torch, dev, rank, world, args.exchange, xchg, comm, try_alignment, elog)
+        bad = [l["carrier"] for l in exchange_legs if not l["ok"]]
+        if bad:
+            exchange_fallback = f"{', '.join(bad)}: no eager alignment on the ground truth on every rank; not timed"
 
-    if use_graph:
-        # set-up, like building the grid: capture the hipGraph of every chunk length the warm-up and the timed region
-        # will use (first call of a shape runs eagerly, the second is captured), so no capture falls into the timed region
-        for k in (args.warmup, args.steps):
-            for chunk in {ITERS_PER_ALIGN if k >= ITERS_PER_ALIGN else 0, k % ITERS_PER_ALIGN} - {0}:
-                poses = []
-                for _ in range(3):  # eager, capture + first replay, replay
-                    T_dev.copy_(T_ident)
-                    align_chunk(chunk, True)
-                    torch.cuda.synchronize()
-                    poses.append(T_dev.clone())
-                # a replayed alignment must reproduce the eagerly launched one (to rounding: a collective may pick another
-                # summation order inside a graph); otherwise stay on eager launches
-                same = all(bool(torch.isfinite(p).all()) and float((p - poses[0]).abs().max()) < 1e-6 for p in poses[1:])
-                ok = torch.ones(1, device=dev) if same else torch.zeros(1, device=dev)
-                if world > 1:
-                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if ok.item() < 0.5:
-                    for key in list(getattr(reg, "_loop_graphs", {})):
-                        reg._loop_graphs[key] = False
-                    if rank == 0:
-                        print("bench: hipGraph replay did not reproduce the eager alignment; using per-call launches",
-                              file=sys.stderr, flush=True)
+    def timed_blocks():
+        if use_graph and cur["xchg"] is None:
+            # set-up, like building the grid: capture the hipGraph of every chunk length the warm-up and the timed region
+            # will use (first call of a shape runs eagerly, the second is captured), so no capture falls into the timed region
+            for k in (args.warmup, args.steps):
+                for chunk in {ITERS_PER_ALIGN if k >= ITERS_PER_ALIGN else 0, k % ITERS_PER_ALIGN} - {0}:
+                    poses = []
+                    for _ in range(3):  # eager, capture + first replay, replay
+                        T_dev.copy_(T_ident)
+                        align_chunk(chunk, True)
+                        torch.cuda.synchronize()
+                        poses.append(T_dev.clone())
+                    # a replayed alignment must reproduce the eagerly launched one (to rounding: a collective may pick another
+                    # summation order inside a graph); otherwise stay on eager launches
+                    same = all(bool(torch.isfinite(p).all()) and float((p - poses[0]).abs().max()) < 1e-6 for p in poses[1:])
+                    ok = torch.ones(1, device=dev) if same else torch.zeros(1, device=dev)
+                    if world > 1:
+                        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if ok.item() < 0.5:
+                        for key in list(getattr(reg, "_loop_graphs", {})):
+                            reg._loop_graphs[key] = False
+                        if rank == 0:
+                            print("bench: hipGraph replay did not reproduce the eager alignment; using per-call launches",
+                                  file=sys.stderr, flush=True)
+            fence()
+        run_steps(args.warmup)
         fence()
-    run_steps(args.warmup)
-    fence()
-    blocks = []
-    for _ in range(max(1, args.repeats)):  # every block: EXACTLY --steps steps between two barrier + synchronize fences
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        fence()
-        blocks.append(time.perf_counter() - t0)
-    if world > 1:  # a block takes as long as its slowest rank
-        tmax = torch.tensor(blocks, dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        blocks = [float(x) for x in tmax.tolist()]
+        blocks = []
+        for _ in range(max(1, args.repeats)):  # every block: EXACTLY --steps steps between two barrier + synchronize fences
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            fence()
+            blocks.append(time.perf_counter() - t0)
+        if world > 1:  # a block takes as long as its slowest rank
+            tmax = torch.tensor(blocks, dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            blocks = [float(x) for x in tmax.tolist()]
+        return blocks
+
+    # N > 1: the direct stores AND the RCCL all-reduce north_star names are both timed (every carrier that verified), the
+    # line's `value` is the faster one and `exchange_legs` holds both. N = 1: one pass.
+    timed = []
+    for name, x, c in carriers:
+        cur["xchg"], cur["comm"] = x, c
+        timed.append((name, x, c, timed_blocks()))
+    best = min(range(len(timed)), key=lambda i: float(np.median(timed[i][3])))
+    _, xchg, comm, blocks = timed[best]
+    cur["xchg"], cur["comm"] = xchg, comm
     elapsed = float(np.median(blocks))
+    timed_legs = None
+    if world > 1:
+        timed_legs = [{"carrier": nm, "ms_per_step": 1e3 * float(np.median(b)) / args.steps,
+                       "min_ms_per_step": 1e3 * min(b) / args.steps, "max_ms_per_step": 1e3 * max(b) / args.steps,
+                       "reported": i == best} for i, (nm, _, _, b) in enumerate(timed)]
+    rccl_ranks = None
+    for _, _, c, _ in timed:
+        if c is not None:
+            rccl_ranks = int(_lib.lib().sp_comm_world(c._h))  # what the communicator itself says
 
     # ---- correctness of what was timed: pose after a full alignment vs the ground truth used to make the data
     T_dev.copy_(T_ident)
@@ -334,12 +432,14 @@ def main():
                                      else "torch.distributed all-reduce")),
                        "exchange_fallback": exchange_fallback,
                        "exchange_verification_legs": exchange_legs,
+                       "rccl_ranks": rccl_ranks,
                        "launch": ("one C call per alignment: one launch per iteration (its prologue waits for the peers' rows of the "
                                   "previous iteration and solves), nothing from the host in between" if xchg is not None else
                                   "one hipGraph replay per alignment (kernels + all-reduces captured)" if graphs_live
                                   else ("per-iteration launches + all-reduce from the host" if group is not None
                                         else "one C call per alignment"))},
             "iterations_per_sec": args.steps / elapsed,
+            "exchange_legs": timed_legs,
             "pose_max_abs_err_vs_ground_truth": pose_err,
             "inliers_last_iteration": int(lin.inlier),
             "setup_s": t_setup,

@@ -83,5 +83,43 @@ def verify_and_fall_back(dist, torch, dev, rank, world, want, xchg, comm, try_al
     return xchg, comm, note, legs
 
 
+def verified_carriers(dist, torch, dev, rank, world, want, xchg, comm, try_alignment, log=print):
+    """Every carrier that is open AND lands one eager alignment on the ground truth on every rank, in ladder order — what
+    bench.py times for N > 1 (`exchange_legs`: the direct stores and the RCCL row side by side; torch.distributed only
+    stands in when neither works, or when it was asked for). try_alignment as in verify_and_fall_back.
+    Returns (carriers, legs): carriers = [(name, xchg or None, comm or None), ...], never empty (raises otherwise)."""
+    candidates = []
+    if xchg is not None:
+        candidates.append((xchg, None))
+    if comm is not None:
+        candidates.append((None, comm))
+    legs, good = [], []
+
+    def leg(x, c):
+        t0 = time.perf_counter()
+        try:
+            err = float(try_alignment(x, c))
+        except Exception as e:
+            if rank == 0:
+                log(f"bench: alignment over {carrier_name(x, c)} raised {e!r}")
+            err = float("inf")
+        ok = _all_agree(dist, torch, dev, err == err and err < 1e-3, world)
+        legs.append({"carrier": carrier_name(x, c), "ok": ok, "pose_err": err, "seconds": time.perf_counter() - t0})
+        if ok:
+            good.append((carrier_name(x, c), x, c))
+        return err
+
+    last = float("nan")
+    for x, c in candidates:
+        last = leg(x, c)
+    if want == "direct" and not any(g[0] == "direct" for g in good):
+        raise RuntimeError(f"--exchange direct: pose error {last:.3g} on an eager alignment")
+    if not good:  # neither of the library's own carriers: the row travels through torch.distributed
+        last = leg(None, None)
+    if not good:
+        raise RuntimeError(f"sharded alignment does not reach the ground truth (max abs pose error {last:.3g})")
+    return good, legs
+
+
 def carrier_name(xchg, comm):
     return "direct" if xchg is not None else ("rccl-row" if comm is not None else "torch.distributed")

@@ -127,7 +127,7 @@ def _ladder_worker(rank, world, port, scenario, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from sycl_points_amd.exchange_select import carrier_name, open_carriers, verify_and_fall_back
+    from sycl_points_amd.exchange_select import carrier_name, open_carriers, verified_carriers, verify_and_fall_back
 
     log = []
     sc = scenario
@@ -158,10 +158,16 @@ def _ladder_worker(rank, world, port, scenario, out_path):
     res = {"error": ""}
     try:
         xchg, comm = open_carriers(dist, torch, "cpu", rank, world, sc.get("want", "auto"), make_direct, make_comm, log.append)
-        xchg, comm, note, legs = verify_and_fall_back(dist, torch, "cpu", rank, world, sc.get("want", "auto"), xchg, comm,
-                                                      try_alignment, log.append)
-        res.update(final=carrier_name(xchg, comm), note=note or "", legs=[(l["carrier"], bool(l["ok"])) for l in legs],
-                   timed=all(l["seconds"] >= 0.0 for l in legs))
+        if sc.get("every_carrier"):  # what bench.py does for N > 1: every carrier that verifies gets timed
+            good, legs = verified_carriers(dist, torch, "cpu", rank, world, sc.get("want", "auto"), xchg, comm, try_alignment,
+                                           log.append)
+            res.update(final=[g[0] for g in good], note="", legs=[(l["carrier"], bool(l["ok"])) for l in legs], timed=True,
+                       handles=[(g[1], g[2]) for g in good])
+        else:
+            xchg, comm, note, legs = verify_and_fall_back(dist, torch, "cpu", rank, world, sc.get("want", "auto"), xchg, comm,
+                                                          try_alignment, log.append)
+            res.update(final=carrier_name(xchg, comm), note=note or "", legs=[(l["carrier"], bool(l["ok"])) for l in legs],
+                       timed=all(l["seconds"] >= 0.0 for l in legs))
     except RuntimeError as e:
         res["error"] = str(e)
     res["calls"] = calls
@@ -189,6 +195,27 @@ def test_exchange_ladder_two_gloo_ranks(tmp_path, scenario, final, tried):
         assert r[k]["final"] == final and r[k]["calls"] == tried and r[k]["timed"]
         assert [c for c, _ in r[k]["legs"]] == tried and r[k]["legs"][-1][1] and not any(ok for _, ok in r[k]["legs"][:-1])
     assert (r[0]["note"] != "") == (len(tried) > 1)
+
+
+@pytest.mark.parametrize("scenario, timed, tried", [
+    ({}, ["direct", "rccl-row"], ["direct", "rccl-row"]),                                 # both carriers of north_star are timed
+    ({"bad": {"direct": 1}}, ["rccl-row"], ["direct", "rccl-row"]),                      # wrong on one rank: dropped on both
+    ({"direct_unavailable_on": 0}, ["rccl-row"], ["rccl-row"]),
+    ({"direct_unavailable_on": "all", "comm_unavailable_on": 1}, ["torch.distributed"], ["torch.distributed"]),
+    ({"bad": {"direct": "all", "rccl-row": 0}}, ["torch.distributed"], ["direct", "rccl-row", "torch.distributed"]),
+    ({"want": "rccl-row"}, ["rccl-row"], ["rccl-row"]),
+    ({"want": "direct"}, ["direct"], ["direct"]),
+])
+def test_every_verified_carrier_is_offered_for_timing(tmp_path, scenario, timed, tried):
+    out = str(tmp_path / "every%d.npy")
+    mp.spawn(_ladder_worker, args=(2, _free_port(), dict(scenario, every_carrier=True), out), nprocs=2, join=True)
+    r = [np.load(out % k, allow_pickle=True)[0] for k in range(2)]
+    for k in range(2):
+        assert r[k]["error"] == "", r[k]["error"]
+        assert r[k]["final"] == timed and r[k]["calls"] == tried
+        # a carrier is handed on with ONLY its own handle, so the loop cannot pick another one by accident
+        for name, (x, c) in zip(r[k]["final"], r[k]["handles"]):
+            assert (x, c) == {"direct": ("XCHG", None), "rccl-row": (None, "COMM"), "torch.distributed": (None, None)}[name]
 
 
 def test_exchange_ladder_gives_up_loudly(tmp_path):
