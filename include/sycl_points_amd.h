@@ -32,7 +32,7 @@ extern "C" {
 #define SP_ERR_RUNTIME 2          /* reference: std::runtime_error    */
 #define SP_ERR_HIP 3              /* reference: sycl::exception from wait_and_throw */
 
-#define SP_ABI_VERSION 4
+#define SP_ABI_VERSION 5
 int sp_abi_version(void);
 const char* sp_last_error(void);
 
@@ -440,6 +440,77 @@ int sp_gicp_align_finish(const sp_gicp_source* source, float* transT_device, con
  * sp_gicp_error_prepared / Registration::compute_error_frozen. Copies 16 floats (column-major) to transT_lin_out (host or
  * device memory) in stream order. */
 int sp_gicp_align_linearization_pose(const void* workspace, int last_k, float* transT_lin_out, void* stream);
+/* Registration::align's optimiser loop for EVERY OptimizationMethod (registration.hpp:201-276 with optimize_gauss_newton
+ * :803-828, optimize_levenberg_marquardt :830-895, optimize_powell_dogleg :897-964 and dogleg_step.hpp:35-101) and, in the same
+ * launch, the robust-scale annealing of pipeline::RobustAligner around it (pipeline/robust.hpp:78-111: one align() per level,
+ * each starting at the pose the previous level ended on) — device-resident: ONE launch whose workgroups loop on the device,
+ * ONE read-back (sp_align_result) per alignment. The reference crosses host <-> device twice per Gauss-Newton iteration and
+ * 2 + inner tries times per LM iteration (:674-675, :685-686); its own example (LM + Geman-McClure + 3 levels on a 1000-point
+ * sample, example_registration.cpp:29-55) is ~60 such round trips.
+ *   step "linearise"  every source point: cached correspondence when its reuse certificate holds, else exact NN on the grid
+ *                     -> K11 sums (28 floats + inlier count) -> one partial row per workgroup
+ *   step "trial"      K12 of the trial pose over the correspondence-cache rows (frozen correspondences, sp_gicp_error_prepared's
+ *                     arithmetic) -> one partial row per workgroup
+ *   between steps     every workgroup waits for the rows of all workgroups (arrival counter, bounded wait), sums them in a fixed
+ *                     order and runs the optimiser's state machine for itself — the same decisions in every workgroup:
+ *                       GN      delta = LDLT(H + lambda I).solve(-b); T <- T exp(delta)
+ *                       LM      up to lm_max_inner_iterations trials T exp(delta(lambda)): accept on new_error <= current_error
+ *                               (lambda /= factor), stop on |new_error - last_error| <= 1e-6, else lambda *= factor
+ *                       DOGLEG  compute_dogleg_step; predicted <= 0 -> shrink; one trial; rho < eta1 -> shrink, else accept
+ *                               (rho > eta2 and a full step -> grow)
+ *                     an outer iteration ends -> is_converged() or max_iterations ends the level -> next robust scale or done.
+ * A launch of one workgroup (<= 1024 source points: the reference pipeline's default random sample) needs no counter at all.
+ * robust_scales[n_levels] (host, 1 <= n_levels <= SP_OPT_MAX_LEVELS): the robust scale of each level; lambda / trust radius /
+ * result fields restart at every level as a fresh align() would. transT_device: in the initial guess, out the final pose.
+ * result_device: sp_align_result in device memory, written once at the end (status 0 ok; 2 a wait ran out — not every workgroup
+ * of the launch was resident, the pose is NaN: run again after sp_gicp_source_set_persistent(source, 0), which makes this
+ * entry point return SP_ERR_RUNTIME "not available" so that the caller takes its per-step loop).
+ * Only enqueues. SP_ERR_RUNTIME (nothing enqueued) when the launch cannot be resident now: the grid exceeds the device's compute
+ * units, `stream` is capturing, or another stream's persistent launch may still be running. reg_type GICP or
+ * POINT_TO_DISTRIBUTION as the target was prepared; no rotation constraint. Workspace: sp_gicp_workspace_bytes(n). */
+enum { SP_OPT_GAUSS_NEWTON = 0, SP_OPT_LEVENBERG_MARQUARDT = 1, SP_OPT_POWELL_DOGLEG = 2 }; /* OptimizationMethod, registration_params.hpp:17-21 */
+enum { SP_OPT_MAX_LEVELS = 8, SP_OPT_LOG_ENTRIES = 64 };
+typedef struct sp_opt_params { /* RegistrationParams: optimization_method, max_iterations, criteria, gn, lm, dogleg (registration_params.hpp:74-114) */
+    int method;
+    int max_iterations;
+    float crit_rotation, crit_translation;
+    float gn_lambda;
+    int lm_max_inner_iterations;
+    float lm_lambda_factor, lm_init_lambda, lm_max_lambda, lm_min_lambda;
+    float dl_initial_radius, dl_min_radius, dl_max_radius, dl_eta1, dl_eta2, dl_gamma_decrease, dl_gamma_increase;
+} sp_opt_params;
+typedef struct sp_opt_log_entry { /* one outer iteration */
+    uint16_t level, iteration;
+    uint16_t trials;     /* K12 evaluations of this iteration */
+    uint16_t accepted;   /* 1 the pose moved (LM: new_error <= current_error; dog-leg: rho >= eta1; GN: always), 2 LM's
+                            stagnation exit (|new_error - last_error| <= 1e-6: pose taken, `updated` false), 0 rejected */
+    float damping;       /* lambda (LM) / trust-region radius (dog-leg) AFTER the iteration */
+    float error;         /* RegistrationResult::error after the iteration */
+} sp_opt_log_entry;
+typedef struct sp_align_result { /* RegistrationResult (result.hpp:12-28) of the LAST level + what the facade needs beside it */
+    float T[16];         /* final pose, column-major */
+    float T_lin[16];     /* pose of the last linearisation: the correspondence cache is frozen at it (compute_error_frozen) */
+    float H[36];         /* row-major */
+    float b[6];
+    float error;         /* RegistrationResult::error (GN / dog-leg: of the last linearisation unless a trial was accepted) */
+    float error_raw;     /* error of the last linearisation (RegistrationResult::error_raw; H_raw = H, b_raw = b on this path) */
+    uint32_t inlier;
+    uint32_t iterations; /* index of the last outer iteration of the last level (RegistrationResult::iterations) */
+    uint32_t converged;
+    uint32_t status;     /* 0 ok, 2 a wait between steps ran out (pose NaN) */
+    uint32_t linearizations, trials; /* steps executed, all levels */
+    uint32_t searched;   /* source points searched for, all linearisations (the rest reused their correspondence) */
+    float damping;       /* final lambda / trust-region radius */
+    uint32_t log_entries;
+    uint32_t pad[3];
+    sp_opt_log_entry log[SP_OPT_LOG_ENTRIES]; /* the first outer iterations, all levels in order */
+} sp_align_result;
+int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                           const sp_factor_params* params, const sp_opt_params* opt, const float* robust_scales, int n_levels,
+                           sp_align_result* result_device, void* workspace, size_t workspace_bytes, void* stream);
+/* 0: sp_gicp_align_fused runs every iteration as a launch of its own and sp_gicp_align_optimize reports "not available" — no
+ * launch whose workgroups wait for each other is started for this source. Default 1. */
+int sp_gicp_source_set_persistent(sp_gicp_source* source, int enable);
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
  * iteration loop can stay on the stream with no host round trip:
  *   delta = LDLT(H + lambda*I).solve(-b);  T <- T * se3_exp(delta);  delta_out[0..5] = delta,

@@ -349,7 +349,9 @@ struct orc_reg_result {
 void orc_registration_align(const orc_reg_params* P, const float* src, const float* src_cov, size_t ns, const float* tgt,
                             const float* tgt_cov, const float* tgt_nrm, size_t nt, const float* init_T16, int nn_mode,
                             orc_reg_result* out, float* trace_T, int* trace_n, const void* prebuilt_nodes,
-                            size_t prebuilt_n_nodes) {
+                            size_t prebuilt_n_nodes, float* trace_steps, int trace_steps_capacity, int* trace_steps_n) {
+    // trace_steps (optional, capacity entries of 5 floats): per outer iteration — all annealing levels in order — {trial
+    // evaluations, accepted, lambda / trust radius after the iteration, result.error after it, decision margin}; *trace_steps_n their count
     RegParams p;
     p.reg_type = P->reg_type; p.robust_type = P->robust_type; p.optimization_method = P->optimization_method;
     p.max_iterations = (size_t)P->max_iterations; p.max_correspondence_distance = P->max_correspondence_distance;
@@ -398,12 +400,19 @@ void orc_registration_align(const orc_reg_params* P, const float* src, const flo
             knn_bruteforce(tq.data(), nq, tgt, nt, 1, idx, d2);
         }
     };
-    std::vector<float> trace;
+    std::vector<float> trace, steps;
     RegResult r;
     if (P->auto_scale)
-        r = align_robust_annealing(p, s, t, nearest, init_T16, true, P->init_scale, P->min_scale, (size_t)P->auto_scaling_iter);
+        r = align_robust_annealing(p, s, t, nearest, init_T16, true, P->init_scale, P->min_scale, (size_t)P->auto_scaling_iter,
+                                   trace_steps ? &steps : nullptr);
     else
-        r = align(p, s, t, nearest, init_T16, -1.0f, trace_T ? &trace : nullptr, P->mp_active ? &prior : nullptr);
+        r = align(p, s, t, nearest, init_T16, -1.0f, trace_T ? &trace : nullptr, P->mp_active ? &prior : nullptr, -1.0f,
+                  trace_steps ? &steps : nullptr);
+    if (trace_steps) {
+        const size_t k = std::min(steps.size() / 5, (size_t)std::max(trace_steps_capacity, 0));
+        std::memcpy(trace_steps, steps.data(), k * 20);
+        if (trace_steps_n) *trace_steps_n = (int)k;
+    }
     std::memcpy(out->H_raw, r.H_raw.d, 144);
     std::memcpy(out->b_raw, r.b_raw.d, 24);
     out->error_raw = r.error_raw;

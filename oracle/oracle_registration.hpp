@@ -589,7 +589,13 @@ inline DoglegStep compute_dogleg_step(const Mat6& H, const Vec6& g, float radius
 inline RegResult align(const RegParams& params, const Cloud& source, const Cloud& target, const NearestFn& nearest,
                        const float* init_T_colmajor, float opt_robust_scale = -1.0f,
                        std::vector<float>* trace_T = nullptr, const MapPrior* map_prior = nullptr,
-                       float opt_rotation_robust_scale = -1.0f) {
+                       float opt_rotation_robust_scale = -1.0f, std::vector<float>* trace_steps = nullptr) {
+    // trace_steps (test instrumentation, not in the reference): per outer iteration {trial evaluations, accepted (1 pose moved,
+    // 2 LM's stagnation exit, 0 rejected), lambda / trust radius after the iteration, result.error after it, margin}; margin =
+    // how far the iteration's closest decision was from its threshold (LM: min |new_error - current_error| / |current_error|;
+    // dog-leg: min(|rho - eta1|, |rho - eta2|) * predicted / |current_error|, i.e. both as the relative change of an error
+    // that would flip the branch; FLT_MAX when no float comparison decided anything): a test comparing another
+    // implementation's decisions with these must allow a different branch where the margin is within rounding
     RegResult result;
     result.T = to_mat4(init_T_colmajor);
     const Mat4 T_initial = result.T;
@@ -627,7 +633,9 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
             result.b = lin.b;
             result.error = lin.error;
             result.inlier = lin.inlier;
+            if (trace_steps) trace_steps->insert(trace_steps->end(), {0.0f, 1.0f, p.gn_lambda, result.error, std::numeric_limits<float>::max()});
         } else if (p.optimization_method == LEVENBERG_MARQUARDT) {
+            float st_trials = 0.0f, st_accepted = 0.0f, st_margin = std::numeric_limits<float>::max();
             const float current_error = lin.error;
             float last_error = std::numeric_limits<float>::max();
             Vec6 delta;
@@ -640,18 +648,22 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
                 error_reduce(p, source, target, nn_idx.data(), nn_d2.data(), new_T.d, robust_scale, genz_alpha, new_error,
                              inl, rot_scale);
                 new_error += prior_error(new_T);  // registration.hpp:854
+                st_trials += 1.0f;
+                st_margin = std::min(st_margin, std::fabs(new_error - current_error) / std::max(std::fabs(current_error), 1e-30f));
                 if (new_error <= current_error) {
                     result.converged = is_converged(p, delta);
                     result.T = new_T;
                     result.error = new_error;
                     result.inlier = inl;
                     lm_lambda = std::clamp(lm_lambda / p.lm_lambda_factor, p.lm_min_lambda, p.lm_max_lambda);
+                    st_accepted = 1.0f;
                     break;
                 } else if (std::fabs(new_error - last_error) <= 1e-6f) {
                     result.converged = is_converged(p, delta);
                     result.T = new_T;
                     result.error = new_error;
                     result.inlier = inl;
+                    st_accepted = 2.0f;
                     break;
                 } else {
                     lm_lambda = std::clamp(lm_lambda * p.lm_lambda_factor, p.lm_min_lambda, p.lm_max_lambda);
@@ -661,7 +673,9 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
             result.iterations = iter;
             result.H = lin.H;
             result.b = lin.b;
+            if (trace_steps) trace_steps->insert(trace_steps->end(), {st_trials, st_accepted, lm_lambda, result.error, st_margin});
         } else if (p.optimization_method == POWELL_DOGLEG) {  // registration.hpp:897-965
+            float st_trials = 0.0f, st_accepted = 0.0f, st_margin = std::numeric_limits<float>::max();
             result.H = lin.H;
             result.b = lin.b;
             result.error = lin.error;
@@ -679,7 +693,10 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
                 error_reduce(p, source, target, nn_idx.data(), nn_d2.data(), new_T.d, robust_scale, genz_alpha, new_error,
                              inl, rot_scale);
                 new_error += prior_error(new_T);  // registration.hpp:933
+                st_trials = 1.0f;
                 const float rho = (lin.error - new_error) / dl.predicted_reduction;
+                st_margin = std::min(std::fabs(rho - p.dl_eta1), std::fabs(rho - p.dl_eta2)) * dl.predicted_reduction /
+                            std::max(std::fabs(lin.error), 1e-30f);
                 if (rho < p.dl_eta1) {
                     trust_region_radius = clamp_radius(trust_region_radius * p.dl_gamma_decrease);
                 } else {
@@ -687,10 +704,12 @@ inline RegResult align(const RegParams& params, const Cloud& source, const Cloud
                     result.T = new_T;
                     result.error = new_error;
                     result.inlier = inl;
+                    st_accepted = 1.0f;
                     if (rho > p.dl_eta2 && dl.step_norm >= trust_region_radius * 0.99f)
                         trust_region_radius = clamp_radius(trust_region_radius * p.dl_gamma_increase);
                 }
             }
+            if (trace_steps) trace_steps->insert(trace_steps->end(), {st_trials, st_accepted, trust_region_radius, result.error, st_margin});
         }
         if (trace_T) trace_T->insert(trace_T->end(), result.T.d, result.T.d + 16);
         if (result.converged) break;
@@ -718,13 +737,14 @@ inline std::vector<float> robust_annealing_scales(bool loss_is_none, bool auto_s
 // pipeline/robust.hpp:42-114 — geometric robust-scale annealing around align().
 inline RegResult align_robust_annealing(const RegParams& params, const Cloud& source, const Cloud& target,
                                         const NearestFn& nearest, const float* init_T_colmajor, bool auto_scale,
-                                        float init_scale, float min_scale, size_t auto_scaling_iter) {
+                                        float init_scale, float min_scale, size_t auto_scaling_iter,
+                                        std::vector<float>* trace_steps = nullptr) {
     RegResult result;
     result.T = to_mat4(init_T_colmajor);
     if (source.n == 0) return result;
     for (const float robust_scale : robust_annealing_scales(params.robust_type == LOSS_NONE, auto_scale, params.robust_default_scale,
                                                             init_scale, min_scale, auto_scaling_iter))
-        result = align(params, source, target, nearest, result.T.d, robust_scale);
+        result = align(params, source, target, nearest, result.T.d, robust_scale, nullptr, nullptr, -1.0f, trace_steps);
     return result;
 }
 

@@ -467,7 +467,7 @@ class Oracle:
         return out.T.copy()
 
     def registration_align(self, params, src, src_cov, tgt, tgt_cov, tgt_nrm=None, init_T=None, nn_mode="kdtree",
-                           trace=False, nodes=None):
+                           trace=False, nodes=None, steps=False):
         src, tgt = _f(src), _f(tgt)
         src_cov = None if src_cov is None else _f(src_cov)
         tgt_cov = None if tgt_cov is None else _f(tgt_cov)
@@ -476,17 +476,24 @@ class Oracle:
         res = RegResult()
         tr = np.zeros((max(params.max_iterations, 1), 16), np.float32) if trace else None
         trn = C.c_int(0)
+        st = np.zeros((4096, 5), np.float32) if steps else None
+        stn = C.c_int(0)
         self.lib.orc_registration_align(C.byref(params), _p(src), _p(src_cov), C.c_size_t(len(src)), _p(tgt), _p(tgt_cov),
                                         _p(tgt_nrm), C.c_size_t(len(tgt)), _p(Tc), C.c_int(0 if nn_mode == "kdtree" else 1),
                                         C.byref(res), _p(tr), C.byref(trn),
                                         None if nodes is None else nodes.ctypes.data_as(C.c_void_p),
-                                        C.c_size_t(0 if nodes is None else len(nodes) // 32))
+                                        C.c_size_t(0 if nodes is None else len(nodes) // 32),
+                                        _p(st), C.c_int(0 if st is None else len(st)), C.byref(stn))
         out = {"T": np.array(res.T, np.float32).reshape(4, 4).T.copy(),
                "H": np.array(res.H, np.float32).reshape(6, 6).T.copy(), "b": np.array(res.b, np.float32),
                "error": float(res.error), "inlier": int(res.inlier), "iterations": int(res.iterations),
                "converged": bool(res.converged),
                "H_raw": np.array(res.H_raw, np.float32).reshape(6, 6).T.copy(), "b_raw": np.array(res.b_raw, np.float32),
                "error_raw": float(res.error_raw)}
+        if steps:  # per outer iteration (all annealing levels in order): trials, accepted, damping after, result.error after, margin of
+            # the closest decision to its threshold
+            out["steps"] = [dict(trials=int(r[0]), accepted=int(r[1]), damping=float(r[2]), error=float(r[3]), margin=float(r[4]))
+                            for r in st[:stn.value]]
         if trace:
             out["trace"] = np.stack([tr[i].reshape(4, 4).T for i in range(trn.value)]) if trn.value else np.zeros((0, 4, 4))
         return out

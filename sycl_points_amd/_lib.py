@@ -54,7 +54,33 @@ class GnParams(C.Structure):  # sp_gn_params
     _fields_ = [("lambda_", C.c_float), ("crit_rotation", C.c_float), ("crit_translation", C.c_float)]
 
 
+class OptParams(C.Structure):  # sp_opt_params
+    _fields_ = [("method", C.c_int), ("max_iterations", C.c_int), ("crit_rotation", C.c_float), ("crit_translation", C.c_float),
+                ("gn_lambda", C.c_float), ("lm_max_inner_iterations", C.c_int), ("lm_lambda_factor", C.c_float),
+                ("lm_init_lambda", C.c_float), ("lm_max_lambda", C.c_float), ("lm_min_lambda", C.c_float),
+                ("dl_initial_radius", C.c_float), ("dl_min_radius", C.c_float), ("dl_max_radius", C.c_float),
+                ("dl_eta1", C.c_float), ("dl_eta2", C.c_float), ("dl_gamma_decrease", C.c_float),
+                ("dl_gamma_increase", C.c_float)]
+
+
+class OptLogEntry(C.Structure):  # sp_opt_log_entry
+    _fields_ = [("level", C.c_uint16), ("iteration", C.c_uint16), ("trials", C.c_uint16), ("accepted", C.c_uint16),
+                ("damping", C.c_float), ("error", C.c_float)]
+
+
+OPT_MAX_LEVELS, OPT_LOG_ENTRIES = 8, 64
+
+
+class AlignResult(C.Structure):  # sp_align_result
+    _fields_ = [("T", C.c_float * 16), ("T_lin", C.c_float * 16), ("H", C.c_float * 36), ("b", C.c_float * 6),
+                ("error", C.c_float), ("error_raw", C.c_float), ("inlier", C.c_uint32), ("iterations", C.c_uint32),
+                ("converged", C.c_uint32), ("status", C.c_uint32), ("linearizations", C.c_uint32), ("trials", C.c_uint32),
+                ("searched", C.c_uint32), ("damping", C.c_float), ("log_entries", C.c_uint32), ("pad", C.c_uint32 * 3),
+                ("log", OptLogEntry * OPT_LOG_ENTRIES)]
+
+
 assert C.sizeof(Linearized) == 192
+assert C.sizeof(OptParams) == 68 and C.sizeof(OptLogEntry) == 16 and C.sizeof(AlignResult) == 4 * (74 + 14) + 16 * 64
 
 _vp, _sz, _f, _i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
 
@@ -124,6 +150,9 @@ SIGNATURES = {
     "sp_gicp_source_prepare": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _vp]),
     "sp_gicp_source_destroy": (None, [_vp]),
     "sp_gicp_iteration_fused": (_i, [_vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_gicp_align_optimize": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), C.POINTER(OptParams), C.POINTER(C.c_float), _i, _vp, _vp,
+                                    _sz, _vp]),
+    "sp_gicp_source_set_persistent": (_i, [_vp, _i]),
     "sp_gicp_align_fused": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_linearization_pose": (_i, [_vp, _i, _vp, _vp]),
@@ -215,7 +244,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.sp_abi_version() != 4:
+        if L.sp_abi_version() != 5:
             raise ImportError("libsycl_points_amd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -1232,7 +1232,72 @@ class Registration:
 
         return self._host_loop(result, T, linearize_at, error_at, scale)
 
-    def align_prepared(self, source, prepared_target, initial_guess=None, robust_scale=-1.0, sort_by_cell=True):
+    def opt_params(self):
+        """sp_opt_params of these RegistrationParams."""
+        p = self.params
+        return _lib.OptParams({"GN": 0, "LM": 1, "DOGLEG": 2}[p.optimization_method], p.max_iterations, p.criteria_rotation,
+                              p.criteria_translation, p.gn_lambda, p.lm_max_inner_iterations, p.lm_lambda_factor,
+                              p.lm_init_lambda, p.lm_max_lambda, p.lm_min_lambda, p.dogleg_initial_trust_region_radius,
+                              p.dogleg_min_trust_region_radius, p.dogleg_max_trust_region_radius, p.dogleg_eta1, p.dogleg_eta2,
+                              p.dogleg_gamma_decrease, p.dogleg_gamma_increase)
+
+    def align_optimize(self, source, prepared_target, initial_guess=None, robust_scales=None, sort_by_cell=True, prepare=True,
+                       enqueue_only=False):
+        """Registration::align for every optimiser — and pipeline::RobustAligner's annealing levels around it (robust_scales:
+        one align() per entry, each from the pose the previous one ended on) — as ONE launch and ONE read-back
+        (sp_gicp_align_optimize). Returns a RegistrationResult that also carries `log` (one entry per outer iteration:
+        level, iteration, trials, accepted, damping, error), `linearizations`, `trials`, `searched`; None when the launch is
+        not available on this device right now or its bounded wait ran out (the caller takes its per-step loop).
+        enqueue_only: returns the device tensor of the sp_align_result instead (nothing synchronised)."""
+        L = _lib.lib()
+        p = self.params
+        n = source.size()
+        dev = source.points.device
+        ws, _ = self._buffers(dev)
+        T0 = identity() if initial_guess is None else np.asarray(initial_guess, np.float32)
+        if getattr(self, "_opt_T_dev", None) is None or self._opt_T_dev.device != dev:
+            self._opt_T_dev = torch.zeros(16, dtype=torch.float32, device=dev)
+            self._opt_res_dev = torch.zeros(C.sizeof(_lib.AlignResult), dtype=torch.uint8, device=dev)
+            self._opt_res_host = torch.zeros(C.sizeof(_lib.AlignResult), dtype=torch.uint8).pin_memory()
+        self._opt_T_dev.copy_(torch.from_numpy(_T16(T0).reshape(-1).copy()), non_blocking=True)
+        psrc, _ = self._prepared_source(n)
+        if prepare:
+            psrc.prepare(prepared_target, source, self._opt_T_dev, sort_by_cell)
+        scales = list(robust_scales) if robust_scales else [p.robust_default_scale]
+        fp = self._factor_params(scales[0])
+        op = self.opt_params()
+        sc = (C.c_float * len(scales))(*scales)
+        rc = L.sp_gicp_align_optimize(prepared_target._h, psrc._h, _ptr(self._opt_T_dev), C.byref(fp), C.byref(op), sc, len(scales),
+                                      _ptr(self._opt_res_dev), _ptr(ws), ws.numel(), _stream())
+        if rc == _lib.SP_ERR_RUNTIME and b"not available" in L.sp_last_error():
+            return None
+        check(rc)
+        if enqueue_only:
+            return self._opt_res_dev
+        self._opt_res_host.copy_(self._opt_res_dev, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        r = _lib.AlignResult.from_buffer_copy(self._opt_res_host.numpy().tobytes())
+        if r.status != 0:
+            return None
+        return self._result_from_align_result(r)
+
+    @staticmethod
+    def _result_from_align_result(r):
+        res = RegistrationResult()
+        res.T = np.array(r.T, np.float32).reshape(4, 4).T.copy()
+        res.converged, res.iterations = bool(r.converged), int(r.iterations)
+        res.H = np.array(r.H, np.float32).reshape(6, 6)
+        res.b = np.array(r.b, np.float32)
+        res.error, res.inlier = float(r.error), int(r.inlier)
+        res.H_raw, res.b_raw, res.error_raw = res.H.copy(), res.b.copy(), float(r.error_raw)
+        res.T_lin = np.array(r.T_lin, np.float32).reshape(4, 4).T.copy()
+        res.linearizations, res.trials, res.searched, res.damping = int(r.linearizations), int(r.trials), int(r.searched), float(r.damping)
+        res.log = [dict(level=e.level, iteration=e.iteration, trials=e.trials, accepted=e.accepted, damping=e.damping, error=e.error)
+                   for e in r.log[:r.log_entries]]
+        return res
+
+    def align_prepared(self, source, prepared_target, initial_guess=None, robust_scale=-1.0, sort_by_cell=True,
+                       device_resident=True):
         """Registration::align (registration.hpp:201-276) with every optimiser (GN / LM / DOGLEG) on the PREPARED path:
         each outer iteration linearises with the fused kernel (sp_gicp_iteration_fused: search or certified reuse +
         linearise + reduce), and the trial steps of LM (:830-895) and dog-leg (:897-965) evaluate the frozen-correspondence
@@ -1254,6 +1319,13 @@ class Registration:
         scale = robust_scale if robust_scale > 0 else p.robust_default_scale
         ws, lin = self._buffers(source.points.device)
         T = _T16(result.T).copy().reshape(-1)
+        pose_terms = (p.degenerate_reg_type.upper() != "NONE") or (p.map_prior_enabled and bool(self._map_prior.has_prior))
+        if device_resident and not pose_terms and p.max_iterations > 0:
+            # the whole optimiser loop as one launch, one read-back (sp_gicp_align_optimize); the host loop below is what is
+            # left for the host-side pose terms and for a device that cannot hold the launch resident
+            res = self.align_optimize(source, prepared_target, result.T, [scale], sort_by_cell)
+            if res is not None:
+                return res
         psrc, _ = self._prepared_source(n)
         psrc.prepare(prepared_target, source, result.T, sort_by_cell)
         fp = self._factor_params(scale)

@@ -1,0 +1,431 @@
+// Registration::align's optimiser loop on the device, for every OptimizationMethod, with the robust-scale annealing of
+// pipeline::RobustAligner around it (replaces registration.hpp:201-276, 803-828, 830-895, 897-964, dogleg_step.hpp:35-101 and
+// pipeline/robust.hpp:78-111 for the prepared GICP / point-to-distribution path): ONE launch, ONE read-back per alignment.
+//
+// The reference drives LM and dog-leg from the host: per outer iteration one search + K11 (submit, wait, toCPU) and per trial
+// step a solve on the host, a K12 launch with two freshly allocated USM vectors, another wait (registration.hpp:674-675,
+// 685-686, 854). Its own example — LM, Geman-McClure, three annealing levels on a 1000-point random sample
+// (example_registration.cpp:29-55) — is about sixty such round trips for work that one compute unit finishes in microseconds.
+//
+// gicp_optimize_kernel is a persistent launch of align_grid(n) workgroups of 1024 lanes. A STEP is a pass over the source:
+//   linearise  fused_point of the per-iteration Gauss-Newton kernel (certificate -> cached correspondence, else exact NN on
+//              the grid; 28 sums + inlier count)                                                -> one partial row per workgroup
+//   trial      error_prepared_point: K12 at the trial pose over the cache rows (frozen correspondences) -> one partial row
+// Between steps every workgroup waits for all rows (arrival counter sharded over 8 lines, one lane polls with sc1 loads and
+// s_sleep, bounded by wall_clock64 — the hand-off of gicp_align_persistent_kernel), sums them in reduce_rows_1024's fixed
+// order and lets ONE lane run the optimiser's state machine (opt_after_*) on LDS: every workgroup takes the same decisions from
+// the same bits, so nothing is broadcast. A launch of ONE workgroup (up to 1024 points: the reference pipeline's default
+// random sample) keeps its totals in LDS and touches no counter.
+// Rows ping-pong by step parity: a workgroup can only write the row of step s + 1 after every workgroup has stored the row
+// of step s, i.e. after every workgroup has finished reading the rows of step s - 1 that it overwrites.
+#include <algorithm>
+
+#include "registration_device.h"
+
+namespace sp {
+namespace {
+
+enum { PHASE_LIN = 0, PHASE_TRIAL = 1 };
+
+struct OptCtl {  // the optimiser's state between steps (LDS, identical in every workgroup)
+    int phase;
+    int done;             // 0 go on, 1 finished, 2 a wait ran out
+    int level, iter, inner;
+    int cache_valid;
+    float lambda, radius;
+    float cur_error, last_error;
+    float predicted, step_norm;  // dog-leg step in flight
+    int conv_ok;          // trial step: success ? is_converged(delta) : false   (registration.hpp:843-847)
+    int conv_any;         // trial step: is_converged(delta)                      (:867, :878, :951)
+    int converged;
+    float res_error;
+    unsigned res_inlier, res_iterations;
+    unsigned n_lin, n_trial, searched, log_n;
+};
+
+struct OptArgs {
+    float* part[2];
+    unsigned* tickets;
+    const float* T_init;          // device: initial guess
+    float* T_out;                 // device: final pose (may alias T_init: it is read before anything is written)
+    sp_opt_params opt;
+    float scales[SP_OPT_MAX_LEVELS];
+    int n_levels;
+    int reuse;                    // later linearisations may trust the correspondence cache
+    sp_align_result* result;
+    unsigned long long budget;    // wall_clock64 ticks a wait may take
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }  // std::clamp
+
+__device__ __forceinline__ bool is_converged6(const float* d, float crit_rot, float crit_trans) {  // registration.hpp:407-410
+    const float nr = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float nt = sqrtf(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    return nr < crit_rot && nt < crit_trans;
+}
+
+struct OptShared {
+    float sT[16];      // current pose (result.T)
+    float sTt[16];     // trial pose
+    float sTlin[16];   // pose of the latest linearisation
+    sp_linearized slin;  // system of the latest linearisation
+    float sdelta[8];
+    LdltScratch ldlt_ws;
+    OptCtl ctl;
+    // what the state machine reads of the launch's arguments (it is a real function: arguments passed by reference would have
+    // to live in scratch memory for the whole kernel)
+    sp_opt_params opt;
+    int n_levels, reuse;
+    sp_align_result* result;
+};
+
+// One LM trial: delta = LDLT(H + lambda I).solve(-b), T_trial = T exp(delta)   (registration.hpp:841-848)
+__device__ __forceinline__ void lm_try(OptShared& S) {
+    const sp_opt_params& o = S.opt;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S.sTt[i] = S.sT[i];
+    gn_update_impl(&S.slin, S.sTt, S.ctl.lambda, o.crit_rotation, o.crit_translation, S.sdelta, false, S.ldlt_ws);
+    S.ctl.conv_ok = S.sdelta[6] > 0.5f ? 1 : 0;
+    S.ctl.conv_any = is_converged6(S.sdelta, o.crit_rotation, o.crit_translation) ? 1 : 0;
+    S.ctl.phase = PHASE_TRIAL;
+}
+
+// An outer iteration has ended (`accepted`: sp_opt_log_entry::accepted): log it; converged or the last iteration ends the
+// level (registration.hpp:266-268); after the last level the launch is done.
+__device__ __forceinline__ void end_outer(OptShared& S, int accepted, unsigned trials, bool publish) {
+    OptCtl& c = S.ctl;
+    const sp_opt_params& o = S.opt;
+    c.res_iterations = (unsigned)c.iter;
+    if (publish && c.log_n < (unsigned)SP_OPT_LOG_ENTRIES) {
+        sp_opt_log_entry e;
+        e.level = (uint16_t)c.level; e.iteration = (uint16_t)c.iter; e.trials = (uint16_t)trials; e.accepted = (uint16_t)accepted;
+        e.damping = o.method == SP_OPT_POWELL_DOGLEG ? c.radius : c.lambda;
+        e.error = c.res_error;
+        S.result->log[c.log_n] = e;
+    }
+    ++c.log_n;
+    if (!c.converged && c.iter + 1 < o.max_iterations) {
+        ++c.iter;
+        c.phase = PHASE_LIN;
+        c.cache_valid = S.reuse;
+        return;
+    }
+    if (c.level + 1 < S.n_levels) {  // the next robust scale: a fresh align() from this pose (pipeline/robust.hpp:100-111)
+        ++c.level;
+        c.iter = 0;
+        c.lambda = o.lm_init_lambda;
+        c.radius = o.dl_initial_radius;
+        c.converged = 0;
+        c.res_error = FLT_MAX;  // RegistrationResult's defaults (result.hpp:12-28)
+        c.res_inlier = 0;
+        c.res_iterations = 0;
+        c.phase = PHASE_LIN;
+        c.cache_valid = S.reuse;  // certificates prove every reused correspondence: the same neighbours as a fresh search
+        return;
+    }
+    c.done = 1;
+}
+
+// After a linearisation step: tot = 28 sums, the uint32 count, the searched count as a float value.
+__device__ __noinline__ void opt_after_linearize(OptShared& S, const float* tot, bool publish) {
+    OptCtl& c = S.ctl;
+    unpack_totals(tot, kAcc - 1, &S.slin);
+    ++c.n_lin;
+    c.searched += (unsigned)tot[kAcc];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S.sTlin[i] = S.sT[i];
+    const sp_opt_params& o = S.opt;
+    if (o.method == SP_OPT_GAUSS_NEWTON) {  // registration.hpp:803-828
+        gn_update_impl(&S.slin, S.sT, o.gn_lambda, o.crit_rotation, o.crit_translation, S.sdelta, false, S.ldlt_ws);
+        c.converged = S.sdelta[6] > 0.5f ? 1 : 0;
+        c.res_error = S.slin.error;
+        c.res_inlier = S.slin.inlier;
+        end_outer(S, 1, 0, publish);
+    } else if (o.method == SP_OPT_LEVENBERG_MARQUARDT) {  // :830-895
+        c.cur_error = S.slin.error;
+        c.last_error = FLT_MAX;
+        c.inner = 0;
+        if (o.lm_max_inner_iterations <= 0) end_outer(S, 0, 0, publish);  // (no trial: result.converged stays false)
+        else lm_try(S);
+    } else {  // :897-964
+        c.res_error = S.slin.error;
+        c.res_inlier = S.slin.inlier;
+        c.cur_error = S.slin.error;
+        c.radius = clampf(c.radius, o.dl_min_radius, o.dl_max_radius);
+        const DoglegStep6 dl = dogleg_step6(S.slin.H, S.slin.b, c.radius, S.ldlt_ws);
+        if (dl.predicted_reduction <= 0.0f) {
+            c.radius = clampf(c.radius * o.dl_gamma_decrease, o.dl_min_radius, o.dl_max_radius);
+            end_outer(S, 0, 0, publish);
+        } else {
+            const Rigid upd = rigid_mul(load_rigid_colmajor(S.sT), se3_exp(dl.p));
+            store_rigid_colmajor(upd, S.sTt);
+            c.conv_any = is_converged6(dl.p, o.crit_rotation, o.crit_translation) ? 1 : 0;
+            c.predicted = dl.predicted_reduction;
+            c.step_norm = dl.step_norm;
+            c.phase = PHASE_TRIAL;
+        }
+    }
+}
+
+// After a trial step: tot[0] = the robust error at the trial pose, tot[1] = the uint32 inlier count.
+__device__ __noinline__ void opt_after_trial(OptShared& S, const float* tot, bool publish) {
+    OptCtl& c = S.ctl;
+    const sp_opt_params& o = S.opt;
+    const float new_error = tot[0];
+    const unsigned inl = __float_as_uint(tot[1]);
+    ++c.n_trial;
+    auto take = [&] {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S.sT[i] = S.sTt[i];
+        c.res_error = new_error;
+        c.res_inlier = inl;
+    };
+    if (o.method == SP_OPT_LEVENBERG_MARQUARDT) {
+        const unsigned tries = (unsigned)c.inner + 1u;
+        if (new_error <= c.cur_error) {  // :866-876
+            c.converged = c.conv_any;
+            take();
+            c.lambda = clampf(c.lambda / o.lm_lambda_factor, o.lm_min_lambda, o.lm_max_lambda);
+            end_outer(S, 1, tries, publish);
+        } else if (fabsf(new_error - c.last_error) <= 1e-6f) {  // :877-884
+            c.converged = c.conv_any;
+            take();
+            end_outer(S, 2, tries, publish);
+        } else {  // :885-889
+            c.lambda = clampf(c.lambda * o.lm_lambda_factor, o.lm_min_lambda, o.lm_max_lambda);
+            c.last_error = new_error;
+            ++c.inner;
+            if (c.inner < o.lm_max_inner_iterations) {
+                lm_try(S);
+            } else {
+                c.converged = c.conv_ok;  // what the last trial left in result.converged (:843-847)
+                end_outer(S, 0, tries, publish);
+            }
+        }
+    } else {  // dog-leg (:936-962)
+        const float rho = (c.cur_error - new_error) / c.predicted;
+        if (rho < o.dl_eta1) {
+            c.radius = clampf(c.radius * o.dl_gamma_decrease, o.dl_min_radius, o.dl_max_radius);
+            end_outer(S, 0, 1, publish);
+        } else {
+            c.converged = c.conv_any;
+            take();
+            if (rho > o.dl_eta2 && c.step_norm >= c.radius * 0.99f)
+                c.radius = clampf(c.radius * o.dl_gamma_increase, o.dl_min_radius, o.dl_max_radius);
+            end_outer(S, 1, 1, publish);
+        }
+    }
+}
+
+// The results (workgroup 0): RegistrationResult of the last level + the linearisation pose + counters.
+__device__ __forceinline__ void opt_publish(float* T_out, const OptShared& S) {
+    sp_align_result* const r = S.result;
+    const OptCtl& c = S.ctl;
+    const unsigned t = threadIdx.x;
+    if (t < 16) { r->T[t] = S.sT[t]; T_out[t] = S.sT[t]; }
+    else if (t < 32) r->T_lin[t - 16] = S.sTlin[t - 16];
+    else if (t >= 64 && t < 100) r->H[t - 64] = S.slin.H[t - 64];
+    else if (t >= 128 && t < 134) r->b[t - 128] = S.slin.b[t - 128];
+    else if (t == 192) {
+        r->error = c.res_error;
+        r->error_raw = S.slin.error;
+        r->inlier = c.res_inlier;
+        r->iterations = c.res_iterations;
+        r->converged = (unsigned)c.converged;
+        r->status = 0u;
+        r->linearizations = c.n_lin;
+        r->trials = c.n_trial;
+        r->searched = c.searched;
+        r->damping = S.opt.method == SP_OPT_POWELL_DOGLEG ? c.radius : c.lambda;
+        r->log_entries = c.log_n < (unsigned)SP_OPT_LOG_ENTRIES ? c.log_n : (unsigned)SP_OPT_LOG_ENTRIES;
+        r->pad[0] = r->pad[1] = r->pad[2] = 0u;
+    }
+}
+
+template <int LOSS, bool FAST_NN, bool P2D>
+__global__ __launch_bounds__(kAlignBlock) void gicp_optimize_kernel(FusedParams P, OptArgs A) {
+    __shared__ OptShared S;
+    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ unsigned s_wait;
+    const unsigned stride = gridDim.x * kAlignBlock;
+    unsigned tile = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const bool single = gridDim.x == 1;
+    const bool publish = blockIdx.x == 0;
+    if (threadIdx.x < 16) {
+        S.sT[threadIdx.x] = A.T_init[threadIdx.x];
+        S.sTlin[threadIdx.x] = A.T_init[threadIdx.x];
+    } else if (threadIdx.x == 32) {
+        OptCtl c;
+        c.phase = PHASE_LIN; c.done = 0; c.level = 0; c.iter = 0; c.inner = 0;
+        c.cache_valid = P.cache_valid;
+        c.lambda = A.opt.lm_init_lambda; c.radius = A.opt.dl_initial_radius;
+        c.cur_error = 0.0f; c.last_error = FLT_MAX; c.predicted = 0.0f; c.step_norm = 0.0f;
+        c.conv_ok = 0; c.conv_any = 0; c.converged = 0;
+        c.res_error = FLT_MAX; c.res_inlier = 0; c.res_iterations = 0;
+        c.n_lin = 0; c.n_trial = 0; c.searched = 0; c.log_n = 0;
+        S.ctl = c;
+        S.opt = A.opt;
+        S.n_levels = A.n_levels;
+        S.reuse = A.reuse;
+        S.result = A.result;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) {
+        reinterpret_cast<float*>(&S.slin)[threadIdx.x - 64] = 0.0f;
+    }
+    __syncthreads();
+    for (unsigned step = 0;; ++step) {
+        const int phase = S.ctl.phase;  // uniform over the grid
+        float* const row = A.part[step & 1] + (size_t)blockIdx.x * kPartial;
+        if (phase == PHASE_LIN) {
+            P.scale = A.scales[S.ctl.level];
+            P.cache_valid = S.ctl.cache_valid;
+            const Rigid T = uniform_pose(S.sT);
+            float acc[kAcc - 1];
+            unsigned cnt = 0, searched = 0;
+#pragma unroll
+            for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
+            for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
+                fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
+            if (single) block_reduce_lds<kAcc - 1, kAlignBlock>(acc, cnt, searched, red[0]);
+            else block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, row, false, searched);
+        } else {
+            const Rigid T = uniform_pose(S.sTt);
+            const Rigid TL = uniform_pose(S.sTlin);
+            float acc[1] = {0.0f};
+            unsigned cnt = 0;
+            for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
+                error_prepared_point<LOSS, P2D>(P, T, TL, i, acc, cnt);
+            if (single) block_reduce_lds<1, kAlignBlock>(acc, cnt, 0u, red[0]);
+            else block_reduce_store<1, kAlignBlock, true>(acc, cnt, row, false, 0u);
+        }
+        if (!single) {
+            // the hand-off of gicp_align_persistent_kernel: wave 0 (the storing lanes) drains its sc1 stores, lane 0 signals
+            if (threadIdx.x < kWave) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (threadIdx.x == 0) {
+                    __hip_atomic_fetch_add(A.tickets + (blockIdx.x & (kTicketShards - 1)) * kTicketStride, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned want = gridDim.x * (step + 1u);
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned flag = 0;
+                    for (;;) {
+                        unsigned have = 0;
+#pragma unroll
+                        for (int sh = 0; sh < kTicketShards; ++sh)
+                            have += __hip_atomic_load(A.tickets + sh * kTicketStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (have >= want) break;
+                        if (wall_clock64() - t0 > A.budget) { flag = 2; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    s_wait = flag;
+                }
+            }
+            __syncthreads();
+            if (s_wait == 2) {  // (uniform per workgroup; every workgroup runs into the same bound) — loud: NaN pose, status 2
+                if (publish) {
+                    if (threadIdx.x < 16) { A.T_out[threadIdx.x] = __int_as_float(0x7fc00000); A.result->T[threadIdx.x] = __int_as_float(0x7fc00000); }
+                    if (threadIdx.x == 16) { A.result->status = 2u; A.result->converged = 0u; A.result->log_entries = 0u; }
+                }
+                return;
+            }
+            reduce_rows_1024<true>(A.part[step & 1], gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1, red, false, [] {});
+        }
+        if (threadIdx.x == 0) {
+            if (phase == PHASE_LIN) opt_after_linearize(S, red[0], publish);
+            else opt_after_trial(S, red[0], publish);
+        }
+        __syncthreads();
+        if (S.ctl.done) {
+            if (publish) opt_publish(A.T_out, S);
+            return;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
+                                     const sp_factor_params* params, const sp_opt_params* opt, const float* robust_scales,
+                                     int n_levels, sp_align_result* result_device, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (!target || !source || !params || !opt || !transT_device || !result_device || !robust_scales) return SP_ERR_INVALID_ARGUMENT;
+    if (n_levels < 1 || n_levels > SP_OPT_MAX_LEVELS) {
+        sp_set_error("[sp_gicp_align_optimize] n_levels must be in 1..SP_OPT_MAX_LEVELS");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (opt->method != SP_OPT_GAUSS_NEWTON && opt->method != SP_OPT_LEVENBERG_MARQUARDT && opt->method != SP_OPT_POWELL_DOGLEG) {
+        sp_set_error("[sp_gicp_align_optimize] unknown optimization method");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (opt->max_iterations < 1 || opt->max_iterations > 65535) {
+        sp_set_error("[sp_gicp_align_optimize] max_iterations must be in 1..65535 (0 iterations: the result is the initial guess)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (const int rc = check_prepared_reg("align_optimize", target, params); rc != SP_OK) return rc;
+    const size_t n = source->n;
+    if (n == 0) {
+        sp_set_error("[sp_gicp_align_optimize] empty source (Registration::align returns the initial guess)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (!workspace || workspace_bytes < sp_gicp_workspace_bytes(n)) {
+        sp_set_error("[Registration] workspace too small (sp_gicp_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    if (source->opt_persistent == 0) {
+        sp_set_error("[sp_gicp_align_optimize] not available: persistent launches are switched off for this source "
+                     "(sp_gicp_source_set_persistent)");
+        return SP_ERR_RUNTIME;
+    }
+    const unsigned grid = align_grid(n);
+    PersistGuard* const guard = persist_acquire(st, grid);
+    if (!guard) {
+        sp_set_error("[sp_gicp_align_optimize] not available now: the launch cannot be resident (grid larger than the device, stream "
+                     "capturing, or another stream's persistent launch still running)");
+        return SP_ERR_RUNTIME;
+    }
+    struct Release {
+        PersistGuard* g; hipStream_t st;
+        ~Release() { persist_release(g, st); }
+    } release{guard, st};
+    OptArgs A;
+    float* const rows = static_cast<float*>(workspace);
+    A.part[0] = rows;
+    A.part[1] = rows + (size_t)kAlignMaxBlocks * kPartial;
+    A.tickets = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kTicketOffsetBytes);
+    if (grid > 1 && zero_async(A.tickets, kTicketShards * kTicketStride * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
+    target->note(st);
+    FusedParams P = make_fused_params(target, source, params, transT_device, 1, nullptr, nullptr);
+    A.T_init = transT_device;
+    A.T_out = transT_device;
+    A.opt = *opt;
+    for (int l = 0; l < SP_OPT_MAX_LEVELS; ++l) A.scales[l] = robust_scales[l < n_levels ? l : n_levels - 1];
+    A.n_levels = n_levels;
+    A.reuse = (source->opt_reuse && P.ccache != nullptr) ? 1 : 0;
+    A.result = result_device;
+    A.budget = 50ull * 100000ull;  // 50 ms of wall_clock64 (100 MHz) per wait
+    if (P.ccache == nullptr) {  // (a target without certificates has no cache rows: the trial steps read them)
+        sp_set_error("[sp_gicp_align_optimize] the prepared target has no reuse certificates");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
+    const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
+#define SP_LAUNCH_OPT(L)                                                                           \
+    if (fast && p2d) gicp_optimize_kernel<L, true, true><<<grid, kAlignBlock, 0, st>>>(P, A);       \
+    else if (fast) gicp_optimize_kernel<L, true, false><<<grid, kAlignBlock, 0, st>>>(P, A);        \
+    else if (p2d) gicp_optimize_kernel<L, false, true><<<grid, kAlignBlock, 0, st>>>(P, A);         \
+    else gicp_optimize_kernel<L, false, false><<<grid, kAlignBlock, 0, st>>>(P, A)
+    switch (params->robust_type) {
+        case SP_LOSS_NONE: SP_LAUNCH_OPT(LOSS_NONE); break;
+        case SP_LOSS_HUBER: SP_LAUNCH_OPT(LOSS_HUBER); break;
+        case SP_LOSS_TUKEY: SP_LAUNCH_OPT(LOSS_TUKEY); break;
+        case SP_LOSS_CAUCHY: SP_LAUNCH_OPT(LOSS_CAUCHY); break;
+        case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_OPT(LOSS_GEMAN_MCCLURE); break;
+        default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
+    }
+#undef SP_LAUNCH_OPT
+    source->cache_valid = true;
+    return launch_status();
+}

@@ -46,7 +46,7 @@ void orc_cov_estimate_robust(const float* pts, size_t n, const int32_t* idx, siz
 void orc_registration_align(const orc_reg_params* P, const float* src, const float* src_cov, size_t ns, const float* tgt,
                             const float* tgt_cov, const float* tgt_nrm, size_t nt, const float* init_T16, int nn_mode,
                             orc_reg_result* out, float* trace_T, int* trace_n, const void* prebuilt_nodes,
-                            size_t prebuilt_n_nodes);
+                            size_t prebuilt_n_nodes, float* trace_steps, int trace_steps_capacity, int* trace_steps_n);
 void orc_se3_exp(const float* twist6, float* T16);
 int orc_map_prior_update(const float* sig4, const float* H_raw36, float error_raw, uint32_t inlier, const float* T_prev16,
                          const float* T_pred16, float* omega36, float* T_pred_inv16);
@@ -337,7 +337,7 @@ static void registration_matches_oracle() {
     orc_registration_align(&op, reinterpret_cast<const float*>(source.points->data()),
                            reinterpret_cast<const float*>(source.covs->data()), n,
                            reinterpret_cast<const float*>(target.points->data()),
-                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr, nullptr, 0);
+                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
     auto tree = alg::knn::KDTree::build(*Q, target);
     auto grid = alg::knn::GridKNN::build(*Q, target);
     HostBruteForceKNN host_knn(*Q, target);
@@ -366,7 +366,7 @@ static void registration_matches_oracle() {
         orc_registration_align(&opc, reinterpret_cast<const float*>(source.points->data()),
                                reinterpret_cast<const float*>(source.covs->data()), n,
                                reinterpret_cast<const float*>(target.points->data()),
-                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &refc, nullptr, nullptr, nullptr, 0);
+                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &refc, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
         alg::registration::Registration regc(*Q, pc);
         const auto rc = regc.align(source, target, *grid);
         CHECK(rc.converged && refc.converged);
@@ -419,7 +419,7 @@ static void registration_matches_oracle() {
         orc_registration_align(&opd, reinterpret_cast<const float*>(source.points->data()),
                                reinterpret_cast<const float*>(source.covs->data()), n,
                                reinterpret_cast<const float*>(target.points->data()),
-                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &refd, nullptr, nullptr, nullptr, 0);
+                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &refd, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
         alg::registration::Registration regd(*Q, pd);
         const auto rd = regd.align(source, target, *tree);
         CHECK(max_abs_diff(rd.T.matrix(), refd.T) < 1e-5f);
@@ -467,7 +467,7 @@ static void registration_matches_oracle() {
         orc_registration_align(&ot, reinterpret_cast<const float*>(source.points->data()),
                                reinterpret_cast<const float*>(source.covs->data()), n,
                                reinterpret_cast<const float*>(target.points->data()),
-                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, Tp.data(), 0, &reft, nullptr, nullptr, nullptr, 0);
+                               reinterpret_cast<const float*>(target.covs->data()), nullptr, n, Tp.data(), 0, &reft, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
         CHECK(max_abs_diff(rt.T.matrix(), reft.T) < 1e-5f);
         CHECK(rt.inlier == reft.inlier && (int)rt.iterations == reft.iterations);
         CHECK(rt.H(0, 0) - rt.H_raw(0, 0) > 0.9f * 0.25f * float(rt.inlier));  // penalty (+ prior) in H, not in H_raw
@@ -495,7 +495,7 @@ static void registration_matches_oracle() {
     orc_registration_align(&op2, reinterpret_cast<const float*>(source.points->data()),
                            reinterpret_cast<const float*>(source.covs->data()), n,
                            reinterpret_cast<const float*>(target.points->data()),
-                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr, nullptr, 0);
+                           reinterpret_cast<const float*>(target.covs->data()), nullptr, n, I.data(), 0, &ref, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
     CHECK(max_abs_diff(r_pipe.T.matrix(), ref.T) < 1e-5f);
     // validate_params (registration.hpp:144-150)
     PointCloudShared nocov(*Q, tc);

@@ -1,0 +1,180 @@
+"""The device-resident optimiser loop (sp_gicp_align_optimize, csrc/registration_opt.hip): Registration::align for GN / LM /
+Powell dog-leg (registration.hpp:201-276, 803-964) and pipeline::RobustAligner's annealing levels (pipeline/robust.hpp:78-111)
+as ONE launch and ONE read-back. Checker: the oracle's align() / align_robust_annealing() on the same clouds — final pose to
+1e-5, the same iteration count / convergence flag / inliers, and the same SEQUENCE of optimiser decisions (trial evaluations
+and accepted / rejected per outer iteration). One workgroup (the reference pipeline's 1000-point sample), several workgroups
+(arrival counter between steps), and the host-driven loop of the same library beside it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def sp():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    import sycl_points_amd.api as api
+
+    return api
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def inputs(orc, n, density_scale=1.0, seed=1234):
+    from sycl_points_amd.synthetic import gicp_pair
+
+    r = 10.0 * (n * density_scale / 1e6) ** (1.0 / 3.0)
+    src, tgt, T_gt = gicp_pair(n, r, seed)
+    ti, _ = orc.kdtree_knn(orc.kdtree_build(tgt), tgt, 20)
+    si, _ = orc.kdtree_knn(orc.kdtree_build(src), src, 20)
+    return src, orc.cov_estimate(src, si), tgt, orc.cov_estimate(tgt, ti), T_gt
+
+
+@pytest.fixture(scope="module", params=[(900, 8.0), (20000, 1.0), (20000, 8.0)],
+                ids=["one-workgroup-900", "20k-config4-density", "20k-sparse"])
+def clouds(orc, request):
+    n, d = request.param
+    return inputs(orc, n, d)
+
+
+CASES = [
+    dict(opt="LM", reg_type="GICP", loss="GEMAN_MCCLURE", scale=0.5),   # BASELINE config 1's optimiser + kernel
+    dict(opt="LM", reg_type="POINT_TO_DISTRIBUTION", loss="NONE", scale=10.0),
+    dict(opt="LM", reg_type="GICP", loss="HUBER", scale=0.5),
+    dict(opt="LM", reg_type="GICP", loss="NONE", scale=10.0),
+    dict(opt="DOGLEG", reg_type="GICP", loss="NONE", scale=10.0),
+    dict(opt="DOGLEG", reg_type="POINT_TO_DISTRIBUTION", loss="NONE", scale=10.0),
+    dict(opt="DOGLEG", reg_type="GICP", loss="CAUCHY", scale=0.3),
+    dict(opt="GN", reg_type="POINT_TO_DISTRIBUTION", loss="CAUCHY", scale=0.3),
+    dict(opt="GN", reg_type="GICP", loss="NONE", scale=10.0),
+]
+
+
+def oracle_params(case, **kw):
+    from oracle.pyoracle import LOSS, OPT, REG, RegParams
+
+    return RegParams.defaults(reg_type=REG[case["reg_type"]], robust_type=LOSS[case["loss"]], robust_default_scale=case["scale"],
+                              optimization_method=OPT[case["opt"]], **kw)
+
+
+def check_against_oracle(res, ref, case, levels=1):
+    assert np.abs(res.T - ref["T"]).max() < 1e-5, (case, np.abs(res.T - ref["T"]).max())
+    # The optimisers branch on float comparisons (LM: new_error <= current_error; dog-leg: rho against eta1 / eta2). The oracle's
+    # trace says how far each iteration's closest decision was from its threshold: wherever that margin is outside rounding
+    # (the K11 / K12 sums of the two implementations agree to ~1e-5 relative) the decisions have to be the oracle's; at the
+    # first iteration decided inside rounding (two errors of a converged alignment that differ in the last bits) the branch may
+    # differ and everything after it with it — the pose bound above holds regardless.
+    got = [(e["trials"], e["accepted"]) for e in res.log]
+    want = [(s["trials"], s["accepted"]) for s in ref["steps"]]
+    tol = 2e-4  # relative change of an error sum that would flip the closest decision
+    decided = next((i for i, s in enumerate(ref["steps"]) if s["margin"] < tol), len(want))
+    assert got[:decided] == want[:decided], (case, got, want, decided)
+    for e, s in zip(res.log[:decided], ref["steps"][:decided]):
+        assert abs(e["damping"] - s["damping"]) <= 1e-6 * abs(s["damping"]), (case, e, s)
+        assert abs(e["error"] - s["error"]) <= 2e-4 * abs(s["error"]), (case, e, s)
+    if decided == len(want):
+        assert got == want
+        assert res.converged == ref["converged"] and res.iterations == ref["iterations"], case
+        assert res.inlier == ref["inlier"]
+        assert abs(res.error - ref["error"]) <= 2e-4 * abs(ref["error"])
+        assert res.linearizations == len(want) and res.trials == sum(t for t, _ in want)
+    assert decided >= min(2, len(want)), "a test case whose FIRST decisions are inside rounding checks nothing: pick another"
+    assert max(e["level"] for e in res.log) == levels - 1
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['opt']}-{c['reg_type']}-{c['loss']}")
+def test_device_resident_optimiser_matches_oracle(sp, orc, clouds, case):
+    src, scov, tgt, tcov, T_gt = clouds
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs, reg_type=case["reg_type"])
+    T0 = orc.se3_exp([0.01, -0.005, 0.02, 0.05, -0.04, 0.03])
+    p = sp.RegistrationParams(reg_type=case["reg_type"], robust_type=case["loss"], robust_default_scale=case["scale"],
+                              optimization_method=case["opt"], max_iterations=25)
+    ref = orc.registration_align(oracle_params(case, max_iterations=25), src, scov, tgt, tcov, init_T=T0, steps=True)
+    reg = sp.Registration(p)
+    res = reg.align_optimize(S, prep, T0, [case["scale"]])
+    assert res is not None, "the persistent launch must be available on an idle MI355X"
+    check_against_oracle(res, ref, case)
+    # the same alignment through the host-driven loop of the library (one read-back per step): same decisions, same pose
+    host = sp.Registration(p).align_prepared(S, prep, initial_guess=T0, device_resident=False)
+    assert np.abs(host.T - res.T).max() < 2e-6 and host.iterations == res.iterations and host.converged == res.converged
+    assert host.inlier == res.inlier
+    # and align_prepared takes the device-resident loop by default
+    again = sp.Registration(p).align_prepared(S, prep, initial_guess=T0)
+    assert hasattr(again, "log") and np.array_equal(again.T, res.T)
+
+
+@pytest.mark.parametrize("opt", ["LM", "DOGLEG", "GN"])
+@pytest.mark.parametrize("n", [1000, 30000])
+def test_annealing_levels_in_one_launch(sp, orc, opt, n):
+    """The reference example's registration stage (example_registration.cpp:29-55): Geman-McClure, robust scale annealed
+    10 -> 5 -> 2.5 over three levels, each level one align() of at most 10 iterations starting from the previous level's pose."""
+    src, scov, tgt, tcov, T_gt = inputs(orc, n, 8.0, seed=99)
+    case = dict(opt=opt, reg_type="GICP", loss="GEMAN_MCCLURE", scale=10.0)
+    ref = orc.registration_align(oracle_params(case, max_iterations=10, auto_scale=1, auto_scaling_iter=3, init_scale=10.0,
+                                               min_scale=2.5), src, scov, tgt, tcov, steps=True)
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    Tg = sp.PointCloudShared(dev(tgt), covs=dev(tcov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(Tg.points), Tg.covs)
+    p = sp.RegistrationParams(robust_type="GEMAN_MCCLURE", optimization_method=opt, max_iterations=10)
+    scales = [float(s) for s in orc.robust_annealing_scales("GEMAN_MCCLURE", True, 10.0, 10.0, 2.5, 3)]
+    assert len(scales) == 3 and abs(scales[1] - 5.0) < 1e-5
+    res = sp.Registration(p).align_optimize(S, prep, None, scales)
+    assert res is not None
+    check_against_oracle(res, ref, case, levels=3)
+    assert np.abs(res.T - T_gt).max() < 2e-3
+    # level by level through separate calls (what RobustAligner does around a generic aligner): the same pose
+    T = None
+    for s in scales:
+        step = sp.Registration(p).align_optimize(S, prep, T, [s])
+        T = step.T
+    assert np.abs(T - res.T).max() < 2e-6
+
+
+def test_optimiser_result_block_and_frozen_error(sp, orc):
+    """sp_align_result carries what Registration::compute_error_frozen needs after align(): the pose of the last
+    linearisation; the correspondence cache is frozen at it."""
+    src, scov, tgt, tcov, _ = inputs(orc, 5000, 8.0)
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(dev(tgt)), dev(tcov))
+    p = sp.RegistrationParams(optimization_method="LM", max_iterations=6, criteria_rotation=0.0, criteria_translation=0.0)
+    reg = sp.Registration(p)
+    res = reg.align_optimize(S, prep, None)
+    assert res.iterations == 5 and not res.converged and res.linearizations == 6
+    L = sp._lib.lib()
+    ws, lin = reg._buffers(S.points.device)
+    fp = reg._factor_params(p.robust_default_scale)
+    Tl = np.ascontiguousarray(res.T_lin.T).reshape(-1)
+    Tt = np.ascontiguousarray(res.T.T).reshape(-1)
+    sp.check(L.sp_gicp_error_prepared(prep._h, reg._psrc._h, Tl.ctypes.data_as(C.c_void_p), Tt.ctypes.data_as(C.c_void_p), 0,
+                                      C.byref(fp), sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+    got = reg._read_lin(lin)
+    # the last accepted trial evaluated exactly this: error at the final pose over the correspondences of the last linearisation
+    last = res.log[-1]
+    assert last["accepted"] in (1, 2) and got.inlier == res.inlier and abs(got.error - res.error) <= 1e-6 * abs(res.error)
+
+
+def test_optimiser_argument_errors_and_switch(sp, orc):
+    src, scov, tgt, tcov, _ = inputs(orc, 3000, 8.0)
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(dev(tgt)), dev(tcov))
+    reg = sp.Registration(sp.RegistrationParams(optimization_method="LM", max_iterations=5))
+    with pytest.raises(sp.SpError):
+        reg.align_optimize(S, prep, None, [1.0] * 9)  # more levels than SP_OPT_MAX_LEVELS
+    ok = reg.align_optimize(S, prep, None)
+    assert ok is not None
+    # persistent launches switched off for this source: "not available", the caller's per-step loop takes over
+    L = sp._lib.lib()
+    sp.check(L.sp_gicp_source_set_persistent(reg._psrc._h, 0))
+    assert reg.align_optimize(S, prep, None) is None
+    res = reg.align_prepared(S, prep)  # falls back to the host-driven loop, same answer
+    assert np.abs(res.T - ok.T).max() < 2e-6 and res.iterations == ok.iterations
+    sp.check(L.sp_gicp_source_set_persistent(reg._psrc._h, 1))
+    assert reg.align_optimize(S, prep, None) is not None
