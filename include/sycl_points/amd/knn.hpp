@@ -384,8 +384,19 @@ public:
                      float cell_size = 0.0f) {
         auto g = std::make_shared<GridKNN>(q);
         throw_on_error(sp_grid_create(cloud.points_device(), cloud.size(), cell_size, points_per_cell, q.stream(), &g->grid_));
+        g->id_ = next_grid_id();
+        return g;
+    }
+    static uint64_t next_grid_id() {
         static std::atomic<uint64_t> next_id{1};
-        g->id_ = next_id.fetch_add(1);
+        return next_id.fetch_add(1);
+    }
+    /// Cell size steered by the measured occupancy instead of the bounding-box volume (sp_grid_create_adaptive): for clouds of
+    /// surfaces — what Registration::align builds when it stands in for the caller's KDTree.
+    static Ptr build_adaptive(const sycl_utils::DeviceQueue& q, const PointCloudShared& cloud, float points_per_cell = 0.5f) {
+        auto g = std::make_shared<GridKNN>(q);
+        throw_on_error(sp_grid_create_adaptive(cloud.points_device(), cloud.size(), points_per_cell, q.stream(), &g->grid_));
+        g->id_ = next_grid_id();
         return g;
     }
     const sp_grid* handle() const { return grid_; }

@@ -12,6 +12,8 @@
 #include <cctype>
 #include <cstring>
 #include <functional>
+#include <optional>
+#include <vector>
 #include <iostream>
 #include <tuple>
 
@@ -154,12 +156,13 @@ public:
         hip_check(hipMalloc(&T_dev_, (16 + 8 + 4) * sizeof(float)), "hipMalloc");  // pose | delta[8] | iterations
         // read-backs (one 192-byte system or one error per optimiser step) land in pinned memory: a copy into pageable memory
         // is staged and blocks inside the runtime (2.24 -> 1.94 ms for the LM alignment of the reference's example)
-        hip_check(hipHostMalloc(&pin_, 512), "hipHostMalloc");
+        hip_check(hipHostMalloc(&pin_, 4096), "hipHostMalloc");
+        hip_check(hipMalloc(&res_dev_, sizeof(sp_align_result)), "hipMalloc");
     }
     ~Registration() {
         if (psrc_) sp_gicp_source_destroy(psrc_);
         if (ptgt_) sp_gicp_target_destroy(ptgt_);
-        (void)hipFree(lin_dev_); (void)hipFree(ws_); (void)hipFree(T_dev_);
+        (void)hipFree(lin_dev_); (void)hipFree(ws_); (void)hipFree(T_dev_); (void)hipFree(res_dev_);
         if (pin_) (void)hipHostFree(pin_);
     }
     Registration(const Registration&) = delete;
@@ -244,8 +247,19 @@ public:
         // GICP + Gauss-Newton on a GridKNN: the whole loop runs on the device (one launch per iteration, convergence
         // test included), the host reads the result back once — same arithmetic as the loop below.
         // (the host-side pose terms — degenerate regularisation, MAP prior — need the reduced system on the host)
-        if (fused && params_.optimization_method == OptimizationMethod::GAUSS_NEWTON && !params_.verbose &&
-            params_.max_iterations > 0 && !pose_terms)
+        const bool on_device = fused && !params_.verbose && params_.max_iterations > 0 && !pose_terms;
+        const bool sharded = comm_ != nullptr || xchg_ != nullptr;
+        // Every optimiser as ONE launch that loops on the device and ONE read-back (sp_gicp_align_optimize): LM and dog-leg always
+        // (the reference crosses host <-> device 2 + inner tries times per iteration, registration.hpp:830-964), Gauss-Newton when
+        // the source fits one workgroup (the pipeline's default 1000-point sample: no launch per iteration, no counter between
+        // steps). std::nullopt: the launch is not available now, or its bounded wait ran out — the loops below take over.
+        if (on_device && !sharded &&
+            (params_.optimization_method != OptimizationMethod::GAUSS_NEWTON || source.size() <= 1024)) {
+            const float scales[1] = {robust_scale};
+            if (auto r = align_optimize_on_device(initial_guess, scales, 1)) return *r;
+            prepare_fused(source, target, *grid, initial_guess);  // (the correspondence cache of the abandoned launch is stale)
+        }
+        if (on_device && params_.optimization_method == OptimizationMethod::GAUSS_NEWTON)
             return align_on_device(source.size(), initial_guess, robust_scale);
         if (comm_ != nullptr || xchg_ != nullptr)
             throw std::runtime_error("[Registration::align] a communicator is set: only the device-resident Gauss-Newton loop "
@@ -268,6 +282,42 @@ public:
                     break;
             }
             if (result.converged) break;
+        }
+        return result;
+    }
+
+    /// MI355X extension: pipeline::RobustAligner's annealing loop (pipeline/robust.hpp:100-111) — one align() per robust scale,
+    /// each starting from the pose the previous one ended on — with all levels in ONE launch and ONE read-back when align()
+    /// would run on the device-resident optimiser (GICP / POINT_TO_DISTRIBUTION on a GridKNN or an accelerated KDTree, no
+    /// rotation constraint, no host-side pose terms, not verbose); level by level through align() otherwise. Returns the last
+    /// level's result, like the reference's loop.
+    RegistrationResult align_levels(const PointCloudShared& source, const PointCloudShared& target, const knn::KNNBase& target_knn,
+                                    const TransformMatrix& initial_guess, const ExecutionOptions& options,
+                                    const std::vector<float>& robust_scales, const std::vector<float>& rotation_robust_scales) {
+        RegistrationResult result;
+        result.T.matrix() = initial_guess;
+        if (source.size() == 0 || robust_scales.empty()) return result;
+        const bool pose_terms = params_.degenerate_reg.type != DegenerateRegularizationType::none || prior_active();
+        const bool candidate = robust_scales.size() > 1 && robust_scales.size() <= size_t(SP_OPT_MAX_LEVELS) && !params_.verbose &&
+                               params_.max_iterations > 0 && !pose_terms && comm_ == nullptr && xchg_ == nullptr &&
+                               !params_.rotation_constraint.enable &&
+                               (params_.reg_type == RegType::GICP || params_.reg_type == RegType::POINT_TO_DISTRIBUTION);
+        if (candidate) {
+            validate_params(source, target, params_);
+            const auto* grid = dynamic_cast<const knn::GridKNN*>(&target_knn);
+            if (grid == nullptr && accelerate_kdtree_)
+                if (const auto* kd = dynamic_cast<const knn::KDTree*>(&target_knn)) grid = grid_for(*kd, target);
+            if (grid != nullptr && grid->size() == target.size() && params_.robust.type != robust::RobustLossType::NONE) {
+                fused_loop_active_ = true;
+                prepare_fused(source, target, *grid, initial_guess);
+                if (auto r = align_optimize_on_device(initial_guess, robust_scales.data(), (int)robust_scales.size())) return *r;
+            }
+        }
+        for (size_t level = 0; level < robust_scales.size(); ++level) {  // pipeline/robust.hpp:100-111
+            ExecutionOptions o = options;
+            o.robust_scale = robust_scales[level];
+            o.rotation_robust_scale = level < rotation_robust_scales.size() ? rotation_robust_scales[level] : options.rotation_robust_scale;
+            result = align(source, target, target_knn, result.T.matrix(), o);
         }
         return result;
     }
@@ -344,6 +394,8 @@ public:
         queue_.wait();
     }
     const RegistrationParams& params() const { return params_; }
+    /// MI355X extension: steps the latest device-resident optimiser run executed (linearisations, trial evaluations)
+    std::pair<uint32_t, uint32_t> last_optimizer_steps() const { return {last_opt_linearizations_, last_opt_trials_}; }
 
 private:
     sp_factor_params factor_params(float robust_scale) const {
@@ -452,7 +504,9 @@ private:
             throw_on_error(sp_gicp_source_create(source.size(), &psrc_));
             psrc_cap_ = source.size();
         }
-        throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, source.points_device(), source.covs_device(), source.size(),
+        last_src_points_ = source.points_device();
+        last_src_covs_ = source.covs_device();
+        throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, last_src_points_, last_src_covs_, source.size(),
                                               T0.data(), 0, source_presorted_ ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT, queue_.stream()));
         neighbors_.indices == nullptr ? neighbors_.allocate(queue_, source.size(), 1) : neighbors_.resize(source.size(), 1);
     }
@@ -464,6 +518,51 @@ private:
             kd_grid_tree_id_ = tree.id();
         }
         return kd_grid_.get();
+    }
+    sp_opt_params opt_params() const {
+        return sp_opt_params{int(params_.optimization_method) == int(OptimizationMethod::GAUSS_NEWTON)          ? SP_OPT_GAUSS_NEWTON
+                             : int(params_.optimization_method) == int(OptimizationMethod::LEVENBERG_MARQUARDT) ? SP_OPT_LEVENBERG_MARQUARDT
+                                                                                                                 : SP_OPT_POWELL_DOGLEG,
+                             (int)params_.max_iterations, params_.criteria.rotation, params_.criteria.translation, params_.gn.lambda,
+                             (int)params_.lm.max_inner_iterations, params_.lm.lambda_factor, params_.lm.init_lambda,
+                             params_.lm.max_lambda, params_.lm.min_lambda, params_.dogleg.initial_trust_region_radius,
+                             params_.dogleg.min_trust_region_radius, params_.dogleg.max_trust_region_radius, params_.dogleg.eta1,
+                             params_.dogleg.eta2, params_.dogleg.gamma_decrease, params_.dogleg.gamma_increase};
+    }
+    /// The prepared source / target are in place (prepare_fused): the whole optimiser loop — every level of `scales` — as one
+    /// launch (sp_gicp_align_optimize) and one read-back. std::nullopt when the launch cannot be resident now or its bounded wait
+    /// ran out (sp_align_result::status): the caller runs its per-step loop from the initial guess.
+    std::optional<RegistrationResult> align_optimize_on_device(const TransformMatrix& initial_guess, const float* scales, int levels) {
+        const sp_factor_params fp = factor_params(scales[0]);
+        const sp_opt_params op = opt_params();
+        hip_check(hipMemcpyAsync(T_dev_, initial_guess.data(), 16 * sizeof(float), hipMemcpyHostToDevice, queue_.stream()), "H2D");
+        const int rc = sp_gicp_align_optimize(ptgt_, psrc_, T_dev_, &fp, &op, scales, levels, res_dev_, ws_, ws_bytes_, queue_.stream());
+        if (rc == SP_ERR_RUNTIME && std::strstr(sp_last_error(), "not available") != nullptr) return std::nullopt;
+        throw_on_error(rc);
+        sp_align_result* const h = reinterpret_cast<sp_align_result*>(static_cast<char*>(pin_) + 1024);
+        hip_check(hipMemcpyAsync(h, res_dev_, sizeof *h, hipMemcpyDeviceToHost, queue_.stream()), "D2H");
+        hip_check(hipStreamSynchronize(queue_.stream()), "sync");
+        if (h->status != 0) {  // not every workgroup of the launch was resident (another process / a CU mask holds compute units)
+            throw_on_error(sp_gicp_source_set_persistent(psrc_, 0));  // this source: per-step launches from now on
+            return std::nullopt;
+        }
+        RegistrationResult result;
+        TransformMatrix T;
+        for (int i = 0; i < 16; ++i) { T.data()[i] = h->T[i]; lin_T_.data()[i] = h->T_lin[i]; }
+        last_lin_fused_ = true;
+        result.T.matrix() = T;
+        result.iterations = h->iterations;
+        result.converged = h->converged != 0;
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) result.H(i, j) = h->H[i * 6 + j];
+            result.b(i) = h->b[i];
+        }
+        result.error = h->error;
+        result.inlier = h->inlier;
+        result.H_raw = result.H; result.b_raw = result.b; result.error_raw = h->error_raw;
+        last_opt_linearizations_ = h->linearizations;
+        last_opt_trials_ = h->trials;
+        return result;
     }
     RegistrationResult align_on_device(size_t N, const TransformMatrix& initial_guess, float robust_scale) {
         const sp_factor_params fp = factor_params(robust_scale);
@@ -498,6 +597,20 @@ private:
         result.T.matrix() = T;
         uint32_t iters;
         std::memcpy(&iters, &host[24], sizeof iters);
+        if (iters == 0xffffffffu) {
+            // the device-side tail of sp_gicp_align_fused ran into its bounded wait (not every workgroup was resident: another
+            // process or a CU mask holds compute units) and left a NaN pose: once more from the initial guess, a launch per
+            // iteration, and this prepared source stays on that form
+            throw_on_error(sp_gicp_source_set_persistent(psrc_, 0));
+            if (retried_without_persistent_)
+                throw std::runtime_error("[Registration::align] the device-resident loop ran into its time limit");
+            retried_without_persistent_ = true;
+            throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, last_src_points_, last_src_covs_, N, initial_guess.data(), 0,
+                                                  source_presorted_ ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT, queue_.stream()));
+            const RegistrationResult again = align_on_device(N, initial_guess, robust_scale);
+            retried_without_persistent_ = false;
+            return again;
+        }
         result.iterations = iters > 0 ? iters - 1 : 0;  // index of the last iteration (registration.hpp:822)
         result.converged = host[16 + 6] > 0.5f;
         result.H = lin.H; result.b = lin.b; result.error = lin.error; result.inlier = lin.inlier;
@@ -633,7 +746,9 @@ private:
     void* ws_ = nullptr;
     size_t ws_bytes_ = 0;
     float* T_dev_ = nullptr;
-    void* pin_ = nullptr;  // 512 bytes of pinned host memory: [0, 256) linear system, [256, 432) pose | delta | iterations | T_lin
+    void* pin_ = nullptr;  // 4 KB of pinned host memory: [0, 256) linear system, [256, 432) pose | delta | iterations | T_lin,
+                           // [1024, 1024 + sizeof(sp_align_result)) the result block of the device-resident optimiser
+    sp_align_result* res_dev_ = nullptr;
     float genz_alpha_ = 1.0f;
     mutable float rotation_robust_scale_ = 10.0f;  // resolved per call from ExecutionOptions (registration.hpp:219-221)
     sp_map_prior_state map_prior_{};               // MapPrior state (map_prior.hpp:203-210)
@@ -651,6 +766,10 @@ private:
     mutable bool fused_loop_active_ = false;  // align() is running its optimiser loop on the prepared path
     mutable bool last_lin_fused_ = false;     // the last linearisation left its correspondences in the prepared source's cache
     TransformMatrix lin_T_ = TransformMatrix::Identity();  // pose of the last fused linearisation
+    const float* last_src_points_ = nullptr;  // device pointers of the source of the latest prepare_fused (valid during align())
+    const float* last_src_covs_ = nullptr;
+    bool retried_without_persistent_ = false;
+    uint32_t last_opt_linearizations_ = 0, last_opt_trials_ = 0;  // steps of the latest device-resident optimiser run
     knn::GridKNN::Ptr kd_grid_;        // GridKNN standing in for the caller's KDTree (grid_for)
     uint64_t kd_grid_tree_id_ = 0;
 };
@@ -691,6 +810,12 @@ public:
     using Ptr = std::shared_ptr<RobustAligner>;
     RobustAligner(RegistrationAligner aligner, const RegistrationPipelineParams& p)
         : aligner_(std::move(aligner)), params_(p.registration), sched_(p.robust) {}
+    /// pipeline/robust.hpp:32-33. With the backend known, the levels go to Registration::align_levels: one launch, one
+    /// read-back for the whole schedule where the device-resident optimiser applies, the same loop as below otherwise.
+    RobustAligner(const Registration::Ptr& registration, const RegistrationPipelineParams& p)
+        : RobustAligner(make_registration_aligner(registration), p) {
+        registration_ = registration;
+    }
     RegistrationResult align(const PointCloudShared& source, const PointCloudShared& target, const knn::KNNBase& knn,
                              const TransformMatrix& initial_guess = TransformMatrix::Identity(),
                              const Registration::ExecutionOptions& options = Registration::ExecutionOptions()) const {
@@ -712,6 +837,16 @@ public:
                               : (autos ? sched_.rotation_init_scale : params_.rotation_constraint.robust.default_scale);
         const float rot_factor =
             levels > 1 ? std::pow(sched_.rotation_min_scale / sched_.rotation_init_scale, 1.0f / static_cast<float>(levels - 1)) : 1.0f;
+        if (registration_ != nullptr) {
+            std::vector<float> scales, rot_scales;
+            for (size_t level = 0; level < levels; ++level) {
+                scales.push_back(scale);
+                rot_scales.push_back(rot_scale);
+                scale *= factor;
+                rot_scale *= rot_factor;
+            }
+            return registration_->align_levels(source, target, knn, initial_guess, options, scales, rot_scales);
+        }
         for (size_t level = 0; level < levels; ++level) {
             auto o = options;
             o.robust_scale = scale;
@@ -731,6 +866,7 @@ private:
     RegistrationAligner aligner_;
     RegistrationParams params_;
     RegistrationRobustScheduleParams sched_;
+    Registration::Ptr registration_;  // set when the wrapped aligner IS a Registration backend
 };
 }  // namespace pipeline
 
@@ -744,8 +880,8 @@ public:
         wrap_aligner();
     }
     RegistrationPipeline(const Registration::Ptr& registration, const RegistrationPipelineParams& p = RegistrationPipelineParams())
-        : RegistrationPipeline(pipeline::make_registration_aligner(registration), p) {
-        registration_ = registration;
+        : params_(p), registration_(registration), aligner_(pipeline::make_registration_aligner(registration)) {
+        wrap_aligner();
     }
     RegistrationPipeline(const sycl_utils::DeviceQueue& queue, const RegistrationPipelineParams& p = RegistrationPipelineParams())
         : RegistrationPipeline(std::make_shared<Registration>(queue, p.registration), p) {}
@@ -781,7 +917,9 @@ public:
 private:
     void wrap_aligner() {  // registration_pipeline.hpp:100-119 (robust wrapper outermost)
         if (params_.robust.auto_scale) {
-            robust_ = std::make_shared<pipeline::RobustAligner>(aligner_, params_);
+            // (no velocity-update wrapper sits between the two in this library, so the robust wrapper may talk to the backend)
+            robust_ = registration_ != nullptr ? std::make_shared<pipeline::RobustAligner>(registration_, params_)
+                                               : std::make_shared<pipeline::RobustAligner>(aligner_, params_);
             aligner_ = robust_->make_aligner();
         }
     }

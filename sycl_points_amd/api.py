@@ -392,10 +392,14 @@ class GridKNN(KNNBase):
         self.device = device
 
     @staticmethod
-    def build(points, cell_size=0.0, points_per_cell=2.0):
+    def build(points, cell_size=0.0, points_per_cell=2.0, adaptive=False):
+        """adaptive: the cell size follows the measured occupancy (sp_grid_create_adaptive) — clouds of surfaces."""
         p = _dev_f32(_points_of(points), 4)
         h = C.c_void_p()
-        check(_lib.lib().sp_grid_create(_ptr(p), p.shape[0], cell_size, points_per_cell, _stream(), C.byref(h)))
+        if adaptive:
+            check(_lib.lib().sp_grid_create_adaptive(_ptr(p), p.shape[0], points_per_cell, _stream(), C.byref(h)))
+        else:
+            check(_lib.lib().sp_grid_create(_ptr(p), p.shape[0], cell_size, points_per_cell, _stream(), C.byref(h)))
         return GridKNN(h, p.shape[0], p.device)
 
     def _set_option(self, name, value):

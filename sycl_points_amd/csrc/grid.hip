@@ -147,8 +147,11 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
                                                              int32_t* __restrict__ idx_out,
                                                              float* __restrict__ d2_out,
                                                              const unsigned* __restrict__ todo = nullptr,
-                                                             const unsigned* __restrict__ todo_count = nullptr) {
+                                                             const unsigned* __restrict__ todo_count = nullptr,
+                                                             float bound2 = FLT_MAX) {
     // (todo: only the listed queries — what grid_search_select_kernel could not prove)
+    // (bound2: only neighbours closer than this squared distance are wanted — rows stay padded beyond it and the walk ends
+    // at the ring that reaches it: a query with nothing nearby does not walk the grid to its end)
     const unsigned t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= (todo ? *todo_count : nq)) return;
     const unsigned qi = todo ? todo[t] : t;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
     int bi[KCAP];
 #pragma unroll
     for (int i = 0; i < KCAP; ++i) { bd[i] = FLT_MAX; bi[i] = -1; }
-    float kth = FLT_MAX;
+    float kth = bound2;
     int kth_idx = -1;
 
     const bool finite_q = isfinite(qx) && isfinite(qy) && isfinite(qz);
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __res
                                 lex_insert<KCAP>(bd, bi, k, d2, i2, kth, kth_idx);
                             if (i + 3 < e && (d3 < kth || (d3 == kth && i3 < kth_idx)))
                                 lex_insert<KCAP>(bd, bi, k, d3, i3, kth, kth_idx);
+                            if (bound2 < kth) { kth = bound2; kth_idx = -1; }  // (a list that is not full yet says FLT_MAX)
                         }
                     }
                 }
@@ -252,6 +256,25 @@ __global__ __launch_bounds__(kBlock) void cell_max_kernel(const unsigned* __rest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+// Occupied cells and the fullest cell in one pass (out[0] += occupied, out[1] = max): what the density-adaptive build steers by.
+__global__ __launch_bounds__(kBlock) void cell_stats_kernel(const unsigned* __restrict__ start, unsigned ncells,
+                                                            unsigned* __restrict__ out) {
+    unsigned m = 0, occ = 0;
+    for (unsigned c = blockIdx.x * kBlock + threadIdx.x; c < ncells; c += gridDim.x * kBlock) {
+        const unsigned k = start[c + 1] - start[c];
+        m = max(m, k);
+        occ += k ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        occ += (unsigned)__shfl_xor((int)occ, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && occ) {
+        atomicAdd(out, occ);
+        atomicMax(out + 1, m);
+    }
 }
 __global__ void row_units_kernel(const unsigned* __restrict__ start, unsigned nx, unsigned rows,
                                  unsigned* __restrict__ units) {
@@ -1331,7 +1354,7 @@ __global__ __launch_bounds__(kBlock) void grid_query_cell_kernel(const float4* _
 
 template <int KCAP>
 int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* T, int T_dev, int32_t* idx, float* d2,
-           hipStream_t st, bool queries_in_cell_order = false) {
+           hipStream_t st, bool queries_in_cell_order = false, float bound2 = FLT_MAX) {
     Mat4Arg tv;
     for (int i = 0; i < 16; ++i) tv.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     if (T && !T_dev)
@@ -1391,7 +1414,7 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
     }
     grid_search_kernel<KCAP><<<div_up(nq, kBlock), kBlock, 0, st>>>(gr->d_pts, gr->d_start, g,
                                                                   reinterpret_cast<const float4*>(q), (unsigned)nq,
-                                                                  (int)k, tv, T_dev ? T : nullptr, idx, d2, order, order_count);
+                                                                  (int)k, tv, T_dev ? T : nullptr, idx, d2, order, order_count, bound2);
     return launch_status();
 }
 
@@ -1407,9 +1430,10 @@ extern "C" void sp_grid_destroy(sp_grid* g) {
     delete g;
 }
 
-extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, float points_per_cell, void* stream,
-                              sp_grid** out) {
-    using namespace sp;
+namespace sp {
+namespace {
+int grid_create_impl(const float* points, size_t n, float cell_size, float points_per_cell, bool adaptive, void* stream,
+                     sp_grid** out) {
     if (!out) return SP_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (n >= (1ull << 31)) {
@@ -1472,72 +1496,118 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
     }
     if (!(h > 0.0f) || !std::isfinite(h)) h = 1.0f;
     const size_t max_cells = 1ull << 25;  // 32M cells = 128 MB of cell_start at most
-    for (;;) {
-        size_t nc = 1;
-        for (int a = 0; a < 3; ++a) {
-            const double d = std::floor((double)ext[a] / h) + 1.0;
-            g->dims[a] = (int)std::min(d, 2.0e6);
-            nc *= (size_t)g->dims[a];
-        }
-        if (nc <= max_cells) { g->ncells = nc; break; }
-        h *= 1.26f;
-    }
-    g->h = h;
-    g->inv_h = 1.0f / h;
-    g->eps = 4.0e-6f * (scale + ext_max + h);  // bounds the float rounding of (p - org) * inv_h cell assignment
-    for (int a = 0; a < 3; ++a) g->org[a] = mn[a];
-
     // 3. sort points by cell id, gather, cell_start (temporaries from the scratch pool: idle again when this returns)
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;
-    ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp;
-    size_t tmp_bytes = 0;
-    unsigned end_bit = 1;
-    while ((1ull << end_bit) <= g->ncells && end_bit < 32) ++end_bit;
-    tmp_bytes = radix_sort_u32_workspace_bytes(n);  // radix_sort.hip
+    ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp, b_stats;
+    size_t tmp_bytes = radix_sort_u32_workspace_bytes(n);  // radix_sort.hip
     e = b_kin.get(n * 4);
     if (e == hipSuccess) e = b_kout.get(n * 4);
     if (e == hipSuccess) e = b_vin.get(n * 4);
     if (e == hipSuccess) e = b_vout.get(n * 4);
     if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(tmp_bytes, 16));
+    if (e == hipSuccess) e = b_stats.get(16);
     if (e == hipSuccess) e = pooled_alloc(&g->d_pts, n * sizeof(float4));
-    if (e == hipSuccess) e = pooled_alloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t));
-    keys_in = b_kin.as<unsigned>(); keys_out = b_kout.as<unsigned>(); vals_in = b_vin.as<unsigned>(); vals_out = b_vout.as<unsigned>();
+    if (e != hipSuccess) return fail(e);
     void* const tmp = b_tmp.p;
-    const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
-    unsigned* units = nullptr;
-    void* stmp = nullptr;
-    size_t stmp_bytes = 0;
-    ScratchBuf b_units, b_stmp;
-    if (e == hipSuccess) {
-        stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
-        e = b_units.get((rows + 1) * 4);
+    // Density-adaptive build (sp_grid_create_adaptive): the cell size of the volume rule assumes the points fill their bounding
+    // box. A cloud of SURFACES (a voxel-downsampled LiDAR scan) leaves most cells empty and packs the occupied ones — 40 points
+    // per occupied cell on the reference's bundled scan at the 0.5 target, and a query scans hundreds of candidates per block of
+    // cells. So the build measures what it made (occupied cells, in the same synchronisation it ends with anyway) and, while the
+    // occupied cells hold well more than a uniform cloud's would, shrinks h by the dimension the two measurements imply (2 — a
+    // surface — for the first correction) and builds again: at most three more sorts, none for a uniform cloud.
+    const double ppc_target = (cell_size > 0.0f) ? 0.0 : (points_per_cell > 0.0f ? points_per_cell : 2.0f);
+    const double occ_target = ppc_target > 0.0 ? ppc_target / (1.0 - std::exp(-ppc_target)) : 0.0;  // Poisson: mean of the non-empty cells
+    double prev_h = 0.0, prev_occ_cells = 0.0;
+    for (int attempt = 0;; ++attempt) {
+        for (;;) {
+            size_t nc = 1;
+            for (int a = 0; a < 3; ++a) {
+                const double d = std::floor((double)ext[a] / h) + 1.0;
+                g->dims[a] = (int)std::min(d, 2.0e6);
+                nc *= (size_t)g->dims[a];
+            }
+            if (nc <= max_cells) { g->ncells = nc; break; }
+            h *= 1.26f;
+            adaptive = false;  // the table is as large as it may get
+        }
+        g->h = h;
+        g->inv_h = 1.0f / h;
+        g->eps = 4.0e-6f * (scale + ext_max + h);  // bounds the float rounding of (p - org) * inv_h cell assignment
+        for (int a = 0; a < 3; ++a) g->org[a] = mn[a];
+        unsigned end_bit = 1;
+        while ((1ull << end_bit) <= g->ncells && end_bit < 32) ++end_bit;
+        keys_in = b_kin.as<unsigned>(); keys_out = b_kout.as<unsigned>(); vals_in = b_vin.as<unsigned>(); vals_out = b_vout.as<unsigned>();
+        const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
+        ScratchBuf b_units, b_stmp;
+        const size_t stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
+        e = pooled_alloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = b_units.get((rows + 1) * 4);
         if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4);
         if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
-        units = b_units.as<unsigned>();
-        stmp = b_stmp.p;
+        unsigned* const units = b_units.as<unsigned>();
+        void* const stmp = b_stmp.p;
+        if (e == hipSuccess) {
+            GridDesc gd{g->inv_h, g->h, g->eps, g->org[0], g->org[1], g->org[2], g->dims[0], g->dims[1], g->dims[2],
+                        (unsigned)n};
+            cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in);
+            bool in_b = false;
+            if (radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, n, end_bit, tmp, tmp_bytes, &in_b, st) != SP_OK)
+                e = hipErrorUnknown;
+            if (!in_b) { keys_out = keys_in; vals_out = vals_in; }  // the passes ping-pong: the sorted pairs are where the last one wrote
+        }
+        unsigned h_stats[2] = {0u, 0u};
+        if (e == hipSuccess) {
+            gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
+            cell_start_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
+                                                                              g->d_start);
+            // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed (same stream: no sync between)
+            row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
+            if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, stmp, stmp_bytes, st) != SP_OK) e = hipErrorUnknown;
+            if (adaptive && e == hipSuccess) {
+                e = zero_async(b_stats.p, 8, st) == SP_OK ? hipSuccess : hipErrorUnknown;
+                cell_stats_kernel<<<std::min(div_up(g->ncells, kBlock), 1024u), kBlock, 0, st>>>(g->d_start, (unsigned)g->ncells,
+                                                                                                 b_stats.as<unsigned>());
+                if (e == hipSuccess) e = hipMemcpyAsync(h_stats, b_stats.p, 8, hipMemcpyDeviceToHost, st);
+            }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // the temporaries are idle from here on
+        if (e != hipSuccess) return fail(e);
+        if (!adaptive || attempt >= 3 || h_stats[0] == 0) break;
+        g->max_cell = h_stats[1];
+        g->max_cell_known = true;
+        const double occ_cells = (double)h_stats[0];
+        const double mean_occ = (double)n / occ_cells;
+        // (act when an occupied cell holds more than twice what it would in a uniform cloud at four times the target — 4 points at
+        // the in-loop search's 0.5 — and aim at 3: the block stages of the search cover 0.5 h and 1.5 h around the query, so a
+        // cell should span about two point spacings, not one)
+        const double occ_aim = std::max(occ_target, 3.0), occ_act = std::max(1.6 * occ_target, 4.0);
+        if (mean_occ <= occ_act) break;
+        // dimension of the point set between the two latest cell sizes (occupied cells ~ h^-D), 2 before there are two
+        double D = 2.0;
+        if (prev_h > 0.0 && prev_occ_cells > 0.0 && occ_cells > prev_occ_cells)
+            D = std::min(3.0, std::max(1.0, std::log(occ_cells / prev_occ_cells) / std::log(prev_h / (double)h)));
+        prev_h = h;
+        prev_occ_cells = occ_cells;
+        const float h_new = (float)((double)h * std::pow(occ_aim / mean_occ, 1.0 / D));
+        if (!(h_new > 0.0f) || !(h_new < 0.97f * h)) break;
+        pooled_free(g->d_start); g->d_start = nullptr;       // (synchronised above: nothing on the device uses them)
+        pooled_free(g->d_unit_off); g->d_unit_off = nullptr;
+        g->max_cell_known = false;
+        h = h_new;
     }
-    if (e == hipSuccess) {
-        GridDesc gd{g->inv_h, g->h, g->eps, g->org[0], g->org[1], g->org[2], g->dims[0], g->dims[1], g->dims[2],
-                    (unsigned)n};
-        cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in);
-        bool in_b = false;
-        if (radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, n, end_bit, tmp, tmp_bytes, &in_b, st) != SP_OK)
-            e = hipErrorUnknown;
-        if (!in_b) { keys_out = keys_in; vals_out = vals_in; }  // the passes ping-pong: the sorted pairs are where the last one wrote
-    }
-    if (e == hipSuccess) {
-        gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
-        cell_start_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
-                                                                          g->d_start);
-        // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed (same stream: no sync between)
-        row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
-        if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, stmp, stmp_bytes, st) != SP_OK) e = hipErrorUnknown;
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the temporaries are idle from here on
-    if (e != hipSuccess) return fail(e);
     *out = g;
     return SP_OK;
+}
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, float points_per_cell, void* stream,
+                              sp_grid** out) {
+    return sp::grid_create_impl(points, n, cell_size, points_per_cell, false, stream, out);
+}
+extern "C" int sp_grid_create_adaptive(const float* points, size_t n, float points_per_cell, void* stream, sp_grid** out) {
+    return sp::grid_create_impl(points, n, 0.0f, points_per_cell, true, stream, out);
 }
 
 // ---- lazy delete (the grid's counterpart of KDTree::remove_nodes_by_flags, kdtree.hpp:282-284, 721-765) -------------
@@ -1673,13 +1743,13 @@ extern "C" int sp_grid_search(const sp_grid* grid, const float* queries, size_t 
 // The grid's own cell-ordered points as queries (row i = neighbours of the point at grid position i): the caller knows the
 // order, no sort (internal: the certificates of sp_gicp_target_create).
 namespace sp {
-int grid_search_own_points(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, hipStream_t st) {
+int grid_search_own_points(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, hipStream_t st, float bound2) {
     if (!grid || k == 0 || k > 10) return SP_ERR_INVALID_ARGUMENT;
     if (grid->n == 0) return SP_OK;
     grid->streams.note(st);
     const float* q = reinterpret_cast<const float*>(grid->d_pts);
     if (k == 1) return launch<1>(grid, q, grid->n, k, nullptr, 0, idx_out, d2_out, st, true);
-    return launch<10>(grid, q, grid->n, k, nullptr, 0, idx_out, d2_out, st, true);
+    return launch<10>(grid, q, grid->n, k, nullptr, 0, idx_out, d2_out, st, true, bound2);
 }
 }  // namespace sp
 

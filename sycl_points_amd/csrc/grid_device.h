@@ -24,8 +24,9 @@ struct sp_grid {
 
 namespace sp {
 
-// grid.hip: kNN of the grid's own cell-ordered points (k <= 10), rows by grid position; enqueues only
-int grid_search_own_points(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, hipStream_t st);
+// grid.hip: kNN of the grid's own cell-ordered points (k <= 10), rows by grid position; enqueues only. bound2 (k > 1): only
+// neighbours closer than this squared distance are looked for, the rest of a row stays padded (-1 / FLT_MAX)
+int grid_search_own_points(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, hipStream_t st, float bound2 = FLT_MAX);
 
 struct GridDesc {
     float inv_h, h, eps;
@@ -249,17 +250,22 @@ __device__ __forceinline__ void fast_eval(const FastFlat& f, unsigned base, cons
 // FLT_MAX: a query with nothing that near is "proven" (no point, idx = -1, d2 = bound2) as soon as the scanned block covers
 // the bound's ball, instead of walking rings of cells out to a neighbour it would discard. With partial overlap (the
 // reference's example: 84 % of the source points have no correspondence) that walk was most of an iteration.
+// `seed` (optional): a REAL point of the grid with its distance to the query — an upper bound better than any constant. The
+// registration hands in a source point's previous correspondence when its reuse certificate has failed: the new nearest
+// neighbour is at most that far away, which proves most answers inside the first block and prunes the rows of the later stages
+// to the seed's ball instead of the caller's bound. The seed wins unless a point is nearer (or as near with a lower index).
 __device__ __forceinline__ bool grid_nn1_fast(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                               const GridDesc& g, float qx, float qy, float qz, Nearest& best,
-                                              float bound2 = FLT_MAX) {
+                                              float bound2 = FLT_MAX, const Nearest* seed = nullptr) {
     best.d2 = bound2; best.idx = -1; best.pos = 0; best.x = best.y = best.z = 0.0f;
     const bool usable = isfinite(qx) && isfinite(qy) && isfinite(qz) && g.n != 0;
     if (!usable) return true;
+    if (seed) best = *seed;
     unsigned s[4], e[4];
     float cov_cells;
     fast_extents(start, g, qx, qy, qz, s, e, cov_cells);
     const FastFlat f = fast_flatten(s, e, true);
-    const unsigned long long none = nn_key(bound2, -1);  // nothing found (below the bound): {bound2, -1}
+    const unsigned long long none = nn_key(best.d2, best.idx);  // nothing better found: {bound2, -1}, or the seed
     unsigned long long key = none;
     unsigned bj = 0;
     for (unsigned base = 0; base < f.total; base += 8) {
@@ -390,6 +396,86 @@ __device__ __forceinline__ bool grid_nn1_ball(const float4* __restrict__ pts, co
     return true;
 }
 
+// The third stage with the WHOLE WAVE on one query at a time (all 64 lanes must call it; `open` marks the lanes whose query
+// is still unproven after the 4x4x4 block, `best` their upper bound). A lane that scans its ball alone walks every row and
+// every candidate serially — on a cloud of surfaces (tens of points per cell) or with a bound of several cells (a source point
+// with nothing within max_correspondence_distance) that is thousands of dependent steps, and the wave, the workgroup and, in
+// the device-resident optimiser loop, the whole step wait for it. Here the rows of the ball are dealt to the lanes (row r to
+// lane r mod 64): each lane prunes and trims its rows against the query's bound, scans their candidates, and a wave-wide
+// minimum of (distance, index) picks the winner. Exact like grid_nn1_ball: every cell the ball intersects is scanned or pruned
+// against a valid upper bound; the result is the (distance, index)-lexicographic minimum, whoever finds it.
+// Any number of rows (no fall-back to the ring walk).
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ void grid_nn1_ball_wave(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                   const GridDesc& g, bool open, float qx, float qy, float qz, Nearest& best) {
+    unsigned long long todo = __ballot(open);
+    const int lane = (int)(threadIdx.x & 63u);
+    // (distance bits : index + 2^31): orders like `d < best || (d == best && idx < best_idx)` with idx = -1 below every index
+    auto key_of = [](float d2, int idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(idx + 0x80000000); };
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), src));
+        const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), src));
+        const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), src));
+        const float ub = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best.d2), src));
+        const int ui = __builtin_amdgcn_readlane(best.idx, src);
+        const float rad = (sqrtf(ub) * 1.000001f + 2.0f * g.eps) * g.inv_h;  // in cells, widened like the row trimming
+        const float fx = (ux - g.ox) * g.inv_h, fy = (uy - g.oy) * g.inv_h, fz = (uz - g.oz) * g.inv_h;
+        auto lo_cell = [](float v, int n) { return (int)fminf(fmaxf(floorf(v), 0.0f), (float)(n - 1)); };
+        const int x0 = lo_cell(fx - rad, g.nx), x1 = lo_cell(fx + rad, g.nx);
+        const int y0 = lo_cell(fy - rad, g.ny), y1 = lo_cell(fy + rad, g.ny);
+        const int z0 = lo_cell(fz - rad, g.nz), z1 = lo_cell(fz + rad, g.nz);
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        const unsigned long long key0 = key_of(ub, ui);
+        unsigned long long key = key0;
+        unsigned bpos = 0;
+        for (int r = lane; r < nrows; r += 64) {
+            const int y = y0 + r % ny, z = z0 + r / ny;
+            const float dyz2 = gap2(uy, g.oy + y * g.h, g.oy + (y + 1) * g.h, g.eps) + gap2(uz, g.oz + z * g.h, g.oz + (z + 1) * g.h, g.eps);
+            if (dyz2 > ub) continue;
+            const float radx = (sqrtf(fmaxf(ub - dyz2, 0.0f)) * 1.000001f + 2.0f * g.eps) * g.inv_h;
+            const int xa = max(x0, (int)fmaxf(floorf(fx - radx), (float)x0));
+            const int xb = min(x1, (int)fminf(floorf(fx + radx), (float)x1));
+            if (xa > xb) continue;
+            const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
+            const unsigned s = start[row + xa], e = start[row + xb + 1];
+            for (unsigned i = s; i < e; i += 4) {
+                float4 c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = pts[min(i + j, e - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long kj = key_of(dist2(ux, uy, uz, c[j].x, c[j].y, c[j].z), __float_as_int(c[j].w));
+                    const bool better = i + j < e && kj < key;
+                    key = better ? kj : key;
+                    bpos = better ? i + j : bpos;
+                }
+            }
+        }
+        const unsigned long long m = wave_min_u64(key);
+        if (m != key0) {  // something beat the bound (uniform over the wave)
+            const int wl = __ffsll((long long)__ballot(key == m)) - 1;
+            const unsigned wpos = (unsigned)__builtin_amdgcn_readlane((int)bpos, wl);
+            if (lane == src) {
+                const float4 w = pts[wpos];
+                best.d2 = __uint_as_float((unsigned)(m >> 32));
+                best.idx = __float_as_int(w.w);
+                best.pos = wpos;
+                best.x = w.x; best.y = w.y; best.z = w.z;
+            }
+        }
+    }
+}
+
 // Stages after an inexact fast result (`best` holds its upper bound or {FLT_MAX, -1}).
 __device__ __forceinline__ void grid_nn1_later_stages(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                       const GridDesc& g, float qx, float qy, float qz, Nearest& best) {
@@ -401,9 +487,10 @@ __device__ __forceinline__ void grid_nn1_later_stages(const float4* __restrict__
 }
 
 __device__ __forceinline__ Nearest grid_nn1_auto(const float4* __restrict__ pts, const unsigned* __restrict__ start,
-                                                 const GridDesc& g, float qx, float qy, float qz, float bound2 = FLT_MAX) {
+                                                 const GridDesc& g, float qx, float qy, float qz, float bound2 = FLT_MAX,
+                                                 const Nearest* seed = nullptr) {
     Nearest best;
-    if (!grid_nn1_fast(pts, start, g, qx, qy, qz, best, bound2)) grid_nn1_later_stages(pts, start, g, qx, qy, qz, best);
+    if (!grid_nn1_fast(pts, start, g, qx, qy, qz, best, bound2, seed)) grid_nn1_later_stages(pts, start, g, qx, qy, qz, best);
     return best;
 }
 

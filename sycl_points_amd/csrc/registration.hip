@@ -455,20 +455,22 @@ __global__ __launch_bounds__(kBlock) void certificate_kernel(const float4* __res
                                                              const int32_t* __restrict__ idx3,
                                                              const float* __restrict__ d23,
                                                              const unsigned* __restrict__ inv,
-                                                             float* __restrict__ rho2, float4* __restrict__ nb) {
+                                                             float* __restrict__ rho2, float4* __restrict__ nb, float bound2) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;  // grid position
     if (i >= n) return;
     const unsigned o = __float_as_uint(gpts[i].w);
     constexpr float kShrink = 0.25f * (1.0f - 1e-3f);
-    // idx3 / d23: the three nearest target points of the point at grid position i (itself first), rows in GRID order
-    rho2[o] = d23[3 * (size_t)i + 1] * kShrink;
+    // idx3 / d23: the three nearest target points of the point at grid position i (itself first), rows in GRID order.
+    // The search was bounded (bound2: a point with nothing nearby does not walk the grid to its end); a neighbour it did not
+    // find is farther than the bound, so the bound stands in for its distance: a smaller, still valid, radius.
+    rho2[o] = fminf(d23[3 * (size_t)i + 1], bound2) * kShrink;
     const int u1 = idx3[3 * (size_t)i + 1];
     float4 r = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);  // no other point: the distance test always passes
     if (u1 >= 0) {
         const float4 p = gpts[inv[u1]];
         r.x = p.x; r.y = p.y; r.z = p.z;
     }
-    r.w = d23[3 * (size_t)i + 2] * kShrink;
+    r.w = fminf(d23[3 * (size_t)i + 2], bound2) * kShrink;
     nb[i] = r;
 }
 
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
     unsigned cnt = 0, searched = 0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock)
-        fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
+        fused_point<LOSS, FAST_NN, P2D, kSeedSearches>(P, T, i, acc, cnt, searched);
     block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
 }
 
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     unsigned tile = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-        fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
+        fused_point<LOSS, FAST_NN, P2D, kSeedSearches>(P, T, i, acc, cnt, searched);
     if constexpr (!SHARDED) {
         block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
     } else if (A.mode == ALIGN_ROWS) {
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_persistent_kernel(Fuse
         if (k == 1) P.cache_valid = A.cache_valid_later;  // (P is this kernel's own copy of the parameters; a launch that
                                                            //  begins later was handed the right value)
         for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-            fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
+            fused_point<LOSS, FAST_NN, P2D, kSeedSearches>(P, T, i, acc, cnt, searched);
         block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, A.part[k & 1] + (size_t)blockIdx.x * kPartial, false, searched);
         if (threadIdx.x < kWave) {  // the storing lanes all sit in wave 0
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1382,11 +1384,13 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
         float* const d23 = b_d23.as<float>();
         unsigned* const inv = b_inv.as<unsigned>();
         int rc2 = e == hipSuccess ? SP_OK : SP_ERR_HIP;
+        // (neighbours beyond three cells are not looked for: isolated points of a scan would walk thousands of empty cells)
+        const float bound2 = 9.0f * grid->h * grid->h;
         if (rc2 == SP_OK)
-            rc2 = grid_search_own_points(grid, 3, idx3, d23, st);  // (in cell order already: no sort of the queries)
+            rc2 = grid_search_own_points(grid, 3, idx3, d23, st, bound2);  // (in cell order already: no sort of the queries)
         if (rc2 == SP_OK) {
             inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
-            certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb);
+            certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb, bound2);
             rc2 = launch_status();
         }
         if (hipStreamSynchronize(st) != hipSuccess && rc2 == SP_OK) rc2 = SP_ERR_HIP;

@@ -137,6 +137,39 @@ __device__ __forceinline__ void reduce_rows_1024(const float* __restrict__ parti
     reduce_rows_1024<SC1>(partials, rows, nv, red, count_is_float, [] {});
 }
 
+// reduce_rows_1024 for a workgroup of BLOCK lanes (a multiple of 64): lane = (part, slot) with BLOCK / 32 parts, every part sums
+// its contiguous range of rows in order, lanes 0..31 add the parts in order. Fixed order: bit-reproducible for a given BLOCK.
+template <int BLOCK, bool SC1>
+__device__ __forceinline__ void reduce_rows_block(const float* __restrict__ partials, unsigned rows, int nv, float (*red)[kPartial]) {
+    constexpr unsigned kParts = BLOCK / 32;
+    const unsigned e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const unsigned per = (rows + kParts - 1) / kParts;
+    const unsigned lo = part * per, hi = min(rows, lo + per);
+    float s = 0.0f;
+    unsigned c = 0;
+    const bool is_count = ((int)e == nv);
+#pragma unroll 4
+    for (unsigned b = lo; b < hi; ++b) {
+        const float v = load_row_word<SC1>(partials + (size_t)b * kPartial + e);
+        if (is_count) c += __float_as_uint(v);
+        else s += v;
+    }
+    red[part][e] = is_count ? __uint_as_float(c) : s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.0f;
+        unsigned ct = 0;
+#pragma unroll
+        for (unsigned p = 0; p < kParts; ++p) {
+            const float v = red[p][e];
+            if (is_count) ct += __float_as_uint(v);
+            else t += v;
+        }
+        red[0][e] = is_count ? __uint_as_float(ct) : t;
+    }
+    __syncthreads();
+}
+
 // totals (21 upper-triangle H, 6 b, error | error only) + count -> sp_linearized
 __device__ __forceinline__ void unpack_totals(const float* tot, int nv, sp_linearized* out) {
     if (nv == kAcc - 1) {
@@ -300,9 +333,17 @@ __device__ __forceinline__ void fused_math(const FusedParams& P, const Rigid& T,
 //   row[2] = (yz, zz, index bits, grid position bits)  ... index -1 (and rho^2 = 0): nothing found, searched again next time
 // Written by whoever searched for the point (fused_point inline, or gicp_search_kernel); the winner's prepared row is
 // gathered here, next to the points the search has just scanned.
+// NOTHING FOUND below the search bound (idx = -1): the row records WHERE the search was made, q, and the margin m by which its
+// bound exceeded max_correspondence_distance B (search_margin2: squared, shrunk against rounding; 0 when there was none). No
+// target lies within B + m of q, so while the point stays within m of q no target lies within B of it: the same "no
+// correspondence" a fresh search would return, proven by the first test of the certificate (|q' - q|^2 < m^2) with no search —
+// a source point outside the overlap is searched once, not in every iteration, and it is the dearest search there is (the
+// whole ball of the bound).
 __device__ __forceinline__ void store_correspondence(float4* __restrict__ row, const FusedParams& P, const Nearest& nn,
-                                                     Sym3& Ct) {
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+                                                     Sym3& Ct, float qx = 0.0f, float qy = 0.0f, float qz = 0.0f,
+                                                     float margin2 = 0.0f) {
+    float4 r0 = make_float4(qx, qy, qz, margin2), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f),
+           r2 = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
     if (nn.idx >= 0) {
         const float4 c0 = P.tcovp[2 * (size_t)nn.pos], c1 = P.tcovp[2 * (size_t)nn.pos + 1];
         r0 = make_float4(nn.x, nn.y, nn.z, c1.z);
@@ -336,13 +377,26 @@ __device__ __forceinline__ bool certified(const FusedParams& P, float d, float r
 __device__ __forceinline__ float search_bound2(const FusedParams& P) {
     return (P.nn_idx == nullptr && P.max_d2 < FLT_MAX) ? __uint_as_float(__float_as_uint(P.max_d2) + 1u) : FLT_MAX;
 }
+// The same bound widened by a margin of a quarter of max_correspondence_distance, for the searches whose failure is recorded in
+// the correspondence cache (store_correspondence): margin2 = what the row's certificate may use (squared, 2 % short of the
+// margin: the bound's ball and the point's motion are compared in float arithmetic).
+__device__ __forceinline__ float search_bound2_margin(const FusedParams& P, float& margin2) {
+    margin2 = 0.0f;
+    if (P.nn_idx != nullptr || !(P.max_d2 < FLT_MAX) || P.ccache == nullptr) return search_bound2(P);
+    const float B = sqrtf(P.max_d2), m = 0.25f * B;
+    const float wide = (B + m) * (B + m);
+    if (!(wide < FLT_MAX)) return search_bound2(P);
+    margin2 = (0.98f * m) * (0.98f * m);
+    return wide;
+}
 
 // One source point of the fused iteration: q = T p -> correspondence (cache row by certificate, else exact NN on the target
 // grid) -> linearise -> accumulate.
 // P.cache_valid: 0 the cache holds nothing (every point is searched), 1 a row is used when its certificate holds: while
 // correspondences hold, an iteration is a pure coalesced stream of 84 bytes per point (12 p + 24 Cs' as planes + 48 cache
 // row) with no search and no gather, and a wave whose lanes all pass never enters the search code.
-template <int LOSS, bool FAST_NN, bool P2D = false>
+// SEED: a point whose certificate fails starts its search from the previous winner (grid_nn1_fast's `seed`).
+template <int LOSS, bool FAST_NN, bool P2D = false, bool SEED = true>
 __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
                                             unsigned& cnt, unsigned& searched) {
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
@@ -351,6 +405,9 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
     Nearest nn;
     Sym3 Ct{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     bool hit = false;
+    bool seeded = false;
+    Nearest seed;
+    seed.d2 = FLT_MAX; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f;
     float4* const row = P.ccache ? P.ccache + 3 * (size_t)i : nullptr;
     if (row && P.cache_valid) {
         const float4 r0 = row[0], r1 = row[1], r2 = row[2];
@@ -361,19 +418,23 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
             nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
             nn.d2 = nn.idx >= 0 ? d : FLT_MAX;
             Ct = Sym3{r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+        } else if (SEED && __float_as_int(r2.z) >= 0) {  // the previous winner: a real point, an upper bound
+            seed.d2 = d; seed.idx = __float_as_int(r2.z); seed.pos = pos; seed.x = r0.x; seed.y = r0.y; seed.z = r0.z;
+            seeded = true;
         }
     }
     if (!hit) {
         ++searched;
-        const float bound2 = search_bound2(P);
+        float margin2;
+        const float bound2 = search_bound2_margin(P, margin2);
+        seeded = seeded && seed.d2 < bound2;
+        if (!seeded) { seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f; }
         if (FAST_NN) {
-            nn = grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz, bound2);
+            nn = grid_nn1_auto(P.tpts, P.tstart, P.g, qx, qy, qz, bound2, &seed);
         } else {
-            Nearest seed;
-            seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f;
             nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 0);
         }
-        if (row) store_correspondence(row, P, nn, Ct);
+        if (row) store_correspondence(row, P, nn, Ct, qx, qy, qz, margin2);
         else if (nn.idx >= 0) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
     }
     if (P.nn_idx) {
@@ -387,6 +448,93 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
     const Sym3 Cs = P2D ? Sym3{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}
                         : Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
     fused_math<LOSS, P2D>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
+}
+
+// fused_point with the wave working together where a lane alone would hold it up: EVERY lane of the wave calls this
+// (`valid`: the lane has a point), the first two search stages run per lane as in fused_point, and the queries still open
+// after them (nothing proven inside the 4x4x4 block: points outside the overlap, holes, the rim) are finished one at a time
+// by all 64 lanes (grid_nn1_ball_wave). Same correspondences, same sums per point as fused_point.
+#ifdef SP_OPT_TIMING
+__device__ unsigned long long g_sp_dbg[24 * 16];
+__device__ unsigned g_sp_step;
+#define SP_PSTAMP(k) if (blockIdx.x == 0 && threadIdx.x == 0 && g_sp_step < 24) g_sp_dbg[g_sp_step * 16 + (k)] = wall_clock64()
+#else
+#define SP_PSTAMP(k)
+#endif
+template <int LOSS, bool P2D = false>
+__device__ __forceinline__ void fused_point_wave(const FusedParams& P, const Rigid& T, unsigned i, bool valid,
+                                                 float (&acc)[kAcc - 1], unsigned& cnt, unsigned& searched) {
+    const unsigned ii = valid ? i : 0u;
+    SP_PSTAMP(0);
+    const float4 s = make_float4(P.src[ii], P.src[P.sstride + ii], P.src[2 * (size_t)P.sstride + ii], 1.0f);
+    float qx, qy, qz;
+    transform_point(T, s.x, s.y, s.z, qx, qy, qz);
+    Nearest nn;
+    nn.d2 = FLT_MAX; nn.idx = -1; nn.pos = 0; nn.x = nn.y = nn.z = 0.0f;
+    Sym3 Ct{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool hit = false;
+    float4* const row = P.ccache + 3 * (size_t)ii;
+    Nearest seed;
+    seed.d2 = FLT_MAX; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f;
+    if (valid && P.cache_valid) {
+        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        const float d = dist2(qx, qy, qz, r0.x, r0.y, r0.z);
+        const unsigned pos = __float_as_uint(r2.w);
+        if (certified(P, d, r0.w, qx, qy, qz, pos)) {
+            hit = true;
+            nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
+            nn.d2 = nn.idx >= 0 ? d : FLT_MAX;
+            Ct = Sym3{r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+        } else if (__float_as_int(r2.z) >= 0) {  // the previous winner: a real point, an upper bound (grid_nn1_fast's seed)
+            seed.d2 = d; seed.idx = __float_as_int(r2.z); seed.pos = pos; seed.x = r0.x; seed.y = r0.y; seed.z = r0.z;
+        }
+    }
+    const bool search = valid && !hit;
+    SP_PSTAMP(1);
+    float margin2 = 0.0f;
+    const float bound2 = search_bound2_margin(P, margin2);
+    bool open = false;
+    bool fast_ok = true;
+    // (a point with a previous winner starts from it, grid_nn1_fast's seed. Sending it straight to the ball scan of that
+    // distance instead of through the block stages was measured on the reference's example: slower, 462 against 397 us per
+    // alignment — the ball scan's batches of four dependent loads cost more than the first block's batches of eight.)
+    const bool seeded = search && seed.d2 < bound2;
+    if (search) {
+        ++searched;
+        if (!seeded) { seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f; }
+        fast_ok = grid_nn1_fast(P.tpts, P.tstart, P.g, qx, qy, qz, nn, bound2, &seed);
+    }
+    SP_PSTAMP(2);
+    if (search && !fast_ok) open = !grid_nn1_block4(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+    SP_PSTAMP(3);
+#ifdef SP_OPT_TIMING
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const unsigned long long a = __ballot(search), b = __ballot(search && !fast_ok), c = __ballot(open);
+        const unsigned long long sd = __ballot(seeded);
+        if (threadIdx.x == 0 && g_sp_step < 24) {
+            unsigned long long* const d = g_sp_dbg + g_sp_step * 16;
+            d[8] = __popcll(a); d[9] = __popcll(b); d[10] = __popcll(c); d[11] = __popcll(sd);
+        }
+    }
+#endif
+    if (__ballot(open)) {  // (uniform)
+        if (open && !(nn.d2 < FLT_MAX)) {  // no bound at all (the caller wants the neighbour whatever its distance): the lane's own walk
+            const Nearest seed = nn;
+            nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 2);
+            open = false;
+        }
+        grid_nn1_ball_wave(P.tpts, P.tstart, P.g, open, qx, qy, qz, nn);
+    }
+    SP_PSTAMP(4);
+    if (search) store_correspondence(row, P, nn, Ct, qx, qy, qz, margin2);
+    SP_PSTAMP(5);
+    if (!valid || nn.idx < 0 || nn.d2 > P.max_d2) return;
+    const float* const cp = P.scovp + ii;
+    const size_t st = P.sstride;
+    const Sym3 Cs = P2D ? Sym3{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}
+                        : Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
+    fused_math<LOSS, P2D>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
+    SP_PSTAMP(6);
 }
 
 // One source point of the K12 on the prepared path (Registration::compute_error_parallel_reduction, registration.hpp:678-777, as
@@ -450,6 +598,9 @@ __device__ __forceinline__ void block_reduce_lds(float (&acc)[NV], unsigned cnt,
 constexpr int kAlignBlock = 1024;      // 16 waves: one workgroup per CU at 4 waves/SIMD -> 256 partial rows
 constexpr int kAlignMaxBlocks = 256;
 constexpr int kSearchedLog = 64;       // launches of an alignment whose searched-point counts are kept
+// Whether a point whose certificate failed starts its search from the previous winner (fused_point's SEED) in the per-iteration
+// kernels of registration.hip. Off: at their 128-register budget it costs the benchmarked instantiation one spilled register.
+constexpr bool kSeedSearches = false;
 
 // The pose of a launch into scalar registers (it is uniform; it would otherwise occupy 12 VGPRs for the whole loop).
 __device__ __forceinline__ Rigid uniform_pose(const float* sT) {

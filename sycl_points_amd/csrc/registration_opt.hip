@@ -242,12 +242,15 @@ __device__ __forceinline__ void opt_publish(float* T_out, const OptShared& S) {
     }
 }
 
-template <int LOSS, bool FAST_NN, bool P2D>
-__global__ __launch_bounds__(kAlignBlock) void gicp_optimize_kernel(FusedParams P, OptArgs A) {
+// BLOCK: lanes per workgroup. The search of a linearisation is bound by vector issue (thousands of wave instructions per 64
+// points), so a SMALL source wants its waves on many compute units, each wave alone on its SIMD — workgroups of 256 lanes —
+// and pays for it with the arrival counter between steps; a large source fills every compute unit with 1024 lanes anyway.
+template <int LOSS, bool FAST_NN, bool P2D, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, OptArgs A) {
     __shared__ OptShared S;
-    __shared__ float red[kFinalThreads / 32][kPartial];
+    __shared__ float red[BLOCK / 32][kPartial];
     __shared__ unsigned s_wait;
-    const unsigned stride = gridDim.x * kAlignBlock;
+    const unsigned stride = gridDim.x * BLOCK;
     unsigned tile = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const bool single = gridDim.x == 1;
@@ -273,8 +276,19 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_optimize_kernel(FusedParams 
         reinterpret_cast<float*>(&S.slin)[threadIdx.x - 64] = 0.0f;
     }
     __syncthreads();
+#ifdef SP_OPT_TIMING  // development builds: wall_clock64 stamps of the first steps into the tail of the result's log
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(&A.result->log[8]);
+#define SP_STAMP(k) if (publish && threadIdx.x == 0 && step < 20) stamps[step * 5 + (k)] = wall_clock64()
+#else
+#define SP_STAMP(k)
+#endif
     for (unsigned step = 0;; ++step) {
         const int phase = S.ctl.phase;  // uniform over the grid
+#ifdef SP_OPT_TIMING
+        if (publish && threadIdx.x == 0) g_sp_step = step;
+        __syncthreads();
+#endif
+        SP_STAMP(0);
         float* const row = A.part[step & 1] + (size_t)blockIdx.x * kPartial;
         if (phase == PHASE_LIN) {
             P.scale = A.scales[S.ctl.level];
@@ -284,20 +298,27 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_optimize_kernel(FusedParams 
             unsigned cnt = 0, searched = 0;
 #pragma unroll
             for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
-            for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-                fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
-            if (single) block_reduce_lds<kAcc - 1, kAlignBlock>(acc, cnt, searched, red[0]);
-            else block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, row, false, searched);
+            if constexpr (FAST_NN) {  // (the staged search: open queries are finished by the whole wave)
+                for (unsigned b = tile * BLOCK; b < P.n; b += stride)
+                    fused_point_wave<LOSS, P2D>(P, T, b + threadIdx.x, b + threadIdx.x < P.n, acc, cnt, searched);
+            } else {
+                for (unsigned i = tile * BLOCK + threadIdx.x; i < P.n; i += stride)
+                    fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
+            }
+            SP_STAMP(4);
+            if (single) block_reduce_lds<kAcc - 1, BLOCK>(acc, cnt, searched, red[0]);
+            else block_reduce_store<kAcc - 1, BLOCK, true>(acc, cnt, row, false, searched);
         } else {
             const Rigid T = uniform_pose(S.sTt);
             const Rigid TL = uniform_pose(S.sTlin);
             float acc[1] = {0.0f};
             unsigned cnt = 0;
-            for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
+            for (unsigned i = tile * BLOCK + threadIdx.x; i < P.n; i += stride)
                 error_prepared_point<LOSS, P2D>(P, T, TL, i, acc, cnt);
-            if (single) block_reduce_lds<1, kAlignBlock>(acc, cnt, 0u, red[0]);
-            else block_reduce_store<1, kAlignBlock, true>(acc, cnt, row, false, 0u);
+            if (single) block_reduce_lds<1, BLOCK>(acc, cnt, 0u, red[0]);
+            else block_reduce_store<1, BLOCK, true>(acc, cnt, row, false, 0u);
         }
+        SP_STAMP(1);
         if (!single) {
             // the hand-off of gicp_align_persistent_kernel: wave 0 (the storing lanes) drains its sc1 stores, lane 0 signals
             if (threadIdx.x < kWave) {
@@ -328,14 +349,19 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_optimize_kernel(FusedParams 
                 }
                 return;
             }
-            reduce_rows_1024<true>(A.part[step & 1], gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1, red, false, [] {});
+            reduce_rows_block<BLOCK, true>(A.part[step & 1], gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1, red);
         }
+        SP_STAMP(2);
         if (threadIdx.x == 0) {
             if (phase == PHASE_LIN) opt_after_linearize(S, red[0], publish);
             else opt_after_trial(S, red[0], publish);
         }
         __syncthreads();
+        SP_STAMP(3);
         if (S.ctl.done) {
+#ifdef SP_OPT_TIMING
+            if (publish) g_sp_step = 0;
+#endif
             if (publish) opt_publish(A.T_out, S);
             return;
         }
@@ -345,6 +371,11 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_optimize_kernel(FusedParams 
 }  // namespace
 }  // namespace sp
 
+#ifdef SP_OPT_TIMING
+extern "C" int sp_internal_opt_debug(unsigned long long* out384) {
+    return hipMemcpyFromSymbol(out384, HIP_SYMBOL(sp::g_sp_dbg), 24 * 16 * 8) == hipSuccess ? 0 : 3;
+}
+#endif
 extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
                                      const sp_factor_params* params, const sp_opt_params* opt, const float* robust_scales,
                                      int n_levels, sp_align_result* result_device, void* workspace, size_t workspace_bytes,
@@ -379,7 +410,10 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
                      "(sp_gicp_source_set_persistent)");
         return SP_ERR_RUNTIME;
     }
-    const unsigned grid = align_grid(n);
+    // workgroups of 256 lanes while they all fit the device one per compute unit (64 K points), of 1024 beyond
+    const bool small = n <= (size_t)256 * 256;
+    const unsigned block = small ? 256u : (unsigned)kAlignBlock;
+    const unsigned grid = std::min<unsigned>((unsigned)((n + block - 1) / block), (unsigned)kAlignMaxBlocks);
     PersistGuard* const guard = persist_acquire(st, grid);
     if (!guard) {
         sp_set_error("[sp_gicp_align_optimize] not available now: the launch cannot be resident (grid larger than the device, stream "
@@ -412,11 +446,14 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     }
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
-#define SP_LAUNCH_OPT(L)                                                                           \
-    if (fast && p2d) gicp_optimize_kernel<L, true, true><<<grid, kAlignBlock, 0, st>>>(P, A);       \
-    else if (fast) gicp_optimize_kernel<L, true, false><<<grid, kAlignBlock, 0, st>>>(P, A);        \
-    else if (p2d) gicp_optimize_kernel<L, false, true><<<grid, kAlignBlock, 0, st>>>(P, A);         \
-    else gicp_optimize_kernel<L, false, false><<<grid, kAlignBlock, 0, st>>>(P, A)
+#define SP_LAUNCH_OPT2(L, B)                                                                        \
+    if (fast && p2d) gicp_optimize_kernel<L, true, true, B><<<grid, B, 0, st>>>(P, A);              \
+    else if (fast) gicp_optimize_kernel<L, true, false, B><<<grid, B, 0, st>>>(P, A);               \
+    else if (p2d) gicp_optimize_kernel<L, false, true, B><<<grid, B, 0, st>>>(P, A);                \
+    else gicp_optimize_kernel<L, false, false, B><<<grid, B, 0, st>>>(P, A)
+#define SP_LAUNCH_OPT(L)                                    \
+    if (small) { SP_LAUNCH_OPT2(L, 256); }                 \
+    else { SP_LAUNCH_OPT2(L, kAlignBlock); }
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_OPT(LOSS_NONE); break;
         case SP_LOSS_HUBER: SP_LAUNCH_OPT(LOSS_HUBER); break;
@@ -425,6 +462,7 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
         case SP_LOSS_GEMAN_MCCLURE: SP_LAUNCH_OPT(LOSS_GEMAN_MCCLURE); break;
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
+#undef SP_LAUNCH_OPT2
 #undef SP_LAUNCH_OPT
     source->cache_valid = true;
     return launch_status();

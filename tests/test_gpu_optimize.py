@@ -178,3 +178,31 @@ def test_optimiser_argument_errors_and_switch(sp, orc):
     assert np.abs(res.T - ok.T).max() < 2e-6 and res.iterations == ok.iterations
     sp.check(L.sp_gicp_source_set_persistent(reg._psrc._h, 1))
     assert reg.align_optimize(S, prep, None) is not None
+
+
+def test_adaptive_grid_on_a_cloud_of_surfaces(sp, orc):
+    """sp_grid_create_adaptive on the reference's bundled scan, voxel-downsampled as its pipelines do before any search
+    (points on surfaces: the volume rule packs ~40 of them into an occupied cell): the cell shrinks until the occupied cells
+    are as full as a uniform cloud's, the lists stay the exact ones (brute-force oracle), and a uniform cloud is left alone."""
+    import os
+
+    from test_gpu_facade import GOLD, read_ply_xyz
+
+    scan = read_ply_xyz(os.path.join(GOLD, "target.ply"))
+    scan = scan[orc.box_filter(scan, 0.5, 50.0) == 1]
+    pts = orc.voxel_downsample(scan, 0.25, 1, stable=True)["points"]
+    P = dev(pts)
+    plain = sp.GridKNN.build(P, points_per_cell=0.5)
+    adapt = sp.GridKNN.build(P, points_per_cell=0.5, adaptive=True)
+    assert adapt.cell_size() < 0.5 * plain.cell_size()
+    assert adapt.max_cell_points() <= 16 < plain.max_cell_points()
+    q = dev(pts[::3] + np.float32([0.07, -0.05, 0.03, 0.0]))
+    oi, od = orc.knn_bruteforce(q.cpu().numpy(), pts, 1)
+    for g in (plain, adapt):
+        r = sp.KNNResult()
+        g.knn_search_async(q, 1, r)
+        assert np.array_equal(r.indices.cpu().numpy().reshape(-1), oi.reshape(-1))
+        assert np.array_equal(r.distances.cpu().numpy().reshape(-1), od.reshape(-1))
+    uni = dev(orc.rng(3).uniform_points(50000, 10.0))
+    a, b = sp.GridKNN.build(uni, points_per_cell=0.5), sp.GridKNN.build(uni, points_per_cell=0.5, adaptive=True)
+    assert a.cell_size() == b.cell_size()
