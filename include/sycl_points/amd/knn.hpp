@@ -216,12 +216,19 @@ public:
     void set_reference_tie_order(bool v) { reference_order_ = v; }
     /// MI355X extension: which structure knn_search_async(queries, k, ..., transT) answers from — the decision itself, without
     /// searching (the Python mirror sycl_points_amd.api.KDTree takes the same one; tests hold the two to each other).
-    enum class Backend { HostTree, Hierarchy, Grid };
+    enum class Backend { HostTree, Hierarchy, Grid, BruteForce };
     Backend backend_for(const PointCloudShared& queries, size_t k, const TransformMatrix& transT = TransformMatrix::Identity()) const {
         if (!(on_hierarchy() && k <= 32)) return Backend::HostTree;
         const bool own_cloud = built_on_ != nullptr && queries.points == built_on_ && queries.points->generation() == built_generation_ &&
                                queries.size() == size_ && transT == TransformMatrix::Identity();
         if (own_cloud && k >= 8 && k <= 20 && uniform_grid() != nullptr) return Backend::Grid;
+        // A small cloud — the reference example searches its 6 k-point downsampled scans with k = 10 — is answered by the exact
+        // brute-force search (sp_knn_bruteforce: bounding pass, then the reference's expression where a neighbour can be) in
+        // tens of microseconds; building the hierarchy alone takes 0.17 ms whatever the size, its k = 10 search 0.2 ms. Same
+        // lists: both break distance ties by the lowest index.
+        if (pristine_ && k <= 20 && transT == TransformMatrix::Identity() && size_ >= 2048 && size_ <= kBruteForceMaxTargets &&
+            size_ >= 256 * k && queries.size() <= kBruteForceMaxQueries)
+            return Backend::BruteForce;
         return Backend::Hierarchy;
     }
 
@@ -232,6 +239,19 @@ public:
         if (k > 100) throw std::runtime_error("[KDTree::knn_search_async] `k` is too large. not support.");
         detail::prepare_result(queue, result, nq, nq ? k : 0);
         if (nq == 0) return sycl_utils::events();
+        if (backend_for(queries, k, transT) == Backend::BruteForce) {
+            const size_t ws_bytes = sp_knn_bruteforce_workspace_bytes(nq, size_, k);
+            void* ws = nullptr;
+            size_t ws_got = 0;
+            if (ws_bytes) ws = sycl_points::detail::DeviceBufferCache::acquire(ws_bytes, &ws_got);
+            const int rc = sp_knn_bruteforce(queries.points_device(), nq, device_points(), size_, k,
+                                             result.indices->device_data_for_write(nq * k),
+                                             result.distances->device_data_for_write(nq * k), ws, ws_bytes, queue.stream());
+            // (back to the cache tagged with this stream: the next user waits for the search's event, nobody for the device)
+            if (ws) sycl_points::detail::DeviceBufferCache::release(ws, ws_got, queue.stream());
+            throw_on_error(rc);
+            return sycl_utils::events(queue.stream());
+        }
         if (on_hierarchy() && k <= 32) {
             // the tree's own cloud, untouched since build() and searched in place (the covariance pre-step of every pipeline):
             // its points are walked in tree order, neighbouring lanes share their path (1.5x faster than in query order)
@@ -305,6 +325,7 @@ public:
 
 private:
     static constexpr size_t kDeviceBuildMinPoints = 1024;
+    static constexpr size_t kBruteForceMaxTargets = 16384, kBruteForceMaxQueries = 65536;
     /// The device-built hierarchy answers: kNN (k <= 32), radius search and — since round 4 — after a lazy delete too
     /// (sp_bvh_radius_search / sp_bvh_remove_by_flags); the reference's tree only for its own tie order and k > 32.
     bool on_hierarchy() const { return hierarchy_ && !reference_order_; }

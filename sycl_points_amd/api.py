@@ -186,12 +186,15 @@ class KDTree(KNNBase):
     GRID_SELF_MIN_POINTS = 32768     # knn.hpp: KDTree::kGridSelfMinPoints
     GRID_SELF_MAX_CELL = 48          # knn.hpp: KDTree::kGridSelfMaxCell
     GRID_SELF_POINTS_PER_CELL = 6.0
+    BRUTE_FORCE_MAX_TARGETS = 16384  # knn.hpp: KDTree::kBruteForceMaxTargets
+    BRUTE_FORCE_MAX_QUERIES = 65536  # knn.hpp: KDTree::kBruteForceMaxQueries
 
     def __init__(self, handle, n, device):
         self._h = handle
         self.n = n
         self.device = device
-        self._bvh = None          # accelerate=True: the device-built hierarchy
+        self._hier = None         # the device-built hierarchy, built when a search first needs it (accelerate=True)
+        self._accelerated = False
         self._points = None       # ... the points it was built on (device tensor), for the lazily built reference tree / the grid
         self._self_grid = None
         self._self_grid_tried = False
@@ -204,7 +207,7 @@ class KDTree(KNNBase):
         if accelerate and p.shape[0] >= KDTree.DEVICE_BUILD_MIN_POINTS:
             pd = _dev_f32(p, 4)
             t = KDTree(None, pd.shape[0], pd.device)
-            t._bvh = BVH.build(pd)
+            t._accelerated = True  # (the hierarchy itself is built lazily, like the facade's: many trees never need it)
             t._points = pd
             t._leaf_threshold = leaf_threshold
             return t
@@ -214,6 +217,12 @@ class KDTree(KNNBase):
         check(_lib.lib().sp_kdtree_create(host.ctypes.data_as(C.c_void_p), host.shape[0], leaf_threshold, _stream(),
                                           C.byref(h)))
         return KDTree(h, host.shape[0], dev)
+
+    @property
+    def _bvh(self):
+        if self._accelerated and self._hier is None:
+            self._hier = BVH.build(self._points)
+        return self._hier
 
     def _host_tree(self):
         if not self._h and self._points is None:
@@ -236,14 +245,19 @@ class KDTree(KNNBase):
         return self._self_grid
 
     def backend_for(self, queries, k, transT=None):
-        """'kdtree' | 'bvh' | 'grid': what knn_search_async(queries, k, ..., transT) answers from (KDTree::backend_for)."""
-        if self._bvh is None or k > 32:
+        """'kdtree' | 'bvh' | 'grid' | 'bruteforce': what knn_search_async(queries, k, ..., transT) answers from
+        (KDTree::backend_for)."""
+        if not self._accelerated or k > 32:
             return "kdtree"
         q = _points_of(queries)
         own = (self._pristine and transT is None and isinstance(q, torch.Tensor) and q.is_cuda and q.shape[0] == self.n and
                q.data_ptr() == self._points.data_ptr())
         if own and 8 <= k <= 20 and self._uniform_grid() is not None:
             return "grid"
+        # a small cloud (the reference example's 6 k-point downsampled scans): exact brute force beats building a hierarchy
+        if (self._pristine and transT is None and k <= 20 and 2048 <= self.n <= KDTree.BRUTE_FORCE_MAX_TARGETS and
+                self.n >= 256 * k and q.shape[0] <= KDTree.BRUTE_FORCE_MAX_QUERIES):
+            return "bruteforce"
         return "bvh"
 
     def __del__(self):
@@ -258,7 +272,11 @@ class KDTree(KNNBase):
         q = _dev_f32(_points_of(queries), 4)
         if k > 100:
             raise SpError(2, "[KDTree::knn_search_async] `k` is too large. not support.")
-        backend = self.backend_for(queries, k, transT) if self._bvh is not None else "kdtree"
+        backend = self.backend_for(queries, k, transT) if self._accelerated else "kdtree"
+        if backend == "bruteforce":
+            res = knn_search_bruteforce(q, self._points, k)
+            result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k
+            return
         if backend == "grid":
             res = self._uniform_grid().self_knn(k)[0]
             result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k
@@ -285,7 +303,7 @@ class KDTree(KNNBase):
         if q.shape[0] == 0 or max_k == 0:
             result.resize(0, 0, q.device)
             return
-        if self._bvh is not None and max_k <= 32:
+        if self._accelerated and max_k <= 32:
             self._bvh.radius_search_async(queries, max_k, radius, result, transT)
             return
         result.resize(q.shape[0], max_k, q.device)
@@ -296,9 +314,9 @@ class KDTree(KNNBase):
     def remove_nodes_by_flags(self, flags, indices):
         if flags.shape[0] != indices.shape[0]:
             raise SpError(2, "[KDTree::remove_nodes_by_flags_impl] flags and indices must have the same size.")
-        if self._bvh is not None:
+        if self._accelerated:
             self._bvh.remove_nodes_by_flags(flags, indices)
-        if self._h or self._bvh is None:
+        if self._h or not self._accelerated:
             check(_lib.lib().sp_kdtree_remove_by_flags(self._host_tree(), _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
         elif self._points is not None:
             self._points = None  # (a reference tree built from here on would not be of the cloud the flags refer to)

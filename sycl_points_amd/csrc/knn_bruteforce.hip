@@ -334,11 +334,12 @@ __global__ void knn_bf_frame_kernel(const unsigned* __restrict__ box, BfFrame* _
 __global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_kernel(const float4* __restrict__ queries, unsigned nq,
                                                                  const float4* __restrict__ targets, unsigned nt,
                                                                  unsigned chunk, const BfFrame* __restrict__ frame,
-                                                                 float* __restrict__ amin) {
+                                                                 float* __restrict__ amin, unsigned il = 0) {
     __shared__ float4 tile[kTile];
     const unsigned split = blockIdx.y;
-    const unsigned t_begin = split * chunk;
-    const unsigned t_end = min(nt, t_begin + chunk);
+    // (il != 0: interleaved chunks, see chunk_target — slot s of chunk c is target s * il + c)
+    const unsigned t_begin = il ? 0u : split * chunk;
+    const unsigned t_end = il ? (split < nt ? (nt - split + il - 1) / il : 0u) : min(nt, t_begin + chunk);
     const float cx = frame->cx, cy = frame->cy, cz = frame->cz;
     unsigned qid[kQ1];
     v2f qx[kQ1 / 2], qy[kQ1 / 2], qz[kQ1 / 2], m[kQ1 / 2];
@@ -358,7 +359,8 @@ __global__ __launch_bounds__(kBlock) void knn_bf_chunkmin_kernel(const float4* _
         // (the tile is padded to a multiple of 4 with copies of its first point: a duplicate cannot change the minimum)
         const unsigned padded = (cnt + 3u) & ~3u;
         for (unsigned i = threadIdx.x; i < padded; i += kBlock) {
-            const float4 p = targets[base + (i < cnt ? i : 0u)];
+            const unsigned slot = base + (i < cnt ? i : 0u);
+            const float4 p = targets[il ? slot * il + split : slot];
             const float x = p.x - cx, y = p.y - cy, z = p.z - cz;
             tile[i] = make_float4(-2.0f * x, -2.0f * y, -2.0f * z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
         }
@@ -422,12 +424,14 @@ __device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) { return (lo
 
 __global__ __launch_bounds__(kBlock) void knn_bf_prep_targets_kernel(const float4* __restrict__ targets, unsigned nt,
                                                                      unsigned rows, const BfFrame* __restrict__ frame,
-                                                                     uint4* __restrict__ tA) {
+                                                                     uint4* __restrict__ tA, unsigned chunk = 0, unsigned il = 0) {
     const unsigned t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= rows) return;
     uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0x7f7fu, 0u);  // (k12 = 3.39e38, everything else 0)
-    if (t < nt) {
-        const float4 p = targets[t];
+    // row t = slot t % chunk of chunk t / chunk; with interleaved chunks (il != 0) that is target slot * il + chunk index
+    const unsigned ti = il ? (t % chunk) * il + t / chunk : t;
+    if (ti < nt) {
+        const float4 p = targets[ti];
         const float x = p.x - frame->cx, y = p.y - frame->cy, z = p.z - frame->cz;
         const float w = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
         if (isfinite(w)) {
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
                                                                 const unsigned* __restrict__ blk_off, unsigned nchunks,
                                                                 unsigned subs, const unsigned* __restrict__ chunk_list,
                                                                 unsigned* __restrict__ cand_cnt,
-                                                                unsigned long long* __restrict__ cand) {
+                                                                unsigned long long* __restrict__ cand, unsigned il = 0) {
     __shared__ float4 tile[kTile];
     const unsigned items = blk_off[nchunks];
     for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {  // (workgroup-uniform)
@@ -719,8 +723,11 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
     const unsigned sub = local % subs;
     const unsigned* const list = chunk_list + chunk_off[c];
     const unsigned sub_len = chunk / subs;  // (a multiple of kGroup: chunks are multiples of 256, subs is 1, 2 or 4)
-    const unsigned t_begin = min(nt, c * chunk + sub * sub_len);
-    const unsigned t_end = min(nt, t_begin + sub_len);
+    // the targets of this work item: a range of the chunk's slots; slot s of chunk c is target c * chunk + s, or, with
+    // interleaved chunks (il != 0: every chunk a uniform sample of the cloud, plan_bounded), target s * il + c
+    const unsigned n_c = il ? (c < nt ? (nt - c + il - 1) / il : 0u) : 0u;  // slots of an interleaved chunk
+    const unsigned t_begin = il ? min(n_c, sub * sub_len) : min(nt, c * chunk + sub * sub_len);
+    const unsigned t_end = il ? min(n_c, t_begin + sub_len) : min(nt, t_begin + sub_len);
     unsigned qid[2];
     v2f qx, qy, qz;
     float cap[2];
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
         // exact path below checks the index as well)
         const unsigned ngroups = (cnt + kGroup - 1) / kGroup;
         for (unsigned i = threadIdx.x; i < ngroups * kGroup; i += kBlock)
-            tile[i] = i < cnt ? targets[base + i] : make_float4(1e18f, 1e18f, 1e18f, 0.0f);
+            tile[i] = i < cnt ? targets[il ? (base + i) * il + c : base + i] : make_float4(1e18f, 1e18f, 1e18f, 0.0f);
         __syncthreads();
 #pragma unroll 2
         for (unsigned g = 0; g < ngroups; ++g) {
@@ -759,7 +766,8 @@ __global__ __launch_bounds__(kBlock) void knn_bf_collect_kernel(const float4* __
                     for (int u = 0; u < 2; ++u) {
                         if (j < cnt && d[t][u] < cap[u]) {
                             const unsigned s = atomicAdd(&cand_cnt[qid[u]], 1u);
-                            if (s < (unsigned)kCandCap) cand[(size_t)qid[u] * kCandCap + s] = cand_key(d[t][u], (int)(base + j));
+                            if (s < (unsigned)kCandCap)
+                                cand[(size_t)qid[u] * kCandCap + s] = cand_key(d[t][u], (int)(il ? (base + j) * il + c : base + j));
                         }
                     }
                 }
@@ -881,9 +889,14 @@ struct BoundedPlan {
     size_t off_min, off_bound, off_counts, off_chunk_list, off_cand, off_operands, bytes;  // workspace layout
 };
 
+// From this many targets on the two-pass path is taken (when they split into at least k chunks). It used to start at 16 K; on
+// the 1 k .. 16 k-point clouds below that (the reference example's downsampled scans) the single-pass kernel's sorted insertion
+// made k = 10 / 20 cost 0.4 / 1.1 ms whatever the size, where the two passes need 0.1 ms (scratch/bf_small.py).
+constexpr size_t kBoundedMinTargets = 2048;
+constexpr size_t kInterleaveMaxTargets = 65536;  // interleaved chunks up to here (run_bounded)
 BoundedPlan plan_bounded(size_t nq, size_t nt, size_t k) {
     BoundedPlan P{};
-    if (k < 1 || nt < (size_t)16 * kTile) return P;
+    if (k < 1 || nt < (size_t)kBoundedMinTargets) return P;
     if (k == 1 && nt > kApproxMaxTargets) return P;  // (exact minima only: the k = 1 kernel finishes the job itself)
     P.a.qpt = kQ1;
     P.a.qblocks = div_up(nq, (size_t)kBlock * kQ1);
@@ -927,6 +940,12 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
     const float4* t4 = reinterpret_cast<const float4*>(t);
     const unsigned G = P.a.nsplit, nwaves = div_up(nq, (size_t)64);
     const bool approx = nt <= kApproxMaxTargets;
+    // Chunks are INTERLEAVED for small target clouds (chunk c = targets c, c + G, c + 2G, ...): the bound is the k-th smallest
+    // chunk minimum, which is tight when every chunk is a uniform sample of the cloud and useless when chunks are spatial
+    // clumps — a cloud stored in voxel order (what downsampling yields) made contiguous chunks list hundreds of candidates per
+    // query and sent most queries to the overflow rescan (0.21 ms per 6 k-point cloud, k = 10, against 0.04). The strided
+    // reads this costs stay inside L2 for clouds of this size; larger clouds keep contiguous chunks.
+    const unsigned il = (approx && nt <= kInterleaveMaxTargets) ? G : 0u;
     if (approx) {
         const unsigned rows = G * P.a.chunk, cols = div_up(nq, (size_t)kMfmaQueries) * kMfmaQueries;
         uint4* tA = reinterpret_cast<uint4*>(w + P.off_operands);
@@ -936,9 +955,9 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
         knn_bf_box_kernel<<<std::min(div_up(nt, kBlock), 64u), kBlock, 0, st>>>(t4, (unsigned)nt, box);
         knn_bf_frame_kernel<<<1, 64, 0, st>>>(box, frame);
         if (g_pass_a_valu) {
-            knn_bf_chunkmin_kernel<<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, frame, amin);
+            knn_bf_chunkmin_kernel<<<dim3(P.a.qblocks, G), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.a.chunk, frame, amin, il);
         } else {
-            knn_bf_prep_targets_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(t4, (unsigned)nt, rows, frame, tA);
+            knn_bf_prep_targets_kernel<<<div_up(rows, kBlock), kBlock, 0, st>>>(t4, (unsigned)nt, rows, frame, tA, P.a.chunk, il);
             knn_bf_prep_queries_kernel<<<div_up(cols, kBlock), kBlock, 0, st>>>(q4, (unsigned)nq, cols, frame, qB, qq);
             const unsigned cpw = 2;  // chunks per workgroup (1 .. 14 and 2 / 4 / 8 tiles per wave all within 10 %: scratch/bf_sweep.sh)
             knn_bf_chunkmin_mfma_kernel<<<dim3(cols / kMfmaQueries, div_up(G, cpw)), kBlock, 0, st>>>(tA, qB, qq, (unsigned)nq, P.a.chunk,
@@ -956,7 +975,7 @@ int run_bounded(const float* q, size_t nq, const float* t, size_t nt, size_t k, 
     knn_bf_offsets_kernel<<<1, kMaxChunks, 0, st>>>(chunk_cnt, G, subs, chunk_off, blk_off);
     knn_bf_lists_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(need_mask, (unsigned)nq, G, chunk_off, wave_cnt, nwaves, chunk_list);
     knn_bf_collect_kernel<<<kNumCU * 8, kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, P.b.chunk, bound, chunk_cnt, chunk_off,
-                                                         blk_off, G, subs, chunk_list, cand_cnt, cand);
+                                                         blk_off, G, subs, chunk_list, cand_cnt, cand, il);
     knn_bf_select_kernel<<<div_up(nq * 64, kBlock), kBlock, 0, st>>>(q4, (unsigned)nq, t4, (unsigned)nt, (int)k, cand_cnt, cand, idx, d2);
     return launch_status();
 }

@@ -805,6 +805,23 @@ static void kdtree_backend_on_the_bundled_scan() {
     random_points(gen, c, 800, 10.0f);
     PointCloudShared small(*Q, c);
     CHECK(alg::knn::KDTree::build(*Q, small)->backend_for(small, 10) == Backend::HostTree);
+    // a cloud of a few thousand points (the example's downsampled scans): exact brute force, no hierarchy is built; the lists
+    // are the brute-force search's own (same tie rule as the hierarchy); a transform or a removed node ends the shortcut
+    PointCloudCPU cm;
+    random_points(gen, cm, 6000, 10.0f);
+    PointCloudShared mid(*Q, cm);
+    auto mt = alg::knn::KDTree::build(*Q, mid);
+    CHECK(mt->backend_for(mid, 10) == Backend::BruteForce && mt->backend_for(mid, 20) == Backend::BruteForce);
+    CHECK(mt->backend_for(mid, 24) == Backend::Hierarchy);  // fewer than k chunks of 256 targets
+    TransformMatrix Tm = TransformMatrix::Identity();
+    Tm(0, 3) = 0.5f;
+    CHECK(mt->backend_for(mid, 10, Tm) == Backend::Hierarchy);
+    const auto r_bf = mt->knn_search(mid, 10);
+    const auto r_ref = alg::knn::knn_search_bruteforce(*Q, mid, mid, 10);
+    bool same = true;
+    for (size_t i = 0; i < 6000 * 10; ++i)
+        same = same && (*r_bf.indices)[i] == (*r_ref.indices)[i] && (*r_bf.distances)[i] == (*r_ref.distances)[i];
+    CHECK(same);
 }
 
 static void kdtree_radius_and_lazy_delete_on_the_hierarchy() {

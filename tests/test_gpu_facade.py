@@ -109,6 +109,15 @@ def test_python_kdtree_takes_the_facades_decisions(orc):
         assert np.array_equal(r.indices.cpu().numpy()[:2000], oi[:, :k]) and np.array_equal(r.distances.cpu().numpy()[:2000], od[:, :k])
     small = dev(orc.rng(5).uniform_points(800, 10.0))
     assert sp.KDTree.build(small, accelerate=True).backend_for(small, 10) == "kdtree"
+    # a few thousand points (the example's downsampled scans): exact brute force, no hierarchy built
+    mid = dev(orc.rng(6).uniform_points(6000, 10.0))
+    tm = sp.KDTree.build(mid, accelerate=True)
+    assert tm.backend_for(mid, 10) == "bruteforce" and tm.backend_for(mid, 20) == "bruteforce" and tm.backend_for(mid, 24) == "bvh"
+    assert tm.backend_for(mid, 10, np.eye(4, dtype=np.float32)) == "bvh"
+    oi, od = orc.knn_bruteforce(mid.cpu().numpy(), mid.cpu().numpy(), 10)
+    r = tm.knn_search(mid, 10)
+    assert tm._hier is None  # (never built)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
     # after a lazy delete the hierarchy keeps answering (sp_bvh_remove_by_flags); the grid shortcut for the own cloud is gone
     flags = np.ones(40000, np.uint8)
     flags[::10] = 0  # (1 = keep, with the kept points' new indices: test_kdtree.cpp:459-512)

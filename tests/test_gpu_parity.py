@@ -192,10 +192,29 @@ def test_bruteforce_pass_a_error_stays_inside_its_bound(sp, orc, valu):
     E = coeff * (np.linalg.norm(q64 - centre, axis=1) + pmax) ** 2
     worst = 0.0
     for c in range(G):
-        blk = t64[c * chunk:(c + 1) * chunk]
+        # (up to 65536 targets the chunks are interleaved — chunk c = targets c, c + G, c + 2G, ... — so that each is a uniform
+        # sample of the cloud whatever its storage order: run_bounded, knn_bruteforce.hip)
+        blk = t64[c::G] if nt <= 65536 else t64[c * chunk:(c + 1) * chunk]
         ref = ((q64[:, None, :] - blk[None, :, :]) ** 2).sum(2).min(1)
         worst = max(worst, float((np.abs(amin[c] - ref) / E).max()))
     assert worst < 0.6, worst
+
+
+@pytest.mark.parametrize("n, k", [(2048, 8), (2560, 10), (6000, 10), (6000, 20), (16384, 20), (30000, 5)])
+def test_bruteforce_small_spatially_ordered_clouds(sp, orc, n, k):
+    # Clouds of a few thousand points take the two-pass search too (from 2048 targets that split into k chunks), with
+    # interleaved chunks; a cloud in spatial order (sorted by voxel key, as downsampling leaves it) with duplicates is the
+    # case contiguous chunks handled worst. Lists bit-identical to the oracle's.
+    g = orc.rng(n + k)
+    pts = g.uniform_points(n, 10.0)
+    pts[:, 2] = np.round(pts[:, 2] * 0.05) / 0.05 * 0.01  # a few sheets: surfaces, not a filled box
+    pts[::97] = pts[5]                                      # duplicates: distance ties, lowest index first
+    order = np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))
+    pts = np.ascontiguousarray(pts[order])
+    q = np.ascontiguousarray(pts[:: max(1, n // 1500)])
+    r = sp.knn_search_bruteforce(dev(q), dev(pts), k)
+    oi, od = orc.knn_bruteforce(q, pts, k)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
 
 
 def test_bruteforce_config2_size_k20(sp, orc):
