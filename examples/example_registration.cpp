@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     const auto voxel_grid = std::make_shared<alg::filter::VoxelGrid>(queue, voxel_size);
     const auto preprocess = std::make_shared<alg::filter::PreprocessFilter>(queue);
 
-    std::map<std::string, double> elapsed;
+    std::map<std::string, double> elapsed, detail;  // detail: parts of the reference's stages, printed beside them
     auto now = [] { return std::chrono::high_resolution_clock::now(); };
     auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     sycl_points::TransformMatrix T_final = sycl_points::TransformMatrix::Identity();
@@ -59,11 +59,19 @@ int main(int argc, char** argv) {
         sycl_points::PointCloudShared source(queue, source_points), target(queue, target_points);
         const double dt_shared = us(t0, now());
         t0 = now();
+        auto t1 = now();
         preprocess->box_filter(source, 0.5f, 50.0f);
+        const double dt_box_s = us(t1, now());
         sycl_points::PointCloudShared source_ds(queue), target_ds(queue);
+        t1 = now();
         voxel_grid->downsampling(source, source_ds);
+        const double dt_vox_s = us(t1, now());
+        t1 = now();
         preprocess->box_filter(target, 0.5f, 50.0f);
+        const double dt_box_t = us(t1, now());
+        t1 = now();
         voxel_grid->downsampling(target, target_ds);
+        const double dt_vox_t = us(t1, now());
         const double dt_down = us(t0, now());
         t0 = now();
         std::shared_ptr<alg::knn::KNNBase> source_knn, target_knn;
@@ -98,6 +106,8 @@ int main(int argc, char** argv) {
             elapsed["5. compute Covariances"] += dt_cov;
             elapsed["6. compute Normals"] += dt_normal;
             elapsed["7. Registration"] += dt_reg;
+            detail["2a. box filter (source + target)"] += dt_box_s + dt_box_t;
+            detail["2b. voxel downsampling (source + target)"] += dt_vox_s + dt_vox_t;
         }
         if (i == LOOP + WARM_UP - 1) {
             T_final = ret.T.matrix();
@@ -109,6 +119,7 @@ int main(int argc, char** argv) {
     double total = 0;
     for (auto& [k, v] : elapsed) { std::printf("%28s: %10.2f us\n", k.c_str(), v / LOOP); total += v / LOOP; }
     std::printf("%28s: %10.2f us\n", "TOTAL", total);
+    for (auto& [k, v] : detail) std::printf("%44s: %10.2f us\n", k.c_str(), v / LOOP);
     std::printf("RESULT");
     for (int i = 0; i < 16; ++i) std::printf(" %.9g", T_final.data()[i]);
     std::printf("\n");

@@ -378,15 +378,39 @@ public:
 
 private:
     void apply_flags(const PointCloudShared& source, PointCloudShared& output) {
-        const bool c = source.has_cov(), n = source.has_normal(), r = source.has_rgb(), i = source.has_intensity(),
-                   t = source.has_timestamps();
+        // FilterByFlags over every attribute the cloud carries (preprocess_operator_base): one scan of the flags, one
+        // compaction launch per attribute, written straight into the new containers (no staging copy), ONE count read-back.
+        const size_t N = source.size();
         PointCloudShared out(queue_);
-        by_flags_.filter_by_flags(*source.points, *out.points, *flags_);
-        if (c) by_flags_.filter_by_flags(*source.covs, *out.covs, *flags_);
-        if (n) by_flags_.filter_by_flags(*source.normals, *out.normals, *flags_);
-        if (r) by_flags_.filter_by_flags(*source.rgb, *out.rgb, *flags_);
-        if (i) by_flags_.filter_by_flags(*source.intensities, *out.intensities, *flags_);
-        if (t) by_flags_.filter_by_flags(*source.timestamp_offsets, *out.timestamp_offsets, *flags_);
+        const void* rows[6];
+        void* dst[6];
+        size_t bytes[6];
+        int na = 0;
+        auto add = [&](auto& src_vec, auto& dst_vec) {
+            using T = typename std::remove_reference_t<decltype(src_vec)>::value_type;
+            rows[na] = src_vec.device_data();
+            dst[na] = dst_vec.device_data_for_write(N);
+            bytes[na] = sizeof(T);
+            ++na;
+        };
+        add(*source.points, *out.points);
+        if (source.has_cov()) add(*source.covs, *out.covs);
+        if (source.has_normal()) add(*source.normals, *out.normals);
+        if (source.has_rgb()) add(*source.rgb, *out.rgb);
+        if (source.has_intensity()) add(*source.intensities, *out.intensities);
+        if (source.has_timestamps()) add(*source.timestamp_offsets, *out.timestamp_offsets);
+        const size_t ws_bytes = sp_compact_workspace_bytes(N);
+        detail::DeviceScratch ws(ws_bytes), count(4);
+        hipStream_t st = queue_.stream();
+        throw_on_error(sp_compact_by_flags_multi(rows, bytes, dst, na, N, flags_->device_data(), nullptr,
+                                                 static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
+        const size_t M = detail::read_u32(count.p, st);  // (synchronises: the scratch is idle when it leaves scope)
+        out.points->set_device_size(M);
+        if (source.has_cov()) out.covs->set_device_size(M);
+        if (source.has_normal()) out.normals->set_device_size(M);
+        if (source.has_rgb()) out.rgb->set_device_size(M);
+        if (source.has_intensity()) out.intensities->set_device_size(M);
+        if (source.has_timestamps()) out.timestamp_offsets->set_device_size(M);
         const double t0 = source.start_time_ms, t1 = source.end_time_ms;
         output.points = out.points; output.covs = out.covs; output.normals = out.normals; output.rgb = out.rgb;
         output.intensities = out.intensities; output.timestamp_offsets = out.timestamp_offsets;

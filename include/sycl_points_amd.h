@@ -266,6 +266,12 @@ size_t sp_compact_workspace_bytes(size_t n);
 int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes, const uint8_t* flags, void* rows_out,
                         int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* The same for several attribute arrays of one cloud at once (FilterByFlags is applied to points, covariances, normals, ...
+ * in turn, preprocess_operator_base / filter_by_flags.hpp:87-99): ONE scan of the flags, one compaction launch per array,
+ * one count. n_arrays <= 16; rows[a] has rows of row_bytes[a] bytes and goes to rows_out[a] (host arrays of device pointers). */
+int sp_compact_by_flags_multi(const void* const* rows, const size_t* row_bytes, void* const* rows_out, int n_arrays, size_t n,
+                              const uint8_t* flags, int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------- registration */
 

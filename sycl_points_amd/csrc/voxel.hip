@@ -224,21 +224,102 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const KEY* __restrict
     __syncthreads();
     const bool head = key != invalid && (i == 0 || prev != key);
     uint32_t keep = 0;
-    if (head) {
-        float px = 0.0f, py = 0.0f, pz = 0.0f, pw = 0.0f;
-        float cx = 0.0f, cy = 0.0f, cz = 0.0f, cw = 0.0f, tsum = 0.0f;
-        unsigned e = i;
-        while (e < n) {
-            const unsigned l = e - base;
-            const bool local = l < (unsigned)kBlock;
-            if ((local ? lkey[l] : sk[e]) != key) break;
-            const uint32_t src = local ? lsrc[l] : sv[e];
-            const float4 p = local ? lpt[l] : pts[src];
-            px += p.x; py += p.y; pz += p.z; pw += p.w;
-            if (a.rgb) { const float4 c = a.rgb[src]; cx += c.x; cy += c.y; cz += c.z; cw += c.w; }
-            if (a.ts) tsum += a.ts[src];
-            ++e;
+    float px = 0.0f, py = 0.0f, pz = 0.0f, pw = 0.0f;
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f, cw = 0.0f, tsum = 0.0f;
+    unsigned e = i;
+    if (head) {  // the part of the run inside the workgroup's 256 positions: out of LDS
+        // eight members per step: their LDS reads are independent (one latency per step, not per member); the sums stay in
+        // index order, and a member past the end of the run ends the walk
+        const unsigned lim = min(n - base, (unsigned)kBlock);  // positions of this workgroup that exist
+        bool go = true;
+        while (go && e - base < lim) {
+            const unsigned l0 = e - base;
+            KEY kk[8];
+            float4 pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned l = min(l0 + j, (unsigned)kBlock - 1u);
+                kk[j] = lkey[l];
+                pp[j] = lpt[l];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (!go) break;
+                if (l0 + j >= lim || kk[j] != key) { go = false; break; }
+                px += pp[j].x; py += pp[j].y; pz += pp[j].z; pw += pp[j].w;
+                if (a.rgb || a.ts) {
+                    const uint32_t src = lsrc[l0 + j];
+                    if (a.rgb) { const float4 c = a.rgb[src]; cx += c.x; cy += c.y; cz += c.z; cw += c.w; }
+                    if (a.ts) tsum += a.ts[src];
+                }
+                ++e;
+            }
         }
+    }
+    // A run that goes on past the workgroup's positions (a voxel of hundreds of points: the near range of a LiDAR scan at
+    // 0.25 m) used to be chased by its head alone — key -> index -> point, three dependent loads per member, 55 us of a
+    // 70 k-point call. The sums must stay in index order (bit-identical results), but the LOADS need not wait for each other:
+    // the head's wave fetches the next 64 members at once, parks them in its quarter of the LDS tile, and the head adds them
+    // in order. One head at a time per wave (there is at most one such run per workgroup boundary, rarely two).
+    __syncthreads();  // every head has finished reading the tile
+    {
+        const unsigned lane = threadIdx.x & 63u, w0 = threadIdx.x & ~63u;
+        bool more = head && e < n && e - base >= (unsigned)kBlock;
+        unsigned long long todo = __ballot(more);
+        while (todo) {
+            const int owner = __ffsll((long long)todo) - 1;
+            const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)e, owner);
+            KEY k0;
+            if constexpr (sizeof(KEY) == 8) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, owner);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)key >> 32), owner);
+                k0 = (KEY)(((unsigned long long)hi << 32) | lo);
+            } else {
+                k0 = (KEY)__builtin_amdgcn_readlane((int)key, owner);
+            }
+            // four batches of 64 members, all their loads in flight together (a voxel of a thousand points is four such rounds)
+            constexpr int kU = 4;
+            bool match[kU];
+            uint32_t src[kU];
+            float4 pt[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const unsigned idx = e0 + 64u * u + lane;
+                match[u] = idx < n && sk[idx] == k0;
+                src[u] = match[u] ? sv[idx] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) pt[u] = match[u] ? pts[src[u]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            unsigned cnt = 64u;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (cnt < 64u) break;  // (uniform: the run ended inside the previous batch)
+                lsrc[w0 + lane] = src[u];
+                lpt[w0 + lane] = pt[u];
+                const unsigned long long mm = __ballot(match[u]);
+                cnt = mm == ~0ull ? 64u : (unsigned)__builtin_ctzll(~mm);  // members of the run among these 64
+                __builtin_amdgcn_wave_barrier();
+                if ((int)lane == owner) {
+                    for (unsigned j0 = 0; j0 < cnt; j0 += 8) {
+                        float4 pp[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pp[j] = lpt[w0 + min(j0 + j, 63u)];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (j0 + j >= cnt) break;
+                            px += pp[j].x; py += pp[j].y; pz += pp[j].z; pw += pp[j].w;
+                            if (a.rgb) { const float4 c = a.rgb[lsrc[w0 + j0 + j]]; cx += c.x; cy += c.y; cz += c.z; cw += c.w; }
+                            if (a.ts) tsum += a.ts[lsrc[w0 + j0 + j]];
+                        }
+                    }
+                    e += cnt;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (cnt < 64u) todo &= todo - 1ull;  // the run has ended: the next head of this wave
+        }
+    }
+    if (head) {
         if (pw >= min_count) {
             keep = 1;
             t_pts[i] = make_float4(px / pw, py / pw, pz / pw, pw / pw);
@@ -533,10 +614,20 @@ extern "C" size_t sp_compact_workspace_bytes(size_t n) {
 extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes, const uint8_t* flags, void* rows_out,
                                    int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+    return sp_compact_by_flags_multi(&rows, &row_bytes, &rows_out, 1, n, flags, new_indices_out_opt, n_out_dev, workspace,
+                                     workspace_bytes, stream);
+}
+
+extern "C" int sp_compact_by_flags_multi(const void* const* rows, const size_t* row_bytes, void* const* rows_out, int n_arrays,
+                                         size_t n, const uint8_t* flags, int32_t* new_indices_out_opt, uint32_t* n_out_dev,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
     using namespace sp;
     hipStream_t st = as_stream(stream);
+    if (n_arrays < 1 || n_arrays > 16 || !rows || !row_bytes || !rows_out) return SP_ERR_INVALID_ARGUMENT;
     if (n == 0) return zero_async(n_out_dev, 4, st);
-    if (row_bytes % 4 != 0 || n >= (1ull << 30)) {
+    bool ok_rows = n < (1ull << 30);
+    for (int a = 0; a < n_arrays; ++a) ok_rows = ok_rows && row_bytes[a] % 4 == 0;
+    if (!ok_rows) {
         sp_set_error("[FilterByFlags] row_bytes must be a multiple of 4 and n < 2^30");
         return SP_ERR_INVALID_ARGUMENT;
     }
@@ -553,8 +644,10 @@ extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes,
         sp_set_error("[FilterByFlags] scan failed");
         return SP_ERR_HIP;
     }
-    compact_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(wide, pos, (unsigned)n, static_cast<const uint32_t*>(rows),
-                                                         (unsigned)(row_bytes / 4), static_cast<uint32_t*>(rows_out),
-                                                         new_indices_out_opt, n_out_dev);
+    // one scan of the flags, then every array through it (the new indices and the count with the first)
+    for (int a = 0; a < n_arrays; ++a)
+        compact_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(wide, pos, (unsigned)n, static_cast<const uint32_t*>(rows[a]),
+                                                             (unsigned)(row_bytes[a] / 4), static_cast<uint32_t*>(rows_out[a]),
+                                                             a == 0 ? new_indices_out_opt : nullptr, n_out_dev);
     return launch_status();
 }
