@@ -372,12 +372,12 @@ public:
             std::swap(indices[i], indices[dist(mt_)]);
         }
         for (size_t i = 0; i < sampling_num; ++i) (*flags_)[indices[i]] = INCLUDE_FLAG;
-        apply_flags(source, output);
+        apply_flags(source, output, sampling_num);  // (exactly sampling_num flags are set: the count need not be read back)
     }
     void random_sampling(PointCloudShared& data, size_t sampling_num) { random_sampling(data, data, sampling_num); }
 
 private:
-    void apply_flags(const PointCloudShared& source, PointCloudShared& output) {
+    void apply_flags(const PointCloudShared& source, PointCloudShared& output, size_t known_count = SIZE_MAX) {
         // FilterByFlags over every attribute the cloud carries (preprocess_operator_base): one scan of the flags, one
         // compaction launch per attribute, written straight into the new containers (no staging copy), ONE count read-back.
         const size_t N = source.size();
@@ -400,11 +400,23 @@ private:
         if (source.has_intensity()) add(*source.intensities, *out.intensities);
         if (source.has_timestamps()) add(*source.timestamp_offsets, *out.timestamp_offsets);
         const size_t ws_bytes = sp_compact_workspace_bytes(N);
-        detail::DeviceScratch ws(ws_bytes), count(4);
         hipStream_t st = queue_.stream();
+        hipStream_t ws_release_stream = nullptr;
+        // (with a known count nothing synchronises here: the scratch goes back tagged with the stream's event instead of idle)
+        struct Scratch {
+            void* p = nullptr; size_t bytes = 0; hipStream_t* tag;
+            Scratch(size_t n, hipStream_t* t) : tag(t) { if (n) p = ::sycl_points::detail::DeviceBufferCache::acquire(n, &bytes); }
+            ~Scratch() {
+                if (!p) return;
+                if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();  // (left by an exception: nothing was waited for)
+                ::sycl_points::detail::DeviceBufferCache::release(p, bytes, *tag, *tag == nullptr);
+            }
+        } ws(ws_bytes, &ws_release_stream), count(4, &ws_release_stream);
         throw_on_error(sp_compact_by_flags_multi(rows, bytes, dst, na, N, flags_->device_data(), nullptr,
                                                  static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
-        const size_t M = detail::read_u32(count.p, st);  // (synchronises: the scratch is idle when it leaves scope)
+        size_t M = known_count;
+        if (known_count == SIZE_MAX) M = detail::read_u32(count.p, st);  // (synchronises: the scratch is idle when it leaves scope)
+        else ws_release_stream = st;
         out.points->set_device_size(M);
         if (source.has_cov()) out.covs->set_device_size(M);
         if (source.has_normal()) out.normals->set_device_size(M);

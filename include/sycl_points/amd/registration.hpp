@@ -479,14 +479,29 @@ private:
     }
     void prepare_fused(const PointCloudShared& source, const PointCloudShared& target, const knn::GridKNN& grid,
                        const TransformMatrix& T0) {
+        // Reuse certificates (one k = 3 self-search of the target) pay when many source points are aligned to the target, or the
+        // target is aligned to again (a submap, frame after frame). A target that is new and large beside its source — the
+        // reference's example: a fresh 6 k-point target per frame, a 1000-point sample aligned to it — is prepared without them
+        // (every linearisation then searches, seeded by the previous winner) and gets them if it comes back.
+        const bool small_source = source.size() * 4 < target.size();
         if (ptgt_ == nullptr || ptgt_grid_id_ != grid.id()) {
             if (ptgt_) sp_gicp_target_destroy(ptgt_);
             ptgt_ = nullptr;
-            throw_on_error(sp_gicp_target_create(grid.handle(), target.covs_device(), target.size(), queue_.stream(), &ptgt_));
+            if (small_source)
+                throw_on_error(sp_gicp_target_create_plain(grid.handle(), target.covs_device(), target.size(), queue_.stream(), &ptgt_));
+            else
+                throw_on_error(sp_gicp_target_create(grid.handle(), target.covs_device(), target.size(), queue_.stream(), &ptgt_));
             ptgt_grid_id_ = grid.id();
             ptgt_covs_ = target.covs.get();  // (created with the GICP rows of these covariances)
             ptgt_covs_gen_ = target.covs->generation();
             ptgt_reg_ = int(RegType::GICP);
+            ptgt_uses_ = 0;
+        }
+        ++ptgt_uses_;
+        if ((ptgt_uses_ >= 2 || !small_source) && !sp_gicp_target_has_certificates(ptgt_)) {
+            throw_on_error(sp_gicp_target_certify(ptgt_, target.covs_device(), queue_.stream()));
+            ptgt_covs_ = target.covs.get();  // (the rows were rewritten from these covariances, for the factor they already served)
+            ptgt_covs_gen_ = target.covs->generation();
         }
         // rows of the factor asked for: plane(Ct) for GICP, inverse(Ct) for point-to-distribution (factor.hpp:311-317) —
         // once per (target covariances, factor): a caller that aligns frame after frame against the same target does not pay
@@ -506,10 +521,14 @@ private:
         }
         last_src_points_ = source.points_device();
         last_src_covs_ = source.covs_device();
-        throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, last_src_points_, last_src_covs_, source.size(),
-                                              T0.data(), 0, source_presorted_ ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT, queue_.stream()));
+        throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, last_src_points_, last_src_covs_, source.size(), T0.data(), 0,
+                                              source_order(source.size()), queue_.stream()));
         neighbors_.indices == nullptr ? neighbors_.allocate(queue_, source.size(), 1) : neighbors_.resize(source.size(), 1);
     }
+    /// How sp_gicp_source_prepare orders the source: as it is when the caller says it is spatially ordered — or when it is a few
+    /// thousand points (the pipeline's random sample): the order only decides which lane handles which point, and the cell sort
+    /// is seven launches for something a handful of waves do not notice.
+    int source_order(size_t n) const { return (source_presorted_ || n <= 4096) ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT; }
     const knn::GridKNN* grid_for(const knn::KDTree& tree, const PointCloudShared& target) {
         if (!tree.pristine() || tree.size() != target.size() || target.size() == 0) return nullptr;
         if (kd_grid_ == nullptr || kd_grid_tree_id_ != tree.id()) {
@@ -606,7 +625,7 @@ private:
                 throw std::runtime_error("[Registration::align] the device-resident loop ran into its time limit");
             retried_without_persistent_ = true;
             throw_on_error(sp_gicp_source_prepare(psrc_, ptgt_, last_src_points_, last_src_covs_, N, initial_guess.data(), 0,
-                                                  source_presorted_ ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT, queue_.stream()));
+                                                  source_order(N), queue_.stream()));
             const RegistrationResult again = align_on_device(N, initial_guess, robust_scale);
             retried_without_persistent_ = false;
             return again;
@@ -759,6 +778,7 @@ private:
     const void* ptgt_covs_ = nullptr;  // the covariance container the prepared rows were computed from, ...
     uint64_t ptgt_covs_gen_ = 0;       // ... its generation then, ...
     int ptgt_reg_ = -1;                // ... and the factor they are the rows of
+    unsigned ptgt_uses_ = 0;           // alignments against this prepared target so far (second use: certificates, prepare_fused)
     bool source_presorted_ = false;
     sp_comm* comm_ = nullptr;  // borrowed (set_communicator)
     sp_xchg* xchg_ = nullptr;  // borrowed (set_exchange)

@@ -375,6 +375,14 @@ typedef struct sp_gn_params { float lambda, crit_rotation, crit_translation; } s
 enum { SP_SOURCE_ORDER_UNKNOWN = 0, SP_SOURCE_SORT = 1, SP_SOURCE_PRESORTED = 2 };
 int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream, sp_gicp_target** out);
 int sp_gicp_target_update(sp_gicp_target* target, const float* tgt_covs, void* stream);
+/* The same without the reuse certificates (no k = 3 self-search: a fifth of the cost at 6 k points, where the search is
+ * 0.1 ms of launch-bound work): every linearisation then searches every point, starting from its previous winner. What a
+ * caller wants for a target it aligns ONE small source against — the reference's example builds a new target per frame and
+ * aligns a 1000-point sample to it. sp_gicp_target_certify adds the certificates later (a target that turns out to be reused);
+ * it synchronises, rewrites the rows and invalidates the correspondence caches of prepared sources. */
+int sp_gicp_target_create_plain(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream, sp_gicp_target** out);
+int sp_gicp_target_certify(sp_gicp_target* target, const float* tgt_covs, void* stream);
+int sp_gicp_target_has_certificates(const sp_gicp_target* target);
 /* The same, choosing the factor the rows serve: SP_REG_GICP (what create makes: V diag(1e-3,1,1) V^T of the covariance) or
  * SP_REG_POINT_TO_DISTRIBUTION (linearize_point_to_distribution, factor.hpp:311-373: the information matrix itself,
  * inverse(Ct) of the RAW covariance, Zero when |det| < 1e-6, so the iteration inverts nothing per point and reads no source

@@ -144,6 +144,9 @@ SIGNATURES = {
     "sp_icp_robust_weights": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp]),
     "sp_genz_counts": (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp, _vp]),
     "sp_gicp_target_create": (_i, [_vp, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "sp_gicp_target_create_plain": (_i, [_vp, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "sp_gicp_target_certify": (_i, [_vp, _vp, _vp]),
+    "sp_gicp_target_has_certificates": (_i, [_vp]),
     "sp_gicp_target_update": (_i, [_vp, _vp, _vp]),
     "sp_gicp_target_prepare": (_i, [_vp, _vp, _i, _vp]),
     "sp_gicp_error_prepared": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _sz, _vp]),

@@ -1347,9 +1347,43 @@ extern "C" int sp_gicp_target_prepare(sp_gicp_target* t, const float* tgt_covs, 
 extern "C" int sp_gicp_target_update(sp_gicp_target* t, const float* tgt_covs, void* stream) {
     return sp_gicp_target_prepare(t, tgt_covs, t ? t->reg_type : SP_REG_GICP, stream);
 }
-extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream,
-                                     sp_gicp_target** out) {
-    using namespace sp;
+namespace sp {
+namespace {
+// Certificates of the correspondence reuse: one k = 3 search of the target's own points on its grid, once per target. The
+// queries are the grid's cell-ordered copy of the points, so neighbouring lanes walk neighbouring cells (0.20 ms per 1M
+// points; the wave / tile self-kNN kernels are built for long lists and take 0.6 ms here) and the rows come out in grid
+// order. Synchronises (temporaries from the library's pool: idle again afterwards).
+int build_certificates(sp_gicp_target* t, hipStream_t st) {
+    const sp_grid* const grid = t->grid;
+    const size_t n = t->n;
+    if (n == 0 || t->rho2 != nullptr) return SP_OK;
+    ScratchBuf b_idx3, b_d23, b_inv;
+    hipError_t e = pooled_alloc(&t->rho2, n * sizeof(float));
+    if (e == hipSuccess) e = pooled_alloc(&t->nb, n * sizeof(float4));
+    if (e == hipSuccess) e = b_idx3.get(n * 3 * sizeof(int32_t));
+    if (e == hipSuccess) e = b_d23.get(n * 3 * sizeof(float));
+    if (e == hipSuccess) e = b_inv.get(n * sizeof(unsigned));
+    int32_t* const idx3 = b_idx3.as<int32_t>();
+    float* const d23 = b_d23.as<float>();
+    unsigned* const inv = b_inv.as<unsigned>();
+    int rc = e == hipSuccess ? SP_OK : SP_ERR_HIP;
+    // (neighbours beyond three cells are not looked for: isolated points of a scan would walk thousands of empty cells)
+    const float bound2 = 9.0f * grid->h * grid->h;
+    if (rc == SP_OK) rc = grid_search_own_points(grid, 3, idx3, d23, st, bound2);  // (in cell order already: no sort of the queries)
+    if (rc == SP_OK) {
+        inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
+        certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb, bound2);
+        rc = launch_status();
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == SP_OK) rc = SP_ERR_HIP;
+    if (rc != SP_OK) {
+        if (e != hipSuccess) sp_set_error(hipGetErrorString(e));
+        pooled_free(t->rho2); t->rho2 = nullptr;  // (synchronised: nothing uses them)
+        pooled_free(t->nb); t->nb = nullptr;
+    }
+    return rc;
+}
+int target_create(const sp_grid* grid, const float* tgt_covs, size_t n, bool certificates, void* stream, sp_gicp_target** out) {
     if (!out || !grid) return SP_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (grid->n != n) {
@@ -1368,43 +1402,35 @@ extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs,
             return SP_ERR_HIP;
         }
     }
-    if (n) {
-        // certificates of the correspondence reuse: one k = 3 search of the target's own points on its grid, once per
-        // target. The queries are the grid's cell-ordered copy of the points, so neighbouring lanes walk neighbouring cells
-        // (0.20 ms per 1M points; the wave / tile self-kNN kernels are built for long lists and take 0.6 ms here) and the
-        // rows come out in grid order. (Temporaries from the library's pool: idle again after the synchronisation below.)
-        hipStream_t st = as_stream(stream);
-        ScratchBuf b_idx3, b_d23, b_inv;
-        hipError_t e = pooled_alloc(&t->rho2, n * sizeof(float));
-        if (e == hipSuccess) e = pooled_alloc(&t->nb, n * sizeof(float4));
-        if (e == hipSuccess) e = b_idx3.get(n * 3 * sizeof(int32_t));
-        if (e == hipSuccess) e = b_d23.get(n * 3 * sizeof(float));
-        if (e == hipSuccess) e = b_inv.get(n * sizeof(unsigned));
-        int32_t* const idx3 = b_idx3.as<int32_t>();
-        float* const d23 = b_d23.as<float>();
-        unsigned* const inv = b_inv.as<unsigned>();
-        int rc2 = e == hipSuccess ? SP_OK : SP_ERR_HIP;
-        // (neighbours beyond three cells are not looked for: isolated points of a scan would walk thousands of empty cells)
-        const float bound2 = 9.0f * grid->h * grid->h;
-        if (rc2 == SP_OK)
-            rc2 = grid_search_own_points(grid, 3, idx3, d23, st, bound2);  // (in cell order already: no sort of the queries)
-        if (rc2 == SP_OK) {
-            inverse_order_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, inv);
-            certificate_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(grid->d_pts, (unsigned)n, idx3, d23, inv, t->rho2, t->nb, bound2);
-            rc2 = launch_status();
-        }
-        if (hipStreamSynchronize(st) != hipSuccess && rc2 == SP_OK) rc2 = SP_ERR_HIP;
-        if (rc2 != SP_OK) {
-            if (e != hipSuccess) sp_set_error(hipGetErrorString(e));
-            sp_gicp_target_destroy(t);
-            return rc2;
-        }
+    if (certificates) {
+        const int rc2 = build_certificates(t, as_stream(stream));
+        if (rc2 != SP_OK) { sp_gicp_target_destroy(t); return rc2; }
     }
     const int rc = sp_gicp_target_update(t, tgt_covs, stream);
     if (rc != SP_OK) { sp_gicp_target_destroy(t); return rc; }
     *out = t;
     return SP_OK;
 }
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_gicp_target_create(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream,
+                                     sp_gicp_target** out) {
+    return sp::target_create(grid, tgt_covs, n, true, stream, out);
+}
+extern "C" int sp_gicp_target_create_plain(const sp_grid* grid, const float* tgt_covs, size_t n, void* stream,
+                                           sp_gicp_target** out) {
+    return sp::target_create(grid, tgt_covs, n, false, stream, out);
+}
+extern "C" int sp_gicp_target_certify(sp_gicp_target* t, const float* tgt_covs, void* stream) {
+    if (!t || !tgt_covs) return SP_ERR_INVALID_ARGUMENT;
+    if (t->rho2 != nullptr) return SP_OK;
+    t->note(sp::as_stream(stream));
+    const int rc = sp::build_certificates(t, sp::as_stream(stream));
+    if (rc != SP_OK) return rc;
+    return sp_gicp_target_update(t, tgt_covs, stream);  // (the rows carry each point's radius: written again, version bumped)
+}
+extern "C" int sp_gicp_target_has_certificates(const sp_gicp_target* t) { return t && t->rho2 != nullptr ? 1 : 0; }
 
 extern "C" void sp_gicp_source_destroy(sp_gicp_source* s) {
     if (!s) return;

@@ -664,7 +664,7 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
     P.tpts = target->grid->d_pts;
     P.tstart = target->grid->d_start;
     P.tcovp = target->covp;
-    P.tnb = source->opt_reuse > 1 ? target->nb : nullptr;
+    P.tnb = source->opt_reuse > 1 ? target->nb : nullptr;  // (null too when the target has no certificates)
     P.g = grid_desc(target->grid);
     P.n = (unsigned)n;
     P.max_d2 = params->max_correspondence_distance * params->max_correspondence_distance;
@@ -676,7 +676,7 @@ FusedParams make_fused_params(const sp_gicp_target* target, const sp_gicp_source
     P.perm = source->perm;
     // the cache rows are always written (sp_gicp_error_prepared reads the frozen correspondences from them); the reuse
     // switch only decides whether a later linearisation may trust them instead of searching
-    P.ccache = target->rho2 ? source->ccache : nullptr;
+    P.ccache = source->ccache;  // (a target without certificates still fills the rows: every linearisation then searches, seeded)
     P.cache_valid = (source->opt_reuse && source->cache_valid && source->cache_target == target &&
                      source->cache_version == target->version) ? 1 : 0;
     P.nn_idx = (nn_idx_out && nn_d2_out) ? nn_idx_out : nullptr;
