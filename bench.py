@@ -386,13 +386,16 @@ def main():
         launches, classes = launch_profile(sp, _lib, torch, reg, prep, T_dev, T_ident, delta, n_local)
         converged = until_converged(sp, torch, S, prep, T_dev, T_ident, delta, n_local, SORT_MODE, REG_TYPE, internal=args.internal)
 
-    stages = reuse0 = p2d = None
+    stages = reuse0 = p2d = hard = lm = None
     if world == 1 and shards == 1 and not args.no_stages and not args.timed_only:
         if args.path == "fused":
             reuse0 = reuse_off_comparison(sp, torch, args, S, prep, T_dev, T_ident, delta, SORT_MODE, REG_TYPE, n_local)
             if args.reg == "gicp":
                 p2d = p2d_block(sp, torch, S, Tg, grid, T_dev, T_ident, delta, n_local, SORT_MODE, T_gt)
-        stages = stage_block(sp, _lib, torch)
+                hard = hard_init_block(sp, _lib, torch, S, prep, n_local, SORT_MODE, T_gt)
+                lm = lm_block(sp, torch, S, prep, n_local, SORT_MODE, T_gt)
+        stages = stage_block(sp, _lib, torch, cpu=not args.no_cpu_baseline)
+        stages["example_registration_config1"] = example_block(cpu=not args.no_cpu_baseline)
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
         dom = max((k for k in kern if kern[k].get("per_iteration", True)), key=lambda k: kern[k]["ms"])
@@ -450,6 +453,8 @@ def main():
             "until_converged": converged,
             "reuse_off_comparison": reuse0,
             "point_to_distribution": p2d,
+            "hard_init": hard,
+            "lm_geman_mcclure": lm,
             "stages": stages,
             "roofline": roofline_block(dom, kern[dom]),
         }
@@ -696,7 +701,192 @@ def reuse_off_comparison(sp, torch, args, S, prep, T_dev, T_ident, delta, sort_m
             "alignments_timed": runs, "note": "reuse=0: every iteration searches all points; includes the source preparation"}
 
 
-def stage_block(sp, _lib, torch):
+def hard_init_block(sp, _lib, torch, S, prep, n, sort_mode, T_gt, reps=7):
+    """Config 4 away from its friendliest input (tests/test_gpu_hard_init.py holds each case to a full oracle alignment at this
+    size): (i) an initial guess ten cells from the truth at the rim, (ii) a third of the source outside the target with
+    max_correspondence_distance 0.3, (iii) Geman-McClure. One alignment with the reference's default criteria each: time,
+    iterations executed, source points searched per launch."""
+    from sycl_points_amd.synthetic import se3_exp_f64
+
+    out = {}
+    cases = {"far_initial_guess": dict(twist=[0.05, -0.03, 0.04, 0.4, -0.3, 0.2], max_corr=2.0, loss="NONE", scale=10.0, shift=False),
+             "partial_overlap": dict(twist=None, max_corr=0.3, loss="NONE", scale=10.0, shift=True),
+             "geman_mcclure": dict(twist=None, max_corr=2.0, loss="GEMAN_MCCLURE", scale=0.5, shift=False)}
+    L = _lib.lib()
+    for name, c in cases.items():
+        src = S
+        if c["shift"]:
+            pts = S.points.clone()
+            run = (torch.arange(n, device=pts.device) // 1024) % 3 == 0
+            pts[run, 0] += 100.0
+            src = sp.PointCloudShared(pts, covs=S.covs, device=pts.device)
+        T0 = np.eye(4, dtype=np.float32) if c["twist"] is None else se3_exp_f64(c["twist"]).astype(np.float32)
+        p = sp.RegistrationParams(max_correspondence_distance=c["max_corr"], robust_type=c["loss"],
+                                  robust_default_scale=c["scale"], max_iterations=ITERS_PER_ALIGN)
+        reg = sp.Registration(p)
+        T0_dev = torch.from_numpy(np.ascontiguousarray(T0.T).reshape(-1).copy()).to(S.points.device)
+        T_dev = T0_dev.clone()
+        dl = torch.zeros(8, dtype=torch.float32, device=S.points.device)
+        ms = []
+        for _ in range(reps + 2):
+            T_dev.copy_(T0_dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reg.align_fused_loop(src, prep, T_dev=T_dev, delta_dev=dl, prepare=True, sort_by_cell=sort_mode)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        ws, lin = reg._buffers(S.points.device)
+        nlog = C.c_size_t(0)
+        off = L.sp_internal_align_searched_log(sp._ptr(ws), C.byref(nlog)) - ws.data_ptr()
+        iters = int(reg._iters_dev[0])
+        searched = ws[off:off + 4 * ITERS_PER_ALIGN].view(torch.int32).cpu().numpy().astype(np.int64)[:iters]
+        out[name] = {"ms_per_alignment": float(np.median(ms[2:])), "iterations": iters, "converged": bool(float(dl[6]) > 0.5),
+                     "inliers": int(reg._read_lin(lin).inlier), "searched_points_per_launch": [int(x) for x in searched],
+                     "max_correspondence_distance": c["max_corr"], "robust": c["loss"],
+                     "pose_max_abs_err_vs_ground_truth": float(np.abs(reg.T_from_device(T_dev) - T_gt).max())}
+    return out
+
+
+def lm_block(sp, torch, S, prep, n, sort_mode, T_gt, reps=7):
+    """The optimiser the reference's callers select (example_registration.cpp:35-36, lidar_odometry.yaml:221) at config-4 size:
+    Levenberg-Marquardt with Geman-McClure, the whole loop as ONE launch and ONE read-back (sp_gicp_align_optimize), one level
+    and the example's three annealing levels (robust scale 10 -> 5 -> 2.5)."""
+    out = {}
+    for label, scales in (("one_level_scale_10", [10.0]), ("three_annealing_levels_10_5_2.5", [10.0, 5.0, 2.5])):
+        p = sp.RegistrationParams(robust_type="GEMAN_MCCLURE", optimization_method="LM", max_iterations=10)
+        reg = sp.Registration(p)
+        ms, res = [], None
+        for _ in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            res = reg.align_optimize(S, prep, None, scales, sort_mode)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        if res is None:
+            out[label] = {"available": False}
+            continue
+        t = float(np.median(ms[2:]))
+        steps = res.linearizations + res.trials
+        out[label] = {"ms_per_alignment": t, "linearizations": res.linearizations, "trial_evaluations": res.trials,
+                      "us_per_step": 1e3 * t / max(steps, 1), "searched_points": res.searched, "converged": res.converged,
+                      "correspondences_per_s": n * res.linearizations / (t * 1e-3),
+                      "pose_max_abs_err_vs_ground_truth": float(np.abs(res.T - T_gt).max()),
+                      "note": "includes the source preparation and the read-back of the 1.4 KB result block"}
+    return out
+
+
+def count_launches(torch, fn):
+    """Kernel / copy / memset nodes of ONE call of fn, counted by capturing it into a hipGraph on a side stream (the C ABI's
+    enqueue-only entry points are capturable). None when the call cannot be captured (it synchronises or allocates)."""
+    hip = C.CDLL("libamdhip64.so")
+    st = torch.cuda.Stream()
+    graph = C.c_void_p()
+    n = C.c_size_t(0)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            if hip.hipStreamBeginCapture(C.c_void_p(st.cuda_stream), 2) != 0:  # hipStreamCaptureModeRelaxed
+                return None
+            try:
+                fn()
+            finally:
+                rc = hip.hipStreamEndCapture(C.c_void_p(st.cuda_stream), C.byref(graph))
+        if rc != 0 or not graph:
+            return None
+        if hip.hipGraphGetNodes(graph, None, C.byref(n)) != 0:
+            return None
+        return int(n.value)
+    except Exception:
+        return None
+    finally:
+        if graph:
+            hip.hipGraphDestroy(graph)
+        torch.cuda.synchronize()
+
+
+def cpu_ms(fn, runs=3):
+    """Median wall time of fn over `runs` runs, ms (the CPU oracle beside a stage)."""
+    t = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        t.append(time.perf_counter() - t0)
+    return 1e3 * float(np.median(t))
+
+
+def example_block(cpu=True, loops=100, warmup=10):
+    """BASELINE config 1: the reference's cpp/examples/example_registration.cpp loop on the bundled scans through the C++ facade
+    (tests/cpp/example_registration, built by __graft_entry__.build(): a child process, this one keeps its device) — the
+    reference's own per-stage timers — with the CPU oracle's time for the same stage on the same clouds beside each."""
+    import re
+    import subprocess
+
+    exe = os.path.join(ROOT, "tests", "cpp", "example_registration")
+    gold = os.path.join(ROOT, "tests", "golden")
+    if not os.path.exists(exe):
+        return {"available": False, "note": "tests/cpp/example_registration is not built"}
+    r = subprocess.run([exe, os.path.join(gold, "source.ply"), os.path.join(gold, "target.ply"), str(loops), str(warmup)],
+                       capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"available": False, "note": r.stderr[-300:]}
+    st = {}
+    for m in re.finditer(r"^\s*(\d[a-z]?\. [^:]+|TOTAL):\s+([0-9.]+) us", r.stdout, re.M):
+        st[m.group(1).strip()] = float(m.group(2)) / 1e3
+    out = {"loops": loops, "warmup": warmup, "gpu_ms": st,
+           "note": "LM + Geman-McClure + 3 annealing levels on a 1000-point sample; box filter [0.5, 50] m, voxel 0.25 m, k = 10"}
+    if cpu:
+        out["cpu_oracle_ms"], out["cpu_cores"] = example_cpu_oracle()
+    return out
+
+
+def example_cpu_oracle():
+    """The same pipeline on the CPU oracle (all host cores), stage by stage like the reference's timers."""
+    from oracle.pyoracle import LOSS, OPT, REG, Oracle, RegParams
+
+    orc = Oracle()
+    gold = os.path.join(ROOT, "tests", "golden")
+
+    def read(path):
+        raw = open(path, "rb").read()
+        head, body = raw.split(b"end_header\n", 1)
+        n = int([l for l in head.split(b"\n") if l.startswith(b"element vertex")][0].split()[-1])
+        a = np.frombuffer(body, dtype="<f4", count=n * 4).reshape(n, 4)
+        pts = np.ones((n, 4), np.float32)
+        pts[:, :3] = a[:, :3]
+        return pts
+
+    src, tgt = read(os.path.join(gold, "source.ply")), read(os.path.join(gold, "target.ply"))
+    t = {}
+
+    def timed(name, fn):
+        out = []
+        t[name] = t.get(name, 0.0) + cpu_ms(lambda: out.append(fn()), 3)
+        return out[-1]
+
+    def down(p):
+        return orc.voxel_downsample(p[orc.box_filter(p, 0.5, 50.0) == 1], 0.25, 1, stable=True)["points"]
+
+    s = timed("2. Downsampling", lambda: down(src))
+    g = timed("2. Downsampling", lambda: down(tgt))
+    ns = timed("3. KNN structure build", lambda: orc.kdtree_build(s))
+    ng = timed("3. KNN structure build", lambda: orc.kdtree_build(g))
+    si = timed("4. kNN Search", lambda: orc.kdtree_knn(ns, s, 10)[0])
+    gi = timed("4. kNN Search", lambda: orc.kdtree_knn(ng, g, 10)[0])
+    sc = timed("5. compute Covariances", lambda: orc.cov_estimate(s, si))
+    gc = timed("5. compute Covariances", lambda: orc.cov_estimate(g, gi))
+    keep = orc.random_sampling_flags(1234, len(s), 1000) == 1
+    p = RegParams.defaults(reg_type=REG["GICP"], robust_type=LOSS["GEMAN_MCCLURE"], optimization_method=OPT["LM"], max_iterations=10,
+                           max_correspondence_distance=2.0, robust_default_scale=10.0, auto_scale=1, init_scale=10.0, min_scale=2.5,
+                           auto_scaling_iter=3)
+    timed("7. Registration", lambda: orc.registration_align(p, s[keep], sc[keep], g, gc, nodes=ng))
+    t["TOTAL (stages 2-5, 7)"] = sum(t.values())
+    return t, orc.num_threads()
+
+
+def stage_block(sp, _lib, torch, cpu=True):
     """BASELINE configs 2 and 3 and the pre-loop of config 4 in the driver's line (outside the timed GICP region): each
     stage with inputs resident in HBM, the median of 11 single runs by HIP events, its rate and the fraction of the roofline
     that bounds it (brute force against the bf16 MFMA peak of its bounding pass, with the fp32 VALU roofline of
@@ -708,9 +898,14 @@ def stage_block(sp, _lib, torch):
     FP32 = 157.3e12
     L = _lib.lib()
     out = {}
+    orc = None
+    if cpu:
+        from oracle.pyoracle import Oracle
+        orc = Oracle()
     g = Mt19937Cloud(1234)
     tgt = torch.from_numpy(g.uniform_points(100000, 10.0)).cuda()
     qry = torch.from_numpy(g.uniform_points(100000, 10.0)).cuda()
+    tgt_np, qry_np = tgt.cpu().numpy(), qry.cpu().numpy()
     BF16 = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
     for k in (1, 20):
         ms, runs = median_ms(torch, lambda: sp.knn_search_bruteforce(qry, tgt, k))
@@ -727,7 +922,13 @@ def stage_block(sp, _lib, torch):
             "frac_of_bound": floor_ms / ms,
             "rate_vs_fp32_valu_roofline_of_the_reference_expression": 9 * 1e10 / (ms * 1e-3) / FP32,
             "ms_with_pass_a_on_packed_fp32_valu": ms_valu,
-            "hbm_GBps_algorithmic": (16 * 2e5 + 8 * 1e5 * k) / (ms * 1e-3) / 1e9}
+            "hbm_GBps_algorithmic": (16 * 2e5 + 8 * 1e5 * k) / (ms * 1e-3) / 1e9,
+            "launches": bf_launches(sp, _lib, torch, qry, tgt, k)}
+        if orc is not None:  # the oracle's brute force on a 10 k-query subsample (all host cores), scaled to the 100 k queries
+            sub = 10000
+            t_cpu = cpu_ms(lambda: orc.knn_bruteforce(qry_np[:sub], tgt_np, k))
+            out[f"bruteforce_100k_x_100k_k{k}"].update(cpu_oracle_ms=t_cpu * (100000 / sub), cpu_cores=orc.num_threads(),
+                                                         cpu_sample=f"{sub} of the 100000 queries, time scaled by {100000 // sub}")
     del tgt, qry
     for name, R in (("sparse_R10", 10.0), ("dense_R2.5", 2.5)):
         n = 1_000_000
@@ -752,7 +953,12 @@ def stage_block(sp, _lib, torch):
         out[f"voxel_downsample_1M_{name}"] = {
             "ms": ms, "runs": runs, "voxels": nvox, "points_per_s": n / (ms * 1e-3), "bound": "HBM at 40 B per point",
             "GBps": 40 * n / (ms * 1e-3) / 1e9, "frac_of_bound": 40 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "ms_whole_api_call_with_count_read_back": ms_api}
+            "ms_whole_api_call_with_count_read_back": ms_api, "launches": count_launches(torch, run)}
+        if orc is not None:
+            P_np = P.cpu().numpy()
+            out[f"voxel_downsample_1M_{name}"].update(cpu_oracle_ms=cpu_ms(lambda: orc.voxel_downsample(P_np, 0.1, 1, stable=True)),
+                                                      cpu_cores=1, cpu_note="the reference aggregates on ONE host thread "
+                                                      "(voxel_downsampling.hpp:146-288: std::sort + a sequential run-length mean)")
         del P, ws, o_p
     n = 1_000_000
     P = torch.from_numpy(Mt19937Cloud(1234).uniform_points(n, 10.0)).cuda()
@@ -761,7 +967,19 @@ def stage_block(sp, _lib, torch):
         ms, runs = median_ms(torch, lambda: grid.self_knn(20, knn, cov, False))
         out[name] = {"ms": ms, "runs": runs, "points_per_s": n / (ms * 1e-3),
                      "bound": f"HBM at {bytes_pt} B per point (API layouts" + (": kNN 176 + K5 464)" if cov else ")"),
-                     "GBps": bytes_pt * n / (ms * 1e-3) / 1e9, "frac_of_bound": bytes_pt * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                     "GBps": bytes_pt * n / (ms * 1e-3) / 1e9, "frac_of_bound": bytes_pt * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "launches": count_launches(torch, lambda: grid.self_knn(20, knn, cov, False))}
+    if orc is not None:  # KD-tree k = 20 of the cloud against itself (+ K5), all host cores; the tree build is its own figure
+        P_np = P.cpu().numpy()
+        nodes = orc.kdtree_build(P_np)
+        t_knn = cpu_ms(lambda: orc.kdtree_knn(nodes, P_np, 20))
+        idx20 = orc.kdtree_knn(nodes, P_np, 20)[0]
+        t_cov = cpu_ms(lambda: orc.cov_estimate(P_np, idx20))
+        t_build = cpu_ms(lambda: orc.kdtree_build(P_np), 1)
+        out["self_knn_k20_1M"].update(cpu_oracle_ms=t_knn, cpu_cores=orc.num_threads(), cpu_kdtree_build_ms=t_build)
+        out["self_knn_k20_plus_covariance_1M"].update(cpu_oracle_ms=t_knn + t_cov, cpu_cores=orc.num_threads(),
+                                                      cpu_kdtree_build_ms=t_build)
+        del idx20
     for label, cloud in (("", P), ("_cell_ordered", P[sp.GridKNN.build(P, points_per_cell=1.0).order()].contiguous())):
         g = grid if cloud is P else sp.GridKNN.build(cloud, points_per_cell=6.0)
         res = g.self_knn(20, True, False, False)[0]
@@ -789,6 +1007,17 @@ def stage_block(sp, _lib, torch):
         "ms_queries_in_cloud_order": ms_q, "ms_build": ms_b, "ms_build_plus_self_knn_uniform_1M": ms_u,
         "cloud": "three noisy planes + slab + 200 k points in a 20 cm ball (tests/test_gpu_bvh.py::nonuniform_cloud)"}
     return out
+
+
+def bf_launches(sp, _lib, torch, qry, tgt, k):
+    L = _lib.lib()
+    nq, nt = qry.shape[0], tgt.shape[0]
+    nbytes = L.sp_knn_bruteforce_workspace_bytes(nq, nt, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=qry.device)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=qry.device)
+    d2 = torch.empty((nq, k), dtype=torch.float32, device=qry.device)
+    return count_launches(torch, lambda: _lib.check(L.sp_knn_bruteforce(sp._ptr(qry), nq, sp._ptr(tgt), nt, k, sp._ptr(idx), sp._ptr(d2),
+                                                                       sp._ptr(ws), nbytes, sp._stream())))
 
 
 def nonuniform_cloud(n, seed=7):

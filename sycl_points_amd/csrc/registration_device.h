@@ -600,7 +600,7 @@ constexpr int kAlignMaxBlocks = 256;
 constexpr int kSearchedLog = 64;       // launches of an alignment whose searched-point counts are kept
 // Whether a point whose certificate failed starts its search from the previous winner (fused_point's SEED) in the per-iteration
 // kernels of registration.hip. Off: at their 128-register budget it costs the benchmarked instantiation one spilled register.
-constexpr bool kSeedSearches = false;
+constexpr bool kSeedSearches = true;
 
 // The pose of a launch into scalar registers (it is uniform; it would otherwise occupy 12 VGPRs for the whole loop).
 __device__ __forceinline__ Rigid uniform_pose(const float* sT) {
