@@ -14,6 +14,7 @@
 #include <sycl_points_amd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -270,7 +271,7 @@ private:
 struct StagedCopy {
     static constexpr size_t kChunk = size_t(8) << 20, kMin = size_t(1) << 20;
     static void h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
-        Buffers* b = bytes >= kMin ? buffers() : nullptr;
+        Buffers* b = bytes >= kMin ? buffers(st) : nullptr;
         if (!b) {
             hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), "H2D");
             hip_check(hipStreamSynchronize(st), "H2D sync");
@@ -290,7 +291,7 @@ struct StagedCopy {
     }
     /// (the caller has synchronised the stream the device data was produced on)
     static void d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
-        Buffers* b = bytes >= kMin ? buffers() : nullptr;
+        Buffers* b = bytes >= kMin ? buffers(st) : nullptr;
         if (!b) {
             hip_check(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "D2H");
             return;
@@ -321,18 +322,35 @@ private:
         hipEvent_t ev[2] = {nullptr, nullptr};
         std::mutex m;
     };
-    static Buffers* buffers() {  // nullptr when pinned memory is not to be had (the runtime's path is taken)
-        static Buffers* b = [] {
+    // One pair of pinned buffers AND events per device: an event belongs to the device that was current when it was
+    // created, and recording it on a stream of another device is an error — a process with DeviceQueue(0) and DeviceQueue(1)
+    // would have thrown on every large copy of the second one. nullptr when pinned memory is not to be had (or the device
+    // ordinal is beyond the table): the runtime's own path is taken.
+    static Buffers* buffers(hipStream_t st) {
+        constexpr int kMaxDevices = 64;
+        static Buffers* table[kMaxDevices] = {};
+        static bool tried[kMaxDevices] = {};
+        static std::mutex table_mutex;
+        int dev = 0, current = 0;
+        hipDevice_t sdev = 0;
+        if (hipGetDevice(&current) != hipSuccess) return nullptr;
+        dev = current;
+        if (st != nullptr && hipStreamGetDevice(st, &sdev) == hipSuccess) dev = (int)sdev;  // the STREAM's device, not the current one
+        else (void)hipGetLastError();
+        if (dev < 0 || dev >= kMaxDevices) return nullptr;
+        std::lock_guard<std::mutex> lock(table_mutex);
+        if (!tried[dev]) {
+            tried[dev] = true;
             auto* nb = new Buffers();  // never destroyed: the HIP runtime may be gone by then
-            for (int i = 0; i < 2; ++i)
-                if (hipHostMalloc(&nb->p[i], kChunk, hipHostMallocPortable) != hipSuccess ||
-                    hipEventCreateWithFlags(&nb->ev[i], hipEventDisableTiming) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return static_cast<Buffers*>(nullptr);
-                }
-            return nb;
-        }();
-        return b;
+            bool ok = dev == current || hipSetDevice(dev) == hipSuccess;  // (events are created on the current device)
+            for (int i = 0; i < 2 && ok; ++i)
+                ok = hipHostMalloc(&nb->p[i], kChunk, hipHostMallocPortable) == hipSuccess &&
+                     hipEventCreateWithFlags(&nb->ev[i], hipEventDisableTiming) == hipSuccess;
+            if (dev != current) (void)hipSetDevice(current);
+            if (!ok) (void)hipGetLastError();
+            table[dev] = ok ? nb : nullptr;
+        }
+        return table[dev];
     }
 };
 }  // namespace detail
@@ -474,7 +492,7 @@ public:
     shared_vector(size_t n, const T& v, const sycl_utils::DeviceQueue::StreamHolder& h) : host_(n, v) { bind(h); }
     shared_vector(const shared_vector& o) : host_(o.host()), queue_(o.queue_), stream_(o.stream_) {}
     shared_vector& operator=(const shared_vector& o) {
-        if (this != &o) { host_ = o.host(); host_dirty_ = true; dev_dirty_ = false; ++generation_; }
+        if (this != &o) { host_ = o.host(); host_dirty_ = true; dev_dirty_ = false; generation_ = next_generation(); }
         return *this;
     }
     ~shared_vector() { if (dev_) detail::DeviceBufferCache::release(dev_, dev_bytes_, stream()); }
@@ -529,7 +547,7 @@ public:
     T* device_data_for_write(size_t n) {
         ensure_capacity(n);
         dev_size_ = n; size_override_ = true; dev_dirty_ = true; host_dirty_ = false;
-        ++generation_;
+        generation_ = next_generation();
         return dev_;
     }
     /// `n` elements that live on the device only for now — a kernel is about to write all of them (device_data_for_write(n)),
@@ -542,19 +560,19 @@ public:
         ensure_capacity(n);
         if (fill_bits && n) hip_check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dev_), (int)*fill_bits, n * (sizeof(T) / 4), stream()), "fill");
         dev_size_ = n; size_override_ = true; dev_dirty_ = true; host_dirty_ = false;
-        ++generation_;
+        generation_ = next_generation();
     }
     /// Read-write device pointer (in-place kernels).
-    T* device_data_rw() { sync_device(); dev_dirty_ = true; dev_size_ = host_.size(); size_override_ = true; ++generation_; return dev_; }
+    T* device_data_rw() { sync_device(); dev_dirty_ = true; dev_size_ = host_.size(); size_override_ = true; generation_ = next_generation(); return dev_; }
     /// After a kernel produced fewer rows than reserved (compaction, downsampling).
-    void set_device_size(size_t n) { dev_size_ = n; size_override_ = true; dev_dirty_ = true; ++generation_; }
+    void set_device_size(size_t n) { dev_size_ = n; size_override_ = true; dev_dirty_ = true; generation_ = next_generation(); }
     /// Changes whenever the contents may have changed (any non-const access counts): a structure built on the container can
     /// tell whether it still describes it.
     uint64_t generation() const { return generation_; }
     hipStream_t stream() const { return queue_ ? queue_->stream : stream_; }
 
 private:
-    void touch() { host_dirty_ = true; ++generation_; }
+    void touch() { host_dirty_ = true; generation_ = next_generation(); }
     void bind(const sycl_utils::DeviceQueue::StreamHolder& h) { stream_ = h.stream; }
     void ensure_capacity(size_t n) const {
         if (n <= dev_cap_) return;
@@ -594,7 +612,14 @@ private:
     mutable T* dev_ = nullptr;
     mutable size_t dev_cap_ = 0, dev_size_ = 0, dev_bytes_ = 0;
     mutable bool host_dirty_ = true, dev_dirty_ = false, size_override_ = false;
-    uint64_t generation_ = 0;
+    // Drawn from ONE process-wide counter: a cache keyed by (container address, generation) — Registration's
+    // prepared target rows — must not match a DIFFERENT container that the allocator placed at a recycled address; with
+    // per-container counts starting at 0 two containers could agree on both.
+    static uint64_t next_generation() {
+        static std::atomic<uint64_t> counter{1};
+        return counter.fetch_add(1, std::memory_order_relaxed);
+    }
+    uint64_t generation_ = next_generation();
     std::shared_ptr<sycl_utils::DeviceQueue::StreamHolder> queue_;
     hipStream_t stream_ = nullptr;
 };

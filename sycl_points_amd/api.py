@@ -194,6 +194,7 @@ class KDTree(KNNBase):
         self.n = n
         self.device = device
         self._hier = None         # the device-built hierarchy, built when a search first needs it (accelerate=True)
+        self._points_version = 0
         self._accelerated = False
         self._points = None       # ... the points it was built on (device tensor), for the lazily built reference tree / the grid
         self._self_grid = None
@@ -209,6 +210,7 @@ class KDTree(KNNBase):
             t = KDTree(None, pd.shape[0], pd.device)
             t._accelerated = True  # (the hierarchy itself is built lazily, like the facade's: many trees never need it)
             t._points = pd
+            t._points_version = pd._version  # (an in-place edit of the caller's tensor after build() ends the own-cloud shortcuts)
             t._leaf_threshold = leaf_threshold
             return t
         host = np.ascontiguousarray(p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else p, np.float32)
@@ -221,6 +223,10 @@ class KDTree(KNNBase):
     @property
     def _bvh(self):
         if self._accelerated and self._hier is None:
+            if self._points._version != self._points_version:
+                # (the facade's tree owns a copy of the points taken at build(); this mirror borrows the caller's tensor)
+                raise SpError(2, "[KDTree] the points tensor was modified in place after build() and before the first search: "
+                                 "build the tree again (or hand build() a clone)")
             self._hier = BVH.build(self._points)
         return self._hier
 
@@ -250,12 +256,13 @@ class KDTree(KNNBase):
         if not self._accelerated or k > 32:
             return "kdtree"
         q = _points_of(queries)
+        unchanged = self._points is not None and self._points._version == self._points_version
         own = (self._pristine and transT is None and isinstance(q, torch.Tensor) and q.is_cuda and q.shape[0] == self.n and
-               q.data_ptr() == self._points.data_ptr())
+               q.data_ptr() == self._points.data_ptr() and unchanged)
         if own and 8 <= k <= 20 and self._uniform_grid() is not None:
             return "grid"
         # a small cloud (the reference example's 6 k-point downsampled scans): exact brute force beats building a hierarchy
-        if (self._pristine and transT is None and k <= 20 and 2048 <= self.n <= KDTree.BRUTE_FORCE_MAX_TARGETS and
+        if (self._pristine and unchanged and transT is None and k <= 20 and 2048 <= self.n <= KDTree.BRUTE_FORCE_MAX_TARGETS and
                 self.n >= 256 * k and q.shape[0] <= KDTree.BRUTE_FORCE_MAX_QUERIES):
             return "bruteforce"
         return "bvh"
@@ -282,7 +289,8 @@ class KDTree(KNNBase):
             result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k
             return
         if backend == "bvh":
-            own = self._pristine and transT is None and q.shape[0] == self.n and q.data_ptr() == self._points.data_ptr()
+            own = (self._pristine and transT is None and q.shape[0] == self.n and q.data_ptr() == self._points.data_ptr() and
+                   self._points._version == self._points_version)
             if own:
                 res = self._bvh.self_knn(k)
                 result.indices, result.distances, result.query_size, result.k = res.indices, res.distances, res.query_size, res.k

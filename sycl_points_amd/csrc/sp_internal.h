@@ -36,7 +36,7 @@ enum {
     /* sp_bvh: searches for 2 <= k <= 21 with the lane's k best in a heap (1, default) or by the sorted-insertion kernel
      * that serves every other search (0). Same lists either way. */
     SP_INTERNAL_BVH_SELF_HEAP = 6,
-    /* sp_bvh: external queries (16 k or more) are searched in the order of the tree's Morton curve (1, default) or as given (0).
+    /* sp_bvh: external queries (400 k or more) are searched in the order of the tree's Morton curve (1, default) or as given (0).
      * Same lists either way. */
     SP_INTERNAL_BVH_SORT_QUERIES = 7,
     /* sp_grid: the same for sp_grid_search / sp_grid_radius_search: in cell order (1, default) or as given (0). */

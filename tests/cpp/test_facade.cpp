@@ -925,6 +925,31 @@ static void large_containers_round_trip() {
     }
 }
 
+static void large_copies_on_queues_of_two_devices() {
+    // The staging buffers and their events are per device, keyed by the STREAM's device: a process with a queue on
+    // device 0 and one on device 1 copies more than a megabyte through each, alternately, whatever device is current. On a box
+    // with one GPU both queues sit on device 0 (the keying is exercised, not the second device).
+    const int second = sp_device_count() > 1 ? 1 : 0;
+    sycl_points::sycl_utils::DeviceQueue q0(0), q1(second);
+    const size_t n = 200000;  // 3.2 MB of points
+    PointCloudCPU c;
+    c.points->resize(n);
+    for (size_t i = 0; i < n; ++i) (*c.points)[i] = PointType((float)i, (float)(i % 13), 2.0f, 1.0f);
+    bool ok = true;
+    for (int round = 0; round < 3 && ok; ++round) {
+        PointCloudShared a(q0, c), b(q1, c);
+        TransformMatrix T = TransformMatrix::Identity();
+        T(0, 3) = (float)(round + 1);
+        alg::transform::transform(b, T);  // (device 1's queue first: the current device is then not device 0)
+        alg::transform::transform(a, T);
+        const auto& ha = a.points->host();
+        const auto& hb = b.points->host();
+        for (size_t i = 0; ok && i < n; i += 991) ok = ha[i].x() == (float)i + (float)(round + 1) && hb[i].x() == ha[i].x();
+    }
+    CHECK(ok);
+    throw_on_error(sp_set_device(0));
+}
+
 static void kdtree_self_knn_large_clouds() {
     // KDTree::knn_search on the tree's own cloud: from 32 k points on, a cloud of near-uniform density is answered by the grid's
     // lane-per-query selection, a clustered one (fullest cell over the limit) by the device-built hierarchy; both must give
@@ -963,6 +988,7 @@ int main() {
     RUN(kdtree_self_knn_large_clouds);
     RUN(containers_read_from_another_queue);
     RUN(large_containers_round_trip);
+    RUN(large_copies_on_queues_of_two_devices);
     RUN(kdtree_backend_on_the_bundled_scan);
     RUN(kdtree_radius_and_lazy_delete_on_the_hierarchy);
     RUN(voxelgrid_known_answer);
