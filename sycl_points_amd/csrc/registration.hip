@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void gicp_fused_kernel(FusedParams P, float
     for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
     unsigned cnt = 0, searched = 0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < P.n; i += gridDim.x * kBlock)
-        fused_point<LOSS, FAST_NN, P2D, kSeedSearches>(P, T, i, acc, cnt, searched);
+        fused_point<LOSS, FAST_NN, P2D, kSeedSearches, kNegCert>(P, T, i, acc, cnt, searched);
     block_reduce_store<kAcc - 1>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
 }
 
@@ -901,8 +901,18 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_kernel(FusedParams P, 
     // (cell-ordered) source: the target cells it reads then stay in that XCD's own L2 from one grid row / layer to the next
     unsigned tile = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-        fused_point<LOSS, FAST_NN, P2D, kSeedSearches>(P, T, i, acc, cnt, searched);
+    if constexpr (FAST_NN && kWaveTail) {
+        if (P.ccache != nullptr) {  // (uniform)
+            for (unsigned b = tile * kAlignBlock; b < P.n; b += stride)
+                fused_point_wave<LOSS, P2D>(P, T, b + threadIdx.x, b + threadIdx.x < P.n, acc, cnt, searched);
+        } else {
+            for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
+                fused_point<LOSS, FAST_NN, P2D, kSeedSearches, kNegCert>(P, T, i, acc, cnt, searched);
+        }
+    } else {
+        for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
+            fused_point<LOSS, FAST_NN, P2D, kSeedSearches, kNegCert>(P, T, i, acc, cnt, searched);
+    }
     if constexpr (!SHARDED) {
         block_reduce_store<kAcc - 1, kAlignBlock>(acc, cnt, partials + (size_t)blockIdx.x * kPartial, false, searched);
     } else if (A.mode == ALIGN_ROWS) {
@@ -1056,7 +1066,7 @@ __global__ __launch_bounds__(kAlignBlock) void gicp_align_persistent_kernel(Fuse
         if (k == 1) P.cache_valid = A.cache_valid_later;  // (P is this kernel's own copy of the parameters; a launch that
                                                            //  begins later was handed the right value)
         for (unsigned i = tile * kAlignBlock + threadIdx.x; i < P.n; i += stride)
-            fused_point<LOSS, FAST_NN, P2D, kSeedSearches>(P, T, i, acc, cnt, searched);
+            fused_point<LOSS, FAST_NN, P2D, kSeedSearches, kNegCert>(P, T, i, acc, cnt, searched);
         block_reduce_store<kAcc - 1, kAlignBlock, true>(acc, cnt, A.part[k & 1] + (size_t)blockIdx.x * kPartial, false, searched);
         if (threadIdx.x < kWave) {  // the storing lanes all sit in wave 0
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

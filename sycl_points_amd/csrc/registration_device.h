@@ -396,7 +396,8 @@ __device__ __forceinline__ float search_bound2_margin(const FusedParams& P, floa
 // correspondences hold, an iteration is a pure coalesced stream of 84 bytes per point (12 p + 24 Cs' as planes + 48 cache
 // row) with no search and no gather, and a wave whose lanes all pass never enters the search code.
 // SEED: a point whose certificate fails starts its search from the previous winner (grid_nn1_fast's `seed`).
-template <int LOSS, bool FAST_NN, bool P2D = false, bool SEED = true>
+// NEG: a search that finds nothing is made with the widened bound and recorded as a negative certificate (store_correspondence).
+template <int LOSS, bool FAST_NN, bool P2D = false, bool SEED = true, bool NEG = true>
 __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
                                             unsigned& cnt, unsigned& searched) {
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
@@ -425,8 +426,8 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
     }
     if (!hit) {
         ++searched;
-        float margin2;
-        const float bound2 = search_bound2_margin(P, margin2);
+        float margin2 = 0.0f;
+        const float bound2 = NEG ? search_bound2_margin(P, margin2) : search_bound2(P);
         seeded = seeded && seed.d2 < bound2;
         if (!seeded) { seed.d2 = bound2; seed.idx = -1; seed.pos = 0; seed.x = seed.y = seed.z = 0.0f; }
         if (FAST_NN) {
@@ -434,8 +435,10 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
         } else {
             nn = grid_nn1(P.tpts, P.tstart, P.g, qx, qy, qz, &seed, 0);
         }
-        if (row) store_correspondence(row, P, nn, Ct, qx, qy, qz, margin2);
-        else if (nn.idx >= 0) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
+        if (row) {
+            if (NEG) store_correspondence(row, P, nn, Ct, qx, qy, qz, margin2);
+            else store_correspondence(row, P, nn, Ct);
+        } else if (nn.idx >= 0) Ct = load_sym(P.tcovp + 2 * (size_t)nn.pos);
     }
     if (P.nn_idx) {
         const unsigned o = P.perm[i];
@@ -528,6 +531,11 @@ __device__ __forceinline__ void fused_point_wave(const FusedParams& P, const Rig
     SP_PSTAMP(4);
     if (search) store_correspondence(row, P, nn, Ct, qx, qy, qz, margin2);
     SP_PSTAMP(5);
+    if (valid && P.nn_idx) {
+        const unsigned o = P.perm[ii];
+        P.nn_idx[o] = nn.idx;
+        P.nn_d2[o] = nn.d2;
+    }
     if (!valid || nn.idx < 0 || nn.d2 > P.max_d2) return;
     const float* const cp = P.scovp + ii;
     const size_t st = P.sstride;
@@ -600,7 +608,20 @@ constexpr int kAlignMaxBlocks = 256;
 constexpr int kSearchedLog = 64;       // launches of an alignment whose searched-point counts are kept
 // Whether a point whose certificate failed starts its search from the previous winner (fused_point's SEED) in the per-iteration
 // kernels of registration.hip. Off: at their 128-register budget it costs the benchmarked instantiation one spilled register.
-constexpr bool kSeedSearches = true;
+#ifndef SP_SEED_SEARCHES
+#define SP_SEED_SEARCHES 1
+#endif
+constexpr bool kSeedSearches = SP_SEED_SEARCHES != 0;
+#ifndef SP_NEG_CERT
+#define SP_NEG_CERT 0
+#endif
+constexpr bool kNegCert = SP_NEG_CERT != 0;  // negative certificates in the per-iteration kernels of registration.hip (fused_point's NEG)
+// Whether the per-iteration kernels finish their open queries (nothing proven inside the 4x4x4 block) with the whole wave
+// (fused_point_wave) instead of each lane for itself. A / B on the same box: profiles/r05_c_*.
+#ifndef SP_WAVE_TAIL
+#define SP_WAVE_TAIL 0
+#endif
+constexpr bool kWaveTail = SP_WAVE_TAIL != 0;
 
 // The pose of a launch into scalar registers (it is uniform; it would otherwise occupy 12 VGPRs for the whole loop).
 __device__ __forceinline__ Rigid uniform_pose(const float* sT) {

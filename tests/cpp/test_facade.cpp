@@ -824,6 +824,35 @@ static void kdtree_backend_on_the_bundled_scan() {
     CHECK(same);
 }
 
+static void raw_scans_full_resolution_alignment() {
+    // the reference's bundled scans as they are — 69 792 vs 69 088 points, no sampling, no voxel filter,
+    // density varying by orders of magnitude (a cell of the in-loop grid holds up to 5000 points near the sensor) — through
+    // Registration::align with the caller's KDTree, against ONE oracle alignment on the same inputs: pose within 1e-5, same
+    // inliers. (How fast each search structure is on this cloud: profiles/r05_h_raw_scan_full_resolution_alignment.txt.)
+    const char* dir = std::getenv("SP_GOLDEN_DIR");
+    if (!dir) { std::printf("  (SP_GOLDEN_DIR not set: skipped)\n"); return; }
+    auto source = PointCloudReader::readFile(std::string(dir) + "/source.ply", *Q);
+    auto target = PointCloudReader::readFile(std::string(dir) + "/target.ply", *Q);
+    CHECK(source.size() == 69792 && target.size() == 69088);
+    auto source_tree = alg::knn::KDTree::build(*Q, source);
+    auto target_tree = alg::knn::KDTree::build(*Q, target);
+    alg::covariance::estimate_async(source_tree->knn_search(source, 20), source).wait_and_throw();
+    alg::covariance::estimate_async(target_tree->knn_search(target, 20), target).wait_and_throw();
+    alg::registration::RegistrationParams p;  // the reference's defaults: GICP, Gauss-Newton, max_corr 2.0, criteria 1e-3
+    orc_reg_params op{3, 0, 0, 20, 2.0f, 10.0f, 1.0f, 1.0f, 2.0f, 1e-6f, 1e3f, 10, 1e-3f, 1e-3f, 0, 4, 10.0f, 0.5f};
+    orc_reg_result ref;
+    const TransformMatrix I = TransformMatrix::Identity();
+    orc_registration_align(&op, reinterpret_cast<const float*>(source.points->data()), reinterpret_cast<const float*>(source.covs->data()),
+                           source.size(), reinterpret_cast<const float*>(target.points->data()),
+                           reinterpret_cast<const float*>(target.covs->data()), nullptr, target.size(), I.data(), 0, &ref, nullptr,
+                           nullptr, nullptr, 0, nullptr, 0, nullptr);
+    alg::registration::Registration reg(*Q, p);
+    const auto r = reg.align(source, target, *target_tree);
+    CHECK(max_abs_diff(r.T.matrix(), ref.T) < 1e-5f);
+    CHECK(r.inlier == ref.inlier && (int)r.iterations == ref.iterations && r.converged == (ref.converged != 0));
+    CHECK(ref.inlier > 60000);
+}
+
 static void kdtree_radius_and_lazy_delete_on_the_hierarchy() {
     // KDTree::radius_search_async / remove_nodes_by_flags (kdtree.hpp:574-765) on a cloud large enough for the device-built
     // hierarchy (no host tree is ever built): radius search = brute force's list cut at the radius; after a removal the tree
@@ -990,6 +1019,7 @@ int main() {
     RUN(large_containers_round_trip);
     RUN(large_copies_on_queues_of_two_devices);
     RUN(kdtree_backend_on_the_bundled_scan);
+    RUN(raw_scans_full_resolution_alignment);
     RUN(kdtree_radius_and_lazy_delete_on_the_hierarchy);
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
