@@ -87,7 +87,13 @@ if os.environ.get("SP_OPT_TIMING"):  # a library built with -DSP_OPT_TIMING: sta
     L = C.CDLL(sp._lib.LIB_PATH)
     L.sp_internal_opt_debug(dbg.ctypes.data_as(C.c_void_p))
     dbg = dbg.astype(np.int64).reshape(24, 16)
+    wg = np.zeros(24 * 8, np.uint64)
+    L.sp_internal_opt_debug_wg(wg.ctypes.data_as(C.c_void_p))
+    wg = wg.astype(np.int64).reshape(24, 8) / 100.0
     print(f"grid {which}: cell {g.cell_size():.3f}")
+    print("points loop + workgroup reduction per workgroup (us), steps 0..18:")
+    for k in range(19):
+        print(f"  {k:2d}: " + " ".join(f"{v:6.1f}" for v in wg[k][:4]))
     print("step: points | block reduce | rows/barrier | state machine  ||  wave 0: loads+cert | fast/seeded | 4x4x4 | ball(wave) | store | math || lanes: searching seeded past-fast open")
     for k in range(20):
         a = st[k]

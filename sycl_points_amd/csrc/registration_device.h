@@ -460,6 +460,7 @@ __device__ __forceinline__ void fused_point(const FusedParams& P, const Rigid& T
 #ifdef SP_OPT_TIMING
 __device__ unsigned long long g_sp_dbg[24 * 16];
 __device__ unsigned g_sp_step;
+__device__ unsigned long long g_sp_wg[24 * 8];
 #define SP_PSTAMP(k) if (blockIdx.x == 0 && threadIdx.x == 0 && g_sp_step < 24) g_sp_dbg[g_sp_step * 16 + (k)] = wall_clock64()
 #else
 #define SP_PSTAMP(k)

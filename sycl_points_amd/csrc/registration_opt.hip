@@ -127,7 +127,7 @@ __device__ __forceinline__ void end_outer(OptShared& S, int accepted, unsigned t
 }
 
 // After a linearisation step: tot = 28 sums, the uint32 count, the searched count as a float value.
-__device__ __noinline__ void opt_after_linearize(OptShared& S, const float* tot, bool publish) {
+__device__ __forceinline__ void opt_after_linearize_impl(OptShared& S, const float* tot, bool publish) {
     OptCtl& c = S.ctl;
     unpack_totals(tot, kAcc - 1, &S.slin);
     ++c.n_lin;
@@ -168,7 +168,7 @@ __device__ __noinline__ void opt_after_linearize(OptShared& S, const float* tot,
 }
 
 // After a trial step: tot[0] = the robust error at the trial pose, tot[1] = the uint32 inlier count.
-__device__ __noinline__ void opt_after_trial(OptShared& S, const float* tot, bool publish) {
+__device__ __forceinline__ void opt_after_trial_impl(OptShared& S, const float* tot, bool publish) {
     OptCtl& c = S.ctl;
     const sp_opt_params& o = S.opt;
     const float new_error = tot[0];
@@ -216,6 +216,11 @@ __device__ __noinline__ void opt_after_trial(OptShared& S, const float* tot, boo
         }
     }
 }
+
+// The state machine as real functions (the 1024-lane instantiations: inlined it takes the point loops' registers with it, 90
+// spilled VGPRs) and inlined (the 256-lane instantiations have 256 registers: 5.5 -> 1.5 us per linearisation step).
+__device__ __noinline__ void opt_after_linearize_call(OptShared& S, const float* tot, bool publish) { opt_after_linearize_impl(S, tot, publish); }
+__device__ __noinline__ void opt_after_trial_call(OptShared& S, const float* tot, bool publish) { opt_after_trial_impl(S, tot, publish); }
 
 // The results (workgroup 0): RegistrationResult of the last level + the linearisation pose + counters.
 __device__ __forceinline__ void opt_publish(float* T_out, const OptShared& S) {
@@ -276,6 +281,14 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
         reinterpret_cast<float*>(&S.slin)[threadIdx.x - 64] = 0.0f;
     }
     __syncthreads();
+#ifdef SP_OPT_TIMING
+    unsigned long long wg_t0 = 0;
+#define SP_WG_BEGIN() if (threadIdx.x == 0) wg_t0 = wall_clock64()
+#define SP_WG_END() if (threadIdx.x == 0 && step < 24 && blockIdx.x < 8) g_sp_wg[step * 8 + blockIdx.x] = wall_clock64() - wg_t0
+#else
+#define SP_WG_BEGIN()
+#define SP_WG_END()
+#endif
 #ifdef SP_OPT_TIMING  // development builds: wall_clock64 stamps of the first steps into the tail of the result's log
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(&A.result->log[8]);
 #define SP_STAMP(k) if (publish && threadIdx.x == 0 && step < 20) stamps[step * 5 + (k)] = wall_clock64()
@@ -289,6 +302,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
         __syncthreads();
 #endif
         SP_STAMP(0);
+        SP_WG_BEGIN();
         float* const row = A.part[step & 1] + (size_t)blockIdx.x * kPartial;
         if (phase == PHASE_LIN) {
             P.scale = A.scales[S.ctl.level];
@@ -319,6 +333,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
             else block_reduce_store<1, BLOCK, true>(acc, cnt, row, false, 0u);
         }
         SP_STAMP(1);
+        SP_WG_END();
         if (!single) {
             // the hand-off of gicp_align_persistent_kernel: wave 0 (the storing lanes) drains its sc1 stores, lane 0 signals
             if (threadIdx.x < kWave) {
@@ -353,8 +368,13 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
         }
         SP_STAMP(2);
         if (threadIdx.x == 0) {
-            if (phase == PHASE_LIN) opt_after_linearize(S, red[0], publish);
-            else opt_after_trial(S, red[0], publish);
+            if constexpr (BLOCK <= 256) {
+                if (phase == PHASE_LIN) opt_after_linearize_impl(S, red[0], publish);
+                else opt_after_trial_impl(S, red[0], publish);
+            } else {
+                if (phase == PHASE_LIN) opt_after_linearize_call(S, red[0], publish);
+                else opt_after_trial_call(S, red[0], publish);
+            }
         }
         __syncthreads();
         SP_STAMP(3);
@@ -374,6 +394,9 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
 #ifdef SP_OPT_TIMING
 extern "C" int sp_internal_opt_debug(unsigned long long* out384) {
     return hipMemcpyFromSymbol(out384, HIP_SYMBOL(sp::g_sp_dbg), 24 * 16 * 8) == hipSuccess ? 0 : 3;
+}
+extern "C" int sp_internal_opt_debug_wg(unsigned long long* out192) {
+    return hipMemcpyFromSymbol(out192, HIP_SYMBOL(sp::g_sp_wg), 24 * 8 * 8) == hipSuccess ? 0 : 3;
 }
 #endif
 extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,
