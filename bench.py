@@ -94,6 +94,9 @@ def parse():
                     help="skip the `stages` block (BASELINE configs 2 and 3 and the pre-loop of config 4, timed after the GICP "
                          "region) and the reuse-off comparison")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points in the CPU-baseline workload")
+    ap.add_argument("--no-example", action="store_true",
+                    help="skip stages.example_registration_config1 (a child process: a profiler wrapped around this command "
+                         "would trace it too)")
     return ap.parse_args()
 
 
@@ -395,7 +398,8 @@ def main():
                 hard = hard_init_block(sp, _lib, torch, S, prep, n_local, SORT_MODE, T_gt)
                 lm = lm_block(sp, torch, S, prep, n_local, SORT_MODE, T_gt)
         stages = stage_block(sp, _lib, torch, cpu=not args.no_cpu_baseline)
-        stages["example_registration_config1"] = example_block(cpu=not args.no_cpu_baseline)
+        if not args.no_example:
+            stages["example_registration_config1"] = example_block(cpu=not args.no_cpu_baseline)
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
     if rank == 0:
         dom = max((k for k in kern if kern[k].get("per_iteration", True)), key=lambda k: kern[k]["ms"])

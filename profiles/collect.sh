@@ -15,12 +15,12 @@ cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 echo "bench done"
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $ROOT/bench.py --steps 20 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/rocprof.err
-cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bench_n1.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $ROOT/bench.py --steps 20 --warmup 20 --no-cpu-baseline --no-example > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/rocprof.err
+cp $(grep -l gicp_align_kernel $(find /tmp/prof_$TAG -name "*kernel_stats.csv") | head -1) $OUT/${TAG}_kernel_stats_bench_n1.csv
 python3 - "$TAG" "$OUT" <<'PY'
 import csv, glob, sys
 tag, out = sys.argv[1], sys.argv[2]
-f = glob.glob(f"/tmp/prof_{tag}/**/*kernel_trace.csv", recursive=True)[0]
+f = max(glob.glob(f"/tmp/prof_{tag}/**/*kernel_trace.csv", recursive=True), key=lambda p: sum("gicp_align_kernel" in l for l in open(p)))
 rows = [r for r in csv.DictReader(open(f)) if "gicp_align_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[20:20 + 31 * 20]  # skip the 20 warm-up launches; keep the 31 timed blocks (one 20-launch alignment each)
