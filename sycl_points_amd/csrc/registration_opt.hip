@@ -7,7 +7,8 @@
 // 685-686, 854). Its own example — LM, Geman-McClure, three annealing levels on a 1000-point random sample
 // (example_registration.cpp:29-55) — is about sixty such round trips for work that one compute unit finishes in microseconds.
 //
-// gicp_optimize_kernel is a persistent launch of align_grid(n) workgroups of 1024 lanes. A STEP is a pass over the source:
+// gicp_optimize_kernel is a persistent launch of up to 256 workgroups (256 lanes each up to 64 K source points, 1024 beyond:
+// see the note above the kernel). A STEP is a pass over the source:
 //   linearise  fused_point of the per-iteration Gauss-Newton kernel (certificate -> cached correspondence, else exact NN on
 //              the grid; 28 sums + inlier count)                                                -> one partial row per workgroup
 //   trial      error_prepared_point: K12 at the trial pose over the cache rows (frozen correspondences) -> one partial row
