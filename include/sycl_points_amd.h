@@ -479,7 +479,8 @@ int sp_gicp_align_linearization_pose(const void* workspace, int last_k, float* t
  *                       DOGLEG  compute_dogleg_step; predicted <= 0 -> shrink; one trial; rho < eta1 -> shrink, else accept
  *                               (rho > eta2 and a full step -> grow)
  *                     an outer iteration ends -> is_converged() or max_iterations ends the level -> next robust scale or done.
- * A launch of one workgroup (<= 1024 source points: the reference pipeline's default random sample) needs no counter at all.
+ * Workgroups have 256 lanes up to 64 K source points (the reference pipeline's default 1000-point random sample: 4 workgroups
+ * on 4 compute units) and 1024 beyond; a launch of one workgroup (<= 256 points) needs no counter at all.
  * robust_scales[n_levels] (host, 1 <= n_levels <= SP_OPT_MAX_LEVELS): the robust scale of each level; lambda / trust radius /
  * result fields restart at every level as a fresh align() would. transT_device: in the initial guess, out the final pose.
  * result_device: sp_align_result in device memory, written once at the end (status 0 ok; 2 a wait ran out — not every workgroup
