@@ -476,6 +476,90 @@ __device__ __forceinline__ void grid_nn1_ball_wave(const float4* __restrict__ pt
     }
 }
 
+// ONE query, the whole wave (all 64 lanes call it with the SAME query and the same `best`: a bound — {d2, idx = -1}: only points
+// nearer than d2 count — or a real point, e.g. the previous winner). The ball of the bound is scanned like grid_nn1_ball_wave
+// scans it, but here the CANDIDATES are dealt to the lanes: lane r finds the extent of row r of the ball (pruned and trimmed
+// against the bound), then the rows are taken four at a time and lane l evaluates candidate l of each — for a bound of a
+// fraction of a cell that is one round trip for the extents and one for the points, whatever the cells hold (a lane scanning
+// its own 2x2x2 block walks every candidate in batches of eight: on a cloud of surfaces, tens of points per cell, that chain
+// is what a small alignment waits for). `best` comes back uniform: the (distance, index)-lexicographic minimum over the ball,
+// or unchanged when nothing beats it. Exact for the reason grid_nn1_ball is.
+__device__ __forceinline__ void grid_nn1_query_wave(const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                    const GridDesc& g, float ux, float uy, float uz, Nearest& best) {
+    const int lane = (int)(threadIdx.x & 63u);
+    auto key_of = [](float d2, int idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(idx + 0x80000000); };
+    const float ub = best.d2;
+    const float rad = (sqrtf(ub) * 1.000001f + 2.0f * g.eps) * g.inv_h;  // in cells, widened like the row trimming
+    const float fx = (ux - g.ox) * g.inv_h, fy = (uy - g.oy) * g.inv_h, fz = (uz - g.oz) * g.inv_h;
+    auto lo_cell = [](float v, int n) { return (int)fminf(fmaxf(floorf(v), 0.0f), (float)(n - 1)); };
+    const int x0 = lo_cell(fx - rad, g.nx), x1 = lo_cell(fx + rad, g.nx);
+    const int y0 = lo_cell(fy - rad, g.ny), y1 = lo_cell(fy + rad, g.ny);
+    const int z0 = lo_cell(fz - rad, g.nz), z1 = lo_cell(fz + rad, g.nz);
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    const unsigned long long key0 = key_of(ub, best.idx);
+    unsigned long long key = key0;
+    unsigned bpos = 0;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+        const int r = r0 + lane;
+        unsigned s = 0, e = 0;
+        if (r < nrows) {
+            const int y = y0 + r % ny, z = z0 + r / ny;
+            const float dyz2 = gap2(uy, g.oy + y * g.h, g.oy + (y + 1) * g.h, g.eps) + gap2(uz, g.oz + z * g.h, g.oz + (z + 1) * g.h, g.eps);
+            if (!(dyz2 > ub)) {
+                const float radx = (sqrtf(fmaxf(ub - dyz2, 0.0f)) * 1.000001f + 2.0f * g.eps) * g.inv_h;
+                const int xa = max(x0, (int)fmaxf(floorf(fx - radx), (float)x0));
+                const int xb = min(x1, (int)fminf(floorf(fx + radx), (float)x1));
+                if (xa <= xb) {
+                    const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
+                    s = start[row + xa];
+                    e = start[row + xb + 1];
+                }
+            }
+        }
+        unsigned long long todo = __ballot(e > s);
+        while (todo) {  // (uniform) four rows at a time, candidate `lane` (+ 64, ...) of each
+            unsigned sj[4], ej[4], len = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sj[j] = ej[j] = 0u;
+                if (todo) {
+                    const int l = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    sj[j] = (unsigned)__builtin_amdgcn_readlane((int)s, l);
+                    ej[j] = (unsigned)__builtin_amdgcn_readlane((int)e, l);
+                    len = max(len, ej[j] - sj[j]);
+                }
+            }
+            for (unsigned base = 0; base < len; base += 64) {
+                float4 c[4];
+                unsigned pj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pj[j] = sj[j] + base + (unsigned)lane;
+                    c[j] = pts[pj[j] < ej[j] ? pj[j] : sj[j]];  // (sj = 0 for a slot without a row: a valid address, never used)
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long kj = key_of(dist2(ux, uy, uz, c[j].x, c[j].y, c[j].z), __float_as_int(c[j].w));
+                    const bool better = pj[j] < ej[j] && kj < key;
+                    key = better ? kj : key;
+                    bpos = better ? pj[j] : bpos;
+                }
+            }
+        }
+    }
+    const unsigned long long m = wave_min_u64(key);
+    if (m != key0) {  // something beat the bound (uniform over the wave)
+        const int wl = __ffsll((long long)__ballot(key == m)) - 1;
+        const unsigned wpos = (unsigned)__builtin_amdgcn_readlane((int)bpos, wl);
+        const float4 w = pts[wpos];
+        best.d2 = __uint_as_float((unsigned)(m >> 32));
+        best.idx = __float_as_int(w.w);
+        best.pos = wpos;
+        best.x = w.x; best.y = w.y; best.z = w.z;
+    }
+}
+
 // Stages after an inexact fast result (`best` holds its upper bound or {FLT_MAX, -1}).
 __device__ __forceinline__ void grid_nn1_later_stages(const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                       const GridDesc& g, float qx, float qy, float qz, Nearest& best) {

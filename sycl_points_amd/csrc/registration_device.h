@@ -546,6 +546,70 @@ __device__ __forceinline__ void fused_point_wave(const FusedParams& P, const Rig
     SP_PSTAMP(6);
 }
 
+// One source point, the WHOLE WAVE (every lane calls it with the same i; what it returns in acc / cnt / searched is the same on
+// every lane: the caller keeps one lane's). For sources of a few thousand points — the reference pipeline aligns a random sample
+// of 1000 — there are more SIMDs than queries, and what a linearisation costs is the longest chain of dependent loads any one
+// lane runs into. Here a query is: cache row + certificate, else ONE ball scan by all 64 lanes (grid_nn1_query_wave) of
+//   the previous winner's distance (a seed: a real point, so the scan is exact and its ball a fraction of a cell), or
+//   half a cell when there is no previous winner (anything found inside is the nearest neighbour), then the search bound's ball,
+// the winner's prepared row, the arithmetic of fused_point (same correspondences, same per-point terms).
+template <int LOSS, bool P2D = false>
+__device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
+                                                 unsigned& cnt, unsigned& searched) {
+    SP_PSTAMP(0);
+    const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
+    float qx, qy, qz;
+    transform_point(T, s.x, s.y, s.z, qx, qy, qz);
+    Nearest nn;
+    nn.d2 = FLT_MAX; nn.idx = -1; nn.pos = 0; nn.x = nn.y = nn.z = 0.0f;
+    Sym3 Ct{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool hit = false, seeded = false;
+    float4* const row = P.ccache + 3 * (size_t)i;
+    if (P.cache_valid) {
+        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        const float d = dist2(qx, qy, qz, r0.x, r0.y, r0.z);
+        const unsigned pos = __float_as_uint(r2.w);
+        if (certified(P, d, r0.w, qx, qy, qz, pos)) {
+            hit = true;
+            nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
+            nn.d2 = nn.idx >= 0 ? d : FLT_MAX;
+            Ct = Sym3{r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+        } else if (__float_as_int(r2.z) >= 0) {  // the previous winner: a real point, an upper bound
+            nn.d2 = d; nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
+            seeded = true;
+        }
+    }
+    SP_PSTAMP(1);
+    if (!hit) {  // (uniform)
+        ++searched;
+        float margin2 = 0.0f;
+        const float bound2 = search_bound2_margin(P, margin2);
+        if (seeded && nn.d2 < bound2) {
+            grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+        } else {
+            const float half = 0.5f * P.g.h;
+            const float first2 = fminf(half * half, bound2);
+            nn.d2 = first2; nn.idx = -1; nn.pos = 0; nn.x = nn.y = nn.z = 0.0f;
+            grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+            if (nn.idx < 0 && first2 < bound2) {
+                nn.d2 = bound2;
+                grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+            }
+        }
+        if (nn.idx < 0) nn.d2 = FLT_MAX;
+        SP_PSTAMP(2); SP_PSTAMP(3); SP_PSTAMP(4);
+        store_correspondence(row, P, nn, Ct, qx, qy, qz, margin2);  // (64 lanes, one address each, the same bits)
+        SP_PSTAMP(5);
+    }
+    if (nn.idx < 0 || nn.d2 > P.max_d2) return;
+    const float* const cp = P.scovp + i;
+    const size_t st = P.sstride;
+    const Sym3 Cs = P2D ? Sym3{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}
+                        : Sym3{cp[0], cp[st], cp[2 * st], cp[3 * st], cp[4 * st], cp[5 * st]};
+    fused_math<LOSS, P2D>(P, T, s, qx, qy, qz, nn, Cs, Ct, acc, cnt);
+    SP_PSTAMP(6);
+}
+
 // One source point of the K12 on the prepared path (Registration::compute_error_parallel_reduction, registration.hpp:678-777, as
 // the LM and dog-leg trial steps call it, :854, :933): the error at the TRIAL pose T with the correspondence FROZEN at that
 // of the last linearisation (pose TL) — read from the point's cache row, not from neighbour arrays. The inlier gate uses the
@@ -653,12 +717,18 @@ struct sp_gicp_target {
     mutable sp::StreamSet streams;  // streams the rows (and the borrowed grid) have been used on
     void note(hipStream_t st) const { streams.note(st); if (grid) grid->streams.note(st); }
 };
+namespace sp {
+// Tagged partial rows of the wave-per-point optimiser launch: 2 (step parity) x kAlignMaxBlocks rows x 32 granules of
+// {float value, uint32 tag} (registration_opt.hip, tagged_rows_exchange).
+constexpr size_t kOptRowsBytes = 2 * (size_t)256 * 32 * sizeof(unsigned long long);
+}  // namespace sp
 struct sp_gicp_source {
     size_t n_max = 0, n = 0;
     float4* pts = nullptr;    // n points in prepared order
     float4* covp = nullptr;   // 2 x float4 per point, prepared order
     unsigned* perm = nullptr; // prepared position -> original index
     float4* ccache = nullptr;      // 3 x float4 per prepared point: its previous correspondence (see fused_point)
+    unsigned long long* opt_rows = nullptr;  // sp_gicp_align_optimize, wave-per-point launches: tagged partial rows (kOptRowsBytes)
     mutable bool cache_valid = false;  // set by the first linearisation after prepare
     const sp_gicp_target* cache_target = nullptr;  // the copies are of this target ...
     unsigned long long cache_version = 0;           // ... at this covariance version
@@ -669,6 +739,7 @@ struct sp_gicp_source {
     int opt_fast_nn = -1;    // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
     int opt_persistent = 1;  // sp_gicp_align_fused: 1 the tail of an alignment as one launch when the grid is resident, 0 a launch per iteration
     int opt_persistent_from = 4;  // first iteration of that tail
+    int opt_wave_query = 1;  // sp_gicp_align_optimize, small sources: one wave per point in the linearisation steps
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;

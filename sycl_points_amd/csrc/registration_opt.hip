@@ -47,6 +47,7 @@ struct OptCtl {  // the optimiser's state between steps (LDS, identical in every
 struct OptArgs {
     float* part[2];
     unsigned* tickets;
+    unsigned long long* trows[2];  // WAVEQ: tagged partial rows, by step parity (zero when the launch starts)
     const float* T_init;          // device: initial guess
     float* T_out;                 // device: final pose (may alias T_init: it is read before anything is written)
     sp_opt_params opt;
@@ -251,7 +252,98 @@ __device__ __forceinline__ void opt_publish(float* T_out, const OptShared& S) {
 // BLOCK: lanes per workgroup. The search of a linearisation is bound by vector issue (thousands of wave instructions per 64
 // points), so a SMALL source wants its waves on many compute units, each wave alone on its SIMD — workgroups of 256 lanes —
 // and pays for it with the arrival counter between steps; a large source fills every compute unit with 1024 lanes anyway.
-template <int LOSS, bool FAST_NN, bool P2D, int BLOCK>
+// The hand-off between two steps of a wave-per-point launch (up to 256 small workgroups, a step of a few microseconds: the
+// counter hand-off — drain the row's stores, count in, poll the counter, read all rows: three dependent trips to memory —
+// costs more than the step). Here a row is 32 granules {value, tag = step + 1} and each granule travels in ONE 8-byte store
+// (the exchange slots' trick, comm.hip): a reader polls the rows themselves, every lane its share of granules, all loads of a
+// round in flight together; a round in which every tag matches IS the data. Rows ping-pong by step parity as the counter form's
+// do; the buffer is zero when the launch starts (tags start at 1).
+// Sums in a fixed order (lane (group, slot): rows group, group + G, ... in order; then the groups in order): the same bits in
+// every workgroup. On return red[0][e] holds the totals (slot nv the uint32 count); false: the wait ran out.
+template <int BLOCK>
+__device__ __forceinline__ bool tagged_rows_exchange(unsigned long long* rows, unsigned tag, float mine, unsigned grid, int nv,
+                                                     float (*red)[kPartial], unsigned long long budget, unsigned* s_wait) {
+    constexpr unsigned kGroups = BLOCK / 32;
+    constexpr int kPer = kAlignMaxBlocks / (int)kGroups;
+    const unsigned e = threadIdx.x & 31u, grp = threadIdx.x >> 5;
+    if (threadIdx.x < 32)
+        __hip_atomic_store(rows + (size_t)blockIdx.x * 32 + e, ((unsigned long long)tag << 32) | __float_as_uint(mine),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool is_count = (int)e == nv;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        unsigned long long g[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned r = grp + (unsigned)j * kGroups;
+            g[j] = r < grid ? __hip_atomic_load(rows + (size_t)r * 32 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : ((unsigned long long)tag << 32);
+        }
+        bool ok = true;
+        float sum = 0.0f;
+        unsigned c = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            ok = ok && (unsigned)(g[j] >> 32) == tag;
+            const unsigned bits = (unsigned)g[j];
+            if (is_count) c += bits;
+            else sum += __uint_as_float(bits);
+        }
+        if (__syncthreads_and(ok ? 1 : 0)) {
+            red[grp][e] = is_count ? __uint_as_float(c) : sum;
+            break;
+        }
+        if (threadIdx.x == 0) *s_wait = (wall_clock64() - t0 > budget) ? 2u : 0u;
+        __syncthreads();
+        if (*s_wait == 2u) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.0f;
+        unsigned ct = 0;
+#pragma unroll
+        for (unsigned p = 0; p < kGroups; ++p) {
+            const float v = red[p][e];
+            if (is_count) ct += __float_as_uint(v);
+            else t += v;
+        }
+        red[0][e] = is_count ? __uint_as_float(ct) : t;
+    }
+    __syncthreads();
+    return true;
+}
+// A workgroup's totals of a wave-per-point step: every lane of a wave holds the wave's sums, so lane 0 of each wave hands them
+// over and lane e < 32 returns slot e of the workgroup's row (sums | uint32 count bits | searched as a float value | zeros).
+template <int NV, int BLOCK>
+__device__ __forceinline__ float waveq_row_slot(const float (&acc)[NV], unsigned cnt, unsigned extra, float (*red)[kPartial]) {
+    const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) red[wave][e] = acc[e];
+        red[wave][NV] = __uint_as_float(cnt);
+        red[wave][NV + 1] = __uint_as_float(extra);
+    }
+    __syncthreads();
+    float v = 0.0f;
+    if ((int)threadIdx.x < NV) {
+#pragma unroll
+        for (int w = 0; w < BLOCK / kWave; ++w) v += red[w][threadIdx.x];
+    } else if ((int)threadIdx.x == NV || (int)threadIdx.x == NV + 1) {
+        unsigned c = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][threadIdx.x]);
+        v = (int)threadIdx.x == NV ? __uint_as_float(c) : (float)c;
+    }
+    return v;
+}
+
+// WAVEQ: one wave per source point in the linearisation steps (fused_query_wave) — sources of up to kWaveQueryMax points, spread
+// over up to 256 workgroups of four waves: the step then costs a handful of dependent round trips instead of the longest
+// per-lane walk through a 2x2x2 block of a surface cloud (the reference's example, 1000 points against 6 k: 16-26 us per
+// linearisation per lane, a few us per wave).
+constexpr size_t kWaveQueryMax = 2048;
+template <int LOSS, bool FAST_NN, bool P2D, int BLOCK, bool WAVEQ = false>
 __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, OptArgs A) {
     __shared__ OptShared S;
     __shared__ float red[BLOCK / 32][kPartial];
@@ -305,6 +397,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
         SP_STAMP(0);
         SP_WG_BEGIN();
         float* const row = A.part[step & 1] + (size_t)blockIdx.x * kPartial;
+        [[maybe_unused]] float mine = 0.0f;  // WAVEQ: slot threadIdx.x < 32 of this workgroup's row
         if (phase == PHASE_LIN) {
             P.scale = A.scales[S.ctl.level];
             P.cache_valid = S.ctl.cache_valid;
@@ -313,29 +406,64 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
             unsigned cnt = 0, searched = 0;
 #pragma unroll
             for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
-            if constexpr (FAST_NN) {  // (the staged search: open queries are finished by the whole wave)
+            if constexpr (WAVEQ) {
+                const unsigned nw = BLOCK / kWave;
+                const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+                for (unsigned i = blockIdx.x * nw + wave; i < P.n; i += gridDim.x * nw)
+                    fused_query_wave<LOSS, P2D>(P, T, i, acc, cnt, searched);
+                SP_STAMP(4);
+                mine = waveq_row_slot<kAcc - 1, BLOCK>(acc, cnt, searched, red);
+            } else if constexpr (FAST_NN && BLOCK <= 256) {  // (the staged search: open queries are finished by the whole wave)
                 for (unsigned b = tile * BLOCK; b < P.n; b += stride)
                     fused_point_wave<LOSS, P2D>(P, T, b + threadIdx.x, b + threadIdx.x < P.n, acc, cnt, searched);
-            } else {
+            } else {  // (1024 lanes: 128 registers — the per-lane stages of the per-iteration kernel fit them, the wave's tail does not)
                 for (unsigned i = tile * BLOCK + threadIdx.x; i < P.n; i += stride)
-                    fused_point<LOSS, FAST_NN, P2D>(P, T, i, acc, cnt, searched);
+                    fused_point<LOSS, FAST_NN, P2D, kSeedSearches, kNegCert>(P, T, i, acc, cnt, searched);
             }
-            SP_STAMP(4);
-            if (single) block_reduce_lds<kAcc - 1, BLOCK>(acc, cnt, searched, red[0]);
-            else block_reduce_store<kAcc - 1, BLOCK, true>(acc, cnt, row, false, searched);
+            if constexpr (!WAVEQ) {
+                SP_STAMP(4);
+                if (single) block_reduce_lds<kAcc - 1, BLOCK>(acc, cnt, searched, red[0]);
+                else block_reduce_store<kAcc - 1, BLOCK, true>(acc, cnt, row, false, searched);
+            }
         } else {
             const Rigid T = uniform_pose(S.sTt);
             const Rigid TL = uniform_pose(S.sTlin);
             float acc[1] = {0.0f};
             unsigned cnt = 0;
-            for (unsigned i = tile * BLOCK + threadIdx.x; i < P.n; i += stride)
-                error_prepared_point<LOSS, P2D>(P, T, TL, i, acc, cnt);
-            if (single) block_reduce_lds<1, BLOCK>(acc, cnt, 0u, red[0]);
-            else block_reduce_store<1, BLOCK, true>(acc, cnt, row, false, 0u);
+            if constexpr (WAVEQ) {
+                // the wave that searched for a point also evaluates it: a cache row is only ever touched by one wave of the launch
+                // (rows written on one XCD are not visible through another XCD's L2 before the launch ends)
+                const unsigned nw = BLOCK / kWave;
+                const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+                for (unsigned i = blockIdx.x * nw + wave; i < P.n; i += gridDim.x * nw)
+                    error_prepared_point<LOSS, P2D>(P, T, TL, i, acc, cnt);
+                mine = waveq_row_slot<1, BLOCK>(acc, cnt, 0u, red);
+            } else {
+                for (unsigned i = tile * BLOCK + threadIdx.x; i < P.n; i += stride)
+                    error_prepared_point<LOSS, P2D>(P, T, TL, i, acc, cnt);
+                if (single) block_reduce_lds<1, BLOCK>(acc, cnt, 0u, red[0]);
+                else block_reduce_store<1, BLOCK, true>(acc, cnt, row, false, 0u);
+            }
         }
         SP_STAMP(1);
         SP_WG_END();
-        if (!single) {
+        auto wait_ran_out = [&] {  // (uniform per workgroup; every workgroup runs into the same bound) — loud: NaN pose, status 2
+            if (publish) {
+                if (threadIdx.x < 16) { A.T_out[threadIdx.x] = __int_as_float(0x7fc00000); A.result->T[threadIdx.x] = __int_as_float(0x7fc00000); }
+                if (threadIdx.x == 16) { A.result->status = 2u; A.result->converged = 0u; A.result->log_entries = 0u; }
+            }
+        };
+        if constexpr (WAVEQ) {
+            if (single) {
+                __syncthreads();
+                if (threadIdx.x < 32) red[0][threadIdx.x] = mine;
+                __syncthreads();
+            } else if (!tagged_rows_exchange<BLOCK>(A.trows[step & 1], step + 1u, mine, gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1,
+                                                    red, A.budget, &s_wait)) {
+                wait_ran_out();
+                return;
+            }
+        } else if (!single) {
             // the hand-off of gicp_align_persistent_kernel: wave 0 (the storing lanes) drains its sc1 stores, lane 0 signals
             if (threadIdx.x < kWave) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,11 +486,8 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
                 }
             }
             __syncthreads();
-            if (s_wait == 2) {  // (uniform per workgroup; every workgroup runs into the same bound) — loud: NaN pose, status 2
-                if (publish) {
-                    if (threadIdx.x < 16) { A.T_out[threadIdx.x] = __int_as_float(0x7fc00000); A.result->T[threadIdx.x] = __int_as_float(0x7fc00000); }
-                    if (threadIdx.x == 16) { A.result->status = 2u; A.result->converged = 0u; A.result->log_entries = 0u; }
-                }
+            if (s_wait == 2) {
+                wait_ran_out();
                 return;
             }
             reduce_rows_block<BLOCK, true>(A.part[step & 1], gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1, red);
@@ -437,7 +562,9 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     // workgroups of 256 lanes while they all fit the device one per compute unit (64 K points), of 1024 beyond
     const bool small = n <= (size_t)256 * 256;
     const unsigned block = small ? 256u : (unsigned)kAlignBlock;
-    const unsigned grid = std::min<unsigned>((unsigned)((n + block - 1) / block), (unsigned)kAlignMaxBlocks);
+    const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
+    const bool waveq = fast && n <= kWaveQueryMax && source->opt_wave_query != 0;  // one wave per point, four waves per workgroup
+    const unsigned grid = std::min<unsigned>((unsigned)(waveq ? (n + 3) / 4 : (n + block - 1) / block), (unsigned)kAlignMaxBlocks);
     PersistGuard* const guard = persist_acquire(st, grid);
     if (!guard) {
         sp_set_error("[sp_gicp_align_optimize] not available now: the launch cannot be resident (grid larger than the device, stream "
@@ -453,7 +580,11 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     A.part[0] = rows;
     A.part[1] = rows + (size_t)kAlignMaxBlocks * kPartial;
     A.tickets = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kTicketOffsetBytes);
-    if (grid > 1 && zero_async(A.tickets, kTicketShards * kTicketStride * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
+    A.trows[0] = source->opt_rows;
+    A.trows[1] = source->opt_rows + (size_t)kAlignMaxBlocks * 32;
+    if (grid > 1 && waveq) {
+        if (zero_async(source->opt_rows, kOptRowsBytes, st) != SP_OK) return SP_ERR_HIP;
+    } else if (grid > 1 && zero_async(A.tickets, kTicketShards * kTicketStride * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
     target->note(st);
     FusedParams P = make_fused_params(target, source, params, transT_device, 1, nullptr, nullptr);
     A.T_init = transT_device;
@@ -468,15 +599,16 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
         sp_set_error("[sp_gicp_align_optimize] the prepared target has no reuse certificates");
         return SP_ERR_INVALID_ARGUMENT;
     }
-    const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
     const bool p2d = params->reg_type == SP_REG_POINT_TO_DISTRIBUTION;
 #define SP_LAUNCH_OPT2(L, B)                                                                        \
     if (fast && p2d) gicp_optimize_kernel<L, true, true, B><<<grid, B, 0, st>>>(P, A);              \
     else if (fast) gicp_optimize_kernel<L, true, false, B><<<grid, B, 0, st>>>(P, A);               \
     else if (p2d) gicp_optimize_kernel<L, false, true, B><<<grid, B, 0, st>>>(P, A);                \
     else gicp_optimize_kernel<L, false, false, B><<<grid, B, 0, st>>>(P, A)
-#define SP_LAUNCH_OPT(L)                                    \
-    if (small) { SP_LAUNCH_OPT2(L, 256); }                 \
+#define SP_LAUNCH_OPT(L)                                                                           \
+    if (waveq && p2d) gicp_optimize_kernel<L, true, true, 256, true><<<grid, 256, 0, st>>>(P, A);  \
+    else if (waveq) gicp_optimize_kernel<L, true, false, 256, true><<<grid, 256, 0, st>>>(P, A);   \
+    else if (small) { SP_LAUNCH_OPT2(L, 256); }                                                    \
     else { SP_LAUNCH_OPT2(L, kAlignBlock); }
     switch (params->robust_type) {
         case SP_LOSS_NONE: SP_LAUNCH_OPT(LOSS_NONE); break;

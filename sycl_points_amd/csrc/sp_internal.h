@@ -40,7 +40,10 @@ enum {
      * Same lists either way. */
     SP_INTERNAL_BVH_SORT_QUERIES = 7,
     /* sp_grid: the same for sp_grid_search / sp_grid_radius_search: in cell order (1, default) or as given (0). */
-    SP_INTERNAL_GRID_SORT_QUERIES = 8
+    SP_INTERNAL_GRID_SORT_QUERIES = 8,
+    /* sp_gicp_source: sp_gicp_align_optimize on a source of up to 2048 points: one wave per point in the linearisation steps
+     * (1, default) or one lane per point (0). Same correspondences either way; the sums are grouped differently. */
+    SP_INTERNAL_OPT_WAVE_QUERY = 9
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);

@@ -180,6 +180,42 @@ def test_optimiser_argument_errors_and_switch(sp, orc):
     assert reg.align_optimize(S, prep, None) is not None
 
 
+@pytest.mark.parametrize("n", [700, 1900])
+@pytest.mark.parametrize("opt,reg_type", [("LM", "GICP"), ("DOGLEG", "POINT_TO_DISTRIBUTION")])
+def test_wave_per_point_and_lane_per_point_agree(sp, orc, n, opt, reg_type):
+    """Sources of up to 2048 points take one WAVE per point in the linearisation steps (fused_query_wave: certificate, else one
+    ball scan by 64 lanes seeded with the previous winner). Every correspondence is the exact nearest neighbour either way, so
+    the lane-per-point form of the same launch (internal switch) must search the same number of points, take the same decisions
+    and end on the same pose up to the grouping of the sums. A third of the source lies 100 m away from the target: no
+    correspondence in any iteration (unseeded scans of the whole bound's ball, negative certificates)."""
+    src, scov, tgt, tcov, T_gt = inputs(orc, n, 8.0, seed=7)
+    src = src.copy()
+    src[::3, 0] += 100.0
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(dev(tgt)), dev(tcov), reg_type=reg_type)
+    T0 = orc.se3_exp([0.01, -0.005, 0.02, 0.05, -0.04, 0.03])
+    case = dict(opt=opt, reg_type=reg_type, loss="GEMAN_MCCLURE", scale=1.0)
+    p = sp.RegistrationParams(reg_type=reg_type, robust_type="GEMAN_MCCLURE", robust_default_scale=1.0, optimization_method=opt,
+                              max_iterations=15, max_correspondence_distance=0.6)
+    scales = [float(v) for v in orc.robust_annealing_scales("GEMAN_MCCLURE", True, 1.0, 2.0, 1.0, 2)]
+    assert len(scales) == 2
+    out = {}
+    for mode in (1, 0):
+        reg = sp.Registration(p)
+        reg._set_source_option("opt_wave_query", mode)
+        out[mode] = reg.align_optimize(S, prep, T0, scales)
+        assert out[mode] is not None
+    w, l = out[1], out[0]
+    assert w.searched == l.searched and w.inlier == l.inlier and w.iterations == l.iterations and w.converged == l.converged
+    assert [(e["trials"], e["accepted"]) for e in w.log] == [(e["trials"], e["accepted"]) for e in l.log]
+    assert np.abs(w.T - l.T).max() < 2e-6
+    assert n // 2 < w.inlier <= n - (n + 2) // 3
+    ref = orc.registration_align(oracle_params(case, max_iterations=15, max_correspondence_distance=0.6, auto_scale=1,
+                                               auto_scaling_iter=2, init_scale=2.0, min_scale=1.0), src, scov, tgt, tcov, init_T=T0,
+                                 steps=True)
+    check_against_oracle(w, ref, case, levels=2)
+
+
 def test_adaptive_grid_on_a_cloud_of_surfaces(sp, orc):
     """sp_grid_create_adaptive on the reference's bundled scan, voxel-downsampled as its pipelines do before any search
     (points on surfaces: the volume rule packs ~40 of them into an occupied cell): the cell shrinks until the occupied cells
