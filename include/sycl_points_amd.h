@@ -52,7 +52,10 @@ int sp_knn_bruteforce(const float* queries, size_t nq, const float* targets, siz
 /* From 16 K targets on, the search bounds every query's k-th distance first (chunk minima of an approximate distance with a
  * proven error term) and evaluates the reference's expression only where a neighbour can be. That first pass runs on the
  * matrix cores (bf16-split operands, v_mfma_f32_32x32x16_bf16); valu != 0 selects its packed-fp32 VALU form instead, for
- * measurement (process-wide; the results do not depend on it). */
+ * measurement (process-wide; the results do not depend on it).
+ * Target clouds of 256 .. 12032 points (a voxel-downsampled scan) are answered by ONE launch that keeps the whole cloud in LDS
+ * (a wave per four queries: lane minima -> bound of the k-th distance -> the targets within it -> 64-lane sort); valu == 2
+ * switches that path off (the general ones then serve every size), valu == 3 on again (default). Same lists. */
 int sp_knn_bruteforce_set_pass_a(int valu);
 
 /* KD-tree (algorithms/knn/kdtree.hpp:142-766).

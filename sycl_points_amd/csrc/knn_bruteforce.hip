@@ -821,9 +821,150 @@ __global__ __launch_bounds__(kBlock) void knn_bf_select_kernel(const float4* __r
     }
 }
 
+// ---- small target clouds (up to kSmallMaxTargets points: a voxel-downsampled scan) ----------------------------------------------
+// The whole target cloud sits in LDS (x | y | z planes, 12 bytes a point) of every workgroup and ONE launch answers every query:
+// a wave takes kSmallQ queries at a time and its 64 lanes deal the targets among themselves (lane l: targets l, l + 64, ...).
+//   pass 1  every lane's nearest target per query; the k-th smallest of the 64 lane minima (64-lane bitonic sort) is an upper
+//           bound tau of the k-th neighbour's distance — k different targets are that near
+//   pass 2  the targets with d <= tau (k of them, plus whatever shares a lane with a nearer one: a handful) go to a list in LDS
+//           by ballot + prefix count; 64 entries a query, more is the overflow path below
+//   select  one candidate per lane, the 64-lane sort by (distance, index), the first k are the answer — the brute-force rule
+//           (ties to the lower index); overflow: every target through insert_candidates (knn_bf_select_kernel's loop)
+// Same expression for the distance as everywhere (dist2), evaluated twice instead of stored. The bounded pipeline above is a
+// dozen launches (boxes, frames, pass A on the matrix cores, offsets, lists, collect, select): ~110 us for two 6 k-point clouds
+// with k = 10 whatever the work; this is one launch of ~10 k wave instructions per four queries.
+constexpr unsigned kSmallMinTargets = 256, kSmallMaxTargets = 12032;
+constexpr int kSmallBlock = 512, kSmallQ = 4;
+constexpr unsigned kSmallListCap = 64;
+constexpr size_t small_lds_bytes(unsigned nt) {
+    return (size_t)3 * ((nt + 63u) & ~63u) * sizeof(float) + (size_t)(kSmallBlock / 64) * kSmallQ * kSmallListCap * sizeof(unsigned long long);
+}
+__global__ __launch_bounds__(kSmallBlock) void knn_bf_small_kernel(const float4* __restrict__ queries, unsigned nq,
+                                                                   const float4* __restrict__ targets, unsigned nt, int k,
+                                                                   int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    extern __shared__ float small_lds[];
+    const unsigned ntp = (nt + 63u) & ~63u;
+    float* const tx = small_lds;
+    float* const ty = small_lds + ntp;
+    float* const tz = small_lds + 2 * (size_t)ntp;
+    unsigned long long* const lists = reinterpret_cast<unsigned long long*>(small_lds + 3 * (size_t)ntp);
+    for (unsigned j = threadIdx.x; j < ntp; j += kSmallBlock) {
+        const float4 p = targets[min(j, nt - 1)];
+        tx[j] = p.x; ty[j] = p.y; tz[j] = p.z;
+    }
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr unsigned kWaves = kSmallBlock / 64;
+    unsigned long long* const my_lists = lists + (size_t)wave * kSmallQ * kSmallListCap;
+    const unsigned groups = (nq + kSmallQ - 1) / kSmallQ;
+    const float inf = __builtin_inff();
+    for (unsigned g = blockIdx.x * kWaves + wave; g < groups; g += gridDim.x * kWaves) {
+        float qx[kSmallQ], qy[kSmallQ], qz[kSmallQ], mn[kSmallQ], tau[kSmallQ];
+#pragma unroll
+        for (int u = 0; u < kSmallQ; ++u) {
+            const float4 q = queries[min(g * kSmallQ + u, nq - 1)];
+            qx[u] = q.x; qy[u] = q.y; qz[u] = q.z;
+            mn[u] = inf;
+        }
+#pragma unroll 4
+        for (unsigned j = lane; j < ntp; j += 64) {
+            const float x = tx[j], y = ty[j], z = tz[j];
+            const bool valid = j < nt;
+#pragma unroll
+            for (int u = 0; u < kSmallQ; ++u) {
+                const float d = dist2(qx[u], qy[u], qz[u], x, y, z);
+                mn[u] = (valid && d < mn[u]) ? d : mn[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kSmallQ; ++u) {
+            Cand c;
+            c.key = cand_key(mn[u], (int)lane);
+            c.pos = 0;
+            c = bitonic_sort64(c, lane);
+            tau[u] = key_d2(bcast_k(c.key, k - 1));
+        }
+        unsigned cnt[kSmallQ];
+#pragma unroll
+        for (int u = 0; u < kSmallQ; ++u) cnt[u] = 0;
+        for (unsigned j = lane; j < ntp; j += 64) {
+            const float x = tx[j], y = ty[j], z = tz[j];
+            const bool valid = j < nt;
+#pragma unroll
+            for (int u = 0; u < kSmallQ; ++u) {
+                const float d = dist2(qx[u], qy[u], qz[u], x, y, z);
+                const bool hit = valid && d <= tau[u];
+                const unsigned long long m = __ballot(hit);
+                if (m) {  // (uniform)
+                    const unsigned pos = cnt[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (hit && pos < kSmallListCap) my_lists[u * kSmallListCap + pos] = cand_key(d, (int)j);
+                    cnt[u] += (unsigned)__builtin_popcountll(m);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < kSmallQ; ++u) {
+            const unsigned q = g * kSmallQ + u;
+            if (q >= nq) continue;  // (uniform)
+            Cand best;
+            best.pos = 0;
+            if (cnt[u] <= kSmallListCap) {
+                Cand c;
+                c.key = lane < cnt[u] ? my_lists[u * kSmallListCap + lane] : kNoCand;
+                c.pos = 0;
+                best = bitonic_sort64(c, lane);
+            } else {  // more than 64 targets within tau (equal distances, duplicates): every target against the sorted top k
+                const unsigned long long kmask = (1ull << k) - 1ull;  // k <= 20
+                best.key = kNoCand;
+                unsigned long long kth = kNoCand;
+                for (unsigned base = 0; base < nt; base += 64) {
+                    const unsigned j = base + lane;
+                    Cand c;
+                    c.key = j < nt ? cand_key(dist2(qx[u], qy[u], qz[u], tx[j], ty[j], tz[j]), (int)j) : kNoCand;
+                    c.pos = 0;
+                    if (base == 0) {
+                        best = bitonic_sort64(c, lane);
+                        kth = bcast_k(best.key, k - 1);
+                    } else {
+                        insert_candidates(c, best, kth, k, kmask, lane);
+                    }
+                }
+            }
+            if (lane < (unsigned)k) {
+                const bool none = best.key >= kNoCand;  // (an empty slot, or a distance `d < FLT_MAX` would not have admitted)
+                idx_out[(size_t)q * k + lane] = none ? -1 : key_idx(best.key);
+                d2_out[(size_t)q * k + lane] = none ? FLT_MAX : key_d2(best.key);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+bool small_applies(size_t nq, size_t nt) {
+    // (measured, self-search: 6 k x 6 k, k = 10: 30 us against 108 for the bounded pipeline; 12 k x 12 k: 145 against 113 — the
+    // matrix cores' bounding pass wins from about 10^8 pairs on)
+    return nt >= kSmallMinTargets && nt <= kSmallMaxTargets && nq * nt <= (size_t)80 * 1000 * 1000;
+}
+int run_small(const float* queries, size_t nq, const float* targets, size_t nt, size_t k, int32_t* idx_out, float* d2_out,
+              hipStream_t st) {
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_bf_small_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)small_lds_bytes(kSmallMaxTargets)) == hipSuccess;
+    if (!attr_ok) return SP_ERR_HIP;
+    const unsigned groups = (unsigned)((nq + kSmallQ - 1) / kSmallQ);
+    const unsigned grid = std::min(256u, (groups + kSmallBlock / 64 - 1) / (kSmallBlock / 64));
+    knn_bf_small_kernel<<<grid, kSmallBlock, small_lds_bytes((unsigned)nt), st>>>(
+        reinterpret_cast<const float4*>(queries), (unsigned)nq, reinterpret_cast<const float4*>(targets), (unsigned)nt, (int)k,
+        idx_out, d2_out);
+    return launch_status();
+}
+
 // Which approximate pass A runs (sp_knn_bruteforce_set_pass_a: 0 = matrix cores (default), 1 = packed VALU): both are kept
 // because both are measured in bench.py's stages block; the lists do not depend on the choice.
 int g_pass_a_valu = 0;
+// (sp_knn_bruteforce_set_pass_a(2 / 3): the one-launch path for small target clouds off / on — tests compare the two)
+int g_small_path = 1;
 
 struct BfPlan {
     unsigned qblocks, nsplit, chunk;
@@ -989,7 +1130,8 @@ __global__ void fill_empty_kernel(int32_t* idx, float* d2, size_t n) {
 }  // namespace sp
 
 extern "C" int sp_knn_bruteforce_set_pass_a(int valu) {
-    sp::g_pass_a_valu = valu ? 1 : 0;
+    if (valu == 2 || valu == 3) sp::g_small_path = valu == 3 ? 1 : 0;
+    else sp::g_pass_a_valu = valu ? 1 : 0;
     return SP_OK;
 }
 
@@ -1021,6 +1163,7 @@ extern "C" int sp_knn_bruteforce(const float* queries, size_t nq, const float* t
         fill_empty_kernel<<<div_up(nq * k, kBlock), kBlock, 0, st>>>(idx_out, d2_out, nq * k);
         return launch_status();
     }
+    if (g_small_path && small_applies(nq, nt)) return run_small(queries, nq, targets, nt, k, idx_out, d2_out, st);
     const BoundedPlan bp = plan_bounded(nq, nt, k);
     if (bp.use) {
         if (workspace == nullptr || workspace_bytes < bp.bytes) {

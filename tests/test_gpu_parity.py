@@ -217,6 +217,37 @@ def test_bruteforce_small_spatially_ordered_clouds(sp, orc, n, k):
     assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("nt, nq, k", [(256, 1, 1), (700, 333, 5), (6096, 6096, 10), (6096, 1000, 20), (12032, 2500, 10),
+                                       (3001, 4099, 3)])
+def test_bruteforce_small_cloud_in_one_launch(sp, orc, nt, nq, k):
+    # Target clouds of 256 .. 12032 points: the whole cloud in LDS, one launch, a wave per four queries (lane minima -> bound
+    # of the k-th distance -> the targets within it -> 64-lane sort). Surfaces with duplicates and a block of identical points
+    # (more than 64 targets at the k-th distance: the kernel's overflow path). Bit-identical to the oracle and to the general
+    # paths of the same library (switch 2 of sp_knn_bruteforce_set_pass_a).
+    from sycl_points_amd import _lib
+
+    g = orc.rng(nt + nq + k)
+    pts = g.uniform_points(nt, 10.0)
+    pts[:, 2] = np.round(pts[:, 2] * 0.05) / 0.05 * 0.01
+    pts[::53] = pts[7]
+    if nt >= 700:
+        pts[100:260] = pts[100]  # 160 identical points
+    q = g.uniform_points(nq, 10.0)
+    q[: min(nq, 64)] = pts[: min(nq, 64)]  # queries ON targets (distance 0, and the block of identical points)
+    if nq > 150:
+        q[100:150] = pts[100]
+    oi, od = orc.knn_bruteforce(q, pts, k)
+    L = _lib.lib()
+    r = sp.knn_search_bruteforce(dev(q), dev(pts), k)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    _lib.check(L.sp_knn_bruteforce_set_pass_a(2))
+    try:
+        general = sp.knn_search_bruteforce(dev(q), dev(pts), k)
+    finally:
+        _lib.check(L.sp_knn_bruteforce_set_pass_a(3))
+    assert torch.equal(general.indices, r.indices) and torch.equal(general.distances, r.distances)
+
+
 def test_bruteforce_config2_size_k20(sp, orc):
     # 100k x 100k at k = 20 (the reference's MAX_K): oracle on a 500-query sample, size-independent properties on all
     # (ascending distances, distance == distance to the reported index, no index twice).
