@@ -20,7 +20,9 @@
 #include <cstring>
 #include <initializer_list>
 #include <limits>
+#include <map>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -263,6 +265,96 @@ private:
         return *c;
     }
 };
+// Host memory of large containers: PINNED blocks from a process-wide pool (round 5). A copy between pageable memory and the
+// device is staged — by the runtime at 3-5 GB/s, or through StagedCopy's pinned buffers below at the host's memcpy speed: for
+// the reference example's two 1.1 MB scans that memcpy was 45 us apiece, a tenth of the loop. A container whose host vector
+// already lives in pinned memory is copied by the DMA engine directly. hipHostMalloc costs a millisecond, so blocks (powers of
+// two from 256 KB) go back to a free list, never to the system; beyond kMaxTotal, or when pinned memory is not to be had (no
+// device, limits), the allocator hands out ordinary heap memory and StagedCopy serves the copies as before.
+struct PinnedPool {
+    static constexpr size_t kMinBytes = size_t(256) << 10, kMaxTotal = size_t(2) << 30;
+    static void* acquire(size_t bytes) {
+        size_t cls = kMinBytes;
+        while (cls < bytes) cls <<= 1;
+        State& s = state();
+        {
+            std::lock_guard<std::mutex> lock(s.m);
+            auto it = s.free.find(cls);
+            if (it != s.free.end() && !it->second.empty()) {
+                void* p = it->second.back();
+                it->second.pop_back();
+                s.live[p] = cls;
+                return p;
+            }
+            if (s.failed || s.total + cls > kMaxTotal) return nullptr;
+            s.total += cls;
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cls, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lock(s.m);
+            s.total -= cls;
+            s.failed = true;  // (no device, or the limit of locked memory: do not try again for every container)
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lock(s.m);
+        s.live[p] = cls;
+        return p;
+    }
+    /// true: p was a pooled block and is back on the free list
+    static bool release(void* p) {
+        State& s = state();
+        std::lock_guard<std::mutex> lock(s.m);
+        auto it = s.live.find(p);
+        if (it == s.live.end()) return false;
+        s.free[it->second].push_back(p);
+        s.live.erase(it);
+        return true;
+    }
+    /// [p, p + bytes) lies inside a live pooled block
+    static bool owns(const void* p, size_t bytes) {
+        State& s = state();
+        std::lock_guard<std::mutex> lock(s.m);
+        auto it = s.live.upper_bound(const_cast<void*>(p));
+        if (it == s.live.begin()) return false;
+        --it;
+        const char* b = static_cast<const char*>(it->first);
+        return static_cast<const char*>(p) >= b && static_cast<const char*>(p) + bytes <= b + it->second;
+    }
+
+private:
+    struct State {
+        std::mutex m;
+        std::map<void*, size_t> live;
+        std::map<size_t, std::vector<void*>> free;
+        size_t total = 0;
+        bool failed = false;
+    };
+    static State& state() {
+        static auto* s = new State();  // never destroyed: containers with static lifetime may outlive any static of ours
+        return *s;
+    }
+};
+/// std::allocator with PinnedPool behind allocations of 256 KB and more (the reference's shared_vector is a std::vector with a
+/// USM allocator, utils/sycl_utils.hpp:630-635: a custom allocator is what its callers already see).
+template <typename T>
+struct host_allocator {
+    using value_type = T;
+    host_allocator() = default;
+    template <class U> host_allocator(const host_allocator<U>&) {}
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= PinnedPool::kMinBytes)
+            if (void* p = PinnedPool::acquire(bytes)) return static_cast<T*>(p);
+        return static_cast<T*>(::operator new(bytes));
+    }
+    void deallocate(T* p, size_t n) {
+        if (n * sizeof(T) >= PinnedPool::kMinBytes && PinnedPool::release(p)) return;
+        ::operator delete(p);
+    }
+    template <class U> bool operator==(const host_allocator<U>&) const { return true; }
+    template <class U> bool operator!=(const host_allocator<U>&) const { return false; }
+};
 // Large copies between a container's host vector and its HBM mirror go through two pinned 8 MB buffers (one filled /
 // drained by the host while the other is in flight): a hipMemcpy from or to pageable memory is staged by the runtime at
 // 3-5 GB/s on this stack — 16 MB of points took 3-5 ms to upload, an 80 MB neighbour list 25 ms to read back — where the
@@ -271,7 +363,7 @@ private:
 struct StagedCopy {
     static constexpr size_t kChunk = size_t(8) << 20, kMin = size_t(1) << 20;
     static void h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
-        Buffers* b = bytes >= kMin ? buffers(st) : nullptr;
+        Buffers* b = (bytes >= kMin && !PinnedPool::owns(src, bytes)) ? buffers(st) : nullptr;  // (pinned already: the DMA engine reads it in place)
         if (!b) {
             hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), "H2D");
             hip_check(hipStreamSynchronize(st), "H2D sync");
@@ -291,7 +383,7 @@ struct StagedCopy {
     }
     /// (the caller has synchronised the stream the device data was produced on)
     static void d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
-        Buffers* b = bytes >= kMin ? buffers(st) : nullptr;
+        Buffers* b = (bytes >= kMin && !PinnedPool::owns(dst, bytes)) ? buffers(st) : nullptr;
         if (!b) {
             hip_check(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "D2H");
             return;
@@ -480,8 +572,9 @@ template <typename T>
 class shared_vector {
 public:
     using value_type = T;
-    using iterator = typename std::vector<T>::iterator;
-    using const_iterator = typename std::vector<T>::const_iterator;
+    using host_vector = std::vector<T, detail::host_allocator<T>>;
+    using iterator = typename host_vector::iterator;
+    using const_iterator = typename host_vector::const_iterator;
 
     shared_vector() = default;
     explicit shared_vector(const sycl_utils::DeviceQueue& q) : queue_(q.ptr) {}
@@ -519,7 +612,7 @@ public:
     iterator end() { sync_host(); touch(); return host_.end(); }
     const_iterator begin() const { sync_host(); return host_.begin(); }
     const_iterator end() const { sync_host(); return host_.end(); }
-    const std::vector<T>& host() const { sync_host(); return host_; }
+    const host_vector& host() const { sync_host(); return host_; }
     /// std::vector::insert / erase on the host copy (PointCloudShared::extend / erase, points/point_cloud.hpp:319-368)
     template <class It>
     iterator insert(const_iterator pos, It first, It last) {
@@ -534,7 +627,7 @@ public:
     }
     /// the elements of `o` appended (its host copy is brought up to date first)
     void append(const shared_vector& o) {
-        const std::vector<T>& src = o.host();
+        const host_vector& src = o.host();
         sync_host();
         host_.insert(host_.end(), src.begin(), src.end());
         touch();
@@ -556,7 +649,7 @@ public:
     /// (25 ms per list on the host clock of the config-4 harness, examples/bench_registration.cpp).
     void resize_on_device(size_t n, const uint32_t* fill_bits = nullptr) {
         static_assert(sizeof(T) % 4 == 0, "device fill works on 32-bit words");
-        std::vector<T>().swap(host_);
+        host_vector().swap(host_);
         ensure_capacity(n);
         if (fill_bits && n) hip_check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dev_), (int)*fill_bits, n * (sizeof(T) / 4), stream()), "fill");
         dev_size_ = n; size_override_ = true; dev_dirty_ = true; host_dirty_ = false;
@@ -608,7 +701,7 @@ private:
         host_dirty_ = false;
     }
 
-    mutable std::vector<T> host_;
+    mutable host_vector host_;
     mutable T* dev_ = nullptr;
     mutable size_t dev_cap_ = 0, dev_size_ = 0, dev_bytes_ = 0;
     mutable bool host_dirty_ = true, dev_dirty_ = false, size_override_ = false;

@@ -226,8 +226,10 @@ public:
         // brute-force search (sp_knn_bruteforce: bounding pass, then the reference's expression where a neighbour can be) in
         // tens of microseconds; building the hierarchy alone takes 0.17 ms whatever the size, its k = 10 search 0.2 ms. Same
         // lists: both break distance ties by the lowest index.
-        if (pristine_ && k <= 20 && transT == TransformMatrix::Identity() && size_ >= 2048 && size_ <= kBruteForceMaxTargets &&
-            size_ >= 256 * k && queries.size() <= kBruteForceMaxQueries)
+        // (up to 12 k targets and 8 * 10^7 pairs sp_knn_bruteforce is ONE launch with the cloud in LDS: 30 us for 6 k x 6 k)
+        const bool small = size_ <= 12032 && queries.size() * size_ <= size_t(80) * 1000 * 1000;
+        if (pristine_ && k <= 20 && transT == TransformMatrix::Identity() && queries.size() <= kBruteForceMaxQueries &&
+            (small || (size_ >= 2048 && size_ <= kBruteForceMaxTargets && size_ >= 256 * k)))
             return Backend::BruteForce;
         return Backend::Hierarchy;
     }

@@ -262,8 +262,10 @@ class KDTree(KNNBase):
         if own and 8 <= k <= 20 and self._uniform_grid() is not None:
             return "grid"
         # a small cloud (the reference example's 6 k-point downsampled scans): exact brute force beats building a hierarchy
-        if (self._pristine and unchanged and transT is None and k <= 20 and 2048 <= self.n <= KDTree.BRUTE_FORCE_MAX_TARGETS and
-                self.n >= 256 * k and q.shape[0] <= KDTree.BRUTE_FORCE_MAX_QUERIES):
+        # (up to 12 k targets and 8 * 10^7 pairs: one launch with the cloud in LDS; beyond, from 2048 targets: the bounded passes)
+        small = self.n <= 12032 and q.shape[0] * self.n <= 80_000_000
+        if (self._pristine and unchanged and transT is None and k <= 20 and q.shape[0] <= KDTree.BRUTE_FORCE_MAX_QUERIES and
+                (small or (2048 <= self.n <= KDTree.BRUTE_FORCE_MAX_TARGETS and self.n >= 256 * k))):
             return "bruteforce"
         return "bvh"
 
