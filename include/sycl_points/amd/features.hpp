@@ -364,19 +364,58 @@ public:
             if (&source != &output) output = PointCloudShared(source);
             return;
         }
-        flags_->assign(N, REMOVE_FLAG);
         std::vector<size_t> indices(N);
         std::iota(indices.begin(), indices.end(), 0);
         for (size_t i = 0; i < sampling_num; ++i) {
             std::uniform_int_distribution<size_t> dist(i, N - 1);
             std::swap(indices[i], indices[dist(mt_)]);
         }
-        for (size_t i = 0; i < sampling_num; ++i) (*flags_)[indices[i]] = INCLUDE_FLAG;
-        apply_flags(source, output, sampling_num);  // (exactly sampling_num flags are set: the count need not be read back)
+        // The reference sets a flag per drawn index and filters every attribute by the flags: the sample in the cloud's own order.
+        // The same rows by their (sorted) indices: 4 KB up, ONE gather launch for all attributes — no scan of the whole cloud's
+        // flags, no launch per attribute, no count to read back.
+        std::vector<uint32_t> picked(sampling_num);
+        for (size_t i = 0; i < sampling_num; ++i) picked[i] = static_cast<uint32_t>(indices[i]);
+        std::sort(picked.begin(), picked.end());
+        gather_rows(source, output, picked);
     }
     void random_sampling(PointCloudShared& data, size_t sampling_num) { random_sampling(data, data, sampling_num); }
 
 private:
+    /// output = the rows `picked` of every attribute of source (sp_gather_rows_multi)
+    void gather_rows(const PointCloudShared& source, PointCloudShared& output, const std::vector<uint32_t>& picked) {
+        const size_t M = picked.size();
+        PointCloudShared out(queue_);
+        const void* rows[6];
+        void* dst[6];
+        size_t bytes[6];
+        int na = 0;
+        auto add = [&](auto& src_vec, auto& dst_vec) {
+            using T = typename std::remove_reference_t<decltype(src_vec)>::value_type;
+            rows[na] = src_vec.device_data();
+            dst[na] = dst_vec.device_data_for_write(M);
+            bytes[na] = sizeof(T);
+            ++na;
+        };
+        add(*source.points, *out.points);
+        if (source.has_cov()) add(*source.covs, *out.covs);
+        if (source.has_normal()) add(*source.normals, *out.normals);
+        if (source.has_rgb()) add(*source.rgb, *out.rgb);
+        if (source.has_intensity()) add(*source.intensities, *out.intensities);
+        if (source.has_timestamps()) add(*source.timestamp_offsets, *out.timestamp_offsets);
+        hipStream_t st = queue_.stream();
+        size_t got = 0;
+        void* idx = ::sycl_points::detail::DeviceBufferCache::acquire(std::max<size_t>(M, 1) * 4, &got);
+        hipError_t e = hipMemcpyAsync(idx, picked.data(), M * 4, hipMemcpyHostToDevice, st);  // (pageable: staged before the call returns)
+        int rc = SP_OK;
+        if (e == hipSuccess) rc = sp_gather_rows_multi(rows, bytes, dst, na, static_cast<const uint32_t*>(idx), M, st);
+        ::sycl_points::detail::DeviceBufferCache::release(idx, got, st);
+        hip_check(e, "H2D");
+        throw_on_error(rc);
+        const double t0 = source.start_time_ms, t1 = source.end_time_ms;
+        output.points = out.points; output.covs = out.covs; output.normals = out.normals; output.rgb = out.rgb;
+        output.intensities = out.intensities; output.timestamp_offsets = out.timestamp_offsets;
+        output.start_time_ms = t0; output.end_time_ms = t1;
+    }
     void apply_flags(const PointCloudShared& source, PointCloudShared& output, size_t known_count = SIZE_MAX) {
         // FilterByFlags over every attribute the cloud carries (preprocess_operator_base): one scan of the flags, one
         // compaction launch per attribute, written straight into the new containers (no staging copy), ONE count read-back.

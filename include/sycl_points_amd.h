@@ -276,6 +276,14 @@ int sp_compact_by_flags_multi(const void* const* rows, const size_t* row_bytes, 
                               const uint8_t* flags, int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* Rows picked by index, every attribute of a cloud in ONE launch: rows_out[a][j] = rows[a][indices[j]] for j < m (indices:
+ * device memory, uint32). What random sampling is once the host has drawn its sample (preprocess_operator/
+ * random_sampling_operator.hpp:24-51 draws on the host, then filters by flags, common/filter_by_flags.hpp:30-57: with the indices
+ * in ascending order the result is that compaction's, without scanning the flags of the whole cloud per attribute).
+ * n_arrays <= 16, row_bytes[a] a multiple of 4. Only enqueues. */
+int sp_gather_rows_multi(const void* const* rows, const size_t* row_bytes, void* const* rows_out, int n_arrays,
+                         const uint32_t* indices, size_t m, void* stream);
+
 /* ------------------------------------------------------------------------------------- registration */
 
 /* RegType (algorithms/registration/factor.hpp:18-32) and RobustLossType (algorithms/robust/robust.hpp:13-19). */

@@ -20,6 +20,8 @@
 #include <cstring>
 
 
+#include <mutex>
+
 #include "grid_device.h"
 #include "radix_sort.h"
 
@@ -1277,8 +1279,31 @@ __global__ void fill_todo_kernel(unsigned* todo, unsigned* count, unsigned n) {
     if (i == 0) *count = n;
 }
 
+// The work units of the self-kNN tiling (ceil(points in row / 64) per x-row, prefix-summed), made on first use: allocates, and
+// reads their number back (one synchronisation per grid that is ever asked for a self-kNN).
+int ensure_units(const sp_grid* gr, hipStream_t st) {
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (gr->units_ready || gr->n == 0) return SP_OK;
+    const unsigned rows = (unsigned)gr->dims[1] * (unsigned)gr->dims[2];
+    const size_t stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
+    ScratchBuf b_units, b_stmp;
+    hipError_t e = b_units.get((rows + 1) * 4);
+    if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
+    if (e == hipSuccess && gr->d_unit_off == nullptr) e = pooled_alloc(&gr->d_unit_off, (rows + 1) * 4);
+    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(gr->d_start, (unsigned)gr->dims[0], rows, b_units.as<unsigned>());
+    if (exclusive_scan_u32(b_units.as<unsigned>(), gr->d_unit_off, rows + 1, nullptr, b_stmp.p, stmp_bytes, st) != SP_OK) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipMemcpyAsync(&gr->n_units, gr->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the temporaries are idle from here on)
+    if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
+    gr->units_ready = true;
+    return SP_OK;
+}
+
 template <int KCAP>
 int launch_self(const sp_grid* gr, int k, const TileOut& out, hipStream_t st) {
+    if (const int rc = ensure_units(gr, st); rc != SP_OK) return rc;
     const GridDesc g = grid_desc(gr);
     if (zero_async(out.todo_count, 4, st) != SP_OK) return SP_ERR_HIP;
     if (KCAP <= 10 && gr->self_knn_mode == 0 && k <= 7) {  // short lists: lane per point, exact without a to-do pass
@@ -1427,6 +1452,7 @@ extern "C" void sp_grid_destroy(sp_grid* g) {
     sp::pooled_free_after(g->d_pts, g->streams);
     sp::pooled_free_after(g->d_start, g->streams);
     sp::pooled_free_after(g->d_unit_off, g->streams);
+    if (g->built_ev) (void)hipEventDestroy(g->built_ev);  // (an event still pending is released when it completes)
     delete g;
 }
 
@@ -1541,9 +1567,11 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
         ScratchBuf b_units, b_stmp;
         const size_t stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
         e = pooled_alloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = b_units.get((rows + 1) * 4);
-        if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4);
-        if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
+        if (adaptive) {  // (this form of the build ends every attempt with a read-back anyway: the work units ride along)
+            if (e == hipSuccess) e = b_units.get((rows + 1) * 4);
+            if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4);
+            if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
+        }
         unsigned* const units = b_units.as<unsigned>();
         void* const stmp = b_stmp.p;
         if (e == hipSuccess) {
@@ -1560,9 +1588,21 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
             gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
             cell_start_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
                                                                               g->d_start);
+            if (!adaptive) {
+                // Nothing is read back and nothing waited for: the temporaries go to the pool behind the stream's work, an event
+                // marks the end of the build for other streams (grid_use), and the work units of the self-kNN tiling are made
+                // when a self-kNN first asks for them (ensure_units).
+                if (hipEventCreateWithFlags(&g->built_ev, hipEventDisableTiming) != hipSuccess ||
+                    hipEventRecord(g->built_ev, st) != hipSuccess || launch_status() != SP_OK)
+                    return fail(hipErrorUnknown);
+                g->build_stream = st;
+                for (ScratchBuf* b : {&bbox_buf, &b_kin, &b_kout, &b_vin, &b_vout, &b_tmp, &b_stats}) b->release_after(g->streams);
+                break;
+            }
             // work units of the self-kNN tiling: ceil(points in row / 64) per x-row, prefix-summed (same stream: no sync between)
             row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
             if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, stmp, stmp_bytes, st) != SP_OK) e = hipErrorUnknown;
+            g->units_ready = true;
             if (adaptive && e == hipSuccess) {
                 e = zero_async(b_stats.p, 8, st) == SP_OK ? hipSuccess : hipErrorUnknown;
                 cell_stats_kernel<<<std::min(div_up(g->ncells, kBlock), 1024u), kBlock, 0, st>>>(g->d_start, (unsigned)g->ncells,
@@ -1655,7 +1695,7 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     const size_t n = g->n;
     if (n == 0 || n_flags == 0) return SP_OK;
     hipStream_t st = as_stream(stream);
-    g->streams.note(st);
+    grid_use(g, st);
     ScratchBuf b_keep, b_scan, b_tmp, b_units, b_start;
     float4* new_pts = nullptr;
     size_t tmp_bytes = 0, tmp2_bytes = 0;
@@ -1688,8 +1728,10 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     e = hipMemcpyAsync(&kept, scan + n, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(g->d_start, new_start, (g->ncells + 1) * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(e);
+    if (g->d_unit_off == nullptr && (e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4)) != hipSuccess) return fail(e);
     row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
     if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, b_tmp.p, tmp2_bytes, st) != SP_OK) e = hipErrorUnknown;
+    g->units_ready = true;
     if (e == hipSuccess) e = hipMemcpyAsync(&g->n_units, g->d_unit_off + rows, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(e);
@@ -1715,7 +1757,7 @@ __global__ __launch_bounds__(kBlock) void grid_order_kernel(const float4* __rest
 extern "C" int sp_grid_order(const sp_grid* grid, uint32_t* idx_out, void* stream) {
     if (!grid || (!idx_out && grid->n)) return SP_ERR_INVALID_ARGUMENT;
     if (grid->n == 0) return SP_OK;
-    grid->streams.note(sp::as_stream(stream));
+    sp::grid_use(grid, sp::as_stream(stream));
     sp::grid_order_kernel<<<sp::div_up(grid->n, sp::kBlock), sp::kBlock, 0, sp::as_stream(stream)>>>(
         grid->d_pts, (unsigned)grid->n, idx_out);
     return sp::launch_status();
@@ -1734,7 +1776,7 @@ extern "C" int sp_grid_search(const sp_grid* grid, const float* queries, size_t 
     }
     if (nq == 0) return SP_OK;
     hipStream_t st = as_stream(stream);
-    grid->streams.note(st);
+    grid_use(grid, st);
     if (k == 1) return launch<1>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     if (k <= 10) return launch<10>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
     return launch<20>(grid, queries, nq, k, transT, transT_on_device, idx_out, d2_out, st);
@@ -1746,7 +1788,7 @@ namespace sp {
 int grid_search_own_points(const sp_grid* grid, size_t k, int32_t* idx_out, float* d2_out, hipStream_t st, float bound2) {
     if (!grid || k == 0 || k > 10) return SP_ERR_INVALID_ARGUMENT;
     if (grid->n == 0) return SP_OK;
-    grid->streams.note(st);
+    grid_use(grid, st);
     const float* q = reinterpret_cast<const float*>(grid->d_pts);
     if (k == 1) return launch<1>(grid, q, grid->n, k, nullptr, 0, idx_out, d2_out, st, true);
     return launch<10>(grid, q, grid->n, k, nullptr, 0, idx_out, d2_out, st, true, bound2);
@@ -1811,7 +1853,7 @@ extern "C" int sp_grid_self_knn_range(const sp_grid* grid, size_t k, size_t pos_
     out.pos_lo = (unsigned)pos_first;
     out.pos_hi = (unsigned)(pos_first + pos_count);
     hipStream_t st = as_stream(stream);
-    grid->streams.note(st);
+    grid_use(grid, st);
     if (k <= 10) return launch_self<10>(grid, (int)k, out, st);
     return launch_self<20>(grid, (int)k, out, st);
 }
@@ -1865,7 +1907,7 @@ int grid_rows(const sp_grid* grid, const void* in, size_t row_bytes, size_t pos_
         return SP_ERR_INVALID_ARGUMENT;
     }
     if (pos_count == 0) return SP_OK;
-    grid->streams.note(st);
+    grid_use(grid, st);
     const unsigned quads = (unsigned)(row_bytes / 16);
     const size_t total = pos_count * quads;
     if (to_positions)

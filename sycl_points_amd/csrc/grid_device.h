@@ -11,8 +11,16 @@ struct sp_grid {
     size_t ncells = 1;
     float4* d_pts = nullptr;      // n points in cell order, w = original index bits
     uint32_t* d_start = nullptr;  // ncells + 1
-    uint32_t* d_unit_off = nullptr;  // rows + 1: first 64-query work unit of every x-row (self-kNN tiling)
-    uint32_t n_units = 0;
+    // rows + 1: first 64-query work unit of every x-row (self-kNN tiling) and their number. Made when a self-kNN first asks
+    // (ensure_units, grid.hip): a grid built for Registration::align's searches never does — three launches and a read-back less
+    // per build
+    mutable uint32_t* d_unit_off = nullptr;
+    mutable uint32_t n_units = 0;
+    mutable bool units_ready = false;
+    // sp_grid_create returns without waiting for the device (round 5): the build's stream, and an event behind its last kernel
+    // that every OTHER stream waits for before it touches the arrays (grid_use)
+    hipStream_t build_stream = nullptr;
+    hipEvent_t built_ev = nullptr;
     mutable uint32_t max_cell = 0;    // points in the fullest cell, measured on first request (sp_grid_max_cell_points)
     mutable bool max_cell_known = false;
     // tuning switch (sp_internal.h): self-kNN kernel — 0 chosen by k (lane per point for k <= 10, wave-cooperative above),
@@ -23,6 +31,13 @@ struct sp_grid {
 };
 
 namespace sp {
+
+// Every entry point that hands the grid's arrays to a stream: note the stream (sp_grid_destroy tags the pool entries with it)
+// and, when it is not the stream the grid was built on, make it wait for the build.
+inline void grid_use(const sp_grid* g, hipStream_t st) {
+    if (g->built_ev != nullptr && st != g->build_stream) (void)hipStreamWaitEvent(st, g->built_ev, 0);
+    g->streams.note(st);
+}
 
 // grid.hip: kNN of the grid's own cell-ordered points (k <= 10), rows by grid position; enqueues only. bound2 (k > 1): only
 // neighbours closer than this squared distance are looked for, the rest of a row stays padded (-1 / FLT_MAX)

@@ -497,14 +497,15 @@ __global__ __launch_bounds__(kBlock) void query_cell_kernel(const float4* __rest
 // gather_points + prepare_cov for the source in one pass over the permutation
 __global__ __launch_bounds__(kBlock) void prepare_source_kernel(const float4* __restrict__ pts,
                                                                 const float4* __restrict__ covs,
-                                                                const unsigned* __restrict__ order, unsigned n,
+                                                                unsigned* __restrict__ order, bool identity, unsigned n,
                                                                 unsigned stride, float* __restrict__ out_pts,
                                                                 float* __restrict__ out_covp) {
     // Output as planes (x | y | z and xx | xy | xz | yy | yz | zz, `stride` floats apart): the per-iteration kernel is
     // bound by the bytes it streams, and the planes carry 36 bytes per point where float4 rows carry 48.
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const unsigned src = order[i];
+    const unsigned src = identity ? i : order[i];
+    if (identity) order[i] = i;  // (the source is used as it lies: the permutation is written here instead of by a launch of its own)
     const float4 p = pts[src];
     out_pts[i] = p.x; out_pts[stride + i] = p.y; out_pts[2 * (size_t)stride + i] = p.z;
     if (!covs) return;  // point-to-distribution: the covariance planes are never read
@@ -515,10 +516,6 @@ __global__ __launch_bounds__(kBlock) void prepare_source_kernel(const float4* __
     out_covp[3 * (size_t)stride + i] = P.m[1][1];
     out_covp[4 * (size_t)stride + i] = (P.m[1][2] + P.m[2][1]) * 0.5f;
     out_covp[5 * (size_t)stride + i] = P.m[2][2];
-}
-__global__ __launch_bounds__(kBlock) void iota_kernel(unsigned* __restrict__ v, unsigned n) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) v[i] = i;
 }
 
 
@@ -1462,6 +1459,7 @@ extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     if (e == hipSuccess) e = hipMalloc(&s->perm, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->ccache, n * 3 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->opt_rows, sp::kOptRowsBytes);
+    if (e == hipSuccess) e = hipMemset(s->opt_rows, 0, sp::kOptRowsBytes);
     if (e == hipSuccess) e = hipMalloc(&s->keys_in, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->keys_out, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->vals_in, n * 4);
@@ -1515,14 +1513,12 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
             return SP_ERR_HIP;
         }
         if (!in_b) { unsigned* t = s->perm; s->perm = s->vals_in; s->vals_in = t; }  // the sorted permutation is where the last pass wrote
-    } else {
-        iota_kernel<<<nb, kBlock, 0, st>>>(s->perm, (unsigned)n);
     }
     s->cache_valid = false;  // no previous correspondences
     s->cache_target = target;
     s->cache_version = target->version;
     prepare_source_kernel<<<nb, kBlock, 0, st>>>(pts, target->reg_type == SP_REG_GICP ? reinterpret_cast<const float4*>(src_covs) : nullptr,
-                                                 s->perm, (unsigned)n,
+                                                 s->perm, sort_by_cell != SP_SOURCE_SORT, (unsigned)n,
                                                  (unsigned)((n + 63) / 64 * 64), reinterpret_cast<float*>(s->pts),
                                                  reinterpret_cast<float*>(s->covp));
     return launch_status();

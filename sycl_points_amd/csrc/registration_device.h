@@ -715,7 +715,7 @@ struct sp_gicp_target {
     int reg_type = SP_REG_GICP;     // what the rows hold: plane(Ct) for GICP, inverse(Ct) for POINT_TO_DISTRIBUTION
     size_t n = 0;
     mutable sp::StreamSet streams;  // streams the rows (and the borrowed grid) have been used on
-    void note(hipStream_t st) const { streams.note(st); if (grid) grid->streams.note(st); }
+    void note(hipStream_t st) const { streams.note(st); if (grid) sp::grid_use(grid, st); }
 };
 namespace sp {
 // Tagged partial rows of the wave-per-point optimiser launch: 2 (step parity) x kAlignMaxBlocks rows x 32 granules of
@@ -729,6 +729,7 @@ struct sp_gicp_source {
     unsigned* perm = nullptr; // prepared position -> original index
     float4* ccache = nullptr;      // 3 x float4 per prepared point: its previous correspondence (see fused_point)
     unsigned long long* opt_rows = nullptr;  // sp_gicp_align_optimize, wave-per-point launches: tagged partial rows (kOptRowsBytes)
+    mutable unsigned opt_epoch = 0;          // ... and the epoch of the latest such launch (12 bits of every row tag)
     mutable bool cache_valid = false;  // set by the first linearisation after prepare
     const sp_gicp_target* cache_target = nullptr;  // the copies are of this target ...
     unsigned long long cache_version = 0;           // ... at this covariance version

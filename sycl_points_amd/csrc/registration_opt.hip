@@ -47,7 +47,8 @@ struct OptCtl {  // the optimiser's state between steps (LDS, identical in every
 struct OptArgs {
     float* part[2];
     unsigned* tickets;
-    unsigned long long* trows[2];  // WAVEQ: tagged partial rows, by step parity (zero when the launch starts)
+    unsigned long long* trows[2];  // WAVEQ: tagged partial rows, by step parity
+    unsigned tag_base;             // WAVEQ: this launch's epoch << 20 (tags of earlier launches never match: no zeroing per launch)
     const float* T_init;          // device: initial guess
     float* T_out;                 // device: final pose (may alias T_init: it is read before anything is written)
     sp_opt_params opt;
@@ -257,7 +258,8 @@ __device__ __forceinline__ void opt_publish(float* T_out, const OptShared& S) {
 // costs more than the step). Here a row is 32 granules {value, tag = step + 1} and each granule travels in ONE 8-byte store
 // (the exchange slots' trick, comm.hip): a reader polls the rows themselves, every lane its share of granules, all loads of a
 // round in flight together; a round in which every tag matches IS the data. Rows ping-pong by step parity as the counter form's
-// do; the buffer is zero when the launch starts (tags start at 1).
+// do. A tag is (epoch of the launch) << 20 | (step + 1) mod 2^20: the buffer is zeroed when the source is created and when the
+// 12-bit epoch wraps, never per launch (a row is rewritten by its owner every second step, so a stale tag is at most two steps old).
 // Sums in a fixed order (lane (group, slot): rows group, group + G, ... in order; then the groups in order): the same bits in
 // every workgroup. On return red[0][e] holds the totals (slot nv the uint32 count); false: the wait ran out.
 template <int BLOCK>
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
                 __syncthreads();
                 if (threadIdx.x < 32) red[0][threadIdx.x] = mine;
                 __syncthreads();
-            } else if (!tagged_rows_exchange<BLOCK>(A.trows[step & 1], step + 1u, mine, gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1,
+            } else if (!tagged_rows_exchange<BLOCK>(A.trows[step & 1], A.tag_base | ((step + 1u) & 0xfffffu), mine, gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1,
                                                     red, A.budget, &s_wait)) {
                 wait_ran_out();
                 return;
@@ -582,8 +584,15 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     A.tickets = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kTicketOffsetBytes);
     A.trows[0] = source->opt_rows;
     A.trows[1] = source->opt_rows + (size_t)kAlignMaxBlocks * 32;
+    A.tag_base = 0;
     if (grid > 1 && waveq) {
-        if (zero_async(source->opt_rows, kOptRowsBytes, st) != SP_OK) return SP_ERR_HIP;
+        // a row's tag is (epoch of the launch, step): rows left by earlier launches never match, so nothing is zeroed per launch —
+        // only when the 12-bit epoch wraps (the buffer is zero when the source is created)
+        if (++source->opt_epoch >= 4096u) {
+            if (zero_async(source->opt_rows, kOptRowsBytes, st) != SP_OK) return SP_ERR_HIP;
+            source->opt_epoch = 1;
+        }
+        A.tag_base = source->opt_epoch << 20;
     } else if (grid > 1 && zero_async(A.tickets, kTicketShards * kTicketStride * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
     target->note(st);
     FusedParams P = make_fused_params(target, source, params, transT_device, 1, nullptr, nullptr);

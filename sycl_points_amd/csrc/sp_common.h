@@ -80,6 +80,8 @@ struct ScratchBuf {  // RAII handle
     hipError_t get(size_t bytes) { return scratch_acquire(&p, bytes); }
     template <class T> T* as() const { return static_cast<T*>(p); }
     ~ScratchBuf() { if (p) scratch_release(p); }
+    /// hand the buffer back while work on `streams` may still use it (the pool waits for their events before reuse)
+    void release_after(const StreamSet& streams) { if (p) { scratch_release_after(p, streams); p = nullptr; } }
     ScratchBuf() = default;
     ScratchBuf(const ScratchBuf&) = delete;
     ScratchBuf& operator=(const ScratchBuf&) = delete;

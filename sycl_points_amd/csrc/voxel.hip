@@ -606,6 +606,53 @@ extern "C" int sp_box_filter_flags(const float* points, size_t n, float min_dist
     return launch_status();
 }
 
+namespace sp {
+namespace {
+struct GatherArrays {
+    const uint32_t* src[16];
+    uint32_t* dst[16];
+    unsigned words[16];   // 32-bit words per row
+    unsigned first[17];   // prefix sums of words: one output element = first[n_arrays] words
+    int n_arrays;
+};
+// out row j of every array = row indices[j] of its source: one lane per 32-bit word of the output
+__global__ __launch_bounds__(kBlock) void gather_rows_multi_kernel(GatherArrays A, const uint32_t* __restrict__ indices, unsigned m) {
+    const unsigned per = A.first[A.n_arrays];
+    const size_t total = (size_t)m * per;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const unsigned j = (unsigned)(t / per), w = (unsigned)(t % per);
+        int a = 0;
+        while (w >= A.first[a + 1]) ++a;
+        const unsigned k = w - A.first[a];
+        A.dst[a][(size_t)j * A.words[a] + k] = A.src[a][(size_t)indices[j] * A.words[a] + k];
+    }
+}
+}  // namespace
+}  // namespace sp
+
+extern "C" int sp_gather_rows_multi(const void* const* rows, const size_t* row_bytes, void* const* rows_out, int n_arrays,
+                                    const uint32_t* indices, size_t m, void* stream) {
+    using namespace sp;
+    if (n_arrays < 1 || n_arrays > 16 || !rows || !row_bytes || !rows_out || (!indices && m)) return SP_ERR_INVALID_ARGUMENT;
+    if (m == 0) return SP_OK;
+    GatherArrays A;
+    A.n_arrays = n_arrays;
+    A.first[0] = 0;
+    for (int a = 0; a < n_arrays; ++a) {
+        if (row_bytes[a] % 4 != 0 || row_bytes[a] == 0 || m >= (1ull << 30)) {
+            sp_set_error("[gather_rows] row_bytes must be a positive multiple of 4 and m < 2^30");
+            return SP_ERR_INVALID_ARGUMENT;
+        }
+        A.src[a] = static_cast<const uint32_t*>(rows[a]);
+        A.dst[a] = static_cast<uint32_t*>(rows_out[a]);
+        A.words[a] = (unsigned)(row_bytes[a] / 4);
+        A.first[a + 1] = A.first[a] + A.words[a];
+    }
+    const size_t total = m * A.first[n_arrays];
+    gather_rows_multi_kernel<<<(unsigned)std::min<size_t>(div_up(total, kBlock), 4096), kBlock, 0, as_stream(stream)>>>(A, indices, (unsigned)m);
+    return launch_status();
+}
+
 extern "C" size_t sp_compact_workspace_bytes(size_t n) {
     if (n == 0) return 0;
     return sp::align_up(n * 4) * 2 + sp::align_up(sp::exclusive_scan_u32_workspace_bytes(n));
