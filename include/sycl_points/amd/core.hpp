@@ -164,12 +164,18 @@ struct DeviceBufferCache {
         void* p;
         size_t bytes;
         int device;
-        std::vector<hipEvent_t> ready;  // empty: idle already
+        // owner != nullptr: every use of the buffer was enqueued on this stream and no other queue exists that could have read
+        // it — work enqueued on the SAME stream later needs no wait at all (round 5: the common case, one queue per process; an
+        // event per released buffer was 2 us of host time, fifty times per loop of the reference's example)
+        hipStream_t owner;
+        std::vector<hipEvent_t> ready;  // otherwise: one event per stream that may still use it; empty: idle already
     };
-    static void* acquire(size_t bytes, size_t* got) {
+    /// `stream`: the stream the caller will use the buffer on (nullptr: unknown — any stream, or the host).
+    static void* acquire(size_t bytes, size_t* got, hipStream_t stream = nullptr) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::vector<hipEvent_t> wait_for;
+        hipStream_t wait_stream = nullptr;
         void* taken = nullptr;
         {
             std::lock_guard<std::mutex> lock(mutex());
@@ -178,7 +184,8 @@ struct DeviceBufferCache {
             for (size_t i = 0; i < pool.size(); ++i) {
                 Entry& e = pool[i];
                 if (e.device != dev || e.bytes < bytes || e.bytes > 2 * bytes + 4096) continue;
-                if (settle(e)) {
+                const bool free_now = (e.owner != nullptr && stream != nullptr && e.owner == stream) || settle(e);
+                if (free_now) {
                     if (best == pool.size() || e.bytes < pool[best].bytes) best = i;
                 } else if (best_busy == pool.size() || e.bytes < pool[best_busy].bytes) {
                     best_busy = i;  // its last user is still running
@@ -192,11 +199,13 @@ struct DeviceBufferCache {
                 taken = pool[pick].p;
                 *got = pool[pick].bytes;
                 wait_for.swap(pool[pick].ready);
+                if (pool[pick].owner != nullptr && pool[pick].owner != stream) wait_stream = pool[pick].owner;
                 total() -= pool[pick].bytes;
                 pool.erase(pool.begin() + (std::ptrdiff_t)pick);
             }
         }
         if (taken) {
+            if (wait_stream) (void)hipStreamSynchronize(wait_stream);  // (another stream, or the host, takes over: wait for the owner's work)
             for (hipEvent_t ev : wait_for) {
                 (void)hipEventSynchronize(ev);
                 (void)hipEventDestroy(ev);
@@ -212,22 +221,26 @@ struct DeviceBufferCache {
     /// knows the device is done with the buffer (it synchronised).
     static void release(void* p, size_t bytes, hipStream_t stream, bool idle = false) {
         if (!p) return;
-        Entry e{p, bytes, 0, {}};
+        Entry e{p, bytes, 0, nullptr, {}};
         (void)hipGetDevice(&e.device);
         if (!idle) {
             std::vector<hipStream_t> streams = QueueStreams::others(stream, e.device);
-            streams.insert(streams.begin(), stream);
-            for (hipStream_t s : streams) {
-                hipEvent_t ev = nullptr;
-                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
-                    if (ev) (void)hipEventDestroy(ev);
-                    for (hipEvent_t done : e.ready) (void)hipEventDestroy(done);
-                    e.ready.clear();
-                    (void)hipGetLastError();
-                    (void)hipDeviceSynchronize();  // no event to be had: wait, as hipFree would
-                    break;
+            if (streams.empty() && stream != nullptr) {
+                e.owner = stream;  // one queue: stream order is all the protection the buffer needs
+            } else {
+                streams.insert(streams.begin(), stream);
+                for (hipStream_t s : streams) {
+                    hipEvent_t ev = nullptr;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
+                        if (ev) (void)hipEventDestroy(ev);
+                        for (hipEvent_t done : e.ready) (void)hipEventDestroy(done);
+                        e.ready.clear();
+                        (void)hipGetLastError();
+                        (void)hipDeviceSynchronize();  // no event to be had: wait, as hipFree would
+                        break;
+                    }
+                    e.ready.push_back(ev);
                 }
-                e.ready.push_back(ev);
             }
         }
         std::vector<void*> drop;
@@ -248,9 +261,26 @@ struct DeviceBufferCache {
         }
         for (void* d : drop) (void)hipFree(d);
     }
+    /// A queue's stream is about to be destroyed: buffers tagged with it wait for it once and are idle from then on.
+    static void forget_stream(hipStream_t s) {
+        bool any = false;
+        {
+            std::lock_guard<std::mutex> lock(mutex());
+            for (Entry& e : buffers()) any = any || e.owner == s;
+        }
+        if (!any) return;
+        (void)hipStreamSynchronize(s);
+        std::lock_guard<std::mutex> lock(mutex());
+        for (Entry& e : buffers())
+            if (e.owner == s) e.owner = nullptr;
+    }
 
 private:
     static bool settle(Entry& e) {  // true once nothing on the device uses the buffer any more
+        if (e.owner != nullptr) {
+            if (hipStreamQuery(e.owner) != hipSuccess) { (void)hipGetLastError(); return false; }
+            e.owner = nullptr;
+        }
         while (!e.ready.empty()) {
             if (hipEventQuery(e.ready.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
             (void)hipEventDestroy(e.ready.back());
@@ -458,6 +488,7 @@ struct DeviceQueue {
         ~StreamHolder() {
             if (stream) {
                 detail::QueueStreams::remove(stream);
+                detail::DeviceBufferCache::forget_stream(stream);
                 (void)hipStreamDestroy(stream);
             }
         }
@@ -670,7 +701,7 @@ private:
     void ensure_capacity(size_t n) const {
         if (n <= dev_cap_) return;
         size_t got = 0;
-        T* nd = static_cast<T*>(detail::DeviceBufferCache::acquire(std::max<size_t>(n, 1) * sizeof(T), &got));
+        T* nd = static_cast<T*>(detail::DeviceBufferCache::acquire(std::max<size_t>(n, 1) * sizeof(T), &got, stream()));
         if (dev_) {
             if (dev_dirty_ && dev_size_)  // (in stream order behind the kernels that wrote the old buffer)
                 hip_check(hipMemcpyAsync(nd, dev_, std::min(dev_size_, n) * sizeof(T), hipMemcpyDeviceToDevice, stream()), "hipMemcpy");

@@ -27,8 +27,9 @@ namespace detail {
 struct DeviceScratch {
     void* p = nullptr;
     size_t bytes = 0;
-    explicit DeviceScratch(size_t n) {
-        if (n) p = ::sycl_points::detail::DeviceBufferCache::acquire(n, &bytes);
+    /// st: the stream the scratch will be used on (a buffer last used on the same stream is taken without waiting)
+    explicit DeviceScratch(size_t n, hipStream_t st = nullptr) {
+        if (n) p = ::sycl_points::detail::DeviceBufferCache::acquire(n, &bytes, st);
     }
     ~DeviceScratch() {
         if (!p) return;
@@ -41,6 +42,15 @@ struct DeviceScratch {
 // One 4-byte read-back through pinned memory (a copy into pageable memory is staged and blocks inside the runtime).
 inline void* pinned_word() {
     static void* p = [] { void* q = nullptr; hip_check(hipHostMalloc(&q, 64), "hipHostMalloc"); return q; }();
+    return p;
+}
+/// 4 KB of pinned host memory per host thread for read-backs of a few hundred bytes (nullptr: none to be had)
+inline void* pinned_block_4k() {
+    thread_local void* p = [] {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 4096, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+        return q;
+    }();
     return p;
 }
 inline uint32_t read_u32(const void* dev, hipStream_t st) {
@@ -223,10 +233,12 @@ private:
         const size_t ws_bytes = sp_voxel_downsample_workspace_bytes(N);
         // voxel count | boxed-path status | key box of sp_voxel_key_box (6 ints) | this cloud's key box, sharded
         constexpr int kInfoInts = 32 + SP_VOXEL_BOX_SHARD_STRIDE * SP_VOXEL_BOX_SHARDS;
-        detail::DeviceScratch ws(ws_bytes), info(kInfoInts * 4);
         hipStream_t st = queue_.stream();
+        detail::DeviceScratch ws(ws_bytes, st), info(kInfoInts * 4, st);
         uint32_t* info_dev = static_cast<uint32_t*>(info.p);
-        int32_t h[kInfoInts];
+        static_assert(kInfoInts * 4 <= 4096, "pinned block");
+        int32_t h_own[kInfoInts];
+        int32_t* const h = detail::pinned_block_4k() ? static_cast<int32_t*>(detail::pinned_block_4k()) : h_own;  // (read-backs by DMA)
         // The sort runs on keys compressed to the (widened) key box of the PREVIOUS cloud — scans of one sensor have similar
         // extents; the device verifies that this cloud fits, and the key kernel finds this cloud's own box on the way (next
         // call's guess; the exact box of the redo when the cloud did not fit). The first call has no guess and computes the
@@ -239,7 +251,7 @@ private:
                 rgb ? reinterpret_cast<float*>(out_rgb->device_data_for_write(N)) : nullptr,
                 inten ? out_inten->device_data_for_write(N) : nullptr, ts ? out_ts->device_data_for_write(N) : nullptr, nullptr,
                 info_dev, box, info_dev + 1, reinterpret_cast<int32_t*>(info_dev + 32), ws.p, ws_bytes, st));
-            hip_check(hipMemcpyAsync(h, info.p, sizeof h, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipMemcpyAsync(h, info.p, kInfoInts * 4, hipMemcpyDeviceToHost, st), "D2H");
             hip_check(hipStreamSynchronize(st), "sync");
             for (int a = 0; a < 3; ++a) {  // fold the shards into h[2..7]
                 h[2 + a] = INT32_MAX; h[5 + a] = INT32_MIN;
@@ -308,8 +320,8 @@ public:
         const size_t N = source.size();
         if (N == 0) return;
         const size_t ws_bytes = sp_compact_workspace_bytes(N);
-        detail::DeviceScratch ws(ws_bytes), count(4), tmp(N * sizeof(T));
         hipStream_t st = queue_.stream();
+        detail::DeviceScratch ws(ws_bytes, st), count(4, st), tmp(N * sizeof(T), st);
         throw_on_error(sp_compact_by_flags(source.device_data(), N, sizeof(T), flags.device_data(), tmp.p, nullptr,
                                            static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
         const size_t M = detail::read_u32(count.p, st);
@@ -325,7 +337,7 @@ public:
         const size_t N = flags.size();
         if (N == 0) return;
         const size_t ws_bytes = sp_compact_workspace_bytes(N);
-        detail::DeviceScratch ws(ws_bytes), count(4);
+        detail::DeviceScratch ws(ws_bytes, queue_.stream()), count(4, queue_.stream());
         throw_on_error(sp_compact_by_flags(flags.device_data(), N, 0 + 4 * 0 + 4, flags.device_data(), nullptr,
                                            indices.device_data_for_write(N), static_cast<uint32_t*>(count.p), ws.p, ws_bytes,
                                            queue_.stream()));
@@ -404,7 +416,7 @@ private:
         if (source.has_timestamps()) add(*source.timestamp_offsets, *out.timestamp_offsets);
         hipStream_t st = queue_.stream();
         size_t got = 0;
-        void* idx = ::sycl_points::detail::DeviceBufferCache::acquire(std::max<size_t>(M, 1) * 4, &got);
+        void* idx = ::sycl_points::detail::DeviceBufferCache::acquire(std::max<size_t>(M, 1) * 4, &got, st);
         hipError_t e = hipMemcpyAsync(idx, picked.data(), M * 4, hipMemcpyHostToDevice, st);  // (pageable: staged before the call returns)
         int rc = SP_OK;
         if (e == hipSuccess) rc = sp_gather_rows_multi(rows, bytes, dst, na, static_cast<const uint32_t*>(idx), M, st);
@@ -444,13 +456,13 @@ private:
         // (with a known count nothing synchronises here: the scratch goes back tagged with the stream's event instead of idle)
         struct Scratch {
             void* p = nullptr; size_t bytes = 0; hipStream_t* tag;
-            Scratch(size_t n, hipStream_t* t) : tag(t) { if (n) p = ::sycl_points::detail::DeviceBufferCache::acquire(n, &bytes); }
+            Scratch(size_t n, hipStream_t* t, hipStream_t use) : tag(t) { if (n) p = ::sycl_points::detail::DeviceBufferCache::acquire(n, &bytes, use); }
             ~Scratch() {
                 if (!p) return;
                 if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();  // (left by an exception: nothing was waited for)
                 ::sycl_points::detail::DeviceBufferCache::release(p, bytes, *tag, *tag == nullptr);
             }
-        } ws(ws_bytes, &ws_release_stream), count(4, &ws_release_stream);
+        } ws(ws_bytes, &ws_release_stream, st), count(4, &ws_release_stream, st);
         throw_on_error(sp_compact_by_flags_multi(rows, bytes, dst, na, N, flags_->device_data(), nullptr,
                                                  static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
         size_t M = known_count;

@@ -96,7 +96,7 @@ inline KNNResult knn_search_bruteforce(const sycl_utils::DeviceQueue& queue, con
     const size_t ws_bytes = sp_knn_bruteforce_workspace_bytes(nq, nt, k);
     void* ws = nullptr;
     size_t ws_got = 0;
-    if (ws_bytes) ws = sycl_points::detail::DeviceBufferCache::acquire(ws_bytes, &ws_got);  // (no hipMalloc / hipFree per call)
+    if (ws_bytes) ws = sycl_points::detail::DeviceBufferCache::acquire(ws_bytes, &ws_got, queue.stream());  // (no hipMalloc / hipFree per call)
     const int rc = sp_knn_bruteforce(queries.points_device(), nq, targets.points_device(), nt, k,
                                      result.indices->device_data_for_write(nq * k),
                                      result.distances->device_data_for_write(nq * k), ws, ws_bytes, queue.stream());
@@ -196,7 +196,7 @@ public:
             // grid of its own) — never does: half a millisecond per million points and tree saved.
             t->hierarchy_ = true;
             size_t got = 0;
-            t->dev_points_ = sycl_points::detail::DeviceBufferCache::acquire(points.size() * 16, &got);
+            t->dev_points_ = sycl_points::detail::DeviceBufferCache::acquire(points.size() * 16, &got, q.stream());
             t->dev_points_bytes_ = got;
             hip_check(hipMemcpyAsync(t->dev_points_, points.device_data(), points.size() * 16, hipMemcpyDeviceToDevice, q.stream()), "D2D");
         }
@@ -245,7 +245,7 @@ public:
             const size_t ws_bytes = sp_knn_bruteforce_workspace_bytes(nq, size_, k);
             void* ws = nullptr;
             size_t ws_got = 0;
-            if (ws_bytes) ws = sycl_points::detail::DeviceBufferCache::acquire(ws_bytes, &ws_got);
+            if (ws_bytes) ws = sycl_points::detail::DeviceBufferCache::acquire(ws_bytes, &ws_got, queue.stream());
             const int rc = sp_knn_bruteforce(queries.points_device(), nq, device_points(), size_, k,
                                              result.indices->device_data_for_write(nq * k),
                                              result.distances->device_data_for_write(nq * k), ws, ws_bytes, queue.stream());
@@ -366,7 +366,7 @@ private:
                     self_grid_ = nullptr;
                 } else {
                     // (from the facade's buffer cache: hipMalloc / hipFree cost 0.1-0.2 ms apiece, per tree and frame)
-                    self_grid_ws_ = sycl_points::detail::DeviceBufferCache::acquire(sp_grid_self_workspace_bytes(self_grid_), &self_grid_ws_bytes_);
+                    self_grid_ws_ = sycl_points::detail::DeviceBufferCache::acquire(sp_grid_self_workspace_bytes(self_grid_), &self_grid_ws_bytes_, queue.stream());
                 }
             }
         }

@@ -18,6 +18,17 @@ std::once_flag g_err_once;
 unsigned* g_err_host = nullptr;  // pinned, mapped
 unsigned* g_err_dev = nullptr;
 }  // namespace
+void* pinned_mailbox() {
+    // 256 bytes of pinned host memory per host thread, for the few words a build reads back (bounding box, counts): a copy into
+    // pageable memory is staged inside the runtime call (20 us for 24 bytes on this stack); nullptr when pinned memory is not to
+    // be had (the caller then reads into its own variable). Never freed: the HIP runtime may be gone when a thread ends.
+    thread_local void* p = [] {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 256, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+        return q;
+    }();
+    return p;
+}
 unsigned* device_error_word() {
     std::call_once(g_err_once, [] {
         void* h = nullptr;

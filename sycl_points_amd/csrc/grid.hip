@@ -1489,11 +1489,12 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
     if ((e = bbox_buf.get(6 * sizeof(unsigned))) != hipSuccess) return fail(e);
     unsigned* const d_bbox = bbox_buf.as<unsigned>();
     const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    unsigned h_bbox[6];
+    unsigned h_bbox_own[6];
+    unsigned* const h_bbox = pinned_mailbox() ? static_cast<unsigned*>(pinned_mailbox()) : h_bbox_own;
     e = hipMemcpyAsync(d_bbox, init, sizeof init, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         bbox_kernel<<<std::min(stream_grid(n, kBlock, 4), 256u), kBlock, 0, st>>>(pts, (unsigned)n, d_bbox);  // (1024 workgroups: 26 us — their 6 atomics each share one cache line)
-        e = hipMemcpyAsync(h_bbox, d_bbox, sizeof h_bbox, hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(h_bbox, d_bbox, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(e);

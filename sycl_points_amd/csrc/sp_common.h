@@ -49,6 +49,7 @@ int zero_async(void* p, size_t bytes, hipStream_t st);  // capi_common.hip; retu
 // pool through pooled_alloc / pooled_free: their destroy waits for the device to go idle (what hipFree does implicitly)
 // before the buffers are offered to the next build.
 hipError_t scratch_acquire(void** ptr, size_t bytes);  // capi_common.hip
+void* pinned_mailbox();  // capi_common.hip: 256 bytes of pinned host memory per host thread (nullptr: none), for small read-backs
 void scratch_release(void* ptr);
 template <class T> hipError_t pooled_alloc(T** ptr, size_t bytes) { return scratch_acquire(reinterpret_cast<void**>(ptr), bytes); }
 inline void pooled_free(void* ptr) { if (ptr) scratch_release(ptr); }  // caller: nothing on the device still uses ptr
