@@ -144,6 +144,12 @@ struct QueueStreams {  // the live DeviceQueue streams of the process
         for (size_t i = 0; i < l.size(); ++i)
             if (l[i].first == s) { l.erase(l.begin() + (std::ptrdiff_t)i); break; }
     }
+    static bool is_live(hipStream_t s) {
+        std::lock_guard<std::mutex> lock(mutex());
+        for (const auto& e : list())
+            if (e.first == s) return true;
+        return false;
+    }
     static std::vector<hipStream_t> others(hipStream_t own, int device) {
         std::lock_guard<std::mutex> lock(mutex());
         std::vector<hipStream_t> out;
@@ -225,7 +231,7 @@ struct DeviceBufferCache {
         (void)hipGetDevice(&e.device);
         if (!idle) {
             std::vector<hipStream_t> streams = QueueStreams::others(stream, e.device);
-            if (streams.empty() && stream != nullptr) {
+            if (streams.empty() && stream != nullptr && QueueStreams::is_live(stream)) {  // (a queue's own stream: its end is announced)
                 e.owner = stream;  // one queue: stream order is all the protection the buffer needs
             } else {
                 streams.insert(streams.begin(), stream);
@@ -278,7 +284,8 @@ struct DeviceBufferCache {
 private:
     static bool settle(Entry& e) {  // true once nothing on the device uses the buffer any more
         if (e.owner != nullptr) {
-            if (hipStreamQuery(e.owner) != hipSuccess) { (void)hipGetLastError(); return false; }
+            // (a stream that is no longer registered has been destroyed — which waited for its work; never query a dead handle)
+            if (QueueStreams::is_live(e.owner) && hipStreamQuery(e.owner) != hipSuccess) { (void)hipGetLastError(); return false; }
             e.owner = nullptr;
         }
         while (!e.ready.empty()) {
@@ -489,6 +496,7 @@ struct DeviceQueue {
             if (stream) {
                 detail::QueueStreams::remove(stream);
                 detail::DeviceBufferCache::forget_stream(stream);
+                sp_stream_retired(stream);  // (the library's own pool tags buffers with the stream too)
                 (void)hipStreamDestroy(stream);
             }
         }

@@ -34,6 +34,12 @@ extern "C" {
 
 #define SP_ABI_VERSION 5
 int sp_abi_version(void);
+/* The library keeps device buffers it no longer needs (temporaries of a build, the arrays of a destroyed grid / tree / target) in
+ * a pool, tagged with the stream whose work may still use them: a later call on the SAME stream takes them without waiting (stream
+ * order), nobody else does. A caller that is about to destroy a stream it has passed to the library calls this first (the
+ * facade's DeviceQueue does): it waits for the stream and clears its tags. Without it such buffers stay out of use until the
+ * pool's sweep (a device-wide wait once 32 of them have piled up). */
+void sp_stream_retired(void* stream);
 const char* sp_last_error(void);
 
 /* Number of devices visible / select the device for the calling thread (utils/sycl_utils.hpp:398-465). */

@@ -87,6 +87,7 @@ _vp, _sz, _f, _i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
 # name -> (restype, argtypes); every symbol include/sycl_points_amd.h declares
 SIGNATURES = {
     "sp_abi_version": (_i, []),
+    "sp_stream_retired": (None, [_vp]),
     "sp_last_error": (C.c_char_p, []),
     "sp_device_count": (_i, []),
     "sp_set_device": (_i, [_i]),

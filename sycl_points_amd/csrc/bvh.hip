@@ -733,7 +733,7 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         // heap kernel; what it hands on (non-finite queries, a tree deeper than its stack) is finished by the sorted-insertion kernel
         unsigned* todo = nullptr;
         // (+ the deep part of the walk's stack: [slot][query], written by the few lanes that get there)
-        if (pooled_alloc(&todo, ((size_t)nq * (1 + kHeapStackDeep) + 1) * sizeof(unsigned)) != hipSuccess) return SP_ERR_HIP;
+        if (pooled_alloc(&todo, ((size_t)nq * (1 + kHeapStackDeep) + 1) * sizeof(unsigned), st) != hipSuccess) return SP_ERR_HIP;
         unsigned* const todo_count = todo + nq;
         unsigned* const deep = todo + nq + 1;
         int rc = zero_async(todo_count, 4, st);
@@ -744,7 +744,7 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
         if (rc == SP_OK && q && nq >= 400000u && b->sort_queries) {
             const size_t wsb = radix_sort_u64_workspace_bytes(nq);
             const size_t words = 6 * (size_t)nq + (wsb + 3) / 4 + 2;
-            if (pooled_alloc(&sortbuf, words * sizeof(uint32_t)) != hipSuccess) { rc = SP_ERR_HIP; }
+            if (pooled_alloc(&sortbuf, words * sizeof(uint32_t), st) != hipSuccess) { rc = SP_ERR_HIP; }
             else {
                 uint64_t *ka = reinterpret_cast<uint64_t*>(sortbuf), *kb = ka + nq;
                 uint32_t *va = reinterpret_cast<uint32_t*>(kb + nq), *vb = va + nq;
@@ -826,19 +826,19 @@ extern "C" int sp_bvh_create(const float* points, size_t n, void* stream, sp_bvh
     const size_t ni = n > 1 ? n - 1 : 1;  // internal nodes
     ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp, b_parent, b_lparent, b_tickets, b_cmin;
     const size_t tmp_bytes = radix_sort_u64_workspace_bytes(n ? n : 1);
-    hipError_t e = pooled_alloc(&b->pts, (n ? n : 1) * sizeof(float4));
-    if (e == hipSuccess) e = pooled_alloc(&b->node, 4 * ni * sizeof(float4));
-    if (e == hipSuccess) e = pooled_alloc(&b->obox, 2 * ni * sizeof(float4));
-    if (e == hipSuccess) e = pooled_alloc(&b->bbox, 8 * sizeof(unsigned));
-    if (e == hipSuccess && n) e = b_kin.get(n * 8);
-    if (e == hipSuccess && n) e = b_kout.get(n * 8);
-    if (e == hipSuccess && n) e = b_vin.get(n * 4);
-    if (e == hipSuccess && n) e = b_vout.get(n * 4);
-    if (e == hipSuccess && n) e = b_tmp.get(tmp_bytes);
-    if (e == hipSuccess && n) e = b_parent.get(ni * 4);
-    if (e == hipSuccess && n) e = b_lparent.get(n * 4);
-    if (e == hipSuccess && n) e = b_tickets.get(ni * 4);
-    if (e == hipSuccess && n) e = b_cmin.get(2 * ni * 4);
+    hipError_t e = pooled_alloc(&b->pts, (n ? n : 1) * sizeof(float4), st);
+    if (e == hipSuccess) e = pooled_alloc(&b->node, 4 * ni * sizeof(float4), st);
+    if (e == hipSuccess) e = pooled_alloc(&b->obox, 2 * ni * sizeof(float4), st);
+    if (e == hipSuccess) e = pooled_alloc(&b->bbox, 8 * sizeof(unsigned), st);
+    if (e == hipSuccess && n) e = b_kin.get(n * 8, st);
+    if (e == hipSuccess && n) e = b_kout.get(n * 8, st);
+    if (e == hipSuccess && n) e = b_vin.get(n * 4, st);
+    if (e == hipSuccess && n) e = b_vout.get(n * 4, st);
+    if (e == hipSuccess && n) e = b_tmp.get(tmp_bytes, st);
+    if (e == hipSuccess && n) e = b_parent.get(ni * 4, st);
+    if (e == hipSuccess && n) e = b_lparent.get(n * 4, st);
+    if (e == hipSuccess && n) e = b_tickets.get(ni * 4, st);
+    if (e == hipSuccess && n) e = b_cmin.get(2 * ni * 4, st);
     auto fail = [&](const char* msg) {
         sp_set_error(msg);
         (void)hipStreamSynchronize(st);
@@ -908,9 +908,9 @@ extern "C" int sp_bvh_remove_by_flags(sp_bvh* bvh, const uint8_t* flags, const i
     bvh->streams.note(st);
     ScratchBuf b_f, b_pre, b_ws;
     const size_t wsb = exclusive_scan_u32_workspace_bytes(n_flags);
-    hipError_t e = b_f.get(n_flags * 4);
-    if (e == hipSuccess) e = b_pre.get(n_flags * 4);
-    if (e == hipSuccess) e = b_ws.get(wsb ? wsb : 16);
+    hipError_t e = b_f.get(n_flags * 4, st);
+    if (e == hipSuccess) e = b_pre.get(n_flags * 4, st);
+    if (e == hipSuccess) e = b_ws.get(wsb ? wsb : 16, st);
     if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
     bvh_flags_to_u32_kernel<<<div_up(n_flags, kBlock), kBlock, 0, st>>>(flags, (unsigned)n_flags, b_f.as<uint32_t>());
     if (exclusive_scan_u32(b_f.as<uint32_t>(), b_pre.as<uint32_t>(), n_flags, nullptr, b_ws.p, wsb, st) != SP_OK) {

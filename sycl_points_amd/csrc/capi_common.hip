@@ -63,9 +63,15 @@ namespace {
 struct PoolEntry {
     void* p; size_t bytes; int device; bool busy;
     std::vector<hipEvent_t> pending;  // work that may still touch p (scratch_release_after); empty: idle
+    // released behind the work of exactly ONE stream: no event is recorded (2 us of host time per buffer) — a caller that will
+    // use the buffer on the same stream takes it at once (stream order), anyone else once the stream has drained
+    hipStream_t owner = nullptr;
 };
-// true once every pending event has completed (they are destroyed then); never blocks
+// true once every pending event has completed (they are destroyed then) / the owner's stream has drained; never blocks
 bool entry_idle(PoolEntry& e) {
+    // (an owner's stream is never queried: the caller may have destroyed it since — a query of a dead handle crashes inside the
+    // runtime. Such an entry waits for its own stream to ask again, for sp_stream_retired, or for the sweep in scratch_acquire)
+    if (e.owner != nullptr) return false;
     while (!e.pending.empty()) {
         if (hipEventQuery(e.pending.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
         (void)hipEventDestroy(e.pending.back());
@@ -77,6 +83,7 @@ std::mutex g_pool_mutex;
 std::vector<PoolEntry> g_pool;
 std::vector<void*> g_to_free;  // surplus buffers: freed by the next scratch_acquire (an allocating call), never by a release
 constexpr size_t kKeep = 24;
+constexpr size_t kForeignMax = 32;
 constexpr size_t kKeepBytes = size_t(4) << 30;  // idle bytes kept per device
 }  // namespace
 
@@ -106,7 +113,7 @@ int zero_async(void* p, size_t bytes, hipStream_t st) {
     return launch_status();
 }
 
-hipError_t scratch_acquire(void** ptr, size_t bytes) {
+hipError_t scratch_acquire(void** ptr, size_t bytes, hipStream_t st) {
     *ptr = nullptr;
     if (bytes < 256) bytes = 256;
     int dev = 0;
@@ -129,7 +136,7 @@ hipError_t scratch_acquire(void** ptr, size_t bytes) {
             size_t k = g_pool.size();
             for (size_t i = 0; i < g_pool.size(); ++i) {
                 const PoolEntry& e = g_pool[i];
-                if (e.busy || e.device != dev || !e.pending.empty()) continue;
+                if (e.busy || e.device != dev || !e.pending.empty() || e.owner != nullptr) continue;
                 const bool smaller = k == g_pool.size() || e.bytes < g_pool[k].bytes;
                 // over the byte budget only: drop the LARGEST idle buffer (the smallest would not bring the total down)
                 const bool larger = k == g_pool.size() || e.bytes > g_pool[k].bytes;
@@ -141,12 +148,22 @@ hipError_t scratch_acquire(void** ptr, size_t bytes) {
             idle_bytes -= g_pool[k].bytes;
             g_pool.erase(g_pool.begin() + (long)k);
         }
+        // Buffers still tagged with a stream other than the caller's: normal for a second queue at work, but a caller that destroys
+        // its streams without sp_stream_retired would strand them for good. Past kForeignMax of them: one device-wide wait, after
+        // which every tag is void (nothing on the device can touch any pooled buffer any more).
+        size_t foreign = 0;
+        for (const auto& e : g_pool) foreign += (!e.busy && e.owner != nullptr && e.owner != st) ? 1 : 0;
+        if (foreign > kForeignMax) {
+            (void)hipDeviceSynchronize();
+            for (auto& e : g_pool)
+                if (!e.busy) e.owner = nullptr;
+        }
         PoolEntry* best = nullptr;
         for (auto& e : g_pool)  // best fit among the idle buffers of this device, not more than 4x oversized
             if (!e.busy && e.device == dev && e.bytes >= bytes && e.bytes <= 4 * bytes && (!best || e.bytes < best->bytes) &&
-                entry_idle(e))
+                ((e.owner != nullptr && st != nullptr && e.owner == st) || entry_idle(e)))
                 best = &e;
-        if (best) { best->busy = true; *ptr = best->p; }
+        if (best) { best->busy = true; best->owner = nullptr; *ptr = best->p; }
     }
     for (void* q : surplus) (void)hipFree(q);
     if (*ptr) return hipSuccess;
@@ -154,19 +171,19 @@ hipError_t scratch_acquire(void** ptr, size_t bytes) {
     const hipError_t err = hipMalloc(&p, bytes);
     if (err != hipSuccess) return err;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    g_pool.push_back(PoolEntry{p, bytes, dev, true, {}});
+    g_pool.push_back(PoolEntry{p, bytes, dev, true, {}, nullptr});
     *ptr = p;
     return hipSuccess;
 }
 
 namespace {
-void release_impl(void* ptr, std::vector<hipEvent_t>&& pending) {
+void release_impl(void* ptr, std::vector<hipEvent_t>&& pending, hipStream_t owner = nullptr) {
     void* drop = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         size_t idle = 0;
         for (auto& e : g_pool) {
-            if (e.p == ptr) { e.busy = false; e.pending = std::move(pending); }
+            if (e.p == ptr) { e.busy = false; e.pending = std::move(pending); e.owner = owner; }
             idle += e.busy ? 0 : 1;
         }
         if (idle > kKeep) {  // drop the smallest buffer that is known to be idle (hipFree of a buffer in use would wait for it).
@@ -175,7 +192,7 @@ void release_impl(void* ptr, std::vector<hipEvent_t>&& pending) {
             // scratch/dbg_capture.py). Entries with pending events are settled by the next scratch_acquire.
             size_t k = g_pool.size();
             for (size_t i = 0; i < g_pool.size(); ++i)
-                if (!g_pool[i].busy && g_pool[i].pending.empty() && (k == g_pool.size() || g_pool[i].bytes < g_pool[k].bytes)) k = i;
+                if (!g_pool[i].busy && g_pool[i].pending.empty() && g_pool[i].owner == nullptr && (k == g_pool.size() || g_pool[i].bytes < g_pool[k].bytes)) k = i;
             if (k != g_pool.size()) {
                 drop = g_pool[k].p;
                 g_pool.erase(g_pool.begin() + (long)k);
@@ -191,6 +208,10 @@ void release_impl(void* ptr, std::vector<hipEvent_t>&& pending) {
 void scratch_release(void* ptr) { release_impl(ptr, {}); }
 
 void scratch_release_after(void* ptr, const StreamSet& streams) {
+    if (!streams.overflow && streams.n == 1 && streams.s[0] != nullptr) {  // one stream: its order protects the buffer, no event
+        release_impl(ptr, {}, streams.s[0]);
+        return;
+    }
     std::vector<hipEvent_t> pending;
     bool ok = !streams.overflow;
     for (int i = 0; ok && i < streams.n; ++i) {
@@ -209,6 +230,20 @@ void scratch_release_after(void* ptr, const StreamSet& streams) {
 }
 }  // namespace sp
 
+extern "C" void sp_stream_retired(void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (st == nullptr) return;
+    bool any = false;
+    {
+        std::lock_guard<std::mutex> lock(sp::g_pool_mutex);
+        for (const auto& e : sp::g_pool) any = any || e.owner == st;
+    }
+    if (!any) return;
+    (void)hipStreamSynchronize(st);  // (still alive: the caller retires it BEFORE hipStreamDestroy)
+    std::lock_guard<std::mutex> lock(sp::g_pool_mutex);
+    for (auto& e : sp::g_pool)
+        if (e.owner == st) e.owner = nullptr;
+}
 extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
 extern "C" const char* sp_last_error(void) { return g_last_error.c_str(); }
 

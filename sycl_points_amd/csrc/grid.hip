@@ -1288,9 +1288,9 @@ int ensure_units(const sp_grid* gr, hipStream_t st) {
     const unsigned rows = (unsigned)gr->dims[1] * (unsigned)gr->dims[2];
     const size_t stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
     ScratchBuf b_units, b_stmp;
-    hipError_t e = b_units.get((rows + 1) * 4);
-    if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
-    if (e == hipSuccess && gr->d_unit_off == nullptr) e = pooled_alloc(&gr->d_unit_off, (rows + 1) * 4);
+    hipError_t e = b_units.get((rows + 1) * 4, st);
+    if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16), st);
+    if (e == hipSuccess && gr->d_unit_off == nullptr) e = pooled_alloc(&gr->d_unit_off, (rows + 1) * 4, st);
     if (e != hipSuccess) { sp_set_error(hipGetErrorString(e)); return SP_ERR_HIP; }
     row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(gr->d_start, (unsigned)gr->dims[0], rows, b_units.as<unsigned>());
     if (exclusive_scan_u32(b_units.as<unsigned>(), gr->d_unit_off, rows + 1, nullptr, b_stmp.p, stmp_bytes, st) != SP_OK) e = hipErrorUnknown;
@@ -1395,7 +1395,7 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
     } release{sortbuf, st};
     if (nq >= 400000 && gr->sort_queries && !queries_in_cell_order && gr->n != 0 && gr->ncells < 0xffffffffull) {
         const size_t wsb = radix_sort_u32_workspace_bytes(nq);
-        if (pooled_alloc(&sortbuf, (4 * nq + 4) * sizeof(uint32_t) + wsb) != hipSuccess) return SP_ERR_HIP;
+        if (pooled_alloc(&sortbuf, (4 * nq + 4) * sizeof(uint32_t) + wsb, st) != hipSuccess) return SP_ERR_HIP;
         uint32_t *ka = sortbuf, *kb = ka + nq, *va = kb + nq, *vb = va + nq;
         order_count = vb + nq;
         grid_query_cell_kernel<<<div_up(nq, kBlock), kBlock, 0, st>>>(reinterpret_cast<const float4*>(q), (unsigned)nq, g, tv,
@@ -1418,7 +1418,7 @@ int launch(const sp_grid* gr, const float* q, size_t nq, size_t k, const float* 
         // candidates than all 27 cells, which decides for queries in random order — 0.8 against 2.2 ms at k = 10.) The list lives in the library's buffer pool for the
         // duration of the call (handed back tagged with an event on this stream).
         unsigned* todo = nullptr;
-        if (pooled_alloc(&todo, (nq + 1) * sizeof(unsigned)) != hipSuccess) return SP_ERR_HIP;
+        if (pooled_alloc(&todo, (nq + 1) * sizeof(unsigned), st) != hipSuccess) return SP_ERR_HIP;
         unsigned* const todo_count = todo + nq;
         int rc = zero_async(todo_count, 4, st);
         if (rc == SP_OK) {
@@ -1478,7 +1478,7 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
     };
     hipError_t e;
     if (n == 0) {
-        if ((e = pooled_alloc(&g->d_start, 2 * sizeof(uint32_t))) != hipSuccess) return fail(e);
+        if ((e = pooled_alloc(&g->d_start, 2 * sizeof(uint32_t), st)) != hipSuccess) return fail(e);
         if ((e = hipMemsetAsync(g->d_start, 0, 2 * sizeof(uint32_t), st)) != hipSuccess) return fail(e);
         *out = g;
         return SP_OK;
@@ -1486,7 +1486,7 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
     const float4* pts = reinterpret_cast<const float4*>(points);
     // 1. bounding box of the finite points
     ScratchBuf bbox_buf;
-    if ((e = bbox_buf.get(6 * sizeof(unsigned))) != hipSuccess) return fail(e);
+    if ((e = bbox_buf.get(6 * sizeof(unsigned), st)) != hipSuccess) return fail(e);
     unsigned* const d_bbox = bbox_buf.as<unsigned>();
     const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     unsigned h_bbox_own[6];
@@ -1527,13 +1527,13 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;
     ScratchBuf b_kin, b_kout, b_vin, b_vout, b_tmp, b_stats;
     size_t tmp_bytes = radix_sort_u32_workspace_bytes(n);  // radix_sort.hip
-    e = b_kin.get(n * 4);
-    if (e == hipSuccess) e = b_kout.get(n * 4);
-    if (e == hipSuccess) e = b_vin.get(n * 4);
-    if (e == hipSuccess) e = b_vout.get(n * 4);
-    if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(tmp_bytes, 16));
-    if (e == hipSuccess) e = b_stats.get(16);
-    if (e == hipSuccess) e = pooled_alloc(&g->d_pts, n * sizeof(float4));
+    e = b_kin.get(n * 4, st);
+    if (e == hipSuccess) e = b_kout.get(n * 4, st);
+    if (e == hipSuccess) e = b_vin.get(n * 4, st);
+    if (e == hipSuccess) e = b_vout.get(n * 4, st);
+    if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(tmp_bytes, 16), st);
+    if (e == hipSuccess) e = b_stats.get(16, st);
+    if (e == hipSuccess) e = pooled_alloc(&g->d_pts, n * sizeof(float4), st);
     if (e != hipSuccess) return fail(e);
     void* const tmp = b_tmp.p;
     // Density-adaptive build (sp_grid_create_adaptive): the cell size of the volume rule assumes the points fill their bounding
@@ -1567,11 +1567,11 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
         const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
         ScratchBuf b_units, b_stmp;
         const size_t stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
-        e = pooled_alloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t));
+        e = pooled_alloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t), st);
         if (adaptive) {  // (this form of the build ends every attempt with a read-back anyway: the work units ride along)
-            if (e == hipSuccess) e = b_units.get((rows + 1) * 4);
-            if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4);
-            if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16));
+            if (e == hipSuccess) e = b_units.get((rows + 1) * 4, st);
+            if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4, st);
+            if (e == hipSuccess) e = b_stmp.get(std::max<size_t>(stmp_bytes, 16), st);
         }
         unsigned* const units = b_units.as<unsigned>();
         void* const stmp = b_stmp.p;
@@ -1703,12 +1703,12 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
     tmp_bytes = exclusive_scan_u32_workspace_bytes(n + 1);
     tmp2_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
-    hipError_t e = b_keep.get((n + 1) * 4);
-    if (e == hipSuccess) e = b_scan.get((n + 1) * 4);
-    if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(std::max(tmp_bytes, tmp2_bytes), 16));
-    if (e == hipSuccess) e = b_units.get((rows + 1) * 4);
-    if (e == hipSuccess) e = b_start.get((g->ncells + 1) * 4);
-    if (e == hipSuccess) e = pooled_alloc(&new_pts, n * sizeof(float4));
+    hipError_t e = b_keep.get((n + 1) * 4, st);
+    if (e == hipSuccess) e = b_scan.get((n + 1) * 4, st);
+    if (e == hipSuccess) e = b_tmp.get(std::max<size_t>(std::max(tmp_bytes, tmp2_bytes), 16), st);
+    if (e == hipSuccess) e = b_units.get((rows + 1) * 4, st);
+    if (e == hipSuccess) e = b_start.get((g->ncells + 1) * 4, st);
+    if (e == hipSuccess) e = pooled_alloc(&new_pts, n * sizeof(float4), st);
     auto fail = [&](hipError_t err) {
         sp_set_error(hipGetErrorString(err));
         (void)hipStreamSynchronize(st);
@@ -1729,7 +1729,7 @@ extern "C" int sp_grid_remove_by_flags(sp_grid* g, const uint8_t* flags, const i
     e = hipMemcpyAsync(&kept, scan + n, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(g->d_start, new_start, (g->ncells + 1) * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(e);
-    if (g->d_unit_off == nullptr && (e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4)) != hipSuccess) return fail(e);
+    if (g->d_unit_off == nullptr && (e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4, st)) != hipSuccess) return fail(e);
     row_units_kernel<<<div_up(rows + 1, kBlock), kBlock, 0, st>>>(g->d_start, (unsigned)g->dims[0], rows, units);
     if (exclusive_scan_u32(units, g->d_unit_off, rows + 1, nullptr, b_tmp.p, tmp2_bytes, st) != SP_OK) e = hipErrorUnknown;
     g->units_ready = true;

@@ -435,11 +435,11 @@ extern "C" int sp_kdtree_create(const float* points_host, size_t n, size_t leaf_
     t->streams.note(st);
     hipError_t e = hipSuccess;
     if (!internal.empty()) {
-        e = pooled_alloc(&t->d_internal, internal.size() * 32);  // (hipMalloc + hipFree are ~0.1-0.2 ms apiece on this runtime)
+        e = pooled_alloc(&t->d_internal, internal.size() * 32, st);  // (hipMalloc + hipFree are ~0.1-0.2 ms apiece on this runtime)
         if (e == hipSuccess) e = hipMemcpyAsync(t->d_internal, internal.data(), internal.size() * 32, hipMemcpyHostToDevice, st);
     }
     if (e == hipSuccess && !leaves.empty()) {
-        e = pooled_alloc(&t->d_leaf, leaves.size() * 16);
+        e = pooled_alloc(&t->d_leaf, leaves.size() * 16, st);
         if (e == hipSuccess) e = hipMemcpyAsync(t->d_leaf, leaves.data(), leaves.size() * 16, hipMemcpyHostToDevice, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host vectors die at return

@@ -1365,11 +1365,11 @@ int build_certificates(sp_gicp_target* t, hipStream_t st) {
     const size_t n = t->n;
     if (n == 0 || t->rho2 != nullptr) return SP_OK;
     ScratchBuf b_idx3, b_d23, b_inv;
-    hipError_t e = pooled_alloc(&t->rho2, n * sizeof(float));
-    if (e == hipSuccess) e = pooled_alloc(&t->nb, n * sizeof(float4));
-    if (e == hipSuccess) e = b_idx3.get(n * 3 * sizeof(int32_t));
-    if (e == hipSuccess) e = b_d23.get(n * 3 * sizeof(float));
-    if (e == hipSuccess) e = b_inv.get(n * sizeof(unsigned));
+    hipError_t e = pooled_alloc(&t->rho2, n * sizeof(float), st);
+    if (e == hipSuccess) e = pooled_alloc(&t->nb, n * sizeof(float4), st);
+    if (e == hipSuccess) e = b_idx3.get(n * 3 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = b_d23.get(n * 3 * sizeof(float), st);
+    if (e == hipSuccess) e = b_inv.get(n * sizeof(unsigned), st);
     int32_t* const idx3 = b_idx3.as<int32_t>();
     float* const d23 = b_d23.as<float>();
     unsigned* const inv = b_inv.as<unsigned>();
@@ -1402,7 +1402,7 @@ int target_create(const sp_grid* grid, const float* tgt_covs, size_t n, bool cer
     t->n = n;
     t->note(as_stream(stream));
     if (n) {
-        const hipError_t e = pooled_alloc(&t->covp, n * 2 * sizeof(float4));
+        const hipError_t e = pooled_alloc(&t->covp, n * 2 * sizeof(float4), as_stream(stream));
         if (e != hipSuccess) {
             sp_set_error(hipGetErrorString(e));
             sp_gicp_target_destroy(t);

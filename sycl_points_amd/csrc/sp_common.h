@@ -48,10 +48,10 @@ int zero_async(void* p, size_t bytes, hipStream_t st);  // capi_common.hip; retu
 // the smallest is dropped first. The arrays of objects that outlive the call (a grid, a prepared target) come from the same
 // pool through pooled_alloc / pooled_free: their destroy waits for the device to go idle (what hipFree does implicitly)
 // before the buffers are offered to the next build.
-hipError_t scratch_acquire(void** ptr, size_t bytes);  // capi_common.hip
+hipError_t scratch_acquire(void** ptr, size_t bytes, hipStream_t st = nullptr);  // capi_common.hip; st: the stream the buffer will be used on (a buffer released behind the same stream's work is taken without waiting)
 void* pinned_mailbox();  // capi_common.hip: 256 bytes of pinned host memory per host thread (nullptr: none), for small read-backs
 void scratch_release(void* ptr);
-template <class T> hipError_t pooled_alloc(T** ptr, size_t bytes) { return scratch_acquire(reinterpret_cast<void**>(ptr), bytes); }
+template <class T> hipError_t pooled_alloc(T** ptr, size_t bytes, hipStream_t st = nullptr) { return scratch_acquire(reinterpret_cast<void**>(ptr), bytes, st); }
 inline void pooled_free(void* ptr) { if (ptr) scratch_release(ptr); }  // caller: nothing on the device still uses ptr
 
 // The streams an object's arrays have been used on (every entry point notes its stream): when the object is destroyed its
@@ -78,7 +78,7 @@ void scratch_release_after(void* ptr, const StreamSet& streams);  // capi_common
 inline void pooled_free_after(void* ptr, const StreamSet& streams) { if (ptr) scratch_release_after(ptr, streams); }
 struct ScratchBuf {  // RAII handle
     void* p = nullptr;
-    hipError_t get(size_t bytes) { return scratch_acquire(&p, bytes); }
+    hipError_t get(size_t bytes, hipStream_t st = nullptr) { return scratch_acquire(&p, bytes, st); }
     template <class T> T* as() const { return static_cast<T*>(p); }
     ~ScratchBuf() { if (p) scratch_release(p); }
     /// hand the buffer back while work on `streams` may still use it (the pool waits for their events before reuse)
