@@ -381,7 +381,8 @@ __global__ __launch_bounds__(kBlock) void bvh_search_kernel(const float4* __rest
 // A non-finite query point or a tree deeper than the stack goes to that kernel through a list.
 constexpr int kSelHalf = 16;   // Morton neighbours either side
 constexpr int kHeapStack = 20; // stacked far siblings per lane in LDS (with the heap: 52 KB per workgroup, three per CU) ...
-constexpr int kHeapStackDeep = 28;  // ... and behind them in HBM, [slot][query]: a handful of queries per million get there
+constexpr int kHeapStackDeep = 28;  // ... and behind them in HBM, in a slot of a shared arena the lane claims when it first gets
+                                    // there (an atomic counter; arena full: handed on): a handful of queries per million do
                                     // (a Morton neighbourhood across a jump of the curve starts them with a wide bound). Without
                                     // it they were handed on, and the other kernel's answer to ITS full stack is a scan of all
                                     // points by one lane: 1.5 ms of the 3.4 ms of the non-uniform 1 M cloud for 11 queries.
@@ -391,11 +392,13 @@ constexpr int kHeapStackDeep = 28;  // ... and behind them in HBM, [slot][query]
 // test (leaf_fn lowers them). Returns false when the per-lane stack overflowed.
 template <int STACK, class LeafFn>
 __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ node, const float4* __restrict__ obox,
-                                         unsigned (*st_node)[kBlock], unsigned* __restrict__ deep, size_t deep_stride,
+                                         unsigned (*st_node)[kBlock], unsigned* __restrict__ arena,
+                                         unsigned* __restrict__ arena_count, unsigned arena_slots,
                                          unsigned lane, float qx, float qy, float qz,
                                          const float& bound, const int& bound_idx, bool active, LeafFn&& leaf_fn) {
     int sp_top = 0;
     bool ok = true;
+    unsigned* deep = nullptr;  // this lane's kHeapStackDeep words of the arena, once claimed
     unsigned cur = 0;
     bool have_cur = active;
     unsigned pf = 1u, pl = 0u;  // pending run of points (empty)
@@ -424,8 +427,16 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ node, const 
                     st_node[sp_top][lane] = far;
                     ++sp_top;
                 } else if (sp_top < STACK + kHeapStackDeep) {
-                    deep[(size_t)(sp_top - STACK) * deep_stride] = far;
-                    ++sp_top;
+                    if (deep == nullptr) {
+                        const unsigned slot = atomicAdd(arena_count, 1u);
+                        if (slot < arena_slots) deep = arena + (size_t)slot * kHeapStackDeep;
+                    }
+                    if (deep != nullptr) {
+                        deep[sp_top - STACK] = far;
+                        ++sp_top;
+                    } else {
+                        ok = false;  // (the arena is full: a cloud that sends thousands of lanes this deep)
+                    }
                 } else {
                     ok = false;
                 }
@@ -438,7 +449,7 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ node, const 
                 have_cur = false;
                 while (sp_top > 0) {
                     --sp_top;
-                    const unsigned c = sp_top < STACK ? st_node[sp_top][lane] : deep[(size_t)(sp_top - STACK) * deep_stride];
+                    const unsigned c = sp_top < STACK ? st_node[sp_top][lane] : deep[sp_top - STACK];
                     const float4 o0 = obox[2 * (size_t)c], o1 = obox[2 * (size_t)c + 1];
                     const float dc = box_d2(o0.x, o0.y, o0.z, o1.x, o1.y, o1.z, qx, qy, qz);
                     if (dc > bound || (dc == bound && __float_as_int(o0.w) > bound_idx)) continue;
@@ -498,7 +509,8 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
                                                           const float* __restrict__ T_dev, float radius_sq,
                                                           int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
                                                           unsigned* __restrict__ todo, unsigned* __restrict__ todo_count,
-                                                          const unsigned* __restrict__ order, unsigned* __restrict__ deep) {
+                                                          const unsigned* __restrict__ order, unsigned* __restrict__ arena,
+                                                          unsigned arena_slots) {
     constexpr int F1 = KCAP > 21 ? 8 : 4;                     // children of the root (slots 1 .. F1)
     constexpr int kDeep = KCAP > 1 + F1 ? KCAP - 1 - F1 : 1;  // grandchildren (slots 1 + F1 ..)
     __shared__ unsigned st_node[kHeapStack][kBlock];
@@ -584,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void bvh_heap_kernel(const float4* __restri
         for (int j = 0; j < kDeep; ++j) heap2[j][lane] = 1 + F1 + j < k ? kNoCand : 0ull;
     float bound = top;
     int bound_idx = 0x7fffffff;
-    const bool ok = bvh_walk<kHeapStack>(node, obox, st_node, deep + gi, nq, lane, qx, qy, qz, bound, bound_idx, mine, [&](unsigned first, unsigned last) {
+    const bool ok = bvh_walk<kHeapStack>(node, obox, st_node, arena, todo_count + 1, arena_slots, lane, qx, qy, qz, bound, bound_idx, mine, [&](unsigned first, unsigned last) {
 #pragma unroll 1
         for (unsigned b = first; b <= last; b += 8) {
             float4 slot[8];
@@ -732,11 +744,13 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
     if (k >= (q ? 1u : 2u) && b->n > (size_t)kBvhLeaf && b->self_heap) {
         // heap kernel; what it hands on (non-finite queries, a tree deeper than its stack) is finished by the sorted-insertion kernel
         unsigned* todo = nullptr;
-        // (+ the deep part of the walk's stack: [slot][query], written by the few lanes that get there)
-        if (pooled_alloc(&todo, ((size_t)nq * (1 + kHeapStackDeep) + 1) * sizeof(unsigned), st) != hipSuccess) return SP_ERR_HIP;
-        unsigned* const todo_count = todo + nq;
-        unsigned* const deep = todo + nq + 1;
-        int rc = zero_async(todo_count, 4, st);
+        // (+ the arena for the deep part of the walks' stacks: a slot of kHeapStackDeep words per lane that gets there, claimed
+        // through the counter behind todo_count — 64 K slots at most, 7 MB, where a column per query was 116 B a query)
+        const unsigned arena_slots = (unsigned)std::min<size_t>(nq, 65536);
+        if (pooled_alloc(&todo, ((size_t)nq + 2 + (size_t)arena_slots * kHeapStackDeep) * sizeof(unsigned), st) != hipSuccess) return SP_ERR_HIP;
+        unsigned* const todo_count = todo + nq;  // [0] the list's length, [1] arena slots claimed
+        unsigned* const deep = todo + nq + 2;
+        int rc = zero_async(todo_count, 8, st);
         // external queries: sorted along the tree's curve first (0.15 ms per million: 10-20 % off a search of a million queries, a
         // loss below a few hundred thousand)
         uint32_t* sortbuf = nullptr;
@@ -763,17 +777,17 @@ int bvh_dispatch(const sp_bvh* b, const float4* q, unsigned nq, size_t k, const 
     do {                                                                                                                                \
         if (!q) {                                                                                                                       \
             bvh_heap_kernel<KC, 0><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
-                                                        todo_count, order, deep);                                                             \
+                                                        todo_count, order, deep, arena_slots);                                                             \
             bvh_search_kernel<OLDK><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,    \
                                                          todo, todo_count);                                                            \
         } else if (r2 < 0.0f) {                                                                                                         \
             bvh_heap_kernel<KC, 1><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
-                                                        todo_count, order, deep);                                                             \
+                                                        todo_count, order, deep, arena_slots);                                                             \
             bvh_search_kernel<OLDK><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out, 0.0f,    \
                                                          todo, todo_count);                                                            \
         } else {                                                                                                                        \
             bvh_heap_kernel<KC, 2><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, r2, idx_out, d2_out, todo, \
-                                                        todo_count, order, deep);                                                             \
+                                                        todo_count, order, deep, arena_slots);                                                             \
             bvh_search_kernel<OLDK, true><<<g, kBlock, 0, st>>>(b->node, b->obox, b->pts, n32, q, nq, kk, Tv, T_dev, idx_out, d2_out,    \
                                                                r2, todo, todo_count);                                                  \
         }                                                                                                                               \
