@@ -173,14 +173,22 @@ __device__ __forceinline__ void reduce_rows_block(const float* __restrict__ part
 // totals (21 upper-triangle H, 6 b, error | error only) + count -> sp_linearized
 __device__ __forceinline__ void unpack_totals(const float* tot, int nv, sp_linearized* out) {
     if (nv == kAcc - 1) {
+        // (unrolled: one lane runs this between two steps of a device-resident loop, and a rolled loop is 21 dependent LDS round
+        // trips — read a total, store it twice — where the unrolled form issues the 27 reads back to back)
+        float v[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = tot[k];
         int k = 0;
+#pragma unroll
         for (int a = 0; a < 6; ++a)
+#pragma unroll
             for (int cc = a; cc < 6; ++cc) {
-                const float v = tot[k++];
-                out->H[a * 6 + cc] = v;
-                out->H[cc * 6 + a] = v;
+                out->H[a * 6 + cc] = v[k];
+                out->H[cc * 6 + a] = v[k];
+                ++k;
             }
-        for (int a = 0; a < 6; ++a) out->b[a] = tot[21 + a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) out->b[a] = v[21 + a];
         out->error = tot[27];
     } else {
         out->error = tot[0];
