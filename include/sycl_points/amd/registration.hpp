@@ -253,8 +253,15 @@ public:
         // (the reference crosses host <-> device 2 + inner tries times per iteration, registration.hpp:830-964), Gauss-Newton when
         // the source fits one workgroup (the pipeline's default 1000-point sample: no launch per iteration, no counter between
         // steps). std::nullopt: the launch is not available now, or its bounded wait ran out — the loops below take over.
+        // A target with crowded cells — a raw scan: thousands of returns in the sensor's own cell — and a source of up to 131072
+        // points: that launch with a WAVE per source point (sp_gicp_source_set_wave_per_point = 2), for Gauss-Newton too: a lane
+        // alone walks thousands of candidates per query there (the reference's bundled scans at full resolution: 0.21 against
+        // 0.69 ms per iteration). The fullest cell is measured once per grid (a kernel and a read-back, cached by the library).
+        const bool crowded = on_device && !sharded && source.size() > 1024 && source.size() <= 131072 &&
+                             sp_grid_max_cell_points(grid->handle()) >= kCrowdedCell;
+        if (on_device && !sharded) throw_on_error(sp_gicp_source_set_wave_per_point(psrc_, crowded ? 2 : 1));
         if (on_device && !sharded &&
-            (params_.optimization_method != OptimizationMethod::GAUSS_NEWTON || source.size() <= 1024)) {
+            (params_.optimization_method != OptimizationMethod::GAUSS_NEWTON || source.size() <= 1024 || crowded)) {
             const float scales[1] = {robust_scale};
             if (auto r = align_optimize_on_device(initial_guess, scales, 1)) return *r;
             prepare_fused(source, target, *grid, initial_guess);  // (the correspondence cache of the abandoned launch is stale)
@@ -310,6 +317,9 @@ public:
             if (grid != nullptr && grid->size() == target.size() && params_.robust.type != robust::RobustLossType::NONE) {
                 fused_loop_active_ = true;
                 prepare_fused(source, target, *grid, initial_guess);
+                const bool crowded = source.size() > 1024 && source.size() <= 131072 &&
+                                     sp_grid_max_cell_points(grid->handle()) >= kCrowdedCell;  // (see align())
+                throw_on_error(sp_gicp_source_set_wave_per_point(psrc_, crowded ? 2 : 1));
                 if (auto r = align_optimize_on_device(initial_guess, robust_scales.data(), (int)robust_scales.size())) return *r;
             }
         }
@@ -528,6 +538,7 @@ private:
     /// How sp_gicp_source_prepare orders the source: as it is when the caller says it is spatially ordered — or when it is a few
     /// thousand points (the pipeline's random sample): the order only decides which lane handles which point, and the cell sort
     /// is seven launches for something a handful of waves do not notice.
+    static constexpr uint32_t kCrowdedCell = 512;  // points in the target grid's fullest cell from which a wave per source point pays
     int source_order(size_t n) const { return (source_presorted_ || n <= 4096) ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT; }
     const knn::GridKNN* grid_for(const knn::KDTree& tree, const PointCloudShared& target) {
         if (!tree.pristine() || tree.size() != target.size() || target.size() == 0) return nullptr;

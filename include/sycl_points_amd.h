@@ -549,6 +549,12 @@ int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gicp_source* s
 /* 0: sp_gicp_align_fused runs every iteration as a launch of its own and sp_gicp_align_optimize reports "not available" — no
  * launch whose workgroups wait for each other is started for this source. Default 1. */
 int sp_gicp_source_set_persistent(sp_gicp_source* source, int enable);
+/* How sp_gicp_align_optimize's linearisation steps deal the source points: 0 a lane per point; 1 (default) a wave per point for
+ * sources of up to 2048 points (more SIMDs than points: the step costs the longest chain of dependent loads, and 64 lanes scanning
+ * one query's ball make that chain a handful of round trips); 2 a wave per point for sources of up to 131072 points — for a
+ * target whose cells are crowded (sp_grid_max_cell_points in the hundreds or thousands: a raw LiDAR scan), where a lane's walk
+ * through its block of cells is thousands of candidates long. Same correspondences in every mode. */
+int sp_gicp_source_set_wave_per_point(sp_gicp_source* source, int mode);
 /* Registration::optimize_gauss_newton (registration.hpp:791-828) as ONE device thread, so a whole fixed-length
  * iteration loop can stay on the stream with no host round trip:
  *   delta = LDLT(H + lambda*I).solve(-b);  T <- T * se3_exp(delta);  delta_out[0..5] = delta,

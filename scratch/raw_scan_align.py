@@ -44,3 +44,15 @@ ms, (T_dev, lin, delta) = timed(lambda: reg.align_device_loop(S, Tg, bvh, iterat
 T = reg.T_from_device(T_dev)
 print(f"{'hierarchy (generic loop)':28s} {'':41s}{ms / ITERS * 1e3:8.1f} us per iteration ({ms:.2f} ms per alignment); "
       f"|T - T_oracle| = {np.abs(T - ref['T']).max():.2e}")
+
+# the device-resident optimiser loop (Gauss-Newton), one wave per source point when the library
+# is told to (sp_gicp_source_set_wave_per_point = 2: what the facade does for a target with crowded cells), a lane per point otherwise
+for name, grid in (("grid, volume rule", sp.GridKNN.build(Tg.points, points_per_cell=0.5)),):
+    prep = sp.PreparedTarget(grid, Tg.covs)
+    for wq in (2, 0):
+        reg = sp.Registration(sp.RegistrationParams(max_iterations=ITERS, criteria_rotation=0.0, criteria_translation=0.0,
+                                                    optimization_method="GN"))
+        reg._set_source_option("opt_wave_query", wq)
+        ms, res = timed(lambda: reg.align_optimize(S, prep, None, None, True))
+        print(f"optimiser launch, GN, opt_wave_query={wq}: {ms / ITERS * 1e3:8.1f} us per iteration ({ms:.2f} ms per alignment); "
+              f"|T - T_oracle| = {np.abs(res.T - ref['T']).max():.2e}, inliers {res.inlier} / {ref['inlier']}, searched {res.searched}")

@@ -160,6 +160,7 @@ SIGNATURES = {
     "sp_gicp_align_optimize": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), C.POINTER(OptParams), C.POINTER(C.c_float), _i, _vp, _vp,
                                     _sz, _vp]),
     "sp_gicp_source_set_persistent": (_i, [_vp, _i]),
+    "sp_gicp_source_set_wave_per_point": (_i, [_vp, _i]),
     "sp_gicp_align_fused": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_step": (_i, [_vp, _vp, _vp, C.POINTER(FactorParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_align_linearization_pose": (_i, [_vp, _i, _vp, _vp]),

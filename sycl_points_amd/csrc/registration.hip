@@ -2019,6 +2019,14 @@ extern "C" int sp_gicp_source_set_persistent(sp_gicp_source* s, int enable) {
     return SP_OK;
 }
 
+// sp_gicp_align_optimize's linearisation steps: 0 a lane per source point, 1 (default) a wave per point for sources of up to 2048
+// points, 2 a wave per point up to 131072 points (for targets with crowded cells: see registration_opt.hip).
+extern "C" int sp_gicp_source_set_wave_per_point(sp_gicp_source* s, int mode) {
+    if (!s || mode < 0 || mode > 2) return SP_ERR_INVALID_ARGUMENT;
+    s->opt_wave_query = mode;
+    return SP_OK;
+}
+
 // Measurement (sp_internal.h): entry k = source points iteration k of the last alignment searched for (the rest reused their
 // correspondence); 0 for iterations that did not run (converged earlier).
 extern "C" const uint32_t* sp_internal_align_searched_log(void* workspace, size_t* n_entries_out) {

@@ -344,7 +344,13 @@ __device__ __forceinline__ float waveq_row_slot(const float (&acc)[NV], unsigned
 // over up to 256 workgroups of four waves: the step then costs a handful of dependent round trips instead of the longest
 // per-lane walk through a 2x2x2 block of a surface cloud (the reference's example, 1000 points against 6 k: 16-26 us per
 // linearisation per lane, a few us per wave).
-constexpr size_t kWaveQueryMax = 2048;
+// By itself (sp_gicp_source_set_wave_per_point = 1, the default) the launch takes this form up to kWaveQueryMax points, where
+// every point has a wave to itself. Told to (= 2: the caller knows the target's cells are crowded — sp_grid_max_cell_points — a
+// raw LiDAR scan with thousands of returns in one cell) up to kWaveQueryForcedMax: a wave then walks through n / 4096 points one
+// after the other, which loses to a lane per point on a cloud of even density (20 k points in a filled box: 67 against 21 us
+// per iteration) and wins where a lane's walk through its 2x2x2 block is thousands of candidates long (the reference's bundled
+// scans at full resolution, 5032 returns in the sensor's own cell: 212 against 686 us; scratch/waveq_crossover.py).
+constexpr size_t kWaveQueryMax = 2048, kWaveQueryForcedMax = 131072;
 template <int LOSS, bool FAST_NN, bool P2D, int BLOCK, bool WAVEQ = false>
 __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, OptArgs A) {
     __shared__ OptShared S;
@@ -565,8 +571,13 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     const bool small = n <= (size_t)256 * 256;
     const unsigned block = small ? 256u : (unsigned)kAlignBlock;
     const bool fast = source->opt_fast_nn < 0 ? source->sorted : (source->opt_fast_nn != 0);
-    const bool waveq = fast && n <= kWaveQueryMax && source->opt_wave_query != 0;  // one wave per point, four waves per workgroup
-    const unsigned grid = std::min<unsigned>((unsigned)(waveq ? (n + 3) / 4 : (n + block - 1) / block), (unsigned)kAlignMaxBlocks);
+    const bool waveq = fast && ((source->opt_wave_query == 1 && n <= kWaveQueryMax) || (source->opt_wave_query == 2 && n <= kWaveQueryForcedMax));
+    // (wave per point: four waves a workgroup, each alone on its SIMD with 256 registers, up to two points a wave; beyond, sixteen
+    // waves a workgroup: a wave then walks through its points one after the other and the other waves of its SIMD hide its round
+    // trips — 212 against 404 us per iteration on the reference's bundled scans)
+    const unsigned wq_block = n <= kWaveQueryMax ? 256u : (unsigned)kAlignBlock;
+    const unsigned wq_waves = wq_block / kWave;
+    const unsigned grid = std::min<unsigned>((unsigned)(waveq ? (n + wq_waves - 1) / wq_waves : (n + block - 1) / block), (unsigned)kAlignMaxBlocks);
     PersistGuard* const guard = persist_acquire(st, grid);
     if (!guard) {
         sp_set_error("[sp_gicp_align_optimize] not available now: the launch cannot be resident (grid larger than the device, stream "
@@ -615,8 +626,10 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     else if (p2d) gicp_optimize_kernel<L, false, true, B><<<grid, B, 0, st>>>(P, A);                \
     else gicp_optimize_kernel<L, false, false, B><<<grid, B, 0, st>>>(P, A)
 #define SP_LAUNCH_OPT(L)                                                                           \
-    if (waveq && p2d) gicp_optimize_kernel<L, true, true, 256, true><<<grid, 256, 0, st>>>(P, A);  \
-    else if (waveq) gicp_optimize_kernel<L, true, false, 256, true><<<grid, 256, 0, st>>>(P, A);   \
+    if (waveq && wq_block == 256u && p2d) gicp_optimize_kernel<L, true, true, 256, true><<<grid, 256, 0, st>>>(P, A);  \
+    else if (waveq && wq_block == 256u) gicp_optimize_kernel<L, true, false, 256, true><<<grid, 256, 0, st>>>(P, A);   \
+    else if (waveq && p2d) gicp_optimize_kernel<L, true, true, kAlignBlock, true><<<grid, kAlignBlock, 0, st>>>(P, A);  \
+    else if (waveq) gicp_optimize_kernel<L, true, false, kAlignBlock, true><<<grid, kAlignBlock, 0, st>>>(P, A);       \
     else if (small) { SP_LAUNCH_OPT2(L, 256); }                                                    \
     else { SP_LAUNCH_OPT2(L, kAlignBlock); }
     switch (params->robust_type) {
