@@ -47,8 +47,12 @@ print(f"{'hierarchy (generic loop)':28s} {'':41s}{ms / ITERS * 1e3:8.1f} us per 
 
 # the device-resident optimiser loop (Gauss-Newton), one wave per source point when the library
 # is told to (sp_gicp_source_set_wave_per_point = 2: what the facade does for a target with crowded cells), a lane per point otherwise
-for name, grid in (("grid, volume rule", sp.GridKNN.build(Tg.points, points_per_cell=0.5)),):
+for name, grid in (("grid, volume rule", sp.GridKNN.build(Tg.points, points_per_cell=0.5)),
+                   ("grid, occupancy-steered", sp.GridKNN.build(Tg.points, points_per_cell=0.5, adaptive=True)),
+                   ("grid, 0.3 m cells", sp.GridKNN.build(Tg.points, cell_size=0.3)),
+                   ("grid, 0.15 m cells", sp.GridKNN.build(Tg.points, cell_size=0.15))):
     prep = sp.PreparedTarget(grid, Tg.covs)
+    print(name, "cell", round(grid.cell_size(), 3), "fullest", grid.max_cell_points())
     for wq in (2, 0):
         reg = sp.Registration(sp.RegistrationParams(max_iterations=ITERS, criteria_rotation=0.0, criteria_translation=0.0,
                                                     optimization_method="GN"))
