@@ -834,11 +834,12 @@ __global__ __launch_bounds__(kBlock) void knn_bf_select_kernel(const float4* __r
 // dozen launches (boxes, frames, pass A on the matrix cores, offsets, lists, collect, select): ~110 us for two 6 k-point clouds
 // with k = 10 whatever the work; this is one launch of ~10 k wave instructions per four queries.
 constexpr unsigned kSmallMinTargets = 256, kSmallMaxTargets = 12032;
-constexpr int kSmallBlock = 512, kSmallQ = 4;
+constexpr int kSmallBlock = 512, kSmallQMax = 4;  // lanes a workgroup; queries a wave scans together (1 .. 4: template parameter)
 constexpr unsigned kSmallListCap = 64;
 constexpr size_t small_lds_bytes(unsigned nt) {
-    return (size_t)3 * ((nt + 63u) & ~63u) * sizeof(float) + (size_t)(kSmallBlock / 64) * kSmallQ * kSmallListCap * sizeof(unsigned long long);
+    return (size_t)3 * ((nt + 63u) & ~63u) * sizeof(float) + (size_t)(kSmallBlock / 64) * kSmallQMax * kSmallListCap * sizeof(unsigned long long);
 }
+template <int kSmallQ>
 __global__ __launch_bounds__(kSmallBlock) void knn_bf_small_kernel(const float4* __restrict__ queries, unsigned nq,
                                                                    const float4* __restrict__ targets, unsigned nt, int k,
                                                                    int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
@@ -948,15 +949,29 @@ bool small_applies(size_t nq, size_t nt) {
 }
 int run_small(const float* queries, size_t nq, const float* targets, size_t nt, size_t k, int32_t* idx_out, float* d2_out,
               hipStream_t st) {
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_bf_small_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)small_lds_bytes(kSmallMaxTargets)) == hipSuccess;
+    auto set_lds = [](const void* f) {
+        return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(kSmallMaxTargets)) == hipSuccess;
+    };
+    static const bool attr_ok = set_lds(reinterpret_cast<const void*>(knn_bf_small_kernel<1>)) &&
+                                set_lds(reinterpret_cast<const void*>(knn_bf_small_kernel<2>)) &&
+                                set_lds(reinterpret_cast<const void*>(knn_bf_small_kernel<3>)) &&
+                                set_lds(reinterpret_cast<const void*>(knn_bf_small_kernel<4>));
     if (!attr_ok) return SP_ERR_HIP;
-    const unsigned groups = (unsigned)((nq + kSmallQ - 1) / kSmallQ);
+    // queries a wave scans together: as few as give every one of the device's 256 x 8 waves a group (a group's time is its scan's
+    // latency, and a wave with nothing to do is a quarter of a CU idle: 6 k queries by fours leave a quarter of the waves empty)
+    constexpr unsigned kWavesAll = 256u * (kSmallBlock / 64);
+    const int q = (int)std::min<size_t>(kSmallQMax, std::max<size_t>(1, (nq + kWavesAll - 1) / kWavesAll));
+    const unsigned groups = (unsigned)((nq + q - 1) / q);
     const unsigned grid = std::min(256u, (groups + kSmallBlock / 64 - 1) / (kSmallBlock / 64));
-    knn_bf_small_kernel<<<grid, kSmallBlock, small_lds_bytes((unsigned)nt), st>>>(
-        reinterpret_cast<const float4*>(queries), (unsigned)nq, reinterpret_cast<const float4*>(targets), (unsigned)nt, (int)k,
-        idx_out, d2_out);
+    const float4* const qp = reinterpret_cast<const float4*>(queries);
+    const float4* const tp = reinterpret_cast<const float4*>(targets);
+    const size_t lds = small_lds_bytes((unsigned)nt);
+    switch (q) {
+        case 1: knn_bf_small_kernel<1><<<grid, kSmallBlock, lds, st>>>(qp, (unsigned)nq, tp, (unsigned)nt, (int)k, idx_out, d2_out); break;
+        case 2: knn_bf_small_kernel<2><<<grid, kSmallBlock, lds, st>>>(qp, (unsigned)nq, tp, (unsigned)nt, (int)k, idx_out, d2_out); break;
+        case 3: knn_bf_small_kernel<3><<<grid, kSmallBlock, lds, st>>>(qp, (unsigned)nq, tp, (unsigned)nt, (int)k, idx_out, d2_out); break;
+        default: knn_bf_small_kernel<4><<<grid, kSmallBlock, lds, st>>>(qp, (unsigned)nq, tp, (unsigned)nt, (int)k, idx_out, d2_out); break;
+    }
     return launch_status();
 }
 
