@@ -220,7 +220,7 @@ INTERNAL_SIGNATURES = {
 }
 VOXEL_BOX_SHARDS, VOXEL_BOX_SHARD_STRIDE = 16, 32  # SP_VOXEL_BOX_SHARDS, SP_VOXEL_BOX_SHARD_STRIDE
 INTERNAL_OPTION = {"stage_mask": 0, "reuse": 1, "fast_nn": 2, "self_knn_mode": 3, "persistent": 4, "persistent_from": 5,
-                   "bvh_self_heap": 6, "bvh_sort_queries": 7, "grid_sort_queries": 8, "opt_wave_query": 9}
+                   "bvh_self_heap": 6, "bvh_sort_queries": 7, "grid_sort_queries": 8, "opt_wave_query": 9, "opt_fuse_trials": 10}
 
 
 def build(force=False):

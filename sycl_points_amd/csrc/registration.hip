@@ -1441,7 +1441,7 @@ extern "C" int sp_gicp_target_has_certificates(const sp_gicp_target* t) { return
 
 extern "C" void sp_gicp_source_destroy(sp_gicp_source* s) {
     if (!s) return;
-    (void)hipFree(s->pts); (void)hipFree(s->covp); (void)hipFree(s->perm); (void)hipFree(s->ccache); (void)hipFree(s->opt_rows);
+    (void)hipFree(s->pts); (void)hipFree(s->covp); (void)hipFree(s->perm); (void)hipFree(s->ccache); (void)hipFree(s->ccache2); (void)hipFree(s->opt_rows);
     (void)hipFree(s->keys_in); (void)hipFree(s->keys_out); (void)hipFree(s->vals_in); (void)hipFree(s->sort_tmp);
     delete s;
 }
@@ -1458,6 +1458,7 @@ extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     if (e == hipSuccess) e = hipMalloc(&s->covp, (n + 64) * 2 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->perm, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->ccache, n * 3 * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&s->ccache2, std::min<size_t>(n, 2048) * 3 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->opt_rows, sp::kOptRowsBytes);
     if (e == hipSuccess) e = hipMemset(s->opt_rows, 0, sp::kOptRowsBytes);
     if (e == hipSuccess) e = hipMalloc(&s->keys_in, n * 4);
@@ -2043,6 +2044,7 @@ extern "C" int sp_internal_source_option(sp_gicp_source* s, int option, int valu
         case SP_INTERNAL_FUSED_PERSISTENT: s->opt_persistent = value; return SP_OK;
         case SP_INTERNAL_FUSED_PERSISTENT_FROM: s->opt_persistent_from = value < 0 ? 0 : value; return SP_OK;
         case SP_INTERNAL_OPT_WAVE_QUERY: s->opt_wave_query = value; return SP_OK;
+        case SP_INTERNAL_OPT_FUSE_TRIALS: s->opt_fuse_trials = value; return SP_OK;
     }
     return SP_ERR_INVALID_ARGUMENT;
 }

@@ -561,9 +561,12 @@ __device__ __forceinline__ void fused_point_wave(const FusedParams& P, const Rig
 //   the previous winner's distance (a seed: a real point, so the scan is exact and its ball a fraction of a cell), or
 //   half a cell when there is no previous winner (anything found inside is the nearest neighbour), then the search bound's ball,
 // the winner's prepared row, the arithmetic of fused_point (same correspondences, same per-point terms).
+// rows_out (optional): the cache rows this linearisation LEAVES — another set than the one it reads (P.ccache) when the step
+// is speculative (registration_opt.hip: an LM / dog-leg trial and the linearisation at its pose in one step; the rows read stay
+// what the trial's frozen correspondences are). Every point's row is then written: found anew, or copied when its certificate held.
 template <int LOSS, bool P2D = false>
 __device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
-                                                 unsigned& cnt, unsigned& searched) {
+                                                 unsigned& cnt, unsigned& searched, float4* rows_out = nullptr) {
     SP_PSTAMP(0);
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
     float qx, qy, qz;
@@ -573,6 +576,7 @@ __device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rig
     Sym3 Ct{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     bool hit = false, seeded = false;
     float4* const row = P.ccache + 3 * (size_t)i;
+    float4* const row_out = rows_out ? rows_out + 3 * (size_t)i : row;
     if (P.cache_valid) {
         const float4 r0 = row[0], r1 = row[1], r2 = row[2];
         const float d = dist2(qx, qy, qz, r0.x, r0.y, r0.z);
@@ -582,6 +586,7 @@ __device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rig
             nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
             nn.d2 = nn.idx >= 0 ? d : FLT_MAX;
             Ct = Sym3{r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+            if (row_out != row) { row_out[0] = r0; row_out[1] = r1; row_out[2] = r2; }
         } else if (__float_as_int(r2.z) >= 0) {  // the previous winner: a real point, an upper bound
             nn.d2 = d; nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
             seeded = true;
@@ -606,7 +611,7 @@ __device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rig
         }
         if (nn.idx < 0) nn.d2 = FLT_MAX;
         SP_PSTAMP(2); SP_PSTAMP(3); SP_PSTAMP(4);
-        store_correspondence(row, P, nn, Ct, qx, qy, qz, margin2);  // (64 lanes, one address each, the same bits)
+        store_correspondence(row_out, P, nn, Ct, qx, qy, qz, margin2);  // (64 lanes, one address each, the same bits)
         SP_PSTAMP(5);
     }
     if (nn.idx < 0 || nn.d2 > P.max_d2) return;
@@ -736,6 +741,7 @@ struct sp_gicp_source {
     float4* covp = nullptr;   // 2 x float4 per point, prepared order
     unsigned* perm = nullptr; // prepared position -> original index
     float4* ccache = nullptr;      // 3 x float4 per prepared point: its previous correspondence (see fused_point)
+    float4* ccache2 = nullptr;     // a second set of cache rows for sp_gicp_align_optimize's fused trial + linearisation steps (min(n_max, 2048) points)
     unsigned long long* opt_rows = nullptr;  // sp_gicp_align_optimize, wave-per-point launches: tagged partial rows (kOptRowsBytes)
     mutable unsigned opt_epoch = 0;          // ... and the epoch of the latest such launch (12 bits of every row tag)
     mutable bool cache_valid = false;  // set by the first linearisation after prepare
@@ -748,6 +754,7 @@ struct sp_gicp_source {
     int opt_fast_nn = -1;    // -1: automatic (2x2x2 fast path when the source is cell-sorted), 0 / 1: forced
     int opt_persistent = 1;  // sp_gicp_align_fused: 1 the tail of an alignment as one launch when the grid is resident, 0 a launch per iteration
     int opt_persistent_from = 4;  // first iteration of that tail
+    int opt_fuse_trials = 1; // sp_gicp_align_optimize, wave-per-point launches: LM / dog-leg trial steps also linearise at the trial pose (sp_internal.h)
     int opt_wave_query = 1;  // sp_gicp_align_optimize, small sources: one wave per point in the linearisation steps
     unsigned *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void* sort_tmp = nullptr;

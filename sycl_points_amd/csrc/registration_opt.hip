@@ -26,7 +26,10 @@
 namespace sp {
 namespace {
 
-enum { PHASE_LIN = 0, PHASE_TRIAL = 1 };
+// PHASE_FUSED (wave-per-point launches of 256-lane workgroups): a trial step that ALSO linearises at the trial pose, into the
+// other set of cache rows — accepted trials are the rule, and the linearisation of the next outer iteration is then already
+// there: an outer iteration costs one step (one hand-off between the workgroups) instead of two.
+enum { PHASE_LIN = 0, PHASE_TRIAL = 1, PHASE_FUSED = 2 };
 
 struct OptCtl {  // the optimiser's state between steps (LDS, identical in every workgroup)
     int phase;
@@ -42,6 +45,9 @@ struct OptCtl {  // the optimiser's state between steps (LDS, identical in every
     float res_error;
     unsigned res_inlier, res_iterations;
     unsigned n_lin, n_trial, searched, log_n;
+    int took;             // the latest trial's pose became the pose
+    int spec_level;       // PHASE_FUSED: the level whose robust scale the speculative linearisation uses
+    int cur;              // which set of cache rows holds the correspondences of the latest linearisation (0: the source's own)
 };
 
 struct OptArgs {
@@ -49,6 +55,8 @@ struct OptArgs {
     unsigned* tickets;
     unsigned long long* trows[2];  // WAVEQ: tagged partial rows, by step parity
     unsigned tag_base;             // WAVEQ: this launch's epoch << 20 (tags of earlier launches never match: no zeroing per launch)
+    float4* rows[2];               // cache rows: [0] the source's own (what the launch leaves), [1] the other set of fused steps
+    int fuse;                      // trial steps also linearise (PHASE_FUSED)
     const float* T_init;          // device: initial guess
     float* T_out;                 // device: final pose (may alias T_init: it is read before anything is written)
     sp_opt_params opt;
@@ -177,11 +185,13 @@ __device__ __forceinline__ void opt_after_trial_impl(OptShared& S, const float* 
     const float new_error = tot[0];
     const unsigned inl = __float_as_uint(tot[1]);
     ++c.n_trial;
+    c.took = 0;
     auto take = [&] {
 #pragma unroll
         for (int i = 0; i < 16; ++i) S.sT[i] = S.sTt[i];
         c.res_error = new_error;
         c.res_inlier = inl;
+        c.took = 1;
     };
     if (o.method == SP_OPT_LEVENBERG_MARQUARDT) {
         const unsigned tries = (unsigned)c.inner + 1u;
@@ -222,6 +232,27 @@ __device__ __forceinline__ void opt_after_trial_impl(OptShared& S, const float* 
 
 // The state machine as real functions (the 1024-lane instantiations: inlined it takes the point loops' registers with it, 90
 // spilled VGPRs) and inlined (the 256-lane instantiations have 256 registers: 5.5 -> 1.5 us per linearisation step).
+// After a fused step: tot[0..29] the linearisation at the trial pose (sums | count | searched), tot[30] / tot[31] the trial's
+// robust error / inlier count. The trial is decided exactly as a plain trial step decides it; when its pose was taken and what
+// follows is the linearisation that was speculated on (same pose, the level whose scale it used), that linearisation is adopted
+// as if its step had just run: the same sequence of state-machine calls as the unfused loop, one hand-off less.
+__device__ __forceinline__ void opt_after_fused_impl(OptShared& S, const float* tot, bool publish) {
+    OptCtl& c = S.ctl;
+    const float trial[2] = {tot[30], tot[31]};
+    opt_after_trial_impl(S, trial, publish);
+    if (!c.done && c.took && c.phase == PHASE_LIN && c.level == c.spec_level) {
+        c.cur ^= 1;  // the rows the speculative linearisation wrote are the correspondences now
+        opt_after_linearize_impl(S, tot, publish);
+    }
+}
+// A trial is due: make it a fused step when there is a linearisation to speculate on (an accepted trial that ends the last level
+// is followed by nothing).
+__device__ __forceinline__ void opt_upgrade_trial(OptShared& S, int fuse) {
+    OptCtl& c = S.ctl;
+    if (!fuse || c.done || c.phase != PHASE_TRIAL) return;
+    const int next = (c.conv_any || c.iter + 1 >= S.opt.max_iterations) ? c.level + 1 : c.level;
+    if (next < S.n_levels) { c.phase = PHASE_FUSED; c.spec_level = next; }
+}
 __device__ __noinline__ void opt_after_linearize_call(OptShared& S, const float* tot, bool publish) { opt_after_linearize_impl(S, tot, publish); }
 __device__ __noinline__ void opt_after_trial_call(OptShared& S, const float* tot, bool publish) { opt_after_trial_impl(S, tot, publish); }
 
@@ -264,14 +295,15 @@ __device__ __forceinline__ void opt_publish(float* T_out, const OptShared& S) {
 // every workgroup. On return red[0][e] holds the totals (slot nv the uint32 count); false: the wait ran out.
 template <int BLOCK>
 __device__ __forceinline__ bool tagged_rows_exchange(unsigned long long* rows, unsigned tag, float mine, unsigned grid, int nv,
-                                                     float (*red)[kPartial], unsigned long long budget, unsigned* s_wait) {
+                                                     float (*red)[kPartial], unsigned long long budget, unsigned* s_wait,
+                                                     unsigned more_counts = 0u) {
     constexpr unsigned kGroups = BLOCK / 32;
     constexpr int kPer = kAlignMaxBlocks / (int)kGroups;
     const unsigned e = threadIdx.x & 31u, grp = threadIdx.x >> 5;
     if (threadIdx.x < 32)
         __hip_atomic_store(rows + (size_t)blockIdx.x * 32 + e, ((unsigned long long)tag << 32) | __float_as_uint(mine),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool is_count = (int)e == nv;
+    const bool is_count = (int)e == nv || ((more_counts >> e) & 1u) != 0u;  // (slots summed as uint32 counts)
     const unsigned long long t0 = wall_clock64();
     for (;;) {
         unsigned long long g[kPer];
@@ -317,25 +349,31 @@ __device__ __forceinline__ bool tagged_rows_exchange(unsigned long long* rows, u
 }
 // A workgroup's totals of a wave-per-point step: every lane of a wave holds the wave's sums, so lane 0 of each wave hands them
 // over and lane e < 32 returns slot e of the workgroup's row (sums | uint32 count bits | searched as a float value | zeros).
+// A fused step (NV = 28) also hands over its trial: slot 30 the robust error (a float sum), slot 31 the inlier count (uint32 bits).
 template <int NV, int BLOCK>
-__device__ __forceinline__ float waveq_row_slot(const float (&acc)[NV], unsigned cnt, unsigned extra, float (*red)[kPartial]) {
+__device__ __forceinline__ float waveq_row_slot(const float (&acc)[NV], unsigned cnt, unsigned extra, float (*red)[kPartial],
+                                                float trial_error = 0.0f, unsigned trial_cnt = 0u) {
     const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lane == 0) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) red[wave][e] = acc[e];
         red[wave][NV] = __uint_as_float(cnt);
         red[wave][NV + 1] = __uint_as_float(extra);
+        if (NV + 3 < kPartial) {
+            red[wave][kPartial - 2] = trial_error;
+            red[wave][kPartial - 1] = __uint_as_float(trial_cnt);
+        }
     }
     __syncthreads();
     float v = 0.0f;
-    if ((int)threadIdx.x < NV) {
+    if ((int)threadIdx.x < NV || (NV + 3 < kPartial && (int)threadIdx.x == kPartial - 2)) {
 #pragma unroll
         for (int w = 0; w < BLOCK / kWave; ++w) v += red[w][threadIdx.x];
-    } else if ((int)threadIdx.x == NV || (int)threadIdx.x == NV + 1) {
+    } else if ((int)threadIdx.x == NV || (int)threadIdx.x == NV + 1 || (NV + 3 < kPartial && (int)threadIdx.x == kPartial - 1)) {
         unsigned c = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / kWave; ++w) c += __float_as_uint(red[w][threadIdx.x]);
-        v = (int)threadIdx.x == NV ? __uint_as_float(c) : (float)c;
+        v = (int)threadIdx.x == NV + 1 ? (float)c : __uint_as_float(c);
     }
     return v;
 }
@@ -373,6 +411,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
         c.conv_ok = 0; c.conv_any = 0; c.converged = 0;
         c.res_error = FLT_MAX; c.res_inlier = 0; c.res_iterations = 0;
         c.n_lin = 0; c.n_trial = 0; c.searched = 0; c.log_n = 0;
+        c.took = 0; c.spec_level = 0; c.cur = 0;
         S.ctl = c;
         S.opt = A.opt;
         S.n_levels = A.n_levels;
@@ -406,6 +445,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
         SP_WG_BEGIN();
         float* const row = A.part[step & 1] + (size_t)blockIdx.x * kPartial;
         [[maybe_unused]] float mine = 0.0f;  // WAVEQ: slot threadIdx.x < 32 of this workgroup's row
+        if constexpr (WAVEQ) P.ccache = A.rows[S.ctl.cur];  // (uniform; the other kinds of launch never leave set 0)
         if (phase == PHASE_LIN) {
             P.scale = A.scales[S.ctl.level];
             P.cache_valid = S.ctl.cache_valid;
@@ -433,9 +473,35 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
                 if (single) block_reduce_lds<kAcc - 1, BLOCK>(acc, cnt, searched, red[0]);
                 else block_reduce_store<kAcc - 1, BLOCK, true>(acc, cnt, row, false, searched);
             }
+        } else if (WAVEQ && phase == PHASE_FUSED) {
+            if constexpr (WAVEQ) {
+                // the trial (frozen correspondences of the current rows, this level's scale) and the linearisation at its pose
+                // (fresh correspondences into the OTHER rows, the scale of the level that would follow) in one pass
+                const Rigid T = uniform_pose(S.sTt);
+                const Rigid TL = uniform_pose(S.sTlin);
+                float acc[kAcc - 1], acc_t[1] = {0.0f};
+                unsigned cnt = 0, searched = 0, cnt_t = 0;
+#pragma unroll
+                for (int e = 0; e < kAcc - 1; ++e) acc[e] = 0.0f;
+                float4* const rows_out = A.rows[S.ctl.cur ^ 1];
+                const float scale_trial = A.scales[S.ctl.level], scale_lin = A.scales[S.ctl.spec_level];
+                const int reuse = S.reuse;
+                const unsigned nw = BLOCK / kWave;
+                const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+                for (unsigned i = blockIdx.x * nw + wave; i < P.n; i += gridDim.x * nw) {
+                    P.scale = scale_trial;
+                    error_prepared_point<LOSS, P2D>(P, T, TL, i, acc_t, cnt_t);
+                    P.scale = scale_lin;
+                    P.cache_valid = reuse;
+                    fused_query_wave<LOSS, P2D>(P, T, i, acc, cnt, searched, rows_out);
+                }
+                SP_STAMP(4);
+                mine = waveq_row_slot<kAcc - 1, BLOCK>(acc, cnt, searched, red, acc_t[0], cnt_t);
+            }
         } else {
             const Rigid T = uniform_pose(S.sTt);
             const Rigid TL = uniform_pose(S.sTlin);
+            P.scale = A.scales[S.ctl.level];
             float acc[1] = {0.0f};
             unsigned cnt = 0;
             if constexpr (WAVEQ) {
@@ -466,8 +532,9 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
                 __syncthreads();
                 if (threadIdx.x < 32) red[0][threadIdx.x] = mine;
                 __syncthreads();
-            } else if (!tagged_rows_exchange<BLOCK>(A.trows[step & 1], A.tag_base | ((step + 1u) & 0xfffffu), mine, gridDim.x, phase == PHASE_LIN ? kAcc - 1 : 1,
-                                                    red, A.budget, &s_wait)) {
+            } else if (!tagged_rows_exchange<BLOCK>(A.trows[step & 1], A.tag_base | ((step + 1u) & 0xfffffu), mine, gridDim.x,
+                                                    phase == PHASE_TRIAL ? 1 : kAcc - 1, red, A.budget, &s_wait,
+                                                    phase == PHASE_FUSED ? 1u << (kPartial - 1) : 0u)) {
                 wait_ran_out();
                 return;
             }
@@ -504,7 +571,9 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
         if (threadIdx.x == 0) {
             if constexpr (BLOCK <= 256) {
                 if (phase == PHASE_LIN) opt_after_linearize_impl(S, red[0], publish);
+                else if (WAVEQ && phase == PHASE_FUSED) opt_after_fused_impl(S, red[0], publish);
                 else opt_after_trial_impl(S, red[0], publish);
+                if constexpr (WAVEQ) opt_upgrade_trial(S, A.fuse);
             } else {
                 if (phase == PHASE_LIN) opt_after_linearize_call(S, red[0], publish);
                 else opt_after_trial_call(S, red[0], publish);
@@ -517,6 +586,15 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
             if (publish) g_sp_step = 0;
 #endif
             if (publish) opt_publish(A.T_out, S);
+            if constexpr (WAVEQ) {
+                if (S.ctl.cur != 0) {  // the launch leaves its correspondences in the source's own rows: every wave copies its points'
+                    const unsigned nw = BLOCK / kWave;
+                    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+                    const unsigned lane = threadIdx.x & (kWave - 1);
+                    for (unsigned i = blockIdx.x * nw + wave; i < P.n; i += gridDim.x * nw)
+                        if (lane < 3) A.rows[0][3 * (size_t)i + lane] = A.rows[1][3 * (size_t)i + lane];
+                }
+            }
             return;
         }
     }
@@ -595,6 +673,11 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     A.tickets = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kTicketOffsetBytes);
     A.trows[0] = source->opt_rows;
     A.trows[1] = source->opt_rows + (size_t)kAlignMaxBlocks * 32;
+    A.rows[0] = source->ccache;
+    A.rows[1] = source->ccache2;
+    // (trial steps that also linearise: the wave-per-point launches of 256-lane workgroups, where a step is a hand-off between
+    // hundreds of workgroups around two microseconds of work)
+    A.fuse = (waveq && wq_block == 256u && source->ccache2 != nullptr && source->opt_fuse_trials) ? 1 : 0;
     A.tag_base = 0;
     if (grid > 1 && waveq) {
         // a row's tag is (epoch of the launch, step): rows left by earlier launches never match, so nothing is zeroed per launch —

@@ -43,7 +43,11 @@ enum {
     SP_INTERNAL_GRID_SORT_QUERIES = 8,
     /* sp_gicp_source: sp_gicp_align_optimize on a source of up to 2048 points: one wave per point in the linearisation steps
      * (1, default) or one lane per point (0). Same correspondences either way; the sums are grouped differently. */
-    SP_INTERNAL_OPT_WAVE_QUERY = 9
+    SP_INTERNAL_OPT_WAVE_QUERY = 9,
+    /* sp_gicp_source: sp_gicp_align_optimize, wave-per-point launches of up to 2048 points: an LM / dog-leg trial step also
+     * linearises at the trial pose (1, default: an accepted trial's next linearisation is then already there) or not (0). The
+     * same sequence of optimiser decisions either way. */
+    SP_INTERNAL_OPT_FUSE_TRIALS = 10
 };
 
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);

@@ -220,6 +220,49 @@ def test_wave_per_point_and_lane_per_point_agree(sp, orc, n, opt, reg_type):
         assert w.searched == l.searched and w.inlier == l.inlier and w.iterations == l.iterations and w.converged == l.converged
 
 
+@pytest.mark.parametrize("n", [900, 1900])
+@pytest.mark.parametrize("opt,reg_type,loss", [("LM", "GICP", "GEMAN_MCCLURE"), ("DOGLEG", "GICP", "CAUCHY"),
+                                               ("LM", "POINT_TO_DISTRIBUTION", "NONE")])
+def test_fused_trial_and_linearisation_steps_change_nothing(sp, orc, n, opt, reg_type, loss):
+    """Wave-per-point launches run an LM / dog-leg trial and the linearisation at the trial pose as ONE step (the linearisation
+    goes to a second set of cache rows and is adopted when the trial is accepted). Same per-point arithmetic, same grouping of
+    the sums, same sequence of state-machine calls as with the switch off: every output bit-identical — pose, H, b, error,
+    counters, the per-iteration log — over three annealing levels, with a third of the source outside the target, and the
+    source's cache rows afterwards (the frozen error of compute_error_frozen reads them)."""
+    src, scov, tgt, tcov, T_gt = inputs(orc, n, 8.0, seed=13)
+    src = src.copy()
+    src[::3, 0] += 100.0
+    S = sp.PointCloudShared(dev(src), covs=dev(scov))
+    prep = sp.PreparedTarget(sp.GridKNN.build(dev(tgt)), dev(tcov), reg_type=reg_type)
+    T0 = orc.se3_exp([0.02, -0.01, 0.015, 0.08, -0.05, 0.04])
+    p = sp.RegistrationParams(reg_type=reg_type, robust_type=loss, robust_default_scale=1.0, optimization_method=opt,
+                              max_iterations=8, max_correspondence_distance=0.8)
+    scales = [4.0, 2.0, 1.0] if loss != "NONE" else [1.0]
+    out, frozen = {}, {}
+    L = sp._lib.lib()
+    for fuse in (1, 0):
+        reg = sp.Registration(p)
+        reg._set_source_option("opt_fuse_trials", fuse)
+        r = reg.align_optimize(S, prep, T0, scales)
+        assert r is not None
+        out[fuse] = r
+        ws, lin = reg._buffers(S.points.device)
+        fp = reg._factor_params(scales[-1])
+        Tl = np.ascontiguousarray(r.T_lin.T).reshape(-1)
+        Tt = np.ascontiguousarray(r.T.T).reshape(-1)
+        sp.check(L.sp_gicp_error_prepared(prep._h, reg._psrc._h, Tl.ctypes.data_as(C.c_void_p), Tt.ctypes.data_as(C.c_void_p), 0,
+                                          C.byref(fp), sp._ptr(lin), sp._ptr(ws), ws.numel(), sp._stream()))
+        got = reg._read_lin(lin)
+        frozen[fuse] = (got.error, got.inlier)
+    a, b = out[1], out[0]
+    assert np.array_equal(a.T, b.T) and np.array_equal(a.T_lin, b.T_lin) and np.array_equal(a.H, b.H) and np.array_equal(a.b, b.b)
+    assert (a.error, a.inlier, a.iterations, a.converged) == (b.error, b.inlier, b.iterations, b.converged)
+    assert (a.linearizations, a.trials, a.searched) == (b.linearizations, b.trials, b.searched)
+    assert a.log == b.log and len(a.log) >= 3
+    assert frozen[1] == frozen[0]
+    assert a.trials >= 2
+
+
 def test_wave_per_point_forced_on_a_crowded_target(sp, orc):
     """sp_gicp_source_set_wave_per_point(source, 2): a wave per source point for sources of up to 131072 points, what the facade
     asks for when the target grid's fullest cell holds hundreds of points (a raw LiDAR scan: thousands of returns at the sensor).
