@@ -53,6 +53,42 @@ inline void* pinned_block_4k() {
     }();
     return p;
 }
+/// A count a kernel hands to the host WITHOUT a copy and a stream synchronisation: the kernel stores it through the device
+/// pointer of a host-mapped pinned word, the host spins on the word (armed with a value no count takes). A D2H copy + a
+/// hipStreamSynchronize is 15-20 us of runtime calls and wake-up for four bytes; the spin sees the store a microsecond or two
+/// after it lands. Later work on the stream stays ordered behind the kernel as ever; the kernel's OTHER outputs may still be in
+/// flight when the count arrives (they stay on the device). One word per host thread.
+struct MappedWord {
+    volatile uint32_t* host = nullptr;
+    uint32_t* dev = nullptr;
+    static constexpr uint32_t kArmed = 0xffffffffu;
+    static MappedWord& mine() {
+        thread_local MappedWord w = [] {
+            MappedWord m;
+            void* h = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return m; }
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return m; }
+            m.host = static_cast<volatile uint32_t*>(h);
+            m.dev = static_cast<uint32_t*>(d);
+            return m;
+        }();
+        return w;
+    }
+    bool usable() const { return host != nullptr; }
+    void arm() const { *host = kArmed; }
+    /// the value once the kernel has stored it; a stream error (the kernel never ran) ends the wait through the synchronisation
+    uint32_t wait(hipStream_t st) const {
+        for (unsigned spins = 0;; ++spins) {
+            const uint32_t v = *host;
+            if (v != kArmed) return v;
+            if (spins > (1u << 22)) {  // (tens of milliseconds: something is wrong or the device is very busy — fall back to waiting)
+                hip_check(hipStreamSynchronize(st), "sync");
+                return *host;
+            }
+        }
+    }
+};
 inline uint32_t read_u32(const void* dev, hipStream_t st) {
     static std::mutex m;  // one pinned word for the process: read-backs are short and rare
     std::lock_guard<std::mutex> lock(m);
@@ -362,9 +398,10 @@ public:
                     float max_distance = std::numeric_limits<float>::max()) {
         const size_t N = source.size();
         if (N == 0) return;
-        throw_on_error(sp_box_filter_flags(source.points_device(), N, min_distance, max_distance,
-                                           flags_->device_data_for_write(N), queue_.stream()));
+        // the box test, the scan of its flags and the move of every attribute's kept rows in one launch (sp_box_filter_compact_multi)
+        box_ = BoxArgs{true, min_distance, max_distance};
         apply_flags(source, output);
+        box_.on = false;
     }
     void box_filter(PointCloudShared& data, float min_distance = 1.0f, float max_distance = std::numeric_limits<float>::max()) {
         box_filter(data, data, min_distance, max_distance);
@@ -463,10 +500,20 @@ private:
                 ::sycl_points::detail::DeviceBufferCache::release(p, bytes, *tag, *tag == nullptr);
             }
         } ws(ws_bytes, &ws_release_stream, st), count(4, &ws_release_stream, st);
-        throw_on_error(sp_compact_by_flags_multi(rows, bytes, dst, na, N, flags_->device_data(), nullptr,
-                                                 static_cast<uint32_t*>(count.p), ws.p, ws_bytes, st));
+        // the count comes through a host-mapped word the kernel stores to (no copy, no synchronisation) when one is to be had
+        const detail::MappedWord& mapped = detail::MappedWord::mine();
+        const bool poll = known_count == SIZE_MAX && mapped.usable();
+        uint32_t* const count_dev = poll ? mapped.dev : static_cast<uint32_t*>(count.p);
+        if (poll) mapped.arm();
+        if (box_.on)
+            throw_on_error(sp_box_filter_compact_multi(source.points_device(), N, box_.min_distance, box_.max_distance, rows, bytes, dst,
+                                                       na, flags_->device_data_for_write(N), nullptr, count_dev, ws.p, ws_bytes, st));
+        else
+            throw_on_error(sp_compact_by_flags_multi(rows, bytes, dst, na, N, flags_->device_data(), nullptr, count_dev, ws.p, ws_bytes,
+                                                     st));
         size_t M = known_count;
-        if (known_count == SIZE_MAX) M = detail::read_u32(count.p, st);  // (synchronises: the scratch is idle when it leaves scope)
+        if (poll) { M = mapped.wait(st); ws_release_stream = st; }  // (nothing synchronised: the scratch goes back behind the stream's work)
+        else if (known_count == SIZE_MAX) M = detail::read_u32(count.p, st);  // (synchronises: the scratch is idle when it leaves scope)
         else ws_release_stream = st;
         out.points->set_device_size(M);
         if (source.has_cov()) out.covs->set_device_size(M);
@@ -479,6 +526,7 @@ private:
         output.intensities = out.intensities; output.timestamp_offsets = out.timestamp_offsets;
         output.start_time_ms = t0; output.end_time_ms = t1;
     }
+    struct BoxArgs { bool on = false; float min_distance = 0.0f, max_distance = 0.0f; } box_;  // apply_flags makes the flags itself
     sycl_utils::DeviceQueue queue_;
     FilterByFlags by_flags_;
     shared_vector_ptr<uint8_t> flags_;

@@ -282,6 +282,16 @@ int sp_compact_by_flags_multi(const void* const* rows, const size_t* row_bytes, 
                               const uint8_t* flags, int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* BoxFilter + FilterByFlags in one launch (+ one that zeroes the scan's state): the box test of sp_box_filter_flags on `points`,
+ * the exclusive scan of its flags by decoupled look-back and the stable move of the kept rows of every attribute array — what
+ * PreprocessFilter::box_filter does with a cloud (preprocess_operator/box_filter_operator.hpp:24-54 + common/filter_by_flags.hpp:
+ * 30-57: a flags kernel, then one filter_by_flags per attribute). flags_out_opt receives the flags (1 keep, 0 remove), the other
+ * arguments are sp_compact_by_flags_multi's (rows_out[a] == NULL: that array is not moved). Only enqueues. */
+int sp_box_filter_compact_multi(const float* points, size_t n, float min_distance, float max_distance, const void* const* rows,
+                                const size_t* row_bytes, void* const* rows_out, int n_arrays, uint8_t* flags_out_opt,
+                                int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 /* Rows picked by index, every attribute of a cloud in ONE launch: rows_out[a][j] = rows[a][indices[j]] for j < m (indices:
  * device memory, uint32). What random sampling is once the host has drawn its sample (preprocess_operator/
  * random_sampling_operator.hpp:24-51 draws on the host, then filters by flags, common/filter_by_flags.hpp:30-57: with the indices

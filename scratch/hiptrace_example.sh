@@ -19,7 +19,7 @@ ker.sort()
 big = [i for i, a in enumerate(api) if a[2].startswith("hipMemcpy") and a[1] - a[0] > 15000]
 opt = [k for k in ker if "gicp_optimize_kernel" in k[1]]
 t_end = api[-1][1]
-t0 = [k for k in ker if "box_filter_kernel" in k[1]][-2][0] - 150000
+t0 = [k for k in ker if "compact_fused" in k[1]][-2][0] - 150000
 print("API calls of the last loop (start us | dur us | gap before us | name)")
 prev = None
 tot = collections.Counter(); cnt = collections.Counter()

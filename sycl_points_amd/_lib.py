@@ -140,6 +140,7 @@ SIGNATURES = {
     "sp_compact_by_flags": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_compact_by_flags_multi": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gather_rows_multi": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sp_box_filter_compact_multi": (_i, [_vp, _sz, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_gicp_workspace_bytes": (_sz, [_sz]),
     "sp_gicp_linearize": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _sz, _vp]),
     "sp_gicp_error": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(FactorParams), _vp, _vp, _sz, _vp]),

@@ -21,4 +21,18 @@ int radix_sort_pairs_u64(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, u
 size_t exclusive_scan_u32_workspace_bytes(size_t n);
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, void* workspace, size_t workspace_bytes,
                        hipStream_t st);
+// Stable compaction by flags in one launch (+ one zeroing launch): rows_out[a][j] = rows[a][i] for the j-th element i whose flag is
+// 1, for up to 16 attribute arrays with rows of `words` 32-bit words. flags: u8 (1 = keep) — or, with box_pts != nullptr, the box
+// filter's test on those points (box_filter_operator.hpp:31-45), the flags it makes written to flags_out (optional).
+// new_indices_out (optional): the output position of every kept element, -1 for the others. *n_out_dev: the number kept.
+struct CompactArrays {
+    const uint32_t* src[16];
+    uint32_t* dst[16];
+    unsigned words[16];
+    int n_arrays;
+};
+size_t compact_fused_workspace_bytes(size_t n);
+int compact_rows_fused(const CompactArrays& arrays, size_t n, const uint8_t* flags, const float4* box_pts, float box_min,
+                       float box_max, uint8_t* flags_out, int32_t* new_indices_out, uint32_t* n_out_dev, void* workspace,
+                       size_t workspace_bytes, hipStream_t st);
 }  // namespace sp

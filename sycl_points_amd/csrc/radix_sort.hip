@@ -23,6 +23,7 @@
 #include "sp_common.h"
 #include "sp_internal.h"
 #include "sp_lookback.h"
+#include "sp_math.h"
 
 namespace sp {
 namespace {
@@ -319,6 +320,105 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* to
     unsigned* const ws = static_cast<unsigned*>(workspace);  // [0] ticket, [64 ...] one state word per tile
     if (zero_async(ws, (tiles + 64) * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
     scan_kernel<<<tiles, kRsThreads, 0, st>>>(in, out, (unsigned)n, ws + 64, ws, device_error_word(), total_out);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------ stable compaction by flags, one launch
+// Flags (or the box filter's test that makes them), their exclusive scan and the move of the kept rows of every attribute in ONE
+// kernel: tiles of 2048 elements handed out by ticket, a lane owns four consecutive elements, the tile's offset comes by the
+// decoupled look-back of the scan above. The chain it replaces was flags | widen to u32 | zero | scan | one compaction launch per
+// attribute: at the sizes of a scan (70 k points) every one of them is launch latency.
+namespace {
+template <bool BOX>
+__global__ __launch_bounds__(kRsThreads) void compact_fused_kernel(CompactArrays A, const uint8_t* __restrict__ flags,
+                                                                   const float4* __restrict__ box_pts, float mn, float mx,
+                                                                   uint8_t* __restrict__ flags_out, unsigned n,
+                                                                   int32_t* __restrict__ new_idx, uint32_t* __restrict__ n_out,
+                                                                   unsigned* __restrict__ state, unsigned* __restrict__ ticket,
+                                                                   unsigned* __restrict__ error) {
+    __shared__ unsigned wave_tot[kRsWaves];
+    __shared__ unsigned s_tile, s_excl;
+    const unsigned tid = threadIdx.x, w = tid >> 6;
+    if (tid == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned tile = s_tile;
+    const unsigned base = tile * kRsTile + tid * kRsItems;
+    unsigned f[kRsItems];
+    unsigned sum = 0;
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        const unsigned e = base + c;
+        f[c] = 0u;
+        if (e < n) {
+            if constexpr (BOX) {  // BoxFilter (preprocess_operator/box_filter_operator.hpp:31-45), as box_filter_kernel (voxel.hip)
+                const float4 p = box_pts[e];
+                unsigned keep = 1u;
+                if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w))) {
+                    keep = 0u;
+                } else {
+                    const float linf = sycl_max(fabsf(p.x), sycl_max(fabsf(p.y), fabsf(p.z)));
+                    if (linf < mn || linf > mx) keep = 0u;
+                }
+                f[c] = keep;
+                if (flags_out) flags_out[e] = (uint8_t)keep;
+            } else {
+                f[c] = flags[e] == 1 ? 1u : 0u;  // INCLUDE_FLAG == 1 (filter_by_flags.hpp:12)
+            }
+        }
+        sum += f[c];
+    }
+    unsigned tile_total;
+    const unsigned before = block_excl_scan<kRsWaves>(sum, wave_tot, &tile_total);
+    if (w == 0) {
+        const unsigned excl = lookback_exclusive(state, tile, tile_total, error);
+        if (tid == 0) {
+            s_excl = excl;
+            // (the last tile; a system-scope store: the caller may have handed a host-mapped word it is spinning on)
+            if ((size_t)(tile + 1) * kRsTile >= n)
+                __hip_atomic_store(n_out, excl + tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    unsigned run = s_excl + before;
+#pragma unroll
+    for (int c = 0; c < kRsItems; ++c) {
+        const unsigned e = base + c;
+        if (e < n) {
+            if (new_idx) new_idx[e] = f[c] ? (int32_t)run : -1;
+            if (f[c]) {
+                for (int a = 0; a < A.n_arrays; ++a) {
+                    const unsigned words = A.words[a];
+                    if ((words & 3u) == 0u && ((reinterpret_cast<uintptr_t>(A.src[a]) | reinterpret_cast<uintptr_t>(A.dst[a])) & 15u) == 0u) {  // rows of whole, aligned 16-byte quads (points, covariances, normals)
+                        const uint4* const src = reinterpret_cast<const uint4*>(A.src[a]) + (size_t)e * (words / 4);
+                        uint4* const dst = reinterpret_cast<uint4*>(A.dst[a]) + (size_t)run * (words / 4);
+                        for (unsigned q = 0; q < words / 4; ++q) dst[q] = src[q];
+                    } else {
+                        for (unsigned d = 0; d < words; ++d) A.dst[a][(size_t)run * words + d] = A.src[a][(size_t)e * words + d];
+                    }
+                }
+            }
+            run += f[c];
+        }
+    }
+}
+}  // namespace
+
+size_t compact_fused_workspace_bytes(size_t n) { return exclusive_scan_u32_workspace_bytes(n); }
+
+int compact_rows_fused(const CompactArrays& arrays, size_t n, const uint8_t* flags, const float4* box_pts, float box_min,
+                       float box_max, uint8_t* flags_out, int32_t* new_indices_out, uint32_t* n_out_dev, void* workspace,
+                       size_t workspace_bytes, hipStream_t st) {
+    if (n == 0) return zero_async(n_out_dev, sizeof(uint32_t), st);
+    if (n >= (1ull << 30) || !workspace || workspace_bytes < compact_fused_workspace_bytes(n)) return SP_ERR_INVALID_ARGUMENT;
+    const unsigned tiles = div_up(n, (size_t)kRsTile);
+    unsigned* const ws = static_cast<unsigned*>(workspace);  // [0] ticket, [64 ...] one state word per tile
+    if (zero_async(ws, (tiles + 64) * sizeof(unsigned), st) != SP_OK) return SP_ERR_HIP;
+    if (box_pts)
+        compact_fused_kernel<true><<<tiles, kRsThreads, 0, st>>>(arrays, nullptr, box_pts, box_min, box_max, flags_out, (unsigned)n,
+                                                                  new_indices_out, n_out_dev, ws + 64, ws, device_error_word());
+    else
+        compact_fused_kernel<false><<<tiles, kRsThreads, 0, st>>>(arrays, flags, nullptr, 0.0f, 0.0f, nullptr, (unsigned)n,
+                                                                   new_indices_out, n_out_dev, ws + 64, ws, device_error_word());
     return launch_status();
 }
 

@@ -432,25 +432,6 @@ __global__ __launch_bounds__(kBlock) void box_filter_kernel(const float4* __rest
     }
     flags[i] = f;
 }
-__global__ __launch_bounds__(kBlock) void widen_flags_kernel(const uint8_t* __restrict__ flags, unsigned n,
-                                                             uint32_t* __restrict__ wide) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) wide[i] = flags[i] == 1 ? 1u : 0u;  // INCLUDE_FLAG == 1 (filter_by_flags.hpp:12)
-}
-__global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restrict__ wide,
-                                                         const uint32_t* __restrict__ pos, unsigned n,
-                                                         const uint32_t* __restrict__ rows, unsigned row_dwords,
-                                                         uint32_t* __restrict__ rows_out, int32_t* __restrict__ new_idx,
-                                                         uint32_t* __restrict__ n_out) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t f = wide[i], p = pos[i];
-    if (f && rows_out)
-        for (unsigned d = 0; d < row_dwords; ++d) rows_out[(size_t)p * row_dwords + d] = rows[(size_t)i * row_dwords + d];
-    if (new_idx) new_idx[i] = f ? (int32_t)p : -1;
-    if (i == n - 1) *n_out = p + f;
-}
-
 }  // namespace
 }  // namespace sp
 
@@ -665,36 +646,62 @@ extern "C" int sp_compact_by_flags(const void* rows, size_t n, size_t row_bytes,
                                      workspace_bytes, stream);
 }
 
+namespace sp {
+namespace {
+int check_compact_arrays(const void* const* rows, const size_t* row_bytes, void* const* rows_out, int n_arrays, size_t n,
+                         CompactArrays* out) {
+    if (n_arrays < 0 || n_arrays > 16 || (n_arrays && (!rows || !row_bytes || !rows_out))) return SP_ERR_INVALID_ARGUMENT;
+    bool ok_rows = n < (1ull << 30);
+    for (int a = 0; a < n_arrays; ++a) ok_rows = ok_rows && row_bytes[a] % 4 == 0 && row_bytes[a] != 0;
+    if (!ok_rows) {
+        sp_set_error("[FilterByFlags] row_bytes must be a positive multiple of 4 and n < 2^30");
+        return SP_ERR_INVALID_ARGUMENT;
+    }
+    int k = 0;
+    for (int a = 0; a < n_arrays; ++a) {
+        if (rows_out[a] == nullptr) continue;  // (an attribute that is only counted)
+        out->src[k] = static_cast<const uint32_t*>(rows[a]);
+        out->dst[k] = static_cast<uint32_t*>(rows_out[a]);
+        out->words[k] = (unsigned)(row_bytes[a] / 4);
+        ++k;
+    }
+    out->n_arrays = k;
+    return SP_OK;
+}
+}  // namespace
+}  // namespace sp
+
 extern "C" int sp_compact_by_flags_multi(const void* const* rows, const size_t* row_bytes, void* const* rows_out, int n_arrays,
                                          size_t n, const uint8_t* flags, int32_t* new_indices_out_opt, uint32_t* n_out_dev,
                                          void* workspace, size_t workspace_bytes, void* stream) {
     using namespace sp;
     hipStream_t st = as_stream(stream);
-    if (n_arrays < 1 || n_arrays > 16 || !rows || !row_bytes || !rows_out) return SP_ERR_INVALID_ARGUMENT;
+    if (n_arrays < 1) return SP_ERR_INVALID_ARGUMENT;
     if (n == 0) return zero_async(n_out_dev, 4, st);
-    bool ok_rows = n < (1ull << 30);
-    for (int a = 0; a < n_arrays; ++a) ok_rows = ok_rows && row_bytes[a] % 4 == 0;
-    if (!ok_rows) {
-        sp_set_error("[FilterByFlags] row_bytes must be a multiple of 4 and n < 2^30");
-        return SP_ERR_INVALID_ARGUMENT;
-    }
+    CompactArrays A;
+    if (const int rc = check_compact_arrays(rows, row_bytes, rows_out, n_arrays, n, &A); rc != SP_OK) return rc;
     if (!workspace || workspace_bytes < sp_compact_workspace_bytes(n)) {
         sp_set_error("[FilterByFlags] workspace too small (sp_compact_workspace_bytes)");
         return SP_ERR_INVALID_ARGUMENT;
     }
-    char* base = static_cast<char*>(workspace);
-    uint32_t* wide = (uint32_t*)base;
-    uint32_t* pos = (uint32_t*)(base + align_up(n * 4));
-    void* prim = base + 2 * align_up(n * 4);
-    widen_flags_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(flags, (unsigned)n, wide);
-    if (exclusive_scan_u32(wide, pos, n, nullptr, prim, exclusive_scan_u32_workspace_bytes(n), st) != SP_OK) {
-        sp_set_error("[FilterByFlags] scan failed");
-        return SP_ERR_HIP;
+    // one launch: the flags' scan by look-back and every array through it (radix_sort.hip, compact_fused_kernel)
+    return compact_rows_fused(A, n, flags, nullptr, 0.0f, 0.0f, nullptr, new_indices_out_opt, n_out_dev, workspace, workspace_bytes, st);
+}
+
+extern "C" int sp_box_filter_compact_multi(const float* points, size_t n, float min_distance, float max_distance,
+                                           const void* const* rows, const size_t* row_bytes, void* const* rows_out, int n_arrays,
+                                           uint8_t* flags_out_opt, int32_t* new_indices_out_opt, uint32_t* n_out_dev, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    using namespace sp;
+    hipStream_t st = as_stream(stream);
+    if (n == 0) return zero_async(n_out_dev, 4, st);
+    if (!points) return SP_ERR_INVALID_ARGUMENT;
+    CompactArrays A;
+    if (const int rc = check_compact_arrays(rows, row_bytes, rows_out, n_arrays, n, &A); rc != SP_OK) return rc;
+    if (!workspace || workspace_bytes < sp_compact_workspace_bytes(n)) {
+        sp_set_error("[BoxFilter] workspace too small (sp_compact_workspace_bytes)");
+        return SP_ERR_INVALID_ARGUMENT;
     }
-    // one scan of the flags, then every array through it (the new indices and the count with the first)
-    for (int a = 0; a < n_arrays; ++a)
-        compact_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(wide, pos, (unsigned)n, static_cast<const uint32_t*>(rows[a]),
-                                                             (unsigned)(row_bytes[a] / 4), static_cast<uint32_t*>(rows_out[a]),
-                                                             a == 0 ? new_indices_out_opt : nullptr, n_out_dev);
-    return launch_status();
+    return compact_rows_fused(A, n, nullptr, reinterpret_cast<const float4*>(points), min_distance, max_distance, flags_out_opt,
+                              new_indices_out_opt, n_out_dev, workspace, workspace_bytes, st);
 }
