@@ -653,6 +653,46 @@ def test_box_filter_transform_compaction(sp, orc):
     assert np.array_equal(out.normals.cpu().numpy(), orc.transform_normals(nrm, T))
 
 
+@pytest.mark.parametrize("n", [1, 777, 2048, 69088, 300001])
+def test_box_filter_and_compaction_in_one_launch(sp, orc, n):
+    # sp_box_filter_compact_multi: the box test, the scan of its flags (decoupled look-back over tiles of 2048) and the stable move
+    # of every attribute's kept rows in one kernel. Against the oracle's flags and a numpy compaction: flags, the kept rows of three
+    # arrays of different row sizes (16 B points, 64 B covariances, 4 B intensities), the new indices, the count; non-finite points,
+    # points on both bounds, several tiles, a last tile that is not full.
+    import ctypes as C
+
+    from sycl_points_amd import _lib
+
+    pts = cloud(orc, n + 3, n, 60.0)
+    if n > 10:
+        pts[3, 0] = np.nan
+        pts[5, 2] = np.inf
+        pts[7, :3] = (0.5, 0.0, 0.0)    # on the lower bound: kept
+        pts[8, :3] = (0.0, -50.0, 1.0)  # on the upper bound: kept
+    covs = np.arange(n * 16, dtype=np.float32).reshape(n, 16)
+    inten = np.arange(n, dtype=np.float32)
+    of = orc.box_filter(pts, 0.5, 50.0)
+    keep = of == 1
+    L = _lib.lib()
+    d_pts, d_cov, d_int = dev(pts), dev(covs), dev(inten)
+    o_pts, o_cov, o_int = torch.zeros_like(d_pts), torch.zeros_like(d_cov), torch.zeros_like(d_int)
+    flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    new_idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(L.sp_compact_workspace_bytes(n), 16), dtype=torch.uint8, device="cuda")
+    rows = (C.c_void_p * 3)(d_pts.data_ptr(), d_cov.data_ptr(), d_int.data_ptr())
+    outs = (C.c_void_p * 3)(o_pts.data_ptr(), o_cov.data_ptr(), o_int.data_ptr())
+    sizes = (C.c_size_t * 3)(16, 64, 4)
+    _lib.check(L.sp_box_filter_compact_multi(d_pts.data_ptr(), n, 0.5, 50.0, rows, sizes, outs, 3, flags.data_ptr(), new_idx.data_ptr(),
+                                             count.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    m = int(count.cpu()[0])
+    assert m == int(keep.sum())
+    assert np.array_equal(flags.cpu().numpy(), of)
+    assert np.array_equal(o_pts.cpu().numpy()[:m].view(np.uint32), pts[keep].view(np.uint32))
+    assert np.array_equal(o_cov.cpu().numpy()[:m], covs[keep]) and np.array_equal(o_int.cpu().numpy()[:m], inten[keep])
+    assert np.array_equal(new_idx.cpu().numpy(), np.where(keep, np.cumsum(of.astype(np.int64)) - 1, -1))
+
+
 # ------------------------------------------------------------------ K11/K12/K13 + align
 def gicp_inputs(orc, n, seed=1234):
     from sycl_points_amd.synthetic import gicp_pair
