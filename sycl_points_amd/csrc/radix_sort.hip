@@ -115,7 +115,11 @@ __global__ __launch_bounds__(kRsScanThreads) void rs_scan_kernel(unsigned* __res
     if (threadIdx.x == 0) digit_total[d] = carry;
 }
 
-template <typename KEY, int kRsBins>
+// FOLD (passes of up to kRsFoldTiles tiles: 131 k keys): there is no scan launch — tile_off holds the RAW tile histograms and
+// every workgroup sums, for each digit, the counts of the tiles before its own and of all tiles itself (a row of at most 64
+// words per lane, L2-resident): at these sizes a launch costs more than reading 64 KB again in every workgroup.
+constexpr unsigned kRsFoldTiles = 64;
+template <typename KEY, int kRsBins, bool FOLD = false>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const KEY* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 KEY* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -132,7 +136,20 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const KEY* __res
     const unsigned base = blockIdx.x * kRsTile;
     const unsigned m = min((unsigned)kRsTile, n - base);
     for (unsigned i = tid; i < kRsWaves * kRsBins; i += kRsThreads) (&cnt[0][0])[i] = 0u;
-    {   // where this tile's first key of digit `tid` goes: the keys of smaller digits + the same digit in earlier tiles
+    if constexpr (FOLD) {
+        unsigned tot = 0, bef = 0;
+        if (tid < kRsBins) {
+            const unsigned* const row = tile_off + (size_t)tid * tiles;
+#pragma unroll 8
+            for (unsigned t = 0; t < tiles; ++t) {
+                const unsigned c = row[t];
+                tot += c;
+                bef += t < blockIdx.x ? c : 0u;
+            }
+        }
+        const unsigned before = block_excl_scan<kRsWaves>(tot, wave_tot, nullptr);
+        if (tid < kRsBins) dbase[tid] = before + bef;
+    } else {   // where this tile's first key of digit `tid` goes: the keys of smaller digits + the same digit in earlier tiles
         const unsigned before = block_excl_scan<kRsWaves>(tid < kRsBins ? digit_total[tid] : 0u, wave_tot, nullptr);
         if (tid < kRsBins) dbase[tid] = before + tile_off[(size_t)tid * tiles + blockIdx.x];
     }
@@ -228,7 +245,15 @@ int radix_sort_pairs(KEY* keys_a, KEY* keys_b, uint32_t* vals_a, uint32_t* vals_
     for (unsigned shift = first_bit; shift < bits; shift += digit) {
         const unsigned width = bits - shift < digit ? bits - shift : digit;
         const unsigned mask = (1u << width) - 1u;
-        if (digit == 9u) {
+        if (tiles <= kRsFoldTiles && digit == 9u) {
+            rs_count_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            rs_scatter_kernel<KEY, 512, true><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
+                                                                            digit_total);
+        } else if (tiles <= kRsFoldTiles) {
+            rs_count_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            rs_scatter_kernel<KEY, 256, true><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
+                                                                            digit_total);
+        } else if (digit == 9u) {
             rs_count_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
             rs_scan_kernel<<<512, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
             rs_scatter_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
