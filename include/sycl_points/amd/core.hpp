@@ -144,6 +144,13 @@ struct QueueStreams {  // the live DeviceQueue streams of the process
         for (size_t i = 0; i < l.size(); ++i)
             if (l[i].first == s) { l.erase(l.begin() + (std::ptrdiff_t)i); break; }
     }
+    /// no live queue other than the one that owns `s`: nothing but work on `s` itself can touch that queue's containers
+    static bool alone(hipStream_t s) {
+        std::lock_guard<std::mutex> lock(mutex());
+        for (const auto& e : list())
+            if (e.first != s) return false;
+        return true;
+    }
     static bool is_live(hipStream_t s) {
         std::lock_guard<std::mutex> lock(mutex());
         for (const auto& e : list())
@@ -735,9 +742,15 @@ private:
                 // copy's event first (wait_upload). The wait this replaces was the 25 us the DMA takes for a 1 MB scan, during
                 // which the host could already be enqueuing the scan's first kernels.
                 hip_check(hipMemcpyAsync(dev_, host_.data(), bytes, hipMemcpyHostToDevice, stream()), "H2D");
-                if (up_ev_ == nullptr) hip_check(hipEventCreateWithFlags(&up_ev_, hipEventDisableTiming), "event");
-                hip_check(hipEventRecord(up_ev_, stream()), "event");
-                up_pending_ = true;
+                if (detail::QueueStreams::alone(stream())) {
+                    if (up_ev_ == nullptr) hip_check(hipEventCreateWithFlags(&up_ev_, hipEventDisableTiming), "event");
+                    hip_check(hipEventRecord(up_ev_, stream()), "event");
+                    up_pending_ = true;
+                } else {
+                    // (another queue exists: its kernels may read this container and are not ordered behind a copy on this
+                    // queue's stream — the copy is waited for, as every upload was before round 5)
+                    hip_check(hipStreamSynchronize(stream()), "H2D sync");
+                }
             } else if (!host_.empty()) {
                 detail::StagedCopy::h2d(dev_, host_.data(), bytes, stream());  // (synchronous: the host vector may be modified right after)
             } else {

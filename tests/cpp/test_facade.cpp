@@ -935,6 +935,49 @@ static void containers_read_from_another_queue() {
     CHECK(same);
 }
 
+static void queues_come_and_go() {
+    // Round 5's host-side machinery under churn: pooled device buffers tagged with the stream they were last used on (facade
+    // cache and library pool), pinned host blocks from a pool, uploads nobody waits for, grid builds that return unsynchronised —
+    // and queues that are created and destroyed around them (DeviceQueue's destructor retires its stream in both pools: a tag on a
+    // dead stream must never be queried). Twelve times: a new queue, a cloud on it, box filter + voxel grid + k = 10 neighbours +
+    // covariances + an alignment of a 1000-point sample against the rest, everything dropped with the queue. Every repetition's
+    // results must be the first one's, bit for bit.
+    std::mt19937 gen(11);
+    PointCloudCPU c;
+    random_points(gen, c, 90000, 12.0f);
+    std::vector<float> first_pts, first_T;
+    size_t first_n = 0;
+    bool same = true;
+    for (int rep = 0; rep < 12 && same; ++rep) {
+        sycl_utils::DeviceQueue q(0);
+        PointCloudShared cloud(q, c), boxed(q), ds(q);
+        alg::filter::PreprocessFilter pre(q);
+        pre.box_filter(cloud, boxed, 0.5f, 11.0f);
+        alg::filter::VoxelGrid vg(q, 0.4f);
+        vg.downsampling(boxed, ds);
+        auto tree = alg::knn::KDTree::build(q, ds);
+        const auto nb = tree->knn_search(ds, 10);
+        alg::covariance::estimate_async(nb, ds).wait_and_throw();
+        PointCloudShared sample(q);
+        pre.set_random_seed(7);
+        pre.random_sampling(ds, sample, 1000);
+        alg::registration::RegistrationParams rp;
+        rp.max_iterations = 5;
+        auto reg = std::make_shared<alg::registration::Registration>(q, rp);
+        TransformMatrix T0 = TransformMatrix::Identity();
+        T0(0, 3) = 0.02f;
+        const auto res = reg->align(sample, ds, *tree, T0);
+        std::vector<float> pts(4 * ds.size()), Tm(16);
+        const auto& hp = ds.points->host();
+        for (size_t i = 0; i < ds.size(); ++i) { pts[4 * i] = hp[i].x(); pts[4 * i + 1] = hp[i].y(); pts[4 * i + 2] = hp[i].z(); pts[4 * i + 3] = hp[i].w(); }
+        for (int i = 0; i < 16; ++i) Tm[i] = res.T.matrix().data()[i];
+        if (rep == 0) { first_pts = pts; first_T = Tm; first_n = ds.size(); }
+        same = ds.size() == first_n && pts == first_pts && Tm == first_T;
+    }
+    CHECK(same);
+    CHECK(first_n > 5000);
+}
+
 static void large_containers_round_trip() {
     // Uploads and downloads of a megabyte or more go through two pinned staging buffers of 8 MB (core.hpp StagedCopy): sizes
     // that are no multiple of the chunk, one chunk exactly, several chunks; device-side modification in between (a transform).
@@ -1016,6 +1059,7 @@ int main() {
     RUN(kdtree_grid_vs_bruteforce);
     RUN(kdtree_self_knn_large_clouds);
     RUN(containers_read_from_another_queue);
+    RUN(queues_come_and_go);
     RUN(large_containers_round_trip);
     RUN(large_copies_on_queues_of_two_devices);
     RUN(kdtree_backend_on_the_bundled_scan);
