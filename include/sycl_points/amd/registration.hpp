@@ -257,8 +257,7 @@ public:
         // points: that launch with a WAVE per source point (sp_gicp_source_set_wave_per_point = 2), for Gauss-Newton too: a lane
         // alone walks thousands of candidates per query there (the reference's bundled scans at full resolution: 0.21 against
         // 0.69 ms per iteration). The fullest cell is measured once per grid (a kernel and a read-back, cached by the library).
-        const bool crowded = on_device && !sharded && source.size() > 1024 && source.size() <= 131072 &&
-                             sp_grid_max_cell_points(grid->handle()) >= kCrowdedCell;
+        const bool crowded = on_device && !sharded && crowded_target(*grid, source.size());
         if (on_device && !sharded) throw_on_error(sp_gicp_source_set_wave_per_point(psrc_, crowded ? 2 : 1));
         if (on_device && !sharded &&
             (params_.optimization_method != OptimizationMethod::GAUSS_NEWTON || source.size() <= 1024 || crowded)) {
@@ -317,8 +316,7 @@ public:
             if (grid != nullptr && grid->size() == target.size() && params_.robust.type != robust::RobustLossType::NONE) {
                 fused_loop_active_ = true;
                 prepare_fused(source, target, *grid, initial_guess);
-                const bool crowded = source.size() > 1024 && source.size() <= 131072 &&
-                                     sp_grid_max_cell_points(grid->handle()) >= kCrowdedCell;  // (see align())
+                const bool crowded = crowded_target(*grid, source.size());  // (see align())
                 throw_on_error(sp_gicp_source_set_wave_per_point(psrc_, crowded ? 2 : 1));
                 if (auto r = align_optimize_on_device(initial_guess, robust_scales.data(), (int)robust_scales.size())) return *r;
             }
@@ -538,7 +536,16 @@ private:
     /// How sp_gicp_source_prepare orders the source: as it is when the caller says it is spatially ordered — or when it is a few
     /// thousand points (the pipeline's random sample): the order only decides which lane handles which point, and the cell sort
     /// is seven launches for something a handful of waves do not notice.
-    static constexpr uint32_t kCrowdedCell = 512;  // points in the target grid's fullest cell from which a wave per source point pays
+    /// Whether a source of n points is better served by a wave per point against this target (measured: scratch/waveq_crossover.py,
+    /// scratch/raw_scan_align.py, scratch/opt_example.py): a fullest cell of 512 points or more (a raw scan) for sources of up to
+    /// 131072 points; of 32 or more (a voxel-downsampled scan: surfaces) up to 16384 — the reference example's whole 6 k-point
+    /// source against its 6 k-point target: 0.28 against 0.37 ms per alignment. Up to 1024 points the launch takes that form by
+    /// itself and the grid is not asked.
+    static bool crowded_target(const knn::GridKNN& grid, size_t n) {
+        if (n <= 1024 || n > 131072) return false;
+        const uint32_t fullest = sp_grid_max_cell_points(grid.handle());
+        return fullest >= 512 || (fullest >= 32 && n <= 16384);
+    }
     int source_order(size_t n) const { return (source_presorted_ || n <= 4096) ? SP_SOURCE_PRESORTED : SP_SOURCE_SORT; }
     const knn::GridKNN* grid_for(const knn::KDTree& tree, const PointCloudShared& target) {
         if (!tree.pristine() || tree.size() != target.size() || target.size() == 0) return nullptr;
