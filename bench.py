@@ -398,6 +398,9 @@ def main():
                 hard = hard_init_block(sp, _lib, torch, S, prep, n_local, SORT_MODE, T_gt)
                 lm = lm_block(sp, torch, S, prep, n_local, SORT_MODE, T_gt)
         stages = stage_block(sp, _lib, torch, cpu=not args.no_cpu_baseline)
+        raw = raw_scan_block(sp, torch)
+        if raw is not None:
+            stages["raw_scans_full_resolution_gn"] = raw
         if not args.no_example:
             stages["example_registration_config1"] = example_block(cpu=not args.no_cpu_baseline)
     graphs_live = use_graph and any(not isinstance(v, (str, bool)) for v in getattr(reg, "_loop_graphs", {}).values())
@@ -781,6 +784,50 @@ def lm_block(sp, torch, S, prep, n, sort_mode, T_gt, reps=7):
     return out
 
 
+def raw_scan_block(sp, torch, iters=20, reps=5):
+    """The reference's bundled scans as they are (69 792 vs 69 088 points, no filter: 5032 returns sit in the sensor's own cell of
+    the in-loop grid) through the device-resident Gauss-Newton loop, `iters` iterations: one WAVE per source point (what
+    Registration::align asks for on a target with crowded cells) against one lane per point. None when the scans are not there."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    if not (os.path.exists(os.path.join(gold, "source.ply")) and os.path.exists(os.path.join(gold, "target.ply"))):
+        return None
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    try:
+        from test_gpu_facade import read_ply_xyz
+    except Exception:
+        return None
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    S = sp.PointCloudShared(dev(read_ply_xyz(os.path.join(gold, "source.ply"))))
+    Tg = sp.PointCloudShared(dev(read_ply_xyz(os.path.join(gold, "target.ply"))))
+    for c in (S, Tg):
+        sp.covariance.estimate(sp.BVH.build(c.points).self_knn(20), c)
+    grid = sp.GridKNN.build(Tg.points, points_per_cell=0.5)
+    prep = sp.PreparedTarget(grid, Tg.covs)
+    out = {"source_points": S.size(), "target_points": Tg.size(), "fullest_cell_of_the_target_grid": grid.max_cell_points(),
+           "iterations": iters}
+    poses = {}
+    for label, mode in (("wave_per_point", 2), ("lane_per_point", 0)):
+        reg = sp.Registration(sp.RegistrationParams(max_iterations=iters, criteria_rotation=0.0, criteria_translation=0.0,
+                                                    optimization_method="GN"))
+        reg._set_source_option("opt_wave_query", mode)
+        ms, res = [], None
+        for _ in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            res = reg.align_optimize(S, prep, None, None, True)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        if res is None:
+            out[label] = {"available": False}
+            continue
+        poses[label] = res.T
+        out[label] = {"us_per_iteration": 1e3 * float(np.median(ms[1:])) / iters, "inliers": res.inlier, "searched_points": res.searched}
+    if len(poses) == 2:
+        out["pose_max_abs_difference_between_the_two"] = float(np.abs(poses["wave_per_point"] - poses["lane_per_point"]).max())
+    return out
+
+
 def count_launches(torch, fn):
     """Kernel / copy / memset nodes of ONE call of fn, counted by capturing it into a hipGraph on a side stream (the C ABI's
     enqueue-only entry points are capturable). None when the call cannot be captured (it synchronises or allocates)."""
@@ -934,6 +981,19 @@ def stage_block(sp, _lib, torch, cpu=True):
             out[f"bruteforce_100k_x_100k_k{k}"].update(cpu_oracle_ms=t_cpu * (100000 / sub), cpu_cores=orc.num_threads(),
                                                          cpu_sample=f"{sub} of the 100000 queries, time scaled by {100000 // sub}")
     del tgt, qry
+    # a cloud of the size the reference's example searches (its 6 k-point downsampled scans, k = 10): ONE launch with the cloud in
+    # LDS (knn_bf_small_kernel); issue-bound, reported against the fp32 VALU roofline of the reference's 9-operation expression
+    small = torch.from_numpy(Mt19937Cloud(77).uniform_points(6096, 10.0)).cuda()
+    small_np = small.cpu().numpy()
+    ms, runs = median_ms(torch, lambda: sp.knn_search_bruteforce(small, small, 10))
+    out["bruteforce_6k_x_6k_k10_one_launch"] = {
+        "ms": ms, "runs": runs, "pairs_per_s": 6096.0 ** 2 / (ms * 1e-3), "launches": bf_launches(sp, _lib, torch, small, small, 10),
+        "bound": "fp32 VALU issue / LDS latency: two scans of the cloud (12 VALU operations per pair) + two 64-lane sorts per query",
+        "rate_vs_fp32_valu_roofline_of_the_reference_expression": 9 * 6096.0 ** 2 / (ms * 1e-3) / FP32}
+    if orc is not None:
+        out["bruteforce_6k_x_6k_k10_one_launch"].update(cpu_oracle_ms=cpu_ms(lambda: orc.knn_bruteforce(small_np, small_np, 10)),
+                                                         cpu_cores=orc.num_threads())
+    del small
     for name, R in (("sparse_R10", 10.0), ("dense_R2.5", 2.5)):
         n = 1_000_000
         P = torch.from_numpy(Mt19937Cloud(1234).uniform_points(n, R)).cuda()
