@@ -500,10 +500,16 @@ __device__ __forceinline__ void grid_nn1_ball_wave(const float4* __restrict__ pt
 // is what a small alignment waits for). `best` comes back uniform: the (distance, index)-lexicographic minimum over the ball,
 // or unchanged when nothing beats it. Exact for the reason grid_nn1_ball is.
 __device__ __forceinline__ void grid_nn1_query_wave(const float4* __restrict__ pts, const unsigned* __restrict__ start,
-                                                    const GridDesc& g, float ux, float uy, float uz, Nearest& best) {
+                                                    const GridDesc& g, float ux, float uy, float uz, float ub, Nearest& best,
+                                                    float& second2) {
+    // ub: the squared radius of the ball that is scanned (every target with d^2 <= ub lies in a scanned cell).
+    // best (in): a real point inside the ball — the previous winner, best.d2 <= ub — or {ub, -1}: only points nearer than ub count.
+    // best (out): the (distance, index)-lexicographic minimum over the ball, or unchanged when nothing qualifies.
+    // second2: a lower bound of the squared distance of every OTHER target: the runner-up of the scan, or ub when the scan saw no
+    // second point nearer than its own radius (what lies outside the ball is farther than that). The margin certificate of the
+    // wave-per-point path is built on it (registration_device.h, fused_query_wave).
     const int lane = (int)(threadIdx.x & 63u);
     auto key_of = [](float d2, int idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(idx + 0x80000000); };
-    const float ub = best.d2;
     const float rad = (sqrtf(ub) * 1.000001f + 2.0f * g.eps) * g.inv_h;  // in cells, widened like the row trimming
     const float fx = (ux - g.ox) * g.inv_h, fy = (uy - g.oy) * g.inv_h, fz = (uz - g.oz) * g.inv_h;
     auto lo_cell = [](float v, int n) { return (int)fminf(fmaxf(floorf(v), 0.0f), (float)(n - 1)); };
@@ -511,8 +517,8 @@ __device__ __forceinline__ void grid_nn1_query_wave(const float4* __restrict__ p
     const int y0 = lo_cell(fy - rad, g.ny), y1 = lo_cell(fy + rad, g.ny);
     const int z0 = lo_cell(fz - rad, g.nz), z1 = lo_cell(fz + rad, g.nz);
     const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-    const unsigned long long key0 = key_of(ub, best.idx);
-    unsigned long long key = key0;
+    constexpr unsigned long long kNone = ~0ull;
+    unsigned long long k1 = kNone, k2 = kNone;  // the lane's two nearest candidates
     unsigned bpos = 0;
     for (int r0 = 0; r0 < nrows; r0 += 64) {
         const int r = r0 + lane;
@@ -556,16 +562,24 @@ __device__ __forceinline__ void grid_nn1_query_wave(const float4* __restrict__ p
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned long long kj = key_of(dist2(ux, uy, uz, c[j].x, c[j].y, c[j].z), __float_as_int(c[j].w));
-                    const bool better = pj[j] < ej[j] && kj < key;
-                    key = better ? kj : key;
-                    bpos = better ? pj[j] : bpos;
+                    const bool valid = pj[j] < ej[j];
+                    const bool first = valid && kj < k1, runner = valid && !first && kj < k2;
+                    k2 = first ? k1 : (runner ? kj : k2);
+                    k1 = first ? kj : k1;
+                    bpos = first ? pj[j] : bpos;
                 }
             }
         }
     }
-    const unsigned long long m = wave_min_u64(key);
-    if (m != key0) {  // something beat the bound (uniform over the wave)
-        const int wl = __ffsll((long long)__ballot(key == m)) - 1;
+    const unsigned long long m = wave_min_u64(k1);
+    // the key to beat: the point handed in (it lies inside the ball, so the scan met it itself), or the bare bound
+    const unsigned long long key_in = best.idx >= 0 ? key_of(best.d2, best.idx) : key_of(ub, -1);
+    const unsigned long long winner = m < key_in ? m : (best.idx >= 0 ? key_in : kNone);  // kNone: nothing qualifies
+    const unsigned long long runner_up = wave_min_u64(k1 == winner ? k2 : k1);  // (each target once: the winner's own entry is left out)
+    second2 = ub;
+    if (winner != kNone && runner_up != kNone) second2 = fminf(ub, __uint_as_float((unsigned)(runner_up >> 32)));
+    if (m < key_in) {
+        const int wl = __ffsll((long long)__ballot(k1 == m)) - 1;
         const unsigned wpos = (unsigned)__builtin_amdgcn_readlane((int)bpos, wl);
         const float4 w = pts[wpos];
         best.d2 = __uint_as_float((unsigned)(m >> 32));

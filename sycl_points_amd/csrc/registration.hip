@@ -1441,7 +1441,7 @@ extern "C" int sp_gicp_target_has_certificates(const sp_gicp_target* t) { return
 
 extern "C" void sp_gicp_source_destroy(sp_gicp_source* s) {
     if (!s) return;
-    (void)hipFree(s->pts); (void)hipFree(s->covp); (void)hipFree(s->perm); (void)hipFree(s->ccache); (void)hipFree(s->ccache2); (void)hipFree(s->opt_rows);
+    (void)hipFree(s->pts); (void)hipFree(s->covp); (void)hipFree(s->perm); (void)hipFree(s->ccache); (void)hipFree(s->ccache2); (void)hipFree(s->qcert); (void)hipFree(s->qcert2); (void)hipFree(s->opt_rows);
     (void)hipFree(s->keys_in); (void)hipFree(s->keys_out); (void)hipFree(s->vals_in); (void)hipFree(s->sort_tmp);
     delete s;
 }
@@ -1459,6 +1459,9 @@ extern "C" int sp_gicp_source_create(size_t n_max, sp_gicp_source** out) {
     if (e == hipSuccess) e = hipMalloc(&s->perm, n * 4);
     if (e == hipSuccess) e = hipMalloc(&s->ccache, n * 3 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->ccache2, std::min<size_t>(n, 2048) * 3 * sizeof(float4));
+    s->qcert_points = std::min<size_t>(n, 131072);  // (what the wave-per-point launch serves)
+    if (e == hipSuccess) e = hipMalloc(&s->qcert, s->qcert_points * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&s->qcert2, std::min<size_t>(n, 2048) * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&s->opt_rows, sp::kOptRowsBytes);
     if (e == hipSuccess) e = hipMemset(s->opt_rows, 0, sp::kOptRowsBytes);
     if (e == hipSuccess) e = hipMalloc(&s->keys_in, n * 4);
@@ -1516,6 +1519,7 @@ extern "C" int sp_gicp_source_prepare(sp_gicp_source* s, const sp_gicp_target* t
         if (!in_b) { unsigned* t = s->perm; s->perm = s->vals_in; s->vals_in = t; }  // the sorted permutation is where the last pass wrote
     }
     s->cache_valid = false;  // no previous correspondences
+    s->qcert_valid = false;
     s->cache_target = target;
     s->cache_version = target->version;
     prepare_source_kernel<<<nb, kBlock, 0, st>>>(pts, target->reg_type == SP_REG_GICP ? reinterpret_cast<const float4*>(src_covs) : nullptr,
@@ -1569,7 +1573,7 @@ extern "C" int sp_gicp_iteration_fused(const sp_gicp_target* target, const sp_gi
         default: sp_set_error("[Registration::dispatch] Combination not found in tags!"); return SP_ERR_RUNTIME;
     }
 #undef SP_LAUNCH_FUSED
-    if (fills_cache) source->cache_valid = true;
+    if (fills_cache) { source->cache_valid = true; source->qcert_valid = false; }  // (these kernels refresh rows, not margin certificates)
     GnArgs ga{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
     if (gn) ga = GnArgs{transT, gn->lambda, gn->crit_rotation, gn->crit_translation, delta_out8};
     if (source->opt_stage_mask & 2) final_reduce_kernel<<<1, kFinalThreads, 0, st>>>(partials, grid, kAcc - 1, out, ga);
@@ -1753,7 +1757,7 @@ int align_step_impl(const sp_gicp_target* target, const sp_gicp_source* source, 
 #endif
 #undef SP_LAUNCH_ALIGN
 #undef SP_LAUNCH_ALIGN2
-    if (fills_cache) source->cache_valid = true;
+    if (fills_cache) { source->cache_valid = true; source->qcert_valid = false; }  // (these kernels refresh rows, not margin certificates)
     return launch_status();
 }
 }  // namespace
@@ -1935,7 +1939,7 @@ int launch_persistent(const sp_gicp_target* target, const sp_gicp_source* source
     }
 #endif
 #undef SP_LAUNCH_PERSIST
-    if (P.ccache != nullptr) source->cache_valid = true;
+    if (P.ccache != nullptr) { source->cache_valid = true; source->qcert_valid = false; }
     return launch_status();
 }
 }  // namespace

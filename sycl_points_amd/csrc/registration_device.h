@@ -557,16 +557,27 @@ __device__ __forceinline__ void fused_point_wave(const FusedParams& P, const Rig
 // One source point, the WHOLE WAVE (every lane calls it with the same i; what it returns in acc / cnt / searched is the same on
 // every lane: the caller keeps one lane's). For sources of a few thousand points — the reference pipeline aligns a random sample
 // of 1000 — there are more SIMDs than queries, and what a linearisation costs is the longest chain of dependent loads any one
-// lane runs into. Here a query is: cache row + certificate, else ONE ball scan by all 64 lanes (grid_nn1_query_wave) of
+// lane runs into. Here a query is: cache row + certificates, else ONE ball scan by all 64 lanes (grid_nn1_query_wave) of
 //   the previous winner's distance (a seed: a real point, so the scan is exact and its ball a fraction of a cell), or
 //   half a cell when there is no previous winner (anything found inside is the nearest neighbour), then the search bound's ball,
 // the winner's prepared row, the arithmetic of fused_point (same correspondences, same per-point terms).
-// rows_out (optional): the cache rows this linearisation LEAVES — another set than the one it reads (P.ccache) when the step
-// is speculative (registration_opt.hip: an LM / dog-leg trial and the linearisation at its pose in one step; the rows read stay
-// what the trial's frozen correspondences are). Every point's row is then written: found anew, or copied when its certificate held.
+//
+// MARGIN CERTIFICATE (qcert, optional: a float4 per source point beside its cache row). The rho certificate asks how near the
+// query is to its winner against the spacing of the TARGET; on a real scan — returns millimetres apart, the two clouds
+// centimetres — it never holds, and every iteration searched every point although the pose had stopped moving. The scan knows
+// more: d1, the winner's distance, and a lower bound d2 of every other target's (the runner-up it met, or its own radius).
+// With the query at q_s then and at q' now: |q' - u| >= d2 - |q' - q_s| for every other target u and |q' - t| <= d1 + |q' - q_s|,
+// so while the point has moved less than (d2 - d1) / 2 since it was searched, t is still the strict nearest neighbour — the
+// winner a fresh search would return, at the distance computed here. qcert = (q_s, margin^2), the margin shrunk against
+// rounding; a seeded scan reaches a little past its seed (twice the point's last move) so that there is a runner-up to measure.
+//
+// rows_out / qc_out (optional): the rows this linearisation LEAVES — another set than the one it reads when the step is
+// speculative (registration_opt.hip: an LM / dog-leg trial and the linearisation at its pose in one step; the rows read stay
+// what the trial's frozen correspondences are). Every point's rows are then written: found anew, or copied when a certificate held.
 template <int LOSS, bool P2D = false>
 __device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rigid& T, unsigned i, float (&acc)[kAcc - 1],
-                                                 unsigned& cnt, unsigned& searched, float4* rows_out = nullptr) {
+                                                 unsigned& cnt, unsigned& searched, float4* rows_out = nullptr,
+                                                 const float4* qc_in = nullptr, float4* qc_out = nullptr) {
     SP_PSTAMP(0);
     const float4 s = make_float4(P.src[i], P.src[P.sstride + i], P.src[2 * (size_t)P.sstride + i], 1.0f);
     float qx, qy, qz;
@@ -575,19 +586,25 @@ __device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rig
     nn.d2 = FLT_MAX; nn.idx = -1; nn.pos = 0; nn.x = nn.y = nn.z = 0.0f;
     Sym3 Ct{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     bool hit = false, seeded = false;
+    float moved2 = 0.0f;  // how far the point is from where it was last searched (squared)
     float4* const row = P.ccache + 3 * (size_t)i;
     float4* const row_out = rows_out ? rows_out + 3 * (size_t)i : row;
+    if (qc_in != nullptr && qc_out == nullptr) qc_out = const_cast<float4*>(qc_in);
     if (P.cache_valid) {
         const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        const float4 qc = qc_in ? qc_in[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const float d = dist2(qx, qy, qz, r0.x, r0.y, r0.z);
         const unsigned pos = __float_as_uint(r2.w);
-        if (certified(P, d, r0.w, qx, qy, qz, pos)) {
+        const bool real = __float_as_int(r2.z) >= 0;
+        if (qc_in) moved2 = dist2(qx, qy, qz, qc.x, qc.y, qc.z);
+        if (certified(P, d, r0.w, qx, qy, qz, pos) || (qc_in && real && moved2 < qc.w)) {
             hit = true;
             nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
             nn.d2 = nn.idx >= 0 ? d : FLT_MAX;
             Ct = Sym3{r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
             if (row_out != row) { row_out[0] = r0; row_out[1] = r1; row_out[2] = r2; }
-        } else if (__float_as_int(r2.z) >= 0) {  // the previous winner: a real point, an upper bound
+            if (qc_out && qc_out != qc_in) qc_out[i] = qc;
+        } else if (real) {  // the previous winner: a real point, an upper bound
             nn.d2 = d; nn.idx = __float_as_int(r2.z); nn.pos = pos; nn.x = r0.x; nn.y = r0.y; nn.z = r0.z;
             seeded = true;
         }
@@ -597,21 +614,39 @@ __device__ __forceinline__ void fused_query_wave(const FusedParams& P, const Rig
         ++searched;
         float margin2 = 0.0f;
         const float bound2 = search_bound2_margin(P, margin2);
+        float second2 = 0.0f, d1 = 0.0f;
         if (seeded && nn.d2 < bound2) {
-            grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+            // (a little past the seed — twice the point's last move, a quarter of a cell at most: room for a runner-up that tells
+            // how far the point may move before its winner can change)
+            const float pad = qc_in ? fminf(2.0f * sqrtf(moved2), 0.25f * P.g.h) : 0.0f;
+            const float reach = sqrtf(nn.d2) + pad;
+            grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, fminf(reach * reach, bound2), nn, second2);
         } else {
             const float half = 0.5f * P.g.h;
             const float first2 = fminf(half * half, bound2);
             nn.d2 = first2; nn.idx = -1; nn.pos = 0; nn.x = nn.y = nn.z = 0.0f;
-            grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+            grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, first2, nn, second2);
             if (nn.idx < 0 && first2 < bound2) {
                 nn.d2 = bound2;
-                grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, nn);
+                grid_nn1_query_wave(P.tpts, P.tstart, P.g, qx, qy, qz, bound2, nn, second2);
             }
         }
+        d1 = nn.d2;
         if (nn.idx < 0) nn.d2 = FLT_MAX;
         SP_PSTAMP(2); SP_PSTAMP(3); SP_PSTAMP(4);
         store_correspondence(row_out, P, nn, Ct, qx, qy, qz, margin2);  // (64 lanes, one address each, the same bits)
+        if (qc_out) {
+            // margin = (d2 - d1) / 2, 5 % short and less the rounding of the three distances involved (a difference of coordinates
+            // of size s is off by an ulp of s, 6e-8 s: 2e-6 s covers them several times); never more than a cell (a second
+            // target may simply not exist)
+            float m = 0.0f;
+            if (nn.idx >= 0) {
+                const float scale = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fmaxf(fabsf(qz), 1.0f));
+                m = 0.475f * (sqrtf(second2) - sqrtf(d1)) - 2.0e-6f * scale;
+                m = fminf(fmaxf(m, 0.0f), P.g.h);
+            }
+            qc_out[i] = make_float4(qx, qy, qz, m * m);
+        }
         SP_PSTAMP(5);
     }
     if (nn.idx < 0 || nn.d2 > P.max_d2) return;
@@ -741,6 +776,10 @@ struct sp_gicp_source {
     float4* covp = nullptr;   // 2 x float4 per point, prepared order
     unsigned* perm = nullptr; // prepared position -> original index
     float4* ccache = nullptr;      // 3 x float4 per prepared point: its previous correspondence (see fused_point)
+    float4* qcert = nullptr;       // margin certificates of the wave-per-point optimiser launch (fused_query_wave), qcert_points of them
+    float4* qcert2 = nullptr;      // ... and of the other row set of fused steps (min(n_max, 2048) points)
+    size_t qcert_points = 0;
+    mutable bool qcert_valid = false;  // the margin certificates belong to the cache rows as they are (only a wave-per-point launch keeps them so)
     float4* ccache2 = nullptr;     // a second set of cache rows for sp_gicp_align_optimize's fused trial + linearisation steps (min(n_max, 2048) points)
     unsigned long long* opt_rows = nullptr;  // sp_gicp_align_optimize, wave-per-point launches: tagged partial rows (kOptRowsBytes)
     mutable unsigned opt_epoch = 0;          // ... and the epoch of the latest such launch (12 bits of every row tag)

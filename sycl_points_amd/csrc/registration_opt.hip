@@ -56,6 +56,8 @@ struct OptArgs {
     unsigned long long* trows[2];  // WAVEQ: tagged partial rows, by step parity
     unsigned tag_base;             // WAVEQ: this launch's epoch << 20 (tags of earlier launches never match: no zeroing per launch)
     float4* rows[2];               // cache rows: [0] the source's own (what the launch leaves), [1] the other set of fused steps
+    float4* qcert[2];              // WAVEQ: the margin certificates beside them (null: none)
+    int qcert_trusted;             // ... and whether those of set 0 belong to its rows as the launch finds them
     int fuse;                      // trial steps also linearise (PHASE_FUSED)
     const float* T_init;          // device: initial guess
     float* T_out;                 // device: final pose (may alias T_init: it is read before anything is written)
@@ -457,8 +459,11 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
             if constexpr (WAVEQ) {
                 const unsigned nw = BLOCK / kWave;
                 const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+                // (rows that another kind of launch refreshed carry no margin certificates of their own: the launch's first
+                // linearisation only writes them)
+                const bool qc_trust = A.qcert_trusted || S.ctl.n_lin > 0;
                 for (unsigned i = blockIdx.x * nw + wave; i < P.n; i += gridDim.x * nw)
-                    fused_query_wave<LOSS, P2D>(P, T, i, acc, cnt, searched);
+                    fused_query_wave<LOSS, P2D>(P, T, i, acc, cnt, searched, nullptr, qc_trust ? A.qcert[S.ctl.cur] : nullptr, A.qcert[S.ctl.cur]);
                 SP_STAMP(4);
                 mine = waveq_row_slot<kAcc - 1, BLOCK>(acc, cnt, searched, red);
             } else if constexpr (FAST_NN && BLOCK <= 256) {  // (the staged search: open queries are finished by the whole wave)
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
                     error_prepared_point<LOSS, P2D>(P, T, TL, i, acc_t, cnt_t);
                     P.scale = scale_lin;
                     P.cache_valid = reuse;
-                    fused_query_wave<LOSS, P2D>(P, T, i, acc, cnt, searched, rows_out);
+                    fused_query_wave<LOSS, P2D>(P, T, i, acc, cnt, searched, rows_out, A.qcert[S.ctl.cur], A.qcert[S.ctl.cur ^ 1]);
                 }
                 SP_STAMP(4);
                 mine = waveq_row_slot<kAcc - 1, BLOCK>(acc, cnt, searched, red, acc_t[0], cnt_t);
@@ -593,6 +598,7 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
                     const unsigned lane = threadIdx.x & (kWave - 1);
                     for (unsigned i = blockIdx.x * nw + wave; i < P.n; i += gridDim.x * nw)
                         if (lane < 3) A.rows[0][3 * (size_t)i + lane] = A.rows[1][3 * (size_t)i + lane];
+                        else if (lane == 3 && A.qcert[0]) A.qcert[0][i] = A.qcert[1][i];
                 }
             }
             return;
@@ -675,9 +681,14 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
     A.trows[1] = source->opt_rows + (size_t)kAlignMaxBlocks * 32;
     A.rows[0] = source->ccache;
     A.rows[1] = source->ccache2;
+    // (the margin certificates: with the reuse of correspondences on, for sources the wave-per-point form serves)
+    const bool margin_certs = waveq && source->opt_reuse != 0 && source->qcert != nullptr && n <= source->qcert_points;
+    A.qcert[0] = margin_certs ? source->qcert : nullptr;
+    A.qcert[1] = margin_certs ? source->qcert2 : nullptr;
+    A.qcert_trusted = (margin_certs && source->qcert_valid && source->cache_valid) ? 1 : 0;
     // (trial steps that also linearise: the wave-per-point launches of 256-lane workgroups, where a step is a hand-off between
     // hundreds of workgroups around two microseconds of work)
-    A.fuse = (waveq && wq_block == 256u && source->ccache2 != nullptr && source->opt_fuse_trials) ? 1 : 0;
+    A.fuse = (waveq && wq_block == 256u && source->ccache2 != nullptr && source->opt_fuse_trials && (!margin_certs || source->qcert2 != nullptr)) ? 1 : 0;
     A.tag_base = 0;
     if (grid > 1 && waveq) {
         // a row's tag is (epoch of the launch, step): rows left by earlier launches never match, so nothing is zeroed per launch —
@@ -726,5 +737,6 @@ extern "C" int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gic
 #undef SP_LAUNCH_OPT2
 #undef SP_LAUNCH_OPT
     source->cache_valid = true;
+    source->qcert_valid = margin_certs;
     return launch_status();
 }

@@ -263,6 +263,48 @@ def test_fused_trial_and_linearisation_steps_change_nothing(sp, orc, n, opt, reg
     assert a.trials >= 2
 
 
+@pytest.mark.parametrize("opt,n_src", [("LM", 1500), ("GN", 1500), ("GN", 6000)])
+def test_margin_certificates_prove_their_correspondences(sp, orc, opt, n_src):
+    """The wave-per-point launch keeps, beside a point's cache row, where the point was when it was searched and how far it may move
+    before its winner can change ((d2 - d1) / 2 from the scan's runner-up): a certificate that holds on real scans, where the
+    spacing-based one never does. Every correspondence it lets through must be the one a fresh search returns: with the reuse of
+    correspondences switched off (every point searched in every linearisation) all outputs are bit-identical — on the reference's
+    bundled scans (box filter + 0.25 m voxels: surfaces, 50 points in the fullest cell), three annealing levels, 12 iterations
+    a level — while the searched count drops to a fraction."""
+    import os
+
+    from test_gpu_facade import GOLD, read_ply_xyz
+
+    def prep(p):
+        p = p[orc.box_filter(p, 0.5, 50.0) == 1]
+        p = orc.voxel_downsample(p, 0.25, 1, stable=True)["points"]
+        idx, _ = orc.kdtree_knn(orc.kdtree_build(p), p, 10)
+        return p, orc.cov_estimate(p, idx)
+
+    s, sc = prep(read_ply_xyz(os.path.join(GOLD, "source.ply")))
+    t, tc = prep(read_ply_xyz(os.path.join(GOLD, "target.ply")))
+    keep = orc.random_sampling_flags(99, len(s), min(n_src, len(s) - 1)) == 1
+    S = sp.PointCloudShared(dev(s[keep]), covs=dev(sc[keep]))
+    prep_t = sp.PreparedTarget(sp.GridKNN.build(dev(t)), dev(tc))
+    p = sp.RegistrationParams(robust_type="GEMAN_MCCLURE", optimization_method=opt, max_iterations=12, criteria_rotation=0.0,
+                              criteria_translation=0.0)
+    out = {}
+    for reuse in (2, 0):
+        reg = sp.Registration(p)
+        reg._set_source_option("reuse", reuse)
+        reg._set_source_option("opt_wave_query", 2)
+        r = reg.align_optimize(S, prep_t, None, [10.0, 5.0, 2.5])
+        assert r is not None
+        out[reuse] = r
+    a, b = out[2], out[0]
+    assert np.array_equal(a.T, b.T) and np.array_equal(a.H, b.H) and np.array_equal(a.b, b.b)
+    assert (a.error, a.inlier, a.iterations, a.converged, a.linearizations, a.trials) == \
+           (b.error, b.inlier, b.iterations, b.converged, b.linearizations, b.trials)
+    assert a.log == b.log
+    assert b.searched == b.linearizations * S.size()
+    assert a.searched < 0.5 * b.searched, (a.searched, b.searched)
+
+
 def test_wave_per_point_forced_on_a_crowded_target(sp, orc):
     """sp_gicp_source_set_wave_per_point(source, 2): a wave per source point for sources of up to 131072 points, what the facade
     asks for when the target grid's fullest cell holds hundreds of points (a raw LiDAR scan: thousands of returns at the sensor).
