@@ -14,6 +14,7 @@
 #include <sycl_points_amd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -308,6 +309,34 @@ private:
         static auto* c = new std::vector<Entry>();  // never destroyed: the HIP runtime may be gone by then
         return *c;
     }
+};
+// A box known to hold every point of a container, remembered by whoever produced the container (voxel downsampling knows its
+// voxels' key box) for whoever builds a spatial structure on it next (GridKNN::build -> sp_grid_create_bounded: no bounding-box
+// kernel, no read-back). Keyed by the container's generation — process-wide unique and changed by every modification — so a
+// stale entry can never be taken for a live one. A ring of 32: the hint is used within the frame that made it, or not at all.
+struct BoundsHints {
+    static void put(uint64_t generation, const float* min_max6) {
+        std::lock_guard<std::mutex> lock(mutex());
+        Entry& e = ring()[next()++ % kEntries];
+        e.generation = generation;
+        for (int a = 0; a < 6; ++a) e.b[a] = min_max6[a];
+    }
+    static bool get(uint64_t generation, float* min_max6) {
+        std::lock_guard<std::mutex> lock(mutex());
+        for (const Entry& e : ring())
+            if (e.generation == generation && generation != 0) {
+                for (int a = 0; a < 6; ++a) min_max6[a] = e.b[a];
+                return true;
+            }
+        return false;
+    }
+
+private:
+    static constexpr size_t kEntries = 32;
+    struct Entry { uint64_t generation = 0; float b[6] = {0, 0, 0, 0, 0, 0}; };
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static std::array<Entry, kEntries>& ring() { static std::array<Entry, kEntries> r; return r; }
+    static size_t& next() { static size_t n = 0; return n; }
 };
 // Host memory of large containers: PINNED blocks from a process-wide pool (round 5). A copy between pageable memory and the
 // device is staged — by the runtime at 3-5 GB/s, or through StagedCopy's pinned buffers below at the host's memcpy speed: for

@@ -334,6 +334,17 @@ private:
         }
         const size_t V = static_cast<uint32_t>(h[0]);
         out_pts.set_device_size(V);
+        if (V > 0 && h[2] <= h[5] && h[3] <= h[6] && h[4] <= h[7]) {
+            // every output point is the mean of points of one voxel, so it lies in that voxel; the voxels' key box is h[2..7]
+            // (coordinates offset by 2^20, compute_voxel_bit): the cloud's bounding box, a voxel wider on every side against the
+            // rounding of floor(p / size), for whoever builds a grid on the cloud next
+            float box[6];
+            for (int a = 0; a < 3; ++a) {
+                box[a] = float(h[2 + a] - (1 << 20) - 1) * voxel_size_;
+                box[3 + a] = float(h[5 + a] - (1 << 20) + 2) * voxel_size_;
+            }
+            ::sycl_points::detail::BoundsHints::put(out_pts.generation(), box);
+        }
         if (rgb) out_rgb->set_device_size(V);
         if (inten) out_inten->set_device_size(V);
         if (ts) out_ts->set_device_size(V);

@@ -406,7 +406,14 @@ public:
     static Ptr build(const sycl_utils::DeviceQueue& q, const PointCloudShared& cloud, float points_per_cell = 0.5f,
                      float cell_size = 0.0f) {
         auto g = std::make_shared<GridKNN>(q);
-        throw_on_error(sp_grid_create(cloud.points_device(), cloud.size(), cell_size, points_per_cell, q.stream(), &g->grid_));
+        // (a cloud whose producer left a bounding box behind — voxel downsampling does: the build then needs no box of its own,
+        // i.e. no kernel, no read-back and no wait before it can size its cell table)
+        float box[6];
+        const float* const pts = cloud.points_device();  // (before the look-up: an upload does not change the generation)
+        if (sycl_points::detail::BoundsHints::get(cloud.points->generation(), box))
+            throw_on_error(sp_grid_create_bounded(pts, cloud.size(), box, cell_size, points_per_cell, q.stream(), &g->grid_));
+        else
+            throw_on_error(sp_grid_create(pts, cloud.size(), cell_size, points_per_cell, q.stream(), &g->grid_));
         g->id_ = next_grid_id();
         return g;
     }

@@ -100,6 +100,13 @@ int sp_grid_create(const float* points, size_t n, float cell_size, float points_
  * most three more sorts; none for a uniform cloud; the table stays below 32 M cells). What Registration::align's in-loop search
  * uses when it stands in for the caller's KDTree (knn/kdtree.hpp:463-553 is density-agnostic; a fixed-volume grid is not). */
 int sp_grid_create_adaptive(const float* points, size_t n, float points_per_cell, void* stream, sp_grid** out);
+/* sp_grid_create for a caller that already knows a box holding every finite point (min x, y, z, max x, y, z): the bounding-box
+ * kernel, its read-back and the wait for it are skipped — the build then never waits for its stream. What voxel downsampling
+ * leaves is such a cloud: its voxels' key box is known on the host (the facade's VoxelGrid hands it on with the cloud). The box
+ * is vouched for: a finite point outside the grid it implies raises the library's device error word (reported by a later call)
+ * and that grid's searches are not exact. */
+int sp_grid_create_bounded(const float* points, size_t n, const float* bounds_min_max6, float cell_size, float points_per_cell,
+                           void* stream, sp_grid** out);
 void sp_grid_destroy(sp_grid* grid);
 size_t sp_grid_size(const sp_grid* grid);
 float sp_grid_cell_size(const sp_grid* grid);

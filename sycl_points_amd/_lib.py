@@ -102,6 +102,7 @@ SIGNATURES = {
     "sp_kdtree_remove_by_flags": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "sp_grid_create": (_i, [_vp, _sz, _f, _f, _vp, C.POINTER(_vp)]),
     "sp_grid_create_adaptive": (_i, [_vp, _sz, _f, _vp, C.POINTER(_vp)]),
+    "sp_grid_create_bounded": (_i, [_vp, _sz, _vp, _f, _f, _vp, _vp]),
     "sp_grid_destroy": (None, [_vp]),
     "sp_grid_size": (_sz, [_vp]),
     "sp_grid_order": (_i, [_vp, _vp, _vp]),

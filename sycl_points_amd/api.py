@@ -420,11 +420,16 @@ class GridKNN(KNNBase):
         self.device = device
 
     @staticmethod
-    def build(points, cell_size=0.0, points_per_cell=2.0, adaptive=False):
-        """adaptive: the cell size follows the measured occupancy (sp_grid_create_adaptive) — clouds of surfaces."""
+    def build(points, cell_size=0.0, points_per_cell=2.0, adaptive=False, bounds=None):
+        """adaptive: the cell size follows the measured occupancy (sp_grid_create_adaptive) — clouds of surfaces.
+        bounds: (min x, y, z, max x, y, z) of a box the caller knows to hold every finite point (sp_grid_create_bounded: no
+        bounding-box kernel, no read-back)."""
         p = _dev_f32(_points_of(points), 4)
         h = C.c_void_p()
-        if adaptive:
+        if bounds is not None:
+            b = (C.c_float * 6)(*[float(v) for v in bounds])
+            check(_lib.lib().sp_grid_create_bounded(_ptr(p), p.shape[0], b, cell_size, points_per_cell, _stream(), C.byref(h)))
+        elif adaptive:
             check(_lib.lib().sp_grid_create_adaptive(_ptr(p), p.shape[0], points_per_cell, _stream(), C.byref(h)))
         else:
             check(_lib.lib().sp_grid_create(_ptr(p), p.shape[0], cell_size, points_per_cell, _stream(), C.byref(h)))

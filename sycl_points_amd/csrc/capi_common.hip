@@ -50,7 +50,10 @@ int launch_status() {
             sp_set_error(code == kDevErrLookback
                              ? "a kernel of an EARLIER call gave up waiting for another workgroup's prefix (exclusive scan look-back): "
                                "the offsets that call produced (compaction, removal, grid units) are wrong"
-                             : "a kernel of an earlier call reported a device-side failure");
+                             : code == kDevErrBounds
+                                   ? "a kernel of an EARLIER call (sp_grid_create_bounded) met a finite point outside the bounds its caller "
+                                     "vouched for: that grid's searches are not exact"
+                                   : "a kernel of an earlier call reported a device-side failure");
             return SP_ERR_HIP;
         }
     }

@@ -89,13 +89,21 @@ __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__
     }
 }
 
+// bounds_error (sp_grid_create_bounded): the box came from the caller — a finite point outside it would sit in a border cell whose
+// geometry does not contain it, and the searches' pruning would be wrong without anybody noticing: it raises the device error word.
 __global__ __launch_bounds__(kBlock) void cell_id_kernel(const float4* __restrict__ pts, GridDesc g,
-                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+                                                         unsigned* __restrict__ bounds_error = nullptr) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= g.n) return;
     const float4 p = pts[i];
     unsigned key = (unsigned)g.nx * g.ny * g.nz;  // non-finite points: a trash cell past the grid, never searched
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+        if (bounds_error) {
+            const float hx = g.ox + g.nx * g.h, hy = g.oy + g.ny * g.h, hz = g.oz + g.nz * g.h;
+            if (p.x < g.ox || p.y < g.oy || p.z < g.oz || p.x > hx || p.y > hy || p.z > hz)
+                __hip_atomic_store(bounds_error, kDevErrBounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         const int cx = cell_coord(p.x, g.ox, g.inv_h, g.nx), cy = cell_coord(p.y, g.oy, g.inv_h, g.ny),
                   cz = cell_coord(p.z, g.oz, g.inv_h, g.nz);
         key = ((unsigned)cz * g.ny + cy) * g.nx + cx;
@@ -1459,7 +1467,7 @@ extern "C" void sp_grid_destroy(sp_grid* g) {
 namespace sp {
 namespace {
 int grid_create_impl(const float* points, size_t n, float cell_size, float points_per_cell, bool adaptive, void* stream,
-                     sp_grid** out) {
+                     sp_grid** out, const float* bounds6 = nullptr) {
     if (!out) return SP_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (n >= (1ull << 31)) {
@@ -1491,18 +1499,23 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
     const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     unsigned h_bbox_own[6];
     unsigned* const h_bbox = pinned_mailbox() ? static_cast<unsigned*>(pinned_mailbox()) : h_bbox_own;
-    e = hipMemcpyAsync(d_bbox, init, sizeof init, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        bbox_kernel<<<std::min(stream_grid(n, kBlock, 4), 256u), kBlock, 0, st>>>(pts, (unsigned)n, d_bbox);  // (1024 workgroups: 26 us — their 6 atomics each share one cache line)
-        e = hipMemcpyAsync(h_bbox, d_bbox, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return fail(e);
     float mn[3], mx[3];
-    bool any = h_bbox[0] != 0xffffffffu;
-    for (int a = 0; a < 3; ++a) {
-        mn[a] = any ? dec(h_bbox[a]) : 0.0f;
-        mx[a] = any ? dec(h_bbox[3 + a]) : 0.0f;
+    if (bounds6) {  // the caller knows a box that holds every finite point (sp_grid_create_bounded): no kernel, no read-back, no wait
+        for (int a = 0; a < 3; ++a) { mn[a] = bounds6[a]; mx[a] = bounds6[3 + a]; }
+        e = hipSuccess;
+    } else {
+        e = hipMemcpyAsync(d_bbox, init, sizeof init, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            bbox_kernel<<<std::min(stream_grid(n, kBlock, 4), 256u), kBlock, 0, st>>>(pts, (unsigned)n, d_bbox);  // (1024 workgroups: 26 us — their 6 atomics each share one cache line)
+            e = hipMemcpyAsync(h_bbox, d_bbox, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(e);
+        bool any = h_bbox[0] != 0xffffffffu;
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = any ? dec(h_bbox[a]) : 0.0f;
+            mx[a] = any ? dec(h_bbox[3 + a]) : 0.0f;
+        }
     }
     // 2. cell size: given, or chosen for `points_per_cell` points per cell on average over the bounding box
     float ext[3], ext_max = 0.0f, scale = 0.0f;
@@ -1578,10 +1591,15 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
         if (e == hipSuccess) {
             GridDesc gd{g->inv_h, g->h, g->eps, g->org[0], g->org[1], g->org[2], g->dims[0], g->dims[1], g->dims[2],
                         (unsigned)n};
-            cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in);
+            cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in, bounds6 ? device_error_word() : nullptr);
             bool in_b = false;
-            if (radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, n, end_bit, tmp, tmp_bytes, &in_b, st) != SP_OK)
-                e = hipErrorUnknown;
+            if (const int rc = radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, n, end_bit, tmp, tmp_bytes, &in_b, st); rc != SP_OK) {
+                // (with the message the sort's own status check left: a launch error — or the device error word, raised by then
+                // by this build's cell_id_kernel for a point outside the caller's box)
+                (void)hipStreamSynchronize(st);
+                sp_grid_destroy(g);
+                return rc;
+            }
             if (!in_b) { keys_out = keys_in; vals_out = vals_in; }  // the passes ping-pong: the sorted pairs are where the last one wrote
         }
         unsigned h_stats[2] = {0u, 0u};
@@ -1593,9 +1611,13 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
                 // Nothing is read back and nothing waited for: the temporaries go to the pool behind the stream's work, an event
                 // marks the end of the build for other streams (grid_use), and the work units of the self-kNN tiling are made
                 // when a self-kNN first asks for them (ensure_units).
-                if (hipEventCreateWithFlags(&g->built_ev, hipEventDisableTiming) != hipSuccess ||
-                    hipEventRecord(g->built_ev, st) != hipSuccess || launch_status() != SP_OK)
+                if (hipEventCreateWithFlags(&g->built_ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(g->built_ev, st) != hipSuccess)
                     return fail(hipErrorUnknown);
+                if (const int ls = launch_status(); ls != SP_OK) {  // (with its own message: a launch error, or the device error word)
+                    (void)hipStreamSynchronize(st);
+                    sp_grid_destroy(g);
+                    return ls;
+                }
                 g->build_stream = st;
                 for (ScratchBuf* b : {&bbox_buf, &b_kin, &b_kout, &b_vin, &b_vout, &b_tmp, &b_stats}) b->release_after(g->streams);
                 break;
@@ -1649,6 +1671,16 @@ extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, fl
 }
 extern "C" int sp_grid_create_adaptive(const float* points, size_t n, float points_per_cell, void* stream, sp_grid** out) {
     return sp::grid_create_impl(points, n, 0.0f, points_per_cell, true, stream, out);
+}
+extern "C" int sp_grid_create_bounded(const float* points, size_t n, const float* bounds_min_max6, float cell_size,
+                                      float points_per_cell, void* stream, sp_grid** out) {
+    if (!bounds_min_max6) return SP_ERR_INVALID_ARGUMENT;
+    for (int a = 0; a < 3; ++a)
+        if (!(bounds_min_max6[a] <= bounds_min_max6[3 + a]) || !std::isfinite(bounds_min_max6[a]) || !std::isfinite(bounds_min_max6[3 + a])) {
+            sp_set_error("[GridKNN::build] bounds must be finite with min <= max");
+            return SP_ERR_INVALID_ARGUMENT;
+        }
+    return sp::grid_create_impl(points, n, cell_size, points_per_cell, false, stream, out, bounds_min_max6);
 }
 
 // ---- lazy delete (the grid's counterpart of KDTree::remove_nodes_by_flags, kdtree.hpp:282-284, 721-765) -------------

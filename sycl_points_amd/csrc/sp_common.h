@@ -25,6 +25,7 @@ int launch_status();
 // look-back poll that ran out (sp_lookback.h) — so that it is not lost: nullptr when the allocation failed (no device).
 unsigned* device_error_word();
 constexpr unsigned kDevErrLookback = 1u;
+constexpr unsigned kDevErrBounds = 2u;  // sp_grid_create_bounded: a finite point outside the bounds the caller vouched for
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

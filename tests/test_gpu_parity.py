@@ -653,6 +653,33 @@ def test_box_filter_transform_compaction(sp, orc):
     assert np.array_equal(out.normals.cpu().numpy(), orc.transform_normals(nrm, T))
 
 
+def test_grid_with_a_box_vouched_for_by_the_caller(sp, orc):
+    # sp_grid_create_bounded: the caller's box instead of a bounding-box kernel and its read-back. Any box that holds the cloud
+    # gives the same neighbours (indices and distances, bit for bit) as the grid that measured its own; a finite point outside the
+    # box is reported — by a later call: the check runs on the device — instead of silently sitting in a cell that does not hold it.
+    from sycl_points_amd import _lib
+
+    g = orc.rng(31)
+    pts = g.uniform_points(40000, 10.0)
+    pts[:, 2] *= 0.2
+    pts[17, 0] = np.nan
+    q = g.uniform_points(5000, 11.0)
+    own = sp.GridKNN.build(dev(pts), points_per_cell=2.0)
+    for box in ((-10.0, -10.0, -2.0, 10.0, 10.0, 2.0), (-25.0, -11.0, -2.5, 12.0, 30.0, 9.0)):
+        bounded = sp.GridKNN.build(dev(pts), points_per_cell=2.0, bounds=box)
+        for k in (1, 7):
+            a, b = own.knn_search(dev(q), k), bounded.knn_search(dev(q), k)
+            assert torch.equal(a.indices, b.indices) and torch.equal(a.distances, b.distances)
+    oi, od = orc.knn_bruteforce(q[:500], pts[np.isfinite(pts[:, 0])], 1)
+    torch.cuda.synchronize()
+    with pytest.raises(sp.SpError, match="outside the bounds"):  # (by the build itself when its kernel has finished by then, else by the next call)
+        bad = sp.GridKNN.build(dev(pts), points_per_cell=2.0, bounds=(-5.0, -10.0, -2.0, 10.0, 10.0, 2.0))  # a fifth of the cloud lies outside
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().sp_grid_order(bad._h, torch.empty(40000, dtype=torch.int32, device="cuda").data_ptr(), sp._stream()))
+    torch.cuda.synchronize()
+    own.knn_search(dev(q), 1)  # (the error word is cleared by the report: later calls are clean)
+
+
 @pytest.mark.parametrize("n", [1, 777, 2048, 69088, 300001])
 def test_box_filter_and_compaction_in_one_launch(sp, orc, n):
     # sp_box_filter_compact_multi: the box test, the scan of its flags (decoupled look-back over tiles of 2048) and the stable move
