@@ -715,6 +715,26 @@ public:
     // ---- device side (what the kernels get)
     /// Read-only device pointer; uploads first if the host copy is newer.
     const T* device_data() const { sync_device(); return dev_; }
+    /// For a kernel that reads the vector ONCE, front to back (the box filter over a fresh scan): the device copy when it is
+    /// current, else the pinned host copy itself (*in_place = true) — pinned blocks are mapped into the device's address
+    /// space, the kernel streams them over PCIe at the rate the DMA engine would have copied them, and there is no copy to
+    /// wait for and no device buffer for a cloud that is dropped right after. The caller launches its kernel and then calls
+    /// host_read_enqueued(that stream): the host copy may not change (or go back to its pool) before that launch has finished.
+    const T* device_readable_once(bool* in_place) const {
+        *in_place = false;
+        if (!dev_dirty_ && (host_dirty_ || dev_ == nullptr || dev_size_ != host_.size()) && !host_.empty() &&
+            detail::PinnedPool::owns(host_.data(), host_.size() * sizeof(T))) {
+            wait_upload();
+            *in_place = true;
+            return host_.data();
+        }
+        return device_data();
+    }
+    void host_read_enqueued(hipStream_t launched_on) const {
+        if (up_ev_ == nullptr) hip_check(hipEventCreateWithFlags(&up_ev_, hipEventDisableTiming), "event");
+        hip_check(hipEventRecord(up_ev_, launched_on), "event");
+        up_pending_ = true;
+    }
     /// Writable device pointer for `n` elements (kernel output): the host copy becomes stale, nothing is uploaded.
     T* device_data_for_write(size_t n) {
         ensure_capacity(n);

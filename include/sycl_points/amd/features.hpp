@@ -492,7 +492,13 @@ private:
             bytes[na] = sizeof(T);
             ++na;
         };
-        add(*source.points, *out.points);
+        // the box filter reads the points once: straight out of the pinned host copy when that is the current one (a fresh scan)
+        bool pts_in_place = false;
+        const PointType* const pts = box_.on ? source.points->device_readable_once(&pts_in_place) : source.points->device_data();
+        rows[na] = pts;
+        dst[na] = out.points->device_data_for_write(N);
+        bytes[na] = sizeof(PointType);
+        ++na;
         if (source.has_cov()) add(*source.covs, *out.covs);
         if (source.has_normal()) add(*source.normals, *out.normals);
         if (source.has_rgb()) add(*source.rgb, *out.rgb);
@@ -516,10 +522,13 @@ private:
         const bool poll = known_count == SIZE_MAX && mapped.usable();
         uint32_t* const count_dev = poll ? mapped.dev : static_cast<uint32_t*>(count.p);
         if (poll) mapped.arm();
-        if (box_.on)
-            throw_on_error(sp_box_filter_compact_multi(source.points_device(), N, box_.min_distance, box_.max_distance, rows, bytes, dst,
-                                                       na, flags_->device_data_for_write(N), nullptr, count_dev, ws.p, ws_bytes, st));
-        else
+        if (box_.on) {
+            const int rc = sp_box_filter_compact_multi(reinterpret_cast<const float*>(pts), N, box_.min_distance, box_.max_distance, rows,
+                                                       bytes, dst, na, flags_->device_data_for_write(N), nullptr, count_dev, ws.p,
+                                                       ws_bytes, st);
+            if (pts_in_place) source.points->host_read_enqueued(st);
+            throw_on_error(rc);
+        } else
             throw_on_error(sp_compact_by_flags_multi(rows, bytes, dst, na, N, flags_->device_data(), nullptr, count_dev, ws.p, ws_bytes,
                                                      st));
         size_t M = known_count;

@@ -17,6 +17,9 @@ ev.sort()
 # loops start with the big host-to-device copy of the source cloud
 starts = [i for i, e in enumerate(ev) if e[2].startswith("COPY") and "HOST_TO_DEVICE" in e[2] and e[2].split()[-1].isdigit() and int(e[2].split()[-1]) > 1000000]
 i0 = starts[-2] if len(starts) >= 2 else 0
+if not starts:  # the box filter reads the scan in place (no upload): a loop starts at the launch before its first compaction
+    comp = [i for i, e in enumerate(ev) if "compact_fused" in e[2]]
+    i0 = max(comp[-4] - 1, 0) if len(comp) >= 4 else 0
 t0 = ev[i0][0]
 prev = t0
 for s, e, n in ev[i0:]:

@@ -369,6 +369,22 @@ __global__ __launch_bounds__(kRsThreads) void compact_fused_kernel(CompactArrays
     const unsigned tile = s_tile;
     const unsigned base = tile * kRsTile + tid * kRsItems;
     unsigned f[kRsItems];
+    // BOX: the four points stay in registers for the move below — one read of the cloud, which may be the caller's pinned HOST
+    // copy (read over PCIe in place: no upload, no device copy of the unfiltered cloud at all)
+    float4 pt[BOX ? kRsItems : 1];
+    if constexpr (BOX) {
+        // read as whole 1 KB rows per wave instruction (every 64-byte line of the — possibly host — memory is asked for once;
+        // a lane reading its own four consecutive points asks for each line four times: 34 GB/s over PCIe), regrouped through LDS
+        __shared__ float4 lp[kRsTile];
+#pragma unroll
+        for (int c = 0; c < kRsItems; ++c) {
+            const unsigned l = c * kRsThreads + tid, e = tile * kRsTile + l;
+            if (e < n) lp[l] = box_pts[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kRsItems; ++c) pt[c] = lp[tid * kRsItems + c];  // (past n: never looked at)
+    }
     unsigned sum = 0;
 #pragma unroll
     for (int c = 0; c < kRsItems; ++c) {
@@ -376,7 +392,7 @@ __global__ __launch_bounds__(kRsThreads) void compact_fused_kernel(CompactArrays
         f[c] = 0u;
         if (e < n) {
             if constexpr (BOX) {  // BoxFilter (preprocess_operator/box_filter_operator.hpp:31-45), as box_filter_kernel (voxel.hip)
-                const float4 p = box_pts[e];
+                const float4 p = pt[c];
                 unsigned keep = 1u;
                 if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w))) {
                     keep = 0u;
@@ -413,6 +429,13 @@ __global__ __launch_bounds__(kRsThreads) void compact_fused_kernel(CompactArrays
             if (f[c]) {
                 for (int a = 0; a < A.n_arrays; ++a) {
                     const unsigned words = A.words[a];
+                    if constexpr (BOX) {
+                        if (reinterpret_cast<const void*>(A.src[a]) == reinterpret_cast<const void*>(box_pts) && words == 4u &&
+                            (reinterpret_cast<uintptr_t>(A.dst[a]) & 15u) == 0u) {
+                            reinterpret_cast<float4*>(A.dst[a])[run] = pt[c];
+                            continue;
+                        }
+                    }
                     if ((words & 3u) == 0u && ((reinterpret_cast<uintptr_t>(A.src[a]) | reinterpret_cast<uintptr_t>(A.dst[a])) & 15u) == 0u) {  // rows of whole, aligned 16-byte quads (points, covariances, normals)
                         const uint4* const src = reinterpret_cast<const uint4*>(A.src[a]) + (size_t)e * (words / 4);
                         uint4* const dst = reinterpret_cast<uint4*>(A.dst[a]) + (size_t)run * (words / 4);

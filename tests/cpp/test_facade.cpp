@@ -190,6 +190,45 @@ static void preprocess_filter() {  // test_preprocess_filter.cpp:29-99
     CHECK(e.size() == 5);
 }
 
+// The box filter reads a fresh scan out of its pinned host copy (no upload): the source container stays what it was, may be
+// written right after the call, filtered again (host copy newer again) and used by a kernel that needs the device copy.
+static void box_filter_reads_the_host_copy_in_place() {
+    std::mt19937 gen(77);
+    PointCloudCPU c;
+    random_points(gen, c, 70001, 12.0f);  // 35 tiles, a ragged last one
+    PointCloudShared scan(*Q, c), kept(*Q), again(*Q);
+    alg::filter::PreprocessFilter f(*Q);
+    auto expect = [&](const PointCloudShared& in, float mn, float mx) {
+        std::vector<PointType> out;
+        for (const PointType& p : in.points->host()) {
+            const float l = std::max(std::fabs(p.x()), std::max(std::fabs(p.y()), std::fabs(p.z())));
+            if (std::isfinite(p.x()) && std::isfinite(p.y()) && std::isfinite(p.z()) && std::isfinite(p.w()) && !(l < mn) && !(l > mx)) out.push_back(p);
+        }
+        return out;
+    };
+    auto same = [](const PointCloudShared& got, const std::vector<PointType>& want) {
+        if (got.size() != want.size()) return false;
+        const auto& h = got.points->host();
+        for (size_t i = 0; i < want.size(); ++i)
+            if (std::memcmp(&h[i], &want[i], sizeof(PointType)) != 0) return false;
+        return true;
+    };
+    const std::vector<PointType> want1 = expect(scan, 2.0f, 9.0f);
+    f.box_filter(scan, kept, 2.0f, 9.0f);
+    CHECK(scan.size() == 70001 && same(kept, want1));
+    for (size_t i = 0; i < 70001; i += 3) (*scan.points)[i] = PointType(3.0f, float(i % 7), -1.0f, 1.0f);  // the host copy changes
+    const std::vector<PointType> want2 = expect(scan, 2.0f, 9.0f);
+    f.box_filter(scan, again, 2.0f, 9.0f);
+    CHECK(same(again, want2) && want2.size() != want1.size());
+    CHECK(same(kept, want1));  // (the first result is its own container)
+    // a kernel that needs the device copy of the unfiltered scan: it is uploaded now
+    alg::transform::transform(scan, TransformMatrix::Identity());
+    const PointType third(3.0f, 3.0f, -1.0f, 1.0f);
+    CHECK(scan.size() == 70001 && std::memcmp(&scan.points->host()[3], &third, sizeof(PointType)) == 0);
+    f.box_filter(scan, 2.0f, 9.0f);  // in place, from the device copy this time
+    CHECK(same(scan, want2));
+}
+
 // A host KNNBase injected through the operator boundary, as the reference's DummyKNN (test_registration_pipeline.cpp:16-61).
 class HostBruteForceKNN : public alg::knn::KNNBase {
 public:
@@ -1067,6 +1106,7 @@ int main() {
     RUN(kdtree_radius_and_lazy_delete_on_the_hierarchy);
     RUN(voxelgrid_known_answer);
     RUN(preprocess_filter);
+    RUN(box_filter_reads_the_host_copy_in_place);
     RUN(point_cloud_extend_erase);
     RUN(pipeline_random_sampling_seam);
     RUN(pipeline_robust_annealing_seam);
