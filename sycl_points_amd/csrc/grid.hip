@@ -1486,7 +1486,7 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
     };
     hipError_t e;
     if (n == 0) {
-        if ((e = pooled_alloc(&g->d_start, 2 * sizeof(uint32_t), st)) != hipSuccess) return fail(e);
+        if ((e = pooled_alloc(&g->d_start, 4 * sizeof(uint32_t), st)) != hipSuccess) return fail(e);
         if ((e = hipMemsetAsync(g->d_start, 0, 2 * sizeof(uint32_t), st)) != hipSuccess) return fail(e);
         *out = g;
         return SP_OK;
@@ -1580,7 +1580,7 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
         const unsigned rows = (unsigned)g->dims[1] * (unsigned)g->dims[2];
         ScratchBuf b_units, b_stmp;
         const size_t stmp_bytes = exclusive_scan_u32_workspace_bytes(rows + 1);
-        e = pooled_alloc(&g->d_start, (g->ncells + 1) * sizeof(uint32_t), st);
+        e = pooled_alloc(&g->d_start, (g->ncells + 3) * sizeof(uint32_t), st);  // (+ 2: fast_extents reads three words at the last cell)
         if (adaptive) {  // (this form of the build ends every attempt with a read-back anyway: the work units ride along)
             if (e == hipSuccess) e = b_units.get((rows + 1) * 4, st);
             if (e == hipSuccess) e = pooled_alloc(&g->d_unit_off, (rows + 1) * 4, st);

@@ -10,7 +10,7 @@ struct sp_grid {
     int dims[3] = {1, 1, 1};
     size_t ncells = 1;
     float4* d_pts = nullptr;      // n points in cell order, w = original index bits
-    uint32_t* d_start = nullptr;  // ncells + 1
+    uint32_t* d_start = nullptr;  // ncells + 1 (+ 2 spare words: fast_extents loads three at a time)
     // rows + 1: first 64-query work unit of every x-row (self-kNN tiling) and their number. Made when a self-kNN first asks
     // (ensure_units, grid.hip): a grid built for Registration::align's searches never does — three launches and a read-back less
     // per build
@@ -210,10 +210,16 @@ __device__ __forceinline__ void fast_extents(const unsigned* __restrict__ start,
     const unsigned dy = yb != ya ? (unsigned)g.nx : 0u, dz = zb != za ? (unsigned)g.ny * g.nx : 0u;
     const unsigned w = (unsigned)(xb - xa) + 1u;
     const unsigned r01 = r00 + dy, r10 = r00 + dz, r11 = r10 + dy;
-    s[0] = start[r00]; e[0] = start[r00 + w];
-    s[1] = start[r01]; e[1] = start[r01 + w];
-    s[2] = start[r10]; e[2] = start[r10 + w];
-    s[3] = start[r11]; e[3] = start[r11 + w];
+    // one 12-byte load per row (start[r], start[r + 1], start[r + 2]: the array carries two spare words) instead of two 4-byte
+    // ones: the searching launches are bound by the NUMBER of scattered requests (profiles/r04_i), not by their bytes
+    struct Three { unsigned a, b, c; };
+    const Three v0 = *reinterpret_cast<const Three*>(start + r00), v1 = *reinterpret_cast<const Three*>(start + r01),
+                v2 = *reinterpret_cast<const Three*>(start + r10), v3 = *reinterpret_cast<const Three*>(start + r11);
+    const bool two = w == 2u;
+    s[0] = v0.a; e[0] = two ? v0.c : v0.b;
+    s[1] = v1.a; e[1] = two ? v1.c : v1.b;
+    s[2] = v2.a; e[2] = two ? v2.c : v2.b;
+    s[3] = v3.a; e[3] = two ? v3.c : v3.b;
     if (dy == 0u) { e[1] = s[1]; e[3] = s[3]; }
     if (dz == 0u) { e[2] = s[2]; e[3] = s[3]; }
 }
