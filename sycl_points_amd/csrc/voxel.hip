@@ -368,23 +368,48 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(uint32_t* __restric
 }
 
 
-template <typename KEY>
+// FOLD (up to kFoldBlocks workgroups: 1 M positions): there is no block_offsets launch — block_off holds the RAW kept counts and
+// every workgroup sums the counts of the workgroups before its own (at most 16 KB, L2-resident; the last one also writes the
+// total): at these sizes a launch costs more than reading the counts again, as in the sort's scatter (radix_sort.hip).
+constexpr unsigned kFoldBlocks = 4096;
+template <typename KEY, bool FOLD>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restrict__ flag,
                                                          const uint32_t* __restrict__ block_off, unsigned n,
                                                          const KEY* __restrict__ sk, KeyBox box,
                                                          const float4* __restrict__ t_pts, AggPtrs a,
                                                          float4* __restrict__ o_pts, float4* __restrict__ o_rgb,
                                                          float* __restrict__ o_inten, float* __restrict__ o_ts,
-                                                         uint64_t* __restrict__ o_keys) {
+                                                         uint64_t* __restrict__ o_keys, uint32_t* __restrict__ n_out) {
     __shared__ unsigned wave_kept[kBlock / 64];
+    __shared__ unsigned wave_before[kBlock / 64];
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t f = i < n ? flag[i] : 0u;
+    unsigned before = 0;
+    if constexpr (FOLD) {
+        for (unsigned b = threadIdx.x; b < blockIdx.x; b += kBlock) before += block_off[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+        if (lane == 0u) wave_before[w] = before;
+    }
     // position = kept voxels of the earlier workgroups + of the earlier waves of this one + of the earlier lanes of this wave
     const unsigned long long m = __ballot(f != 0u);
     if (lane == 0u) wave_kept[w] = (unsigned)__builtin_popcountll(m);
     __syncthreads();
-    unsigned p = block_off[blockIdx.x] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if constexpr (FOLD) {
+        before = 0;
+#pragma unroll
+        for (unsigned j = 0; j < kBlock / 64; ++j) before += wave_before[j];
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+            unsigned all = before;
+#pragma unroll
+            for (unsigned j = 0; j < kBlock / 64; ++j) all += wave_kept[j];
+            *n_out = all;
+        }
+    } else {
+        before = block_off[blockIdx.x];
+    }
+    unsigned p = before + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
     for (unsigned j = 0; j < w; ++j) p += wave_kept[j];
     if (f) {
         o_pts[p] = t_pts[i];
@@ -510,10 +535,16 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
         if (!in_b) { uint32_t* t = k_in; k_in = k_sorted; k_sorted = t; t = vals_in; vals_in = vals_sorted; vals_sorted = t; }
         aggregate_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(k_sorted, kb.invalid, vals_sorted, (unsigned)n, pts,
                                                                          (float)min_voxel_count, a, t_pts, flag, pos);
+        if (div_up(n, kBlock) <= kFoldBlocks) {
+            scatter_kernel<uint32_t, true><<<div_up(n, kBlock), kBlock, 0, st>>>(
+                flag, pos, (unsigned)n, k_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
+                reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+            return launch_status();
+        }
         block_offsets_kernel<<<1, 1024, 0, st>>>(pos, div_up(n, kBlock), n_out_dev);
-        scatter_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(
+        scatter_kernel<uint32_t, false><<<div_up(n, kBlock), kBlock, 0, st>>>(
             flag, pos, (unsigned)n, k_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
-            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt);
+            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
         return launch_status();
     }
     uint64_t* keys_in = (uint64_t*)(base + w.keys_in);
@@ -533,10 +564,16 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
     if (!in_b64) { uint64_t* t = keys_in; keys_in = keys_sorted; keys_sorted = t; uint32_t* tv = vals_in; vals_in = vals_sorted; vals_sorted = tv; }
     aggregate_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(keys_sorted, kInvalidKey, vals_sorted, (unsigned)n, pts,
                                                                      (float)min_voxel_count, a, t_pts, flag, pos);
+    if (div_up(n, kBlock) <= kFoldBlocks) {
+        scatter_kernel<uint64_t, true><<<div_up(n, kBlock), kBlock, 0, st>>>(
+            flag, pos, (unsigned)n, keys_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
+            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+        return launch_status();
+    }
     block_offsets_kernel<<<1, 1024, 0, st>>>(pos, div_up(n, kBlock), n_out_dev);
-    scatter_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(
+    scatter_kernel<uint64_t, false><<<div_up(n, kBlock), kBlock, 0, st>>>(
         flag, pos, (unsigned)n, keys_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
-        reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt);
+        reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
     return launch_status();
 }
 }  // namespace
