@@ -314,7 +314,14 @@ public:
             throw_on_error(sp_kdtree_remove_by_flags(host_tree(), flags.device_data(), indices.device_data(), flags.size(), queue.stream()));
         queue.wait();
         pristine_ = false;
-        removed_after_host_tree_ = tree_ == nullptr;  // a host tree built later would come from export_points: see host_tree()
+        // only the hierarchy exists: a reference-topology tree built later (k > 32, set_reference_tie_order) starts from the
+        // ORIGINAL points, so it has to see the same removals in the same order — kept here, replayed by host_tree()
+        if (tree_ == nullptr) {
+            Removal r;
+            r.flags.assign(flags.host().begin(), flags.host().end());
+            r.indices.assign(indices.host().begin(), indices.host().end());
+            removals_.push_back(std::move(r));
+        }
         if (self_grid_) { sp_grid_destroy(self_grid_); self_grid_ = nullptr; }
         self_grid_tried_ = true;
         built_on_ = nullptr;
@@ -340,10 +347,6 @@ private:
     const float* device_points() const { return static_cast<const float*>(dev_points_); }
     /// The reference's tree (host build with its rule, kdtree.hpp:292-413).
     sp_kdtree* host_tree() const {
-        if (tree_ == nullptr && removed_after_host_tree_)
-            throw std::runtime_error("[KDTree] the reference-topology tree is needed (k > 32 or set_reference_tie_order) after nodes "
-                                     "were removed from a tree that had not built it: call set_reference_tie_order(true) before "
-                                     "remove_nodes_by_flags");
         if (tree_ == nullptr) {
             std::vector<float> host(4 * std::max<size_t>(size_, 1));
             if (size_) {
@@ -351,6 +354,26 @@ private:
                 hip_check(hipStreamSynchronize(queue.stream()), "sync");
             }
             throw_on_error(sp_kdtree_create(host.data(), size_, leaf_threshold_, queue.stream(), &tree_));
+            // nodes removed while only the hierarchy existed: the same lazy deletes, in their order (kdtree.hpp:721-765)
+            for (const Removal& r : removals_) {
+                const size_t n = r.flags.size();
+                size_t got_f = 0, got_i = 0;
+                hipStream_t st = queue.stream();
+                void* df = sycl_points::detail::DeviceBufferCache::acquire(std::max<size_t>(n, 1), &got_f, st);
+                void* di = sycl_points::detail::DeviceBufferCache::acquire(std::max<size_t>(n, 1) * 4, &got_i, st);
+                hipError_t e = hipMemcpyAsync(df, r.flags.data(), n, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(di, r.indices.data(), n * 4, hipMemcpyHostToDevice, st);
+                int rc = SP_OK;
+                if (e == hipSuccess)
+                    rc = sp_kdtree_remove_by_flags(tree_, static_cast<const uint8_t*>(df), static_cast<const int32_t*>(di), n, st);
+                (void)hipStreamSynchronize(st);
+                sycl_points::detail::DeviceBufferCache::release(df, got_f, st, true);
+                sycl_points::detail::DeviceBufferCache::release(di, got_i, st, true);
+                hip_check(e, "H2D");
+                throw_on_error(rc);
+            }
+            removals_.clear();
+            removals_.shrink_to_fit();
         }
         return tree_;
     }
@@ -386,7 +409,8 @@ private:
     uint64_t id_ = 0;
     size_t size_ = 0, leaf_threshold_ = 16;
     bool pristine_ = true, reference_order_ = false;
-    bool removed_after_host_tree_ = false;  // nodes were removed while only the hierarchy existed
+    struct Removal { std::vector<uint8_t> flags; std::vector<int32_t> indices; };
+    mutable std::vector<Removal> removals_;  // lazy deletes the reference-topology tree has not seen yet (it does not exist)
     std::shared_ptr<PointContainerShared> built_on_;  // the cloud's point container at build(), and its generation then
     uint64_t built_generation_ = 0;
 };

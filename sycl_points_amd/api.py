@@ -199,6 +199,7 @@ class KDTree(KNNBase):
         self._points = None       # ... the points it was built on (device tensor), for the lazily built reference tree / the grid
         self._self_grid = None
         self._self_grid_tried = False
+        self._removals = []       # lazy deletes the (not yet built) reference tree has to replay
         self._pristine = True
         self._leaf_threshold = 16
 
@@ -231,14 +232,20 @@ class KDTree(KNNBase):
         return self._hier
 
     def _host_tree(self):
-        if not self._h and self._points is None:
-            raise SpError(2, "[KDTree] the reference tree is needed (k > 32) after nodes were removed from the device hierarchy")
         if not self._h:
+            if self._points._version != self._points_version:
+                raise SpError(2, "[KDTree] the points tensor was modified in place after build() and before the reference tree was "
+                                 "needed: build the tree again (or hand build() a clone)")
             host = np.ascontiguousarray(self._points.detach().cpu().numpy(), np.float32)
             h = C.c_void_p()
             check(_lib.lib().sp_kdtree_create(host.ctypes.data_as(C.c_void_p), host.shape[0], self._leaf_threshold, _stream(),
                                               C.byref(h)))
             self._h = h
+            # nodes removed while only the hierarchy existed: the same lazy deletes, in their order (KDTree::host_tree)
+            for flags, indices in self._removals:
+                check(_lib.lib().sp_kdtree_remove_by_flags(self._h, _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
+            torch.cuda.current_stream().synchronize()
+            self._removals = []
         return self._h
 
     def _uniform_grid(self):
@@ -328,8 +335,8 @@ class KDTree(KNNBase):
             self._bvh.remove_nodes_by_flags(flags, indices)
         if self._h or not self._accelerated:
             check(_lib.lib().sp_kdtree_remove_by_flags(self._host_tree(), _ptr(flags), _ptr(indices), flags.shape[0], _stream()))
-        elif self._points is not None:
-            self._points = None  # (a reference tree built from here on would not be of the cloud the flags refer to)
+        else:  # (a reference tree built from here on starts from the original points: it replays these)
+            self._removals.append((flags.clone(), indices.clone()))
         torch.cuda.current_stream().synchronize()
         self._pristine = False  # no own-cloud shortcut / grid any more: the points carry other indices now
         self._self_grid = None

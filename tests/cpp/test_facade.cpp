@@ -122,6 +122,36 @@ static void kdtree_grid_vs_bruteforce() {  // test_kdtree.cpp:301-317, 392-408
             same = same && (*kd.indices)[i] == (*gr.indices)[i] && (*kd.distances)[i] == (*gr.distances)[i];
         CHECK(same);
     }
+    {   // nodes leave a tree that only has its device-built hierarchy, then k > 32 is asked for — the reference-topology
+        // tree is built from the original points and replays the lazy delete: the kept points' neighbours, as a tree with the
+        // reference order from the start gives them
+        std::mt19937 g2(5);
+        PointCloudCPU big;
+        random_points(g2, big, 4000, 10.0f);
+        PointCloudShared bigs(*Q, big);
+        shared_vector<uint8_t> flags(4000, uint8_t(1), *Q);
+        shared_vector<int32_t> new_idx(4000, int32_t(-1), *Q);
+        int32_t next = 0;
+        for (size_t i = 0; i < 4000; ++i) {
+            if (i % 4 == 1) flags[i] = 0;
+            else new_idx[i] = next++;
+        }
+        auto lazy = alg::knn::KDTree::build(*Q, bigs);
+        auto ref = alg::knn::KDTree::build(*Q, bigs);
+        ref->set_reference_tie_order(true);
+        (void)ref->knn_search(query, 40);  // its reference-topology tree exists BEFORE the removal
+        lazy->remove_nodes_by_flags(flags, new_idx);
+        ref->remove_nodes_by_flags(flags, new_idx);
+        auto a = lazy->knn_search(query, 40);
+        auto b = ref->knn_search(query, 40);
+        bool same = a.indices->size() == b.indices->size() && a.indices->size() == 100 * 40;
+        for (size_t i = 0; same && i < a.indices->size(); ++i)
+            same = (*a.indices)[i] == (*b.indices)[i] && (*a.distances)[i] == (*b.distances)[i];
+        CHECK(same);
+        bool no_removed = true;
+        for (size_t i = 0; i < a.indices->size(); ++i) no_removed = no_removed && (*a.indices)[i] >= 0 && (*a.indices)[i] < next;
+        CHECK(no_removed);
+    }
     // SinglePoint (test_kdtree.cpp:358-389)
     PointCloudCPU one, q1;
     one.points->push_back(PointType(0, 0, 0, 1));

@@ -292,3 +292,40 @@ def test_bvh_radius_search_and_lazy_delete_match_the_oracle(sp, orc):
             sk = b.self_knn(6)
             bi, bd = orc.knn_bruteforce(cur, cur, 6)
             assert np.array_equal(sk.indices.cpu().numpy()[:len(cur)], bi) and np.array_equal(sk.distances.cpu().numpy()[:len(cur)], bd)
+
+
+def test_kdtree_k_above_32_after_nodes_left_the_hierarchy(sp, orc):
+    """an accelerated KDTree whose nodes were removed while only the device-built hierarchy existed still answers
+    k > 32 (the reference's tree does, up to 100: kdtree.hpp:221-223, 721-765) — the reference-topology tree is built from the
+    original points when first needed and replays the lazy deletes in their order. Against the oracle's KD-tree with the same
+    two removals; k <= 32 (the hierarchy) and k = 40 (the replayed tree) agree with a brute force over the kept points."""
+    pts = orc.rng(99).uniform_points(6000, 5.0)
+    qry = orc.rng(7).uniform_points(300, 5.0)
+    tree = sp.KDTree.build(dev(pts), accelerate=True)
+    assert tree.backend_for(dev(qry), 10) in ("bvh", "bruteforce")
+    nodes = orc.kdtree_build(pts)
+    cur = pts
+    for rnd in range(2):
+        flags = np.ones(len(cur), np.uint8)
+        flags[rnd::5] = 0
+        new_idx = np.where(flags == 1, np.cumsum(flags) - 1, -1).astype(np.int32)
+        tree.remove_nodes_by_flags(dev(flags), dev(new_idx))
+        orc.kdtree_remove_by_flags(nodes, flags, new_idx)
+        cur = cur[flags == 1]
+    r = tree.knn_search(dev(qry), 40)  # builds the reference tree now, with both removals replayed
+    oi, od = orc.kdtree_knn(nodes, qry, 40)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
+    fi, fd = orc.kdtree_knn(orc.kdtree_build(cur), qry, 40)  # a fresh tree on the kept points: the same distances
+    assert np.array_equal(od, fd) and np.array_equal(np.sort(oi, 1), np.sort(fi, 1))
+    r = tree.knn_search(dev(qry), 10)
+    bi, bd = orc.knn_bruteforce(qry, cur, 10)
+    assert np.array_equal(r.indices.cpu().numpy(), bi) and np.array_equal(r.distances.cpu().numpy(), bd)
+    # a third removal reaches both structures
+    flags = np.ones(len(cur), np.uint8)
+    flags[::3] = 0
+    new_idx = np.where(flags == 1, np.cumsum(flags) - 1, -1).astype(np.int32)
+    tree.remove_nodes_by_flags(dev(flags), dev(new_idx))
+    orc.kdtree_remove_by_flags(nodes, flags, new_idx)
+    r = tree.knn_search(dev(qry), 33)
+    oi, od = orc.kdtree_knn(nodes, qry, 33)
+    assert np.array_equal(r.indices.cpu().numpy(), oi) and np.array_equal(r.distances.cpu().numpy(), od)
