@@ -601,6 +601,19 @@ def test_voxel_config3_1m(sp, orc):
     assert np.mean(k2 == k) > 0.999  # means of one-point voxels are the points themselves
 
 
+def test_voxel_above_the_offsets_fold(sp, orc):
+    """More than 4096 aggregation workgroups (1 048 576 sorted positions): the scatter takes its offsets from the
+    block_offsets launch again instead of summing the kept counts itself (voxel.hip kFoldBlocks) — both key widths against the
+    oracle, and a size just below the limit on the folded path."""
+    for n in (1_300_000, 1_048_576):
+        pts = cloud(orc, 77, n, 6.0)
+        o = orc.voxel_downsample(pts, 0.2, 1, stable=True)
+        for boxed in (True, False):
+            out, keys = sp.VoxelGrid(0.2).downsampling(dev(pts), return_keys=True, boxed=boxed)
+            assert np.array_equal(keys.cpu().numpy().view(np.uint64), o["keys"]), (n, boxed)
+            assert np.array_equal(out.points.cpu().numpy(), o["points"]), (n, boxed)
+
+
 def test_voxel_config3_dense_1m_boxed(sp, orc):
     """BASELINE config 3's dense variant at full size (R = 2.5, voxel 0.1, 1 M points, about 8 points per voxel)
     through the path bench.py times for it: keys compressed to the cloud's key box (18 key bits: the sort takes two passes of
