@@ -216,6 +216,7 @@ INTERNAL_SIGNATURES = {
     "sp_internal_source_option": (_i, [_vp, _i, _i]),
     "sp_internal_grid_option": (_i, [_vp, _i, _i]),
     "sp_internal_bvh_option": (_i, [_vp, _i, _i]),
+    "sp_internal_grid_small_build": (_i, [_i]),
     "sp_internal_align_searched_log": (_vp, [_vp, _vp]),
     "sp_internal_radix_sort_workspace_bytes": (_sz, [_sz]),
     "sp_internal_radix_sort_u32": (_i, [_vp, _vp, _vp, _vp, _sz, C.c_uint, _vp, _sz, _vp, _vp]),

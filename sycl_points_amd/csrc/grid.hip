@@ -149,6 +149,187 @@ __global__ __launch_bounds__(kBlock) void cell_start_kernel(const unsigned* __re
     }
 }
 
+// The whole build of a SMALL grid (up to kSmallBuildPoints points, fewer than kSmallBuildCells cells) by ONE workgroup: cell ids, the
+// stable LSD radix sort of (cell id, index) with the tile in LDS (the ranking of rs_scatter_kernel, radix_sort.hip: wave
+// match-any by eight ballots, per-wave digit counters, wave order = position order; the pairs stay in registers between passes),
+// the gather into cell order and the cell table (a suffix minimum over the runs' first positions). It replaces seven launches
+// (cell ids | 2 x (count, scatter) | gather | cell table): at the size of a voxel-downsampled scan those are launch latency
+// (45 us on the example's 6 k-point target against the 15 us of this kernel). Same structure bit for bit.
+constexpr unsigned kSmallBuildPoints = 8192, kSmallBuildCells = 32768;  // (cells: 0 .. ncells, ncells < kSmallBuildCells)
+bool g_small_build = true;  // (sp_internal_grid_small_build: tests and measurements compare the two builds)
+constexpr int kSbThreads = 1024, kSbWaves = kSbThreads / 64, kSbItems = kSmallBuildPoints / kSbThreads;
+__global__ __launch_bounds__(kSbThreads) void grid_build_small_kernel(const float4* __restrict__ pts, GridDesc g, unsigned ncells,
+                                                                       unsigned passes, float4* __restrict__ out_pts,
+                                                                       unsigned* __restrict__ start,
+                                                                       unsigned* __restrict__ bounds_error) {
+    __shared__ unsigned cnt[kSbWaves][256];
+    __shared__ unsigned tstart[256];
+    __shared__ unsigned wave_tot[kSbWaves];
+    __shared__ unsigned lk[kSmallBuildPoints];
+    __shared__ unsigned short lv[kSmallBuildPoints];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const unsigned n = g.n;
+    // wave w owns the positions [w * 512, (w + 1) * 512), 64 at a time: position order = (wave, chunk, lane)
+    unsigned k[kSbItems], v[kSbItems], rank[kSbItems];
+    bool out_of_box = false;
+#pragma unroll
+    for (int c = 0; c < kSbItems; ++c) {
+        const unsigned e = w * (kSmallBuildPoints / kSbWaves) + c * 64 + lane;
+        k[c] = ncells;  // non-finite points: the trash cell past the grid (cell_id_kernel)
+        v[c] = e;
+        if (e < n) {
+            const float4 p = pts[e];
+            if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+                if (bounds_error) {
+                    const float hx = g.ox + g.nx * g.h, hy = g.oy + g.ny * g.h, hz = g.oz + g.nz * g.h;
+                    out_of_box |= p.x < g.ox || p.y < g.oy || p.z < g.oz || p.x > hx || p.y > hy || p.z > hz;
+                }
+                const int cx = cell_coord(p.x, g.ox, g.inv_h, g.nx), cy = cell_coord(p.y, g.oy, g.inv_h, g.ny),
+                          cz = cell_coord(p.z, g.oz, g.inv_h, g.nz);
+                k[c] = ((unsigned)cz * g.ny + cy) * g.nx + cx;
+            }
+        }
+    }
+    if (out_of_box) __hip_atomic_store(bounds_error, kDevErrBounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (unsigned pass = 0; pass < passes; ++pass) {
+        const unsigned shift = 8u * pass;
+        for (unsigned i = tid; i < kSbWaves * 256; i += kSbThreads) (&cnt[0][0])[i] = 0u;
+        __syncthreads();
+        volatile unsigned* const my_cnt = cnt[w];
+#pragma unroll
+        for (int c = 0; c < kSbItems; ++c) {
+            const unsigned e = w * (kSmallBuildPoints / kSbWaves) + c * 64 + lane;
+            const bool valid = e < n;
+            const unsigned d = (k[c] >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long mm = __ballot(bit);
+                peers &= bit ? mm : ~mm;
+            }
+            const unsigned old = my_cnt[d];  // read by every lane BEFORE the digit's first lane bumps it (LDS ops of a wave are in order)
+            const unsigned lower = (unsigned)__builtin_popcountll(peers & lt);
+            rank[c] = old + lower;
+            if (valid && lower == 0u) my_cnt[d] = old + (unsigned)__builtin_popcountll(peers);
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        {   // digit tid: the waves' totals -> each wave's offset inside the digit; the digit's first position
+            unsigned tot = 0;
+            if (tid < 256u) {
+#pragma unroll
+                for (int i = 0; i < kSbWaves; ++i) { const unsigned c = cnt[i][tid]; cnt[i][tid] = tot; tot += c; }
+            }
+            unsigned inc = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(inc, off, 64);
+                if ((int)lane >= off) inc += o;
+            }
+            if (lane == 63u) wave_tot[w] = inc;
+            __syncthreads();
+            unsigned before = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) before += (unsigned)i < w ? wave_tot[i] : 0u;  // (digits live in waves 0..3)
+            if (tid < 256u) tstart[tid] = before + inc - tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kSbItems; ++c) {
+            const unsigned e = w * (kSmallBuildPoints / kSbWaves) + c * 64 + lane;
+            if (e < n) {
+                const unsigned d = (k[c] >> shift) & 255u;
+                const unsigned pos = tstart[d] + cnt[w][d] + rank[c];
+                lk[pos] = k[c];
+                lv[pos] = (unsigned short)v[c];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kSbItems; ++c) {
+            const unsigned e = w * (kSmallBuildPoints / kSbWaves) + c * 64 + lane;
+            if (e < n) { k[c] = lk[e]; v[c] = lv[e]; }
+        }
+        __syncthreads();
+    }
+    // points into cell order, {x, y, z, index bits} (gather_sorted_kernel)
+#pragma unroll
+    for (int c = 0; c < kSbItems; ++c) {
+        const unsigned e = w * (kSmallBuildPoints / kSbWaves) + c * 64 + lane;
+        if (e < n) {
+            float4 p = pts[v[c]];
+            p.w = __uint_as_float(v[c]);
+            out_pts[e] = p;
+        }
+    }
+    // start[c] = first sorted position whose key >= c, c in [0, ncells]: every run's first position is marked at its cell in an
+    // LDS table, and the table's suffix minimum is the answer (32 consecutive cells a lane; the scan across lanes by shuffles,
+    // across waves through LDS). cell_start_kernel's walk over the empty cells between two runs is serial per gap: on a cloud
+    // of surfaces (most cells empty) it was 15 of this kernel's 25 us.
+    __shared__ unsigned short table[kSmallBuildCells];
+    __shared__ unsigned wave_min[kSbWaves];
+    constexpr unsigned kPerLane = kSmallBuildCells / kSbThreads;  // 32
+    static_assert(kPerLane % 8 == 0, "whole 16-byte groups");
+    {
+        uint4* const t4 = reinterpret_cast<uint4*>(table);
+        for (unsigned i = tid; i < kSmallBuildCells / 8; i += kSbThreads) t4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kSbItems; ++c) {
+        const unsigned e = w * (kSmallBuildPoints / kSbWaves) + c * 64 + lane;
+        if (e < n) {
+            const unsigned key = min(k[c], ncells);
+            if (e == 0u || min(lk[e - 1], ncells) != key) table[key] = (unsigned short)e;
+        }
+    }
+    __syncthreads();
+    unsigned sfx[kPerLane];  // suffix minima inside the lane's 32 cells
+    {
+        const uint4* const t4 = reinterpret_cast<const uint4*>(table) + tid * (kPerLane / 8);
+        unsigned run = 0xffffu;
+#pragma unroll
+        for (int q = kPerLane / 8 - 1; q >= 0; --q) {
+            const uint4 u = t4[q];
+            const unsigned wds[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                run = min(run, wds[j] >> 16);
+                sfx[q * 8 + j * 2 + 1] = run;
+                run = min(run, wds[j] & 0xffffu);
+                sfx[q * 8 + j * 2] = run;
+            }
+        }
+        // exclusive suffix minimum over the lanes to the right: inside the wave, then over the waves
+        unsigned inc = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_down(inc, off, 64);
+            if ((int)lane + off < 64) inc = min(inc, o);
+        }
+        if (lane == 0u) wave_min[w] = inc;
+        __syncthreads();
+        unsigned carry = __shfl_down(inc, 1, 64);
+        if (lane == 63u) carry = 0xffffu;
+#pragma unroll
+        for (int i = 0; i < kSbWaves; ++i) carry = (unsigned)i > w ? min(carry, wave_min[i]) : carry;
+        carry = min(carry, n);  // (no run at or after the cell: the table closes at n)
+        const unsigned c0 = tid * kPerLane;
+        if (c0 + kPerLane <= ncells + 1u) {  // (all 32 cells exist: whole 16-byte stores)
+            uint4* const dst = reinterpret_cast<uint4*>(start + c0);
+#pragma unroll
+            for (int q = 0; q < (int)kPerLane / 4; ++q)
+                dst[q] = make_uint4(min(sfx[q * 4], carry), min(sfx[q * 4 + 1], carry), min(sfx[q * 4 + 2], carry), min(sfx[q * 4 + 3], carry));
+        } else {
+#pragma unroll
+            for (int j = 0; j < (int)kPerLane; ++j)
+                if (c0 + j <= ncells) start[c0 + j] = min(sfx[j], carry);
+        }
+    }
+}
+
 template <int KCAP>
 __global__ __launch_bounds__(kBlock) void grid_search_kernel(const float4* __restrict__ pts,
                                                              const unsigned* __restrict__ start, GridDesc g,
@@ -1588,25 +1769,34 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
         }
         unsigned* const units = b_units.as<unsigned>();
         void* const stmp = b_stmp.p;
+        bool small = false;
         if (e == hipSuccess) {
             GridDesc gd{g->inv_h, g->h, g->eps, g->org[0], g->org[1], g->org[2], g->dims[0], g->dims[1], g->dims[2],
                         (unsigned)n};
-            cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in, bounds6 ? device_error_word() : nullptr);
-            bool in_b = false;
-            if (const int rc = radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, n, end_bit, tmp, tmp_bytes, &in_b, st); rc != SP_OK) {
-                // (with the message the sort's own status check left: a launch error — or the device error word, raised by then
-                // by this build's cell_id_kernel for a point outside the caller's box)
-                (void)hipStreamSynchronize(st);
-                sp_grid_destroy(g);
-                return rc;
+            small = !adaptive && n <= kSmallBuildPoints && g->ncells < kSmallBuildCells && g_small_build;
+            if (small) {  // cell ids, sort, gather and cell table in one launch of one workgroup
+                grid_build_small_kernel<<<1, kSbThreads, 0, st>>>(pts, gd, (unsigned)g->ncells, (end_bit + 7u) / 8u, g->d_pts, g->d_start,
+                                                                  bounds6 ? device_error_word() : nullptr);
+            } else {
+                cell_id_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, gd, keys_in, vals_in, bounds6 ? device_error_word() : nullptr);
+                bool in_b = false;
+                if (const int rc = radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, n, end_bit, tmp, tmp_bytes, &in_b, st); rc != SP_OK) {
+                    // (with the message the sort's own status check left: a launch error — or the device error word, raised by then
+                    // by this build's cell_id_kernel for a point outside the caller's box)
+                    (void)hipStreamSynchronize(st);
+                    sp_grid_destroy(g);
+                    return rc;
+                }
+                if (!in_b) { keys_out = keys_in; vals_out = vals_in; }  // the passes ping-pong: the sorted pairs are where the last one wrote
             }
-            if (!in_b) { keys_out = keys_in; vals_out = vals_in; }  // the passes ping-pong: the sorted pairs are where the last one wrote
         }
         unsigned h_stats[2] = {0u, 0u};
         if (e == hipSuccess) {
-            gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
-            cell_start_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
-                                                                              g->d_start);
+            if (!small) {
+                gather_sorted_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(pts, vals_out, (unsigned)n, g->d_pts);
+                cell_start_kernel<<<div_up(n + 1, kBlock), kBlock, 0, st>>>(keys_out, (unsigned)n, (unsigned)g->ncells,
+                                                                                  g->d_start);
+            }
             if (!adaptive) {
                 // Nothing is read back and nothing waited for: the temporaries go to the pool behind the stream's work, an event
                 // marks the end of the build for other streams (grid_use), and the work units of the self-kNN tiling are made
@@ -1665,6 +1855,11 @@ int grid_create_impl(const float* points, size_t n, float cell_size, float point
 }  // namespace
 }  // namespace sp
 
+extern "C" int sp_internal_grid_small_build(int enable) {
+    const int was = sp::g_small_build ? 1 : 0;
+    if (enable >= 0) sp::g_small_build = enable != 0;
+    return was;
+}
 extern "C" int sp_grid_create(const float* points, size_t n, float cell_size, float points_per_cell, void* stream,
                               sp_grid** out) {
     return sp::grid_create_impl(points, n, cell_size, points_per_cell, false, stream, out);

@@ -53,6 +53,9 @@ enum {
 int sp_internal_source_option(sp_gicp_source* source, int option, int value);
 int sp_internal_grid_option(sp_grid* grid, int option, int value);
 int sp_internal_bvh_option(sp_bvh* bvh, int option, int value);
+/* Process-wide: grids of up to 8192 points and fewer than 32768 cells are built by one launch of one workgroup (1, default) or by the
+ * general chain of launches (0); < 0 only asks. Returns the previous setting. Same structure bit for bit. */
+int sp_internal_grid_small_build(int enable);
 /* Device pointer to the per-launch log of an sp_gicp_align_* workspace: entry k = number of source points launch k had to
  * search for (the others reused their previous correspondence by certificate). *n_entries_out = entries kept (64). */
 const uint32_t* sp_internal_align_searched_log(void* workspace, size_t* n_entries_out);

@@ -693,6 +693,70 @@ def test_grid_with_a_box_vouched_for_by_the_caller(sp, orc):
     own.knn_search(dev(q), 1)  # (the error word is cleared by the report: later calls are clean)
 
 
+def test_small_grids_are_built_by_one_workgroup_to_the_same_structure(sp, orc):
+    """Grids of up to 8192 points and fewer than 32768 cells: cell ids, sort, gather and cell table in ONE launch of one workgroup
+    (grid_build_small_kernel) — the same structure as the general chain of launches: the cell-order permutation, the neighbours
+    (k = 1, 10, bit for bit, and against the brute-force oracle), the fullest cell. Uniform clouds of 1 .. 8192 points (and 8193: the
+    general build either way), a surface, two far clusters (one long run of empty cells), points that are not finite, duplicates,
+    one cell for everything, a given cell size, a caller's box — and a point outside that box is still reported."""
+    from sycl_points_amd import _lib
+
+    L = _lib.lib()
+    g = orc.rng(2024)
+    rs = np.random.RandomState(5)
+    clouds = {}
+    for n in (1, 2, 63, 64, 65, 1000, 4097, 8191, 8192, 8193):
+        clouds[f"uniform{n}"] = (g.uniform_points(n, 6.0), {})
+    surf = g.uniform_points(6000, 20.0)
+    surf[:, 2] = np.float32(0.05) * np.sin(surf[:, 0]) + np.float32(1.0)
+    clouds["surface"] = (surf, {})
+    two = g.uniform_points(5000, 1.0)
+    two[2500:, :3] += np.float32([300.0, -200.0, 40.0])
+    clouds["two clusters"] = (two, {})
+    bad = g.uniform_points(3000, 4.0)
+    bad[::7, 1] = np.nan
+    bad[5, 0] = np.inf
+    clouds["not finite"] = (bad, {})
+    dup = g.uniform_points(2000, 3.0)
+    dup[1000:] = dup[:1000]
+    clouds["duplicates"] = (dup, {})
+    clouds["one cell"] = (g.uniform_points(700, 1.0), dict(cell_size=50.0))
+    clouds["cell size"] = (g.uniform_points(8000, 5.0), dict(cell_size=0.4))
+    clouds["box"] = (g.uniform_points(6100, 9.0), dict(bounds=(-9.5, -9.0, -9.25, 9.0, 10.0, 9.5)))
+    assert L.sp_internal_grid_small_build(-1) == 1
+    try:
+        for name, (pts, kw) in clouds.items():
+            q = np.concatenate([pts[rs.choice(len(pts), min(len(pts), 400))], g.uniform_points(100, 8.0)])
+            q[np.isnan(q)] = 0.0
+            q[np.isinf(q)] = 0.0
+            built = {}
+            for small in (1, 0):
+                L.sp_internal_grid_small_build(small)
+                gr = sp.GridKNN.build(dev(pts), **kw)
+                res = [gr.knn_search(dev(q), k) for k in (1, 10)]
+                built[small] = (gr.order().cpu().numpy(), [(r.indices.cpu().numpy(), r.distances.cpu().numpy()) for r in res],
+                                gr.max_cell_points(), gr.cell_size())
+            a, b = built[1], built[0]
+            assert np.array_equal(a[0], b[0]), name
+            assert a[2] == b[2] and a[3] == b[3], name
+            for (ai, ad), (bi, bd) in zip(a[1], b[1]):
+                assert np.array_equal(ai, bi) and np.array_equal(ad, bd), name
+            fin = np.isfinite(pts[:, :3]).all(1)
+            oi, od = orc.knn_bruteforce(q, pts[fin], 1)
+            assert np.array_equal(a[1][0][1], od), name
+            assert np.array_equal(np.flatnonzero(fin)[oi[:, 0]], a[1][0][0][:, 0]) or name == "duplicates", name
+        L.sp_internal_grid_small_build(1)
+        pts = g.uniform_points(5000, 4.0)
+        torch.cuda.synchronize()
+        with pytest.raises(sp.SpError, match="outside the bounds"):
+            badg = sp.GridKNN.build(dev(pts), bounds=(-2.0, -4.0, -4.0, 4.0, 4.0, 4.0))
+            torch.cuda.synchronize()
+            _lib.check(L.sp_grid_order(badg._h, torch.empty(5000, dtype=torch.int32, device="cuda").data_ptr(), sp._stream()))
+        torch.cuda.synchronize()
+    finally:
+        L.sp_internal_grid_small_build(1)
+
+
 @pytest.mark.parametrize("n", [1, 777, 2048, 69088, 300001])
 def test_box_filter_and_compaction_in_one_launch(sp, orc, n):
     # sp_box_filter_compact_multi: the box test, the scan of its flags (decoupled look-back over tiles of 2048) and the stable move
