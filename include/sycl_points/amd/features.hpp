@@ -28,14 +28,18 @@ struct DeviceScratch {
     void* p = nullptr;
     size_t bytes = 0;
     /// st: the stream the scratch will be used on (a buffer last used on the same stream is taken without waiting)
-    explicit DeviceScratch(size_t n, hipStream_t st = nullptr) {
+    explicit DeviceScratch(size_t n, hipStream_t st = nullptr) : st_(st) {
         if (n) p = ::sycl_points::detail::DeviceBufferCache::acquire(n, &bytes, st);
     }
     ~DeviceScratch() {
         if (!p) return;
         if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();
-        ::sycl_points::detail::DeviceBufferCache::release(p, bytes, nullptr, /*idle=*/true);
+        if (stream_ordered) ::sycl_points::detail::DeviceBufferCache::release(p, bytes, st_, /*idle=*/false);
+        else ::sycl_points::detail::DeviceBufferCache::release(p, bytes, nullptr, /*idle=*/true);
     }
+    /// set by a user that did NOT synchronise: everything that touched the scratch was enqueued on the stream it was taken for
+    bool stream_ordered = false;
+    hipStream_t st_ = nullptr;
     DeviceScratch(const DeviceScratch&) = delete;
     DeviceScratch& operator=(const DeviceScratch&) = delete;
 };
@@ -279,22 +283,30 @@ private:
         // extents; the device verifies that this cloud fits, and the key kernel finds this cloud's own box on the way (next
         // call's guess; the exact box of the redo when the cloud did not fit). The first call has no guess and computes the
         // box first: every call sorts compressed keys (the 64-bit sort is left for boxes of >= 2^32 cells).
+        // The call reports {voxels, points outside the box, this cloud's key box} in ONE record (sp_voxel_downsample_report): through
+        // host-mapped words the last kernel stores to and this thread spins on when they are to be had — no copy, no
+        // synchronisation: the scratch then goes back behind the stream's work — else through a copy and a wait.
+        const detail::MappedWord& mapped = detail::MappedWord::mine();
+        const bool poll = mapped.usable();
         auto launch = [&](const int32_t* box) {
-            throw_on_error(sp_voxel_downsample_boxed(
+            uint32_t* const report = poll ? mapped.dev : info_dev;
+            if (poll) mapped.arm();
+            throw_on_error(sp_voxel_downsample_report(
                 pts, N, voxel_size_inv_, min_voxel_count_, rgb ? reinterpret_cast<const float*>(rgb->device_data()) : nullptr,
                 inten ? inten->device_data() : nullptr, ts ? ts->device_data() : nullptr,
                 reinterpret_cast<float*>(out_pts.device_data_for_write(N)),
                 rgb ? reinterpret_cast<float*>(out_rgb->device_data_for_write(N)) : nullptr,
                 inten ? out_inten->device_data_for_write(N) : nullptr, ts ? out_ts->device_data_for_write(N) : nullptr, nullptr,
-                info_dev, box, info_dev + 1, reinterpret_cast<int32_t*>(info_dev + 32), ws.p, ws_bytes, st));
-            hip_check(hipMemcpyAsync(h, info.p, kInfoInts * 4, hipMemcpyDeviceToHost, st), "D2H");
-            hip_check(hipStreamSynchronize(st), "sync");
-            for (int a = 0; a < 3; ++a) {  // fold the shards into h[2..7]
-                h[2 + a] = INT32_MAX; h[5 + a] = INT32_MIN;
-                for (int s = 0; s < SP_VOXEL_BOX_SHARDS; ++s) {
-                    h[2 + a] = std::min(h[2 + a], h[32 + SP_VOXEL_BOX_SHARD_STRIDE * s + a]);
-                    h[5 + a] = std::max(h[5 + a], h[32 + SP_VOXEL_BOX_SHARD_STRIDE * s + 3 + a]);
-                }
+                nullptr, box, report, ws.p, ws_bytes, st));
+            if (poll) {
+                h[0] = static_cast<int32_t>(mapped.wait(st));
+                std::atomic_thread_fence(std::memory_order_acquire);
+                for (int j = 1; j < 8; ++j) h[j] = static_cast<int32_t>(mapped.host[j]);
+                ws.stream_ordered = true;  // (kernels of the call may still be running: not idle, but ordered on st)
+                info.stream_ordered = true;
+            } else {
+                hip_check(hipMemcpyAsync(h, info.p, 32, hipMemcpyDeviceToHost, st), "D2H");
+                hip_check(hipStreamSynchronize(st), "sync");
             }
         };
         if (!have_key_box_) {

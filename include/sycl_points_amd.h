@@ -32,7 +32,7 @@ extern "C" {
 #define SP_ERR_RUNTIME 2          /* reference: std::runtime_error    */
 #define SP_ERR_HIP 3              /* reference: sycl::exception from wait_and_throw */
 
-#define SP_ABI_VERSION 5
+#define SP_ABI_VERSION 6
 int sp_abi_version(void);
 /* The library keeps device buffers it no longer needs (temporaries of a build, the arrays of a destroyed grid / tree / target) in
  * a pool, tagged with the stream whose work may still use them: a later call on the SAME stream takes them without waiting (stream
@@ -263,6 +263,20 @@ int sp_voxel_downsample_boxed(const float* points, size_t n, float inv_voxel_siz
                               float* rgb_out, float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt,
                               uint32_t* n_out_dev, const int32_t* box6_host, uint32_t* status_dev_opt,
                               int32_t* box_shards_dev_opt, void* workspace, size_t workspace_bytes, void* stream);
+/* sp_voxel_downsample_boxed with ONE record in place of the status word and the sharded box (VoxelGrid::downsampling,
+ * voxel_downsampling.hpp:146-288, frame after frame):
+ *   report8 = {voxels written, valid points outside box6 (non-zero: discard the outputs and call again with the box below),
+ *              THIS cloud's key box min x, y, z, max x, y, z (INT32_MAX / INT32_MIN when no point is valid)}
+ * stored once by the call's last kernel, word 0 LAST and behind a system-scope release: report8 may be the device pointer of
+ * host-mapped pinned memory whose word 0 the caller armed with a value no count takes and spins on — no copy, no
+ * synchronisation. (The other outputs may still be in flight when word 0 lands; work enqueued on the stream stays ordered
+ * behind them.) The key kernel's workgroups leave one record each in the workspace and the last kernel folds them, so there are
+ * no atomics to initialise: one launch fewer than the boxed call, two with its read-back. n_out_dev_opt may be NULL. */
+int sp_voxel_downsample_report(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
+                               const float* rgb, const float* intensities, const float* timestamps, float* points_out,
+                               float* rgb_out, float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt,
+                               uint32_t* n_out_dev_opt, const int32_t* box6_host, uint32_t* report8, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------- transform */
 

@@ -135,6 +135,7 @@ SIGNATURES = {
     "sp_voxel_downsample": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_voxel_key_box": (_i, [_vp, _sz, _f, _vp, _vp]),
     "sp_voxel_downsample_boxed": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sp_voxel_downsample_report": (_i, [_vp, _sz, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sp_transform": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sp_box_filter_flags": (_i, [_vp, _sz, _f, _f, _vp, _vp]),
     "sp_compact_workspace_bytes": (_sz, [_sz]),
@@ -255,7 +256,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.sp_abi_version() != 5:
+        if L.sp_abi_version() != 6:
             raise ImportError("libsycl_points_amd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -56,9 +56,10 @@ __device__ __forceinline__ bool voxel_coords(const float4 p, float inv, int& c0,
 }
 
 // Bounding box of the voxel coordinates (integer atomics: order-independent). box = {min x,y,z, max x,y,z}.
-__global__ void box_init_kernel(int32_t* box) {
+__global__ void box_init_kernel(int32_t* box, bool eight = false) {  // eight: a whole record of voxel_report (no point outside)
     if (threadIdx.x < 3) box[threadIdx.x] = INT32_MAX;
     else if (threadIdx.x < 6) box[threadIdx.x] = INT32_MIN;
+    else if (eight && threadIdx.x < 8) box[threadIdx.x] = 0;
 }
 __global__ __launch_bounds__(kBlock) void key_box_kernel(const float4* __restrict__ pts, unsigned n, float inv,
                                                          int32_t* __restrict__ box) {
@@ -119,8 +120,13 @@ __global__ __launch_bounds__(kBlock) void voxel_init_kernel(uint32_t* status, in
 // (two thousand workgroups on sixteen shards packed into six lines took 12 us); the caller folds the shards.
 __global__ __launch_bounds__(kBlock) void key32_kernel(const float4* __restrict__ pts, unsigned n, float inv, KeyBox b,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                       uint32_t* __restrict__ status, int32_t* __restrict__ box_shards) {
+                                                       uint32_t* __restrict__ status, int32_t* __restrict__ box_shards,
+                                                       int32_t* __restrict__ wg_records = nullptr) {
+    // wg_records (sp_voxel_downsample_report): instead of atomics on the status word and the sharded box — which need a launch to
+    // initialise them — every workgroup stores ONE record {box lo xyz, hi xyz, points outside the given box, 0}; the call's last
+    // kernel folds the records (voxel_report).
     int lo0 = INT32_MAX, lo1 = INT32_MAX, lo2 = INT32_MAX, hi0 = INT32_MIN, hi1 = INT32_MIN, hi2 = INT32_MIN;
+    int outside = 0;
     // four independent loads per trip (a latency chain otherwise)
     const unsigned stride = gridDim.x * kBlock;
     for (unsigned i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
@@ -138,32 +144,82 @@ __global__ __launch_bounds__(kBlock) void key32_kernel(const float4* __restrict_
                 hi0 = max(hi0, c0); hi1 = max(hi1, c1); hi2 = max(hi2, c2);
                 const unsigned x = (unsigned)(c0 - b.x0), y = (unsigned)(c1 - b.y0), z = (unsigned)(c2 - b.z0);
                 if (x < b.nx && y < b.ny && z < b.nz) key = (z * b.ny + y) * b.nx + x;
+                else if (wg_records) ++outside;
                 else if (status) atomicAdd(status, 1u);
             }
             keys[i] = key;
             vals[i] = i;
         }
     }
-    if (!box_shards) return;  // uniform
+    if (!box_shards && !wg_records) return;  // uniform
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
         lo0 = min(lo0, __shfl_xor(lo0, off)); lo1 = min(lo1, __shfl_xor(lo1, off)); lo2 = min(lo2, __shfl_xor(lo2, off));
         hi0 = max(hi0, __shfl_xor(hi0, off)); hi1 = max(hi1, __shfl_xor(hi1, off)); hi2 = max(hi2, __shfl_xor(hi2, off));
+        outside += __shfl_xor(outside, off);
     }
-    __shared__ int red[kBlock / kWave][6];
+    __shared__ int red[kBlock / kWave][7];
     const unsigned wave = threadIdx.x / kWave;
     if ((threadIdx.x & (kWave - 1)) == 0) {
         red[wave][0] = lo0; red[wave][1] = lo1; red[wave][2] = lo2;
         red[wave][3] = hi0; red[wave][4] = hi1; red[wave][5] = hi2;
+        red[wave][6] = outside;
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 7) {
         int v = red[0][threadIdx.x];
-        for (unsigned w = 1; w < kBlock / kWave; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
-        int32_t* const dst = box_shards + kBoxStride * (blockIdx.x & (kBoxShards - 1)) + threadIdx.x;
-        if (threadIdx.x < 3) { if (v != INT32_MAX) atomicMin(dst, v); }
-        else if (v != INT32_MIN) atomicMax(dst, v);
+        for (unsigned w = 1; w < kBlock / kWave; ++w)
+            v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : (threadIdx.x < 6 ? max(v, red[w][threadIdx.x]) : v + red[w][threadIdx.x]);
+        if (wg_records) {
+            wg_records[blockIdx.x * 8 + threadIdx.x] = v;
+        } else if (threadIdx.x < 6) {
+            int32_t* const dst = box_shards + kBoxStride * (blockIdx.x & (kBoxShards - 1)) + threadIdx.x;
+            if (threadIdx.x < 3) { if (v != INT32_MAX) atomicMin(dst, v); }
+            else if (v != INT32_MIN) atomicMax(dst, v);
+        }
     }
+}
+// sp_voxel_downsample_report: the records of the key kernel's workgroups folded into report8 = {voxels, points outside the given
+// box, this cloud's key box lo xyz, hi xyz}, by one workgroup of kBlock lanes (all of them call). Word 0 goes last, behind a
+// system-scope fence: report8 may be host-mapped memory the caller spins on.
+__device__ __forceinline__ void voxel_report(const int32_t* __restrict__ records, unsigned n_records, unsigned voxels,
+                                             uint32_t* __restrict__ report8) {
+    __shared__ int rred[kBlock / kWave][7];
+    int v[7] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0};
+    for (unsigned r = threadIdx.x; r < n_records; r += kBlock) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int x = records[r * 8 + j];
+            v[j] = j < 3 ? min(v[j], x) : (j < 6 ? max(v[j], x) : v[j] + x);
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int x = __shfl_xor(v[j], off);
+            v[j] = j < 3 ? min(v[j], x) : (j < 6 ? max(v[j], x) : v[j] + x);
+        }
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) rred[threadIdx.x / kWave][j] = v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            int x = rred[0][j];
+            for (unsigned w = 1; w < kBlock / kWave; ++w) x = j < 3 ? min(x, rred[w][j]) : (j < 6 ? max(x, rred[w][j]) : x + rred[w][j]);
+            report8[j < 6 ? 2 + j : 1] = (uint32_t)x;
+        }
+        __threadfence_system();
+        __hip_atomic_store(report8, voxels, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(kBlock) void voxel_report_kernel(const int32_t* __restrict__ records, unsigned n_records,
+                                                              const uint32_t* __restrict__ voxels_dev, uint32_t* __restrict__ report8) {
+    voxel_report(records, n_records, voxels_dev ? *voxels_dev : 0u, report8);
 }
 __device__ __forceinline__ uint64_t expand_key(uint32_t k, const KeyBox& b) {
     if (k >= b.invalid) return kInvalidKey;
@@ -379,8 +435,11 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restr
                                                          const float4* __restrict__ t_pts, AggPtrs a,
                                                          float4* __restrict__ o_pts, float4* __restrict__ o_rgb,
                                                          float* __restrict__ o_inten, float* __restrict__ o_ts,
-                                                         uint64_t* __restrict__ o_keys, uint32_t* __restrict__ n_out) {
+                                                         uint64_t* __restrict__ o_keys, uint32_t* __restrict__ n_out,
+                                                         const int32_t* __restrict__ records = nullptr, unsigned n_records = 0,
+                                                         uint32_t* __restrict__ report8 = nullptr) {
     __shared__ unsigned wave_kept[kBlock / 64];
+    __shared__ unsigned s_all;
     __shared__ unsigned wave_before[kBlock / 64];
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -404,7 +463,8 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restr
             unsigned all = before;
 #pragma unroll
             for (unsigned j = 0; j < kBlock / 64; ++j) all += wave_kept[j];
-            *n_out = all;
+            if (n_out) *n_out = all;
+            s_all = all;
         }
     } else {
         before = block_off[blockIdx.x];
@@ -418,12 +478,19 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(const uint32_t* __restr
         if (a.ts) o_ts[p] = a.t_ts[i];
         if (o_keys) o_keys[p] = sizeof(KEY) == 8 ? (uint64_t)sk[i] : expand_key((uint32_t)sk[i], box);
     }
+    if constexpr (FOLD) {
+        if (report8 && blockIdx.x == gridDim.x - 1) {  // (uniform per workgroup)
+            __syncthreads();
+            voxel_report(records, n_records, s_all, report8);
+        }
+    }
 }
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+constexpr unsigned kKeyGridMax = 1024;  // workgroups of key32_kernel at most
 
 struct VoxelWs {
-    size_t keys_in, keys_out, vals_in, vals_out, flag, pos, t_pts, t_rgb, t_inten, t_ts, prim, prim_bytes, total;
+    size_t keys_in, keys_out, vals_in, vals_out, flag, pos, t_pts, t_rgb, t_inten, t_ts, prim, prim_bytes, records, total;
 };
 
 VoxelWs voxel_ws(size_t n) {
@@ -438,6 +505,7 @@ VoxelWs voxel_ws(size_t n) {
     if (radix_sort_u32_workspace_bytes(n) > w.prim_bytes) w.prim_bytes = radix_sort_u32_workspace_bytes(n);
     if (exclusive_scan_u32_workspace_bytes(n) > w.prim_bytes) w.prim_bytes = exclusive_scan_u32_workspace_bytes(n);
     w.prim = take(w.prim_bytes);
+    w.records = take(kKeyGridMax * 8 * sizeof(int32_t));  // one record per workgroup of the key kernel (sp_voxel_downsample_report)
     w.total = o;
     return w;
 }
@@ -476,13 +544,16 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
                           const float* intensities, const float* timestamps, float* points_out, float* rgb_out,
                           float* intensities_out, float* timestamps_out, uint64_t* keys_out_opt, uint32_t* n_out_dev,
                           const int32_t* box6_host, uint32_t* status_dev, int32_t* box_shards_dev, void* workspace,
-                          size_t workspace_bytes, hipStream_t st) {
+                          size_t workspace_bytes, hipStream_t st, uint32_t* report8 = nullptr) {
     if (!(inv_voxel_size > 0.0f)) {
         sp_set_error("voxel_size must be positive");  // voxel_downsampling.hpp:23-25
         return SP_ERR_INVALID_ARGUMENT;
     }
     if (status_dev || box_shards_dev) voxel_init_kernel<<<1, kBlock, 0, st>>>(status_dev, box_shards_dev);
-    if (n == 0) return zero_async(n_out_dev, 4, st);
+    if (n == 0) {
+        if (report8) voxel_report_kernel<<<1, kBlock, 0, st>>>(nullptr, 0u, nullptr, report8);  // {0, 0, empty box}
+        return n_out_dev ? zero_async(n_out_dev, 4, st) : launch_status();
+    }
     if (n >= (1ull << 32)) {
         sp_set_error("[VoxelGrid::downsampling] more than 2^32 points");
         return SP_ERR_INVALID_ARGUMENT;
@@ -506,6 +577,8 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
     a.t_rgb = (float4*)(base + w.t_rgb);
     a.t_inten = (float*)(base + w.t_inten);
     a.t_ts = (float*)(base + w.t_ts);
+    int32_t* const records = report8 ? (int32_t*)(base + w.records) : nullptr;
+    const unsigned agg_blocks = div_up(n, kBlock);
 
     // compressed 32-bit keys when the caller knows the bounding box of the voxel coordinates and it has < 2^32 cells
     KeyBox kb{0, 0, 0, 0, 0, 0, 0};
@@ -523,8 +596,9 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
     if (boxed) {
         uint32_t* k_in = (uint32_t*)(base + w.keys_in);
         uint32_t* k_sorted = (uint32_t*)(base + w.keys_out);
-        key32_kernel<<<std::min(stream_grid(n, kBlock, 4), 1024u), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in,
-                                                                                    vals_in, status_dev, box_shards_dev);
+        const unsigned key_grid = std::min(stream_grid(n, kBlock, 4), kKeyGridMax);
+        key32_kernel<<<key_grid, kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, status_dev, box_shards_dev,
+                                                  records);
         unsigned end_bit = 1;
         while ((1ull << end_bit) <= (uint64_t)kb.invalid && end_bit < 32) ++end_bit;  // `invalid` itself must be representable
         bool in_b = false;  // the hand-written sort (radix_sort.hip) ping-pongs between the two buffer pairs
@@ -535,22 +609,30 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
         if (!in_b) { uint32_t* t = k_in; k_in = k_sorted; k_sorted = t; t = vals_in; vals_in = vals_sorted; vals_sorted = t; }
         aggregate_kernel<uint32_t><<<div_up(n, kBlock), kBlock, 0, st>>>(k_sorted, kb.invalid, vals_sorted, (unsigned)n, pts,
                                                                          (float)min_voxel_count, a, t_pts, flag, pos);
-        if (div_up(n, kBlock) <= kFoldBlocks) {
-            scatter_kernel<uint32_t, true><<<div_up(n, kBlock), kBlock, 0, st>>>(
+        if (agg_blocks <= kFoldBlocks) {
+            scatter_kernel<uint32_t, true><<<agg_blocks, kBlock, 0, st>>>(
                 flag, pos, (unsigned)n, k_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
-                reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+                reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev, records, key_grid, report8);
             return launch_status();
         }
-        block_offsets_kernel<<<1, 1024, 0, st>>>(pos, div_up(n, kBlock), n_out_dev);
-        scatter_kernel<uint32_t, false><<<div_up(n, kBlock), kBlock, 0, st>>>(
+        uint32_t* const total = n_out_dev ? n_out_dev : reinterpret_cast<uint32_t*>(base + w.prim);  // (the sort is over: its scratch is free)
+        block_offsets_kernel<<<1, 1024, 0, st>>>(pos, agg_blocks, total);
+        scatter_kernel<uint32_t, false><<<agg_blocks, kBlock, 0, st>>>(
             flag, pos, (unsigned)n, k_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
             reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+        if (report8) voxel_report_kernel<<<1, kBlock, 0, st>>>(records, key_grid, total, report8);
         return launch_status();
     }
     uint64_t* keys_in = (uint64_t*)(base + w.keys_in);
     uint64_t* keys_sorted = (uint64_t*)(base + w.keys_out);
     // no usable box (none given, or one of >= 2^32 cells): the 63-bit keys themselves, eight passes of the same sort
     key_kernel<<<stream_grid(n), kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, keys_in, vals_in);
+    if (records) {  // this cloud's box for the report: one record, by integer atomics (no point is "outside": there is no box)
+        unsigned grid = div_up(n, kBlock * 16);
+        if (grid > 256u) grid = 256u;
+        box_init_kernel<<<1, 64, 0, st>>>(records, true);
+        key_box_kernel<<<grid ? grid : 1u, kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, records);
+    }
     if (box_shards_dev) {  // this cloud's box for the caller, as on the boxed path
         unsigned grid = div_up(n, kBlock * 16);
         if (grid > 256u) grid = 256u;
@@ -564,16 +646,18 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
     if (!in_b64) { uint64_t* t = keys_in; keys_in = keys_sorted; keys_sorted = t; uint32_t* tv = vals_in; vals_in = vals_sorted; vals_sorted = tv; }
     aggregate_kernel<uint64_t><<<div_up(n, kBlock), kBlock, 0, st>>>(keys_sorted, kInvalidKey, vals_sorted, (unsigned)n, pts,
                                                                      (float)min_voxel_count, a, t_pts, flag, pos);
-    if (div_up(n, kBlock) <= kFoldBlocks) {
-        scatter_kernel<uint64_t, true><<<div_up(n, kBlock), kBlock, 0, st>>>(
+    if (agg_blocks <= kFoldBlocks) {
+        scatter_kernel<uint64_t, true><<<agg_blocks, kBlock, 0, st>>>(
             flag, pos, (unsigned)n, keys_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
-            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+            reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev, records, 1u, report8);
         return launch_status();
     }
-    block_offsets_kernel<<<1, 1024, 0, st>>>(pos, div_up(n, kBlock), n_out_dev);
-    scatter_kernel<uint64_t, false><<<div_up(n, kBlock), kBlock, 0, st>>>(
+    uint32_t* const total = n_out_dev ? n_out_dev : reinterpret_cast<uint32_t*>(base + w.prim);
+    block_offsets_kernel<<<1, 1024, 0, st>>>(pos, agg_blocks, total);
+    scatter_kernel<uint64_t, false><<<agg_blocks, kBlock, 0, st>>>(
         flag, pos, (unsigned)n, keys_sorted, kb, t_pts, a, reinterpret_cast<float4*>(points_out),
         reinterpret_cast<float4*>(rgb_out), intensities_out, timestamps_out, keys_out_opt, n_out_dev);
+    if (report8) voxel_report_kernel<<<1, kBlock, 0, st>>>(records, 1u, total, report8);
     return launch_status();
 }
 }  // namespace
@@ -612,6 +696,18 @@ extern "C" int sp_voxel_downsample_boxed(const float* points, size_t n, float in
     return sp::voxel_downsample_impl(points, n, inv_voxel_size, min_voxel_count, rgb, intensities, timestamps, points_out,
                                      rgb_out, intensities_out, timestamps_out, keys_out_opt, n_out_dev, box6_host,
                                      status_dev_opt, box_shards_dev_opt, workspace, workspace_bytes, sp::as_stream(stream));
+}
+
+extern "C" int sp_voxel_downsample_report(const float* points, size_t n, float inv_voxel_size, size_t min_voxel_count,
+                                          const float* rgb, const float* intensities, const float* timestamps,
+                                          float* points_out, float* rgb_out, float* intensities_out,
+                                          float* timestamps_out, uint64_t* keys_out_opt, uint32_t* n_out_dev_opt,
+                                          const int32_t* box6_host, uint32_t* report8, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    if (!report8) return SP_ERR_INVALID_ARGUMENT;
+    return sp::voxel_downsample_impl(points, n, inv_voxel_size, min_voxel_count, rgb, intensities, timestamps, points_out,
+                                     rgb_out, intensities_out, timestamps_out, keys_out_opt, n_out_dev_opt, box6_host, nullptr,
+                                     nullptr, workspace, workspace_bytes, sp::as_stream(stream), report8);
 }
 
 extern "C" int sp_box_filter_flags(const float* points, size_t n, float min_distance, float max_distance,

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
-    assert _lib.lib().sp_abi_version() == 5
+    assert _lib.lib().sp_abi_version() == 6
     # measurement / tuning switches are per handle and live in csrc/sp_internal.h, not in the public header
     assert not [s for s in syms if s.startswith(("sp_debug", "sp_internal"))]
     assert all(hasattr(lib, s) for s in _lib.INTERNAL_SIGNATURES)

@@ -588,6 +588,66 @@ def test_voxel_boxed_path_equals_64bit_path(sp, orc):
     assert sh[:, :3].min(0).tolist() + sh[:, 3:6].max(0).tolist() == true_box
 
 
+def test_voxel_report_record(sp, orc):
+    """sp_voxel_downsample_report: the boxed call with ONE 8-word record {voxels, points outside the box, this cloud's key box}
+    stored by the call's last kernel (no status word, no sharded box, no initialisation launch): outputs identical to
+    sp_voxel_downsample_boxed, the record equal to that call's count / status / folded shards — for a covering box, a box the cloud
+    leaves, no box at all (64-bit keys), an empty cloud, and above the offsets fold (a report launch of its own)."""
+    import ctypes as C
+
+    L = sp._lib.lib()
+
+    def run(pts, vs, box, report_api):
+        n = len(pts)
+        P = dev(pts) if n else torch.empty((0, 4), dtype=torch.float32, device="cuda")
+        nb = L.sp_voxel_downsample_workspace_bytes(max(n, 1))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        o = torch.zeros((max(n, 1), 4), dtype=torch.float32, device="cuda")
+        keys = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda")
+        bx = None if box is None else np.asarray(box, np.int32).ctypes.data_as(C.c_void_p)
+        if report_api:
+            rep = torch.full((8,), 0x7fffffff, dtype=torch.int32, device="cuda")
+            sp._lib.check(L.sp_voxel_downsample_report(sp._ptr(P), n, 1.0 / vs, 1, None, None, None, sp._ptr(o), None, None, None,
+                                                       sp._ptr(keys), None, bx, sp._ptr(rep), sp._ptr(ws), nb, sp._stream()))
+            r = rep.cpu().numpy().astype(np.int64)
+            cnt, status, kb = int(r[0]), int(r[1]), r[2:8].tolist()
+        else:
+            cs = torch.zeros(2, dtype=torch.int32, device="cuda")
+            shards = torch.zeros((sp._lib.VOXEL_BOX_SHARDS, sp._lib.VOXEL_BOX_SHARD_STRIDE), dtype=torch.int32, device="cuda")
+            sp._lib.check(L.sp_voxel_downsample_boxed(sp._ptr(P), n, 1.0 / vs, 1, None, None, None, sp._ptr(o), None, None, None,
+                                                      sp._ptr(keys), sp._ptr(cs), bx, C.c_void_p(cs.data_ptr() + 4), sp._ptr(shards),
+                                                      sp._ptr(ws), nb, sp._stream()))
+            sh = shards.cpu().numpy().astype(np.int64)
+            cnt, status = int(cs[0]), int(cs[1])
+            kb = sh[:, :3].min(0).tolist() + sh[:, 3:6].max(0).tolist()
+        return cnt, status, kb, o[:cnt].cpu().numpy(), keys[:cnt].cpu().numpy()
+
+    pts = cloud(orc, 41, 50000, 6.0)
+    pts[11, 2] = np.nan
+    keys = sp.VoxelGrid(0.25).compute_voxel_bit(dev(pts)).cpu().numpy().view(np.uint64)
+    ok = keys != np.uint64(0xFFFFFFFFFFFFFFFF)
+    f = [(keys[ok] >> np.uint64(s)) & np.uint64((1 << 21) - 1) for s in (0, 21, 42)]
+    true_box = [int(x.min()) for x in f] + [int(x.max()) for x in f]
+    wide = [b - 3 for b in true_box[:3]] + [b + 5 for b in true_box[3:]]
+    tight = true_box[:3] + [true_box[3] - 4] + true_box[4:]  # the cloud leaves it in x
+    for box in (wide, true_box, tight, None):
+        a, b = run(pts, 0.25, box, True), run(pts, 0.25, box, False)
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] == true_box, (box, a[:3], b[:3])
+        assert (a[1] > 0) == (box is tight)
+        if a[1] == 0:
+            assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+            o = orc.voxel_downsample(pts, 0.25, 1, stable=True)
+            assert np.array_equal(a[4].view(np.uint64), o["keys"]) and np.array_equal(a[3], o["points"])
+    e = run(np.zeros((0, 4), np.float32), 0.25, None, True)
+    assert e[0] == 0 and e[1] == 0 and e[2][0] > e[2][3]  # empty cloud: an empty box
+    big = cloud(orc, 42, 1_200_000, 6.0)  # 4688 aggregation workgroups: offsets launch + a report launch
+    a, b = run(big, 0.2, None, True), run(big, 0.2, None, False)
+    kb = a[2]
+    c, d = run(big, 0.2, kb, True), run(big, 0.2, kb, False)
+    for x, y in ((a, b), (c, d), (a, c)):
+        assert x[0] == y[0] and x[1] == y[1] == 0 and x[2] == y[2] and np.array_equal(x[3], y[3]) and np.array_equal(x[4], y[4])
+
+
 def test_voxel_config3_1m(sp, orc):
     # BASELINE config 3 at full size: 1M points, voxel 0.1; oracle keys everywhere, oracle means on the whole cloud
     pts = cloud(orc, 1234, 1000000, 10.0)
