@@ -1003,13 +1003,12 @@ def stage_block(sp, _lib, torch, cpu=True):
         nbytes = L.sp_voxel_downsample_workspace_bytes(n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=P.device)
         o_p = torch.empty((n, 4), dtype=torch.float32, device=P.device)
-        info = torch.zeros(32 + _lib.VOXEL_BOX_SHARDS * _lib.VOXEL_BOX_SHARD_STRIDE, dtype=torch.int32, device=P.device)
-        b = info.data_ptr()
+        info = torch.zeros(8, dtype=torch.int32, device=P.device)  # the call's record: voxels, points outside the box, key box
 
         def run():
-            _lib.check(L.sp_voxel_downsample_boxed(sp._ptr(P), n, vg.voxel_size_inv, 1, None, None, None, sp._ptr(o_p), None,
-                                                   None, None, None, C.c_void_p(b), box.ctypes.data_as(C.c_void_p),
-                                                   C.c_void_p(b + 4), C.c_void_p(b + 128), sp._ptr(ws), nbytes, sp._stream()))
+            _lib.check(L.sp_voxel_downsample_report(sp._ptr(P), n, vg.voxel_size_inv, 1, None, None, None, sp._ptr(o_p), None,
+                                                    None, None, None, None, box.ctypes.data_as(C.c_void_p), sp._ptr(info),
+                                                    sp._ptr(ws), nbytes, sp._stream()))
 
         ms, runs = median_ms(torch, run)
         assert int(info[0]) == nvox and int(info[1]) == 0

@@ -695,23 +695,23 @@ class VoxelGrid:
         # leaves the remembered box is detected (status != 0) and redone with its own exact box, so results never depend on
         # the guess. The first call of a VoxelGrid has no guess: it computes the box first (sp_voxel_key_box, one small
         # read-back) — every call sorts compressed keys; the 64-bit sort is left for boxes of >= 2^32 cells.
-        S, ST = _lib.VOXEL_BOX_SHARDS, _lib.VOXEL_BOX_SHARD_STRIDE
-        info = torch.zeros(32 + ST * S, dtype=torch.int32, device=p.device)
+        # (sp_voxel_downsample_report: all of it in ONE 8-word record the call's last kernel stores — no status word and sharded
+        # box to initialise and fold)
+        info = torch.zeros(16, dtype=torch.int32, device=p.device)
         base = info.data_ptr()
         args = (_ptr(p), n, self.voxel_size_inv, self.min_voxel_count, _ptr(rgb), _ptr(inten), _ptr(ts), _ptr(o_p), _ptr(o_c),
-                _ptr(o_i), _ptr(o_t), _ptr(o_k), C.c_void_p(base))
+                _ptr(o_i), _ptr(o_t), _ptr(o_k), None)
 
         def run(box):
-            check(L.sp_voxel_downsample_boxed(*args, None if box is None else box.ctypes.data_as(C.c_void_p),
-                                              C.c_void_p(base + 4), C.c_void_p(base + 128), _ptr(ws), nbytes, _stream()))
+            check(L.sp_voxel_downsample_report(*args, None if box is None else box.ctypes.data_as(C.c_void_p),
+                                               C.c_void_p(base), _ptr(ws), nbytes, _stream()))
             c = info.cpu().numpy()
-            sh = c[32:].reshape(S, ST)[:, :6].astype(np.int64)
-            return c, np.concatenate([sh[:, :3].min(0), sh[:, 3:].max(0)])
+            return c, c[2:8].astype(np.int64)
 
         guess = getattr(self, "_key_box", None) if boxed else None
         if guess is None and boxed:
-            check(L.sp_voxel_key_box(_ptr(p), n, self.voxel_size_inv, C.c_void_p(base + 8), _stream()))
-            b0 = info[2:8].cpu().numpy().astype(np.int64)
+            check(L.sp_voxel_key_box(_ptr(p), n, self.voxel_size_inv, C.c_void_p(base + 32), _stream()))
+            b0 = info[8:14].cpu().numpy().astype(np.int64)
             guess = np.ascontiguousarray(b0.astype(np.int32)) if (b0[:3] <= b0[3:]).all() else None
         counts, box = run(guess)
         if counts[1] != 0:  # the cloud left the remembered box: again, with its own
