@@ -519,6 +519,46 @@ def test_voxel_downsample_matches_oracle(sp, orc, r, vs, minc):
     assert np.allclose(out.points.cpu().numpy(), o2["points"], atol=1e-5)
 
 
+@pytest.mark.parametrize("attrs", ["none", "rgb", "ts", "rgb+ts+intensity"])
+def test_voxel_runs_of_thousands_of_points(sp, orc, attrs):
+    """Voxels of a few to several thousand points (a scan's near range): the sequential sums of runs that span waves, the
+    workgroup's 256 positions and several 256-member rounds of the fetch past them — every attribute combination the kernel is
+    instantiated for, bit for bit against the oracle's loop; with members that are -0.0 (0 + -0.0 = +0.0 in the oracle's sum)."""
+    rs = np.random.RandomState(17)
+    n = 60000
+    pts = cloud(orc, 99, n, 1.0)                      # 8 voxels of 1.0 m hold ~4000 points each ...
+    pts[:20000, :3] *= np.float32(6.0)                # ... 20000 points spread over ~1700 voxels (runs of ~12)
+    pts[30000:30400, :3] = np.float32([0.25, 0.5, 0.75])  # 400 identical points
+    pts[40000:40003, 0] = np.float32(-0.0)
+    pts[50000:50600, :3] = np.float32([-0.0, 0.5, 0.5])   # a run whose x sum is made of -0.0 terms only... inside a bigger voxel
+    rgb = rs.uniform(0, 1, (n, 4)).astype(np.float32) if "rgb" in attrs else None
+    ts = rs.uniform(0, 100, n).astype(np.float32) if "ts" in attrs else None
+    inten = rs.uniform(0, 255, n).astype(np.float32) if "intensity" in attrs else None
+    if inten is not None:
+        inten[3000:] = np.round(inten[3000:])  # (the O(L^2) median of 4000-point runs: ties by position)
+    pc = sp.PointCloudShared(dev(pts), rgb=None if rgb is None else dev(rgb), intensities=None if inten is None else dev(inten),
+                             timestamp_offsets=None if ts is None else dev(ts))
+    for minc in (1, 50):
+        vg = sp.VoxelGrid(1.0)
+        vg.set_min_voxel_count(minc)
+        out, keys = vg.downsampling(pc, return_keys=True)
+        o = orc.voxel_downsample(pts, 1.0, minc, rgb, inten, ts, stable=True)
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64), o["keys"])
+        assert np.array_equal(out.points.cpu().numpy().view(np.uint32), o["points"].view(np.uint32))  # (bits: the sign of a zero too)
+        if rgb is not None:
+            assert np.array_equal(out.rgb.cpu().numpy(), o["rgb"])
+        if ts is not None:
+            assert np.array_equal(out.timestamp_offsets.cpu().numpy(), o["timestamps"])
+        if inten is not None:
+            assert np.array_equal(out.intensities.cpu().numpy(), o["intensities"])
+    only_zero = np.zeros((700, 4), np.float32)
+    only_zero[:, :3] = np.float32(-0.0)
+    only_zero[:, 3] = 1.0
+    out = sp.VoxelGrid(1.0).downsampling(dev(only_zero))
+    o = orc.voxel_downsample(only_zero, 1.0, 1, stable=True)
+    assert np.array_equal(out.points.cpu().numpy().view(np.uint32), o["points"].view(np.uint32))
+
+
 def test_voxel_known_answer_and_edges(sp, orc):
     # test_downsampling_filters.cpp:27-88
     pts = np.array([[0.10, 0, 0, 1], [0.40, 0, 0, 1], [1.10, 0, 0, 1], [1.40, 0, 0, 1], [0.20, 0, 0, 1]], np.float32)
