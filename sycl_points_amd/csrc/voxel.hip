@@ -15,6 +15,7 @@
 #include "radix_sort.h"
 #include "sp_common.h"
 #include "sp_math.h"
+#include "sp_wave_select.h"
 
 void sp_set_error(const char* msg);
 
@@ -341,8 +342,10 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const KEY* __restrict
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const unsigned idx = e0 + 64u * u + lane;
-                match[u] = idx < n && sk[idx] == k0;
-                src[u] = match[u] ? sv[idx] : 0u;
+                const bool in = idx < n;
+                const KEY kk = in ? sk[idx] : invalid;
+                src[u] = in ? sv[idx] : 0u;  // (not behind the key's compare: key and index in ONE memory round trip, the points in the next)
+                match[u] = in && kk == k0;
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) pt[u] = match[u] ? pts[src[u]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -350,27 +353,41 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const KEY* __restrict
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 if (cnt < 64u) break;  // (uniform: the run ended inside the previous batch)
-                lsrc[w0 + lane] = src[u];
-                lpt[w0 + lane] = pt[u];
                 const unsigned long long mm = __ballot(match[u]);
                 cnt = mm == ~0ull ? 64u : (unsigned)__builtin_ctzll(~mm);  // members of the run among these 64
-                __builtin_amdgcn_wave_barrier();
-                if ((int)lane == owner) {
-                    for (unsigned j0 = 0; j0 < cnt; j0 += 8) {
-                        float4 pp[8];
+                if (cnt == 0u) break;
+                // The point sums of these cnt members, sequentially, WITHOUT the head adding them one by one out of LDS (40 ns a
+                // member): lane 0 starts from the head's sums, then lane j takes lane j - 1's sums (one DPP move, wave_shr:1) plus its
+                // own point, cnt - 1 times — lane j is final after j steps and stays so; eight steps a trip (a step too many changes
+                // nothing, a taken branch costs as much as a step). The same adds in the same order: the same bits.
+                float sx = __fadd_rn(bcast_f(px, owner), pt[u].x), sy = __fadd_rn(bcast_f(py, owner), pt[u].y),
+                      sz = __fadd_rn(bcast_f(pz, owner), pt[u].z), sw = __fadd_rn(bcast_f(pw, owner), pt[u].w);
+                const bool moving = lane > 0u && lane < cnt;
+                for (unsigned it = 0; it + 1u < cnt; it += 8) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pp[j] = lpt[w0 + min(j0 + j, 63u)];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            if (j0 + j >= cnt) break;
-                            px += pp[j].x; py += pp[j].y; pz += pp[j].z; pw += pp[j].w;
-                            if (a.rgb) { const float4 c = a.rgb[lsrc[w0 + j0 + j]]; cx += c.x; cy += c.y; cz += c.z; cw += c.w; }
-                            if (a.ts) tsum += a.ts[lsrc[w0 + j0 + j]];
+                    for (int q = 0; q < 8; ++q) {
+                        const float tx = __fadd_rn(shift_up1_f(sx), pt[u].x), ty = __fadd_rn(shift_up1_f(sy), pt[u].y),
+                                    tz = __fadd_rn(shift_up1_f(sz), pt[u].z), tw = __fadd_rn(shift_up1_f(sw), pt[u].w);
+                        sx = moving ? tx : sx; sy = moving ? ty : sy; sz = moving ? tz : sz; sw = moving ? tw : sw;
+                    }
+                }
+                const float lx = bcast_f(sx, (int)cnt - 1), ly = bcast_f(sy, (int)cnt - 1), lz = bcast_f(sz, (int)cnt - 1),
+                            lw = bcast_f(sw, (int)cnt - 1);
+                if (a.rgb || a.ts) {  // (uniform) the other attributes: by the head, member by member, through the staged indices
+                    lsrc[w0 + lane] = src[u];
+                    __builtin_amdgcn_wave_barrier();
+                    if ((int)lane == owner) {
+                        for (unsigned j = 0; j < cnt; ++j) {
+                            if (a.rgb) { const float4 c = a.rgb[lsrc[w0 + j]]; cx += c.x; cy += c.y; cz += c.z; cw += c.w; }
+                            if (a.ts) tsum += a.ts[lsrc[w0 + j]];
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if ((int)lane == owner) {
+                    px = lx; py = ly; pz = lz; pw = lw;
                     e += cnt;
                 }
-                __builtin_amdgcn_wave_barrier();
             }
             if (cnt < 64u) todo &= todo - 1ull;  // the run has ended: the next head of this wave
         }
