@@ -889,18 +889,43 @@ __global__ __launch_bounds__(kSmallBlock) void knn_bf_small_kernel(const float4*
         unsigned cnt[kSmallQ];
 #pragma unroll
         for (int u = 0; u < kSmallQ; ++u) cnt[u] = 0;
-        for (unsigned j = lane; j < ntp; j += 64) {
-            const float x = tx[j], y = ty[j], z = tz[j];
-            const bool valid = j < nt;
+        // four targets a lane per trip: their twelve LDS reads and the distances are independent of the (rare) list stores, which
+        // the one-target form put between every two reads — the loop is bound by latency, not by issue (two busy waves a SIMD)
+        constexpr int kT = 4;
+        for (unsigned j0 = lane; j0 < ntp; j0 += 64 * kT) {
+            float x[kT], y[kT], z[kT];
 #pragma unroll
-            for (int u = 0; u < kSmallQ; ++u) {
-                const float d = dist2(qx[u], qy[u], qz[u], x, y, z);
-                const bool hit = valid && d <= tau[u];
-                const unsigned long long m = __ballot(hit);
-                if (m) {  // (uniform)
-                    const unsigned pos = cnt[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (hit && pos < kSmallListCap) my_lists[u * kSmallListCap + pos] = cand_key(d, (int)j);
-                    cnt[u] += (unsigned)__builtin_popcountll(m);
+            for (int t = 0; t < kT; ++t) {
+                const unsigned j = min(j0 + 64u * t, ntp - 64u + lane);  // (past the end: the last trip's own target again, not counted)
+                x[t] = tx[j]; y[t] = ty[j]; z[t] = tz[j];
+            }
+            float d[kT][kSmallQ];
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int t = 0; t < kT; ++t) {
+                const bool valid = j0 + 64u * t < nt;
+#pragma unroll
+                for (int u = 0; u < kSmallQ; ++u) {
+                    d[t][u] = dist2(qx[u], qy[u], qz[u], x[t], y[t], z[t]);
+                    d[t][u] = valid ? d[t][u] : inf;  // (tau is finite or inf; inf <= inf is caught by `valid` below)
+                    any |= __ballot(valid && d[t][u] <= tau[u]);
+                }
+            }
+            if (any) {  // (uniform; one trip in ten: k of nt targets are hits)
+#pragma unroll
+                for (int t = 0; t < kT; ++t) {
+                    const unsigned j = j0 + 64u * t;
+                    const bool valid = j < nt;
+#pragma unroll
+                    for (int u = 0; u < kSmallQ; ++u) {
+                        const bool hit = valid && d[t][u] <= tau[u];
+                        const unsigned long long m = __ballot(hit);
+                        if (m) {  // (uniform)
+                            const unsigned pos = cnt[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            if (hit && pos < kSmallListCap) my_lists[u * kSmallListCap + pos] = cand_key(d[t][u], (int)j);
+                            cnt[u] += (unsigned)__builtin_popcountll(m);
+                        }
+                    }
                 }
             }
         }
