@@ -70,7 +70,7 @@ struct MappedWord {
         thread_local MappedWord w = [] {
             MappedWord m;
             void* h = nullptr;
-            if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return m; }
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return m; }  // (every device of the process may store to it)
             void* d = nullptr;
             if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return m; }
             m.host = static_cast<volatile uint32_t*>(h);

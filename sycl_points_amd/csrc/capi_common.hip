@@ -32,7 +32,7 @@ void* pinned_mailbox() {
 unsigned* device_error_word() {
     std::call_once(g_err_once, [] {
         void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }  // (kernels on any device of the process raise it)
         *static_cast<volatile unsigned*>(h) = 0u;
         void* d = nullptr;
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
