@@ -11,7 +11,16 @@ size_t radix_sort_u32_workspace_bytes(size_t n);
 // buffers; both are overwritten. *result_in_b tells where the sorted pairs are. Only enqueues on `st`. Key bits at and above
 // `bits` are ignored, as are those below `first_bit` (a stable sort by the remaining ones).
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
-                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st, unsigned first_bit = 0);
+                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st, unsigned first_bit = 0,
+                         bool first_hist_ready = false);
+// The first pass's per-tile digit histograms may come from the kernel that MADE the keys (it has them in registers: no launch
+// and no read of the keys for the count). radix_first_pass(n, bits) says what that kernel has to leave at the START of the
+// workspace: hist[digit * tiles + tile] = keys of tile `tile` (keys [tile * tile_keys, (tile + 1) * tile_keys)) whose low
+// `digit_bits` bits (masked to the sort's `bits`) equal `digit`; then call radix_sort_pairs_u32(..., first_hist_ready = true).
+struct RadixFirstPass {
+    unsigned tiles, tile_keys, digit_bits, mask;
+};
+RadixFirstPass radix_first_pass(size_t n, unsigned bits);
 // The same for 64-bit keys, on the low `bits` <= 64 key bits.
 size_t radix_sort_u64_workspace_bytes(size_t n);
 int radix_sort_pairs_u64(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,

@@ -230,7 +230,7 @@ size_t radix_sort_u64_workspace_bytes(size_t n) { return radix_sort_u32_workspac
 namespace {
 template <typename KEY>
 int radix_sort_pairs(KEY* keys_a, KEY* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits, void* workspace,
-                     bool* result_in_b, hipStream_t st, unsigned first_bit) {
+                     bool* result_in_b, hipStream_t st, unsigned first_bit, bool first_hist_ready = false) {
     const unsigned tiles = div_up(n, (size_t)kRsTile);
     // 9-bit digits where they save a pass (18 key bits — the cell ids of a 6-points-per-cell grid on 1 M points, a dense voxel
     // box — sort in 2 passes instead of 3; 24 bits stay at 3 passes of 8)
@@ -245,21 +245,22 @@ int radix_sort_pairs(KEY* keys_a, KEY* keys_b, uint32_t* vals_a, uint32_t* vals_
     for (unsigned shift = first_bit; shift < bits; shift += digit) {
         const unsigned width = bits - shift < digit ? bits - shift : digit;
         const unsigned mask = (1u << width) - 1u;
+        const bool counted = first_hist_ready && shift == first_bit;  // (the keys' producer left this pass's tile histograms)
         if (tiles <= kRsFoldTiles && digit == 9u) {
-            rs_count_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            if (!counted) rs_count_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
             rs_scatter_kernel<KEY, 512, true><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
                                                                             digit_total);
         } else if (tiles <= kRsFoldTiles) {
-            rs_count_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            if (!counted) rs_count_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
             rs_scatter_kernel<KEY, 256, true><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
                                                                             digit_total);
         } else if (digit == 9u) {
-            rs_count_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            if (!counted) rs_count_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
             rs_scan_kernel<<<512, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
             rs_scatter_kernel<KEY, 512><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
                                                                       digit_total);
         } else {
-            rs_count_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
+            if (!counted) rs_count_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, (unsigned)n, shift, mask, tiles, tile_hist);
             rs_scan_kernel<<<256, kRsScanThreads, 0, st>>>(tile_hist, tiles, digit_total);
             rs_scatter_kernel<KEY, 256><<<tiles, kRsThreads, 0, st>>>(kin, vin, kout, vout, (unsigned)n, shift, mask, tiles, tile_hist,
                                                                       digit_total);
@@ -274,12 +275,18 @@ int radix_sort_pairs(KEY* keys_a, KEY* keys_b, uint32_t* vals_a, uint32_t* vals_
 }  // namespace
 
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned bits,
-                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st, unsigned first_bit) {
+                         void* workspace, size_t workspace_bytes, bool* result_in_b, hipStream_t st, unsigned first_bit,
+                         bool first_hist_ready) {
     *result_in_b = false;
     if (n == 0 || bits <= first_bit) return SP_OK;
     if (n >= (1ull << 32) - kRsTile || bits > 32 || !workspace || workspace_bytes < radix_sort_u32_workspace_bytes(n))
         return SP_ERR_INVALID_ARGUMENT;
-    return radix_sort_pairs<uint32_t>(keys_a, keys_b, vals_a, vals_b, n, bits, workspace, result_in_b, st, first_bit);
+    return radix_sort_pairs<uint32_t>(keys_a, keys_b, vals_a, vals_b, n, bits, workspace, result_in_b, st, first_bit, first_hist_ready);
+}
+RadixFirstPass radix_first_pass(size_t n, unsigned bits) {  // (mirrors radix_sort_pairs: first_bit = 0)
+    const unsigned digit = (bits + 8u) / 9u < (bits + 7u) / 8u ? 9u : 8u;
+    const unsigned width = bits < digit ? bits : digit;
+    return RadixFirstPass{(unsigned)div_up(n, (size_t)kRsTile), (unsigned)kRsTile, digit, (1u << width) - 1u};
 }
 
 // 64-bit keys (the uncompressed voxel keys, voxel_constants.hpp:36-62): the same passes over the low `bits` <= 64 key bits.

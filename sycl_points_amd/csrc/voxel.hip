@@ -222,6 +222,73 @@ __global__ __launch_bounds__(kBlock) void voxel_report_kernel(const int32_t* __r
                                                               const uint32_t* __restrict__ voxels_dev, uint32_t* __restrict__ report8) {
     voxel_report(records, n_records, voxels_dev ? *voxels_dev : 0u, report8);
 }
+// key32_kernel for sp_voxel_downsample_report, tile by tile of the sort that follows (radix_sort.h, RadixFirstPass): the keys are
+// in registers here, so the sort's first count — a launch and a read of every key — is this kernel's by-product:
+// tile_hist[digit * tiles + tile] for every digit of the first pass. One record per workgroup as in key32_kernel.
+template <int BINS>
+__global__ __launch_bounds__(kBlock) void key32_tiles_kernel(const float4* __restrict__ pts, unsigned n, float inv, KeyBox b,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                             int32_t* __restrict__ wg_records, unsigned tiles, unsigned tile_keys,
+                                                             unsigned mask, unsigned* __restrict__ tile_hist) {
+    constexpr int kWaves = kBlock / kWave;
+    __shared__ unsigned h[kWaves][BINS];
+    int lo0 = INT32_MAX, lo1 = INT32_MAX, lo2 = INT32_MAX, hi0 = INT32_MIN, hi1 = INT32_MIN, hi2 = INT32_MIN;
+    int outside = 0;
+    const unsigned wave = threadIdx.x / kWave;
+    constexpr int kPer = 8;  // keys a lane and tile (tile_keys == kPer * kBlock, checked by the caller)
+    for (unsigned tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        for (unsigned d = threadIdx.x; d < kWaves * BINS; d += kBlock) (&h[0][0])[d] = 0u;
+        __syncthreads();
+        const unsigned base = tile * tile_keys;
+        float4 p[kPer];
+#pragma unroll
+        for (int c = 0; c < kPer; ++c) p[c] = pts[min(base + c * kBlock + threadIdx.x, n - 1)];
+#pragma unroll
+        for (int c = 0; c < kPer; ++c) {
+            const unsigned i = base + c * kBlock + threadIdx.x;
+            if (i >= n) continue;
+            int c0, c1, c2;
+            uint32_t key = b.invalid;
+            if (voxel_coords(p[c], inv, c0, c1, c2)) {
+                lo0 = min(lo0, c0); lo1 = min(lo1, c1); lo2 = min(lo2, c2);
+                hi0 = max(hi0, c0); hi1 = max(hi1, c1); hi2 = max(hi2, c2);
+                const unsigned x = (unsigned)(c0 - b.x0), y = (unsigned)(c1 - b.y0), z = (unsigned)(c2 - b.z0);
+                if (x < b.nx && y < b.ny && z < b.nz) key = (z * b.ny + y) * b.nx + x;
+                else ++outside;
+            }
+            keys[i] = key;
+            vals[i] = i;
+            atomicAdd(&h[wave][key & mask], 1u);
+        }
+        __syncthreads();
+        for (unsigned d = threadIdx.x; d < (unsigned)BINS; d += kBlock) {
+            unsigned v = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) v += h[w][d];
+            tile_hist[(size_t)d * tiles + tile] = v;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        lo0 = min(lo0, __shfl_xor(lo0, off)); lo1 = min(lo1, __shfl_xor(lo1, off)); lo2 = min(lo2, __shfl_xor(lo2, off));
+        hi0 = max(hi0, __shfl_xor(hi0, off)); hi1 = max(hi1, __shfl_xor(hi1, off)); hi2 = max(hi2, __shfl_xor(hi2, off));
+        outside += __shfl_xor(outside, off);
+    }
+    __shared__ int red[kWaves][7];
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red[wave][0] = lo0; red[wave][1] = lo1; red[wave][2] = lo2;
+        red[wave][3] = hi0; red[wave][4] = hi1; red[wave][5] = hi2;
+        red[wave][6] = outside;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        int v = red[0][threadIdx.x];
+        for (unsigned w = 1; w < (unsigned)kWaves; ++w)
+            v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : (threadIdx.x < 6 ? max(v, red[w][threadIdx.x]) : v + red[w][threadIdx.x]);
+        wg_records[blockIdx.x * 8 + threadIdx.x] = v;
+    }
+}
 __device__ __forceinline__ uint64_t expand_key(uint32_t k, const KeyBox& b) {
     if (k >= b.invalid) return kInvalidKey;
     const unsigned x = k % b.nx, yz = k / b.nx, y = yz % b.ny, z = yz / b.ny;
@@ -613,13 +680,26 @@ int voxel_downsample_impl(const float* points, size_t n, float inv_voxel_size, s
     if (boxed) {
         uint32_t* k_in = (uint32_t*)(base + w.keys_in);
         uint32_t* k_sorted = (uint32_t*)(base + w.keys_out);
-        const unsigned key_grid = std::min(stream_grid(n, kBlock, 4), kKeyGridMax);
-        key32_kernel<<<key_grid, kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, status_dev, box_shards_dev,
-                                                  records);
         unsigned end_bit = 1;
         while ((1ull << end_bit) <= (uint64_t)kb.invalid && end_bit < 32) ++end_bit;  // `invalid` itself must be representable
+        unsigned key_grid = std::min(stream_grid(n, kBlock, 4), kKeyGridMax);
+        const RadixFirstPass fp = radix_first_pass(n, end_bit);
+        const bool counted = records != nullptr && fp.tile_keys == 8u * kBlock;  // (the report call: the key kernel also counts)
+        if (counted) {
+            key_grid = std::min(fp.tiles, kKeyGridMax);
+            unsigned* const hist = reinterpret_cast<unsigned*>(base + w.prim);
+            if (fp.digit_bits == 9u)
+                key32_tiles_kernel<512><<<key_grid, kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, records, fp.tiles,
+                                                                     fp.tile_keys, fp.mask, hist);
+            else
+                key32_tiles_kernel<256><<<key_grid, kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, records, fp.tiles,
+                                                                     fp.tile_keys, fp.mask, hist);
+        } else {
+            key32_kernel<<<key_grid, kBlock, 0, st>>>(pts, (unsigned)n, inv_voxel_size, kb, k_in, vals_in, status_dev, box_shards_dev,
+                                                      records);
+        }
         bool in_b = false;  // the hand-written sort (radix_sort.hip) ping-pongs between the two buffer pairs
-        if (radix_sort_pairs_u32(k_in, k_sorted, vals_in, vals_sorted, n, end_bit, base + w.prim, w.prim_bytes, &in_b, st) != SP_OK) {
+        if (radix_sort_pairs_u32(k_in, k_sorted, vals_in, vals_sorted, n, end_bit, base + w.prim, w.prim_bytes, &in_b, st, 0, counted) != SP_OK) {
             sp_set_error("[VoxelGrid::downsampling] radix sort failed");
             return SP_ERR_HIP;
         }
