@@ -158,12 +158,24 @@ public:
         // is staged and blocks inside the runtime (2.24 -> 1.94 ms for the LM alignment of the reference's example)
         hip_check(hipHostMalloc(&pin_, 4096), "hipHostMalloc");
         hip_check(hipMalloc(&res_dev_, sizeof(sp_align_result)), "hipMalloc");
+        // the device-resident optimiser's pose (64 bytes each way) and result block in host-mapped memory, when it is to be had:
+        // the host writes the initial guess, the launch stores the block and then its `done` word, the host spins on that word —
+        // no copy in, no copy out, no synchronisation
+        void* m = nullptr;
+        if (hipHostMalloc(&m, kMappedBytes, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, m, 0) == hipSuccess) { map_host_ = static_cast<char*>(m); map_dev_ = static_cast<char*>(d); }
+            else { (void)hipGetLastError(); (void)hipHostFree(m); }
+        } else {
+            (void)hipGetLastError();
+        }
     }
     ~Registration() {
         if (psrc_) sp_gicp_source_destroy(psrc_);
         if (ptgt_) sp_gicp_target_destroy(ptgt_);
         (void)hipFree(lin_dev_); (void)hipFree(ws_); (void)hipFree(T_dev_); (void)hipFree(res_dev_);
         if (pin_) (void)hipHostFree(pin_);
+        if (map_host_) (void)hipHostFree(map_host_);
     }
     Registration(const Registration&) = delete;
     Registration& operator=(const Registration&) = delete;
@@ -572,13 +584,32 @@ private:
     std::optional<RegistrationResult> align_optimize_on_device(const TransformMatrix& initial_guess, const float* scales, int levels) {
         const sp_factor_params fp = factor_params(scales[0]);
         const sp_opt_params op = opt_params();
-        hip_check(hipMemcpyAsync(T_dev_, initial_guess.data(), 16 * sizeof(float), hipMemcpyHostToDevice, queue_.stream()), "H2D");
-        const int rc = sp_gicp_align_optimize(ptgt_, psrc_, T_dev_, &fp, &op, scales, levels, res_dev_, ws_, ws_bytes_, queue_.stream());
-        if (rc == SP_ERR_RUNTIME && std::strstr(sp_last_error(), "not available") != nullptr) return std::nullopt;
-        throw_on_error(rc);
-        sp_align_result* const h = reinterpret_cast<sp_align_result*>(static_cast<char*>(pin_) + 1024);
-        hip_check(hipMemcpyAsync(h, res_dev_, sizeof *h, hipMemcpyDeviceToHost, queue_.stream()), "D2H");
-        hip_check(hipStreamSynchronize(queue_.stream()), "sync");
+        sp_align_result* h;
+        if (map_host_) {
+            std::memcpy(map_host_, initial_guess.data(), 16 * sizeof(float));
+            h = reinterpret_cast<sp_align_result*>(map_host_ + 256);
+            volatile uint32_t* const done = &h->pad[0];
+            *done = 0u;
+            const int rc = sp_gicp_align_optimize(ptgt_, psrc_, reinterpret_cast<float*>(map_dev_), &fp, &op, scales, levels,
+                                                  reinterpret_cast<sp_align_result*>(map_dev_ + 256), ws_, ws_bytes_, queue_.stream());
+            if (rc == SP_ERR_RUNTIME && std::strstr(sp_last_error(), "not available") != nullptr) return std::nullopt;
+            throw_on_error(rc);
+            for (unsigned spins = 0; *done != SP_ALIGN_RESULT_DONE; ++spins) {
+                if (spins > (1u << 24)) {  // (a fraction of a second: the device is busy elsewhere, or the launch failed — wait for the stream)
+                    hip_check(hipStreamSynchronize(queue_.stream()), "sync");
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            hip_check(hipMemcpyAsync(T_dev_, initial_guess.data(), 16 * sizeof(float), hipMemcpyHostToDevice, queue_.stream()), "H2D");
+            const int rc = sp_gicp_align_optimize(ptgt_, psrc_, T_dev_, &fp, &op, scales, levels, res_dev_, ws_, ws_bytes_, queue_.stream());
+            if (rc == SP_ERR_RUNTIME && std::strstr(sp_last_error(), "not available") != nullptr) return std::nullopt;
+            throw_on_error(rc);
+            h = reinterpret_cast<sp_align_result*>(static_cast<char*>(pin_) + 1024);
+            hip_check(hipMemcpyAsync(h, res_dev_, sizeof *h, hipMemcpyDeviceToHost, queue_.stream()), "D2H");
+            hip_check(hipStreamSynchronize(queue_.stream()), "sync");
+        }
         if (h->status != 0) {  // not every workgroup of the launch was resident (another process / a CU mask holds compute units)
             throw_on_error(sp_gicp_source_set_persistent(psrc_, 0));  // this source: per-step launches from now on
             return std::nullopt;
@@ -786,6 +817,9 @@ private:
     void* pin_ = nullptr;  // 4 KB of pinned host memory: [0, 256) linear system, [256, 432) pose | delta | iterations | T_lin,
                            // [1024, 1024 + sizeof(sp_align_result)) the result block of the device-resident optimiser
     sp_align_result* res_dev_ = nullptr;
+    static constexpr size_t kMappedBytes = 256 + ((sizeof(sp_align_result) + 255) / 256) * 256;  // pose | result block
+    char* map_host_ = nullptr;  // host-mapped: [0, 64) the optimiser's pose, [256, ...) its result block
+    char* map_dev_ = nullptr;   // ... as the device sees it
     float genz_alpha_ = 1.0f;
     mutable float rotation_robust_scale_ = 10.0f;  // resolved per call from ExecutionOptions (registration.hpp:219-221)
     sp_map_prior_state map_prior_{};               // MapPrior state (map_prior.hpp:203-210)

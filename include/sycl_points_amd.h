@@ -556,6 +556,7 @@ typedef struct sp_opt_log_entry { /* one outer iteration */
     float damping;       /* lambda (LM) / trust-region radius (dog-leg) AFTER the iteration */
     float error;         /* RegistrationResult::error after the iteration */
 } sp_opt_log_entry;
+#define SP_ALIGN_RESULT_DONE 0x600DF00Du
 typedef struct sp_align_result { /* RegistrationResult (result.hpp:12-28) of the LAST level + what the facade needs beside it */
     float T[16];         /* final pose, column-major */
     float T_lin[16];     /* pose of the last linearisation: the correspondence cache is frozen at it (compute_error_frozen) */
@@ -571,7 +572,9 @@ typedef struct sp_align_result { /* RegistrationResult (result.hpp:12-28) of the
     uint32_t searched;   /* source points searched for, all linearisations (the rest reused their correspondence) */
     float damping;       /* final lambda / trust-region radius */
     uint32_t log_entries;
-    uint32_t pad[3];
+    uint32_t pad[3];     /* pad[0] = SP_ALIGN_RESULT_DONE, stored LAST (system-scope release) when the block is complete: result_device
+                          * may be the device pointer of host-mapped pinned memory whose pad[0] the caller cleared and spins on — no
+                          * read-back copy, no synchronisation (transT_device may be host-mapped too: 64 bytes each way) */
     sp_opt_log_entry log[SP_OPT_LOG_ENTRIES]; /* the first outer iterations, all levels in order */
 } sp_align_result;
 int sp_gicp_align_optimize(const sp_gicp_target* target, const sp_gicp_source* source, float* transT_device,

@@ -279,7 +279,7 @@ __device__ __forceinline__ void opt_publish(float* T_out, const OptShared& S) {
         r->searched = c.searched;
         r->damping = S.opt.method == SP_OPT_POWELL_DOGLEG ? c.radius : c.lambda;
         r->log_entries = c.log_n < (unsigned)SP_OPT_LOG_ENTRIES ? c.log_n : (unsigned)SP_OPT_LOG_ENTRIES;
-        r->pad[0] = r->pad[1] = r->pad[2] = 0u;
+        r->pad[1] = r->pad[2] = 0u;  // (pad[0]: the done flag, stored last by the caller of this function)
     }
 }
 
@@ -530,6 +530,11 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
             if (publish) {
                 if (threadIdx.x < 16) { A.T_out[threadIdx.x] = __int_as_float(0x7fc00000); A.result->T[threadIdx.x] = __int_as_float(0x7fc00000); }
                 if (threadIdx.x == 16) { A.result->status = 2u; A.result->converged = 0u; A.result->log_entries = 0u; }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __threadfence_system();
+                    __hip_atomic_store(&A.result->pad[0], (unsigned)SP_ALIGN_RESULT_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         };
         if constexpr (WAVEQ) {
@@ -590,7 +595,16 @@ __global__ __launch_bounds__(BLOCK) void gicp_optimize_kernel(FusedParams P, Opt
 #ifdef SP_OPT_TIMING
             if (publish) g_sp_step = 0;
 #endif
-            if (publish) opt_publish(A.T_out, S);
+            if (publish) {
+                opt_publish(A.T_out, S);
+                // the block is complete: the flag goes last, behind a system-scope release — result_device may be host-mapped memory
+                // whose pad[0] the caller cleared and spins on (no read-back copy, no synchronisation)
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __threadfence_system();
+                    __hip_atomic_store(&A.result->pad[0], (unsigned)SP_ALIGN_RESULT_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
             if constexpr (WAVEQ) {
                 if (S.ctl.cur != 0) {  // the launch leaves its correspondences in the source's own rows: every wave copies its points'
                     const unsigned nw = BLOCK / kWave;
