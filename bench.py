@@ -879,14 +879,21 @@ def example_block(cpu=True, loops=100, warmup=10):
     gold = os.path.join(ROOT, "tests", "golden")
     if not os.path.exists(exe):
         return {"available": False, "note": "tests/cpp/example_registration is not built"}
-    r = subprocess.run([exe, os.path.join(gold, "source.ply"), os.path.join(gold, "target.ply"), str(loops), str(warmup)],
-                       capture_output=True, text=True, timeout=600)
-    if r.returncode != 0:
-        return {"available": False, "note": r.stderr[-300:]}
-    st = {}
-    for m in re.finditer(r"^\s*(\d[a-z]?\. [^:]+|TOTAL):\s+([0-9.]+) us", r.stdout, re.M):
-        st[m.group(1).strip()] = float(m.group(2)) / 1e3
-    out = {"loops": loops, "warmup": warmup, "gpu_ms": st,
+    # the loop is host-latency-bound (≈ 50 launches and a dozen waits per pass): three child runs, the one with the median TOTAL is
+    # reported and the three totals stand beside it
+    runs = []
+    for _ in range(3):
+        r = subprocess.run([exe, os.path.join(gold, "source.ply"), os.path.join(gold, "target.ply"), str(loops), str(warmup)],
+                           capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"available": False, "note": r.stderr[-300:]}
+        st = {}
+        for m in re.finditer(r"^\s*(\d[a-z]?\. [^:]+|TOTAL):\s+([0-9.]+) us", r.stdout, re.M):
+            st[m.group(1).strip()] = float(m.group(2)) / 1e3
+        runs.append(st)
+    runs.sort(key=lambda x: x.get("TOTAL", 0.0))
+    st = runs[1]
+    out = {"loops": loops, "warmup": warmup, "gpu_ms": st, "total_ms_of_the_three_runs": [x.get("TOTAL") for x in runs],
            "note": "LM + Geman-McClure + 3 annealing levels on a 1000-point sample; box filter [0.5, 50] m, voxel 0.25 m, k = 10"}
     if cpu:
         out["cpu_oracle_ms"], out["cpu_cores"] = example_cpu_oracle()
