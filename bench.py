@@ -75,10 +75,12 @@ def parse():
                     help="sharded runs: issue every launch / collective from the host instead of replaying one "
                          "captured hipGraph per alignment")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's tile to run")
-    ap.add_argument("--shard-chunk", type=int, default=1024,
+    ap.add_argument("--shard-chunk", type=int, default=-1,
                     help="N > 1: the (spatially ordered) source is dealt to the ranks in chunks of this many consecutive "
                          "points, round-robin (every rank sees the same mix of converged and still-moving regions); 0: one "
-                         "contiguous tile per rank (a spatial slab)")
+                         "contiguous tile per rank (a spatial slab); -1 (default): sharding.default_chunk — half a rank's tile "
+                         "from 4 ranks on (rank r holds slabs r and r + N of 2 N: as far from the rotation centre together as "
+                         "any other pair, and only two slabs of the target to keep in cache), 1024 points below")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: build the clouds of an N-rank run (N x --points, config 5 density) and time "
                          "rank 0's tile against the full target, without the collective")
@@ -198,12 +200,14 @@ def main():
 
     import sycl_points_amd.api as sp
     from sycl_points_amd import _lib
-    from sycl_points_amd.sharding import shard_indices
+    from sycl_points_amd.sharding import default_chunk, shard_indices
     from sycl_points_amd.synthetic import gicp_pair
 
     n_gpu = args.points
     shards = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
     n_total = n_gpu * shards
+    if args.shard_chunk < 0:
+        args.shard_chunk = default_chunk(n_total, shards)
     rng_range = 10.0 * (n_total / 1e6) ** (1.0 / 3.0)  # config 4 density at every size (R=20 at 8M)
 
     # ---- untimed set-up: clouds, k=20 covariances (fused self-kNN on a grid), NN structure on the target

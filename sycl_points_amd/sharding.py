@@ -29,6 +29,17 @@ def shard_indices(n_total, rank, world, chunk=1024):
     return idx[idx < n_total]
 
 
+def default_chunk(n_total, world):
+    """Chunk size of shard_indices for a cell-ordered source of n_total points on `world` ranks. From 4 ranks on: half a rank's
+    tile, so that rank r holds slabs r and r + world of 2 * world — every pair lies as far from the middle of the cloud, taken
+    together, as any other (the slabs that move furthest under a rotation keep searching longest), and a rank's searches touch two
+    slabs of the replicated target instead of all of it (per-rank step of the emulated 8-rank run 48.2 against 50.4 us, slowest
+    rank; 4 ranks 40.2 against 42.6; profiles/r05_zzz_shard_chunk_by_rank.txt). Two ranks: 1024-point chunks (35.7 against 36.7)."""
+    if world >= 4 and n_total >= 4 * world:
+        return max(1, (n_total // world) // 2)
+    return 1024
+
+
 def split_count(count):
     """Inlier count as two floats that stay exact under a float sum over ranks (count = hi * 4096 + lo)."""
     return float(count & 4095), float(count >> 12)

@@ -34,6 +34,26 @@ def test_shard_indices_partition_the_source():
                 assert np.array_equal(parts[r], np.arange(lo, hi))
 
 
+def test_default_chunk_deals_half_tiles_from_four_ranks_on():
+    """sharding.default_chunk: from 4 ranks on rank r holds slabs r and r + world of 2 * world (a partition, equal sizes, the two
+    slabs as far from the middle of the cloud together as any other pair); 2 ranks keep 1024-point chunks."""
+    for n, w in ((8_000_000, 8), (4_000_000, 4), (6_000_000, 6), (8_000_001, 8), (37, 4)):
+        c = sharding.default_chunk(n, w)
+        assert c == (n // w) // 2
+        parts = [sharding.shard_indices(n, r, w, c) for r in range(w)]
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= c
+        if n % (2 * w) == 0:
+            mid = (2 * w - 1) / 2.0
+            for r in range(w):
+                slabs = sorted(set((parts[r] // c).tolist()))
+                assert slabs == [r, r + w]
+                assert abs(slabs[0] - mid) + abs(slabs[1] - mid) == w  # the same for every rank
+    assert sharding.default_chunk(2_000_000, 2) == 1024
+    assert sharding.default_chunk(1_000_000, 1) == 1024
+    assert sharding.default_chunk(5, 8) == 1024  # fewer points than 4 per rank: shard_indices falls back to contiguous tiles
+
+
 def test_shard_ranges_cover_exactly():
     for n, w in ((10, 3), (1_000_000, 8), (7, 8), (0, 2), (8_000_001, 8)):
         r = [sharding.shard_range(n, k, w) for k in range(w)]
