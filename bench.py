@@ -190,13 +190,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # SP_BENCH_SHARE_GPU=1 (rehearsal on the one-GPU box, never the driver's run): every rank uses cuda:0 and gloo carries
+    # torch.distributed, so that this file's N > 1 branches run on the real kernels; the line then says "rehearsal" in `data`
+    share_gpu = os.environ.get("SP_BENCH_SHARE_GPU") == "1" and world > 1
+    if share_gpu:
+        # the direct stores need every rank's launch resident at once (one GPU runs them one after the other: rows time out)
+        # and gloo cannot be captured into a hipGraph: the rehearsal carries the row through torch.distributed, eagerly
+        local_rank, args.exchange, args.no_graph = 0, "torch-row", True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import sycl_points_amd.api as sp
     from sycl_points_amd import _lib
@@ -424,7 +434,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not share_gpu else "synthetic; REHEARSAL: all ranks on one GPU over gloo, not a measurement",
             "config": {"workload": f"{'GICP' if args.reg == 'gicp' else 'point-to-distribution ICP'} {n_total}-vs-{n_total} "
                                    f"uniform-random clouds (BASELINE config "
                                    f"{'4' if world == 1 else '5 generalised'}), k=20 covariances, GN lambda=1, "
